@@ -1,0 +1,430 @@
+"""Host-side mirror of the Algames.jl API surface for the Newton / augmented-Lagrangian hot path.
+
+Same names, argument meaning and error behaviour as the reference (Julia `f!` -> Python `f`), but a
+`GameProblem` owns a *batch* of B games (x0 of shape (B, n)) that are solved together on one MI355X
+through the C ABI of include/algames_hip.h.  Index sets / stamps are kept 1-based like the reference
+so that its tests' literal values can be quoted unchanged.
+
+Reference: src/Algames.jl:19-165 (exports), src/problem/problem.jl, src/problem/solver_methods.jl,
+src/struct/*.jl, src/dynamics/{double_integrator,unicycle}.jl, src/objective/objective.jl,
+src/constraints/{game_constraints,constraints_methods}.jl.
+"""
+import dataclasses
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import (ALG_MODEL_DOUBLE_INTEGRATOR, ALG_MODEL_UNICYCLE, ALG_TRAJ_PD, ALG_TRAJ_TRIAL,
+                   ALG_TRAJ_DELTA, AlgamesError, Batch, CLib)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "lib", "libalgames_hip.so")
+_hip = None
+
+
+def hip_lib():
+    """The product backend.  Fails loudly when the HIP extension is missing -- there is no CPU fallback."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise AlgamesError(
+                f"{HIP_LIB_PATH} is not built. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        _hip = CLib(HIP_LIB_PATH, "alg_")
+    return _hip
+
+
+# --------------------------------------------------------------------------------------------------
+# Models (src/dynamics/double_integrator.jl:2-25, src/dynamics/unicycle.jl:2-25)
+# --------------------------------------------------------------------------------------------------
+class AbstractGameModel:
+    pass
+
+
+class DoubleIntegratorGame(AbstractGameModel):
+    model_id = ALG_MODEL_DOUBLE_INTEGRATOR
+
+    def __init__(self, p=2, d=2):
+        self.p, self.d = p, d
+        self.n, self.m = 2 * d * p, d * p
+        self.pu = [[i + (j - 1) * p for j in range(1, d + 1)] for i in range(1, p + 1)]
+        self.px = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
+        self.pz = [[i + (j - 1) * p for j in range(1, 2 * d + 1)] for i in range(1, p + 1)]
+        self.ni = [2 * d] * p
+        self.mi = [d] * p
+
+
+class UnicycleGame(AbstractGameModel):
+    model_id = ALG_MODEL_UNICYCLE
+
+    def __init__(self, p=2):
+        self.p, self.d = p, 2
+        self.n, self.m = 4 * p, 2 * p
+        self.pu = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
+        self.px = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
+        self.pz = [[i + (j - 1) * p for j in range(1, 5)] for i in range(1, p + 1)]
+        self.ni = [4] * p
+        self.mi = [2] * p
+
+
+def dim(model):
+    return model.mi[0] if isinstance(model, DoubleIntegratorGame) else 2
+
+
+# --------------------------------------------------------------------------------------------------
+# ProblemSize (src/struct/problem_size.jl:5-35) and index maps (src/core/newton_core.jl:40-89)
+# --------------------------------------------------------------------------------------------------
+class ProblemSize:
+    def __init__(self, N, model):
+        self.N, self.n, self.m, self.p = N, model.n, model.m, model.p
+        self.ni, self.mi = list(model.ni), list(model.mi)
+        self.pu, self.px, self.pz = model.pu, model.px, model.pz
+        self.S = self.n * self.p * (N - 1) + self.m * (N - 1) + self.n * (N - 1)
+
+    def __eq__(self, o):
+        return all(getattr(self, f) == getattr(o, f) for f in ("N", "n", "m", "p", "ni", "mi", "pu", "px", "pz", "S"))
+
+
+def stampify(*a):
+    """Stamps are plain tuples: VStamp (prob,i0,n1,i1,v1), HStamp (n2,i2,v2), Stamp = V + H."""
+    return tuple(a)
+
+
+def valid(stamp, N, p):
+    """Stamp validity rules, src/core/stamp.jl:167-229."""
+    def v1(prob, i0, n1, i1, k):
+        if prob == "opt" and 1 <= i0 <= p:
+            if n1 == "u" and i1 == i0 and 1 <= k <= N - 1:
+                return True
+            if n1 == "x" and i1 == 1 and 2 <= k <= N:
+                return True
+        if prob == "dyn" and i0 == 1:
+            if n1 == "x" and i1 == 1 and 1 <= k <= N - 1:
+                return True
+        return False
+
+    def v2(n2, i2, k, prob=None, i0=None):
+        if n2 == "u" and 1 <= i2 <= p and 1 <= k <= N - 1:
+            return True
+        if n2 == "λ" and 1 <= k <= N - 1 and ((prob is None and 1 <= i2 <= p) or (prob == "opt" and i2 == i0)):
+            return True
+        if n2 == "x" and i2 == 1 and 2 <= k <= N:
+            return True
+        return False
+
+    if len(stamp) == 5:
+        return v1(*stamp)
+    if len(stamp) == 3:
+        return v2(*stamp)
+    prob, i0 = stamp[0], stamp[1]
+    if prob == "opt" and not (1 <= i0 <= p):
+        return False
+    if prob == "dyn" and i0 != 1:
+        return False
+    if prob not in ("opt", "dyn"):
+        return False
+    return v1(*stamp[:5]) and v2(*stamp[5:], prob=prob, i0=i0)
+
+
+def vertical_indices(probsize):
+    """Row ("vertical") 1-based index ranges of `core.res`, src/core/newton_core.jl:40-63."""
+    N, n, p, mi = probsize.N, probsize.n, probsize.p, probsize.mi
+    out, off = {}, 0
+    for i in range(1, p + 1):
+        for k in range(1, N):
+            out[stampify("opt", i, "x", 1, k + 1)] = list(range(off + 1, off + n + 1)); off += n
+            out[stampify("opt", i, "u", i, k)] = list(range(off + 1, off + mi[i - 1] + 1)); off += mi[i - 1]
+    for k in range(1, N):
+        out[stampify("dyn", 1, "x", 1, k)] = list(range(off + 1, off + n + 1)); off += n
+    return out
+
+
+def horizontal_indices(probsize):
+    """Column ("horizontal") 1-based index ranges of `Δtraj`, src/core/newton_core.jl:65-89."""
+    N, n, p, mi = probsize.N, probsize.n, probsize.p, probsize.mi
+    out, off = {}, 0
+    for k in range(1, N):
+        out[stampify("x", 1, k + 1)] = list(range(off + 1, off + n + 1)); off += n
+        for i in range(1, p + 1):
+            out[stampify("u", i, k)] = list(range(off + 1, off + mi[i - 1] + 1)); off += mi[i - 1]
+        for i in range(1, p + 1):
+            out[stampify("λ", i, k)] = list(range(off + 1, off + n + 1)); off += n
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# Options / Regularizer (src/struct/options.jl:5-116, src/struct/regularizer.jl:5-35)
+# --------------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class Regularizer:
+    x: float = 1e-3
+    u: float = 1e-3
+    λ: float = 1e-3
+
+
+def _ones10():
+    return [1.0] * 10
+
+
+@dataclasses.dataclass
+class Options:
+    θ: float = 1e-2
+    f_init: object = "rand"          # replaced by a counter-based generator, see alg_init_traj
+    amplitude_init: float = 1e-8
+    shift: int = 2 ** 10
+    regularize: bool = True
+    reg: Regularizer = dataclasses.field(default_factory=Regularizer)
+    reg_0: float = 1e-3
+    α_0: float = 1.0
+    α_increase: float = 1.2
+    α_decrease: float = 0.5
+    β: float = 0.01
+    ls_iter: int = 25
+    Δ_min: float = 1e-9
+    ρ_0: float = 1.0
+    ρ_trial: float = 1.0
+    ρ_increase: float = 10.0
+    ρ_max: float = 1e7
+    λ_max: float = 1e7
+    α_dual: float = 1.0
+    αx_dual: list = dataclasses.field(default_factory=_ones10)
+    active_set_tolerance: float = 1e-4
+    ϵ_dyn: float = 1e-3
+    ϵ_sta: float = 1e-3
+    ϵ_con: float = 1e-3
+    ϵ_opt: float = 1e-3
+    outer_iter: int = 7
+    inner_iter: int = 20
+    γ: float = 1.0
+    mpc_horizon: int = 20
+    upsampling: int = 2
+    inner_print: bool = True
+    outer_print: bool = True
+    seed: int = 100
+    dual_reset: bool = True
+
+    def to_abi(self):
+        return dict(amplitude_init=self.amplitude_init, shift=int(min(self.shift, 2 ** 30)),
+                    regularize=int(self.regularize), reg_0=self.reg_0, alpha_decrease=self.α_decrease,
+                    beta=self.β, ls_iter=self.ls_iter, dual_reset=int(self.dual_reset),
+                    delta_min=self.Δ_min, rho_0=self.ρ_0, rho_increase=self.ρ_increase,
+                    rho_max=self.ρ_max, lambda_max=self.λ_max, alpha_dual=self.α_dual,
+                    alphax_dual=list(self.αx_dual)[:10], eps_dyn=self.ϵ_dyn, eps_sta=self.ϵ_sta,
+                    eps_con=self.ϵ_con, eps_opt=self.ϵ_opt, outer_iter=self.outer_iter,
+                    inner_iter=self.inner_iter, seed=self.seed)
+
+
+# --------------------------------------------------------------------------------------------------
+# GameObjective (src/objective/objective.jl:6-100)
+# --------------------------------------------------------------------------------------------------
+def _diag(M):
+    M = np.asarray(M, dtype=np.float64)
+    return np.diag(M).copy() if M.ndim == 2 else M.copy()
+
+
+def expand_vector(v, inds, n):
+    V = np.zeros(n)
+    V[np.asarray(inds) - 1] = v
+    return V
+
+
+class GameObjective:
+    def __init__(self, Q, R, xf, uf, N, model):
+        p = model.p
+        assert len(Q) == len(R) == len(xf) == len(uf) == p
+        self.probsize = ProblemSize(N, model)
+        self.Qdiag = np.stack([_diag(Q[i]) for i in range(p)])          # (p, ni)
+        self.Rdiag = np.stack([_diag(R[i]) for i in range(p)])          # (p, mi)
+        self.xf = np.stack([np.asarray(xf[i], dtype=np.float64) for i in range(p)])
+        self.uf = np.stack([np.asarray(uf[i], dtype=np.float64) for i in range(p)])
+        self.collision_radius = None
+        self.collision_μ = None
+
+
+def add_collision_cost(game_obj, radius, μ):
+    """add_collision_cost!(game_obj, radius, μ), objective.jl:84-100 (one set per objective)."""
+    p = game_obj.probsize.p
+    assert p == len(radius) == len(μ)
+    if game_obj.collision_radius is not None:
+        raise AlgamesError("only one collision-cost set per GameObjective is supported")
+    game_obj.collision_radius = np.asarray(radius, dtype=np.float64)
+    game_obj.collision_μ = np.asarray(μ, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------------------
+# GameConstraintValues (src/constraints/game_constraints.jl, constraints_methods.jl)
+# --------------------------------------------------------------------------------------------------
+class GameConstraintValues:
+    def __init__(self, probsize):
+        self.probsize = probsize
+        self.α_dual = 1.0
+        self.αx_dual = [1.0] * probsize.p
+        self.collision_radius = None     # per player, pair radius = r_i + r_j
+        self.u_max = None
+        self.u_min = None
+
+
+def add_collision_avoidance(game_con, radius):
+    """add_collision_avoidance!(game_con, radius), constraints_methods.jl:21-39."""
+    p = game_con.probsize.p
+    r = np.asarray(radius, dtype=np.float64)
+    if r.ndim == 0:
+        r = r * np.ones(p)
+    assert p == len(r)
+    if game_con.collision_radius is not None:
+        raise AlgamesError("only one collision-avoidance set per GameConstraintValues is supported")
+    game_con.collision_radius = r
+
+
+def add_control_bound(game_con, u_max, u_min):
+    """add_control_bound!(game_con, u_max, u_min), constraints_methods.jl:104-115."""
+    u_max = np.asarray(u_max, dtype=np.float64); u_min = np.asarray(u_min, dtype=np.float64)
+    if not np.all(u_max >= u_min):
+        raise ValueError("Upper bounds must be greater than or equal to lower bounds")   # control_bound_constraint.jl:69-75
+    if game_con.u_max is not None:
+        raise AlgamesError("only one control-bound set per GameConstraintValues is supported")
+    game_con.u_max, game_con.u_min = u_max, u_min
+
+
+# --------------------------------------------------------------------------------------------------
+# PrimalDualTraj / Statistics views
+# --------------------------------------------------------------------------------------------------
+class PrimalDualTraj:
+    """Batched view of a primal-dual trajectory (src/struct/primal_dual_traj.jl:5-23).
+    states (B,N,n), controls (B,N-1,m) in joint order, duals (B,p,N-1,n)."""
+
+    def __init__(self, states, controls, duals):
+        self.states, self.controls, self.duals = states, controls, duals
+
+
+class Statistics:
+    """Per-game `Statistics` history (src/struct/statistics.jl:5-15) as numpy record arrays."""
+
+    def __init__(self, summary, history_fn):
+        self.summary = summary
+        self._history_fn = history_fn
+
+    def history(self, game=0):
+        return self._history_fn(game)
+
+    @property
+    def iter(self):
+        return self.summary["records"]
+
+
+# --------------------------------------------------------------------------------------------------
+# GameProblem (src/problem/problem.jl:19-53)
+# --------------------------------------------------------------------------------------------------
+class GameProblem:
+    def __init__(self, N, dt, x0, model, opts, game_obj, game_con, backend=None, device=0, game_id0=0):
+        self.probsize = ProblemSize(N, model)
+        self.model, self.opts, self.game_obj, self.game_con = model, opts, game_obj, game_con
+        self.dt = dt
+        x0 = np.asarray(x0, dtype=np.float64)
+        self.single = x0.ndim == 1
+        self.x0 = np.ascontiguousarray(x0.reshape(-1, model.n))
+        self.B = self.x0.shape[0]
+        self.game_id0 = game_id0
+        lib = backend if backend is not None else hip_lib()
+        self.batch = Batch(lib, model.model_id, model.p, N, dt, self.B, d=model.d, device=device)
+        self.batch.set_x0(self.x0)
+        self.batch.set_lqr(game_obj.Qdiag, game_obj.Rdiag, game_obj.xf, game_obj.uf)
+        if game_obj.collision_radius is not None:
+            self.batch.add_collision_cost(game_obj.collision_radius, game_obj.collision_μ)
+        if game_con.collision_radius is not None:
+            self.batch.add_collision_avoidance(game_con.collision_radius)
+        if game_con.u_max is not None:
+            self.batch.add_control_bound(game_con.u_max, game_con.u_min)
+        self.stats = None
+        self._sync_options()       # set_constraint_params!(game_con, opts), problem.jl:49
+
+    def _sync_options(self):
+        # `opts` is shared by reference in Julia and read at solve time (tests mutate it after construction)
+        self.batch.set_options(**self.opts.to_abi())
+
+    def _traj(self, which):
+        X, U, L = self.batch.split_traj(self.batch.get_traj(which))
+        return PrimalDualTraj(X, U, L)
+
+    @property
+    def pdtraj(self):
+        return self._traj(ALG_TRAJ_PD)
+
+    @property
+    def pdtraj_trial(self):
+        return self._traj(ALG_TRAJ_TRIAL)
+
+    @property
+    def Δpdtraj(self):
+        return self._traj(ALG_TRAJ_DELTA)
+
+    def set_pdtraj(self, states=None, controls=None, duals=None):
+        cur = self.pdtraj
+        X = cur.states if states is None else np.broadcast_to(np.asarray(states, dtype=np.float64), cur.states.shape)
+        U = cur.controls if controls is None else np.broadcast_to(np.asarray(controls, dtype=np.float64), cur.controls.shape)
+        L = cur.duals if duals is None else np.broadcast_to(np.asarray(duals, dtype=np.float64), cur.duals.shape)
+        self.batch.set_traj(self.batch.join_traj(np.array(X), np.array(U), np.array(L)))
+
+
+# --------------------------------------------------------------------------------------------------
+# Solver methods (src/problem/solver_methods.jl:5-125, src/problem/global_quantities.jl:1-193)
+# --------------------------------------------------------------------------------------------------
+def newton_solve(prob, init=True):
+    """newton_solve!(prob) for every game of the batch (solver_methods.jl:5-65).
+    init=False keeps the stored controls/duals as the initial guess (explicit warm start)."""
+    prob._sync_options()
+    summary = prob.batch.newton_solve(init=init, game_id0=prob.game_id0)
+    prob.stats = Statistics(summary, prob.batch.get_history)
+    return None
+
+
+def residual(prob, which=ALG_TRAJ_PD, reg=0.0):
+    """residual!(prob, pdtraj) (+ regularize_residual!): returns core.res, shape (B, S), vertical order."""
+    prob._sync_options()
+    return prob.batch.residual(which, reg)[0]
+
+
+def residual_norm(prob, which=ALG_TRAJ_PD):
+    """residual_norm(prob, pdtraj), global_quantities.jl:88-97."""
+    prob._sync_options()
+    return prob.batch.residual(which, 0.0, want_res=False)[1]
+
+
+def residual_jacobian(prob, reg=0.0):
+    """residual_jacobian! + regularize_residual_jacobian!: dense (B, S, S), [row vertical, col horizontal]."""
+    prob._sync_options()
+    return prob.batch.residual_jacobian(reg)
+
+
+def inner_iteration(prob, LS_count, t_elap, Δ, k, l):
+    """inner_iteration(prob, LS_count, t_elap, Δ, k, l) (solver_methods.jl:67-103).
+    Returns (LS_count (B,), control_flow (B,) of 'continue'/'break', Δ (B,), info)."""
+    prob._sync_options()
+    info = prob.batch.newton_step(k, l)
+    LS = np.where(info["ls_failed"] == 1, np.asarray(LS_count) + 1, 0)
+    LS = np.where(info["ls_j"] == 0, np.asarray(LS_count), LS)
+    flow = np.where(info["control_flow"] == 1, "break", "continue")
+    return LS, flow, info["delta"], info
+
+
+def line_search(prob, res_norm, reg=0.0):
+    """line_search(prob, res_norm) (solver_methods.jl:105-125) -> (α, j)."""
+    prob._sync_options()
+    return prob.batch.line_search(res_norm, reg)
+
+
+def dynamics_violation(prob):
+    return prob.batch.record()["dyn_vio"]
+
+
+def control_violation(prob):
+    return prob.batch.record()["con_vio"]
+
+
+def state_violation(prob):
+    return prob.batch.record()["sta_vio"]
+
+
+def optimality_violation(prob):
+    return prob.batch.record()["opt_vio"]

@@ -1,0 +1,217 @@
+/*
+ * algames_hip.h -- C ABI of the MI355X-native batched ALGAMES Newton / augmented-Lagrangian
+ * hot path (libalgames_hip.so).
+ *
+ * The reference (RoboticExplorationLab/Algames.jl v0.1.6) has no FFI: its boundary is the
+ * Julia API itself.  Every entry point below names the reference function (file:line under
+ * /root/reference) that it replaces for a *batch* of B independent games that share
+ * (model, p, N, dt, options, constraint structure) and differ in data (x0, targets,
+ * multipliers, iterate).  A Julia host binds these with `ccall`.
+ *
+ * Conventions
+ *   - all floating point data is IEEE fp64, all buffers are caller-owned host memory unless a
+ *     function says "device"; the library owns device memory and its HIP stream.
+ *   - batched buffers are game-major and contiguous: buf[g*len + e].
+ *   - return value: 0 = ALG_OK, <0 = error, message in alg_last_error() (thread local).
+ *     Numerical failure of individual games is reported per game (alg_game_stats.status),
+ *     never as a call error.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ *
+ * Layouts (src/core/newton_core.jl:40-89)
+ *   traj  (len n+S):  [ x_1 (n) | for k=1..N-1: x_{k+1} (n), u_{1,k} (mi) .. u_{p,k} (mi),
+ *                                               lambda_{1,k} (n) .. lambda_{p,k} (n) ]
+ *          i.e. x_1 followed by the reference's "horizontal" order = order of `Δtraj`
+ *          (src/struct/primal_dual_traj.jl:46-107).  u_{i,k} holds joint-control entries
+ *          pu[i] = {i + (j-1)p} in increasing order.
+ *   res   (len S):    reference "vertical" order: for i=1..p, for k=1..N-1:
+ *          [opt_i,x_{k+1} (n) | opt_i,u_{i,k} (mi)], then for k=1..N-1: dyn_k (n).
+ *   jac   (S x S, column-major): rows vertical order, columns horizontal order.
+ *   con duals / penalties / values (len alg_con_len()):
+ *          [ collision avoidance: for pair q=(i,j) in the order of
+ *            add_collision_avoidance! (constraints_methods.jl:21-33: for i, for j != i),
+ *            for knot k=2..N: 1 row ]  then
+ *          [ control bound: for knot k=1..N-1: rows (u-u_max)(m) then (u_min-u)(m) ].
+ *          Rows of infinite bounds are kept (the reference drops them,
+ *          control_bound_constraint.jl:35-38); they are never active and report value -inf.
+ */
+#ifndef ALGAMES_HIP_H
+#define ALGAMES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALG_OK 0
+#define ALG_ERR_ARG (-1)        /* bad argument / unsupported configuration            */
+#define ALG_ERR_DEVICE (-2)     /* HIP runtime error                                   */
+#define ALG_ERR_STATE (-3)      /* call sequence error (e.g. data not set)             */
+
+/* src/dynamics/double_integrator.jl:13-31, src/dynamics/unicycle.jl:14-32 */
+#define ALG_MODEL_DOUBLE_INTEGRATOR 0
+#define ALG_MODEL_UNICYCLE 1
+
+/* which trajectory buffer of the problem (problem.jl:27-29) */
+#define ALG_TRAJ_PD 0      /* prob.pdtraj        */
+#define ALG_TRAJ_TRIAL 1   /* prob.pdtraj_trial  */
+#define ALG_TRAJ_DELTA 2   /* prob.Δpdtraj (x_1 slot is zero) */
+
+/* per-game status */
+#define ALG_STATUS_OK 0
+#define ALG_STATUS_SINGULAR 1   /* zero / non-finite pivot in the Newton solve (reference: SingularException) */
+#define ALG_STATUS_NAN 2        /* non-finite residual */
+
+typedef struct alg_handle alg_handle;
+
+/* ProblemSize + model + dt (src/struct/problem_size.jl:18-35, problem.jl:35-53) */
+typedef struct alg_desc {
+    int32_t model;   /* ALG_MODEL_*                                           */
+    int32_t p;       /* number of players                                     */
+    int32_t d;       /* integrator dimension (DoubleIntegrator; unicycle: 2)  */
+    int32_t N;       /* knot points                                           */
+    double  dt;      /* step                                                  */
+    int32_t batch;   /* number of games B owned by this handle                */
+    int32_t device;  /* HIP device ordinal (ignored by the CPU oracle)        */
+} alg_desc;
+
+/* POD mirror of the `Options` fields read on the hot path (src/struct/options.jl:5-116). */
+typedef struct alg_options {
+    double  amplitude_init;  /* 1e-8  */
+    int32_t shift;           /* 2^10  */
+    int32_t regularize;      /* true  */
+    double  reg_0;           /* 1e-3  */
+    double  alpha_decrease;  /* 0.5   */
+    double  beta;            /* 0.01  */
+    int32_t ls_iter;         /* 25    */
+    int32_t dual_reset;      /* true  */
+    double  delta_min;       /* 1e-9  */
+    double  rho_0;           /* 1.0   */
+    double  rho_increase;    /* 10.0  */
+    double  rho_max;         /* 1e7   */
+    double  lambda_max;      /* 1e7   */
+    double  alpha_dual;      /* 1.0   */
+    double  alphax_dual[10]; /* ones  */
+    double  eps_dyn, eps_sta, eps_con, eps_opt; /* 1e-3 */
+    int32_t outer_iter;      /* 7     */
+    int32_t inner_iter;      /* 20    */
+    int64_t seed;            /* 100   */
+} alg_options;
+
+/* One `Statistics` record (src/struct/statistics.jl:5-15,44-57): what record! pushes. */
+typedef struct alg_record {
+    int32_t outer;     /* stats.outer_iter[end]        */
+    int32_t ls_j;      /* line-search count j of the step taken after this record (0 if none) */
+    double  alpha;     /* step taken after this record (0 if none)                            */
+    double  res;       /* ||res||_1 / S                */
+    double  delta;     /* Δ_traj passed to record!     */
+    double  dyn_vio, con_vio, sta_vio, opt_vio; /* the four .max scalars */
+} alg_record;
+
+/* Result of newton_solve! for one game (src/problem/solver_methods.jl:5-65). */
+typedef struct alg_game_stats {
+    int32_t status;        /* ALG_STATUS_*                                              */
+    int32_t outer_iters;   /* `out`                                                     */
+    int32_t newton_iters;  /* inner iterations that performed a linear solve            */
+    int32_t records;       /* stats.iter                                                */
+    int32_t converged;     /* exit test solver_methods.jl:49-53 met (not the k==outer_iter arm) */
+    int32_t ls_failures;   /* failed line searches                                      */
+    alg_record last;       /* final record! (solver_methods.jl:63)                      */
+} alg_game_stats;
+
+/* Result of one inner_iteration (src/problem/solver_methods.jl:67-103). */
+typedef struct alg_step_info {
+    int32_t status;
+    int32_t control_flow;  /* 0 = :continue, 1 = :break                                 */
+    int32_t ls_j;          /* j returned by line_search (0 if the step was skipped)     */
+    int32_t ls_failed;     /* j == ls_iter                                              */
+    double  alpha;
+    double  delta;         /* Δ_step                                                    */
+    alg_record rec;        /* the record! made at the top of the iteration              */
+} alg_step_info;
+
+const char* alg_last_error(void);
+void alg_default_options(alg_options* o);                 /* Options() defaults, options.jl:5-116 */
+
+/* sizes derived from a descriptor (problem_size.jl:18-35) */
+int alg_dims(const alg_desc* d, int32_t* n, int32_t* m, int32_t* mi, int32_t* S,
+             int32_t* traj_len, int32_t* con_len);
+
+/* GameProblem(N, dt, x0, model, opts, game_obj, game_con)  (problem.jl:35-53) */
+int  alg_create(const alg_desc* d, alg_handle** out);
+void alg_destroy(alg_handle* h);
+int  alg_set_options(alg_handle* h, const alg_options* o);   /* also set_constraint_params!, game_constraints.jl:33-53 */
+int  alg_get_options(alg_handle* h, alg_options* o);
+/* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = library stream. */
+int  alg_set_stream(alg_handle* h, void* hip_stream);
+
+/* x0: B x n */
+int alg_set_x0(alg_handle* h, const double* x0);
+/* GameObjective(Q,R,xf,uf,N,model) (objective.jl:12-35): diagonals on the player's own indices.
+ * Qdiag, xf: [B x] p x ni ; Rdiag, uf: [B x] p x mi.  per_game=0: one set shared by all games. */
+int alg_set_lqr(alg_handle* h, const double* Qdiag, const double* Rdiag, const double* xf,
+                const double* uf, int32_t per_game);
+/* add_collision_cost!(game_obj, radius, mu) (objective.jl:84-100); NULL,NULL removes it. */
+int alg_add_collision_cost(alg_handle* h, const double* radius /*p*/, const double* mu /*p*/);
+/* add_collision_avoidance!(game_con, radius::Vector) (constraints_methods.jl:21-33) */
+int alg_add_collision_avoidance(alg_handle* h, const double* radius /*p*/);
+/* add_control_bound!(game_con, u_max, u_min) (constraints_methods.jl:104-115); +-inf allowed */
+int alg_add_control_bound(alg_handle* h, const double* u_max /*m*/, const double* u_min /*m*/);
+
+/* set_traj!/get_traj! (primal_dual_traj.jl:46-107) over the batch: B x traj_len */
+int alg_set_traj(alg_handle* h, int32_t which, const double* z);
+int alg_get_traj(alg_handle* h, int32_t which, double* z);
+/* ALConVal lambda / mu (Altro 0.3.0): B x con_len each; NULL pointers are skipped */
+int alg_set_con_duals(alg_handle* h, const double* lambda, const double* mu);
+int alg_get_con_duals(alg_handle* h, double* lambda, double* mu);
+
+/* init_traj! + rollout!(RK3) (solver_methods.jl:12-18, primal_dual_traj.jl:29-44).
+ * f_init = rand is replaced by a counter-based generator (SplitMix64 keyed by seed, global game id
+ * game_id0+g, element counter) because Julia's MersenneTwister stream cannot be reproduced
+ * (SURVEY.md section 7 "hard parts").  use_shift!=0 applies the `shift` warm start to the stored pdtraj. */
+int alg_init_traj(alg_handle* h, int64_t game_id0, int32_t use_shift);
+/* rollout!(RK3, model, pdtraj.pr) only (keeps controls/duals as set by alg_set_traj). */
+int alg_rollout(alg_handle* h, int32_t which);
+
+/* residual! + regularize_residual! (global_quantities.jl:9-86).  `which` selects the iterate;
+ * the proximal term is taken w.r.t. pdtraj with reg = reg_x = reg_u (0 disables).
+ * res (B x S, vertical order) and res_norm (B, ||res||_1/S) may each be NULL. */
+int alg_residual(alg_handle* h, int32_t which, double reg, double* res, double* res_norm);
+/* residual_jacobian! + regularize_residual_jacobian! (global_quantities.jl:109-193) at pdtraj:
+ * jac is B x S x S dense column-major (parity / inspection entry point; the solver itself never
+ * materialises it). */
+int alg_residual_jacobian(alg_handle* h, double reg, double* jac);
+/* Δtraj = -lu(jac) \ res ; set_traj!(Δpdtraj, Δtraj) (solver_methods.jl:87-88).  delta: B x S or NULL. */
+int alg_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status /*B or NULL*/);
+/* line_search (solver_methods.jl:105-125) on the stored Δpdtraj. */
+int alg_line_search(alg_handle* h, double reg, const double* res_norm /*B*/, double* alpha /*B*/,
+                    int32_t* j /*B*/);
+/* update_traj!(target, source, alpha, Δpdtraj) (primal_dual_traj.jl:109-128); alpha: B */
+int alg_update_traj(alg_handle* h, int32_t target, int32_t source, const double* alpha);
+/* record!'s scalars at pdtraj (statistics.jl:44-57, violations.jl) */
+int alg_record_stats(alg_handle* h, alg_record* rec /*B*/);
+/* reset!(game_con) (constraints_methods.jl:295-327) */
+int alg_reset_con(alg_handle* h);
+/* evaluate!(game_con, pdtraj.pr); dual_update!(game_con); penalty_update!(game_con)
+ * (solver_methods.jl:57-61, constraints_methods.jl:329-379,421-440).  vals: B x con_len or NULL. */
+int alg_dual_penalty_update(alg_handle* h, double* vals);
+
+/* inner_iteration(prob, LS_count, t_elap, Δ, k, l) (solver_methods.jl:67-103) for every game;
+ * reg is set to reg_0*l^4 as in solver_methods.jl:39. */
+int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, alg_step_info* info /*B*/);
+/* newton_solve!(prob) (solver_methods.jl:5-65) for every game.  init!=0: run alg_init_traj first
+ * (game ids game_id0+g); init==0: keep the stored controls/duals as the initial guess, still
+ * rolling out the states (solver_methods.jl:17).  stats: B or NULL. */
+int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats);
+/* Same, asynchronous on the handle's stream: no host synchronisation, results stay on the device
+ * until alg_get_stats().  Used by the benchmark so that HIP events bracket only device work. */
+int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0);
+int alg_get_stats(alg_handle* h, alg_game_stats* stats /*B*/);
+/* Statistics history of one game (statistics.jl:5-15): up to max_records; returns count in *n_out */
+int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out);
+int alg_synchronize(alg_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALGAMES_HIP_H */

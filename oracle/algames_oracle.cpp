@@ -1,0 +1,976 @@
+// algames_oracle.cpp -- CPU ORACLE (test infrastructure, NOT the product).
+//
+// A literal fp64 restatement of the hot path of RoboticExplorationLab/Algames.jl v0.1.6
+// (newton_solve! -> residual!/residual_jacobian! -> lu \ -> line_search), one game at a time,
+// batched with an OpenMP loop over games.  It deliberately keeps the reference's structure:
+// a global S-vector residual in "vertical" order, a global S x S Jacobian in
+// (vertical, horizontal) order, a general partial-pivot LU of that matrix (stand-in for
+// UMFPACK `lu`, src/problem/solver_methods.jl:87), >= 3 residual evaluations per Newton
+// iteration (solver_methods.jl:73, statistics.jl:50, solver_methods.jl:113), forward-mode
+// dual numbers for the RK2 Jacobian (stand-in for ForwardDiff inside
+// RobotDynamics.discrete_jacobian!, src/problem/local_quantities.jl:20-27).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+//
+// PARITY PINNING.  The reference is Julia with un-vendored dependencies and cannot be executed
+// in this environment (no julia binary).  This oracle is pinned against every
+// literal known-answer value the reference's own tests hold for this path (SURVEY.md Appendix B;
+// tests/test_oracle_kat.py cites each test file:line) and the five end-to-end convergence
+// thresholds of test/problem/solver_methods.jl.  The following third-party formulas are
+// restated from the published source of the pinned dependency versions and are NOT fixed by
+// any literal value in the reference tree ("parity unpinned" for these items): the RK2 / RK3
+// formulas of RobotDynamics 0.3.1, TrajectoryOptimization 0.4.1's CollisionConstraint value and
+// Jacobian, the terminal-knot dt convention.  They are covered only by the end-to-end
+// thresholds.
+//
+// Every function cites the reference file:line it follows (paths relative to /root/reference).
+
+#include "../include/algames_hip.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+// ------------------------------------------------------------------------------------------
+// Sizes and index maps
+// ------------------------------------------------------------------------------------------
+struct Dims {
+    int model = 0, p = 0, d = 0, N = 0;
+    int n = 0, m = 0, mi = 0, ni = 0, S = 0, b = 0;
+    int traj_len = 0, npair = 0, col_len = 0, ctl_len = 0, con_len = 0;
+    double dt = 0;
+    // src/struct/problem_size.jl:18-35 ; src/dynamics/double_integrator.jl:13-25 ; unicycle.jl:14-25
+    bool init(const alg_desc& a) {
+        model = a.model; p = a.p; N = a.N; dt = a.dt;
+        if (p < 1 || p > 10 || N < 2) return false;
+        if (model == ALG_MODEL_DOUBLE_INTEGRATOR) {
+            d = a.d; if (d < 1 || d > 3) return false;
+            n = 2 * d * p; m = d * p; mi = d; ni = 2 * d;
+        } else if (model == ALG_MODEL_UNICYCLE) {
+            d = 2; n = 4 * p; m = 2 * p; mi = 2; ni = 4;
+        } else return false;
+        S = n * p * (N - 1) + m * (N - 1) + n * (N - 1);   // problem_size.jl:22
+        b = n + m + p * n;
+        traj_len = n + S;
+        npair = p * (p - 1);
+        col_len = npair * (N - 1);
+        ctl_len = 2 * m * (N - 1);
+        con_len = col_len + ctl_len;
+        return true;
+    }
+    // index sets pu/px/pz = {i + (j-1)p} (double_integrator.jl:18-20), 0-based
+    int pu(int i, int j) const { return i + j * p; }
+    int pz(int i, int j) const { return i + j * p; }
+    int px(int i, int j) const { return i + j * p; }
+    // horizontal order (newton_core.jl:65-89), 0-based knot k = 0..N-2 <-> reference k = 1..N-1
+    int hx(int k) const { return k * b; }                       // x_{k+1}
+    int hu(int k, int i) const { return k * b + n + i * mi; }   // u_{i,k}
+    int hl(int k, int i) const { return k * b + n + m + i * n; } // lambda_{i,k}
+    // vertical order (newton_core.jl:40-63)
+    int vx(int i, int k) const { return i * (N - 1) * (n + mi) + k * (n + mi); }      // opt_i, x_{k+1}
+    int vu(int i, int k) const { return i * (N - 1) * (n + mi) + k * (n + mi) + n; }  // opt_i, u_{i,k}
+    int vd(int k) const { return p * (N - 1) * (n + mi) + k * n; }                     // dyn_k
+    // ordered pair index, order of add_collision_avoidance! (constraints_methods.jl:21-33)
+    int pair(int i, int j) const { return i * (p - 1) + (j < i ? j : j - 1); }
+};
+
+// ------------------------------------------------------------------------------------------
+// Forward-mode dual numbers (stand-in for ForwardDiff 0.10 used by discrete_jacobian!)
+// ------------------------------------------------------------------------------------------
+constexpr int MAXD = 96;
+struct Dual {
+    double v = 0;
+    std::array<double, MAXD> e{};
+    int nd = 0;
+};
+inline Dual dconst(double v, int nd) { Dual r; r.v = v; r.nd = nd; return r; }
+inline Dual operator+(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v + b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] + b.e[i]; return r; }
+inline Dual operator*(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v * b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * b.v + a.v * b.e[i]; return r; }
+inline Dual operator*(const Dual& a, double s) { Dual r; r.nd = a.nd; r.v = a.v * s; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * s; return r; }
+inline Dual dcos(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::cos(a.v); double s = -std::sin(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
+inline Dual dsin(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::sin(a.v); double c = std::cos(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = c * a.e[i]; return r; }
+inline double dcos(double a) { return std::cos(a); }
+inline double dsin(double a) { return std::sin(a); }
+
+// continuous dynamics.  DoubleIntegrator: xdot = [x[m+1:n]; u] (double_integrator.jl:27-31).
+// Unicycle: xdot_i = cos(th_i) v_i, ydot_i = sin(th_i) v_i, thdot = u[1:p], vdot = u[p+1:2p]
+// (unicycle.jl:27-32; state = [x(1..p), y(1..p), th(1..p), v(1..p)]).
+template <class T>
+void dynamics(const Dims& D, const T* x, const T* u, T* xd) {
+    if (D.model == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        for (int i = 0; i < D.m; i++) xd[i] = x[D.m + i];
+        for (int i = 0; i < D.m; i++) xd[D.m + i] = u[i];
+    } else {
+        const int P = D.p, M = D.m;
+        for (int i = 0; i < P; i++) xd[i] = dcos(x[M + i]) * x[M + i + P];
+        for (int i = 0; i < P; i++) xd[P + i] = dsin(x[M + i]) * x[M + i + P];
+        for (int i = 0; i < M; i++) xd[M + i] = u[i];
+    }
+}
+
+// RobotDynamics 0.3.1 discrete_dynamics(RK2,...): k1 = f(x,u) dt; k2 = f(x + k1/2, u) dt; x + k2
+// [restated from the published source; parity unpinned, see header]
+template <class T>
+void rk2(const Dims& D, const T* x, const T* u, T* xn) {
+    std::vector<T> k1(D.n), xm(D.n), k2(D.n);
+    dynamics(D, x, u, k1.data());
+    for (int i = 0; i < D.n; i++) xm[i] = x[i] + k1[i] * (D.dt * 0.5);
+    dynamics(D, xm.data(), u, k2.data());
+    for (int i = 0; i < D.n; i++) xn[i] = x[i] + k2[i] * D.dt;
+}
+// RobotDynamics 0.3.1 discrete_dynamics(RK3,...) used by rollout! (solver_methods.jl:17)
+void rk3(const Dims& D, const double* x, const double* u, double* xn) {
+    std::vector<double> k1(D.n), k2(D.n), k3(D.n), t(D.n);
+    dynamics(D, x, u, k1.data());
+    for (int i = 0; i < D.n; i++) { k1[i] *= D.dt; t[i] = x[i] + k1[i] / 2; }
+    dynamics(D, t.data(), u, k2.data());
+    for (int i = 0; i < D.n; i++) { k2[i] *= D.dt; t[i] = x[i] - k1[i] + 2 * k2[i]; }
+    dynamics(D, t.data(), u, k3.data());
+    for (int i = 0; i < D.n; i++) { k3[i] *= D.dt; xn[i] = x[i] + (k1[i] + 4 * k2[i] + k3[i]) / 6; }
+}
+// ∇dynamics! (local_quantities.jl:20-27): n x (n+m) Jacobian [A B] of the RK2 map, row-major J[r*(n+m)+c]
+void rk2_jacobian(const Dims& D, const double* x, const double* u, double* J) {
+    const int nd = D.n + D.m;
+    std::vector<Dual> xd(D.n), ud(D.m), xn(D.n);
+    for (int i = 0; i < D.n; i++) { xd[i] = dconst(x[i], nd); xd[i].e[i] = 1.0; }
+    for (int i = 0; i < D.m; i++) { ud[i] = dconst(u[i], nd); ud[i].e[D.n + i] = 1.0; }
+    rk2(D, xd.data(), ud.data(), xn.data());
+    for (int r = 0; r < D.n; r++) for (int c = 0; c < nd; c++) J[r * nd + c] = xn[r].e[c];
+}
+
+// SplitMix64-based counter RNG shared bit-for-bit with the device:
+// value(seed, game, counter) in [0,1)
+inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+inline double counter_uniform(uint64_t seed, uint64_t game, uint64_t counter) {
+    uint64_t h = splitmix64(seed ^ splitmix64(game * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull));
+    h = splitmix64(h + counter * 0x9E3779B97F4A7C15ull);
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// One game
+// ------------------------------------------------------------------------------------------
+struct Shared {
+    Dims D;
+    alg_options opt;
+    bool has_colcost = false, has_colavoid = false, has_ctl = false;
+    std::vector<double> cc_radius, cc_mu;   // collision cost (objective.jl:84-100)
+    std::vector<double> ca_radius;          // collision avoidance radii per player
+    std::vector<double> umax, umin;         // control bound
+};
+
+struct Game {
+    // joint-dimension zero-padded LQR data per player (objective.jl:24-28)
+    std::vector<double> Q, R, xf, uf;     // p*n, p*m, p*n, p*m
+    std::vector<double> x0;
+    std::vector<double> z[3];             // pdtraj, trial, delta (traj_len each)
+    std::vector<double> lam, mu, vals;    // con_len
+    std::vector<alg_record> hist;
+    alg_game_stats st{};
+    // scratch
+    std::vector<double> res, jac;
+};
+
+struct Handle {
+    Shared sh;
+    std::vector<Game> g;
+    bool x0_set = false, lqr_set = false;
+};
+
+inline const double* state(const Dims& D, const std::vector<double>& z, int k) {  // knot k = 0..N-1
+    return k == 0 ? z.data() : z.data() + D.n + D.hx(k - 1);
+}
+inline double* state(const Dims& D, std::vector<double>& z, int k) {
+    return k == 0 ? z.data() : z.data() + D.n + D.hx(k - 1);
+}
+inline void get_control(const Dims& D, const std::vector<double>& z, int k, double* u) {  // joint order
+    for (int i = 0; i < D.p; i++) for (int j = 0; j < D.mi; j++) u[D.pu(i, j)] = z[D.n + D.hu(k, i) + j];
+}
+inline void set_control(const Dims& D, std::vector<double>& z, int k, const double* u) {
+    for (int i = 0; i < D.p; i++) for (int j = 0; j < D.mi; j++) z[D.n + D.hu(k, i) + j] = u[D.pu(i, j)];
+}
+inline const double* dual(const Dims& D, const std::vector<double>& z, int i, int k) {
+    return z.data() + D.n + D.hl(k, i);
+}
+
+// ---- objective (src/objective/objective.jl) ------------------------------------------------
+// cost_gradient! / TrajectoryOptimization.cost_gradient!(E,obj,traj,true): q scaled by dt for
+// k<N and by 1 at the terminal knot, r scaled by dt for k<N and 0 at the terminal knot
+// [PINNED test/objective/objective.jl:52-64].
+// q (n) of player i at knot k for all objectives j (LQR + collision costs), summed as in
+// global_quantities.jl:26-31.
+void cost_grad_x(const Shared& sh, const Game& g, int i, int k, const double* x, double* q) {
+    const Dims& D = sh.D;
+    const double w = (k < D.N - 1) ? D.dt : 1.0;
+    for (int r = 0; r < D.n; r++) q[r] = w * (g.Q[i * D.n + r] * (x[r] - g.xf[i * D.n + r]));   // LQRCost: Q(x-xf)
+    if (sh.has_colcost) {
+        // CollisionCost gradient (objective.jl:134-149)
+        const double eps = 1e-10, eps_norm = eps * std::sqrt((double)D.n);
+        for (int j = 0; j < D.p; j++) if (j != i) {
+            double dl[2], nrm = 0;
+            for (int a = 0; a < 2; a++) { dl[a] = x[D.px(i, a)] - x[D.px(j, a)]; nrm += dl[a] * dl[a]; }
+            nrm = std::sqrt(nrm);
+            const double mu = sh.cc_mu[i], rad = sh.cc_radius[i];
+            if (std::max(0.0, rad - nrm) > 0.0) {
+                for (int a = 0; a < 2; a++) {
+                    double gg = mu * (rad * (eps + dl[a]) / (eps_norm + nrm) - dl[a]);
+                    q[D.px(i, a)] += w * (-gg);
+                    q[D.px(j, a)] += w * (gg);
+                }
+            }
+        }
+    }
+}
+// r[pu[i]] of player i at knot k < N-1 (global_quantities.jl:34-40); only the LQR term is non-zero
+void cost_grad_u(const Shared& sh, const Game& g, int i, const double* u, double* r /*mi*/) {
+    const Dims& D = sh.D;
+    for (int j = 0; j < D.mi; j++) { int c = D.pu(i, j); r[j] = D.dt * (g.R[i * D.m + c] * (u[c] - g.uf[i * D.m + c])); }
+}
+// cost_hessian!: Q (n x n, row-major) of player i at knot k, all objectives (global_quantities.jl:128-136)
+void cost_hess_x(const Shared& sh, const Game& g, int i, int k, const double* x, double* Qm) {
+    const Dims& D = sh.D;
+    const double w = (k < D.N - 1) ? D.dt : 1.0;
+    std::fill(Qm, Qm + D.n * D.n, 0.0);
+    for (int r = 0; r < D.n; r++) Qm[r * D.n + r] += w * g.Q[i * D.n + r];
+    if (sh.has_colcost) {
+        // CollisionCost Hessian (objective.jl:157-173)
+        for (int j = 0; j < D.p; j++) if (j != i) {
+            double dl[2], nrm = 0;
+            for (int a = 0; a < 2; a++) { dl[a] = x[D.px(i, a)] - x[D.px(j, a)]; nrm += dl[a] * dl[a]; }
+            nrm = std::sqrt(nrm);
+            const double mu = sh.cc_mu[i], rad = sh.cc_radius[i];
+            if (std::max(0.0, rad - nrm) > 0.0) {
+                for (int a = 0; a < 2; a++) for (int c = 0; c < 2; c++) {
+                    double h = mu * ((a == c ? 1.0 : 0.0) - (a == c ? rad / nrm : 0.0) + rad * (dl[a] * dl[c]) / (nrm * nrm * nrm));
+                    Qm[D.px(i, a) * D.n + D.px(i, c)] += w * h;
+                    Qm[D.px(i, a) * D.n + D.px(j, c)] += -w * h;
+                    Qm[D.px(j, a) * D.n + D.px(i, c)] += -w * h;
+                    Qm[D.px(j, a) * D.n + D.px(j, c)] += w * h;
+                }
+            }
+        }
+    }
+}
+
+// ---- constraints ----------------------------------------------------------------------------
+// con buffer offsets
+inline int con_col(const Dims& D, int pairq, int k /*knot 1..N-1 (0-based)*/) { return pairq * (D.N - 1) + (k - 1); }
+inline int con_ctl(const Dims& D, int k /*0..N-2*/, int row) { return D.col_len + k * 2 * D.m + row; }
+
+// TrajectoryOptimization 0.4.1 CollisionConstraint: c = radius^2 - |x[x1]-x[x2]|^2, d c/d x1 = -2 d,
+// d c/d x2 = 2 d  [restated; parity unpinned].  Pair radius = r_i + r_j (constraints_methods.jl:27-29).
+inline double colavoid_val(const Shared& sh, int i, int j, const double* x, double* dl) {
+    const Dims& D = sh.D;
+    double R = sh.ca_radius[i] + sh.ca_radius[j], s = 0;
+    for (int a = 0; a < 2; a++) { dl[a] = x[D.px(i, a)] - x[D.px(j, a)]; s += dl[a] * dl[a]; }
+    return R * R - s;
+}
+// ControlBoundConstraint evaluate (control_bound_constraint.jl:94-96): [u - u_max; u_min - u]
+inline double ctl_val(const Shared& sh, const double* u, int row) {
+    const int m = sh.D.m;
+    return row < m ? u[row] - sh.umax[row] : sh.umin[row - m] - u[row - m];
+}
+// evaluate!(game_con, traj) (constraints_methods.jl:367-379)
+void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
+    const Dims& D = sh.D;
+    std::vector<double> u(D.m);
+    if (sh.has_colavoid)
+        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i)
+            for (int k = 1; k < D.N; k++) { double dl[2]; g.vals[con_col(D, D.pair(i, j), k)] = colavoid_val(sh, i, j, state(D, z, k), dl); }
+    if (sh.has_ctl)
+        for (int k = 0; k < D.N - 1; k++) { get_control(D, z, k, u.data()); for (int r = 0; r < 2 * D.m; r++) g.vals[con_ctl(D, k, r)] = ctl_val(sh, u.data(), r); }
+}
+// Altro 0.3.0 / TrajOpt cost_expansion!(conval): a = (c >= 0) | (lambda > 0); I_mu = diag(a*mu);
+// grad = C'(lambda + I_mu c); hess = C' I_mu C  [PINNED test/constraints/constraint_derivatives.jl:28-34]
+inline double al_active_mu(double c, double lam, double mu) { return ((c >= 0) || (lam > 0)) ? mu : 0.0; }
+
+// ---- residual! (global_quantities.jl:9-65) + regularize_residual! (:67-86) -------------------
+void residual(const Shared& sh, Game& g, const std::vector<double>& z, double reg, const std::vector<double>* zref) {
+    const Dims& D = sh.D;
+    const int n = D.n, m = D.m, p = D.p, N = D.N, nd = n + m;
+    std::vector<double>& res = g.res;
+    res.assign(D.S, 0.0);                                                            // :18
+    std::vector<double> q(n), r(D.mi), u(m), J(n * nd), xn(n), uref(m);
+    // Cost (:23-41).  stamp (opt,i,x,k) is invalid for the first knot (stamp.jl:203).
+    for (int i = 0; i < p; i++) {
+        for (int k = 1; k < N; k++) {
+            cost_grad_x(sh, g, i, k, state(D, z, k), q.data());
+            for (int a = 0; a < n; a++) res[D.vx(i, k - 1) + a] += q[a];
+        }
+        for (int k = 0; k < N - 1; k++) {
+            get_control(D, z, k, u.data());
+            cost_grad_u(sh, g, i, u.data(), r.data());
+            for (int a = 0; a < D.mi; a++) res[D.vu(i, k) + a] += r[a];
+        }
+    }
+    // Dynamics penalty (:43-54)
+    for (int k = 0; k < N - 1; k++) {
+        get_control(D, z, k, u.data());
+        rk2_jacobian(D, state(D, z, k), u.data(), J.data());
+        for (int i = 0; i < p; i++) {
+            const double* lam = dual(D, z, i, k);
+            if (k >= 1)                                                              // (opt,i,x,k) valid only for knots 2..N
+                for (int c = 0; c < n; c++) { double s = 0; for (int rr = 0; rr < n; rr++) s += J[rr * nd + c] * lam[rr]; res[D.vx(i, k - 1) + c] += s; }
+            for (int j = 0; j < D.mi; j++) { int c = n + D.pu(i, j); double s = 0; for (int rr = 0; rr < n; rr++) s += J[rr * nd + c] * lam[rr]; res[D.vu(i, k) + j] += s; }
+            for (int c = 0; c < n; c++) res[D.vx(i, k) + c] += -lam[c];
+        }
+    }
+    // Constraints: constraint_residual! (constraint_derivatives.jl:39-74)
+    if (sh.has_colavoid) {
+        for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i) {
+            const int qd = D.pair(i, j);
+            for (int k = 1; k < N; k++) {
+                double dl[2];
+                const double c = colavoid_val(sh, i, j, state(D, z, k), dl);
+                const int ci = con_col(D, qd, k);
+                g.vals[ci] = c;
+                const double w = g.lam[ci] + al_active_mu(c, g.lam[ci], g.mu[ci]) * c;
+                for (int a = 0; a < 2; a++) {                                        // grad = C' w, C = [-2d' at px[i], +2d' at px[j]]
+                    res[D.vx(i, k - 1) + D.px(i, a)] += -2 * dl[a] * w;
+                    res[D.vx(i, k - 1) + D.px(j, a)] += 2 * dl[a] * w;
+                }
+            }
+        }
+    }
+    if (sh.has_ctl) {
+        for (int k = 0; k < N - 1; k++) {
+            get_control(D, z, k, u.data());
+            for (int i = 0; i < p; i++) for (int j = 0; j < D.mi; j++) {
+                const int c = D.pu(i, j);
+                double gsum = 0;
+                for (int half = 0; half < 2; half++) {
+                    const int row = half * m + c, ci = con_ctl(D, k, row);
+                    const double cv = ctl_val(sh, u.data(), row);
+                    g.vals[ci] = cv;
+                    if (!std::isfinite(cv)) continue;                                // infinite bound: row absent in the reference
+                    const double w = g.lam[ci] + al_active_mu(cv, g.lam[ci], g.mu[ci]) * cv;
+                    gsum += (half == 0 ? 1.0 : -1.0) * w;
+                }
+                res[D.vu(i, k) + j] += gsum;
+            }
+        }
+    }
+    // Dynamics (:60-63, local_quantities.jl:5-14)
+    for (int k = 0; k < N - 1; k++) {
+        get_control(D, z, k, u.data());
+        rk2(D, state(D, z, k), u.data(), xn.data());
+        const double* x1 = state(D, z, k + 1);
+        for (int a = 0; a < n; a++) res[D.vd(k) + a] += xn[a] - x1[a];
+    }
+    // regularize_residual! (:67-86)
+    if (zref && reg != 0.0) {
+        for (int k = 0; k < N - 1; k++) {
+            const double* x = state(D, z, k + 1); const double* xr = state(D, *zref, k + 1);
+            get_control(D, z, k, u.data()); get_control(D, *zref, k, uref.data());
+            for (int i = 0; i < p; i++) {
+                for (int a = 0; a < n; a++) res[D.vx(i, k) + a] += reg * (x[a] - xr[a]);
+                for (int j = 0; j < D.mi; j++) { int c = D.pu(i, j); res[D.vu(i, k) + j] += reg * (u[c] - uref[c]); }
+            }
+        }
+    }
+}
+
+double res_norm(const Shared& sh, const Game& g) {   // norm(core.res,1)/length(core.res)  (solver_methods.jl:76)
+    double s = 0; for (double v : g.res) s += std::fabs(v); return s / sh.D.S;
+}
+
+// ---- residual_jacobian! (:109-174) + regularize_residual_jacobian! (:176-193) ----------------
+// add(row_vertical, col_horizontal, value)
+template <class Add>
+void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double reg, Add add) {
+    const Dims& D = sh.D;
+    const int n = D.n, m = D.m, p = D.p, N = D.N, nd = n + m;
+    std::vector<double> Qm(n * n), u(m), J(n * nd);
+    // Cost (:128-145)
+    for (int i = 0; i < p; i++) {
+        for (int k = 1; k < N; k++) {
+            cost_hess_x(sh, g, i, k, state(D, z, k), Qm.data());
+            for (int a = 0; a < n; a++) for (int c = 0; c < n; c++) if (Qm[a * n + c] != 0.0) add(D.vx(i, k - 1) + a, D.hx(k - 1) + c, Qm[a * n + c]);
+        }
+        for (int k = 0; k < N - 1; k++)
+            for (int j = 0; j < D.mi; j++) { int c = D.pu(i, j); add(D.vu(i, k) + j, D.hu(k, i) + j, D.dt * g.R[i * m + c]); }   // R[pu[i],pu[i]] diagonal
+    }
+    // Constraints: constraint_jacobian_residual! (constraint_derivatives.jl:1-36)
+    if (sh.has_colavoid) {
+        for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i) {
+            const int qd = D.pair(i, j);
+            for (int k = 1; k < N; k++) {
+                double dl[2];
+                const double c = colavoid_val(sh, i, j, state(D, z, k), dl);
+                const int ci = con_col(D, qd, k);
+                const double am = al_active_mu(c, g.lam[ci], g.mu[ci]);
+                if (am == 0.0) continue;
+                // hess = C' I_mu C with C = [-2d at px[i], 2d at px[j]]
+                int idx[4] = {D.px(i, 0), D.px(i, 1), D.px(j, 0), D.px(j, 1)};
+                double cv[4] = {-2 * dl[0], -2 * dl[1], 2 * dl[0], 2 * dl[1]};
+                for (int a = 0; a < 4; a++) for (int c2 = 0; c2 < 4; c2++)
+                    add(D.vx(i, k - 1) + idx[a], D.hx(k - 1) + idx[c2], am * cv[a] * cv[c2]);
+            }
+        }
+    }
+    if (sh.has_ctl) {
+        for (int k = 0; k < N - 1; k++) {
+            get_control(D, z, k, u.data());
+            for (int i = 0; i < p; i++) for (int j = 0; j < D.mi; j++) {
+                const int c = D.pu(i, j);
+                double h = 0;
+                for (int half = 0; half < 2; half++) {
+                    const int row = half * m + c, ci = con_ctl(D, k, row);
+                    const double cv = ctl_val(sh, u.data(), row);
+                    if (!std::isfinite(cv)) continue;
+                    h += al_active_mu(cv, g.lam[ci], g.mu[ci]);
+                }
+                if (h != 0.0) add(D.vu(i, k) + j, D.hu(k, i) + j, h);
+            }
+        }
+    }
+    // Dynamics (:151-172)
+    for (int k = 0; k < N - 1; k++) {
+        get_control(D, z, k, u.data());
+        rk2_jacobian(D, state(D, z, k), u.data(), J.data());
+        if (k >= 1) for (int a = 0; a < n; a++) for (int c = 0; c < n; c++) if (J[a * nd + c] != 0.0) add(D.vd(k) + a, D.hx(k - 1) + c, J[a * nd + c]);
+        for (int i = 0; i < p; i++) for (int j = 0; j < D.mi; j++) for (int a = 0; a < n; a++) {
+            double v = J[a * nd + n + D.pu(i, j)]; if (v != 0.0) add(D.vd(k) + a, D.hu(k, i) + j, v);
+        }
+        for (int a = 0; a < n; a++) add(D.vd(k) + a, D.hx(k) + a, -1.0);
+        for (int i = 0; i < p; i++) {
+            if (k >= 1) for (int a = 0; a < n; a++) for (int c = 0; c < n; c++) if (J[a * nd + c] != 0.0) add(D.vx(i, k - 1) + c, D.hl(k, i) + a, J[a * nd + c]);
+            for (int j = 0; j < D.mi; j++) for (int a = 0; a < n; a++) { double v = J[a * nd + n + D.pu(i, j)]; if (v != 0.0) add(D.vu(i, k) + j, D.hl(k, i) + a, v); }
+            for (int a = 0; a < n; a++) add(D.vx(i, k) + a, D.hl(k, i) + a, -1.0);
+        }
+    }
+    // regularize_residual_jacobian! (:176-193)
+    if (reg != 0.0)
+        for (int k = 0; k < N - 1; k++) for (int i = 0; i < p; i++) {
+            for (int a = 0; a < n; a++) add(D.vx(i, k) + a, D.hx(k) + a, reg);
+            for (int j = 0; j < D.mi; j++) add(D.vu(i, k) + j, D.hu(k, i) + j, reg);
+        }
+}
+
+// ---- linear solve: general partial-pivot LU (stand-in for UMFPACK lu, solver_methods.jl:87) ---
+// Rows are permuted to time-major order so the matrix is banded; the LU then does *full* partial
+// pivoting over each column inside the band (LAPACK dgbtf2 algorithm), i.e. exactly the pivots a
+// dense partial-pivot LU of the row-permuted matrix would take.
+struct Banded {
+    int S = 0, kl = 0, ku = 0, ld = 0;
+    std::vector<double> ab;    // (2kl+ku+1) x S, column-major, LAPACK band storage
+    std::vector<int> ipiv;
+    void init(int S_, int kl_, int ku_) { S = S_; kl = kl_; ku = ku_; ld = 2 * kl + ku + 1; ab.assign((size_t)ld * S, 0.0); ipiv.assign(S, 0); }
+    double& at(int r, int c) { return ab[(size_t)c * ld + (kl + ku + r - c)]; }
+    // returns 0 ok, >0 singular at column
+    int factor() {
+        for (int j = 0; j < S; j++) {
+            const int km = std::min(kl, S - 1 - j);
+            int jp = 0; double best = std::fabs(at(j, j));
+            for (int i = 1; i <= km; i++) { double v = std::fabs(at(j + i, j)); if (v > best) { best = v; jp = i; } }
+            ipiv[j] = j + jp;
+            if (best == 0.0 || !std::isfinite(best)) return j + 1;
+            const int ju = std::min(j + ku + kl, S - 1);   // last column affected (U fill-in bound)
+            if (jp != 0) for (int c = j; c <= ju; c++) std::swap(at(j, c), at(j + jp, c));
+            const double inv = 1.0 / at(j, j);
+            for (int i = 1; i <= km; i++) at(j + i, j) *= inv;
+            for (int c = j + 1; c <= ju; c++) {
+                const double v = at(j, c);
+                if (v != 0.0) for (int i = 1; i <= km; i++) at(j + i, c) -= at(j + i, j) * v;
+            }
+        }
+        return 0;
+    }
+    void solve(std::vector<double>& x) {
+        for (int j = 0; j < S; j++) {
+            const int km = std::min(kl, S - 1 - j);
+            if (ipiv[j] != j) std::swap(x[j], x[ipiv[j]]);
+            const double v = x[j];
+            if (v != 0.0) for (int i = 1; i <= km; i++) x[j + i] -= at(j + i, j) * v;
+        }
+        for (int j = S - 1; j >= 0; j--) {
+            x[j] /= at(j, j);
+            const double v = x[j];
+            const int i0 = std::max(0, j - ku - kl);
+            if (v != 0.0) for (int i = i0; i < j; i++) x[i] -= at(i, j) * v;
+        }
+    }
+};
+
+// Row / column permutations that make the KKT matrix narrow-banded: per time step k the rows are ordered
+// (dyn_k, opt_u_k, opt_x_{k+1}) and the columns (lambda_k, u_k, x_{k+1}).  A permutation changes neither the
+// solution nor the fact that every column is searched in full for its pivot.
+void build_perms(const Dims& D, std::vector<int>& rpos, std::vector<int>& cpos) {
+    rpos.assign(D.S, 0); cpos.assign(D.S, 0);
+    int off = 0;
+    for (int k = 0; k < D.N - 1; k++) {
+        for (int a = 0; a < D.n; a++) rpos[D.vd(k) + a] = off++;
+        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.mi; j++) rpos[D.vu(i, k) + j] = off++;
+        for (int i = 0; i < D.p; i++) for (int a = 0; a < D.n; a++) rpos[D.vx(i, k) + a] = off++;
+    }
+    off = 0;
+    for (int k = 0; k < D.N - 1; k++) {
+        for (int i = 0; i < D.p; i++) for (int a = 0; a < D.n; a++) cpos[D.hl(k, i) + a] = off++;
+        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.mi; j++) cpos[D.hu(k, i) + j] = off++;
+        for (int a = 0; a < D.n; a++) cpos[D.hx(k) + a] = off++;
+    }
+}
+
+// Δtraj = - lu(jac) \ res ; set_traj!(core, Δpdtraj, Δtraj)  (solver_methods.jl:87-88)
+int newton_direction(const Shared& sh, Game& g, double reg) {
+    const Dims& D = sh.D;
+    std::vector<int> rpos, cpos; build_perms(D, rpos, cpos);
+    int kl = 0, ku = 0;
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double) { int dlt = rpos[r] - cpos[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); });
+    Banded B; B.init(D.S, kl, ku);
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double v) { B.at(rpos[r], cpos[c]) += v; });
+    std::vector<double> rhs(D.S);
+    for (int r = 0; r < D.S; r++) rhs[rpos[r]] = g.res[r];
+    if (B.factor() != 0) return ALG_STATUS_SINGULAR;
+    B.solve(rhs);
+    std::vector<double>& dz = g.z[2];
+    for (int a = 0; a < D.n; a++) dz[a] = 0.0;
+    for (int c = 0; c < D.S; c++) dz[D.n + c] = -rhs[cpos[c]];
+    for (int c = 0; c < D.S; c++) if (!std::isfinite(dz[D.n + c])) return ALG_STATUS_SINGULAR;
+    return ALG_STATUS_OK;
+}
+
+// update_traj!(target, source, alpha, Δ) (primal_dual_traj.jl:109-128): x_{2..N}, u_{1..N-1}, duals; x_1 untouched
+void update_traj(const Shared& sh, std::vector<double>& tgt, const std::vector<double>& src, double alpha, const std::vector<double>& dz) {
+    const Dims& D = sh.D;
+    for (int c = 0; c < D.S; c++) tgt[D.n + c] = src[D.n + c] + alpha * dz[D.n + c];
+}
+// Δ_step (primal_dual_traj.jl:130-147)
+double delta_step(const Shared& sh, const std::vector<double>& dz, double alpha) {
+    const Dims& D = sh.D;
+    double s = 0;
+    for (int k = 0; k < D.N - 1; k++) {
+        for (int a = 0; a < D.n; a++) s += std::fabs(dz[D.n + D.hx(k) + a]);
+        for (int a = 0; a < D.m; a++) s += std::fabs(dz[D.n + D.hu(k, 0) + a]);
+    }
+    s *= alpha;
+    s /= (double)((D.N - 1) * (D.n + D.m));
+    return s;
+}
+
+// record! (statistics.jl:44-57): residual_norm (recomputes residual!, unregularised) + four violations
+alg_record record(const Shared& sh, Game& g, double delta, int outer) {
+    const Dims& D = sh.D;
+    alg_record rc{};
+    rc.outer = outer; rc.delta = delta;
+    residual(sh, g, g.z[0], 0.0, nullptr);                       // residual_norm(prob, pdtraj) (global_quantities.jl:92-97)
+    rc.res = res_norm(sh, g);
+    // dynamics_violation (violations.jl:18-26): max_k max|dyn_k|
+    double dv = 0; for (int k = 0; k < D.N - 1; k++) for (int a = 0; a < D.n; a++) dv = std::max(dv, std::fabs(g.res[D.vd(k) + a]));
+    rc.dyn_vio = dv;
+    // control_violation / state_violation (violations.jl:57-67,101-114): max(0, max c) [PINNED test/struct/violations.jl:27-49]
+    double cv = 0, sv = 0;
+    if (sh.has_ctl) for (int k = 0; k < D.N - 1; k++) for (int r = 0; r < 2 * D.m; r++) cv = std::max(cv, std::max(0.0, g.vals[con_ctl(D, k, r)]));
+    if (sh.has_colavoid) for (int q = 0; q < D.npair; q++) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, q, k)]));
+    rc.con_vio = cv; rc.sta_vio = sv;
+    // optimality_violation (violations.jl:153-168): max |res| over opt rows
+    double ov = 0; const int nopt = D.p * (D.N - 1) * (D.n + D.mi);
+    for (int r = 0; r < nopt; r++) ov = std::max(ov, std::fabs(g.res[r]));
+    rc.opt_vio = ov;
+    return rc;
+}
+
+// line_search (solver_methods.jl:105-125)
+void line_search(const Shared& sh, Game& g, double reg, double res_norm0, double* alpha_out, int* j_out) {
+    const alg_options& o = sh.opt;
+    int j = 1; double alpha = 1.0;
+    while (j < o.ls_iter) {
+        update_traj(sh, g.z[1], g.z[0], alpha, g.z[2]);
+        residual(sh, g, g.z[1], o.regularize ? reg : 0.0, &g.z[0]);
+        const double rt = res_norm(sh, g);
+        if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
+        alpha *= o.alpha_decrease; j += 1;
+    }
+    *alpha_out = alpha; *j_out = j;
+}
+
+// inner_iteration (solver_methods.jl:67-103)
+alg_step_info inner_iteration(const Shared& sh, Game& g, int& LS_count, double& Delta, int k, int l) {
+    const alg_options& o = sh.opt;
+    alg_step_info info{};
+    const double reg = o.reg_0 * std::pow((double)l, 4);                  // solver_methods.jl:39
+    residual(sh, g, g.z[0], o.regularize ? reg : 0.0, &g.z[0]);           // :73-74 (adds zero)
+    alg_record rc = record(sh, g, Delta, k);                              // :75
+    const double rn = res_norm(sh, g);                                    // :76
+    info.rec = rc;
+    Delta = 0.0;                                                          // :79
+    if (!std::isfinite(rn)) { info.status = ALG_STATUS_NAN; info.control_flow = 1; g.hist.push_back(rc); g.st.records++; return info; }
+    if (rc.opt_vio < o.eps_opt) { info.control_flow = 1; g.hist.push_back(rc); g.st.records++; return info; }   // :80-82
+    int st = newton_direction(sh, g, reg);                                // :84-88
+    if (st != ALG_STATUS_OK) { info.status = st; info.control_flow = 1; g.hist.push_back(rc); g.st.records++; return info; }
+    g.st.newton_iters++;
+    double alpha; int j;
+    line_search(sh, g, reg, rn, &alpha, &j);                              // :91
+    const bool failed = (j == o.ls_iter);                                 // :92
+    if (failed) { LS_count += 1; g.st.ls_failures++; } else LS_count = 0; // :93
+    update_traj(sh, g.z[0], g.z[0], alpha, g.z[2]);                       // :94
+    Delta = delta_step(sh, g.z[2], alpha);                                // :95
+    info.alpha = alpha; info.ls_j = j; info.ls_failed = failed; info.delta = Delta;
+    rc.alpha = alpha; rc.ls_j = j; info.rec = rc;
+    g.hist.push_back(rc); g.st.records++;
+    if (Delta < o.delta_min) info.control_flow = 1;                       // :96-98
+    return info;
+}
+
+// reset!(game_con) (constraints_methods.jl:295-327): lambda <- 0, mu <- mu0 = rho_0 [PINNED test/constraints/constraints_methods.jl:176-229]
+void reset_con(const Shared& sh, Game& g) {
+    std::fill(g.lam.begin(), g.lam.end(), 0.0);
+    std::fill(g.mu.begin(), g.mu.end(), sh.opt.rho_0);
+}
+// evaluate! + dual_update! + penalty_update! (solver_methods.jl:57-61; constraints_methods.jl:349-365,421-440;
+// Altro.penalty_update!: mu <- min(phi mu, mu_max) [PINNED test/constraints/constraints_methods.jl:180-193])
+void dual_penalty_update(const Shared& sh, Game& g) {
+    const Dims& D = sh.D; const alg_options& o = sh.opt;
+    evaluate_con(sh, g, g.z[0]);
+    if (sh.has_colavoid)
+        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i) for (int k = 1; k < D.N; k++) {
+            const int ci = con_col(D, D.pair(i, j), k);
+            const double lb = g.lam[ci] + o.alphax_dual[i] * g.mu[ci] * g.vals[ci];
+            g.lam[ci] = std::min(std::max(lb, 0.0), o.lambda_max);
+        }
+    if (sh.has_ctl)
+        for (int k = 0; k < D.N - 1; k++) for (int r = 0; r < 2 * D.m; r++) {
+            const int ci = con_ctl(D, k, r);
+            if (!std::isfinite(g.vals[ci])) continue;
+            const double lb = g.lam[ci] + o.alpha_dual * g.mu[ci] * g.vals[ci];
+            g.lam[ci] = std::min(std::max(lb, 0.0), o.lambda_max);
+        }
+    for (double& v : g.mu) v = std::min(std::max(v * o.rho_increase, 0.0), o.rho_max);
+}
+
+// rollout!(RK3, model, traj) (solver_methods.jl:17)
+void rollout(const Shared& sh, std::vector<double>& z) {
+    const Dims& D = sh.D;
+    std::vector<double> u(D.m), xn(D.n);
+    for (int k = 0; k < D.N - 1; k++) {
+        get_control(D, z, k, u.data());
+        rk3(D, state(D, z, k), u.data(), xn.data());
+        std::copy(xn.begin(), xn.end(), state(D, z, k + 1));
+    }
+}
+
+// init_traj! (primal_dual_traj.jl:29-44) with f = counter RNG.  Element counters: knot k (0-based),
+// entry e of z_k=[x_k;u_k] (joint order) -> k*(n+m)+e ; dual (i,k,r) -> N*(n+m) + (i*(N-1)+k)*n + r.
+// The terminal knot's control is drawn by the reference but never used.
+void init_traj(const Shared& sh, Game& g, std::vector<double>& z, uint64_t game_id, bool use_shift, bool zero) {
+    const Dims& D = sh.D; const alg_options& o = sh.opt;
+    const int s = use_shift ? o.shift : (1 << 30);
+    std::vector<double> old = z, u(D.m);
+    for (int k = 0; k < D.N; k++) {
+        const bool sh_ok = (k + s <= D.N - 1);
+        // states are overwritten by the rollout for k >= 1, kept here for literalness
+        if (k >= 1) for (int a = 0; a < D.n; a++)
+            state(D, z, k)[a] = sh_ok ? state(D, old, k + s)[a] : (zero ? 0.0 : o.amplitude_init * counter_uniform(o.seed, game_id, (uint64_t)k * (D.n + D.m) + a));
+        if (k < D.N - 1) {
+            if (sh_ok && k + s < D.N - 1) get_control(D, old, k + s, u.data());
+            else for (int a = 0; a < D.m; a++) u[a] = zero ? 0.0 : o.amplitude_init * counter_uniform(o.seed, game_id, (uint64_t)k * (D.n + D.m) + D.n + a);
+            set_control(D, z, k, u.data());
+        }
+    }
+    for (int i = 0; i < D.p; i++) for (int k = 0; k < D.N - 1; k++) for (int r = 0; r < D.n; r++)
+        z[D.n + D.hl(k, i) + r] = (k + s <= D.N - 2) ? old[D.n + D.hl(k + s, i) + r]
+                                 : (zero ? 0.0 : o.amplitude_init * counter_uniform(o.seed, game_id, (uint64_t)D.N * (D.n + D.m) + ((uint64_t)i * (D.N - 1) + k) * D.n + r));
+    for (int a = 0; a < D.n; a++) z[a] = g.x0[a];                          // set_state!(pdtraj.pr[1], x0)
+}
+
+// newton_solve! (solver_methods.jl:5-65)
+void newton_solve(const Shared& sh, Game& g, bool init, uint64_t game_id) {
+    const alg_options& o = sh.opt;
+    g.st = alg_game_stats{}; g.hist.clear();                               // reset!(prob.stats)
+    if (init) init_traj(sh, g, g.z[0], game_id, true, false);             // :13
+    else for (int a = 0; a < sh.D.n; a++) g.z[0][a] = g.x0[a];
+    g.z[1] = g.z[0];                                                       // :14 (trial is overwritten before use; x_1 = x0 matters)
+    std::fill(g.z[2].begin(), g.z[2].end(), 0.0);                          // :15
+    rollout(sh, g.z[0]);                                                   // :17
+    if (o.dual_reset) reset_con(sh, g);                                    // :25
+    int out = 0; double Delta = 0.0;
+    for (int k = 1; k <= o.outer_iter; k++) {                              // :30
+        out = k;
+        int LS_count = 0;                                                  // :35
+        alg_record last{};
+        bool any = false;
+        for (int l = 1; l <= o.inner_iter; l++) {                          // :38
+            alg_step_info info = inner_iteration(sh, g, LS_count, Delta, k, l);
+            last = info.rec; any = true;
+            if (info.status != ALG_STATUS_OK) { g.st.status = info.status; break; }
+            if (LS_count >= 1 || info.control_flow == 1) break;            // :43
+        }
+        if (g.st.status != ALG_STATUS_OK) break;
+        const bool conv = any && last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
+        if (conv) g.st.converged = 1;
+        if (k == o.outer_iter || conv) break;                              // :49-55
+        dual_penalty_update(sh, g);                                        // :57-61
+    }
+    alg_record fin = record(sh, g, Delta, out);                            // :63
+    g.hist.push_back(fin); g.st.records++;
+    g.st.outer_iters = out; g.st.last = fin;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI (same signatures as include/algames_hip.h with the orc_ prefix)
+// ------------------------------------------------------------------------------------------
+#define H ((Handle*)h)
+extern "C" {
+
+const char* orc_last_error(void) { return g_err.c_str(); }
+
+void orc_default_options(alg_options* o) {   // options.jl:5-116
+    std::memset(o, 0, sizeof(*o));
+    o->amplitude_init = 1e-8; o->shift = 1 << 10; o->regularize = 1; o->reg_0 = 1e-3;
+    o->alpha_decrease = 0.5; o->beta = 0.01; o->ls_iter = 25; o->dual_reset = 1; o->delta_min = 1e-9;
+    o->rho_0 = 1.0; o->rho_increase = 10.0; o->rho_max = 1e7; o->lambda_max = 1e7; o->alpha_dual = 1.0;
+    for (int i = 0; i < 10; i++) o->alphax_dual[i] = 1.0;
+    o->eps_dyn = o->eps_sta = o->eps_con = o->eps_opt = 1e-3;
+    o->outer_iter = 7; o->inner_iter = 20; o->seed = 100;
+}
+
+int orc_dims(const alg_desc* d, int32_t* n, int32_t* m, int32_t* mi, int32_t* S, int32_t* traj_len, int32_t* con_len) {
+    Dims D; if (!d || !D.init(*d)) return fail(ALG_ERR_ARG, "orc_dims: unsupported descriptor");
+    if (n) *n = D.n; if (m) *m = D.m; if (mi) *mi = D.mi; if (S) *S = D.S; if (traj_len) *traj_len = D.traj_len; if (con_len) *con_len = D.con_len;
+    return ALG_OK;
+}
+
+int orc_create(const alg_desc* d, alg_handle** out) {
+    if (!d || !out) return fail(ALG_ERR_ARG, "orc_create: null argument");
+    Handle* hd = new Handle();
+    if (!hd->sh.D.init(*d) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "orc_create: unsupported descriptor"); }
+    if (hd->sh.D.n + hd->sh.D.m > MAXD) { delete hd; return fail(ALG_ERR_ARG, "orc_create: n+m too large for the dual-number width"); }
+    orc_default_options(&hd->sh.opt);
+    const Dims& D = hd->sh.D;
+    hd->g.resize(d->batch);
+    for (Game& g : hd->g) {
+        g.Q.assign(D.p * D.n, 0.0); g.R.assign(D.p * D.m, 0.0); g.xf.assign(D.p * D.n, 0.0); g.uf.assign(D.p * D.m, 0.0);
+        g.x0.assign(D.n, 0.0);
+        for (auto& z : g.z) z.assign(D.traj_len, 0.0);
+        g.lam.assign(D.con_len, 0.0); g.mu.assign(D.con_len, hd->sh.opt.rho_0); g.vals.assign(D.con_len, 0.0);
+    }
+    *out = (alg_handle*)hd;
+    return ALG_OK;
+}
+void orc_destroy(alg_handle* h) { delete H; }
+
+int orc_set_options(alg_handle* h, const alg_options* o) {
+    if (!h || !o) return fail(ALG_ERR_ARG, "orc_set_options: null argument");
+    if (o->ls_iter < 1 || o->outer_iter < 1 || o->inner_iter < 1) return fail(ALG_ERR_ARG, "orc_set_options: iteration counts must be >= 1");
+    H->sh.opt = *o; return ALG_OK;
+}
+int orc_get_options(alg_handle* h, alg_options* o) { *o = H->sh.opt; return ALG_OK; }
+int orc_set_stream(alg_handle*, void*) { return ALG_OK; }
+
+int orc_set_x0(alg_handle* h, const double* x0) {
+    const Dims& D = H->sh.D;
+    for (size_t gi = 0; gi < H->g.size(); gi++) { Game& g = H->g[gi]; std::copy(x0 + gi * D.n, x0 + (gi + 1) * D.n, g.x0.begin()); for (auto& z : g.z) std::copy(g.x0.begin(), g.x0.end(), z.begin()); std::fill(g.z[2].begin(), g.z[2].begin() + D.n, 0.0); }
+    H->x0_set = true; return ALG_OK;
+}
+// GameObjective constructor (objective.jl:12-35): expand_vector onto pz[i] / pu[i]
+int orc_set_lqr(alg_handle* h, const double* Qd, const double* Rd, const double* xf, const double* uf, int32_t per_game) {
+    const Dims& D = H->sh.D;
+    for (size_t gi = 0; gi < H->g.size(); gi++) {
+        Game& g = H->g[gi];
+        const size_t ox = per_game ? gi * D.p * D.ni : 0, ou = per_game ? gi * D.p * D.mi : 0;
+        std::fill(g.Q.begin(), g.Q.end(), 0.0); std::fill(g.R.begin(), g.R.end(), 0.0);
+        std::fill(g.xf.begin(), g.xf.end(), 0.0); std::fill(g.uf.begin(), g.uf.end(), 0.0);
+        for (int i = 0; i < D.p; i++) {
+            for (int j = 0; j < D.ni; j++) { g.Q[i * D.n + D.pz(i, j)] = Qd[ox + i * D.ni + j]; g.xf[i * D.n + D.pz(i, j)] = xf[ox + i * D.ni + j]; }
+            for (int j = 0; j < D.mi; j++) { g.R[i * D.m + D.pu(i, j)] = Rd[ou + i * D.mi + j]; g.uf[i * D.m + D.pu(i, j)] = uf[ou + i * D.mi + j]; }
+        }
+    }
+    H->lqr_set = true; return ALG_OK;
+}
+int orc_add_collision_cost(alg_handle* h, const double* radius, const double* mu) {
+    Shared& s = H->sh;
+    if (!radius || !mu) { s.has_colcost = false; return ALG_OK; }
+    s.cc_radius.assign(radius, radius + s.D.p); s.cc_mu.assign(mu, mu + s.D.p); s.has_colcost = true; return ALG_OK;
+}
+int orc_add_collision_avoidance(alg_handle* h, const double* radius) {
+    Shared& s = H->sh;
+    if (!radius) { s.has_colavoid = false; return ALG_OK; }
+    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; return ALG_OK;
+}
+int orc_add_control_bound(alg_handle* h, const double* umax, const double* umin) {
+    Shared& s = H->sh;
+    if (!umax || !umin) { s.has_ctl = false; return ALG_OK; }
+    for (int i = 0; i < s.D.m; i++) if (!(umax[i] >= umin[i])) return fail(ALG_ERR_ARG, "Upper bounds must be greater than or equal to lower bounds");  // control_bound_constraint.jl:69-75
+    s.umax.assign(umax, umax + s.D.m); s.umin.assign(umin, umin + s.D.m); s.has_ctl = true; return ALG_OK;
+}
+int orc_set_traj(alg_handle* h, int32_t which, const double* z) {
+    if (which < 0 || which > 2) return fail(ALG_ERR_ARG, "bad traj selector");
+    const int L = H->sh.D.traj_len;
+    for (size_t gi = 0; gi < H->g.size(); gi++) std::copy(z + gi * L, z + (gi + 1) * L, H->g[gi].z[which].begin());
+    return ALG_OK;
+}
+int orc_get_traj(alg_handle* h, int32_t which, double* z) {
+    if (which < 0 || which > 2) return fail(ALG_ERR_ARG, "bad traj selector");
+    const int L = H->sh.D.traj_len;
+    for (size_t gi = 0; gi < H->g.size(); gi++) std::copy(H->g[gi].z[which].begin(), H->g[gi].z[which].end(), z + gi * L);
+    return ALG_OK;
+}
+int orc_set_con_duals(alg_handle* h, const double* lam, const double* mu) {
+    const int L = H->sh.D.con_len;
+    for (size_t gi = 0; gi < H->g.size(); gi++) { if (lam) std::copy(lam + gi * L, lam + (gi + 1) * L, H->g[gi].lam.begin()); if (mu) std::copy(mu + gi * L, mu + (gi + 1) * L, H->g[gi].mu.begin()); }
+    return ALG_OK;
+}
+int orc_get_con_duals(alg_handle* h, double* lam, double* mu) {
+    const int L = H->sh.D.con_len;
+    for (size_t gi = 0; gi < H->g.size(); gi++) { if (lam) std::copy(H->g[gi].lam.begin(), H->g[gi].lam.end(), lam + gi * L); if (mu) std::copy(H->g[gi].mu.begin(), H->g[gi].mu.end(), mu + gi * L); }
+    return ALG_OK;
+}
+int orc_init_traj(alg_handle* h, int64_t game_id0, int32_t use_shift) {
+    const int B = (int)H->g.size();
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) { Game& g = H->g[gi]; init_traj(H->sh, g, g.z[0], (uint64_t)(game_id0 + gi), use_shift != 0, false); g.z[1] = g.z[0]; rollout(H->sh, g.z[0]); }
+    return ALG_OK;
+}
+int orc_rollout(alg_handle* h, int32_t which) {
+    if (which < 0 || which > 1) return fail(ALG_ERR_ARG, "bad traj selector");
+    for (Game& g : H->g) rollout(H->sh, g.z[which]);
+    return ALG_OK;
+}
+int orc_residual(alg_handle* h, int32_t which, double reg, double* res, double* rn) {
+    if (which < 0 || which > 1) return fail(ALG_ERR_ARG, "bad traj selector");
+    const int B = (int)H->g.size(), S = H->sh.D.S;
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) {
+        Game& g = H->g[gi];
+        residual(H->sh, g, g.z[which], reg, &g.z[0]);
+        if (res) std::copy(g.res.begin(), g.res.end(), res + (size_t)gi * S);
+        if (rn) rn[gi] = res_norm(H->sh, g);
+    }
+    return ALG_OK;
+}
+int orc_residual_jacobian(alg_handle* h, double reg, double* jac) {
+    const int B = (int)H->g.size(); const size_t S = H->sh.D.S;
+    for (int gi = 0; gi < B; gi++) {
+        double* Jm = jac + (size_t)gi * S * S; std::fill(Jm, Jm + S * S, 0.0);
+        jacobian(H->sh, H->g[gi], H->g[gi].z[0], reg, [&](int r, int c, double v) { Jm[(size_t)c * S + r] += v; });
+    }
+    return ALG_OK;
+}
+int orc_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status) {
+    const int B = (int)H->g.size(), S = H->sh.D.S, n = H->sh.D.n;
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) {
+        Game& g = H->g[gi];
+        residual(H->sh, g, g.z[0], 0.0, nullptr);
+        int st = newton_direction(H->sh, g, reg);
+        if (status) status[gi] = st;
+        if (delta) std::copy(g.z[2].begin() + n, g.z[2].end(), delta + (size_t)gi * S);
+    }
+    return ALG_OK;
+}
+int orc_line_search(alg_handle* h, double reg, const double* rn, double* alpha, int32_t* j) {
+    const int B = (int)H->g.size();
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) { int jj; double a; line_search(H->sh, H->g[gi], reg, rn[gi], &a, &jj); alpha[gi] = a; j[gi] = jj; }
+    return ALG_OK;
+}
+int orc_update_traj(alg_handle* h, int32_t target, int32_t source, const double* alpha) {
+    if (target < 0 || target > 1 || source < 0 || source > 1) return fail(ALG_ERR_ARG, "bad traj selector");
+    for (size_t gi = 0; gi < H->g.size(); gi++) { Game& g = H->g[gi]; update_traj(H->sh, g.z[target], g.z[source], alpha[gi], g.z[2]); }
+    return ALG_OK;
+}
+int orc_record_stats(alg_handle* h, alg_record* rec) {
+    for (size_t gi = 0; gi < H->g.size(); gi++) rec[gi] = record(H->sh, H->g[gi], 0.0, 0);
+    return ALG_OK;
+}
+int orc_reset_con(alg_handle* h) { for (Game& g : H->g) reset_con(H->sh, g); return ALG_OK; }
+int orc_dual_penalty_update(alg_handle* h, double* vals) {
+    const int L = H->sh.D.con_len;
+    for (size_t gi = 0; gi < H->g.size(); gi++) { Game& g = H->g[gi]; dual_penalty_update(H->sh, g); if (vals) std::copy(g.vals.begin(), g.vals.end(), vals + gi * L); }
+    return ALG_OK;
+}
+int orc_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, alg_step_info* info) {
+    const int B = (int)H->g.size();
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) { int ls = 0; double dl = 0; alg_step_info si = inner_iteration(H->sh, H->g[gi], ls, dl, k_outer, l_inner); if (info) info[gi] = si; }
+    return ALG_OK;
+}
+int orc_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats) {
+    const int B = (int)H->g.size();
+    if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "orc_newton_solve: x0 / LQR data not set");
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) { newton_solve(H->sh, H->g[gi], init != 0, (uint64_t)(game_id0 + gi)); if (stats) stats[gi] = H->g[gi].st; }
+    return ALG_OK;
+}
+int orc_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) { return orc_newton_solve(h, init, game_id0, nullptr); }
+int orc_get_stats(alg_handle* h, alg_game_stats* stats) { for (size_t gi = 0; gi < H->g.size(); gi++) stats[gi] = H->g[gi].st; return ALG_OK; }
+int orc_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out) {
+    if (game < 0 || game >= (int)H->g.size()) return fail(ALG_ERR_ARG, "bad game index");
+    const auto& hs = H->g[game].hist; int c = std::min<int>(max_records, (int)hs.size());
+    for (int i = 0; i < c; i++) out[i] = hs[i];
+    if (n_out) *n_out = c; return ALG_OK;
+}
+int orc_synchronize(alg_handle*) { return ALG_OK; }
+
+// ---- fine-grained pieces exposed for the known-answer tests (Appendix B) ----------------------
+int orc_kat_dynamics(const alg_desc* d, const double* x, const double* u, double* xdot, double* x_rk2, double* x_rk3, double* jac_rk2) {
+    Dims D; if (!D.init(*d)) return fail(ALG_ERR_ARG, "bad descriptor");
+    if (xdot) dynamics(D, x, u, xdot);
+    if (x_rk2) rk2(D, x, u, x_rk2);
+    if (x_rk3) rk3(D, x, u, x_rk3);
+    if (jac_rk2) rk2_jacobian(D, x, u, jac_rk2);
+    return ALG_OK;
+}
+// cost gradient/Hessian of player i at knot k (0-based) for state x / control u: q (n), r (mi), Q (n x n row-major)
+int orc_kat_cost(alg_handle* h, int32_t game, int32_t i, int32_t k, const double* x, const double* u, double* q, double* r, double* Qm) {
+    Game& g = H->g[game];
+    if (q) cost_grad_x(H->sh, g, i, k, x, q);
+    if (r) cost_grad_u(H->sh, g, i, u, r);
+    if (Qm) cost_hess_x(H->sh, g, i, k, x, Qm);
+    return ALG_OK;
+}
+// stage_cost of CollisionCost (objective.jl:122-126), for the 0.05 KAT
+double orc_kat_collision_cost(double mu, double r, const double* xi, const double* xj) {
+    double s = 0; for (int a = 0; a < 2; a++) s += (xi[a] - xj[a]) * (xi[a] - xj[a]);
+    double v = std::max(0.0, r - std::sqrt(s)); return 0.5 * mu * v * v;
+}
+int orc_kat_evaluate_con(alg_handle* h, double* vals) {
+    const int L = H->sh.D.con_len;
+    for (size_t gi = 0; gi < H->g.size(); gi++) { Game& g = H->g[gi]; evaluate_con(H->sh, g, g.z[0]); std::copy(g.vals.begin(), g.vals.end(), vals + gi * L); }
+    return ALG_OK;
+}
+double orc_kat_delta_step(alg_handle* h, int32_t game, double alpha) { return delta_step(H->sh, H->g[game].z[2], alpha); }
+double orc_counter_uniform(uint64_t seed, uint64_t game, uint64_t counter) { return counter_uniform(seed, game, counter); }
+// dense partial-pivot LU solve of the literal S x S system in the reference's own (vertical, horizontal)
+// ordering -- cross-check of the banded solver on small problems.  delta: S
+int orc_kat_dense_direction(alg_handle* h, int32_t game, double reg, double* delta) {
+    Game& g = H->g[game]; const int S = H->sh.D.S;
+    std::vector<double> A((size_t)S * S, 0.0), rhs(S);
+    residual(H->sh, g, g.z[0], 0.0, nullptr);
+    jacobian(H->sh, g, g.z[0], reg, [&](int r, int c, double v) { A[(size_t)r * S + c] += v; });
+    for (int r = 0; r < S; r++) rhs[r] = g.res[r];
+    for (int j = 0; j < S; j++) {
+        int pv = j; double best = std::fabs(A[(size_t)j * S + j]);
+        for (int r = j + 1; r < S; r++) { double v = std::fabs(A[(size_t)r * S + j]); if (v > best) { best = v; pv = r; } }
+        if (best == 0.0) return fail(ALG_ERR_STATE, "singular");
+        if (pv != j) { for (int c = 0; c < S; c++) std::swap(A[(size_t)j * S + c], A[(size_t)pv * S + c]); std::swap(rhs[j], rhs[pv]); }
+        for (int r = j + 1; r < S; r++) {
+            double f = A[(size_t)r * S + j] / A[(size_t)j * S + j];
+            if (f == 0.0) continue;
+            for (int c = j; c < S; c++) A[(size_t)r * S + c] -= f * A[(size_t)j * S + c];
+            rhs[r] -= f * rhs[j];
+        }
+    }
+    for (int j = S - 1; j >= 0; j--) { double s = rhs[j]; for (int c = j + 1; c < S; c++) s -= A[(size_t)j * S + c] * delta[c]; delta[j] = s / A[(size_t)j * S + j]; }
+    for (int j = 0; j < S; j++) delta[j] = -delta[j];
+    return ALG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,89 @@
+"""Python binding of the CPU oracle (oracle/lib/liboracle.so).  TEST INFRASTRUCTURE ONLY:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_here))
+import algames_jl_amd  # noqa: E402
+from algames_jl_amd._abi import CLib, Batch, alg_desc, _dptr, _f64, _P  # noqa: E402
+
+LIB_PATH = os.path.join(_here, "lib", "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_here, "algames_oracle.cpp")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _here, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = CLib(LIB_PATH, "orc_")
+        d = _lib.dll
+        d.orc_kat_dynamics.restype = C.c_int
+        d.orc_kat_dynamics.argtypes = [C.POINTER(alg_desc)] + [C.POINTER(C.c_double)] * 6
+        d.orc_kat_cost.restype = C.c_int
+        d.orc_kat_cost.argtypes = [_P, C.c_int32, C.c_int32, C.c_int32] + [C.POINTER(C.c_double)] * 5
+        d.orc_kat_collision_cost.restype = C.c_double
+        d.orc_kat_collision_cost.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        d.orc_kat_evaluate_con.restype = C.c_int
+        d.orc_kat_evaluate_con.argtypes = [_P, C.POINTER(C.c_double)]
+        d.orc_kat_delta_step.restype = C.c_double
+        d.orc_kat_delta_step.argtypes = [_P, C.c_int32, C.c_double]
+        d.orc_counter_uniform.restype = C.c_double
+        d.orc_counter_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        d.orc_kat_dense_direction.restype = C.c_int
+        d.orc_kat_dense_direction.argtypes = [_P, C.c_int32, C.c_double, C.POINTER(C.c_double)]
+    return _lib
+
+
+class OracleBatch(Batch):
+    def __init__(self, model, p, N, dt, batch, d=2):
+        super().__init__(lib(), model, p, N, dt, batch, d=d, device=0)
+
+    # fine-grained known-answer hooks ------------------------------------------------------------
+    def kat_dynamics(self, x, u):
+        x, u = _f64(x, (self.n,)), _f64(u, (self.m,))
+        xd, x2, x3 = np.empty(self.n), np.empty(self.n), np.empty(self.n)
+        J = np.empty((self.n, self.n + self.m))
+        self.lib.check(self.lib.dll.orc_kat_dynamics(C.byref(self.desc), _dptr(x), _dptr(u), _dptr(xd), _dptr(x2), _dptr(x3), _dptr(J)))
+        return xd, x2, x3, J
+
+    def kat_cost(self, i, k, x, u, game=0):
+        x, u = _f64(x, (self.n,)), _f64(u, (self.m,))
+        q, r, Q = np.empty(self.n), np.empty(self.mi), np.empty((self.n, self.n))
+        self.lib.check(self.lib.dll.orc_kat_cost(self.h, game, i, k, _dptr(x), _dptr(u), _dptr(q), _dptr(r), _dptr(Q)))
+        return q, r, Q
+
+    def kat_evaluate_con(self):
+        v = np.empty((self.B, self.con_len))
+        self.lib.check(self.lib.dll.orc_kat_evaluate_con(self.h, _dptr(v)))
+        return v
+
+    def kat_delta_step(self, alpha, game=0):
+        return self.lib.dll.orc_kat_delta_step(self.h, game, alpha)
+
+    def kat_dense_direction(self, reg, game=0):
+        d = np.empty(self.S)
+        self.lib.check(self.lib.dll.orc_kat_dense_direction(self.h, game, reg, _dptr(d)))
+        return d
+
+
+def collision_cost_value(mu, r, xi, xj):
+    return lib().dll.orc_kat_collision_cost(mu, r, _dptr(_f64(xi)), _dptr(_f64(xj)))
+
+
+def counter_uniform(seed, game, counter):
+    return lib().dll.orc_counter_uniform(seed, game, counter)

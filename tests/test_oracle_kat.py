@@ -1,0 +1,508 @@
+"""Pins the CPU oracle (and the host-side index logic) to every literal known-answer value the
+reference's own tests hold for the Newton / augmented-Lagrangian path.
+Each test cites the reference test file:line (relative to /root/reference) it restates.
+The reference itself (Julia) cannot run here, so these literals + the end-to-end thresholds of
+test/problem/solver_methods.jl are the pinning."""
+import numpy as np
+import pytest
+
+DI, UNI = 0, 1
+
+
+# ---------------------------------------------------------------- layout / indexing (host logic)
+def test_vertical_indices_literals(alg):
+    # test/core/newton_core.jl:4-16
+    model = alg.UnicycleGame(p=2)
+    ps = alg.ProblemSize(3, model)
+    n, mi = ps.n, ps.mi
+    v = alg.vertical_indices(ps)
+    assert v[alg.stampify("opt", 1, "x", 1, 2)] == list(range(1, n + 1))
+    assert v[alg.stampify("opt", 1, "u", 1, 1)] == [n + i for i in range(1, mi[0] + 1)]
+    assert v[alg.stampify("opt", 1, "x", 1, 3)] == [n + mi[0] + i for i in range(1, n + 1)]
+    assert v[alg.stampify("opt", 1, "u", 1, 2)] == [2 * n + mi[0] + i for i in range(1, mi[0] + 1)]
+    assert v[alg.stampify("opt", 2, "x", 1, 2)] == [2 * n + 2 * mi[0] + i for i in range(1, n + 1)]
+    # test/core/newton_core.jl:18-41: a permutation of 1:S
+    allinds = sorted(sum(v.values(), []))
+    assert allinds == list(range(1, ps.S + 1))
+    assert ps.S == ps.p * n * 2 + ps.m * 2 + n * 2
+
+
+def test_horizontal_indices_literals(alg):
+    # test/core/newton_core.jl:44-59
+    model = alg.UnicycleGame(p=2)
+    ps = alg.ProblemSize(3, model)
+    n, m, mi = ps.n, ps.m, ps.mi
+    h = alg.horizontal_indices(ps)
+    assert h[alg.stampify("x", 1, 2)] == list(range(1, n + 1))
+    assert h[alg.stampify("u", 1, 1)] == [n + i for i in range(1, mi[0] + 1)]
+    assert h[alg.stampify("u", 2, 1)] == [n + mi[0] + i for i in range(1, mi[1] + 1)]
+    assert h[alg.stampify("λ", 1, 1)] == [n + m + i for i in range(1, n + 1)]
+    assert h[alg.stampify("λ", 2, 1)] == [2 * n + m + i for i in range(1, n + 1)]
+    assert h[alg.stampify("x", 1, 3)] == [3 * n + m + i for i in range(1, n + 1)]
+    assert sorted(sum(h.values(), [])) == list(range(1, ps.S + 1))
+
+
+def test_stamp_validity_truth_table(alg):
+    # test/core/stamp.jl:8-104 (N=10, p=3)
+    N, p = 10, 3
+    V = lambda *a: alg.valid(alg.stampify(*a), N, p)
+    assert V("opt", 1, "x", 1, 5)
+    assert not V("opt", 4, "x", 1, 5)
+    assert not V("opt", 2, "u", 2, 10)
+    assert V("opt", 2, "u", 2, 9)
+    assert not V("opt", 2, "u", 3, 9)
+    assert not V("opt", 2, "z", 1, 1)
+    assert not V("dyn", 1, "u", 2, 1)
+    assert V("dyn", 1, "x", 1, 1)
+    assert not V("dyn", 2, "x", 1, 1)
+    assert not V("dyn", 2, "x", 2, 1)
+    assert V("opt", 2, "u", 2, 4)
+    assert V("u", 2, 3)
+    assert not V("u", 0, 3)
+    assert not V("u", 1, 100)
+    assert not V("x", 2, 2)
+    assert not V("x", 1, 1)
+    assert V("x", 1, 2)
+    assert V("λ", 1, 2)
+    assert not V("λ", 0, 2)
+    assert V("λ", 2, 4)
+    assert not V("λ", 2, 40)
+    assert V("opt", 1, "x", 1, 5, "x", 1, 3)
+    assert not V("opt", 1, "x", 1, 5, "u", 0, 3)
+    assert V("opt", 1, "x", 1, 5, "u", 3, 3)
+    assert V("opt", 1, "x", 1, 5, "u", 1, 3)
+    assert not V("opt", 1, "x", 1, 5, "λ", 3, 3)
+    assert V("opt", 1, "x", 1, 5, "λ", 1, 3)
+    assert V("dyn", 1, "x", 1, 5, "x", 1, 3)
+    assert V("dyn", 1, "x", 1, 5, "u", 2, 3)
+
+
+def test_model_index_sets(alg):
+    # test/dynamics/double_integrator.jl:3-18
+    m = alg.DoubleIntegratorGame(p=2, d=3)
+    assert (m.n, m.m, m.p) == (12, 6, 2)
+    assert m.ni == [6, 6] and m.mi == [3, 3]
+    assert m.pu == [[1, 3, 5], [2, 4, 6]]
+    assert m.px == [[1, 3], [2, 4]]
+    assert m.pz == [[1, 3, 5, 7, 9, 11], [2, 4, 6, 8, 10, 12]]
+    # test/dynamics/unicycle.jl:3-20
+    u = alg.UnicycleGame(p=3)
+    assert (u.n, u.m, u.p) == (12, 6, 3)
+    assert u.pu == [[1, 4], [2, 5], [3, 6]]
+    assert u.px == [[1, 4], [2, 5], [3, 6]]
+    assert u.pz == [[1, 4, 7, 10], [2, 5, 8, 11], [3, 6, 9, 12]]
+    # ProblemSize.S, src/struct/problem_size.jl:22
+    assert alg.ProblemSize(40, alg.DoubleIntegratorGame(p=3)).S == 2106
+    assert alg.ProblemSize(50, alg.UnicycleGame(p=4)).S == 4312
+
+
+def test_oracle_layout_matches_reference_indices(alg, orc):
+    """The oracle's flat layouts ARE the reference's vertical / horizontal orders: plant one value per
+    block through split/join and recover it at the literal offsets of newton_core.jl."""
+    model = alg.UnicycleGame(p=3)
+    N = 10
+    ps = alg.ProblemSize(N, model)
+    b = orc.OracleBatch(UNI, 3, N, 0.1, 1)
+    h = alg.horizontal_indices(ps)
+    rng = np.random.default_rng(0)
+    dtraj = rng.random(ps.S)
+    z = np.concatenate([np.zeros(ps.n), dtraj])[None]
+    X, U, L = b.split_traj(z)
+    # test/struct/primal_dual_traj.jl:48-63 (set_traj!)
+    ix = lambda s: np.array(h[s]) - 1
+    assert np.array_equal(X[0, 1], dtraj[ix(alg.stampify("x", 1, 2))])
+    assert np.array_equal(X[0, N - 1], dtraj[ix(alg.stampify("x", 1, N))])
+    for (i, k) in [(1, 1), (2, 1), (1, 2), (2, 2), (3, 2), (1, N - 1)]:
+        assert np.array_equal(U[0, k - 1][np.array(model.pu[i - 1]) - 1], dtraj[ix(alg.stampify("u", i, k))])
+    assert np.array_equal(L[0, 0, 0], dtraj[ix(alg.stampify("λ", 1, 1))])
+    assert np.array_equal(L[0, 0, N - 2], dtraj[ix(alg.stampify("λ", 1, N - 1))])
+    assert np.array_equal(L[0, 2, N - 2], dtraj[ix(alg.stampify("λ", 3, N - 1))])
+    # test/struct/primal_dual_traj.jl:65-84 (get_traj! round trip, exact)
+    assert np.array_equal(b.join_traj(X, U, L), z)
+    b.set_traj(z); assert np.array_equal(b.get_traj(), z)
+
+
+def test_update_traj_and_delta_step(orc):
+    # test/struct/primal_dual_traj.jl:86-107: 10 + 0.5*100 = 60 everywhere, x_1 untouched
+    b = orc.OracleBatch(UNI, 3, 10, 0.1, 1)
+    x0 = np.random.default_rng(1).random(b.n)
+    src = np.full((1, b.traj_len), 10.0); src[0, :b.n] = x0
+    dlt = np.full((1, b.traj_len), 100.0); dlt[0, :b.n] = 0
+    tgt = np.zeros((1, b.traj_len)); tgt[0, :b.n] = x0
+    b.set_traj(src, 0); b.set_traj(tgt, 1); b.set_traj(dlt, 2)
+    b.update_traj(0.5, target=1, source=0)
+    out = b.get_traj(1)
+    assert np.array_equal(out[0, :b.n], x0)
+    assert np.all(out[0, b.n:] == 60.0)
+    # test/struct/primal_dual_traj.jl:109-123: Δ_step == 10*α (duals ignored)
+    ten = np.full((1, b.traj_len), 10.0)
+    b.set_traj(ten, 2)
+    assert b.kat_delta_step(0.5) == 10.0 * 0.5
+
+
+# ---------------------------------------------------------------- dynamics
+def test_dynamics_and_rk2(orc):
+    rng = np.random.default_rng(2)
+    # src/dynamics/double_integrator.jl:27-31 ; test/problem/local_quantities.jl:4-14 (RK2 within 1e-3 of Euler at dt=0.01)
+    b = orc.OracleBatch(DI, 3, 10, 0.01, 1)
+    x, u = rng.random(b.n), rng.random(b.m)
+    xd, x2, x3, J = b.kat_dynamics(x, u)
+    assert np.array_equal(xd, np.concatenate([x[b.m:], u]))
+    assert np.abs(x2 - (x + 0.01 * xd)).sum() < 1e-3
+    # exact DI maps: A = [[I, dt I],[0, I]], B = [[dt^2/2 I],[dt I]]; RK3 gives the same map
+    dt, m = 0.01, b.m
+    A = np.block([[np.eye(m), dt * np.eye(m)], [np.zeros((m, m)), np.eye(m)]])
+    Bm = np.vstack([dt * dt / 2 * np.eye(m), dt * np.eye(m)])
+    assert np.allclose(J, np.hstack([A, Bm]), atol=1e-15)
+    assert np.allclose(x2, A @ x + Bm @ u, atol=1e-15) and np.allclose(x3, x2, atol=1e-15)
+    # src/dynamics/unicycle.jl:27-32
+    b = orc.OracleBatch(UNI, 3, 10, 0.2, 1)
+    x, u = rng.random(b.n), rng.random(b.m)
+    xd, x2, x3, J = b.kat_dynamics(x, u)
+    p = 3
+    ref = np.concatenate([np.cos(x[6:9]) * x[9:12], np.sin(x[6:9]) * x[9:12], u])
+    assert np.allclose(xd, ref, atol=1e-16)
+    # test/problem/local_quantities.jl:24-57: discrete_jacobian!(RK2) == derivative of discrete_dynamics(RK2)
+    Jfd = np.zeros_like(J); eps = 1e-6
+    for c in range(b.n + b.m):
+        zp = np.concatenate([x, u]); zm = zp.copy(); zp[c] += eps; zm[c] -= eps
+        Jfd[:, c] = (b.kat_dynamics(zp[:b.n], zp[b.n:])[1] - b.kat_dynamics(zm[:b.n], zm[b.n:])[1]) / (2 * eps)
+    assert np.abs(J - Jfd).sum() < 1e-7
+    # RK3 formula (RobotDynamics 0.3.1) restated independently
+    f = lambda xx: np.concatenate([np.cos(xx[6:9]) * xx[9:12], np.sin(xx[6:9]) * xx[9:12], u])
+    k1 = 0.2 * f(x); k2 = 0.2 * f(x + k1 / 2); k3 = 0.2 * f(x - k1 + 2 * k2)
+    assert np.allclose(x3, x + (k1 + 4 * k2 + k3) / 6, atol=1e-15)
+    assert np.allclose(x2, x + 0.2 * f(x + 0.1 * f(x)), atol=1e-15)
+
+
+# ---------------------------------------------------------------- objective
+def test_lqr_gradient_hessian_scaling(orc):
+    # test/objective/objective.jl:11-64: zero cost at (xf, uf) through the pz/pu padding; q=(Qx+q)dt,
+    # r=(Ru+r)dt for stage knots, terminal unscaled, r_N = 0, Q dt / Q
+    rng = np.random.default_rng(3)
+    N, dt, p = 10, 0.1, 3
+    b = orc.OracleBatch(UNI, p, N, dt, 1)
+    Q, R = rng.random((p, 4)), rng.random((p, 2))
+    xf = np.array([[i] * 4 for i in (1, 2, 3)], float); uf = np.array([[2 * i] * 2 for i in (1, 2, 3)], float)
+    b.set_lqr(Q, R, xf, uf)
+    X = np.array([1, 2, 3] * 4, float); U = np.array([2, 4, 6] * 2, float)
+    for i in range(p):
+        q, r, _ = b.kat_cost(i, 0, X, U)
+        assert np.abs(q).max() <= 1e-10 and np.abs(r).max() <= 1e-10
+    x, u = 10 * rng.random(b.n), 10 * rng.random(b.m)
+    Qfull = np.zeros(b.n); Qfull[[0, 3, 6, 9]] = Q[0]; xff = np.zeros(b.n); xff[[0, 3, 6, 9]] = xf[0]
+    q, r, Qm = b.kat_cost(0, 0, x, u)
+    assert np.abs(q - Qfull * (x - xff) * dt).sum() < 1e-10
+    assert np.abs(r - R[0] * (u[[0, 3]] - uf[0]) * dt).sum() < 1e-10
+    assert np.abs(Qm - np.diag(Qfull) * dt).sum() < 1e-10
+    q, r, Qm = b.kat_cost(0, N - 1, x, u)
+    assert np.abs(q - Qfull * (x - xff)).sum() < 1e-10
+    assert np.abs(Qm - np.diag(Qfull)).sum() < 1e-10
+
+
+def test_collision_cost_value_gradient_hessian(orc):
+    # test/objective/objective.jl:108-147: x=[1,1.1,2,2,0,0,0,0], μ=10, r=0.2 -> 0.05
+    x = np.array([1.0, 1.1, 2.0, 2.0, 0, 0, 0, 0])
+    assert abs(orc.collision_cost_value(10.0, 0.2, x[[0, 2]], x[[1, 3]]) - 0.05) < 1e-10
+    # test/objective/objective.jl:155-200: gradient/Hessian vs derivatives of stage_cost (active and inactive)
+    rng = np.random.default_rng(4)
+    dt = 0.1
+    for rad, tolg in ((1e3, 1e-7), (1e-3, 1e-7)):
+        b = orc.OracleBatch(DI, 2, 10, dt, 1)
+        b.set_lqr(np.zeros((2, 4)), np.zeros((2, 2)), np.zeros((2, 4)), np.zeros((2, 2)))
+        b.add_collision_cost([rad, rad], [10.0, 10.0])
+        x, u = rng.random(b.n), rng.random(b.m)
+        val = lambda xx: orc.collision_cost_value(10.0, rad, xx[[0, 2]], xx[[1, 3]])
+        q, r, Qm = b.kat_cost(0, b.N - 1, x, u)       # terminal knot: unscaled
+        g = np.zeros(b.n); Hfd = np.zeros((b.n, b.n)); e = 1e-5
+        for c in range(b.n):
+            xp, xm = x.copy(), x.copy(); xp[c] += e; xm[c] -= e
+            g[c] = (val(xp) - val(xm)) / (2 * e)
+            Hfd[:, c] = (b.kat_cost(0, b.N - 1, xp, u)[0] - b.kat_cost(0, b.N - 1, xm, u)[0]) / (2 * e)
+        assert np.abs(q - g).sum() / max(np.abs(q).sum(), 1e-300) < 1e-6 or np.abs(q - g).sum() < tolg
+        assert np.abs(Qm - Hfd).sum() < 1e-2
+        assert np.all(r == 0)
+        qs = b.kat_cost(0, 0, x, u)[0]                # stage knot: scaled by dt
+        assert np.allclose(qs, q * dt, rtol=1e-15, atol=0)
+
+
+# ---------------------------------------------------------------- constraints
+def test_control_bound_evaluate_literal(orc):
+    # test/constraints/control_bound_constraint.jl:3-15
+    b = orc.OracleBatch(DI, 3, 5, 0.1, 1)      # m = 6
+    U = np.array([13.0, 1.0, -12.0, 1.0, 2.0, 30.0])
+    u_max = np.array([np.inf, np.inf, -11.0, 15.0, 2.0, 30.0])
+    u_min = np.array([-np.inf, -10.0, -np.inf, 1.0, -2.0, -30.0])
+    b.add_control_bound(u_max, u_min)
+    X, _, L = b.split_traj(b.get_traj())
+    b.set_traj(b.join_traj(X, np.broadcast_to(U, (1, 4, 6)).copy(), L))
+    vals = b.kat_evaluate_con()[0]
+    ctl = vals[b.p * (b.p - 1) * (b.N - 1):].reshape(b.N - 1, 12)
+    finite = ctl[0][np.isfinite(ctl[0])]
+    assert np.array_equal(finite, np.array([-1.0, -14.0, 0.0, 0.0, -11.0, 0.0, -4.0, -60.0]))
+    with pytest.raises(Exception):              # checkBounds, control_bound_constraint.jl:69-75
+        b.add_control_bound(np.zeros(6), np.ones(6))
+
+
+def test_al_expansion_formula(orc):
+    # test/constraints/constraint_derivatives.jl:3-34: vals = [-0.9; -1.1], grad = C'λ + C' Iρ c,
+    # hess = C' Iρ C with Iρ = diag((c>=0)|(λ>0)) μ
+    N, p = 10, 3
+    b = orc.OracleBatch(UNI, p, N, 0.1, 1)
+    b.set_lqr(np.zeros((p, 4)), np.zeros((p, 2)), np.zeros((p, 4)), np.zeros((p, 2)))
+    b.add_control_bound(np.ones(b.m), -np.ones(b.m))
+    z = np.full((1, b.traj_len), 0.1)
+    X, U, L = b.split_traj(z)
+    b.set_traj(b.join_traj(X, U, np.zeros_like(L)))      # duals 0 so only the constraint term is in opt_u rows
+    lam = np.zeros((1, b.con_len)); mu = np.full((1, b.con_len), 1.0)
+    off = p * (p - 1) * (N - 1)
+    lamc = lam[0, off:].reshape(N - 1, 2 * b.m)
+    for k in range(N - 2):
+        lamc[k] = k + 1
+    b.set_con_duals(lam, mu)
+    vals = b.kat_evaluate_con()[0, off:].reshape(N - 1, 2 * b.m)
+    assert np.allclose(vals[0], np.r_[-0.9 * np.ones(b.m), -1.1 * np.ones(b.m)], atol=1e-16)
+    assert np.allclose(vals[-1], np.r_[-0.9 * np.ones(b.m), -1.1 * np.ones(b.m)], atol=1e-16)
+    res = b.residual()[0][0]
+    J = b.residual_jacobian()[0]
+    C = np.vstack([np.eye(b.m), -np.eye(b.m)])
+    for k in (0, N - 2):
+        Irho = np.diag(((vals[k] >= 0) | (lamc[k] > 0)) * 1.0)
+        grad = C.T @ lamc[k] + C.T @ Irho @ vals[k]
+        hess = C.T @ Irho @ C
+        for i in range(p):
+            rows = i * (N - 1) * (b.n + 2) + k * (b.n + 2) + b.n + np.arange(2)
+            pu = np.array([i, i + p])
+            assert np.allclose(res[rows], grad[pu], atol=1e-15)
+            cols = k * b.b + b.n + i * 2 + np.arange(2)
+            assert np.allclose(J[np.ix_(rows, cols)], hess[np.ix_(pu, pu)], atol=1e-15)
+
+
+def test_penalty_schedule_and_dual_update(orc):
+    # test/constraints/constraints_methods.jl:135-229
+    N, p = 20, 3
+    b = orc.OracleBatch(DI, p, N, 0.1, 1)
+    b.set_lqr(np.zeros((p, 4)), np.zeros((p, 2)), np.zeros((p, 4)), np.zeros((p, 2)))
+    b.add_control_bound(10 * np.ones(b.m), -10 * np.ones(b.m))
+    b.set_options(rho_0=1e-3, rho_increase=1e1, rho_max=1e-1, lambda_max=1e1)
+    off = p * (p - 1) * (N - 1)
+    b.reset_con()
+    assert np.all(b.get_con_duals()[1][0, off:] == 1e-3)
+    b.dual_penalty_update(); assert np.allclose(b.get_con_duals()[1][0, off:], 1e-2, rtol=1e-15)
+    b.dual_penalty_update(); assert np.allclose(b.get_con_duals()[1][0, off:], 1e-1, rtol=1e-15)
+    for _ in range(4):
+        b.dual_penalty_update()
+    assert np.all(b.get_con_duals()[1][0, off:] == 1e-1)          # capped at μ_max
+    b.reset_con()
+    lam, mu = b.get_con_duals()
+    assert np.all(mu[0, off:] == 1e-3) and np.all(lam == 0)
+    # dual update at the zero trajectory: c < 0 -> λ stays 0 (:203-205)
+    b.set_traj(np.zeros((1, b.traj_len)))
+    b.dual_penalty_update()
+    assert np.all(b.get_con_duals()[0] == 0)
+    # all-100 trajectory: vals = [90; -110], λ = 1e-3 [90; 0] (:207-212)
+    b.reset_con()
+    b.set_traj(np.full((1, b.traj_len), 1e2))
+    vals = b.dual_penalty_update()[0, off:].reshape(N - 1, 2 * b.m)
+    assert np.array_equal(vals[0], np.r_[90 * np.ones(b.m), -110 * np.ones(b.m)])
+    lam = b.get_con_duals()[0][0, off:].reshape(N - 1, 2 * b.m)
+    assert np.allclose(lam[0], 1e-3 * np.r_[90 * np.ones(b.m), np.zeros(b.m)], rtol=1e-15)
+    # all-1e5 trajectory: clamp to λ_max = 10 (:214-219)
+    b.reset_con()
+    b.set_traj(np.full((1, b.traj_len), 1e5))
+    vals = b.dual_penalty_update()[0, off:].reshape(N - 1, 2 * b.m)
+    assert np.array_equal(vals[0], np.r_[(1e5 - 10) * np.ones(b.m), -(1e5 + 10) * np.ones(b.m)])
+    lam = b.get_con_duals()[0][0, off:].reshape(N - 1, 2 * b.m)
+    assert np.array_equal(lam[0], np.r_[10.0 * np.ones(b.m), np.zeros(b.m)])
+    b.reset_con()
+    assert np.all(b.get_con_duals()[0] == 0)
+
+
+def test_violations(orc):
+    # test/struct/violations.jl:3-33: zero trajectory -> zero dynamics violation; control violation 0.9
+    N, p = 10, 3
+    b = orc.OracleBatch(UNI, p, N, 0.1, 1)
+    b.set_lqr(np.zeros((p, 4)), np.zeros((p, 2)), np.zeros((p, 4)), np.zeros((p, 2)))
+    b.set_traj(np.zeros((1, b.traj_len)))
+    assert b.record()["dyn_vio"][0] == 0.0
+    b.add_control_bound(0.1 * np.ones(b.m), -0.1 * np.ones(b.m))
+    z = np.ones((1, b.traj_len)); z[0, :b.n] = 0
+    b.set_traj(z)
+    rec = b.record()
+    assert rec["con_vio"][0] == 0.9
+    # dynamics violation == max |RK2(z_1) - x_2| (violations.jl:18-26)
+    X, U, L = b.split_traj(z)
+    x2 = b.kat_dynamics(X[0, 0], U[0, 0])[1]
+    viol = max(np.abs(b.kat_dynamics(X[0, k], U[0, k])[1] - X[0, k + 1]).max() for k in range(N - 1))
+    assert abs(rec["dyn_vio"][0] - viol) < 1e-15
+    # optimality violation = max |res| over the opt rows (violations.jl:153-168; test :62-68)
+    res = b.residual()[0][0]
+    nopt = p * (N - 1) * (b.n + 2)
+    assert rec["opt_vio"][0] == np.abs(res[:nopt]).max()
+    assert abs(rec["res"][0] - np.abs(res).sum() / b.S) < 1e-15
+
+
+def test_collision_avoidance_constraint_terms(orc):
+    """CollisionConstraint (TrajectoryOptimization 0.4.1; formula restated, parity unpinned):
+    consistency of value / AL gradient / Gauss-Newton Hessian through finite differences."""
+    N, p = 6, 3
+    b = orc.OracleBatch(DI, p, N, 0.1, 1)
+    b.set_lqr(np.zeros((p, 4)), np.zeros((p, 2)), np.zeros((p, 4)), np.zeros((p, 2)))
+    b.add_collision_avoidance([0.6, 0.7, 0.8])
+    rng = np.random.default_rng(5)
+    z = rng.random((1, b.traj_len))
+    X, U, L = b.split_traj(z)
+    z = b.join_traj(X, U, np.zeros_like(L)); b.set_traj(z)
+    vals = b.kat_evaluate_con()[0][:p * (p - 1) * (N - 1)].reshape(p * (p - 1), N - 1)
+    q = 0
+    for i in range(p):
+        for j in range(p):
+            if j == i:
+                continue
+            R = [0.6, 0.7, 0.8][i] + [0.6, 0.7, 0.8][j]
+            for k in range(1, N):
+                dl = X[0, k][[i, i + p]] - X[0, k][[j, j + p]]
+                assert abs(vals[q, k - 1] - (R * R - dl @ dl)) < 1e-15
+            q += 1
+    # AL term: opt_i,x rows = d/dx [ λ c + 1/2 μ a c^2 ] with a frozen; check against FD of that scalar
+    lam = rng.random((1, b.con_len)); mu = 3.0 * np.ones((1, b.con_len))
+    b.set_con_duals(lam, mu)
+    res0 = b.residual()[0][0]
+    # residual of pure-constraint problem in row block opt_1,x_2 equals gradient of player-1 penalty at knot 2
+    def pen(xk, i, k):
+        s = 0.0
+        for j in range(p):
+            if j == i:
+                continue
+            qq = i * (p - 1) + (j if j < i else j - 1)
+            R = [0.6, 0.7, 0.8][i] + [0.6, 0.7, 0.8][j]
+            dl = xk[[i, i + p]] - xk[[j, j + p]]
+            c = R * R - dl @ dl
+            lm = lam[0, qq * (N - 1) + (k - 1)]
+            a = 1.0 if (c >= 0 or lm > 0) else 0.0
+            s += lm * c + 0.5 * 3.0 * a * c * c
+        return s
+    for i in range(p):
+        for k in (1, N - 1):
+            g = np.zeros(b.n); e = 1e-6
+            for c in range(b.n):
+                xp, xm = X[0, k].copy(), X[0, k].copy(); xp[c] += e; xm[c] -= e
+                g[c] = (pen(xp, i, k) - pen(xm, i, k)) / (2 * e)
+            rows = i * (N - 1) * (b.n + 2) + (k - 1) * (b.n + 2) + np.arange(b.n)
+            assert np.allclose(res0[rows], g, atol=1e-6)
+
+
+# ---------------------------------------------------------------- linear algebra of the oracle itself
+@pytest.mark.parametrize("model,p,N", [(DI, 2, 8), (UNI, 2, 6), (UNI, 3, 5)])
+def test_banded_lu_equals_dense_lu_in_reference_order(orc, model, p, N):
+    """Δtraj from the banded partial-pivot LU == dense partial-pivot LU of the literal S x S matrix in
+    the reference's own (vertical, horizontal) order, and J Δ = -res."""
+    b = orc.OracleBatch(model, p, N, 0.1, 1)
+    rng = np.random.default_rng(6)
+    ni = b.n // p
+    b.set_lqr(1 + rng.random((p, ni)), 0.5 + rng.random((p, b.mi)), rng.random((p, ni)), rng.random((p, b.mi)))
+    b.set_x0(rng.random(b.n))
+    b.add_collision_cost(np.full(p, 3.0), np.full(p, 2.0))
+    b.add_collision_avoidance(np.full(p, 0.4))
+    b.add_control_bound(np.full(b.m, 0.5), np.full(b.m, -0.5))
+    z = rng.random((1, b.traj_len)); b.set_traj(z)
+    b.set_con_duals(rng.random((1, b.con_len)), 2.0 * np.ones((1, b.con_len)))
+    reg = 1e-3
+    d_band, st = b.newton_direction(reg)
+    assert st[0] == 0
+    d_dense = b.kat_dense_direction(reg)
+    assert np.allclose(d_band[0], d_dense, rtol=1e-9, atol=1e-10)
+    J = b.residual_jacobian(reg)[0]
+    res = b.residual()[0][0]
+    assert np.abs(J @ d_band[0] + res).max() < 1e-9 * max(1.0, np.abs(res).max())
+
+
+def test_jacobian_is_derivative_of_residual_for_linear_dynamics(orc):
+    """For the double integrator without collision terms the Gauss-Newton Jacobian is exact:
+    finite differences of residual! reproduce residual_jacobian! (structure + ordering check)."""
+    p, N = 2, 5
+    b = orc.OracleBatch(DI, p, N, 0.1, 1)
+    rng = np.random.default_rng(7)
+    b.set_lqr(1 + rng.random((p, 4)), 0.5 + rng.random((p, 2)), rng.random((p, 4)), rng.random((p, 2)))
+    x0 = rng.random(b.n); b.set_x0(x0)
+    z = rng.random((1, b.traj_len)); z[0, :b.n] = x0; b.set_traj(z)
+    J = b.residual_jacobian(0.0)[0]
+    r0 = b.residual()[0][0]
+    Jfd = np.zeros_like(J); e = 1e-6
+    for c in range(b.S):
+        zp = z.copy(); zp[0, b.n + c] += e; b.set_traj(zp)
+        Jfd[:, c] = (b.residual()[0][0] - r0) / e
+    assert np.abs(J - Jfd).max() < 1e-6
+
+
+# ---------------------------------------------------------------- end-to-end (test/problem/solver_methods.jl)
+def _problem(alg, orc, model, x0, opts, constrained=False):
+    N, dt, p = 20, 0.1, model.p
+    Q = [np.ones(model.ni[i]) for i in range(p)]
+    R = [0.5 * np.ones(model.mi[i]) for i in range(p)]
+    xf = [np.zeros(model.ni[i]) for i in range(p)]
+    uf = [-np.ones(model.mi[i]) for i in range(p)]
+    game_obj = alg.GameObjective(Q, R, xf, uf, N, model)
+    game_con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    if constrained:
+        alg.add_collision_avoidance(game_con, 0.05)
+        alg.add_control_bound(game_con, np.ones(model.m), -np.ones(model.m))
+    return alg.GameProblem(N, dt, x0, model, opts, game_obj, game_con, backend=orc.lib())
+
+
+def _check(alg, prob, tol):
+    res = alg.residual(prob)
+    assert np.abs(res).sum() / res.shape[1] < tol
+    assert alg.dynamics_violation(prob)[0] < tol
+
+
+def test_e2e_linear_one_player_one_newton_step(alg, orc):
+    # test/problem/solver_methods.jl:6-34
+    opts = alg.Options(inner_print=False, outer_print=False)
+    prob = _problem(alg, orc, alg.DoubleIntegratorGame(p=1), [1.0, 1.0, 0.0, 0.9], opts)
+    opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = 1, 1, 25, 1e-7, 1e-10, 1e-10
+    alg.newton_solve(prob)
+    _check(alg, prob, 1e-6)
+    assert prob.stats.summary["newton_iters"][0] == 1
+
+
+def test_e2e_unicycle_one_player(alg, orc):
+    # test/problem/solver_methods.jl:36-65
+    opts = alg.Options(inner_print=False, outer_print=False)
+    prob = _problem(alg, orc, alg.UnicycleGame(p=1), [1.0, 1.0, 0.0, 0.9], opts)
+    opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = 7, 20, 25, 1e-7, 1e-10, 1e-10
+    alg.newton_solve(prob)
+    _check(alg, prob, 1e-6)
+
+
+def test_e2e_linear_two_players_one_newton_step(alg, orc):
+    # test/problem/solver_methods.jl:68-97  (BASELINE config C1)
+    opts = alg.Options(inner_print=False, outer_print=False)
+    prob = _problem(alg, orc, alg.DoubleIntegratorGame(p=2), [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9], opts)
+    opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = 1, 1, 25, 1e-7, 1e-10, 1e-10
+    alg.newton_solve(prob)
+    _check(alg, prob, 1e-6)
+
+
+def test_e2e_unicycle_two_players(alg, orc):
+    # test/problem/solver_methods.jl:100-129
+    opts = alg.Options(inner_print=False, outer_print=False)
+    prob = _problem(alg, orc, alg.UnicycleGame(p=2), [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9], opts)
+    opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = 7, 20, 25, 1e-7, 1e-10, 1e-10
+    alg.newton_solve(prob)
+    _check(alg, prob, 1e-6)
+
+
+def test_e2e_unicycle_two_players_constrained(alg, orc):
+    # test/problem/solver_methods.jl:132-182 with its *effective* options (SURVEY.md section 4 warning: the problem is
+    # built with the previous block's opts object).  The circle constraints of :156-160 are outside the
+    # hot-path scope and are omitted.
+    opts = alg.Options(inner_print=False, outer_print=False)
+    opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = 7, 20, 25, 1e-7, 1e-10, 1e-10
+    prob = _problem(alg, orc, alg.UnicycleGame(p=2), [1.0, 2.0, 1.1, 2.0, 0.0, 0.0, 0.9, 0.9], opts, constrained=True)
+    alg.newton_solve(prob)
+    last = prob.stats.summary["last"][0]
+    res = alg.residual(prob)
+    assert np.abs(res).sum() / res.shape[1] < 1e-3
+    for f in ("dyn_vio", "sta_vio", "con_vio", "opt_vio"):
+        assert last[f] < 1e-3, (f, last[f])

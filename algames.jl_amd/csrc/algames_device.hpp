@@ -1,0 +1,972 @@
+// algames_device.hpp -- gfx950 device code of the batched ALGAMES Newton / augmented-Lagrangian path.
+//
+// Execution model: ONE GAME PER WAVEFRONT (workgroup = 64 threads = 1 wave).  Games are independent
+// (SURVEY.md 8(e)), so every wave runs its own solver state machine; no inter-workgroup traffic.
+//
+//  * streaming phases (residual / statistics / line-search trials / updates): lane k owns time step k
+//    ("lane-per-knot"), everything in registers, wave shuffles for the ||.||_1 / max reductions.
+//  * Newton direction: the KKT system of solver_methods.jl:87 is never materialised.  Its
+//    block-tridiagonal structure is eliminated by a structured block LU in the order
+//    (u_k via R^, lambda_k via -I, x_{k+1} via an m x m pivoted solve) -- a game-theoretic Riccati
+//    sweep: backward over k with per-player value matrices P_i (n x n) in LDS, a partial-pivot
+//    Gauss-Jordan of the m x m control system, feedback gains spilled to HBM (m*(n+1) doubles per
+//    step instead of the b^2 + b*p*n of a dense block LU), forward sweep for (dx, du), backward
+//    costate sweep for dlambda.
+//
+// Reference citations are relative to /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/algames_hip.h"
+
+namespace alg {
+
+constexpr int WAVE = 64;
+constexpr int MAXP = 10;    // alphax_dual caps p <= 10 (options.jl:68)
+constexpr int MAXM = 32;
+constexpr int HIST_MAX = 192;
+
+// Everything that is shared by the games of a handle; passed to kernels by value.
+struct Params {
+    int model, p, d, N, n, m, mi, ni, S, b, traj_len, npair, col_len, ctl_len, con_len, B;
+    double dt;
+    alg_options opt;
+    int has_colcost, has_colavoid, has_ctl, lqr_per_game;
+    double cc_radius[MAXP], cc_mu[MAXP], ca_radius[MAXP];
+    double umax[MAXM], umin[MAXM];
+    int hist_max;
+    int kscratch_len;       // per game doubles of gain scratch
+};
+
+// Device pointers of a handle (all game-major).
+struct Buffers {
+    double* traj[3];        // B x traj_len : pdtraj, trial, delta
+    double* x0;             // B x n
+    double* Qd; double* Rd; double* xf; double* uf;   // [B|1] x p x ni / mi (compact, own indices)
+    double* lam; double* mu; double* vals;            // B x con_len
+    double* res;            // B x S     residual scratch (vertical order)
+    double* kgain;          // B x kscratch_len
+    alg_game_stats* stats;  // B
+    alg_record* hist;       // B x hist_max
+};
+
+template <int MODEL_, int P_, int D_>
+struct Cfg {
+    static constexpr int MODEL = MODEL_, P = P_, D = D_;
+    static constexpr int n = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 * D_ * P_ : 4 * P_;
+    static constexpr int m = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? D_ * P_ : 2 * P_;
+    static constexpr int mi = m / P_;
+    static constexpr int ni = n / P_;
+    static constexpr int b = n + m + P_ * n;
+    static constexpr int NPAIR = P_ * (P_ - 1);
+    static constexpr int NC = 4 * P_;            // Jacobian coefficients per knot
+    static constexpr int WC = m + n + 1;         // augmented width of the control system
+};
+
+// ---- index maps (newton_core.jl:40-89), 0-based --------------------------------------------------
+template <class C> __device__ __forceinline__ int hx(int k) { return k * C::b; }
+template <class C> __device__ __forceinline__ int hu(int k, int i) { return k * C::b + C::n + i * C::mi; }
+template <class C> __device__ __forceinline__ int hl(int k, int i) { return k * C::b + C::n + C::m + i * C::n; }
+template <class C> __device__ __forceinline__ int vx(int N, int i, int k) { return i * (N - 1) * (C::n + C::mi) + k * (C::n + C::mi); }
+template <class C> __device__ __forceinline__ int vu(int N, int i, int k) { return vx<C>(N, i, k) + C::n; }
+template <class C> __device__ __forceinline__ int vd(int N, int k) { return C::P * (N - 1) * (C::n + C::mi) + k * C::n; }
+// joint control index c -> offset inside the u block of the horizontal order (player-grouped)
+template <class C> __device__ __forceinline__ int uoff(int c) { return (c % C::P) * C::mi + c / C::P; }
+template <class C> __device__ __forceinline__ int pairq(int i, int j) { return i * (C::P - 1) + (j < i ? j : j - 1); }
+template <class C> __device__ __forceinline__ int con_col(int N, int q, int k /*knot 1..N-1*/) { return q * (N - 1) + (k - 1); }
+template <class C> __device__ __forceinline__ int con_ctl(const Params& pr, int k, int row) { return pr.col_len + k * 2 * C::m + row; }
+
+// state of knot k (0-based) inside a traj buffer
+template <class C> __device__ __forceinline__ const double* zstate(const double* z, int k) { return k == 0 ? z : z + C::n + hx<C>(k - 1); }
+
+// ---- wave reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// fmax drops NaNs; carry a separate finite flag where NaN detection matters
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+
+// ---- counter RNG shared bit-for-bit with the oracle ------------------------------
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline double counter_uniform(uint64_t seed, uint64_t game, uint64_t counter) {
+    uint64_t h = splitmix64(seed ^ splitmix64(game * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull));
+    h = splitmix64(h + counter * 0x9E3779B97F4A7C15ull);
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ================================================================================================
+// Models.  Both in-scope models are player-decoupled: player i owns state entries pz(i,j)=i+j*P and
+// control entries pu(i,j)=i+j*P (double_integrator.jl:18-20, unicycle.jl:18-20).  The RK2 (explicit
+// midpoint) Jacobian [A B] (local_quantities.jl:20-27) is I + a handful of entries per player; those
+// entries are the "Jacobian coefficients" coef[4*P]:
+//   unicycle (state [x(P) y(P) th(P) v(P)], control [om(P) a(P)]), with thm = th + dt/2 om, vm = v + dt/2 a:
+//     coef[0*P+i] = d x+/d th = -dt vm sin thm      coef[1*P+i] = d x+/d v = dt cos thm
+//     coef[2*P+i] = d y+/d th =  dt vm cos thm      coef[3*P+i] = d y+/d v = dt sin thm
+//     d x+/d om = dt/2 coef0, d x+/d a = dt/2 coef1, d y+/d om = dt/2 coef2, d y+/d a = dt/2 coef3,
+//     d th+/d om = dt, d v+/d a = dt
+//   double integrator: A = [[I, dt I],[0, I]], B = [[dt^2/2 I],[dt I]] (no state dependence; coef unused)
+// ================================================================================================
+template <class C>
+__device__ __forceinline__ void model_player(int i, const double* x, const double* u, double dt,
+                                             double* xn /*ni: entries pz(i,j)*/, double* coef /*4: entries j*P+i*/) {
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+#pragma unroll
+        for (int j = 0; j < C::D; j++) {
+            const int ip = i + j * C::P, iv = C::m + i + j * C::P;
+            // k1 = f(x,u) dt ; xm = x + k1/2 ; k2 = f(xm,u) dt ; x + k2   (RobotDynamics 0.3.1 RK2)
+            const double vm = x[iv] + (u[ip] * dt) * 0.5;
+            xn[j] = x[ip] + vm * dt;
+            xn[C::D + j] = x[iv] + u[ip] * dt;
+        }
+        coef[0] = coef[1] = coef[2] = coef[3] = 0.0;
+    } else {
+        const int P = C::P;
+        const double th = x[2 * P + i], v = x[3 * P + i], om = u[i], a = u[P + i];
+        const double thm = th + (om * dt) * 0.5, vm = v + (a * dt) * 0.5;
+        double s, c;
+        sincos(thm, &s, &c);
+        xn[0] = x[i] + (c * vm) * dt;
+        xn[1] = x[P + i] + (s * vm) * dt;
+        xn[2] = th + om * dt;
+        xn[3] = v + a * dt;
+        coef[0] = -dt * vm * s; coef[1] = dt * c; coef[2] = dt * vm * c; coef[3] = dt * s;
+    }
+}
+// RK3 step of player i (rollout!, solver_methods.jl:17; RobotDynamics 0.3.1 RK3)
+template <class C>
+__device__ __forceinline__ void model_player_rk3(int i, const double* x, const double* u, double dt, double* xn) {
+    double xi[C::ni], k1[C::ni], k2[C::ni], k3[C::ni], t[C::ni], ui[C::mi];
+#pragma unroll
+    for (int j = 0; j < C::ni; j++) xi[j] = x[i + j * C::P];
+#pragma unroll
+    for (int j = 0; j < C::mi; j++) ui[j] = u[i + j * C::P];
+    auto f = [&](const double* s, double* o) {
+        if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+#pragma unroll
+            for (int j = 0; j < C::D; j++) { o[j] = s[C::D + j]; o[C::D + j] = ui[j]; }
+        } else {
+            double sn, cs; sincos(s[2], &sn, &cs);
+            o[0] = cs * s[3]; o[1] = sn * s[3]; o[2] = ui[0]; o[3] = ui[1];
+        }
+    };
+    f(xi, k1);
+#pragma unroll
+    for (int j = 0; j < C::ni; j++) { k1[j] *= dt; t[j] = xi[j] + k1[j] / 2; }
+    f(t, k2);
+#pragma unroll
+    for (int j = 0; j < C::ni; j++) { k2[j] *= dt; t[j] = xi[j] - k1[j] + 2 * k2[j]; }
+    f(t, k3);
+#pragma unroll
+    for (int j = 0; j < C::ni; j++) { k3[j] *= dt; xn[j] = xi[j] + (k1[j] + 4 * k2[j] + k3[j]) / 6; }
+}
+
+// (A^T v)[r] for a vector accessor v(r'): A = I + E
+template <class C, class V>
+__device__ __forceinline__ double AT_vec(const double* coef, double dt, V v, int r) {
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        return r < C::m ? v(r) : v(r) + dt * v(r - C::m);
+    } else {
+        const int P = C::P, blk = r / P, i = r % P;
+        if (blk == 2) return v(r) + coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i);
+        if (blk == 3) return v(r) + coef[1 * P + i] * v(i) + coef[3 * P + i] * v(P + i);
+        return v(r);
+    }
+}
+// (A v)[r]
+template <class C, class V>
+__device__ __forceinline__ double A_vec(const double* coef, double dt, V v, int r) {
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        return r < C::m ? v(r) + dt * v(r + C::m) : v(r);
+    } else {
+        const int P = C::P, blk = r / P, i = r % P;
+        if (blk == 0) return v(r) + coef[0 * P + i] * v(2 * P + i) + coef[1 * P + i] * v(3 * P + i);
+        if (blk == 1) return v(r) + coef[2 * P + i] * v(2 * P + i) + coef[3 * P + i] * v(3 * P + i);
+        return v(r);
+    }
+}
+// (X A)[c] for a row accessor X(r'): column op
+template <class C, class V>
+__device__ __forceinline__ double XA_vec(const double* coef, double dt, V X, int c) { return AT_vec<C>(coef, dt, X, c); }
+// A[r][c]
+template <class C>
+__device__ __forceinline__ double A_entry(const double* coef, double dt, int r, int c) {
+    double e = (r == c) ? 1.0 : 0.0;
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        if (r < C::m && c == r + C::m) e = dt;
+    } else {
+        const int P = C::P, br = r / P, i = r % P;
+        if (br == 0) { if (c == 2 * P + i) e = coef[0 * P + i]; else if (c == 3 * P + i) e = coef[1 * P + i]; }
+        else if (br == 1) { if (c == 2 * P + i) e = coef[2 * P + i]; else if (c == 3 * P + i) e = coef[3 * P + i]; }
+    }
+    return e;
+}
+// B[r][c]  (c: joint control index)
+template <class C>
+__device__ __forceinline__ double B_entry(const double* coef, double dt, int r, int c) {
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        if (r == c) return 0.5 * dt * dt;
+        if (r == c + C::m) return dt;
+        return 0.0;
+    } else {
+        const int P = C::P, i = c % P, kind = c / P;   // kind 0: omega_i, 1: a_i
+        if (kind == 0) {
+            if (r == i) return 0.5 * dt * coef[0 * P + i];
+            if (r == P + i) return 0.5 * dt * coef[2 * P + i];
+            if (r == 2 * P + i) return dt;
+        } else {
+            if (r == i) return 0.5 * dt * coef[1 * P + i];
+            if (r == P + i) return 0.5 * dt * coef[3 * P + i];
+            if (r == 3 * P + i) return dt;
+        }
+        return 0.0;
+    }
+}
+// (B^T v)[c] : column c of B has <= 3 non-zeros
+template <class C, class V>
+__device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int c) {
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        return 0.5 * dt * dt * v(c) + dt * v(c + C::m);
+    } else {
+        const int P = C::P, i = c % P, kind = c / P;
+        if (kind == 0) return 0.5 * dt * (coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i)) + dt * v(2 * P + i);
+        return 0.5 * dt * (coef[1 * P + i] * v(i) + coef[3 * P + i] * v(P + i)) + dt * v(3 * P + i);
+    }
+}
+// (B w)[r] for a control-vector accessor w(c): row r of B has <= 2 non-zeros
+template <class C, class V>
+__device__ __forceinline__ double B_vec(const double* coef, double dt, V w, int r) {
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        return r < C::m ? 0.5 * dt * dt * w(r) : dt * w(r - C::m);
+    } else {
+        const int P = C::P, br = r / P, i = r % P;
+        if (br == 0) return 0.5 * dt * (coef[0 * P + i] * w(i) + coef[1 * P + i] * w(P + i));
+        if (br == 1) return 0.5 * dt * (coef[2 * P + i] * w(i) + coef[3 * P + i] * w(P + i));
+        if (br == 2) return dt * w(i);
+        return dt * w(P + i);
+    }
+}
+
+// ================================================================================================
+// Per-game data view
+// ================================================================================================
+struct Game {
+    double* z[3];
+    const double* x0;
+    const double* Qd; const double* Rd; const double* xf; const double* uf;
+    double* lam; double* mu; double* vals;
+    double* res; double* kgain;
+    alg_game_stats* st; alg_record* hist;
+};
+__device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, int g) {
+    Game G;
+    for (int t = 0; t < 3; t++) G.z[t] = bf.traj[t] + (size_t)g * pr.traj_len;
+    G.x0 = bf.x0 + (size_t)g * pr.n;
+    const size_t gq = pr.lqr_per_game ? (size_t)g : 0;
+    G.Qd = bf.Qd + gq * pr.p * pr.ni; G.xf = bf.xf + gq * pr.p * pr.ni;
+    G.Rd = bf.Rd + gq * pr.p * pr.mi; G.uf = bf.uf + gq * pr.p * pr.mi;
+    G.lam = bf.lam + (size_t)g * pr.con_len; G.mu = bf.mu + (size_t)g * pr.con_len; G.vals = bf.vals + (size_t)g * pr.con_len;
+    G.res = bf.res + (size_t)g * pr.S; G.kgain = bf.kgain + (size_t)g * pr.kscratch_len;
+    G.st = bf.stats + g; G.hist = bf.hist + (size_t)g * pr.hist_max;
+    return G;
+}
+
+// Altro 0.3.0 cost_expansion!: a = (c >= 0) | (lambda > 0)  [PINNED test/constraints/constraint_derivatives.jl:28-34]
+__device__ __forceinline__ double al_active_mu(double c, double lam, double mu) { return ((c >= 0.0) || (lam > 0.0)) ? mu : 0.0; }
+
+// Collision terms of the ordered pair (i,j) at state x of knot kn (0-based).  gv[2]: contribution of the pair to row
+// opt_i at px(i,.) (the contribution at px(j,.) is -gv); H[3] = (H00,H01,H11): symmetric 2x2 block with sign pattern
+// [[+H,-H],[-H,+H]] on (px[i],px[j]).  Cost part: CollisionCost gradient/Hessian (objective.jl:134-173) scaled by
+// w = dt (stage) or 1 (terminal) (TrajOpt cost_gradient!/cost_hessian!); constraint part: CollisionConstraint
+// c = R^2 - |d|^2, C = [-2d', 2d'] with the AL expansion grad = C'(lam + a mu c), hess = a mu C'C.
+template <class C>
+__device__ __forceinline__ void pair_terms(const Params& pr, const Game& G, int i, int j, const double* x, int kn,
+                                           double* gv, double* H, double* cval) {
+    const double dl0 = x[i] - x[j], dl1 = x[C::P + i] - x[C::P + j];
+    const double s2 = dl0 * dl0 + dl1 * dl1;
+    gv[0] = gv[1] = 0.0; H[0] = H[1] = H[2] = 0.0;
+    if (pr.has_colcost) {
+        const double w = (kn < pr.N - 1) ? pr.dt : 1.0;
+        const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+        if (fmax(0.0, rad - nrm) > 0.0) {
+            const double eps = 1e-10, eps_norm = eps * sqrt((double)C::n);
+            const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
+            const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
+            gv[0] += w * (-g0); gv[1] += w * (-g1);
+            const double n3 = nrm * nrm * nrm;
+            H[0] += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
+            H[1] += w * (mu * (rad * (dl0 * dl1) / n3));
+            H[2] += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
+        }
+    }
+    if (pr.has_colavoid) {
+        const double R = pr.ca_radius[i] + pr.ca_radius[j];
+        const double c = R * R - s2;
+        const int ci = con_col<C>(pr.N, pairq<C>(i, j), kn);
+        const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
+        const double wl = lm + am * c;
+        gv[0] += -2.0 * dl0 * wl; gv[1] += -2.0 * dl1 * wl;
+        H[0] += am * 4.0 * dl0 * dl0; H[1] += am * 4.0 * dl0 * dl1; H[2] += am * 4.0 * dl1 * dl1;
+        if (cval) *cval = c;
+    }
+}
+
+// ================================================================================================
+// Streaming phase: residual! + regularize_residual! + the scalars of record! (lane-per-knot)
+//   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl
+// ================================================================================================
+struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; };
+
+template <class C, bool WRITE>
+__device__ void residual_pass(const Params& pr, const Game& G, const double* z, const double* zref, double reg,
+                              double* res_out, ResOut& out) {
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni;
+    const int N = pr.N, lane = threadIdx.x;
+    const double dt = pr.dt;
+    double l1 = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
+    for (int k = lane; k < N - 1; k += WAVE) {
+        // ---- load knot k and k+1 -----------------------------------------------------------------
+        double xk[n], uk[m], x1[n], u1[m];
+        const double* sk = zstate<C>(z, k);
+        const double* s1 = z + n + hx<C>(k);
+#pragma unroll
+        for (int a = 0; a < n; a++) { xk[a] = sk[a]; x1[a] = s1[a]; }
+#pragma unroll
+        for (int c = 0; c < m; c++) uk[c] = z[n + hu<C>(k, 0) + uoff<C>(c)];
+        const bool has_next = (k + 1 <= N - 2);
+        if (has_next) {
+#pragma unroll
+            for (int c = 0; c < m; c++) u1[c] = z[n + hu<C>(k + 1, 0) + uoff<C>(c)];
+        } else {
+#pragma unroll
+            for (int c = 0; c < m; c++) u1[c] = 0.0;
+        }
+        // ---- dynamics of knot k (defect) and Jacobian coefficients of knots k, k+1 -----------------
+        double coefk[C::NC], coef1[C::NC], xn[n];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            double xo[ni], co[4];
+            model_player<C>(i, xk, uk, dt, xo, co);
+#pragma unroll
+            for (int j = 0; j < ni; j++) xn[i + j * P] = xo[j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) coefk[j * P + i] = co[j];
+            model_player<C>(i, x1, u1, dt, xo, co);
+#pragma unroll
+            for (int j = 0; j < 4; j++) coef1[j * P + i] = co[j];
+        }
+        // dyn_k = RK2(x_k,u_k) - x_{k+1}  (global_quantities.jl:60-63)
+#pragma unroll
+        for (int a = 0; a < n; a++) {
+            const double r = xn[a] - x1[a];
+            if (WRITE) res_out[vd<C>(N, k) + a] = r;
+            l1 += fabs(r); vdyn = fmax(vdyn, fabs(r)); bad |= !isfinite(r);
+        }
+        // ---- control-bound AL terms at knot k (constraint_derivatives.jl:61-72) --------------------
+        double gctl[m];
+#pragma unroll
+        for (int c = 0; c < m; c++) gctl[c] = 0.0;
+        if (pr.has_ctl) {
+#pragma unroll
+            for (int c = 0; c < m; c++) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int row = half * m + c, ci = con_ctl<C>(pr, k, row);
+                    const double cv = half == 0 ? uk[c] - pr.umax[c] : pr.umin[c] - uk[c];
+                    G.vals[ci] = cv;
+                    if (isfinite(cv)) {
+                        const double lm = G.lam[ci];
+                        const double wl = lm + al_active_mu(cv, lm, G.mu[ci]) * cv;
+                        gctl[c] += (half == 0 ? wl : -wl);
+                        vcon = fmax(vcon, fmax(0.0, cv));
+                    }
+                }
+            }
+        }
+        const int kn = k + 1;                                   // knot whose x rows this lane owns
+        const double w = (kn < N - 1) ? dt : 1.0;               // stage / terminal scaling
+        // ---- rows of every player ------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const double* lk = z + n + hl<C>(k, i);
+            const double* l1p = z + n + hl<C>(has_next ? k + 1 : k, i);
+            double row[n];
+            // cost gradient q (objective.jl:43-61 + LQRCost): w * Q_i (x - xf_i) on pz[i]
+#pragma unroll
+            for (int a = 0; a < n; a++) row[a] = 0.0;
+#pragma unroll
+            for (int j = 0; j < ni; j++) row[i + j * P] = w * (G.Qd[i * ni + j] * (x1[i + j * P] - G.xf[i * ni + j]));
+            // collision cost + collision avoidance of the ordered pairs (i,j)
+            if (pr.has_colcost || pr.has_colavoid) {
+#pragma unroll
+                for (int j = 0; j < P; j++) if (j != i) {
+                    double gv[2], H[3], cval = 0.0;
+                    pair_terms<C>(pr, G, i, j, x1, kn, gv, H, &cval);
+                    row[i] += gv[0]; row[P + i] += gv[1]; row[j] -= gv[0]; row[P + j] -= gv[1];
+                    if (pr.has_colavoid) { G.vals[con_col<C>(N, pairq<C>(i, j), kn)] = cval; vsta = fmax(vsta, fmax(0.0, cval)); }
+                }
+            }
+            // dynamics penalty: + A_{kn}' lambda_{i,kn} (kn <= N-2) - lambda_{i,k}  (global_quantities.jl:43-54)
+            if (has_next) {
+#pragma unroll
+                for (int a = 0; a < n; a++) row[a] += AT_vec<C>(coef1, dt, [&](int r) { return l1p[r]; }, a);
+            }
+#pragma unroll
+            for (int a = 0; a < n; a++) row[a] -= lk[a];
+            if (zref) {                                                        // regularize_residual! (:67-86)
+                const double* xr = zref + n + hx<C>(k);
+#pragma unroll
+                for (int a = 0; a < n; a++) row[a] += reg * (x1[a] - xr[a]);
+            }
+#pragma unroll
+            for (int a = 0; a < n; a++) {
+                if (WRITE) res_out[vx<C>(N, i, k) + a] = row[a];
+                l1 += fabs(row[a]); vopt = fmax(vopt, fabs(row[a])); bad |= !isfinite(row[a]);
+            }
+            // opt_i,u_{i,k}: dt R_i (u - uf_i)[pu[i]] + ctl grad[pu[i]] + B_i' lambda_{i,k} (+ reg (u - uref)[pu[i]])
+#pragma unroll
+            for (int j = 0; j < mi; j++) {
+                const int c = i + j * P;
+                double r = dt * (G.Rd[i * mi + j] * (uk[c] - G.uf[i * mi + j])) + gctl[c]
+                         + BT_vec<C>(coefk, dt, [&](int rr) { return lk[rr]; }, c);
+                if (zref) r += reg * (uk[c] - zref[n + hu<C>(k, 0) + uoff<C>(c)]);
+                if (WRITE) res_out[vu<C>(N, i, k) + j] = r;
+                l1 += fabs(r); vopt = fmax(vopt, fabs(r)); bad |= !isfinite(r);
+            }
+        }
+    }
+    out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
+    out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
+}
+
+// update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
+template <class C>
+__device__ __forceinline__ void update_traj(const Params& pr, double* tgt, const double* src, double alpha, const double* dz) {
+    for (int e = threadIdx.x; e < pr.S; e += WAVE) tgt[C::n + e] = src[C::n + e] + alpha * dz[C::n + e];
+}
+// Δ_step (primal_dual_traj.jl:130-147)
+template <class C>
+__device__ __forceinline__ double delta_step(const Params& pr, const double* dz, double alpha) {
+    double s = 0;
+    for (int e = threadIdx.x; e < (pr.N - 1) * (C::n + C::m); e += WAVE) {
+        const int k = e / (C::n + C::m), a = e % (C::n + C::m);
+        s += fabs(dz[C::n + k * C::b + a]);
+    }
+    s = wave_sum(s);
+    s *= alpha;
+    s /= (double)((pr.N - 1) * (C::n + C::m));
+    return s;
+}
+
+// ================================================================================================
+// Newton direction: structured elimination of the KKT system (see file header)
+// ================================================================================================
+template <class C>
+struct DirLds {
+    double Pm[C::P * C::n * C::n];     // P_i (row-major n x n per player)
+    double Tm[C::P * C::n * C::n];     // T_i = P_i F
+    double F[C::n * C::n];
+    double f[C::n];
+    double s[C::P * C::n];
+    double t[C::P * C::n];
+    double xk[C::n], x1[C::n], uk[C::m], u1[C::m];
+    double coefk[C::NC], coefn[C::NC];
+    double gv[(C::NPAIR > 0 ? C::NPAIR : 1) * 2], Hh[(C::NPAIR > 0 ? C::NPAIR : 1) * 3];
+    double Rhat[C::m];
+    double V[C::m * C::n];
+    double W[C::m * C::WC];
+    double dx[C::n], du[C::m];
+    double dl[C::P * C::n];
+    int singular;
+};
+
+// Entry (r,c) of Q^_i = sum_j E[i][j].Q + state-constraint hess + reg I  at knot kn
+template <class C>
+__device__ __forceinline__ double qhat_entry(const Params& pr, const Game& G, const DirLds<C>& L, int i, int r, int c, double w, double reg) {
+    constexpr int P = C::P;
+    double e = 0.0;
+    if (r == c) {
+        e = reg;
+        if (r % P == i) e += w * G.Qd[i * C::ni + r / P];
+    }
+    if (C::NPAIR > 0 && r < 2 * P && c < 2 * P) {
+        const int jr = r % P, ar = r / P, jc = c % P, ac = c / P;
+        const int hidx = ar + ac;     // (0,0)->0 (0,1)/(1,0)->1 (1,1)->2
+        if (jr == i && jc == i) {
+            for (int j = 0; j < P; j++) if (j != i) e += L.Hh[pairq<C>(i, j) * 3 + hidx];
+        } else if (jr == i) {
+            e -= L.Hh[pairq<C>(i, jc) * 3 + hidx];
+        } else if (jc == i) {
+            e -= L.Hh[pairq<C>(i, jr) * 3 + hidx];
+        } else if (jr == jc) {
+            e += L.Hh[pairq<C>(i, jr) * 3 + hidx];
+        }
+    }
+    return e;
+}
+
+// Loads knot data of step k into LDS and computes coefficients, pair tables, R^ (wave-cooperative).
+template <class C>
+__device__ void step_context(const Params& pr, const Game& G, DirLds<C>& L, const double* z, int k, double reg) {
+    constexpr int n = C::n, m = C::m, P = C::P;
+    const int N = pr.N, lane = threadIdx.x;
+    const bool has_next = (k + 1 <= N - 2);
+    if (lane < n) { L.xk[lane] = zstate<C>(z, k)[lane]; L.x1[lane] = z[n + hx<C>(k) + lane]; }
+    if (lane < m) { L.uk[lane] = z[n + hu<C>(k, 0) + uoff<C>(lane)]; L.u1[lane] = has_next ? z[n + hu<C>(k + 1, 0) + uoff<C>(lane)] : 0.0; }
+    __syncthreads();
+    if (lane < P) {
+        double xo[C::ni], co[4];
+        model_player<C>(lane, L.xk, L.uk, pr.dt, xo, co);
+        for (int j = 0; j < 4; j++) L.coefk[j * P + lane] = co[j];
+        model_player<C>(lane, L.x1, L.u1, pr.dt, xo, co);
+        for (int j = 0; j < 4; j++) L.coefn[j * P + lane] = co[j];
+    }
+    if (C::NPAIR > 0 && lane >= 8 && lane < 8 + C::NPAIR && (pr.has_colcost || pr.has_colavoid)) {
+        const int q = lane - 8, i = q / (P - 1), jj = q % (P - 1), j = jj < i ? jj : jj + 1;
+        pair_terms<C>(pr, G, i, j, L.x1, k + 1, &L.gv[q * 2], &L.Hh[q * 3], nullptr);
+    } else if (C::NPAIR > 0 && lane >= 8 && lane < 8 + C::NPAIR) {
+        const int q = lane - 8;
+        L.gv[q * 2] = L.gv[q * 2 + 1] = 0.0; L.Hh[q * 3] = L.Hh[q * 3 + 1] = L.Hh[q * 3 + 2] = 0.0;
+    }
+    if (lane >= 32 && lane < 32 + m) {
+        // R^[c] = dt R_i[c] + reg + control-bound hess (diagonal)  (global_quantities.jl:138-144,176-193; constraint_derivatives.jl:24-33)
+        const int c = lane - 32, i = c % P, j = c / P;
+        double rh = pr.dt * G.Rd[i * C::mi + j] + reg;
+        if (pr.has_ctl) {
+            for (int half = 0; half < 2; half++) {
+                const int ci = con_ctl<C>(pr, k, half * m + c);
+                const double cv = half == 0 ? L.uk[c] - pr.umax[c] : pr.umin[c] - L.uk[c];
+                if (isfinite(cv)) rh += al_active_mu(cv, G.lam[ci], G.mu[ci]);
+            }
+        }
+        L.Rhat[c] = rh;
+    }
+    __syncthreads();
+}
+
+// Partial-pivot Gauss-Jordan of the m x m control system with n+1 right-hand sides held in L.W (m x WC, row-major).
+// Every lane scans the pivot column redundantly (wave-uniform pivot choice, no reduction).
+template <class C>
+__device__ void solve_control_system(DirLds<C>& L) {
+    constexpr int m = C::m, WC = C::WC;
+    const int lane = threadIdx.x;
+    for (int c = 0; c < m; c++) {
+        int piv = c; double best = fabs(L.W[c * WC + c]);
+        for (int r = c + 1; r < m; r++) { const double v = fabs(L.W[r * WC + c]); if (v > best) { best = v; piv = r; } }
+        if (!(best > 0.0) || !isfinite(best)) { if (lane == 0) L.singular = 1; __syncthreads(); return; }
+        __syncthreads();
+        if (piv != c && lane < WC) { const double a = L.W[c * WC + lane], bb = L.W[piv * WC + lane]; L.W[c * WC + lane] = bb; L.W[piv * WC + lane] = a; }
+        __syncthreads();
+        const double inv = 1.0 / L.W[c * WC + c];
+        // factors of all rows, read before anything is overwritten
+        double fac[(m * WC + WAVE - 1) / WAVE]; double prow[(m * WC + WAVE - 1) / WAVE];
+        int cnt = 0;
+        for (int e = lane; e < m * WC; e += WAVE, cnt++) {
+            const int r = e / WC, col = e % WC;
+            fac[cnt] = (r == c) ? 0.0 : L.W[r * WC + c] * inv;
+            prow[cnt] = L.W[c * WC + col];
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int e = lane; e < m * WC; e += WAVE, cnt++) {
+            const int r = e / WC, col = e % WC;
+            if (r == c) L.W[e] = prow[cnt] * inv;
+            else L.W[e] -= fac[cnt] * prow[cnt];
+        }
+        __syncthreads();
+    }
+}
+
+// Solves J d = -res for the stored residual G.res (vertical order) and writes d into the delta buffer
+// (solver_methods.jl:87-88).  Returns ALG_STATUS_*.
+template <class C>
+__device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg) {
+    constexpr int n = C::n, m = C::m, P = C::P, WC = C::WC;
+    const int N = pr.N, lane = threadIdx.x;
+    const double dt = pr.dt;
+    const double* z = G.z[0];
+    const double* res = G.res;
+    double* dz = G.z[2];
+    if (lane == 0) L.singular = 0;
+    __syncthreads();
+    // ------------------------------------------------------------------ backward sweep
+    for (int k = N - 2; k >= 0; k--) {
+        step_context<C>(pr, G, L, z, k, reg);
+        const int kn = k + 1;
+        const double w = (kn < N - 1) ? dt : 1.0;
+        if (k < N - 2) {
+            // t_i = P_i f + s_i ; T_i = P_i F     (P, F, f, s of step k+1)
+            for (int e = lane; e < P * n; e += WAVE) {
+                const int i = e / n, r = e % n; double acc = L.s[e];
+                for (int c = 0; c < n; c++) acc += L.Pm[i * n * n + r * n + c] * L.f[c];
+                L.t[e] = acc;
+            }
+            for (int e = lane; e < P * n * n; e += WAVE) {
+                const int i = e / (n * n), r = (e / n) % n, c = e % n; double acc = 0.0;
+                for (int q = 0; q < n; q++) acc += L.Pm[i * n * n + r * n + q] * L.F[q * n + c];
+                L.Tm[e] = acc;
+            }
+            __syncthreads();
+            // P_i = Q^_i + A_{k+1}' T_i ; s_i = rx_i + A_{k+1}' t_i
+            for (int e = lane; e < P * n * n; e += WAVE) {
+                const int i = e / (n * n), r = (e / n) % n, c = e % n;
+                const double* Ti = &L.Tm[i * n * n];
+                L.Pm[e] = qhat_entry<C>(pr, G, L, i, r, c, w, reg) + AT_vec<C>(L.coefn, dt, [&](int rr) { return Ti[rr * n + c]; }, r);
+            }
+            for (int e = lane; e < P * n; e += WAVE) {
+                const int i = e / n, r = e % n; const double* ti = &L.t[i * n];
+                L.s[e] = res[vx<C>(N, i, k) + r] + AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
+            }
+        } else {
+            for (int e = lane; e < P * n * n; e += WAVE) {
+                const int i = e / (n * n), r = (e / n) % n, c = e % n;
+                L.Pm[e] = qhat_entry<C>(pr, G, L, i, r, c, w, reg);
+            }
+            for (int e = lane; e < P * n; e += WAVE) L.s[e] = res[vx<C>(N, e / n, k) + e % n];
+        }
+        __syncthreads();
+        // V[c][:] = B[:,c]' P_{i(c)}   (m x n)
+        for (int e = lane; e < m * n; e += WAVE) {
+            const int c = e / n, col = e % n; const double* Pi = &L.Pm[(c % P) * n * n];
+            L.V[e] = BT_vec<C>(L.coefk, dt, [&](int rr) { return Pi[rr * n + col]; }, c);
+        }
+        __syncthreads();
+        // W = diag(R^) + V B ; rhs = [ V A_k | V rd + B' s + ru ]
+        for (int e = lane; e < m * WC; e += WAVE) {
+            const int c = e / WC, col = e % WC; const double* Vc = &L.V[c * n];
+            double v;
+            if (col < m) {
+                v = BT_vec<C>(L.coefk, dt, [&](int rr) { return Vc[rr]; }, col) + (col == c ? L.Rhat[c] : 0.0);
+            } else if (col < m + n) {
+                v = (k >= 1) ? XA_vec<C>(L.coefk, dt, [&](int rr) { return Vc[rr]; }, col - m) : 0.0;
+            } else {
+                const int i = c % P, j = c / P; const double* si = &L.s[i * n];
+                double acc = res[vu<C>(N, i, k) + j] + BT_vec<C>(L.coefk, dt, [&](int rr) { return si[rr]; }, c);
+                for (int rr = 0; rr < n; rr++) acc += Vc[rr] * res[vd<C>(N, k) + rr];
+                v = acc;
+            }
+            L.W[e] = v;
+        }
+        __syncthreads();
+        solve_control_system<C>(L);
+        if (L.singular) return ALG_STATUS_SINGULAR;
+        // K = -Y[:, :n], kappa = -Y[:, n]  -> HBM scratch ; F = A_k + B K ; f = rd + B kappa
+        double* Kg = G.kgain + (size_t)k * (m * (n + 1));
+        for (int e = lane; e < m * (n + 1); e += WAVE) { const int c = e / (n + 1), col = e % (n + 1); Kg[e] = -L.W[c * WC + m + col]; }
+        for (int e = lane; e < n * n; e += WAVE) {
+            const int r = e / n, c = e % n;
+            L.F[e] = ((k >= 1) ? A_entry<C>(L.coefk, dt, r, c) : 0.0) + B_vec<C>(L.coefk, dt, [&](int cc) { return -L.W[cc * WC + m + c]; }, r);
+        }
+        if (lane < n) L.f[lane] = res[vd<C>(N, k) + lane] + B_vec<C>(L.coefk, dt, [&](int cc) { return -L.W[cc * WC + m + n]; }, lane);
+        __syncthreads();
+    }
+    // ------------------------------------------------------------------ forward sweep: dx, du
+    if (lane < n) { L.dx[lane] = 0.0; dz[lane] = 0.0; }
+    __syncthreads();
+    for (int k = 0; k < N - 1; k++) {
+        const double* Kg = G.kgain + (size_t)k * (m * (n + 1));
+        if (lane < n) { L.xk[lane] = zstate<C>(z, k)[lane]; }
+        if (lane < m) { L.uk[lane] = z[n + hu<C>(k, 0) + uoff<C>(lane)]; }
+        __syncthreads();
+        if (lane < P) {
+            double xo[C::ni], co[4];
+            model_player<C>(lane, L.xk, L.uk, dt, xo, co);
+            for (int j = 0; j < 4; j++) L.coefk[j * P + lane] = co[j];
+        }
+        if (lane >= 32 && lane < 32 + m) {
+            const int c = lane - 32; double acc = Kg[c * (n + 1) + n];
+            for (int q = 0; q < n; q++) acc += Kg[c * (n + 1) + q] * L.dx[q];
+            L.du[c] = acc;
+        }
+        __syncthreads();
+        double dxn = 0.0;
+        if (lane < n) dxn = A_vec<C>(L.coefk, dt, [&](int rr) { return L.dx[rr]; }, lane)
+                          + B_vec<C>(L.coefk, dt, [&](int cc) { return L.du[cc]; }, lane) + res[vd<C>(N, k) + lane];
+        __syncthreads();
+        if (lane < n) { L.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; }
+        if (lane >= 32 && lane < 32 + m) dz[n + hu<C>(k, 0) + uoff<C>(lane - 32)] = L.du[lane - 32];
+        __syncthreads();
+    }
+    // ------------------------------------------------------------------ costate sweep: dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
+    for (int k = N - 2; k >= 0; k--) {
+        step_context<C>(pr, G, L, z, k, reg);
+        const int kn = k + 1;
+        const double w = (kn < N - 1) ? dt : 1.0;
+        if (lane < n) L.dx[lane] = dz[n + hx<C>(k) + lane];
+        __syncthreads();
+        double v[(P * n + WAVE - 1) / WAVE]; int cnt = 0;
+        for (int e = lane; e < P * n; e += WAVE, cnt++) {
+            const int i = e / n, r = e % n;
+            double acc = res[vx<C>(N, i, k) + r];
+            for (int c = 0; c < n; c++) acc += qhat_entry<C>(pr, G, L, i, r, c, w, reg) * L.dx[c];
+            if (k < N - 2) { const double* dli = &L.dl[i * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, r); }
+            v[cnt] = acc;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int e = lane; e < P * n; e += WAVE, cnt++) { L.dl[e] = v[cnt]; dz[n + hl<C>(k, 0) + e] = v[cnt]; }
+        __syncthreads();
+    }
+    // non-finite direction -> singular (the reference would throw / propagate NaN)
+    int bad = 0;
+    for (int e = lane; e < pr.S; e += WAVE) bad |= !isfinite(dz[n + e]);
+    return wave_or(bad) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;
+}
+
+// residual_jacobian! + regularize_residual_jacobian! into a dense S x S column-major matrix (global_quantities.jl:109-193).
+// Parity / inspection entry point; built from the same block functions the solver uses.
+template <class C>
+__device__ void jacobian_dense(const Params& pr, const Game& G, DirLds<C>& L, double reg, double* J) {
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi;
+    const int N = pr.N, lane = threadIdx.x; const size_t S = pr.S; const double dt = pr.dt;
+    for (size_t e = lane; e < S * S; e += WAVE) J[e] = 0.0;
+    __syncthreads();
+    auto at = [&](int r, int c) -> double& { return J[(size_t)c * S + r]; };
+    for (int k = 0; k < N - 1; k++) {
+        step_context<C>(pr, G, L, G.z[0], k, reg);
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
+        for (int e = lane; e < P * n * n; e += WAVE) {
+            const int i = e / (n * n), r = (e / n) % n, c = e % n;
+            at(vx<C>(N, i, k) + r, hx<C>(k) + c) = qhat_entry<C>(pr, G, L, i, r, c, w, reg);
+        }
+        for (int c = lane; c < m; c += WAVE) { const int i = c % P, j = c / P; at(vu<C>(N, i, k) + j, hu<C>(k, i) + j) = L.Rhat[c]; }
+        for (int e = lane; e < n * n; e += WAVE) {
+            const int r = e / n, c = e % n; const double a = A_entry<C>(L.coefk, dt, r, c);
+            if (k >= 1) {
+                at(vd<C>(N, k) + r, hx<C>(k - 1) + c) = a;
+                for (int i = 0; i < P; i++) at(vx<C>(N, i, k - 1) + c, hl<C>(k, i) + r) = a;
+            }
+        }
+        for (int e = lane; e < n * m; e += WAVE) {
+            const int r = e / m, c = e % m, i = c % P, j = c / P; const double bv = B_entry<C>(L.coefk, dt, r, c);
+            at(vd<C>(N, k) + r, hu<C>(k, i) + j) = bv;
+            at(vu<C>(N, i, k) + j, hl<C>(k, i) + r) = bv;
+        }
+        for (int r = lane; r < n; r += WAVE) {
+            at(vd<C>(N, k) + r, hx<C>(k) + r) = -1.0;
+            for (int i = 0; i < P; i++) at(vx<C>(N, i, k) + r, hl<C>(k, i) + r) = -1.0;
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================
+// Solver control flow (solver_methods.jl:5-125), per game
+// ================================================================================================
+// record! (statistics.jl:44-57): unregularised residual at pdtraj (also refreshes G.res and G.vals)
+template <class C>
+__device__ __forceinline__ alg_record make_record(const Params& pr, const Game& G, double delta, int outer, int* nonfinite) {
+    ResOut ro;
+    residual_pass<C, true>(pr, G, G.z[0], nullptr, 0.0, G.res, ro);
+    alg_record rc;
+    rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
+    rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
+    if (nonfinite) *nonfinite = ro.nonfinite;
+    return rc;
+}
+
+// line_search (solver_methods.jl:105-125)
+template <class C>
+__device__ void line_search(const Params& pr, const Game& G, double reg, double res_norm0, double* alpha_out, int* j_out) {
+    const alg_options& o = pr.opt;
+    int j = 1; double alpha = 1.0;
+    while (j < o.ls_iter) {
+        update_traj<C>(pr, G.z[1], G.z[0], alpha, G.z[2]);
+        __syncthreads();
+        ResOut ro;
+        residual_pass<C, false>(pr, G, G.z[1], o.regularize ? G.z[0] : nullptr, reg, nullptr, ro);
+        const double rt = ro.l1 / (double)pr.S;
+        if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
+        alpha *= o.alpha_decrease; j += 1;
+    }
+    *alpha_out = alpha; *j_out = j;
+}
+
+__device__ __forceinline__ void push_record(const Params& pr, const Game& G, const alg_record& rc) {
+    if (threadIdx.x == 0) {
+        const int idx = G.st->records;
+        if (idx < pr.hist_max) G.hist[idx] = rc;
+        G.st->records = idx + 1;
+    }
+}
+
+// inner_iteration (solver_methods.jl:67-103)
+template <class C>
+__device__ alg_step_info inner_iteration(const Params& pr, const Game& G, DirLds<C>& L, int& LS_count, double& Delta, int k, int l) {
+    const alg_options& o = pr.opt;
+    alg_step_info info;
+    info.status = ALG_STATUS_OK; info.control_flow = 0; info.ls_j = 0; info.ls_failed = 0; info.alpha = 0.0; info.delta = 0.0;
+    const double lf = (double)l;
+    const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
+    int nonfinite = 0;
+    alg_record rc = make_record<C>(pr, G, Delta, k, &nonfinite);           // :73-76 (the regularisation term is zero at pdtraj)
+    const double rn = rc.res;
+    info.rec = rc;
+    Delta = 0.0;                                                           // :79
+    if (nonfinite) { info.status = ALG_STATUS_NAN; info.control_flow = 1; push_record(pr, G, rc); return info; }
+    if (rc.opt_vio < o.eps_opt) { info.control_flow = 1; push_record(pr, G, rc); return info; }   // :80-82
+    __syncthreads();
+    const int st = newton_direction<C>(pr, G, L, reg);                     // :84-88
+    if (st != ALG_STATUS_OK) { info.status = st; info.control_flow = 1; push_record(pr, G, rc); return info; }
+    __syncthreads();
+    double alpha; int j;
+    line_search<C>(pr, G, reg, rn, &alpha, &j);                            // :91
+    const int failed = (j == o.ls_iter);                                   // :92
+    if (failed) LS_count += 1; else LS_count = 0;                          // :93
+    __syncthreads();
+    update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);                     // :94
+    Delta = delta_step<C>(pr, G.z[2], alpha);                              // :95
+    __syncthreads();
+    info.alpha = alpha; info.ls_j = j; info.ls_failed = failed; info.delta = Delta;
+    rc.alpha = alpha; rc.ls_j = j; info.rec = rc;
+    if (threadIdx.x == 0) { G.st->newton_iters += 1; if (failed) G.st->ls_failures += 1; }
+    push_record(pr, G, rc);
+    if (Delta < o.delta_min) info.control_flow = 1;                        // :96-98
+    return info;
+}
+
+// reset!(game_con) (constraints_methods.jl:295-327)
+__device__ __forceinline__ void reset_con(const Params& pr, const Game& G) {
+    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) { G.lam[e] = 0.0; G.mu[e] = pr.opt.rho_0; }
+}
+// evaluate! + dual_update! + penalty_update! (solver_methods.jl:57-61; constraints_methods.jl:329-379,421-440)
+template <class C>
+__device__ void dual_penalty_update(const Params& pr, const Game& G) {
+    constexpr int n = C::n, m = C::m, P = C::P;
+    const int N = pr.N; const alg_options& o = pr.opt; const double* z = G.z[0];
+    if (pr.has_colavoid) {
+        for (int e = threadIdx.x; e < pr.col_len; e += WAVE) {
+            const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / (P - 1), jj = q % (P - 1), j = jj < i ? jj : jj + 1;
+            const double* x = zstate<C>(z, k);
+            const double d0 = x[i] - x[j], d1 = x[P + i] - x[P + j], R = pr.ca_radius[i] + pr.ca_radius[j];
+            const double c = R * R - (d0 * d0 + d1 * d1);
+            G.vals[e] = c;
+            const double lb = G.lam[e] + o.alphax_dual[i] * G.mu[e] * c;
+            G.lam[e] = fmin(fmax(lb, 0.0), o.lambda_max);
+        }
+    }
+    if (pr.has_ctl) {
+        for (int e = threadIdx.x; e < pr.ctl_len; e += WAVE) {
+            const int k = e / (2 * m), row = e % (2 * m), c = row % m;
+            const double u = z[n + hu<C>(k, 0) + uoff<C>(c)];
+            const double cv = row < m ? u - pr.umax[c] : pr.umin[c] - u;
+            const int ci = pr.col_len + e;
+            G.vals[ci] = cv;
+            if (isfinite(cv)) { const double lb = G.lam[ci] + o.alpha_dual * G.mu[ci] * cv; G.lam[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
+        }
+    }
+    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) G.mu[e] = fmin(fmax(G.mu[e] * o.rho_increase, 0.0), o.rho_max);
+}
+
+// rollout!(RK3, model, traj) (solver_methods.jl:17): lanes < P integrate their own player (players are decoupled)
+template <class C>
+__device__ void rollout(const Params& pr, double* z) {
+    constexpr int n = C::n, m = C::m, P = C::P;
+    const int lane = threadIdx.x;
+    if (lane < P) {
+        double x[n], u[m];     // only this player's entries are used
+        for (int j = 0; j < C::ni; j++) x[lane + j * P] = z[lane + j * P];
+        for (int k = 0; k < pr.N - 1; k++) {
+            for (int j = 0; j < C::mi; j++) u[lane + j * P] = z[n + hu<C>(k, lane) + j];
+            double xn[C::ni];
+            model_player_rk3<C>(lane, x, u, pr.dt, xn);
+            for (int j = 0; j < C::ni; j++) { x[lane + j * P] = xn[j]; z[n + hx<C>(k) + lane + j * P] = xn[j]; }
+        }
+    }
+}
+
+// init_traj! (primal_dual_traj.jl:29-44) with the counter RNG (same element counters as the oracle)
+template <class C>
+__device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t game_id, bool use_shift) {
+    constexpr int n = C::n, m = C::m, P = C::P;
+    const int N = pr.N, lane = threadIdx.x; const alg_options& o = pr.opt;
+    const int s = use_shift ? o.shift : (1 << 30);
+    if (use_shift && s < N) {
+        // in-place shift: element e of step k takes element e of step k+s; ascending k is safe within one wave only
+        // with a barrier per step, so stage through the trial buffer
+        double* tmp = G.z[1];
+        for (int e = lane; e < pr.traj_len; e += WAVE) tmp[e] = z[e];
+        __syncthreads();
+        z = z; // (same buffer)
+        for (int e = lane; e < pr.S; e += WAVE) {
+            const int k = e / C::b, a = e % C::b;
+            double v;
+            if (a < n) {           // x_{k+1}: knot kn = k+1
+                const int kn = k + 1;
+                v = (kn + s <= N - 1) ? tmp[n + hx<C>(kn + s - 1) + a] : o.amplitude_init * counter_uniform(o.seed, game_id, (uint64_t)kn * (n + m) + a);
+            } else if (a < n + m) { // u_k (player-grouped offset a-n -> joint index)
+                const int off = a - n, i = off / C::mi, j = off % C::mi, c = i + j * P;
+                v = (k + s < N - 1) ? tmp[n + hu<C>(k + s, 0) + off] : o.amplitude_init * counter_uniform(o.seed, game_id, (uint64_t)k * (n + m) + n + c);
+            } else {               // lambda_{i,k}
+                const int off = a - n - m, i = off / n, r = off % n;
+                v = (k + s <= N - 2) ? tmp[n + hl<C>(k + s, i) + r]
+                                     : o.amplitude_init * counter_uniform(o.seed, game_id, (uint64_t)N * (n + m) + ((uint64_t)i * (N - 1) + k) * n + r);
+            }
+            z[n + e] = v;
+        }
+    } else {
+        for (int e = lane; e < pr.S; e += WAVE) {
+            const int k = e / C::b, a = e % C::b;
+            uint64_t ctr;
+            if (a < n) ctr = (uint64_t)(k + 1) * (n + m) + a;
+            else if (a < n + m) { const int off = a - n, i = off / C::mi, j = off % C::mi; ctr = (uint64_t)k * (n + m) + n + (i + j * P); }
+            else { const int off = a - n - m, i = off / n, r = off % n; ctr = (uint64_t)N * (n + m) + ((uint64_t)i * (N - 1) + k) * n + r; }
+            z[n + e] = o.amplitude_init * counter_uniform(o.seed, game_id, ctr);
+        }
+    }
+    if (lane < n) z[lane] = G.x0[lane];
+    __syncthreads();
+}
+
+// newton_solve! (solver_methods.jl:5-65)
+template <class C>
+__device__ void newton_solve(const Params& pr, const Game& G, DirLds<C>& L, int init, uint64_t game_id) {
+    const alg_options& o = pr.opt; const int lane = threadIdx.x;
+    if (lane == 0) { alg_game_stats z{}; *G.st = z; }                       // reset!(prob.stats)
+    if (init) init_traj<C>(pr, G, G.z[0], game_id, true);                  // :13
+    else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
+    if (lane < C::n) { G.z[1][lane] = G.x0[lane]; G.z[2][lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
+    __syncthreads();
+    rollout<C>(pr, G.z[0]);                                                // :17
+    if (o.dual_reset) reset_con(pr, G);                                    // :25
+    __syncthreads();
+    int out = 0, status = ALG_STATUS_OK, converged = 0; double Delta = 0.0;
+    for (int k = 1; k <= o.outer_iter; k++) {                              // :30
+        out = k;
+        int LS_count = 0; alg_record last; bool any = false;
+        for (int l = 1; l <= o.inner_iter; l++) {                          // :38
+            alg_step_info info = inner_iteration<C>(pr, G, L, LS_count, Delta, k, l);
+            last = info.rec; any = true;
+            if (info.status != ALG_STATUS_OK) { status = info.status; break; }
+            if (LS_count >= 1 || info.control_flow == 1) break;            // :43
+        }
+        if (status != ALG_STATUS_OK) break;
+        const bool conv = any && last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
+        if (conv) converged = 1;
+        if (k == o.outer_iter || conv) break;                              // :49-55
+        __syncthreads();
+        dual_penalty_update<C>(pr, G);                                     // :57-61
+        __syncthreads();
+    }
+    __syncthreads();
+    alg_record fin = make_record<C>(pr, G, Delta, out, nullptr);           // :63
+    push_record(pr, G, fin);
+    if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; G.st->last = fin; }
+}
+
+} // namespace alg

@@ -1,0 +1,530 @@
+// algames_hip.hip -- kernels and the C ABI (include/algames_hip.h) of libalgames_hip.so.
+// gfx950 only.  One workgroup (= one wavefront) per game; see algames_device.hpp.
+#include "algames_device.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace alg;
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_newton_solve(Params pr, Buffers bf, int init, uint64_t game_id0) {
+    __shared__ DirLds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_newton_step(Params pr, Buffers bf, int k, int l, alg_step_info* out) {
+    __shared__ DirLds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    int ls = 0; double dl = 0.0;
+    alg_step_info info = inner_iteration<C>(pr, G, L, ls, dl, k, l);
+    if (threadIdx.x == 0 && out) out[g] = info;
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int which, double reg, double* res_out, double* rn_out) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    ResOut ro;
+    // the proximal term is taken w.r.t. pdtraj (regularize_residual!, global_quantities.jl:67-86)
+    residual_pass<C, true>(pr, G, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, G.res, ro);
+    __syncthreads();
+    if (res_out) for (int e = threadIdx.x; e < pr.S; e += WAVE) res_out[(size_t)g * pr.S + e] = G.res[e];
+    if (rn_out && threadIdx.x == 0) rn_out[g] = ro.l1 / (double)pr.S;
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, Buffers bf, double reg, double* J) {
+    __shared__ DirLds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    jacobian_dense<C>(pr, G, L, reg, J + (size_t)g * pr.S * pr.S);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_direction(Params pr, Buffers bf, double reg, int* status) {
+    __shared__ DirLds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    ResOut ro;
+    residual_pass<C, true>(pr, G, G.z[0], nullptr, 0.0, G.res, ro);
+    __syncthreads();
+    const int st = newton_direction<C>(pr, G, L, reg);
+    if (status && threadIdx.x == 0) status[g] = st;
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_line_search(Params pr, Buffers bf, double reg, const double* rn, double* alpha, int* j) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    double a; int jj;
+    line_search<C>(pr, G, reg, rn[g], &a, &jj);
+    if (threadIdx.x == 0) { alpha[g] = a; j[g] = jj; }
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_update(Params pr, Buffers bf, int tgt, int src, const double* alpha) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    update_traj<C>(pr, G.z[tgt], G.z[src], alpha[g], G.z[2]);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_record(Params pr, Buffers bf, alg_record* out) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    alg_record rc = make_record<C>(pr, G, 0.0, 0, nullptr);
+    if (threadIdx.x == 0) out[g] = rc;
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_dual_update(Params pr, Buffers bf) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    dual_penalty_update<C>(pr, G);
+}
+
+__global__ void __launch_bounds__(WAVE) k_reset_con(Params pr, Buffers bf) {
+    Game G = game_view(pr, bf, blockIdx.x);
+    reset_con(pr, G);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_init(Params pr, Buffers bf, uint64_t game_id0, int use_shift, int do_init, int which) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    if (do_init) {
+        init_traj<C>(pr, G, G.z[0], game_id0 + (uint64_t)g, use_shift != 0);
+        if (threadIdx.x < C::n) G.z[1][threadIdx.x] = G.x0[threadIdx.x];
+        __syncthreads();
+        rollout<C>(pr, G.z[0]);
+    } else {
+        rollout<C>(pr, G.z[which]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) return fail(ALG_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+bool fill_dims(const alg_desc& a, Params& p) {
+    std::memset(&p, 0, sizeof(p));
+    p.model = a.model; p.p = a.p; p.N = a.N; p.dt = a.dt; p.B = a.batch;
+    if (a.p < 1 || a.p > MAXP || a.N < 2) return false;
+    if (a.model == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        p.d = a.d; if (p.d < 1 || p.d > 3) return false;
+        p.n = 2 * p.d * p.p; p.m = p.d * p.p; p.mi = p.d; p.ni = 2 * p.d;
+    } else if (a.model == ALG_MODEL_UNICYCLE) {
+        p.d = 2; p.n = 4 * p.p; p.m = 2 * p.p; p.mi = 2; p.ni = 4;
+    } else return false;
+    p.S = p.n * p.p * (p.N - 1) + p.m * (p.N - 1) + p.n * (p.N - 1);     // problem_size.jl:22
+    p.b = p.n + p.m + p.p * p.n;
+    p.traj_len = p.n + p.S;
+    p.npair = p.p * (p.p - 1);
+    p.col_len = p.npair * (p.N - 1);
+    p.ctl_len = 2 * p.m * (p.N - 1);
+    p.con_len = p.col_len + p.ctl_len;
+    p.hist_max = HIST_MAX;
+    p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
+    return true;
+}
+
+// supported template instantiations: (model, p, d)
+#define ALG_FOR_EACH_CFG(X)                                   \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2)                       \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2)                       \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2)                       \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2)                       \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3)                       \
+    X(ALG_MODEL_UNICYCLE, 1, 2)                                \
+    X(ALG_MODEL_UNICYCLE, 2, 2)                                \
+    X(ALG_MODEL_UNICYCLE, 3, 2)                                \
+    X(ALG_MODEL_UNICYCLE, 4, 2)
+
+bool cfg_supported(const Params& p) {
+#define X(M, P, D) if (p.model == (M) && p.p == (P) && p.d == (D)) return true;
+    ALG_FOR_EACH_CFG(X)
+#undef X
+    return false;
+}
+
+struct Handle {
+    Params pr;
+    Buffers bf;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    bool x0_set = false, lqr_set = false;
+    std::vector<void*> allocs;
+    // small device scratch for per-game scalar I/O
+    double* d_tmp = nullptr;      // B doubles x 2
+    int* d_itmp = nullptr;        // B ints
+    alg_step_info* d_info = nullptr;
+    alg_record* d_rec = nullptr;
+    double* d_lqr[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+template <class T>
+int dalloc(Handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return ALG_OK;
+}
+
+int use_device(Handle* h) { HIPCHK(hipSetDevice(h->device)); return ALG_OK; }
+int h2d(Handle* h, void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ALG_OK;
+}
+int d2h(Handle* h, void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ALG_OK;
+}
+int launch_check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALG_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    return ALG_OK;
+}
+
+#define H ((Handle*)h)
+#define LAUNCH(kernel, ...)                                                                     \
+    do {                                                                                        \
+        const Params& pr_ = H->pr;                                                              \
+        bool done_ = false;                                                                     \
+        LAUNCH_CASES_(kernel, __VA_ARGS__)                                                      \
+        if (!done_) return fail(ALG_ERR_ARG, "unsupported (model, p, d) configuration");        \
+        int rc_ = launch_check(#kernel);                                                        \
+        if (rc_ != ALG_OK) return rc_;                                                          \
+    } while (0)
+
+#define LAUNCH_ONE_(M, P, D, kernel, ...)                                                       \
+    if (!done_ && pr_.model == (M) && pr_.p == (P) && pr_.d == (D)) {                           \
+        hipLaunchKernelGGL((kernel<Cfg<M, P, D>>), dim3(pr_.B), dim3(WAVE), 0, H->stream, __VA_ARGS__); \
+        done_ = true;                                                                           \
+    }
+#define LAUNCH_CASES_(kernel, ...)                                       \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, kernel, __VA_ARGS__)  \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, kernel, __VA_ARGS__)  \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, kernel, __VA_ARGS__)  \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, kernel, __VA_ARGS__)  \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, kernel, __VA_ARGS__)  \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 1, 2, kernel, __VA_ARGS__)           \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 2, 2, kernel, __VA_ARGS__)           \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 3, 2, kernel, __VA_ARGS__)           \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 4, 2, kernel, __VA_ARGS__)
+
+int alloc_all(Handle* hd) {
+    int rc;
+    const Params& p = hd->pr; const size_t B = p.B;
+    for (int t = 0; t < 3; t++) if ((rc = dalloc(hd, &hd->bf.traj[t], B * p.traj_len))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.x0, B * p.n))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.lam, B * p.con_len))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.mu, B * p.con_len))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.vals, B * p.con_len))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.res, B * p.S))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.kgain, B * p.kscratch_len))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.stats, B))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max))) return rc;
+    if ((rc = dalloc(hd, &hd->d_tmp, 2 * B))) return rc;
+    if ((rc = dalloc(hd, &hd->d_itmp, B))) return rc;
+    if ((rc = dalloc(hd, &hd->d_info, B))) return rc;
+    if ((rc = dalloc(hd, &hd->d_rec, B))) return rc;
+    // LQR buffers sized for the per-game case
+    if ((rc = dalloc(hd, &hd->d_lqr[0], B * p.p * p.ni))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr[1], B * p.p * p.mi))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr[2], B * p.p * p.ni))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr[3], B * p.p * p.mi))) return rc;
+    hd->bf.Qd = hd->d_lqr[0]; hd->bf.Rd = hd->d_lqr[1]; hd->bf.xf = hd->d_lqr[2]; hd->bf.uf = hd->d_lqr[3];
+    return ALG_OK;
+}
+
+int sync(Handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); return ALG_OK; }
+
+} // namespace
+
+extern "C" {
+
+const char* alg_last_error(void) { return g_err.c_str(); }
+
+void alg_default_options(alg_options* o) {   // options.jl:5-116
+    std::memset(o, 0, sizeof(*o));
+    o->amplitude_init = 1e-8; o->shift = 1 << 10; o->regularize = 1; o->reg_0 = 1e-3;
+    o->alpha_decrease = 0.5; o->beta = 0.01; o->ls_iter = 25; o->dual_reset = 1; o->delta_min = 1e-9;
+    o->rho_0 = 1.0; o->rho_increase = 10.0; o->rho_max = 1e7; o->lambda_max = 1e7; o->alpha_dual = 1.0;
+    for (int i = 0; i < 10; i++) o->alphax_dual[i] = 1.0;
+    o->eps_dyn = o->eps_sta = o->eps_con = o->eps_opt = 1e-3;
+    o->outer_iter = 7; o->inner_iter = 20; o->seed = 100;
+}
+
+int alg_dims(const alg_desc* d, int32_t* n, int32_t* m, int32_t* mi, int32_t* S, int32_t* traj_len, int32_t* con_len) {
+    Params p;
+    if (!d || !fill_dims(*d, p)) return fail(ALG_ERR_ARG, "alg_dims: unsupported descriptor");
+    if (n) *n = p.n; if (m) *m = p.m; if (mi) *mi = p.mi; if (S) *S = p.S; if (traj_len) *traj_len = p.traj_len; if (con_len) *con_len = p.con_len;
+    return ALG_OK;
+}
+
+int alg_create(const alg_desc* d, alg_handle** out) {
+    if (!d || !out) return fail(ALG_ERR_ARG, "alg_create: null argument");
+    Handle* hd = new Handle();
+    if (!fill_dims(*d, hd->pr) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "alg_create: unsupported descriptor"); }
+    if (!cfg_supported(hd->pr)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2 p<=4, d=3 p=2; Unicycle p<=4)"); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete hd; return fail(ALG_ERR_DEVICE, "alg_create: no HIP device available (this library has no CPU fallback)"); }
+    if (d->device < 0 || d->device >= ndev) { delete hd; return fail(ALG_ERR_ARG, "alg_create: bad device ordinal"); }
+    hd->device = d->device;
+    alg_handle* h = (alg_handle*)hd;
+    int rc = use_device(hd); if (rc) { delete hd; return rc; }
+    if (hipStreamCreateWithFlags(&hd->own_stream, hipStreamNonBlocking) != hipSuccess) { delete hd; return fail(ALG_ERR_DEVICE, "hipStreamCreate failed"); }
+    hd->stream = hd->own_stream;
+    alg_default_options(&hd->pr.opt);
+    if ((rc = alloc_all(hd))) goto bad;
+    // mu starts at rho_0 like a freshly built ALConVal after set_constraint_params!/reset
+    hipLaunchKernelGGL(k_reset_con, dim3(hd->pr.B), dim3(WAVE), 0, hd->stream, hd->pr, hd->bf);
+    if ((rc = sync(hd))) goto bad;
+    *out = h;
+    return ALG_OK;
+bad:
+    alg_destroy(h);
+    return rc;
+}
+
+void alg_destroy(alg_handle* h) {
+    if (!h) return;
+    hipSetDevice(H->device);
+    if (H->stream) hipStreamSynchronize(H->stream);
+    for (void* q : H->allocs) hipFree(q);
+    if (H->own_stream) hipStreamDestroy(H->own_stream);
+    delete H;
+}
+
+int alg_set_options(alg_handle* h, const alg_options* o) {
+    if (!h || !o) return fail(ALG_ERR_ARG, "alg_set_options: null argument");
+    if (o->ls_iter < 1 || o->outer_iter < 1 || o->inner_iter < 1) return fail(ALG_ERR_ARG, "alg_set_options: iteration counts must be >= 1");
+    H->pr.opt = *o;
+    return ALG_OK;
+}
+int alg_get_options(alg_handle* h, alg_options* o) { *o = H->pr.opt; return ALG_OK; }
+int alg_set_stream(alg_handle* h, void* s) { H->stream = s ? (hipStream_t)s : H->own_stream; return ALG_OK; }
+
+int alg_set_x0(alg_handle* h, const double* x0) {
+    if (!h || !x0) return fail(ALG_ERR_ARG, "alg_set_x0: null argument");
+    int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr;
+    if ((rc = h2d(H, H->bf.x0, x0, sizeof(double) * p.B * p.n))) return rc;
+    // x_1 of every trajectory buffer (set_state!(pdtraj.pr[1], x0))
+    for (int t = 0; t < 2; t++)
+        HIPCHK(hipMemcpy2DAsync(H->bf.traj[t], sizeof(double) * p.traj_len, H->bf.x0, sizeof(double) * p.n, sizeof(double) * p.n, p.B, hipMemcpyDeviceToDevice, H->stream));
+    H->x0_set = true;
+    return sync(H);
+}
+
+int alg_set_lqr(alg_handle* h, const double* Qd, const double* Rd, const double* xf, const double* uf, int32_t per_game) {
+    if (!h || !Qd || !Rd || !xf || !uf) return fail(ALG_ERR_ARG, "alg_set_lqr: null argument");
+    int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr; const size_t nb = per_game ? p.B : 1;
+    if ((rc = h2d(H, H->d_lqr[0], Qd, sizeof(double) * nb * p.p * p.ni))) return rc;
+    if ((rc = h2d(H, H->d_lqr[1], Rd, sizeof(double) * nb * p.p * p.mi))) return rc;
+    if ((rc = h2d(H, H->d_lqr[2], xf, sizeof(double) * nb * p.p * p.ni))) return rc;
+    if ((rc = h2d(H, H->d_lqr[3], uf, sizeof(double) * nb * p.p * p.mi))) return rc;
+    H->pr.lqr_per_game = per_game ? 1 : 0;
+    H->lqr_set = true;
+    return ALG_OK;
+}
+
+int alg_add_collision_cost(alg_handle* h, const double* radius, const double* mu) {
+    Params& p = H->pr;
+    if (!radius || !mu) { p.has_colcost = 0; return ALG_OK; }
+    for (int i = 0; i < p.p; i++) { p.cc_radius[i] = radius[i]; p.cc_mu[i] = mu[i]; }
+    p.has_colcost = 1; return ALG_OK;
+}
+int alg_add_collision_avoidance(alg_handle* h, const double* radius) {
+    Params& p = H->pr;
+    if (!radius) { p.has_colavoid = 0; return ALG_OK; }
+    for (int i = 0; i < p.p; i++) p.ca_radius[i] = radius[i];
+    p.has_colavoid = 1; return ALG_OK;
+}
+int alg_add_control_bound(alg_handle* h, const double* umax, const double* umin) {
+    Params& p = H->pr;
+    if (!umax || !umin) { p.has_ctl = 0; return ALG_OK; }
+    if (p.m > MAXM) return fail(ALG_ERR_ARG, "alg_add_control_bound: m too large");
+    for (int i = 0; i < p.m; i++) if (!(umax[i] >= umin[i])) return fail(ALG_ERR_ARG, "Upper bounds must be greater than or equal to lower bounds");
+    for (int i = 0; i < p.m; i++) { p.umax[i] = umax[i]; p.umin[i] = umin[i]; }
+    p.has_ctl = 1; return ALG_OK;
+}
+
+int alg_set_traj(alg_handle* h, int32_t which, const double* z) {
+    if (which < 0 || which > 2 || !z) return fail(ALG_ERR_ARG, "alg_set_traj: bad argument");
+    int rc = use_device(H); if (rc) return rc;
+    return h2d(H, H->bf.traj[which], z, sizeof(double) * H->pr.B * H->pr.traj_len);
+}
+int alg_get_traj(alg_handle* h, int32_t which, double* z) {
+    if (which < 0 || which > 2 || !z) return fail(ALG_ERR_ARG, "alg_get_traj: bad argument");
+    int rc = use_device(H); if (rc) return rc;
+    return d2h(H, z, H->bf.traj[which], sizeof(double) * H->pr.B * H->pr.traj_len);
+}
+int alg_set_con_duals(alg_handle* h, const double* lam, const double* mu) {
+    int rc = use_device(H); if (rc) return rc;
+    const size_t bytes = sizeof(double) * H->pr.B * H->pr.con_len;
+    if (bytes == 0) return ALG_OK;
+    if (lam && (rc = h2d(H, H->bf.lam, lam, bytes))) return rc;
+    if (mu && (rc = h2d(H, H->bf.mu, mu, bytes))) return rc;
+    return ALG_OK;
+}
+int alg_get_con_duals(alg_handle* h, double* lam, double* mu) {
+    int rc = use_device(H); if (rc) return rc;
+    const size_t bytes = sizeof(double) * H->pr.B * H->pr.con_len;
+    if (bytes == 0) return ALG_OK;
+    if (lam && (rc = d2h(H, lam, H->bf.lam, bytes))) return rc;
+    if (mu && (rc = d2h(H, mu, H->bf.mu, bytes))) return rc;
+    return ALG_OK;
+}
+
+int alg_init_traj(alg_handle* h, int64_t game_id0, int32_t use_shift) {
+    int rc = use_device(H); if (rc) return rc;
+    if (!H->x0_set) return fail(ALG_ERR_STATE, "alg_init_traj: x0 not set");
+    LAUNCH(k_init, H->pr, H->bf, (uint64_t)game_id0, (int)use_shift, 1, 0);
+    return sync(H);
+}
+int alg_rollout(alg_handle* h, int32_t which) {
+    if (which < 0 || which > 1) return fail(ALG_ERR_ARG, "alg_rollout: bad traj selector");
+    int rc = use_device(H); if (rc) return rc;
+    LAUNCH(k_init, H->pr, H->bf, (uint64_t)0, 0, 0, (int)which);
+    return sync(H);
+}
+
+int alg_residual(alg_handle* h, int32_t which, double reg, double* res, double* rn) {
+    if (which < 0 || which > 1) return fail(ALG_ERR_ARG, "alg_residual: bad traj selector");
+    int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr;
+    double* d_res = nullptr;
+    if (res) HIPCHK(hipMalloc((void**)&d_res, sizeof(double) * p.B * p.S));
+    LAUNCH(k_residual, H->pr, H->bf, (int)which, reg, d_res, H->d_tmp);
+    if (res) { rc = d2h(H, res, d_res, sizeof(double) * p.B * p.S); hipFree(d_res); if (rc) return rc; }
+    if (rn && (rc = d2h(H, rn, H->d_tmp, sizeof(double) * p.B))) return rc;
+    return sync(H);
+}
+
+int alg_residual_jacobian(alg_handle* h, double reg, double* jac) {
+    if (!jac) return fail(ALG_ERR_ARG, "alg_residual_jacobian: null output");
+    int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr;
+    const size_t bytes = sizeof(double) * (size_t)p.B * p.S * p.S;
+    double* d_j = nullptr;
+    HIPCHK(hipMalloc((void**)&d_j, bytes));
+    LAUNCH(k_jacobian, H->pr, H->bf, reg, d_j);
+    rc = d2h(H, jac, d_j, bytes);
+    hipFree(d_j);
+    return rc;
+}
+
+int alg_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status) {
+    int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr;
+    LAUNCH(k_direction, H->pr, H->bf, reg, H->d_itmp);
+    if (status && (rc = d2h(H, status, H->d_itmp, sizeof(int) * p.B))) return rc;
+    if (delta) {
+        // strip the x_1 slot: delta is B x S in horizontal order
+        HIPCHK(hipMemcpy2DAsync(delta, sizeof(double) * p.S, H->bf.traj[2] + p.n, sizeof(double) * p.traj_len, sizeof(double) * p.S, p.B, hipMemcpyDeviceToHost, H->stream));
+    }
+    return sync(H);
+}
+
+int alg_line_search(alg_handle* h, double reg, const double* rn, double* alpha, int32_t* j) {
+    if (!rn || !alpha || !j) return fail(ALG_ERR_ARG, "alg_line_search: null argument");
+    int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr;
+    if ((rc = h2d(H, H->d_tmp, rn, sizeof(double) * p.B))) return rc;
+    LAUNCH(k_line_search, H->pr, H->bf, reg, (const double*)H->d_tmp, H->d_tmp + p.B, H->d_itmp);
+    if ((rc = d2h(H, alpha, H->d_tmp + p.B, sizeof(double) * p.B))) return rc;
+    return d2h(H, j, H->d_itmp, sizeof(int) * p.B);
+}
+
+int alg_update_traj(alg_handle* h, int32_t target, int32_t source, const double* alpha) {
+    if (target < 0 || target > 1 || source < 0 || source > 1 || !alpha) return fail(ALG_ERR_ARG, "alg_update_traj: bad argument");
+    int rc = use_device(H); if (rc) return rc;
+    if ((rc = h2d(H, H->d_tmp, alpha, sizeof(double) * H->pr.B))) return rc;
+    LAUNCH(k_update, H->pr, H->bf, (int)target, (int)source, (const double*)H->d_tmp);
+    return sync(H);
+}
+
+int alg_record_stats(alg_handle* h, alg_record* rec) {
+    if (!rec) return fail(ALG_ERR_ARG, "alg_record_stats: null output");
+    int rc = use_device(H); if (rc) return rc;
+    LAUNCH(k_record, H->pr, H->bf, H->d_rec);
+    return d2h(H, rec, H->d_rec, sizeof(alg_record) * H->pr.B);
+}
+
+int alg_reset_con(alg_handle* h) {
+    int rc = use_device(H); if (rc) return rc;
+    hipLaunchKernelGGL(k_reset_con, dim3(H->pr.B), dim3(WAVE), 0, H->stream, H->pr, H->bf);
+    if ((rc = launch_check("k_reset_con"))) return rc;
+    return sync(H);
+}
+
+int alg_dual_penalty_update(alg_handle* h, double* vals) {
+    int rc = use_device(H); if (rc) return rc;
+    LAUNCH(k_dual_update, H->pr, H->bf);
+    if (vals && H->pr.con_len > 0) return d2h(H, vals, H->bf.vals, sizeof(double) * H->pr.B * H->pr.con_len);
+    return sync(H);
+}
+
+int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, alg_step_info* info) {
+    int rc = use_device(H); if (rc) return rc;
+    LAUNCH(k_newton_step, H->pr, H->bf, (int)k_outer, (int)l_inner, H->d_info);
+    if (info) return d2h(H, info, H->d_info, sizeof(alg_step_info) * H->pr.B);
+    return sync(H);
+}
+
+int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) {
+    int rc = use_device(H); if (rc) return rc;
+    if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_newton_solve: x0 / LQR data not set");
+    LAUNCH(k_newton_solve, H->pr, H->bf, (int)init, (uint64_t)game_id0);
+    return ALG_OK;
+}
+int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats) {
+    int rc = alg_newton_solve_async(h, init, game_id0); if (rc) return rc;
+    if (stats) return alg_get_stats(h, stats);
+    return sync(H);
+}
+int alg_get_stats(alg_handle* h, alg_game_stats* stats) {
+    if (!stats) return fail(ALG_ERR_ARG, "alg_get_stats: null output");
+    int rc = use_device(H); if (rc) return rc;
+    return d2h(H, stats, H->bf.stats, sizeof(alg_game_stats) * H->pr.B);
+}
+int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out) {
+    if (game < 0 || game >= H->pr.B || !out) return fail(ALG_ERR_ARG, "alg_get_history: bad argument");
+    int rc = use_device(H); if (rc) return rc;
+    alg_game_stats st;
+    if ((rc = d2h(H, &st, H->bf.stats + game, sizeof(st)))) return rc;
+    int c = std::min(std::min(st.records, H->pr.hist_max), (int)max_records);
+    if (c > 0 && (rc = d2h(H, out, H->bf.hist + (size_t)game * H->pr.hist_max, sizeof(alg_record) * c))) return rc;
+    if (n_out) *n_out = c;
+    return ALG_OK;
+}
+int alg_synchronize(alg_handle* h) { int rc = use_device(H); if (rc) return rc; return sync(H); }
+
+} // extern "C"

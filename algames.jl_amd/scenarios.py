@@ -1,0 +1,124 @@
+"""Synthetic scenario sets of the BASELINE configurations.
+
+All random numbers come from the same counter-based generator the library uses on the device
+(SplitMix64 keyed by (seed, stream, counter)), so inputs depend only on the *global* scenario id:
+sharding a batch over ranks does not change them.
+"""
+import numpy as np
+
+from . import host
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def counter_uniform(seed, game, counter):
+    """Bit-identical to alg::counter_uniform (algames_device.hpp) / the oracle's counter_uniform."""
+    game = np.asarray(game, dtype=np.uint64)
+    counter = np.asarray(counter, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = _splitmix64(np.uint64(seed) ^ _splitmix64(game * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x632BE59BD9B4E019)))
+        h = _splitmix64(h + counter * np.uint64(0x9E3779B97F4A7C15))
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+SCENARIO_STREAM = 0x5CE7A210   # keeps scenario draws disjoint from the init_traj draws of the same game id
+
+
+def shard_range(total, rank, world):
+    """Contiguous shard [lo, hi) of `total` scenarios for `rank` of `world`."""
+    per = (total + world - 1) // world
+    lo = min(rank * per, total)
+    return lo, min(lo + per, total)
+
+
+def _uniform(seed, ids, count, lo, hi):
+    ids = np.asarray(ids, dtype=np.uint64)
+    u = counter_uniform(seed ^ SCENARIO_STREAM, ids[:, None], np.arange(count, dtype=np.uint64)[None, :])
+    return lo + (hi - lo) * u
+
+
+def c2_double_integrator(ids, N=40, seed=100, p=3):
+    """C2 / C4: 3-player DoubleIntegrator (d=2), base = examples/ibr_example.jl:10-74 with N 20 -> 40.
+    Returns (model, N, dt, x0 (B,n), game_obj, game_con, opts)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    model = host.DoubleIntegratorGame(p=p, d=2)
+    dt = 0.1
+    Q = [50.0 * np.ones(4) for _ in range(p)]
+    R = [0.01 * np.ones(2) for _ in range(p)]
+    xf = [np.zeros(4) for _ in range(p)]
+    uf = [np.zeros(2) for _ in range(p)]
+    game_obj = host.GameObjective(Q, R, xf, uf, N, model)
+    host.add_collision_cost(game_obj, 3.0 * np.ones(p), 2.0 * np.ones(p))          # ibr_example.jl:44-46
+    game_con = host.GameConstraintValues(host.ProblemSize(N, model))
+    host.add_collision_avoidance(game_con, 0.25)                                      # ibr_example.jl:51-52
+    # spiral start, ibr_example.jl:67-70
+    th = np.linspace(0.0, 2 * np.pi * (1 - 1 / p), p)
+    rad = 0.5
+    base = np.zeros(model.n)
+    base[0:p] = (rad + th / 10) * np.cos(th)
+    base[p:2 * p] = (rad + th / 10) * np.sin(th)
+    x0 = np.tile(base, (len(ids), 1))
+    x0[:, :2 * p] += _uniform(seed, ids, 2 * p, -0.05, 0.05)
+    opts = host.Options(Δ_min=1e-9, inner_print=False, seed=seed)                    # ibr_example.jl:74
+    return model, N, dt, x0, game_obj, game_con, opts
+
+
+def c3_unicycle(ids, N=50, seed=100, p=4):
+    """C3 (p=4, N=50) / C5 (p=3, N=30): Unicycle, costs of test/problem/solver_methods.jl:141-144 with uf = 0 and
+    xf_i = antipode of the start; collision avoidance radius 0.05 and control bounds +-1 (:150-155); the
+    effective options of that test."""
+    ids = np.asarray(ids, dtype=np.int64)
+    model = host.UnicycleGame(p=p)
+    dt = 0.1
+    B = len(ids)
+    ang = 2 * np.pi * np.arange(p) / p + _uniform(seed, ids, p, -0.1, 0.1)            # (B,p)
+    x0 = np.zeros((B, model.n))
+    x0[:, 0:p] = np.cos(ang)
+    x0[:, p:2 * p] = np.sin(ang)
+    x0[:, 2 * p:3 * p] = ang + np.pi                                                 # heading toward the centre
+    x0[:, 3 * p:4 * p] = 0.5
+    Q = [np.ones(4) for _ in range(p)]
+    R = [0.5 * np.ones(2) for _ in range(p)]
+    uf = [np.zeros(2) for _ in range(p)]
+    game_obj = host.GameObjective(Q, R, [np.zeros(4)] * p, uf, N, model)
+    xf = np.zeros((B, p, 4))
+    xf[:, :, 0] = -x0[:, 0:p]
+    xf[:, :, 1] = -x0[:, p:2 * p]
+    xf[:, :, 2] = x0[:, 2 * p:3 * p]
+    xf[:, :, 3] = 0.5
+    game_obj.xf = xf                                                                # per-game targets
+    game_obj.Qdiag = np.broadcast_to(game_obj.Qdiag, (B, p, 4)).copy()
+    game_obj.Rdiag = np.broadcast_to(game_obj.Rdiag, (B, p, 2)).copy()
+    game_obj.uf = np.broadcast_to(game_obj.uf, (B, p, 2)).copy()
+    game_con = host.GameConstraintValues(host.ProblemSize(N, model))
+    host.add_collision_avoidance(game_con, 0.05)
+    host.add_control_bound(game_con, np.ones(model.m), -np.ones(model.m))
+    opts = host.Options(inner_print=False, outer_print=False, outer_iter=7, inner_iter=20, ls_iter=25,
+                        reg_0=1e-7, seed=seed)
+    return model, N, dt, x0, game_obj, game_con, opts
+
+
+def make_problem(cfg, ids, backend=None, device=0, **kw):
+    """cfg in {'C2','C3','C5'} -> GameProblem over the scenarios `ids` (global scenario ids)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    if cfg == "C2":
+        model, N, dt, x0, obj, con, opts = c2_double_integrator(ids, **kw)
+    elif cfg == "C3":
+        model, N, dt, x0, obj, con, opts = c3_unicycle(ids, N=50, p=4, **kw)
+    elif cfg == "C5":
+        model, N, dt, x0, obj, con, opts = c3_unicycle(ids, N=30, p=3, **kw)
+    else:
+        raise ValueError(cfg)
+    contiguous = len(ids) > 0 and np.array_equal(ids, ids[0] + np.arange(len(ids)))
+    if not contiguous:
+        raise ValueError("scenario ids of one problem must be contiguous (the device RNG is keyed by game_id0 + g)")
+    return host.GameProblem(N, dt, x0, model, opts, obj, con, backend=backend, device=device, game_id0=int(ids[0]))

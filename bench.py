@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Benchmark of the batched ALGAMES Newton / augmented-Lagrangian hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: a full batched `newton_solve!` (init_traj! + RK3 rollout,
+AL outer loop, Newton inner loop, structured KKT solve, line search, dual/penalty updates) of the BASELINE
+config C2 -- 3-player DoubleIntegrator, N = 40, 4096 synthetic scenarios per GPU -- with all
+inputs already resident in HBM.  Every step re-initialises the iterate from the counter RNG, so all K steps do
+identical work.  metric = game-Newton-iterations per second (inner iterations that performed a linear
+solve, summed over games and ranks) -- BASELINE.json's "Newton iters/sec (batch)"; games-to-convergence/s is
+reported next to it.  Weak scaling: the scenario batch is sharded by contiguous global scenario ids, one
+rank per GPU, no data-path collective (games are independent); the only collectives are the timing
+barrier / max and the final count reduction.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def survey_balg(N, n, m, p):
+    """Algorithmic bytes per game-Newton-iteration, SURVEY.md 8(d): 8*[2(S+n) + 2(N-1)(b^2 + b*p*n)]."""
+    b = n + m + p * n
+    S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
+    return 8 * (2 * (S + n) + 2 * (N - 1) * (b * b + b * p * n))
+
+
+def structured_bytes(N, n, m, p, newton_iters_per_game, ls_trials_per_iter=1.0):
+    """Algorithmic bytes per game-Newton-iteration of THIS implementation's structured elimination:
+    iterate read by the statistics pass, residual written + read, gains written + read, iterate read by the
+    three sweeps' knot loads (3x), delta written, trial written + read, iterate updated (read + write)."""
+    S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
+    gains = (N - 1) * m * (n + 1)
+    it = S + n
+    return 8 * (it + 2 * S + 2 * gains + 3 * it + S + ls_trials_per_iter * (2 * it + S) + 2 * it + S)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--games-per-gpu", type=int, default=4096)
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import algames_jl_amd as alg
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+
+    G = args.games_per_gpu
+    ids = np.arange(rank * G, (rank + 1) * G)                       # contiguous global scenario ids
+    prob = alg.scenarios.make_problem(args.config, ids, device=local_rank)
+    b = prob.batch
+    stream = torch.cuda.current_stream()
+    b.set_stream(stream.cuda_stream)                                # kernels run on torch's current stream
+    prob._sync_options()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        b.newton_solve_async(init=True, game_id0=int(ids[0]))
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]   # HIP events on the launch stream
+
+    st = b.get_stats()
+    iters_rank = int(st["newton_iters"].sum())
+    conv_rank = int(st["converged"].sum())
+    bad_rank = int((st["status"] != 0).sum())
+    tot = torch.tensor([iters_rank, conv_rank, bad_rank], dtype=torch.int64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    iters_all, conv_all, bad_all = [int(v) for v in tot.tolist()]
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        K = args.steps
+        value = iters_all * K / elapsed
+        kern_s = float(np.mean(kernel_ms)) * 1e-3
+        p, n, m, N = b.p, b.n, b.m, b.N
+        balg = survey_balg(N, n, m, p)
+        own = structured_bytes(N, n, m, p, iters_rank / G)
+        out = {
+            "metric": "newton_iters_per_sec", "value": value, "unit": "game-Newton-iterations/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": {"C2": "C2: 3-player DoubleIntegrator (d=2), N=40, collision cost + collision avoidance",
+                                    "C3": "C3: 4-player Unicycle, N=50, collision avoidance + control bounds",
+                                    "C5": "C5: 3-player Unicycle, N=30, collision avoidance + control bounds"}[args.config],
+                       "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
+                       "parallelism": f"scenario-sharded x{world}", "solver": "fused per-game newton_solve! kernel, one game per wavefront"},
+            "games_to_convergence_per_sec": conv_all * K / elapsed,
+            "games_converged": conv_all, "games_failed": bad_all,
+            "roofline": {
+                "bound": "hbm", "kernel": "k_newton_solve",
+                # contract: SURVEY 8(d) algorithmic bytes per game-iteration x game-iterations per launch / launch duration
+                "achieved": balg * iters_rank / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": balg * iters_rank / kern_s / HBM_PEAK,
+                "survey_bytes_per_game_iter": balg,
+                # the structured elimination never spills b x b factors: its own algorithmic bytes
+                "own_bytes_per_game_iter": own, "own_achieved": own * iters_rank / kern_s / 1e9,
+                "own_frac": own * iters_rank / kern_s / HBM_PEAK,
+                "kernel_ms_avg": 1e3 * kern_s, "traffic": None,
+            },
+        }
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+        if prof:
+            try:
+                pj = json.load(open(prof[-1]))
+                if pj.get("config") == args.config and pj.get("games_per_gpu") == G:
+                    out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = os.path.relpath(prof[-1], ROOT)
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(alg, args.config, G)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(alg, cfg, G):
+    """The oracle (literal CPU restatement of the reference algorithm: global KKT assembly + general partial-pivot
+    LU per game, OpenMP over games) timed on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as orc
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    nsample = int(min(G, max(8, 4 * cores)))
+    prob = alg.scenarios.make_problem(cfg, np.arange(nsample), backend=orc.lib())
+    t0 = time.perf_counter()
+    alg.newton_solve(prob)
+    dt = time.perf_counter() - t0
+    s = prob.stats.summary
+    return {"value": float(s["newton_iters"].sum() / dt), "unit": "game-Newton-iterations/s", "cores": cores,
+            "kind": "port", "sample": f"first {nsample} scenarios of the same {cfg} workload, one newton_solve! each, "
+                                      f"{dt:.1f} s wall, OpenMP over games",
+            "games_to_convergence_per_sec": float(s["converged"].sum() / dt)}
+
+
+if __name__ == "__main__":
+    main()

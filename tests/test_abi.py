@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the built C-ABI library exports every symbol that
+include/algames_hip.h declares, struct layouts match, and the product path fails loudly without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "algames_hip.h")
+
+
+def _declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(alg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_functions_all_bound_by_ctypes(alg):
+    names = _declared_functions()
+    assert len(names) >= 30
+    assert sorted("alg_" + k for k in alg._abi.SIGNATURES) == names
+
+
+def test_hip_library_exports_every_declared_symbol(alg):
+    import __graft_entry__ as ge
+    if not os.path.exists(alg.HIP_LIB_PATH):
+        ge.build()
+    dll = ctypes.CDLL(alg.HIP_LIB_PATH)          # loads without a GPU; no compute call is made
+    for name in _declared_functions():
+        assert hasattr(dll, name), name
+    lib = alg.hip_lib()
+    assert lib.missing == []
+    o = lib.default_opts()                        # Options() defaults, src/struct/options.jl:5-116
+    assert (o.amplitude_init, o.shift, o.reg_0, o.ls_iter, o.outer_iter, o.inner_iter, o.seed) == (1e-8, 1024, 1e-3, 25, 7, 20, 100)
+    assert (o.rho_0, o.rho_increase, o.rho_max, o.lambda_max, o.beta, o.alpha_decrease) == (1.0, 10.0, 1e7, 1e7, 0.01, 0.5)
+    sz = lib.sizes(alg.alg_desc(0, 3, 2, 40, 0.1, 1, 0))
+    assert sz == dict(n=12, m=6, mi=2, S=2106, traj_len=2118, con_len=6 * 39 + 12 * 39)
+
+
+def test_oracle_and_product_agree_on_abi_sizes(alg, orc):
+    for (model, p, d, N) in [(0, 2, 2, 20), (0, 3, 2, 40), (1, 4, 2, 50), (1, 3, 2, 30), (0, 2, 3, 7)]:
+        desc = alg.alg_desc(model, p, d, N, 0.1, 1, 0)
+        assert alg.hip_lib().sizes(desc) == orc.lib().sizes(desc)
+
+
+def test_product_path_fails_loudly_without_gpu(alg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    model = alg.DoubleIntegratorGame(p=2)
+    N = 5
+    obj = alg.GameObjective([np.ones(4)] * 2, [np.ones(2)] * 2, [np.zeros(4)] * 2, [np.zeros(2)] * 2, N, model)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    with pytest.raises(alg.AlgamesError, match="no HIP device|no CPU fallback"):
+        alg.GameProblem(N, 0.1, np.zeros(model.n), model, alg.Options(), obj, con)
+
+
+def test_device_code_is_gfx950_only():
+    lib = os.path.join(ROOT, "algames.jl_amd", "lib", "libalgames_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("not built")
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={lib}"],
+                         capture_output=True, text=True)
+    if out.returncode == 0 and out.stdout.strip():
+        targets = [t for t in out.stdout.split() if "amdgcn" in t]
+        assert targets and all("gfx950" in t for t in targets), targets

@@ -1,0 +1,256 @@
+"""Parity of the HIP path (through the C ABI of libalgames_hip.so) against the CPU oracle, on the same seeded
+inputs.  Tolerances (SURVEY.md 8(d) "parity tolerance"):
+  * residual vectors: |diff| <= 1e-10 (1 + ||res||_inf)            (we check the tighter 1e-12)
+  * Jacobian blocks: 1e-12 relative to the largest entry
+  * Newton direction: 1e-9 relative (different but equivalent elimination orders)
+  * accepted step sizes and iteration counts: identical
+  * final primal trajectories <= 1e-8 abs, duals <= 1e-6 rel, final statistics within 1e-9 (abs/rel)
+All of these need a real MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DI, UNI = 0, 1
+CASES = [  # (model, p, d, N)
+    (DI, 1, 2, 6), (DI, 2, 2, 20), (DI, 3, 2, 12), (DI, 4, 2, 7), (DI, 2, 3, 8),
+    (UNI, 1, 2, 9), (UNI, 2, 2, 20), (UNI, 3, 2, 10), (UNI, 4, 2, 8),
+]
+
+
+def _pair(alg, orc, model, p, d, N, B, seed=0, ingredients=("cost", "avoid", "ctl"), dt=0.1):
+    """A HIP batch and an oracle batch with identical random data."""
+    g = alg.Batch(alg.hip_lib(), model, p, N, dt, B, d=d)
+    o = orc.OracleBatch(model, p, N, dt, B, d=d)
+    rng = np.random.default_rng(seed)
+    ni = g.n // p
+    Q, R = 1 + rng.random((B, p, ni)), 0.5 + rng.random((B, p, g.mi))
+    xf, uf = rng.random((B, p, ni)), rng.random((B, p, g.mi)) - 0.5
+    x0 = rng.random((B, g.n))
+    z = rng.random((B, g.traj_len)); z[:, :g.n] = x0
+    lam, mu = rng.random((B, g.con_len)), 1.0 + 2.0 * rng.random((B, g.con_len))
+    lam[rng.random((B, g.con_len)) < 0.3] = 0.0      # exercise the (c >= 0) | (lambda > 0) rule both ways
+    for b in (g, o):
+        b.set_x0(x0); b.set_lqr(Q, R, xf, uf)
+        if "cost" in ingredients and p > 1:
+            b.add_collision_cost(np.full(p, 3.0), 1.0 + np.arange(p))
+        if "avoid" in ingredients and p > 1:
+            b.add_collision_avoidance(0.3 + 0.1 * np.arange(p))
+        if "ctl" in ingredients:
+            umax = np.full(b.m, 0.6); umin = np.full(b.m, -0.4); umax[0] = np.inf
+            b.add_control_bound(umax, umin)
+        b.set_traj(z); b.set_con_duals(lam, mu)
+    return g, o
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_residual_parity(alg, orc, case):
+    g, o = _pair(alg, orc, *case, B=5)
+    for which, reg in ((0, 0.0), (0, 1e-3)):
+        rg, ng = g.residual(which, reg); ro, no = o.residual(which, reg)
+        assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max())
+        assert np.allclose(ng, no, rtol=1e-13, atol=0)
+    # trial iterate with the proximal term (regularize_residual!, global_quantities.jl:67-86)
+    zt = np.random.default_rng(9).random((g.B, g.traj_len)); zt[:, :g.n] = g.get_traj()[:, :g.n]
+    g.set_traj(zt, 1); o.set_traj(zt, 1)
+    rg, ng = g.residual(1, 0.37); ro, no = o.residual(1, 0.37)
+    assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max())
+    assert np.allclose(ng, no, rtol=1e-13, atol=0)
+    # record! scalars (statistics.jl:44-57)
+    a, b = g.record(), o.record()
+    for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+        assert np.allclose(a[f], b[f], rtol=1e-12, atol=1e-15), f
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_jacobian_parity(alg, orc, case):
+    g, o = _pair(alg, orc, *case, B=2)
+    for reg in (0.0, 1e-3 * 3 ** 4):
+        Jg, Jo = g.residual_jacobian(reg), o.residual_jacobian(reg)
+        assert (Jg != 0).sum() > 0
+        assert np.array_equal(Jg != 0, Jo != 0) or np.abs(Jg - Jo).max() <= 1e-12 * np.abs(Jo).max()
+        assert np.abs(Jg - Jo).max() <= 1e-12 * np.abs(Jo).max()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_newton_direction_parity(alg, orc, case):
+    g, o = _pair(alg, orc, *case, B=4)
+    for reg in (1e-3, 1e-7 * 2 ** 4):
+        dg, sg = g.newton_direction(reg); do, so = o.newton_direction(reg)
+        assert np.all(sg == 0) and np.all(so == 0)
+        scale = np.abs(do).max(axis=1, keepdims=True)
+        assert (np.abs(dg - do) / scale).max() < 1e-9
+        # and it really solves the reference's linear system J d = -res
+        J = o.residual_jacobian(reg); res = o.residual()[0]
+        lin = np.einsum("brc,bc->br", J, dg) + res
+        assert np.abs(lin).max() <= 1e-8 * max(1.0, np.abs(res).max())
+        # Δpdtraj buffer (set_traj!, primal_dual_traj.jl:46-75): x_1 slot zero
+        zd = g.get_traj(2)
+        assert np.all(zd[:, :g.n] == 0) and np.array_equal(zd[:, g.n:], dg)
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[6], CASES[8]])
+def test_line_search_and_update_parity(alg, orc, case):
+    g, o = _pair(alg, orc, *case, B=6, seed=3)
+    reg = 1e-3
+    dg, _ = g.newton_direction(reg); do, _ = o.newton_direction(reg)
+    # same direction in both so that only the line search is compared
+    zd = np.zeros((g.B, g.traj_len)); zd[:, g.n:] = do
+    g.set_traj(zd, 2); o.set_traj(zd, 2)
+    rn = o.residual()[1]
+    ag, jg = g.line_search(rn, reg); ao, jo = o.line_search(rn, reg)
+    assert np.array_equal(jg, jo) and np.array_equal(ag, ao)
+    # an unreachable target forces the failure branch: j == ls_iter, alpha = 0.5^24 (solver_methods.jl:111-124)
+    ag, jg = g.line_search(1e-30 * rn, reg); ao, jo = o.line_search(1e-30 * rn, reg)
+    assert np.all(jg == 25) and np.array_equal(jg, jo) and np.all(ag == 0.5 ** 24) and np.array_equal(ag, ao)
+    g.update_traj(ao, 0, 0); o.update_traj(ao, 0, 0)
+    assert np.array_equal(g.get_traj(0), o.get_traj(0))      # update_traj! is a plain axpy: bitwise equal
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[6], CASES[7]])
+def test_inner_iteration_parity(alg, orc, case):
+    g, o = _pair(alg, orc, *case, B=4, seed=5)
+    for l in (1, 2):
+        ig, io = g.newton_step(1, l), o.newton_step(1, l)
+        for f in ("status", "control_flow", "ls_j", "ls_failed"):
+            assert np.array_equal(ig[f], io[f]), f
+        assert np.array_equal(ig["alpha"], io["alpha"])
+        assert np.allclose(ig["delta"], io["delta"], rtol=1e-9)
+        for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+            assert np.allclose(ig["rec"][f], io["rec"][f], rtol=1e-9, atol=1e-14), f
+        zg, zo = g.get_traj(0), o.get_traj(0)
+        assert np.abs(zg - zo).max() <= 1e-9 * max(1.0, np.abs(zo).max())
+
+
+def test_dual_penalty_update_and_reset_parity(alg, orc):
+    for case in (CASES[2], CASES[8]):
+        g, o = _pair(alg, orc, *case, B=3, seed=7)
+        for b in (g, o):
+            b.set_options(rho_increase=7.0, rho_max=50.0, lambda_max=1.5, alpha_dual=0.7, alphax_dual=[0.5, 1.0, 1.5, 2.0] + [1.0] * 6)
+        vg, vo = g.dual_penalty_update(), o.dual_penalty_update()
+        fin = np.isfinite(vo)
+        assert np.array_equal(np.isfinite(vg), fin) and np.abs(vg[fin] - vo[fin]).max() < 1e-14
+        (lg, mg), (lo, mo) = g.get_con_duals(), o.get_con_duals()
+        assert np.abs(lg - lo).max() < 1e-14 and np.array_equal(mg, mo)
+        g.reset_con(); o.reset_con()
+        (lg, mg), (lo, mo) = g.get_con_duals(), o.get_con_duals()
+        assert np.all(lg == 0) and np.array_equal(mg, mo) and np.all(mg == 1.0)
+
+
+def test_init_traj_and_rollout_parity(alg, orc):
+    for case in (CASES[2], CASES[7]):
+        g, o = _pair(alg, orc, *case, B=4, seed=11)
+        g.init_traj(game_id0=1000); o.init_traj(game_id0=1000)
+        zg, zo = g.get_traj(0), o.get_traj(0)
+        Xg, Ug, Lg = g.split_traj(zg); Xo, Uo, Lo = o.split_traj(zo)
+        assert np.array_equal(Ug, Uo) and np.array_equal(Lg, Lo)          # counter RNG: bit-identical
+        assert np.all(Ug > 0) and np.all(Ug < 1e-8)
+        assert np.abs(Xg - Xo).max() < 1e-14                              # RK3 rollout (solver_methods.jl:17)
+        # shift warm start (primal_dual_traj.jl:29-44), shift = 2
+        for b in (g, o):
+            b.set_options(shift=2)
+            b.set_traj(zo + 0.25, 0)
+            b.init_traj(game_id0=1000, use_shift=True)
+        Xg, Ug, Lg = g.split_traj(g.get_traj(0)); Xo, Uo, Lo = o.split_traj(o.get_traj(0))
+        assert np.array_equal(Ug, Uo) and np.array_equal(Lg, Lo)
+        assert np.array_equal(Uo[:, 0], (g.split_traj(zo + 0.25)[1])[:, 2])
+        assert np.abs(Xg - Xo).max() < 1e-13
+
+
+def _solve_pair(alg, orc, cfg, ids, **kw):
+    pg = alg.scenarios.make_problem(cfg, ids, **kw)
+    po = alg.scenarios.make_problem(cfg, ids, backend=orc.lib(), **kw)
+    alg.newton_solve(pg); alg.newton_solve(po)
+    return pg, po
+
+
+def _assert_solve_parity(pg, po):
+    sg, so = pg.stats.summary, po.stats.summary
+    for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]), (f, sg[f], so[f])
+    for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+        assert np.allclose(sg["last"][f], so["last"][f], rtol=1e-9, atol=1e-9), f
+    Xg, Ug, Lg = pg.batch.split_traj(pg.batch.get_traj()); Xo, Uo, Lo = po.batch.split_traj(po.batch.get_traj())
+    assert np.abs(Xg - Xo).max() <= 1e-8 and np.abs(Ug - Uo).max() <= 1e-8
+    assert np.abs(Lg - Lo).max() <= 1e-6 * max(1.0, np.abs(Lo).max())
+    (lg, mg), (lo, mo) = pg.batch.get_con_duals(), po.batch.get_con_duals()
+    assert np.array_equal(mg, mo)
+    assert np.abs(lg - lo).max() <= 1e-6 * max(1.0, np.abs(lo).max())
+    for game in (0, len(sg) - 1):
+        hg, ho = pg.stats.history(game), po.stats.history(game)
+        assert len(hg) == len(ho)
+        assert np.array_equal(hg["outer"], ho["outer"]) and np.array_equal(hg["ls_j"], ho["ls_j"]) and np.array_equal(hg["alpha"], ho["alpha"])
+        assert np.allclose(hg["res"], ho["res"], rtol=1e-7, atol=1e-12)
+
+
+def test_newton_solve_parity_c2_small_horizon(alg, orc):
+    pg, po = _solve_pair(alg, orc, "C2", np.arange(40, 56), N=12)
+    _assert_solve_parity(pg, po)
+    assert np.all(pg.stats.summary["converged"] == 1)
+
+
+def test_newton_solve_parity_c2_full_horizon(alg, orc):
+    # BASELINE config C2 (3-player DoubleIntegrator, N = 40) on a 24-game slice of the 4096 scenarios
+    pg, po = _solve_pair(alg, orc, "C2", np.arange(4072, 4096))
+    _assert_solve_parity(pg, po)
+    s = pg.stats.summary
+    assert np.all(s["converged"] == 1) and np.all(s["status"] == 0)
+    assert np.all(s["last"]["opt_vio"] < 1e-3) and np.all(s["last"]["sta_vio"] < 1e-3) and np.all(s["last"]["dyn_vio"] < 1e-3)
+
+
+def test_reference_e2e_thresholds_on_gpu(alg):
+    """The five newton_solve! problems of test/problem/solver_methods.jl run through the product path."""
+    def problem(model, x0, opts, constrained=False):
+        N, dt, p = 20, 0.1, model.p
+        obj = alg.GameObjective([np.ones(model.ni[i]) for i in range(p)], [0.5 * np.ones(model.mi[i]) for i in range(p)],
+                                [np.zeros(model.ni[i]) for i in range(p)], [-np.ones(model.mi[i]) for i in range(p)], N, model)
+        con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+        if constrained:
+            alg.add_collision_avoidance(con, 0.05)
+            alg.add_control_bound(con, np.ones(model.m), -np.ones(model.m))
+        return alg.GameProblem(N, dt, x0, model, opts, obj, con)
+
+    def tight(opts, outer, inner):
+        opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = outer, inner, 25, 1e-7, 1e-10, 1e-10
+
+    for model, x0, outer, inner in ((alg.DoubleIntegratorGame(p=1), [1.0, 1.0, 0.0, 0.9], 1, 1),                      # :6-34
+                                    (alg.UnicycleGame(p=1), [1.0, 1.0, 0.0, 0.9], 7, 20),                              # :36-65
+                                    (alg.DoubleIntegratorGame(p=2), [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9], 1, 1),   # :68-97
+                                    (alg.UnicycleGame(p=2), [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9], 7, 20)):         # :100-129
+        opts = alg.Options(inner_print=False, outer_print=False)
+        prob = problem(model, x0, opts)
+        tight(opts, outer, inner)
+        alg.newton_solve(prob)
+        res = alg.residual(prob)
+        assert np.abs(res).sum() / res.shape[1] < 1e-6
+        assert alg.dynamics_violation(prob)[0] < 1e-6
+    opts = alg.Options(inner_print=False, outer_print=False)                                                         # :132-182
+    tight(opts, 7, 20)
+    prob = problem(alg.UnicycleGame(p=2), [1.0, 2.0, 1.1, 2.0, 0.0, 0.0, 0.9, 0.9], opts, constrained=True)
+    alg.newton_solve(prob)
+    last = prob.stats.summary["last"][0]
+    assert np.abs(alg.residual(prob)).sum() / prob.probsize.S < 1e-3
+    assert max(last["dyn_vio"], last["sta_vio"], last["con_vio"], last["opt_vio"]) < 1e-3
+
+
+def test_full_size_c2_properties(alg):
+    """BASELINE config C2 at full size (4096 games): size-independent properties.
+    (1) every game converges to the reference's exit test; (2) the run is deterministic;
+    (3) a game's result does not depend on its position in the batch / the batch it is solved with."""
+    ids = np.arange(4096)
+    prob = alg.scenarios.make_problem("C2", ids)
+    alg.newton_solve(prob)
+    s = prob.stats.summary
+    assert np.all(s["status"] == 0) and np.all(s["converged"] == 1)
+    assert np.all(s["last"]["opt_vio"] < 1e-3) and np.all(s["last"]["sta_vio"] < 1e-3)
+    assert np.all(s["last"]["dyn_vio"] < 1e-3) and np.all(s["last"]["con_vio"] < 1e-3)
+    z1 = prob.batch.get_traj()
+    alg.newton_solve(prob)
+    assert np.array_equal(prob.batch.get_traj(), z1)                       # deterministic, restartable
+    sub = alg.scenarios.make_problem("C2", np.arange(1000, 1064))
+    alg.newton_solve(sub)
+    assert np.array_equal(sub.batch.get_traj(), z1[1000:1064])
+    assert np.array_equal(sub.stats.summary["newton_iters"], s["newton_iters"][1000:1064])
+    # generalized-Nash structure: dynamics satisfied, collision-avoidance multipliers non-negative
+    lam, _ = prob.batch.get_con_duals()
+    assert lam.min() >= 0.0

@@ -1,0 +1,129 @@
+# AlgamesHIP.jl -- Julia host shim over the C ABI of libalgames_hip.so (include/algames_hip.h).
+#
+# UNEXECUTED IN THIS ENVIRONMENT: neither the build container nor the GPU box has a `julia` binary
+# (SURVEY.md section 0), so this file is the binding a maintainer of Algames.jl would add; every call it makes
+# is exercised through the identical ctypes binding (algames.jl_amd/_abi.py) by the test-suite.
+#
+# It keeps the reference API surface for the hot path: `GameProblem` / `Options` are the reference's own
+# types; `newton_solve!(probs::Vector{<:GameProblem})` solves a batch of structurally identical problems
+# on one MI355X and writes the results back into each `prob.pdtraj`, the constraint multipliers and
+# `prob.stats` -- replacing src/problem/solver_methods.jl:5-65 for that batch.
+module AlgamesHIP
+
+using Algames
+using StaticArrays
+import Algames: newton_solve!
+
+const LIB = get(ENV, "ALGAMES_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libalgames_hip.so"))
+
+struct AlgDesc
+    model::Int32; p::Int32; d::Int32; N::Int32
+    dt::Float64
+    batch::Int32; device::Int32
+end
+
+struct AlgOptions                      # POD mirror of include/algames_hip.h: alg_options
+    amplitude_init::Float64; shift::Int32; regularize::Int32
+    reg_0::Float64; alpha_decrease::Float64; beta::Float64
+    ls_iter::Int32; dual_reset::Int32; delta_min::Float64
+    rho_0::Float64; rho_increase::Float64; rho_max::Float64; lambda_max::Float64; alpha_dual::Float64
+    alphax_dual::NTuple{10,Float64}
+    eps_dyn::Float64; eps_sta::Float64; eps_con::Float64; eps_opt::Float64
+    outer_iter::Int32; inner_iter::Int32
+    seed::Int64
+end
+
+struct AlgRecord
+    outer::Int32; ls_j::Int32
+    alpha::Float64; res::Float64; delta::Float64
+    dyn_vio::Float64; con_vio::Float64; sta_vio::Float64; opt_vio::Float64
+end
+
+struct AlgGameStats
+    status::Int32; outer_iters::Int32; newton_iters::Int32; records::Int32; converged::Int32; ls_failures::Int32
+    last::AlgRecord
+end
+
+check(rc) = rc == 0 || error(unsafe_string(ccall((:alg_last_error, LIB), Cstring, ())))
+
+model_id(::DoubleIntegratorGame) = Int32(0)
+model_id(::UnicycleGame) = Int32(1)
+
+function abi_options(o::Options)
+    ax = ntuple(i -> i <= length(o.αx_dual) ? Float64(o.αx_dual[i]) : 1.0, 10)
+    AlgOptions(o.amplitude_init, min(o.shift, 2^30), o.regularize, o.reg_0, o.α_decrease, o.β, o.ls_iter,
+               o.dual_reset, o.Δ_min, o.ρ_0, o.ρ_increase, o.ρ_max, o.λ_max, o.α_dual, ax,
+               o.ϵ_dyn, o.ϵ_sta, o.ϵ_con, o.ϵ_opt, o.outer_iter, o.inner_iter, o.seed)
+end
+
+"""
+    newton_solve!(probs::Vector{<:GameProblem}; device=0, game_id0=0)
+
+Batched drop-in for `newton_solve!(prob)` (src/problem/solver_methods.jl:5-65).  All problems must share
+model, N, dt, options and constraint structure (collision avoidance radii, control bounds, collision cost);
+they may differ in x0 and in the LQR data.
+"""
+function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0::Integer=0)
+    prob = probs[1]; ps = prob.probsize; B = length(probs)
+    N, n, m, p = ps.N, ps.n, ps.m, ps.p
+    ni, mi = ps.ni[1], ps.mi[1]
+    d = prob.model isa DoubleIntegratorGame ? mi : 2
+    dt = prob.pdtraj.pr[1].dt
+    desc = Ref(AlgDesc(model_id(prob.model), p, d, N, dt, B, device))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:alg_create, LIB), Cint, (Ref{AlgDesc}, Ref{Ptr{Cvoid}}), desc, h))
+    try
+        check(ccall((:alg_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{AlgOptions}), h[], Ref(abi_options(prob.opts))))
+        # x0: B x n, game-major (Julia is column-major: build n x B)
+        x0 = hcat([Vector(pr.x0) for pr in probs]...)
+        check(ccall((:alg_set_x0, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], x0))
+        # LQR data from game_obj.obj[i][1] (LQRCost: Q diagonal, q = -Q xf), per game: (ni x p x B) in memory order
+        Qd = zeros(ni, p, B); Rd = zeros(mi, p, B); xf = zeros(ni, p, B); uf = zeros(mi, p, B)
+        for (g, pr) in enumerate(probs), i in 1:p
+            c = pr.game_obj.obj[i][1].cost[1]
+            Qfull = diag(c.Q); Rfull = diag(c.R)
+            Qd[:, i, g] = Qfull[ps.pz[i]]; Rd[:, i, g] = Rfull[ps.pu[i]]
+            xf[:, i, g] = -(c.q ./ map(x -> x == 0 ? 1.0 : x, Qfull))[ps.pz[i]]
+            uf[:, i, g] = -(c.r ./ map(x -> x == 0 ? 1.0 : x, Rfull))[ps.pu[i]]
+        end
+        check(ccall((:alg_set_lqr, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32),
+                    h[], Qd, Rd, xf, uf, 1))
+        # collision costs: game_obj.obj[i][2:end] are CollisionCost objectives (objective.jl:84-100)
+        if length(prob.game_obj.obj[1]) > 1
+            rad = [prob.game_obj.obj[i][2].cost[1].r for i in 1:p]
+            mu = [prob.game_obj.obj[i][2].cost[1].μ for i in 1:p]
+            check(ccall((:alg_add_collision_cost, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], rad, mu))
+        end
+        # collision avoidance: state_conval[i][q].con.radius = r_i + r_j (constraints_methods.jl:27-29)
+        if p > 1 && !isempty(prob.game_con.state_conval[1])
+            R12 = prob.game_con.state_conval[1][1].con.radius          # r_1 + r_2
+            R1p = p > 2 ? prob.game_con.state_conval[1][2].con.radius : R12
+            R2p = p > 2 ? prob.game_con.state_conval[2][2].con.radius : R12
+            r1 = p > 2 ? (R12 + R1p - R2p) / 2 : R12 / 2
+            radius = [i == 1 ? r1 : prob.game_con.state_conval[1][i-1].con.radius - r1 for i in 1:p]
+            check(ccall((:alg_add_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], radius))
+        end
+        if !isempty(prob.game_con.control_conval)
+            con = prob.game_con.control_conval[1].con
+            check(ccall((:alg_add_control_bound, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[],
+                        Vector(con.u_max), Vector(con.u_min)))
+        end
+        stats = Vector{AlgGameStats}(undef, B)
+        check(ccall((:alg_newton_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{AlgGameStats}), h[], 1, game_id0, stats))
+        # write back: pdtraj (x_1 | horizontal-order vector, primal_dual_traj.jl:46-75), multipliers, stats
+        S = ps.S
+        z = zeros(n + S, B)
+        check(ccall((:alg_get_traj, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), h[], 0, z))
+        for (g, pr) in enumerate(probs)
+            Algames.set_traj!(pr.core, pr.pdtraj, view(z, n+1:n+S, g))
+            Algames.RobotDynamics.set_state!(pr.pdtraj.pr[1], SVector{n}(z[1:n, g]))
+        end
+        # (constraint multipliers lambda / mu: alg_get_con_duals, layout documented in include/algames_hip.h;
+        #  Statistics history: alg_get_history -> record!(stats, ...) with the stored scalars)
+        return stats
+    finally
+        ccall((:alg_destroy, LIB), Cvoid, (Ptr{Cvoid},), h[])
+    end
+end
+
+end # module

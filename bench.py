@@ -80,8 +80,9 @@ def main():
     ids = np.arange(rank * G, (rank + 1) * G)                       # contiguous global scenario ids
     prob = alg.scenarios.make_problem(args.config, ids, device=local_rank)
     b = prob.batch
-    stream = torch.cuda.current_stream()
-    b.set_stream(stream.cuda_stream)                                # kernels run on torch's current stream
+    stream = torch.cuda.Stream()                                    # a real (non-NULL) HIP stream owned by torch
+    torch.cuda.set_stream(stream)
+    b.set_stream(stream.cuda_stream)                                # the library launches on this stream
     prob._sync_options()
 
     def barrier():
@@ -171,7 +172,7 @@ def cpu_baseline(alg, cfg, G):
     import oracle as orc
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    nsample = int(min(G, max(8, 4 * cores)))
+    nsample = int(min(G, max(8, 16 * cores)))
     prob = alg.scenarios.make_problem(cfg, np.arange(nsample), backend=orc.lib())
     t0 = time.perf_counter()
     alg.newton_solve(prob)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: prof_run.sh <tag> [bench args...]   -- run on the GPU box via gpurun; writes gpurun_out/<tag>/
+set -u
+TAG=$1; shift
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- $BENCH > $OUT/bench_write.json 2> $OUT/write.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- $BENCH > $OUT/bench_sq.json 2> $OUT/sq.err
+cd $R
+python bench.py --steps 5 --warmup 2 $* > $OUT/bench.json 2> $OUT/bench.err
+find $OUT -name "*.csv" | head -20
+tail -c 600 $OUT/bench.json

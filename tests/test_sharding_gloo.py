@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world_size-2 `gloo` run of the scenario sharding.
+Games are independent, so the multi-GPU path is: contiguous shards of global scenario ids, one rank per
+device, no data-path collective, one final reduction of the counters.  Here each rank solves its shard with
+the CPU oracle standing in for the device (the oracle is test infrastructure) and the reduced counters and
+gathered trajectories must equal the single-process solve of the whole batch -- i.e. inputs depend only on
+global scenario ids and the reduction is what bench.py does."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch, torch.distributed as dist
+import algames_jl_amd as alg, oracle as orc
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+TOTAL = 10
+lo, hi = alg.scenarios.shard_range(TOTAL, rank, world)
+prob = alg.scenarios.make_problem("C2", np.arange(lo, hi), N=10, backend=orc.lib())
+alg.newton_solve(prob)
+s = prob.stats.summary
+cnt = torch.tensor([int(s["newton_iters"].sum()), int(s["converged"].sum()), hi - lo], dtype=torch.int64)
+dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+z = torch.from_numpy(prob.batch.get_traj())
+per = (TOTAL + world - 1) // world
+pad = torch.zeros(per, z.shape[1], dtype=torch.float64); pad[: z.shape[0]] = z
+out = [torch.zeros_like(pad) for _ in range(world)]
+dist.all_gather(out, pad)
+if rank == 0:
+    full = alg.scenarios.make_problem("C2", np.arange(TOTAL), N=10, backend=orc.lib())
+    alg.newton_solve(full)
+    fs = full.stats.summary
+    zall = torch.cat(out)[:TOTAL].numpy()
+    assert cnt.tolist() == [int(fs["newton_iters"].sum()), int(fs["converged"].sum()), TOTAL], (cnt, fs["newton_iters"].sum())
+    assert np.array_equal(zall, full.batch.get_traj())
+    print("SHARDING_OK", cnt.tolist())
+dist.destroy_process_group()
+'''
+
+
+def test_shard_range_partitions():
+    import algames_jl_amd as alg
+    for total, world in ((4096, 1), (65536, 8), (10, 3), (7, 8)):
+        cuts = [alg.scenarios.shard_range(total, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        assert all(lo <= hi for lo, hi in cuts)
+
+
+def test_scenarios_depend_only_on_global_id():
+    import algames_jl_amd as alg
+    a = alg.scenarios.c2_double_integrator(np.arange(0, 64))[3]
+    b = alg.scenarios.c2_double_integrator(np.arange(32, 64))[3]
+    assert np.array_equal(a[32:], b)
+    c = alg.scenarios.c3_unicycle(np.arange(5, 9))[3]
+    d = alg.scenarios.c3_unicycle(np.arange(0, 9))[3]
+    assert np.array_equal(c, d[5:])
+
+
+def test_world_size_2_gloo_sharded_solve(orc):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    code = "ROOT = %r\n" % ROOT + WORKER
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", "--no-python", sys.executable, "-c", code]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "SHARDING_OK" in out.stdout

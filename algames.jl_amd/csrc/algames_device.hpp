@@ -3,15 +3,18 @@
 // Execution model: ONE GAME PER WAVEFRONT (workgroup = 64 threads = 1 wave).  Games are independent
 // (SURVEY.md 8(e)), so every wave runs its own solver state machine; no inter-workgroup traffic.
 //
-//  * streaming phases (residual / statistics / line-search trials / updates): lane k owns time step k
-//    ("lane-per-knot"), everything in registers, wave shuffles for the ||.||_1 / max reductions.
-//  * Newton direction: the KKT system of solver_methods.jl:87 is never materialised.  Its
-//    block-tridiagonal structure is eliminated by a structured block LU in the order
-//    (u_k via R^, lambda_k via -I, x_{k+1} via an m x m pivoted solve) -- a game-theoretic Riccati
-//    sweep: backward over k with per-player value matrices P_i (n x n) in LDS, a partial-pivot
-//    Gauss-Jordan of the m x m control system, feedback gains spilled to HBM (m*(n+1) doubles per
-//    step instead of the b^2 + b*p*n of a dense block LU), forward sweep for (dx, du), backward
-//    costate sweep for dlambda.
+//  * assemble pass (residual / statistics / line-search trials): work item = (knot k, player i); rows are formed in
+//    registers, wave shuffles give ||.||_1 and the violation maxima, and (for the Newton direction) one compact
+//    "step record" per knot is left in HBM: Jacobian coefficients, pair Hessian blocks, R^, and the residual rows.
+//  * Newton direction: the KKT system of solver_methods.jl:87 is never materialised.  Its block-tridiagonal
+//    structure is eliminated by a structured block LU in the order (u_k via R^, lambda_k via -I,
+//    x_{k+1} via an m x m pivoted solve) -- a game-theoretic Riccati sweep.  Backward over k: the per-player value
+//    matrices P_i (n x n, LDS) are advanced with two chained v_mfma_f64_16x16x4_f64 products per player
+//    ([P_i F | P_i f + s_i], then A' x that + [Q^_i | rx_i]); the m x m control system is LU-factored with partial
+//    pivoting redundantly in every lane's registers (wave-uniform pivots, no cross-lane traffic) and each lane
+//    back-substitutes its own right-hand-side column; gains go to HBM (m (n+1) doubles per step instead of the
+//    b^2 + b p n of a dense block LU).  Then a forward sweep for (dx, du) and a backward costate sweep for dlambda.
+//    Records and gains are prefetched one step ahead into a double-buffered LDS slot.
 //
 // Reference citations are relative to /root/reference.
 #pragma once
@@ -36,6 +39,7 @@ struct Params {
     double umax[MAXM], umin[MAXM];
     int hist_max;
     int kscratch_len;       // per game doubles of gain scratch
+    int rec_len;            // per game doubles of step records
 };
 
 // Device pointers of a handle (all game-major).
@@ -44,8 +48,9 @@ struct Buffers {
     double* x0;             // B x n
     double* Qd; double* Rd; double* xf; double* uf;   // [B|1] x p x ni / mi (compact, own indices)
     double* lam; double* mu; double* vals;            // B x con_len
-    double* res;            // B x S     residual scratch (vertical order)
-    double* kgain;          // B x kscratch_len
+    double* res;            // B x S     residual in vertical order (alg_residual output only)
+    double* rec;            // B x (N-1) x Rec::LEN  step records (assemble pass -> direction sweeps)
+    double* kgain;          // B x kscratch_len      feedback gains (backward sweep -> forward sweep)
     alg_game_stats* stats;  // B
     alg_record* hist;       // B x hist_max
 };
@@ -59,7 +64,7 @@ struct Cfg {
     static constexpr int ni = n / P_;
     static constexpr int b = n + m + P_ * n;
     static constexpr int NPAIR = P_ * (P_ - 1);
-    static constexpr int NC = 4 * P_;            // Jacobian coefficients per knot
+    static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
     static constexpr int WC = m + n + 1;         // augmented width of the control system
 };
 
@@ -270,7 +275,7 @@ struct Game {
     const double* x0;
     const double* Qd; const double* Rd; const double* xf; const double* uf;
     double* lam; double* mu; double* vals;
-    double* res; double* kgain;
+    double* res; double* rec; double* kgain;
     alg_game_stats* st; alg_record* hist;
 };
 __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, int g) {
@@ -281,7 +286,7 @@ __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, i
     G.Qd = bf.Qd + gq * pr.p * pr.ni; G.xf = bf.xf + gq * pr.p * pr.ni;
     G.Rd = bf.Rd + gq * pr.p * pr.mi; G.uf = bf.uf + gq * pr.p * pr.mi;
     G.lam = bf.lam + (size_t)g * pr.con_len; G.mu = bf.mu + (size_t)g * pr.con_len; G.vals = bf.vals + (size_t)g * pr.con_len;
-    G.res = bf.res + (size_t)g * pr.S; G.kgain = bf.kgain + (size_t)g * pr.kscratch_len;
+    G.res = bf.res + (size_t)g * pr.S; G.rec = bf.rec + (size_t)g * pr.rec_len; G.kgain = bf.kgain + (size_t)g * pr.kscratch_len;
     G.st = bf.stats + g; G.hist = bf.hist + (size_t)g * pr.hist_max;
     return G;
 }
@@ -289,165 +294,186 @@ __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, i
 // Altro 0.3.0 cost_expansion!: a = (c >= 0) | (lambda > 0)  [PINNED test/constraints/constraint_derivatives.jl:28-34]
 __device__ __forceinline__ double al_active_mu(double c, double lam, double mu) { return ((c >= 0.0) || (lam > 0.0)) ? mu : 0.0; }
 
-// Collision terms of the ordered pair (i,j) at state x of knot kn (0-based).  gv[2]: contribution of the pair to row
-// opt_i at px(i,.) (the contribution at px(j,.) is -gv); H[3] = (H00,H01,H11): symmetric 2x2 block with sign pattern
-// [[+H,-H],[-H,+H]] on (px[i],px[j]).  Cost part: CollisionCost gradient/Hessian (objective.jl:134-173) scaled by
-// w = dt (stage) or 1 (terminal) (TrajOpt cost_gradient!/cost_hessian!); constraint part: CollisionConstraint
-// c = R^2 - |d|^2, C = [-2d', 2d'] with the AL expansion grad = C'(lam + a mu c), hess = a mu C'C.
-template <class C>
-__device__ __forceinline__ void pair_terms(const Params& pr, const Game& G, int i, int j, const double* x, int kn,
-                                           double* gv, double* H, double* cval) {
-    const double dl0 = x[i] - x[j], dl1 = x[C::P + i] - x[C::P + j];
-    const double s2 = dl0 * dl0 + dl1 * dl1;
-    gv[0] = gv[1] = 0.0; H[0] = H[1] = H[2] = 0.0;
-    if (pr.has_colcost) {
-        const double w = (kn < pr.N - 1) ? pr.dt : 1.0;
-        const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
-        if (fmax(0.0, rad - nrm) > 0.0) {
-            const double eps = 1e-10, eps_norm = eps * sqrt((double)C::n);
-            const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
-            const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
-            gv[0] += w * (-g0); gv[1] += w * (-g1);
-            const double n3 = nrm * nrm * nrm;
-            H[0] += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
-            H[1] += w * (mu * (rad * (dl0 * dl1) / n3));
-            H[2] += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
-        }
-    }
-    if (pr.has_colavoid) {
-        const double R = pr.ca_radius[i] + pr.ca_radius[j];
-        const double c = R * R - s2;
-        const int ci = con_col<C>(pr.N, pairq<C>(i, j), kn);
-        const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
-        const double wl = lm + am * c;
-        gv[0] += -2.0 * dl0 * wl; gv[1] += -2.0 * dl1 * wl;
-        H[0] += am * 4.0 * dl0 * dl0; H[1] += am * 4.0 * dl0 * dl1; H[2] += am * 4.0 * dl1 * dl1;
-        if (cval) *cval = c;
-    }
-}
+// ================================================================================================
+// Step records.  The assemble pass (parallel over knots) leaves one compact record per time step k in HBM;
+// the serial sweeps of the Newton direction read nothing else (plus the gains they spill themselves).
+//   [coefk (NC)] [Hh (3 NPAIR): pair Hessian blocks at knot k+1] [Rhat (m): R^ of knot k incl. reg]
+//   [rx (P n): rows opt_i,x_{k+1}] [ru (m): rows opt_i,u_{i,k}, joint control order] [rd (n): dyn_k]
+// ================================================================================================
+template <class C> struct Rec {
+    static constexpr int COEF = 0;
+    static constexpr int HH = COEF + C::NC;
+    static constexpr int RHAT = HH + 3 * C::NPAIR;
+    static constexpr int RX = RHAT + C::m;
+    static constexpr int RU = RX + C::P * C::n;
+    static constexpr int RD = RU + C::m;
+    static constexpr int LEN = RD + C::n;
+};
 
 // ================================================================================================
-// Streaming phase: residual! + regularize_residual! + the scalars of record! (lane-per-knot)
-//   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl
+// Assemble pass: residual! + regularize_residual! + the scalars of record! (+ step records)
+//   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl.   Work item = (knot k, player i).
+//   MODE 0: statistics only (line-search trials)   MODE 1: + step records (Newton direction input)
+//   MODE 2: + residual vector in the reference's vertical order (alg_residual)
 // ================================================================================================
 struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; };
 
-template <class C, bool WRITE>
-__device__ void residual_pass(const Params& pr, const Game& G, const double* z, const double* zref, double reg,
-                              double* res_out, ResOut& out) {
+template <class C, int MODE>
+__device__ void assemble_pass(const Params& pr, const Game& G, const double* z, const double* zref, double reg,
+                              double jreg, ResOut& out) {
     constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni;
+    using R = Rec<C>;
     const int N = pr.N, lane = threadIdx.x;
     const double dt = pr.dt;
     double l1 = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
-    for (int k = lane; k < N - 1; k += WAVE) {
-        // ---- load knot k and k+1 -----------------------------------------------------------------
-        double xk[n], uk[m], x1[n], u1[m];
+    const int items = (N - 1) * P;
+    // ---------------- phase 1: dynamics defect, Jacobian coefficients, control rows -------------------
+    for (int e = lane; e < items; e += WAVE) {
+        const int k = e / P, i = e % P;
+        double* rec = G.rec + (size_t)k * R::LEN;
         const double* sk = zstate<C>(z, k);
-        const double* s1 = z + n + hx<C>(k);
+        double xi[ni], ui[mi], xo[ni], co[4];      // this player's own state / control entries
 #pragma unroll
-        for (int a = 0; a < n; a++) { xk[a] = sk[a]; x1[a] = s1[a]; }
+        for (int j = 0; j < ni; j++) xi[j] = sk[i + j * P];
 #pragma unroll
-        for (int c = 0; c < m; c++) uk[c] = z[n + hu<C>(k, 0) + uoff<C>(c)];
-        const bool has_next = (k + 1 <= N - 2);
-        if (has_next) {
+        for (int j = 0; j < mi; j++) ui[j] = z[n + hu<C>(k, i) + j];
+        // own-player dynamics (players are decoupled)
+        if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
-            for (int c = 0; c < m; c++) u1[c] = z[n + hu<C>(k + 1, 0) + uoff<C>(c)];
+            for (int j = 0; j < C::D; j++) {
+                const double vm = xi[C::D + j] + (ui[j] * dt) * 0.5;
+                xo[j] = xi[j] + vm * dt; xo[C::D + j] = xi[C::D + j] + ui[j] * dt;
+            }
+            co[0] = co[1] = co[2] = co[3] = 0.0;
         } else {
+            const double thm = xi[2] + (ui[0] * dt) * 0.5, vm = xi[3] + (ui[1] * dt) * 0.5;
+            double sn, cs; sincos(thm, &sn, &cs);
+            xo[0] = xi[0] + (cs * vm) * dt; xo[1] = xi[1] + (sn * vm) * dt; xo[2] = xi[2] + ui[0] * dt; xo[3] = xi[3] + ui[1] * dt;
+            co[0] = -dt * vm * sn; co[1] = dt * cs; co[2] = dt * vm * cs; co[3] = dt * sn;
+            // coefficients are also needed by the rows of knot k-1 (A_k' lambda): publish through the record
 #pragma unroll
-            for (int c = 0; c < m; c++) u1[c] = 0.0;
+            for (int j = 0; j < 4; j++) rec[R::COEF + j * P + i] = co[j];
         }
-        // ---- dynamics of knot k (defect) and Jacobian coefficients of knots k, k+1 -----------------
-        double coefk[C::NC], coef1[C::NC], xn[n];
+        const double* x1 = z + n + hx<C>(k);
+        // dyn_k rows of this player: RK2(x_k,u_k) - x_{k+1}  (global_quantities.jl:60-63)
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            double xo[ni], co[4];
-            model_player<C>(i, xk, uk, dt, xo, co);
-#pragma unroll
-            for (int j = 0; j < ni; j++) xn[i + j * P] = xo[j];
-#pragma unroll
-            for (int j = 0; j < 4; j++) coefk[j * P + i] = co[j];
-            model_player<C>(i, x1, u1, dt, xo, co);
-#pragma unroll
-            for (int j = 0; j < 4; j++) coef1[j * P + i] = co[j];
-        }
-        // dyn_k = RK2(x_k,u_k) - x_{k+1}  (global_quantities.jl:60-63)
-#pragma unroll
-        for (int a = 0; a < n; a++) {
-            const double r = xn[a] - x1[a];
-            if (WRITE) res_out[vd<C>(N, k) + a] = r;
+        for (int j = 0; j < ni; j++) {
+            const double r = xo[j] - x1[i + j * P];
+            if (MODE >= 1) rec[R::RD + i + j * P] = r;
+            if (MODE == 2) G.res[vd<C>(N, k) + i + j * P] = r;
             l1 += fabs(r); vdyn = fmax(vdyn, fabs(r)); bad |= !isfinite(r);
         }
-        // ---- control-bound AL terms at knot k (constraint_derivatives.jl:61-72) --------------------
-        double gctl[m];
+        // rows opt_i,u_{i,k}: dt R_i (u - uf_i) + control-bound AL gradient + B_i' lambda_{i,k} (+ reg (u - uref))
+        const double* lk = z + n + hl<C>(k, i);
 #pragma unroll
-        for (int c = 0; c < m; c++) gctl[c] = 0.0;
-        if (pr.has_ctl) {
-#pragma unroll
-            for (int c = 0; c < m; c++) {
+        for (int j = 0; j < mi; j++) {
+            const int c = i + j * P;
+            double g = 0.0, rh = dt * G.Rd[i * mi + j] + jreg;
+            if (pr.has_ctl) {
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
-                    const int row = half * m + c, ci = con_ctl<C>(pr, k, row);
-                    const double cv = half == 0 ? uk[c] - pr.umax[c] : pr.umin[c] - uk[c];
+                    const int ci = con_ctl<C>(pr, k, half * m + c);
+                    const double cv = half == 0 ? ui[j] - pr.umax[c] : pr.umin[c] - ui[j];
                     G.vals[ci] = cv;
                     if (isfinite(cv)) {
-                        const double lm = G.lam[ci];
-                        const double wl = lm + al_active_mu(cv, lm, G.mu[ci]) * cv;
-                        gctl[c] += (half == 0 ? wl : -wl);
+                        const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
+                        const double wl = lm + am * cv;
+                        g += (half == 0 ? wl : -wl); rh += am;
                         vcon = fmax(vcon, fmax(0.0, cv));
                     }
                 }
             }
+            double bl;   // (B_i' lambda_{i,k})[c]
+            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) bl = 0.5 * dt * dt * lk[c] + dt * lk[c + m];
+            else bl = (j == 0) ? 0.5 * dt * (co[0] * lk[i] + co[2] * lk[P + i]) + dt * lk[2 * P + i]
+                               : 0.5 * dt * (co[1] * lk[i] + co[3] * lk[P + i]) + dt * lk[3 * P + i];
+            double r = dt * (G.Rd[i * mi + j] * (ui[j] - G.uf[i * mi + j])) + g + bl;
+            if (zref) r += reg * (ui[j] - zref[n + hu<C>(k, i) + j]);
+            if (MODE >= 1) { rec[R::RU + c] = r; rec[R::RHAT + c] = rh; }
+            if (MODE == 2) G.res[vu<C>(N, i, k) + j] = r;
+            l1 += fabs(r); vopt = fmax(vopt, fabs(r)); bad |= !isfinite(r);
         }
-        const int kn = k + 1;                                   // knot whose x rows this lane owns
-        const double w = (kn < N - 1) ? dt : 1.0;               // stage / terminal scaling
-        // ---- rows of every player ------------------------------------------------------------------
+    }
+    if constexpr (C::NC > 0) __syncthreads();      // coefficients of knot k+1 come from another lane's record write
+    // ---------------- phase 2: rows opt_i,x_{k+1} ------------------------------------------------------
+    for (int e = lane; e < items; e += WAVE) {
+        const int k = e / P, i = e % P, kn = k + 1;
+        double* rec = G.rec + (size_t)k * R::LEN;
+        const bool has_next = (kn <= N - 2);
+        const double* coef1 = G.rec + (size_t)(has_next ? kn : k) * R::LEN + R::COEF;     // coefficients of knot kn
+        const double* x1 = z + n + hx<C>(k);
+        const double* lk = z + n + hl<C>(k, i);
+        const double* ln = z + n + hl<C>(has_next ? kn : k, i);
+        const double* xr = zref ? zref + n + hx<C>(k) : nullptr;
+        const double w = (kn < N - 1) ? dt : 1.0;
+        // pair terms of the ordered pairs (i, j): positions of all players
+        double pos[2 * P];
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            const double* lk = z + n + hl<C>(k, i);
-            const double* l1p = z + n + hl<C>(has_next ? k + 1 : k, i);
-            double row[n];
-            // cost gradient q (objective.jl:43-61 + LQRCost): w * Q_i (x - xf_i) on pz[i]
+        for (int a = 0; a < 2 * P; a++) pos[a] = x1[a];
+        double gacc0 = 0.0, gacc1 = 0.0;          // contribution at px(i,.)
+        double gj[2 * (P > 1 ? P - 1 : 1)];       // minus-contributions at px(j,.) per pair slot
+        if (P > 1 && (pr.has_colcost || pr.has_colavoid)) {
 #pragma unroll
-            for (int a = 0; a < n; a++) row[a] = 0.0;
+            for (int jj = 0; jj < P - 1; jj++) {
+                const int j = jj < i ? jj : jj + 1;
+                double dl0 = 0, dl1 = 0;
+                // runtime (i, j): select positions without dynamic register indexing
 #pragma unroll
-            for (int j = 0; j < ni; j++) row[i + j * P] = w * (G.Qd[i * ni + j] * (x1[i + j * P] - G.xf[i * ni + j]));
-            // collision cost + collision avoidance of the ordered pairs (i,j)
-            if (pr.has_colcost || pr.has_colavoid) {
-#pragma unroll
-                for (int j = 0; j < P; j++) if (j != i) {
-                    double gv[2], H[3], cval = 0.0;
-                    pair_terms<C>(pr, G, i, j, x1, kn, gv, H, &cval);
-                    row[i] += gv[0]; row[P + i] += gv[1]; row[j] -= gv[0]; row[P + j] -= gv[1];
-                    if (pr.has_colavoid) { G.vals[con_col<C>(N, pairq<C>(i, j), kn)] = cval; vsta = fmax(vsta, fmax(0.0, cval)); }
+                for (int a = 0; a < P; a++) {
+                    dl0 += (a == i ? pos[a] : 0.0) - (a == j ? pos[a] : 0.0);
+                    dl1 += (a == i ? pos[P + a] : 0.0) - (a == j ? pos[P + a] : 0.0);
                 }
+                double gv0 = 0, gv1 = 0, H0 = 0, H1 = 0, H2 = 0;
+                const double s2 = dl0 * dl0 + dl1 * dl1;
+                if (pr.has_colcost) {
+                    const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+                    if (fmax(0.0, rad - nrm) > 0.0) {
+                        const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
+                        const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
+                        const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
+                        gv0 += w * (-g0); gv1 += w * (-g1);
+                        const double n3 = nrm * nrm * nrm;
+                        H0 += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
+                        H1 += w * (mu * (rad * (dl0 * dl1) / n3));
+                        H2 += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
+                    }
+                }
+                if (pr.has_colavoid) {
+                    const double Rr = pr.ca_radius[i] + pr.ca_radius[j];
+                    const double c = Rr * Rr - s2;
+                    const int ci = con_col<C>(N, pairq<C>(i, j), kn);
+                    const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
+                    const double wl = lm + am * c;
+                    gv0 += -2.0 * dl0 * wl; gv1 += -2.0 * dl1 * wl;
+                    H0 += am * 4.0 * dl0 * dl0; H1 += am * 4.0 * dl0 * dl1; H2 += am * 4.0 * dl1 * dl1;
+                    G.vals[ci] = c; vsta = fmax(vsta, fmax(0.0, c));
+                }
+                gacc0 += gv0; gacc1 += gv1; gj[2 * jj] = gv0; gj[2 * jj + 1] = gv1;
+                if (MODE >= 1) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
             }
-            // dynamics penalty: + A_{kn}' lambda_{i,kn} (kn <= N-2) - lambda_{i,k}  (global_quantities.jl:43-54)
-            if (has_next) {
+        } else if (P > 1 && MODE >= 1) {
 #pragma unroll
-                for (int a = 0; a < n; a++) row[a] += AT_vec<C>(coef1, dt, [&](int r) { return l1p[r]; }, a);
+            for (int jj = 0; jj < P - 1; jj++) { double* hh = rec + R::HH + 3 * (i * (P - 1) + jj); hh[0] = hh[1] = hh[2] = 0.0; gj[2 * jj] = gj[2 * jj + 1] = 0.0; }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < (P > 1 ? P - 1 : 1); jj++) gj[2 * jj] = gj[2 * jj + 1] = 0.0;
+        }
+        // stream over the n entries of the row
+#pragma unroll
+        for (int a = 0; a < n; a++) {
+            double r = -lk[a];
+            if (has_next) r += AT_vec<C>(coef1, dt, [&](int rr) { return ln[rr]; }, a);
+            const int owner = a % P, jblk = a / P;
+            if (owner == i) r += w * (G.Qd[i * ni + jblk] * (x1[a] - G.xf[i * ni + jblk]));      // LQR gradient on pz[i]
+            if (a < 2 * P && P > 1) {
+                const int ax = a / P;                                                              // 0: x, 1: y
+                if (owner == i) r += (ax == 0 ? gacc0 : gacc1);
+                else { const int jj = owner < i ? owner : owner - 1; r -= gj[2 * jj + ax]; }
             }
-#pragma unroll
-            for (int a = 0; a < n; a++) row[a] -= lk[a];
-            if (zref) {                                                        // regularize_residual! (:67-86)
-                const double* xr = zref + n + hx<C>(k);
-#pragma unroll
-                for (int a = 0; a < n; a++) row[a] += reg * (x1[a] - xr[a]);
-            }
-#pragma unroll
-            for (int a = 0; a < n; a++) {
-                if (WRITE) res_out[vx<C>(N, i, k) + a] = row[a];
-                l1 += fabs(row[a]); vopt = fmax(vopt, fabs(row[a])); bad |= !isfinite(row[a]);
-            }
-            // opt_i,u_{i,k}: dt R_i (u - uf_i)[pu[i]] + ctl grad[pu[i]] + B_i' lambda_{i,k} (+ reg (u - uref)[pu[i]])
-#pragma unroll
-            for (int j = 0; j < mi; j++) {
-                const int c = i + j * P;
-                double r = dt * (G.Rd[i * mi + j] * (uk[c] - G.uf[i * mi + j])) + gctl[c]
-                         + BT_vec<C>(coefk, dt, [&](int rr) { return lk[rr]; }, c);
-                if (zref) r += reg * (uk[c] - zref[n + hu<C>(k, 0) + uoff<C>(c)]);
-                if (WRITE) res_out[vu<C>(N, i, k) + j] = r;
-                l1 += fabs(r); vopt = fmax(vopt, fabs(r)); bad |= !isfinite(r);
-            }
+            if (xr) r += reg * (x1[a] - xr[a]);
+            if (MODE >= 1) rec[R::RX + i * n + a] = r;
+            if (MODE == 2) G.res[vx<C>(N, i, k) + a] = r;
+            l1 += fabs(r); vopt = fmax(vopt, fabs(r)); bad |= !isfinite(r);
         }
     }
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
@@ -476,250 +502,313 @@ __device__ __forceinline__ double delta_step(const Params& pr, const double* dz,
 // ================================================================================================
 // Newton direction: structured elimination of the KKT system (see file header)
 // ================================================================================================
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 template <class C>
 struct DirLds {
-    double Pm[C::P * C::n * C::n];     // P_i (row-major n x n per player)
-    double Tm[C::P * C::n * C::n];     // T_i = P_i F
-    double F[C::n * C::n];
-    double f[C::n];
+    static constexpr int LDP = C::n + 1;                 // padded row stride of P_i
+    static constexpr int KB = C::n / 4;                  // k-blocks of the 16x16x4 f64 MFMA
+    static_assert(C::n % 4 == 0 && C::n <= 16, "MFMA tile path needs n % 4 == 0 and n <= 16");
+    double Pm[C::P * C::n * LDP];      // P_i, row-major
+    double Fx[C::n * 16];              // [F | f | 0]: n x 16 (f in column n when n < 16)
+    double fv[C::n];
     double s[C::P * C::n];
     double t[C::P * C::n];
-    double xk[C::n], x1[C::n], uk[C::m], u1[C::m];
-    double coefk[C::NC], coefn[C::NC];
-    double gv[(C::NPAIR > 0 ? C::NPAIR : 1) * 2], Hh[(C::NPAIR > 0 ? C::NPAIR : 1) * 3];
-    double Rhat[C::m];
     double V[C::m * C::n];
-    double W[C::m * C::WC];
+    double W[C::m * C::m];
+    double rec[2][Rec<C>::LEN];
+    double kg[2][C::m * (C::n + 1)];
+    double coefn[C::NC > 0 ? C::NC : 1];
+    double qd[C::P * C::ni];
     double dx[C::n], du[C::m];
     double dl[C::P * C::n];
     int singular;
 };
 
-// Entry (r,c) of Q^_i = sum_j E[i][j].Q + state-constraint hess + reg I  at knot kn
+// (i,r,c) entry of the position block of Q^_i built from the pair Hessian table Hh (sign pattern [[+H,-H],[-H,+H]])
 template <class C>
-__device__ __forceinline__ double qhat_entry(const Params& pr, const Game& G, const DirLds<C>& L, int i, int r, int c, double w, double reg) {
+__device__ __forceinline__ double pairblock(const double* Hh, int i, int r, int c) {
     constexpr int P = C::P;
+    if (P == 1) return 0.0;
+    const int jr = r % P, ar = r / P, jc = c % P, ac = c / P, hidx = ar + ac;
     double e = 0.0;
-    if (r == c) {
-        e = reg;
-        if (r % P == i) e += w * G.Qd[i * C::ni + r / P];
-    }
-    if (C::NPAIR > 0 && r < 2 * P && c < 2 * P) {
-        const int jr = r % P, ar = r / P, jc = c % P, ac = c / P;
-        const int hidx = ar + ac;     // (0,0)->0 (0,1)/(1,0)->1 (1,1)->2
-        if (jr == i && jc == i) {
-            for (int j = 0; j < P; j++) if (j != i) e += L.Hh[pairq<C>(i, j) * 3 + hidx];
-        } else if (jr == i) {
-            e -= L.Hh[pairq<C>(i, jc) * 3 + hidx];
-        } else if (jc == i) {
-            e -= L.Hh[pairq<C>(i, jr) * 3 + hidx];
-        } else if (jr == jc) {
-            e += L.Hh[pairq<C>(i, jr) * 3 + hidx];
-        }
-    }
+    if (jr == i && jc == i) { for (int j = 0; j < P; j++) if (j != i) e += Hh[pairq<C>(i, j) * 3 + hidx]; }
+    else if (jr == i) e = -Hh[pairq<C>(i, jc) * 3 + hidx];
+    else if (jc == i) e = -Hh[pairq<C>(i, jr) * 3 + hidx];
+    else if (jr == jc) e = Hh[pairq<C>(i, jr) * 3 + hidx];
+    return e;
+}
+// Entry (r,c) of Q^_i = sum_j E[i][j].Q + state-constraint hess + reg I at a knot with stage weight w
+template <class C>
+__device__ __forceinline__ double qhat_entry(const double* qd, const double* Hh, int i, int r, int c, double w, double reg) {
+    double e = 0.0;
+    if (r == c) { e = reg; if (r % C::P == i) e += w * qd[i * C::ni + r / C::P]; }
+    if (C::P > 1 && r < 2 * C::P && c < 2 * C::P) e += pairblock<C>(Hh, i, r, c);
     return e;
 }
 
-// Loads knot data of step k into LDS and computes coefficients, pair tables, R^ (wave-cooperative).
-template <class C>
-__device__ void step_context(const Params& pr, const Game& G, DirLds<C>& L, const double* z, int k, double reg) {
-    constexpr int n = C::n, m = C::m, P = C::P;
-    const int N = pr.N, lane = threadIdx.x;
-    const bool has_next = (k + 1 <= N - 2);
-    if (lane < n) { L.xk[lane] = zstate<C>(z, k)[lane]; L.x1[lane] = z[n + hx<C>(k) + lane]; }
-    if (lane < m) { L.uk[lane] = z[n + hu<C>(k, 0) + uoff<C>(lane)]; L.u1[lane] = has_next ? z[n + hu<C>(k + 1, 0) + uoff<C>(lane)] : 0.0; }
-    __syncthreads();
-    if (lane < P) {
-        double xo[C::ni], co[4];
-        model_player<C>(lane, L.xk, L.uk, pr.dt, xo, co);
-        for (int j = 0; j < 4; j++) L.coefk[j * P + lane] = co[j];
-        model_player<C>(lane, L.x1, L.u1, pr.dt, xo, co);
-        for (int j = 0; j < 4; j++) L.coefn[j * P + lane] = co[j];
-    }
-    if (C::NPAIR > 0 && lane >= 8 && lane < 8 + C::NPAIR && (pr.has_colcost || pr.has_colavoid)) {
-        const int q = lane - 8, i = q / (P - 1), jj = q % (P - 1), j = jj < i ? jj : jj + 1;
-        pair_terms<C>(pr, G, i, j, L.x1, k + 1, &L.gv[q * 2], &L.Hh[q * 3], nullptr);
-    } else if (C::NPAIR > 0 && lane >= 8 && lane < 8 + C::NPAIR) {
-        const int q = lane - 8;
-        L.gv[q * 2] = L.gv[q * 2 + 1] = 0.0; L.Hh[q * 3] = L.Hh[q * 3 + 1] = L.Hh[q * 3 + 2] = 0.0;
-    }
-    if (lane >= 32 && lane < 32 + m) {
-        // R^[c] = dt R_i[c] + reg + control-bound hess (diagonal)  (global_quantities.jl:138-144,176-193; constraint_derivatives.jl:24-33)
-        const int c = lane - 32, i = c % P, j = c / P;
-        double rh = pr.dt * G.Rd[i * C::mi + j] + reg;
-        if (pr.has_ctl) {
-            for (int half = 0; half < 2; half++) {
-                const int ci = con_ctl<C>(pr, k, half * m + c);
-                const double cv = half == 0 ? L.uk[c] - pr.umax[c] : pr.umin[c] - L.uk[c];
-                if (isfinite(cv)) rh += al_active_mu(cv, G.lam[ci], G.mu[ci]);
+// Partial-pivot LU of the m x m control system, done redundantly in the registers of every lane (the pivot choice
+// is wave-uniform), applied to this lane's own right-hand-side column.  Returns 0 or 1 (singular).
+template <int M>
+__device__ __forceinline__ int lu_solve_regs(const double* Wl /*LDS, row-major M x M*/, double* b /*M*/) {
+    double a[M][M];
+#pragma unroll
+    for (int r = 0; r < M; r++)
+#pragma unroll
+        for (int c = 0; c < M; c++) a[r][c] = Wl[r * M + c];
+    int sing = 0;
+#pragma unroll
+    for (int c = 0; c < M; c++) {
+        int piv = c; double best = fabs(a[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < M; r++) { const double v = fabs(a[r][c]); if (v > best) { best = v; piv = r; } }
+        piv = __builtin_amdgcn_readfirstlane(piv);
+        if (!(best > 0.0) || !isfinite(best)) sing = 1;
+#pragma unroll
+        for (int r = c + 1; r < M; r++) {
+            if (piv == r) {
+#pragma unroll
+                for (int j = c; j < M; j++) { const double tmp = a[c][j]; a[c][j] = a[r][j]; a[r][j] = tmp; }
+                const double tb = b[c]; b[c] = b[r]; b[r] = tb;
             }
         }
-        L.Rhat[c] = rh;
+        const double inv = 1.0 / a[c][c];
+        a[c][c] = inv;
+#pragma unroll
+        for (int r = c + 1; r < M; r++) {
+            const double f = a[r][c] * inv;
+#pragma unroll
+            for (int j = c + 1; j < M; j++) a[r][j] -= f * a[c][j];
+            b[r] -= f * b[c];
+        }
     }
-    __syncthreads();
+#pragma unroll
+    for (int c = M - 1; c >= 0; c--) {
+        double acc = b[c];
+#pragma unroll
+        for (int j = c + 1; j < M; j++) acc -= a[c][j] * b[j];
+        b[c] = acc * a[c][c];
+    }
+    return sing;
 }
 
-// Partial-pivot Gauss-Jordan of the m x m control system with n+1 right-hand sides held in L.W (m x WC, row-major).
-// Every lane scans the pivot column redundantly (wave-uniform pivot choice, no reduction).
-template <class C>
-__device__ void solve_control_system(DirLds<C>& L) {
-    constexpr int m = C::m, WC = C::WC;
-    const int lane = threadIdx.x;
-    for (int c = 0; c < m; c++) {
-        int piv = c; double best = fabs(L.W[c * WC + c]);
-        for (int r = c + 1; r < m; r++) { const double v = fabs(L.W[r * WC + c]); if (v > best) { best = v; piv = r; } }
-        if (!(best > 0.0) || !isfinite(best)) { if (lane == 0) L.singular = 1; __syncthreads(); return; }
-        __syncthreads();
-        if (piv != c && lane < WC) { const double a = L.W[c * WC + lane], bb = L.W[piv * WC + lane]; L.W[c * WC + lane] = bb; L.W[piv * WC + lane] = a; }
-        __syncthreads();
-        const double inv = 1.0 / L.W[c * WC + c];
-        // factors of all rows, read before anything is overwritten
-        double fac[(m * WC + WAVE - 1) / WAVE]; double prow[(m * WC + WAVE - 1) / WAVE];
-        int cnt = 0;
-        for (int e = lane; e < m * WC; e += WAVE, cnt++) {
-            const int r = e / WC, col = e % WC;
-            fac[cnt] = (r == c) ? 0.0 : L.W[r * WC + c] * inv;
-            prow[cnt] = L.W[c * WC + col];
-        }
-        __syncthreads();
-        cnt = 0;
-        for (int e = lane; e < m * WC; e += WAVE, cnt++) {
-            const int r = e / WC, col = e % WC;
-            if (r == c) L.W[e] = prow[cnt] * inv;
-            else L.W[e] -= fac[cnt] * prow[cnt];
-        }
-        __syncthreads();
-    }
-}
-
-// Solves J d = -res for the stored residual G.res (vertical order) and writes d into the delta buffer
+// Solves J d = -res for the step records left by assemble_pass<C,1> and writes d into the delta buffer
 // (solver_methods.jl:87-88).  Returns ALG_STATUS_*.
 template <class C>
 __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg) {
-    constexpr int n = C::n, m = C::m, P = C::P, WC = C::WC;
+    constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
+    using R = Rec<C>;
     const int N = pr.N, lane = threadIdx.x;
+    const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
     const double dt = pr.dt;
-    const double* z = G.z[0];
-    const double* res = G.res;
     double* dz = G.z[2];
+    constexpr int RPL = (R::LEN + WAVE - 1) / WAVE;      // record doubles per lane
+    constexpr int KPL = (NK + WAVE - 1) / WAVE;
     if (lane == 0) L.singular = 0;
+    for (int e = lane; e < P * C::ni; e += WAVE) L.qd[e] = G.Qd[e];
+    for (int e = lane; e < n * 16; e += WAVE) L.Fx[e] = 0.0;
+    for (int e = lane; e < P * n * LDP; e += WAVE) L.Pm[e] = 0.0;
+    for (int e = lane; e < R::LEN; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     __syncthreads();
     // ------------------------------------------------------------------ backward sweep
-    for (int k = N - 2; k >= 0; k--) {
-        step_context<C>(pr, G, L, z, k, reg);
+    int cur = 0;
+    for (int k = N - 2; k >= 0; k--, cur ^= 1) {
+        const double* Rc = L.rec[cur];
+        double pre[RPL];
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+        }
         const int kn = k + 1;
         const double w = (kn < N - 1) ? dt : 1.0;
-        if (k < N - 2) {
-            // t_i = P_i f + s_i ; T_i = P_i F     (P, F, f, s of step k+1)
-            for (int e = lane; e < P * n; e += WAVE) {
-                const int i = e / n, r = e % n; double acc = L.s[e];
-                for (int c = 0; c < n; c++) acc += L.Pm[i * n * n + r * n + c] * L.f[c];
-                L.t[e] = acc;
+        const double* coefk = Rc + R::COEF;
+        const double* Hh = Rc + R::HH;
+        // ---- P_i <- Q^_i + A_{k+1}' (P_i [F|f] + [0|s_i]) ,  s_i <- rx_i + A_{k+1}' (P_i f + s_i)   via chained f64 MFMAs
+        {
+            double bF[KB], aA[KB];
+            if (k < N - 2) {
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) {
+                    bF[kb] = L.Fx[(4 * kb + lq) * 16 + lrow];
+                    aA[kb] = lrow < n ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
+                }
             }
-            for (int e = lane; e < P * n * n; e += WAVE) {
-                const int i = e / (n * n), r = (e / n) % n, c = e % n; double acc = 0.0;
-                for (int q = 0; q < n; q++) acc += L.Pm[i * n * n + r * n + q] * L.F[q * n + c];
-                L.Tm[e] = acc;
+            double4_t acc2[P];
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                // C-init of the second product: [Q^_i | rx_i]
+                double4_t c2;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int row = lq + 4 * r4, col = lrow;
+                    double v = 0.0;
+                    if (row < n) {
+                        if (col < n) v = qhat_entry<C>(L.qd, Hh, i, row, col, w, reg);
+                        else if (col == n) v = Rc[R::RX + i * n + row];
+                    }
+                    c2[r4] = v;
+                }
+                if (k < N - 2) {
+                    double4_t c1;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) { const int row = lq + 4 * r4; c1[r4] = (lrow == n && row < n) ? L.s[i * n + row] : 0.0; }
+#pragma unroll
+                    for (int kb = 0; kb < KB; kb++) {
+                        const double aP = lrow < n ? L.Pm[i * n * LDP + lrow * LDP + 4 * kb + lq] : 0.0;
+                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aP, bF[kb], c1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
+                }
+                acc2[i] = c2;
             }
-            __syncthreads();
-            // P_i = Q^_i + A_{k+1}' T_i ; s_i = rx_i + A_{k+1}' t_i
-            for (int e = lane; e < P * n * n; e += WAVE) {
-                const int i = e / (n * n), r = (e / n) % n, c = e % n;
-                const double* Ti = &L.Tm[i * n * n];
-                L.Pm[e] = qhat_entry<C>(pr, G, L, i, r, c, w, reg) + AT_vec<C>(L.coefn, dt, [&](int rr) { return Ti[rr * n + c]; }, r);
+            if (n == 16 && k < N - 2) {
+                // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
+                for (int e = lane; e < P * n; e += WAVE) {
+                    const int i = e / n, r = e % n; double a = L.s[e];
+                    for (int c = 0; c < n; c++) a += L.Pm[i * n * LDP + r * LDP + c] * L.fv[c];
+                    L.t[e] = a;
+                }
             }
-            for (int e = lane; e < P * n; e += WAVE) {
-                const int i = e / n, r = e % n; const double* ti = &L.t[i * n];
-                L.s[e] = res[vx<C>(N, i, k) + r] + AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
+            __syncthreads();           // all reads of Pm / s done
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int row = lq + 4 * r4;
+                    if (row < n) {
+                        if (lrow < n) L.Pm[i * n * LDP + row * LDP + lrow] = acc2[i][r4];
+                        else if (lrow == n && n < 16) L.s[i * n + row] = acc2[i][r4];
+                    }
+                }
             }
-        } else {
-            for (int e = lane; e < P * n * n; e += WAVE) {
-                const int i = e / (n * n), r = (e / n) % n, c = e % n;
-                L.Pm[e] = qhat_entry<C>(pr, G, L, i, r, c, w, reg);
+            if (n == 16) {
+                for (int e = lane; e < P * n; e += WAVE) {
+                    const int i = e / n, r = e % n; const double* ti = &L.t[i * n];
+                    double v = Rc[R::RX + e];
+                    if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
+                    L.s[e] = v;
+                }
             }
-            for (int e = lane; e < P * n; e += WAVE) L.s[e] = res[vx<C>(N, e / n, k) + e % n];
         }
         __syncthreads();
-        // V[c][:] = B[:,c]' P_{i(c)}   (m x n)
+        // ---- V[c][:] = B[:,c]' P_{i(c)}   (m x n)
         for (int e = lane; e < m * n; e += WAVE) {
-            const int c = e / n, col = e % n; const double* Pi = &L.Pm[(c % P) * n * n];
-            L.V[e] = BT_vec<C>(L.coefk, dt, [&](int rr) { return Pi[rr * n + col]; }, c);
+            const int c = e / n, col = e % n; const double* Pi = &L.Pm[(c % P) * n * LDP];
+            L.V[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
         }
         __syncthreads();
-        // W = diag(R^) + V B ; rhs = [ V A_k | V rd + B' s + ru ]
-        for (int e = lane; e < m * WC; e += WAVE) {
-            const int c = e / WC, col = e % WC; const double* Vc = &L.V[c * n];
+        // ---- W = diag(R^) + V B (cooperative) ; this lane's right-hand-side column of [ V A_k | V rd + B' s + ru ]
+        for (int e = lane; e < m * m; e += WAVE) {
+            const int c = e / m, c2 = e % m; const double* Vc = &L.V[c * n];
+            L.W[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, c2) + (c == c2 ? Rc[R::RHAT + c] : 0.0);
+        }
+        double b[m];
+        const int col = lane <= n ? lane : n;           // lanes > n mirror the last column (results unused)
+#pragma unroll
+        for (int c = 0; c < m; c++) {
+            const double* Vc = &L.V[c * n];
             double v;
-            if (col < m) {
-                v = BT_vec<C>(L.coefk, dt, [&](int rr) { return Vc[rr]; }, col) + (col == c ? L.Rhat[c] : 0.0);
-            } else if (col < m + n) {
-                v = (k >= 1) ? XA_vec<C>(L.coefk, dt, [&](int rr) { return Vc[rr]; }, col - m) : 0.0;
-            } else {
-                const int i = c % P, j = c / P; const double* si = &L.s[i * n];
-                double acc = res[vu<C>(N, i, k) + j] + BT_vec<C>(L.coefk, dt, [&](int rr) { return si[rr]; }, c);
-                for (int rr = 0; rr < n; rr++) acc += Vc[rr] * res[vd<C>(N, k) + rr];
-                v = acc;
+            if (col < n) v = (k >= 1) ? XA_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, col) : 0.0;
+            else {
+                const double* si = &L.s[(c % P) * n];
+                v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return si[rr]; }, c);
+                for (int rr = 0; rr < n; rr++) v += Vc[rr] * Rc[R::RD + rr];
             }
-            L.W[e] = v;
+            b[c] = v;
         }
         __syncthreads();
-        solve_control_system<C>(L);
-        if (L.singular) return ALG_STATUS_SINGULAR;
-        // K = -Y[:, :n], kappa = -Y[:, n]  -> HBM scratch ; F = A_k + B K ; f = rd + B kappa
-        double* Kg = G.kgain + (size_t)k * (m * (n + 1));
-        for (int e = lane; e < m * (n + 1); e += WAVE) { const int c = e / (n + 1), col = e % (n + 1); Kg[e] = -L.W[c * WC + m + col]; }
-        for (int e = lane; e < n * n; e += WAVE) {
-            const int r = e / n, c = e % n;
-            L.F[e] = ((k >= 1) ? A_entry<C>(L.coefk, dt, r, c) : 0.0) + B_vec<C>(L.coefk, dt, [&](int cc) { return -L.W[cc * WC + m + c]; }, r);
+        const int sing = lu_solve_regs<m>(L.W, b);
+        if (sing) return ALG_STATUS_SINGULAR;          // wave-uniform
+        // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
+        if (lane <= n) {
+            double* Kg = G.kgain + (size_t)k * NK + lane * m;
+#pragma unroll
+            for (int c = 0; c < m; c++) { b[c] = -b[c]; Kg[c] = b[c]; }
+#pragma unroll
+            for (int r = 0; r < n; r++) {
+                double v = B_vec<C>(coefk, dt, [&](int cc) { return b[cc]; }, r);
+                if (lane < n) v += (k >= 1) ? A_entry<C>(coefk, dt, r, lane) : 0.0;
+                else v += Rc[R::RD + r];
+                if (lane < n || n < 16) L.Fx[r * 16 + lane] = v;
+                if (lane == n) L.fv[r] = v;
+            }
         }
-        if (lane < n) L.f[lane] = res[vd<C>(N, k) + lane] + B_vec<C>(L.coefk, dt, [&](int cc) { return -L.W[cc * WC + m + n]; }, lane);
+        if (C::NC > 0 && lane < C::NC) L.coefn[lane] = coefk[lane];
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN) L.rec[cur ^ 1][e] = pre[q]; }
+        }
         __syncthreads();
     }
     // ------------------------------------------------------------------ forward sweep: dx, du
     if (lane < n) { L.dx[lane] = 0.0; dz[lane] = 0.0; }
+    for (int e = lane; e < R::LEN; e += WAVE) L.rec[0][e] = G.rec[e];
+    for (int e = lane; e < NK; e += WAVE) L.kg[0][e] = G.kgain[e];
     __syncthreads();
-    for (int k = 0; k < N - 1; k++) {
-        const double* Kg = G.kgain + (size_t)k * (m * (n + 1));
-        if (lane < n) { L.xk[lane] = zstate<C>(z, k)[lane]; }
-        if (lane < m) { L.uk[lane] = z[n + hu<C>(k, 0) + uoff<C>(lane)]; }
-        __syncthreads();
-        if (lane < P) {
-            double xo[C::ni], co[4];
-            model_player<C>(lane, L.xk, L.uk, dt, xo, co);
-            for (int j = 0; j < 4; j++) L.coefk[j * P + lane] = co[j];
+    cur = 0;
+    for (int k = 0; k < N - 1; k++, cur ^= 1) {
+        const double* Rc = L.rec[cur]; const double* Kl = L.kg[cur];
+        double pre[RPL], prek[KPL];
+        if (k + 1 < N - 1) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN ? G.rec[(size_t)(k + 1) * R::LEN + e] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; prek[q] = e < NK ? G.kgain[(size_t)(k + 1) * NK + e] : 0.0; }
         }
-        if (lane >= 32 && lane < 32 + m) {
-            const int c = lane - 32; double acc = Kg[c * (n + 1) + n];
-            for (int q = 0; q < n; q++) acc += Kg[c * (n + 1) + q] * L.dx[q];
-            L.du[c] = acc;
+        if (lane < m) {
+            double acc = Kl[n * m + lane];
+            for (int q = 0; q < n; q++) acc += Kl[q * m + lane] * L.dx[q];
+            L.du[lane] = acc;
+            dz[n + hu<C>(k, 0) + uoff<C>(lane)] = acc;
         }
         __syncthreads();
         double dxn = 0.0;
-        if (lane < n) dxn = A_vec<C>(L.coefk, dt, [&](int rr) { return L.dx[rr]; }, lane)
-                          + B_vec<C>(L.coefk, dt, [&](int cc) { return L.du[cc]; }, lane) + res[vd<C>(N, k) + lane];
+        if (lane < n) dxn = A_vec<C>(Rc + R::COEF, dt, [&](int rr) { return L.dx[rr]; }, lane)
+                          + B_vec<C>(Rc + R::COEF, dt, [&](int cc) { return L.du[cc]; }, lane) + Rc[R::RD + lane];
         __syncthreads();
         if (lane < n) { L.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; }
-        if (lane >= 32 && lane < 32 + m) dz[n + hu<C>(k, 0) + uoff<C>(lane - 32)] = L.du[lane - 32];
+        if (k + 1 < N - 1) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN) L.rec[cur ^ 1][e] = pre[q]; }
+#pragma unroll
+            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.kg[cur ^ 1][e] = prek[q]; }
+        }
         __syncthreads();
     }
-    // ------------------------------------------------------------------ costate sweep: dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    for (int k = N - 2; k >= 0; k--) {
-        step_context<C>(pr, G, L, z, k, reg);
-        const int kn = k + 1;
-        const double w = (kn < N - 1) ? dt : 1.0;
+    // ------------------------------------------------------------------ costate sweep:
+    //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
+    for (int e = lane; e < R::LEN; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    __syncthreads();
+    cur = 0;
+    for (int k = N - 2; k >= 0; k--, cur ^= 1) {
+        const double* Rc = L.rec[cur];
+        double pre[RPL];
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+        }
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
         if (lane < n) L.dx[lane] = dz[n + hx<C>(k) + lane];
         __syncthreads();
         double v[(P * n + WAVE - 1) / WAVE]; int cnt = 0;
         for (int e = lane; e < P * n; e += WAVE, cnt++) {
             const int i = e / n, r = e % n;
-            double acc = res[vx<C>(N, i, k) + r];
-            for (int c = 0; c < n; c++) acc += qhat_entry<C>(pr, G, L, i, r, c, w, reg) * L.dx[c];
+            double acc = Rc[R::RX + e];
+            double qd = reg; if (r % P == i) qd += w * L.qd[i * C::ni + r / P];
+            acc += qd * L.dx[r];
+            if (P > 1 && r < 2 * P) for (int c = 0; c < 2 * P; c++) acc += pairblock<C>(Rc + R::HH, i, r, c) * L.dx[c];
             if (k < N - 2) { const double* dli = &L.dl[i * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, r); }
             v[cnt] = acc;
         }
         __syncthreads();
         cnt = 0;
         for (int e = lane; e < P * n; e += WAVE, cnt++) { L.dl[e] = v[cnt]; dz[n + hl<C>(k, 0) + e] = v[cnt]; }
+        if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN) L.rec[cur ^ 1][e] = pre[q]; }
+        }
         __syncthreads();
     }
     // non-finite direction -> singular (the reference would throw / propagate NaN)
@@ -729,31 +818,33 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 }
 
 // residual_jacobian! + regularize_residual_jacobian! into a dense S x S column-major matrix (global_quantities.jl:109-193).
-// Parity / inspection entry point; built from the same block functions the solver uses.
+// Parity / inspection entry point; built from the same step records and block functions the solver uses.
 template <class C>
-__device__ void jacobian_dense(const Params& pr, const Game& G, DirLds<C>& L, double reg, double* J) {
-    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi;
+__device__ void jacobian_dense(const Params& pr, const Game& G, double reg, double* J) {
+    constexpr int n = C::n, m = C::m, P = C::P;
+    using R = Rec<C>;
     const int N = pr.N, lane = threadIdx.x; const size_t S = pr.S; const double dt = pr.dt;
     for (size_t e = lane; e < S * S; e += WAVE) J[e] = 0.0;
     __syncthreads();
     auto at = [&](int r, int c) -> double& { return J[(size_t)c * S + r]; };
     for (int k = 0; k < N - 1; k++) {
-        step_context<C>(pr, G, L, G.z[0], k, reg);
+        const double* Rc = G.rec + (size_t)k * R::LEN;
+        const double* coefk = Rc + R::COEF;
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         for (int e = lane; e < P * n * n; e += WAVE) {
             const int i = e / (n * n), r = (e / n) % n, c = e % n;
-            at(vx<C>(N, i, k) + r, hx<C>(k) + c) = qhat_entry<C>(pr, G, L, i, r, c, w, reg);
+            at(vx<C>(N, i, k) + r, hx<C>(k) + c) = qhat_entry<C>(G.Qd, Rc + R::HH, i, r, c, w, reg);
         }
-        for (int c = lane; c < m; c += WAVE) { const int i = c % P, j = c / P; at(vu<C>(N, i, k) + j, hu<C>(k, i) + j) = L.Rhat[c]; }
+        for (int c = lane; c < m; c += WAVE) { const int i = c % P, j = c / P; at(vu<C>(N, i, k) + j, hu<C>(k, i) + j) = Rc[R::RHAT + c]; }
         for (int e = lane; e < n * n; e += WAVE) {
-            const int r = e / n, c = e % n; const double a = A_entry<C>(L.coefk, dt, r, c);
+            const int r = e / n, c = e % n; const double a = A_entry<C>(coefk, dt, r, c);
             if (k >= 1) {
                 at(vd<C>(N, k) + r, hx<C>(k - 1) + c) = a;
                 for (int i = 0; i < P; i++) at(vx<C>(N, i, k - 1) + c, hl<C>(k, i) + r) = a;
             }
         }
         for (int e = lane; e < n * m; e += WAVE) {
-            const int r = e / m, c = e % m, i = c % P, j = c / P; const double bv = B_entry<C>(L.coefk, dt, r, c);
+            const int r = e / m, c = e % m, i = c % P, j = c / P; const double bv = B_entry<C>(coefk, dt, r, c);
             at(vd<C>(N, k) + r, hu<C>(k, i) + j) = bv;
             at(vu<C>(N, i, k) + j, hl<C>(k, i) + r) = bv;
         }
@@ -761,18 +852,18 @@ __device__ void jacobian_dense(const Params& pr, const Game& G, DirLds<C>& L, do
             at(vd<C>(N, k) + r, hx<C>(k) + r) = -1.0;
             for (int i = 0; i < P; i++) at(vx<C>(N, i, k) + r, hl<C>(k, i) + r) = -1.0;
         }
-        __syncthreads();
     }
 }
 
 // ================================================================================================
 // Solver control flow (solver_methods.jl:5-125), per game
 // ================================================================================================
-// record! (statistics.jl:44-57): unregularised residual at pdtraj (also refreshes G.res and G.vals)
+// record! (statistics.jl:44-57): unregularised residual at pdtraj; also leaves the step records (with the Jacobian
+// regularisation jreg folded into R^) for the Newton direction and refreshes G.vals
 template <class C>
-__device__ __forceinline__ alg_record make_record(const Params& pr, const Game& G, double delta, int outer, int* nonfinite) {
+__device__ __forceinline__ alg_record make_record(const Params& pr, const Game& G, double delta, int outer, double jreg, int* nonfinite) {
     ResOut ro;
-    residual_pass<C, true>(pr, G, G.z[0], nullptr, 0.0, G.res, ro);
+    assemble_pass<C, 1>(pr, G, G.z[0], nullptr, 0.0, jreg, ro);
     alg_record rc;
     rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
     rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
@@ -789,7 +880,7 @@ __device__ void line_search(const Params& pr, const Game& G, double reg, double 
         update_traj<C>(pr, G.z[1], G.z[0], alpha, G.z[2]);
         __syncthreads();
         ResOut ro;
-        residual_pass<C, false>(pr, G, G.z[1], o.regularize ? G.z[0] : nullptr, reg, nullptr, ro);
+        assemble_pass<C, 0>(pr, G, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, ro);
         const double rt = ro.l1 / (double)pr.S;
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
@@ -814,7 +905,7 @@ __device__ alg_step_info inner_iteration(const Params& pr, const Game& G, DirLds
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
     int nonfinite = 0;
-    alg_record rc = make_record<C>(pr, G, Delta, k, &nonfinite);           // :73-76 (the regularisation term is zero at pdtraj)
+    alg_record rc = make_record<C>(pr, G, Delta, k, reg, &nonfinite);      // :73-76 (the regularisation term is zero at pdtraj)
     const double rn = rc.res;
     info.rec = rc;
     Delta = 0.0;                                                           // :79
@@ -851,7 +942,8 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
     const int N = pr.N; const alg_options& o = pr.opt; const double* z = G.z[0];
     if (pr.has_colavoid) {
         for (int e = threadIdx.x; e < pr.col_len; e += WAVE) {
-            const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / (P - 1), jj = q % (P - 1), j = jj < i ? jj : jj + 1;
+            constexpr int PM1 = P > 1 ? P - 1 : 1;
+            const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / PM1, jj = q % PM1, j = jj < i ? jj : jj + 1;
             const double* x = zstate<C>(z, k);
             const double d0 = x[i] - x[j], d1 = x[P + i] - x[P + j], R = pr.ca_radius[i] + pr.ca_radius[j];
             const double c = R * R - (d0 * d0 + d1 * d1);
@@ -964,7 +1056,7 @@ __device__ void newton_solve(const Params& pr, const Game& G, DirLds<C>& L, int 
         __syncthreads();
     }
     __syncthreads();
-    alg_record fin = make_record<C>(pr, G, Delta, out, nullptr);           // :63
+    alg_record fin = make_record<C>(pr, G, Delta, out, 0.0, nullptr);      // :63
     push_record(pr, G, fin);
     if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; G.st->last = fin; }
 }

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int wh
     Game G = game_view(pr, bf, g);
     ResOut ro;
     // the proximal term is taken w.r.t. pdtraj (regularize_residual!, global_quantities.jl:67-86)
-    residual_pass<C, true>(pr, G, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, G.res, ro);
+    assemble_pass<C, 2>(pr, G, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, 0.0, ro);
     __syncthreads();
     if (res_out) for (int e = threadIdx.x; e < pr.S; e += WAVE) res_out[(size_t)g * pr.S + e] = G.res[e];
     if (rn_out && threadIdx.x == 0) rn_out[g] = ro.l1 / (double)pr.S;
@@ -45,10 +45,12 @@ __global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int wh
 
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, Buffers bf, double reg, double* J) {
-    __shared__ DirLds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
-    jacobian_dense<C>(pr, G, L, reg, J + (size_t)g * pr.S * pr.S);
+    ResOut ro;
+    assemble_pass<C, 1>(pr, G, G.z[0], nullptr, 0.0, reg, ro);
+    __syncthreads();
+    jacobian_dense<C>(pr, G, reg, J + (size_t)g * pr.S * pr.S);
 }
 
 template <class C>
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(WAVE) k_direction(Params pr, Buffers bf, doubl
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     ResOut ro;
-    residual_pass<C, true>(pr, G, G.z[0], nullptr, 0.0, G.res, ro);
+    assemble_pass<C, 1>(pr, G, G.z[0], nullptr, 0.0, reg, ro);
     __syncthreads();
     const int st = newton_direction<C>(pr, G, L, reg);
     if (status && threadIdx.x == 0) status[g] = st;
@@ -83,7 +85,7 @@ template <class C>
 __global__ void __launch_bounds__(WAVE) k_record(Params pr, Buffers bf, alg_record* out) {
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
-    alg_record rc = make_record<C>(pr, G, 0.0, 0, nullptr);
+    alg_record rc = make_record<C>(pr, G, 0.0, 0, 0.0, nullptr);
     if (threadIdx.x == 0) out[g] = rc;
 }
 
@@ -146,6 +148,10 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.con_len = p.col_len + p.ctl_len;
     p.hist_max = HIST_MAX;
     p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
+    {   // Rec<C>::LEN
+        const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : 0;
+        p.rec_len = (p.N - 1) * (nc + 3 * p.npair + p.m + p.p * p.n + p.m + p.n);
+    }
     return true;
 }
 
@@ -175,6 +181,8 @@ struct Handle {
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool x0_set = false, lqr_set = false;
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;
+    std::vector<const char*> alloc_names;
     // small device scratch for per-game scalar I/O
     double* d_tmp = nullptr;      // B doubles x 2
     int* d_itmp = nullptr;        // B ints
@@ -183,12 +191,17 @@ struct Handle {
     double* d_lqr[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
+constexpr size_t GUARD = 4096;     // guard zone behind every device buffer (checked by alg_debug_check_guards)
 template <class T>
-int dalloc(Handle* h, T** p, size_t count) {
+int dalloc(Handle* h, T** p, size_t count, const char* name = "?") {
     void* q = nullptr;
-    HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
-    HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIPCHK(hipMalloc(&q, bytes + GUARD));
+    HIPCHK(hipMemsetAsync(q, 0, bytes, h->stream));
+    HIPCHK(hipMemsetAsync((char*)q + bytes, 0xAB, GUARD, h->stream));
     h->allocs.push_back(q);
+    h->alloc_bytes.push_back(bytes);
+    h->alloc_names.push_back(name);
     *p = (T*)q;
     return ALG_OK;
 }
@@ -240,24 +253,25 @@ int launch_check(const char* what) {
 int alloc_all(Handle* hd) {
     int rc;
     const Params& p = hd->pr; const size_t B = p.B;
-    for (int t = 0; t < 3; t++) if ((rc = dalloc(hd, &hd->bf.traj[t], B * p.traj_len))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.x0, B * p.n))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.lam, B * p.con_len))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.mu, B * p.con_len))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.vals, B * p.con_len))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.res, B * p.S))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.kgain, B * p.kscratch_len))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.stats, B))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max))) return rc;
-    if ((rc = dalloc(hd, &hd->d_tmp, 2 * B))) return rc;
-    if ((rc = dalloc(hd, &hd->d_itmp, B))) return rc;
-    if ((rc = dalloc(hd, &hd->d_info, B))) return rc;
-    if ((rc = dalloc(hd, &hd->d_rec, B))) return rc;
+    for (int t = 0; t < 3; t++) if ((rc = dalloc(hd, &hd->bf.traj[t], B * p.traj_len, "bf.traj[t]"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.x0, B * p.n, "bf.x0"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.lam, B * p.con_len, "bf.lam"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.mu, B * p.con_len, "bf.mu"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.vals, B * p.con_len, "bf.vals"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.res, B * p.S, "bf.res"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.kgain, B * p.kscratch_len, "bf.kgain"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.rec, B * p.rec_len, "bf.rec"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.stats, B, "bf.stats"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max, "bf.hist"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_tmp, 2 * B, "d_tmp"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_itmp, B, "d_itmp"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_info, B, "d_info"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_rec, B, "d_rec"))) return rc;
     // LQR buffers sized for the per-game case
-    if ((rc = dalloc(hd, &hd->d_lqr[0], B * p.p * p.ni))) return rc;
-    if ((rc = dalloc(hd, &hd->d_lqr[1], B * p.p * p.mi))) return rc;
-    if ((rc = dalloc(hd, &hd->d_lqr[2], B * p.p * p.ni))) return rc;
-    if ((rc = dalloc(hd, &hd->d_lqr[3], B * p.p * p.mi))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr[0], B * p.p * p.ni, "d_lqr[0]"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr[1], B * p.p * p.mi, "d_lqr[1]"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr[2], B * p.p * p.ni, "d_lqr[2]"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr[3], B * p.p * p.mi, "d_lqr[3]"))) return rc;
     hd->bf.Qd = hd->d_lqr[0]; hd->bf.Rd = hd->d_lqr[1]; hd->bf.xf = hd->d_lqr[2]; hd->bf.uf = hd->d_lqr[3];
     return ALG_OK;
 }
@@ -524,6 +538,20 @@ int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record
     if (c > 0 && (rc = d2h(H, out, H->bf.hist + (size_t)game * H->pr.hist_max, sizeof(alg_record) * c))) return rc;
     if (n_out) *n_out = c;
     return ALG_OK;
+}
+// debug aid (not part of the public header): returns the number of device buffers whose guard zone was overwritten
+int alg_debug_check_guards(alg_handle* h) {
+    int rc = use_device(H); if (rc) return rc;
+    if ((rc = sync(H))) return rc;
+    int bad = 0; std::vector<unsigned char> g(GUARD);
+    for (size_t i = 0; i < H->allocs.size(); i++) {
+        if (hipMemcpy(g.data(), (char*)H->allocs[i] + H->alloc_bytes[i], GUARD, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        size_t first = GUARD, cnt = 0;
+        for (size_t j = 0; j < GUARD; j++) if (g[j] != 0xAB) { if (first == GUARD) first = j; cnt++; }
+        if (cnt) { const double* gd = (const double*)g.data(); for (int j = 0; j < 128; j++) fprintf(stderr, "%s%.4g", j % 8 ? " " : "\n  ", gd[j]); fprintf(stderr, "\n"); }
+        if (cnt) { bad++; fprintf(stderr, "[alg guard] buffer %s (%zu bytes) overrun: %zu bytes touched, first at +%zu\n", H->alloc_names[i], H->alloc_bytes[i], cnt, first); }
+    }
+    return bad;
 }
 int alg_synchronize(alg_handle* h) { int rc = use_device(H); if (rc) return rc; return sync(H); }
 

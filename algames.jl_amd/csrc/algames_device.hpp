@@ -295,186 +295,251 @@ __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, i
 __device__ __forceinline__ double al_active_mu(double c, double lam, double mu) { return ((c >= 0.0) || (lam > 0.0)) ? mu : 0.0; }
 
 // ================================================================================================
-// Step records.  The assemble pass (parallel over knots) leaves one compact record per time step k in HBM;
-// the serial sweeps of the Newton direction read nothing else (plus the gains they spill themselves).
-//   [coefk (NC)] [Hh (3 NPAIR): pair Hessian blocks at knot k+1] [Rhat (m): R^ of knot k incl. reg]
-//   [rx (P n): rows opt_i,x_{k+1}] [ru (m): rows opt_i,u_{i,k}, joint control order] [rd (n): dyn_k]
+// Step records.  The assemble pass leaves one compact record per time step k in HBM; the serial sweeps of the Newton
+// direction read nothing else (plus the gains they spill themselves).
+//   [coefk (NC)] [Hh (3 NPAIR): pair Hessian blocks at knot k+1] [Hd (3 P): sum_j Hh(i,j)] [Rhat (m): R^ of knot k incl. reg]
+//   [rx (P n): rows opt_i,x_{k+1}] [ru (m): rows opt_i,u_{i,k}, joint order] [rd (n): dyn_k]      <- LEN_SWEEP
+//   [gvt (2 P^2): pair gradient table, only used inside the assemble pass]
 // ================================================================================================
 template <class C> struct Rec {
     static constexpr int COEF = 0;
     static constexpr int HH = COEF + C::NC;
-    static constexpr int RHAT = HH + 3 * C::NPAIR;
+    static constexpr int HD = HH + 3 * C::NPAIR;
+    static constexpr int RHAT = HD + 3 * C::P;
     static constexpr int RX = RHAT + C::m;
     static constexpr int RU = RX + C::P * C::n;
     static constexpr int RD = RU + C::m;
-    static constexpr int LEN = RD + C::n;
+    static constexpr int LEN_SWEEP = RD + C::n;
+    static constexpr int GVT = LEN_SWEEP;
+    static constexpr int LEN = GVT + 2 * C::P * C::P;
 };
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// LDS of the Newton-direction sweeps
+template <class C>
+struct DirLds {
+    static constexpr int LDP = C::n + 1;                 // padded row stride of P_i
+    static constexpr int KB = C::n / 4;                  // k-blocks of the 16x16x4 f64 MFMA
+    static constexpr int NHX = C::P * C::P * C::P * 3;   // expanded pair-Hessian table [i][jr][jc][3]
+    static_assert(C::n % 4 == 0 && C::n <= 16, "MFMA tile path needs n % 4 == 0 and n <= 16");
+    double Pm[C::P * C::n * LDP];      // P_i, row-major
+    double Fx[C::n * 16];              // [F | f | 0]: n x 16 (f in column n when n < 16)
+    double fv[C::n];
+    double s[C::P * C::n];
+    double t[C::n == 16 ? C::P * C::n : 1];
+    double V[C::m * C::n];
+    double W[C::m * C::m];
+    double g[C::m];
+    double rec[2][Rec<C>::LEN_SWEEP];
+    double kg[2][C::m * (C::n + 1)];
+    double hx[NHX];
+    double coefn[C::NC > 0 ? C::NC : 1];
+    double qdf[C::P * C::n];           // LQR diagonal of player i padded to joint dims (zero off pz[i])
+    double dx[C::n], du[C::m];
+    double dl[C::P * C::n];
+};
+// LDS of the assemble pass (never live at the same time as DirLds: the kernels hold a union)
+template <class C>
+struct AsmLds {
+    double blk[4][C::b];               // rotating window of horizontal-order blocks k-1, k, k+1 (+ prefetch slot)
+    double zr[2][C::n + C::m];         // [x_{k+1} | u_k] of the reference trajectory (proximal term)
+    double aux[2][C::NC + 2 * C::P * C::P + 1];   // [coef of knot k+1 | gvt of step k]
+    double tq[C::P * C::n], tx[C::P * C::n], tr[C::m], tu[C::m];   // LQR diagonals / targets padded to joint dims
+};
+template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 
 // ================================================================================================
 // Assemble pass: residual! + regularize_residual! + the scalars of record! (+ step records)
-//   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl.   Work item = (knot k, player i).
+//   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl.
+//   phase A (parallel, work item = (knot, player)): unicycle Jacobian coefficients, collision cost / collision
+//           avoidance terms of the ordered pairs (i, j) -> record [coef | Hh | Hd | gvt], constraint values
+//   phase B (serial over knots, lane = residual row of the step, all loads coalesced and staged through LDS):
+//           rows opt_i,x_{k+1} | opt_i,u_{i,k} | dyn_k  -> record [rx | ru | rd], R^, statistics
 //   MODE 0: statistics only (line-search trials)   MODE 1: + step records (Newton direction input)
 //   MODE 2: + residual vector in the reference's vertical order (alg_residual)
 // ================================================================================================
 struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; };
 
 template <class C, int MODE>
-__device__ void assemble_pass(const Params& pr, const Game& G, const double* z, const double* zref, double reg,
-                              double jreg, ResOut& out) {
-    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni;
+__device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, const double* __restrict__ z,
+                              const double* __restrict__ zref, double reg, double jreg, ResOut& out) {
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b;
     using R = Rec<C>;
     const int N = pr.N, lane = threadIdx.x;
     const double dt = pr.dt;
     double l1 = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
-    const int items = (N - 1) * P;
-    // ---------------- phase 1: dynamics defect, Jacobian coefficients, control rows -------------------
-    for (int e = lane; e < items; e += WAVE) {
-        const int k = e / P, i = e % P;
-        double* rec = G.rec + (size_t)k * R::LEN;
-        const double* sk = zstate<C>(z, k);
-        double xi[ni], ui[mi], xo[ni], co[4];      // this player's own state / control entries
-#pragma unroll
-        for (int j = 0; j < ni; j++) xi[j] = sk[i + j * P];
-#pragma unroll
-        for (int j = 0; j < mi; j++) ui[j] = z[n + hu<C>(k, i) + j];
-        // own-player dynamics (players are decoupled)
-        if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-#pragma unroll
-            for (int j = 0; j < C::D; j++) {
-                const double vm = xi[C::D + j] + (ui[j] * dt) * 0.5;
-                xo[j] = xi[j] + vm * dt; xo[C::D + j] = xi[C::D + j] + ui[j] * dt;
+    // ---------------- phase A ------------------------------------------------------------------------------
+    if (C::NC > 0 || (P > 1)) {
+        const int items = (N - 1) * P;
+        const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
+        for (int e = lane; e < items; e += WAVE) {
+            const int k = e / P, i = e % P, kn = k + 1;
+            double* __restrict__ rec = G.rec + (size_t)k * R::LEN;
+            if constexpr (C::NC > 0) {
+                // Jacobian coefficients of knot k (A_k, B_k): see the model section
+                const double* sk = zstate<C>(z, k);
+                const double th = sk[2 * P + i], v = sk[3 * P + i];
+                const double om = z[n + hu<C>(k, i)], ac = z[n + hu<C>(k, i) + 1];
+                const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
+                double sn, cs; sincos(thm, &sn, &cs);
+                rec[R::COEF + 0 * P + i] = -dt * vm * sn; rec[R::COEF + 1 * P + i] = dt * cs;
+                rec[R::COEF + 2 * P + i] = dt * vm * cs;  rec[R::COEF + 3 * P + i] = dt * sn;
             }
-            co[0] = co[1] = co[2] = co[3] = 0.0;
-        } else {
-            const double thm = xi[2] + (ui[0] * dt) * 0.5, vm = xi[3] + (ui[1] * dt) * 0.5;
-            double sn, cs; sincos(thm, &sn, &cs);
-            xo[0] = xi[0] + (cs * vm) * dt; xo[1] = xi[1] + (sn * vm) * dt; xo[2] = xi[2] + ui[0] * dt; xo[3] = xi[3] + ui[1] * dt;
-            co[0] = -dt * vm * sn; co[1] = dt * cs; co[2] = dt * vm * cs; co[3] = dt * sn;
-            // coefficients are also needed by the rows of knot k-1 (A_k' lambda): publish through the record
+            if constexpr (P > 1) {
+                const double w = (kn < N - 1) ? dt : 1.0;
+                const double* x1 = z + n + hx<C>(k);
+                const double xi0 = x1[i], xi1 = x1[P + i];
+                double ga0 = 0, ga1 = 0, d0 = 0, d1 = 0, d2 = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) rec[R::COEF + j * P + i] = co[j];
-        }
-        const double* x1 = z + n + hx<C>(k);
-        // dyn_k rows of this player: RK2(x_k,u_k) - x_{k+1}  (global_quantities.jl:60-63)
-#pragma unroll
-        for (int j = 0; j < ni; j++) {
-            const double r = xo[j] - x1[i + j * P];
-            if (MODE >= 1) rec[R::RD + i + j * P] = r;
-            if (MODE == 2) G.res[vd<C>(N, k) + i + j * P] = r;
-            l1 += fabs(r); vdyn = fmax(vdyn, fabs(r)); bad |= !isfinite(r);
-        }
-        // rows opt_i,u_{i,k}: dt R_i (u - uf_i) + control-bound AL gradient + B_i' lambda_{i,k} (+ reg (u - uref))
-        const double* lk = z + n + hl<C>(k, i);
-#pragma unroll
-        for (int j = 0; j < mi; j++) {
-            const int c = i + j * P;
-            double g = 0.0, rh = dt * G.Rd[i * mi + j] + jreg;
-            if (pr.has_ctl) {
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int ci = con_ctl<C>(pr, k, half * m + c);
-                    const double cv = half == 0 ? ui[j] - pr.umax[c] : pr.umin[c] - ui[j];
-                    G.vals[ci] = cv;
-                    if (isfinite(cv)) {
-                        const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
-                        const double wl = lm + am * cv;
-                        g += (half == 0 ? wl : -wl); rh += am;
-                        vcon = fmax(vcon, fmax(0.0, cv));
+                for (int jj = 0; jj < P - 1; jj++) {
+                    const int j = jj < i ? jj : jj + 1;
+                    double gv0 = 0, gv1 = 0, H0 = 0, H1 = 0, H2 = 0;
+                    if (pairs_on) {
+                        const double dl0 = xi0 - x1[j], dl1 = xi1 - x1[P + j];
+                        const double s2 = dl0 * dl0 + dl1 * dl1;
+                        if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173
+                            const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+                            if (fmax(0.0, rad - nrm) > 0.0) {
+                                const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
+                                const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
+                                const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
+                                gv0 += w * (-g0); gv1 += w * (-g1);
+                                const double n3 = nrm * nrm * nrm;
+                                H0 += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
+                                H1 += w * (mu * (rad * (dl0 * dl1) / n3));
+                                H2 += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
+                            }
+                        }
+                        if (pr.has_colavoid) {                                   // CollisionConstraint + AL expansion
+                            const double Rr = pr.ca_radius[i] + pr.ca_radius[j];
+                            const double c = Rr * Rr - s2;
+                            const int ci = con_col<C>(N, pairq<C>(i, j), kn);
+                            const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
+                            const double wl = lm + am * c;
+                            gv0 += -2.0 * dl0 * wl; gv1 += -2.0 * dl1 * wl;
+                            H0 += am * 4.0 * dl0 * dl0; H1 += am * 4.0 * dl0 * dl1; H2 += am * 4.0 * dl1 * dl1;
+                            G.vals[ci] = c; vsta = fmax(vsta, fmax(0.0, c));
+                        }
                     }
+                    ga0 += gv0; ga1 += gv1; d0 += H0; d1 += H1; d2 += H2;
+                    rec[R::GVT + (i * P + j) * 2 + 0] = -gv0; rec[R::GVT + (i * P + j) * 2 + 1] = -gv1;   // row opt_i at px(j,.)
+                    if (MODE >= 1) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
                 }
+                rec[R::GVT + (i * P + i) * 2 + 0] = ga0; rec[R::GVT + (i * P + i) * 2 + 1] = ga1;           // row opt_i at px(i,.)
+                if (MODE >= 1) { rec[R::HD + 3 * i] = d0; rec[R::HD + 3 * i + 1] = d1; rec[R::HD + 3 * i + 2] = d2; }
             }
-            double bl;   // (B_i' lambda_{i,k})[c]
-            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) bl = 0.5 * dt * dt * lk[c] + dt * lk[c + m];
-            else bl = (j == 0) ? 0.5 * dt * (co[0] * lk[i] + co[2] * lk[P + i]) + dt * lk[2 * P + i]
-                               : 0.5 * dt * (co[1] * lk[i] + co[3] * lk[P + i]) + dt * lk[3 * P + i];
-            double r = dt * (G.Rd[i * mi + j] * (ui[j] - G.uf[i * mi + j])) + g + bl;
-            if (zref) r += reg * (ui[j] - zref[n + hu<C>(k, i) + j]);
-            if (MODE >= 1) { rec[R::RU + c] = r; rec[R::RHAT + c] = rh; }
-            if (MODE == 2) G.res[vu<C>(N, i, k) + j] = r;
-            l1 += fabs(r); vopt = fmax(vopt, fabs(r)); bad |= !isfinite(r);
         }
+        __syncthreads();
     }
-    if constexpr (C::NC > 0) __syncthreads();      // coefficients of knot k+1 come from another lane's record write
-    // ---------------- phase 2: rows opt_i,x_{k+1} ------------------------------------------------------
-    for (int e = lane; e < items; e += WAVE) {
-        const int k = e / P, i = e % P, kn = k + 1;
-        double* rec = G.rec + (size_t)k * R::LEN;
-        const bool has_next = (kn <= N - 2);
-        const double* coef1 = G.rec + (size_t)(has_next ? kn : k) * R::LEN + R::COEF;     // coefficients of knot kn
-        const double* x1 = z + n + hx<C>(k);
-        const double* lk = z + n + hl<C>(k, i);
-        const double* ln = z + n + hl<C>(has_next ? kn : k, i);
-        const double* xr = zref ? zref + n + hx<C>(k) : nullptr;
-        const double w = (kn < N - 1) ? dt : 1.0;
-        // pair terms of the ordered pairs (i, j): positions of all players
-        double pos[2 * P];
+    // ---------------- phase B ------------------------------------------------------------------------------
+    // row e of step k: [0, P n) opt_i,x ; [P n, P n + m) opt_i,u ; [P n + m, b) dyn ; lanes take rows e = lane + 64 q
+    constexpr int AUX = C::NC + 2 * P * P;
+    constexpr int NPASS = (b + WAVE - 1) / WAVE;
+    // per-game constant tables: LQR diagonal / targets padded to joint dims
+    for (int e = lane; e < P * n; e += WAVE) {
+        const int i = e / n, a = e % n; const bool own = (a % P == i);
+        L.tq[e] = own ? G.Qd[i * ni + a / P] : 0.0; L.tx[e] = own ? G.xf[i * ni + a / P] : 0.0;
+    }
+    for (int c = lane; c < m; c += WAVE) { L.tr[c] = G.Rd[(c % P) * mi + c / P]; L.tu[c] = G.uf[(c % P) * mi + c / P]; }
+    auto load_block = [&](int kb, int e) -> double { return (e < b && kb >= 0 && kb <= N - 2) ? z[n + (size_t)kb * b + e] : 0.0; };
+    auto load_ref = [&](int kb) -> double { return (zref && lane < n + m && kb <= N - 2) ? zref[n + (size_t)kb * b + lane] : 0.0; };
+    auto load_aux = [&](int kb) -> double {      // [coef of knot kb+1 | gvt of step kb]
+        if (lane < C::NC) return (kb + 1 <= N - 2) ? G.rec[(size_t)(kb + 1) * R::LEN + R::COEF + lane] : 0.0;
+        if (lane < AUX) return G.rec[(size_t)kb * R::LEN + R::GVT + (lane - C::NC)];
+        return 0.0;
+    };
+    if (lane < n) L.blk[0][lane] = z[lane];                                // x_1 sits where block -1's x part would be
 #pragma unroll
-        for (int a = 0; a < 2 * P; a++) pos[a] = x1[a];
-        double gacc0 = 0.0, gacc1 = 0.0;          // contribution at px(i,.)
-        double gj[2 * (P > 1 ? P - 1 : 1)];       // minus-contributions at px(j,.) per pair slot
-        if (P > 1 && (pr.has_colcost || pr.has_colavoid)) {
+    for (int q = 0; q < NPASS; q++) { const int e = lane + q * WAVE; if (e < b) { L.blk[1][e] = load_block(0, e); L.blk[2][e] = load_block(1, e); } }
+    if (lane < n + m) L.zr[0][lane] = load_ref(0);
+    if (lane < AUX) L.aux[1][lane] = load_aux(0);                          // aux[(k+1)&1] = [coef of knot k+1 | gvt of step k]
+    if (C::NC > 0 && lane < C::NC) L.aux[0][lane] = G.rec[R::COEF + lane]; // coef of knot 0
+    __syncthreads();
+    for (int k = 0; k < N - 1; k++) {
+        const int s0 = k & 3, s1 = (k + 1) & 3, s2 = (k + 2) & 3, s3 = (k + 3) & 3, a0 = k & 1;
+        const double* Bp = L.blk[s0];     // block k-1 : x_k in [0, n)
+        const double* Bk = L.blk[s1];     // block k   : x_{k+1} | u_k | lambda_k
+        const double* Bn = L.blk[s2];     // block k+1 : .. | lambda_{k+1}
+        const double* Zr = L.zr[a0];
+        const double* Ck = L.aux[a0];         // coefficients of knot k (first NC entries)
+        const double* Ax = L.aux[a0 ^ 1];     // [coefficients of knot k+1 | gvt of step k]
+        double pre[NPASS];
 #pragma unroll
-            for (int jj = 0; jj < P - 1; jj++) {
-                const int j = jj < i ? jj : jj + 1;
-                double dl0 = 0, dl1 = 0;
-                // runtime (i, j): select positions without dynamic register indexing
+        for (int q = 0; q < NPASS; q++) pre[q] = load_block(k + 2, lane + q * WAVE);
+        const double prer = load_ref(k + 1);
+        const bool has_next = (k + 1 <= N - 2);
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
 #pragma unroll
-                for (int a = 0; a < P; a++) {
-                    dl0 += (a == i ? pos[a] : 0.0) - (a == j ? pos[a] : 0.0);
-                    dl1 += (a == i ? pos[P + a] : 0.0) - (a == j ? pos[P + a] : 0.0);
-                }
-                double gv0 = 0, gv1 = 0, H0 = 0, H1 = 0, H2 = 0;
-                const double s2 = dl0 * dl0 + dl1 * dl1;
-                if (pr.has_colcost) {
-                    const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
-                    if (fmax(0.0, rad - nrm) > 0.0) {
-                        const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
-                        const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
-                        const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
-                        gv0 += w * (-g0); gv1 += w * (-g1);
-                        const double n3 = nrm * nrm * nrm;
-                        H0 += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
-                        H1 += w * (mu * (rad * (dl0 * dl1) / n3));
-                        H2 += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
+        for (int q = 0; q < NPASS; q++) {
+            const int e = lane + q * WAVE;
+            if (e >= b) continue;
+            double r = 0.0, rhat = 0.0; int vrow = 0; bool dynrow = false;
+            if (e < P * n) {
+                // opt_i,x_{k+1}[a] = cost grad + pair terms + A_{k+1}' lambda_{i,k+1} - lambda_{i,k} (+ reg (x - xref))
+                const int i = e / n, a = e % n;
+                const double* ln = Bn + n + m + i * n;
+                r = -Bk[e + n + m];
+                if (has_next) r += AT_vec<C>(Ax, dt, [&](int rr) { return ln[rr]; }, a);
+                r += w * (L.tq[e] * (Bk[a] - L.tx[e]));
+                if (P > 1 && a < 2 * P) r += Ax[C::NC + (i * P + a % P) * 2 + a / P];
+                if (zref) r += reg * (Bk[a] - Zr[a]);
+                if (MODE == 2) vrow = vx<C>(N, i, k) + a;
+            } else if (e < P * n + m) {
+                // opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
+                const int c = e - P * n, i = c % P;
+                const double u = Bk[n + uoff<C>(c)];
+                const double* lk = Bk + n + m + i * n;
+                double g = 0.0; rhat = dt * L.tr[c] + jreg;
+                if (pr.has_ctl) {
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int ci = con_ctl<C>(pr, k, half * m + c);
+                        const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                        G.vals[ci] = cv;
+                        if (isfinite(cv)) {
+                            const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
+                            const double wl = lm + am * cv;
+                            g += (half == 0 ? wl : -wl); rhat += am;
+                            vcon = fmax(vcon, fmax(0.0, cv));
+                        }
                     }
                 }
-                if (pr.has_colavoid) {
-                    const double Rr = pr.ca_radius[i] + pr.ca_radius[j];
-                    const double c = Rr * Rr - s2;
-                    const int ci = con_col<C>(N, pairq<C>(i, j), kn);
-                    const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
-                    const double wl = lm + am * c;
-                    gv0 += -2.0 * dl0 * wl; gv1 += -2.0 * dl1 * wl;
-                    H0 += am * 4.0 * dl0 * dl0; H1 += am * 4.0 * dl0 * dl1; H2 += am * 4.0 * dl1 * dl1;
-                    G.vals[ci] = c; vsta = fmax(vsta, fmax(0.0, c));
+                r = dt * (L.tr[c] * (u - L.tu[c])) + g + BT_vec<C>(Ck, dt, [&](int rr) { return lk[rr]; }, c);
+                if (zref) r += reg * (u - Zr[n + uoff<C>(c)]);
+                if (MODE >= 1) G.rec[(size_t)k * R::LEN + R::RHAT + c] = rhat;
+                if (MODE == 2) vrow = vu<C>(N, i, k) + c / P;
+            } else {
+                // dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint, RobotDynamics 0.3.1)
+                const int a = e - P * n - m;
+                double xn;
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                    if (a < m) { const double vm = Bp[a + m] + (Bk[n + uoff<C>(a)] * dt) * 0.5; xn = Bp[a] + vm * dt; }
+                    else xn = Bp[a] + Bk[n + uoff<C>(a - m)] * dt;
+                } else {
+                    const int blkk = a / P, i = a % P;
+                    if (blkk <= 1) {
+                        const double vm = Bp[3 * P + i] + (Bk[n + uoff<C>(P + i)] * dt) * 0.5;
+                        xn = Bp[a] + vm * Ck[(blkk == 0 ? 1 : 3) * P + i];                  // dt cos(thm) / dt sin(thm)
+                    } else xn = Bp[a] + Bk[n + uoff<C>((blkk - 2) * P + i)] * dt;
                 }
-                gacc0 += gv0; gacc1 += gv1; gj[2 * jj] = gv0; gj[2 * jj + 1] = gv1;
-                if (MODE >= 1) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
+                r = xn - Bk[a];
+                dynrow = true;
+                if (MODE == 2) vrow = vd<C>(N, k) + a;
             }
-        } else if (P > 1 && MODE >= 1) {
-#pragma unroll
-            for (int jj = 0; jj < P - 1; jj++) { double* hh = rec + R::HH + 3 * (i * (P - 1) + jj); hh[0] = hh[1] = hh[2] = 0.0; gj[2 * jj] = gj[2 * jj + 1] = 0.0; }
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < (P > 1 ? P - 1 : 1); jj++) gj[2 * jj] = gj[2 * jj + 1] = 0.0;
+            l1 += fabs(r); bad |= !isfinite(r);
+            if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
+            if (MODE >= 1) G.rec[(size_t)k * R::LEN + R::RX + e] = r;           // rx | ru | rd are contiguous: coalesced
+            if (MODE == 2) G.res[vrow] = r;
         }
-        // stream over the n entries of the row
+        const double prea = (k + 1 <= N - 2) ? load_aux(k + 1) : 0.0;
+        // rotate the window
 #pragma unroll
-        for (int a = 0; a < n; a++) {
-            double r = -lk[a];
-            if (has_next) r += AT_vec<C>(coef1, dt, [&](int rr) { return ln[rr]; }, a);
-            const int owner = a % P, jblk = a / P;
-            if (owner == i) r += w * (G.Qd[i * ni + jblk] * (x1[a] - G.xf[i * ni + jblk]));      // LQR gradient on pz[i]
-            if (a < 2 * P && P > 1) {
-                const int ax = a / P;                                                              // 0: x, 1: y
-                if (owner == i) r += (ax == 0 ? gacc0 : gacc1);
-                else { const int jj = owner < i ? owner : owner - 1; r -= gj[2 * jj + ax]; }
-            }
-            if (xr) r += reg * (x1[a] - xr[a]);
-            if (MODE >= 1) rec[R::RX + i * n + a] = r;
-            if (MODE == 2) G.res[vx<C>(N, i, k) + a] = r;
-            l1 += fabs(r); vopt = fmax(vopt, fabs(r)); bad |= !isfinite(r);
-        }
+        for (int q = 0; q < NPASS; q++) { const int e = lane + q * WAVE; if (e < b) L.blk[s3][e] = pre[q]; }
+        if (lane < n + m) L.zr[a0 ^ 1][lane] = prer;
+        __syncthreads();                 // everyone is done with aux[a0] (coefficients of knot k) before it is refilled
+        if (lane < AUX) L.aux[a0][lane] = prea;
+        __syncthreads();
     }
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
     out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
@@ -502,29 +567,6 @@ __device__ __forceinline__ double delta_step(const Params& pr, const double* dz,
 // ================================================================================================
 // Newton direction: structured elimination of the KKT system (see file header)
 // ================================================================================================
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-template <class C>
-struct DirLds {
-    static constexpr int LDP = C::n + 1;                 // padded row stride of P_i
-    static constexpr int KB = C::n / 4;                  // k-blocks of the 16x16x4 f64 MFMA
-    static_assert(C::n % 4 == 0 && C::n <= 16, "MFMA tile path needs n % 4 == 0 and n <= 16");
-    double Pm[C::P * C::n * LDP];      // P_i, row-major
-    double Fx[C::n * 16];              // [F | f | 0]: n x 16 (f in column n when n < 16)
-    double fv[C::n];
-    double s[C::P * C::n];
-    double t[C::P * C::n];
-    double V[C::m * C::n];
-    double W[C::m * C::m];
-    double rec[2][Rec<C>::LEN];
-    double kg[2][C::m * (C::n + 1)];
-    double coefn[C::NC > 0 ? C::NC : 1];
-    double qd[C::P * C::ni];
-    double dx[C::n], du[C::m];
-    double dl[C::P * C::n];
-    int singular;
-};
-
 // (i,r,c) entry of the position block of Q^_i built from the pair Hessian table Hh (sign pattern [[+H,-H],[-H,+H]])
 template <class C>
 __device__ __forceinline__ double pairblock(const double* Hh, int i, int r, int c) {
@@ -592,6 +634,36 @@ __device__ __forceinline__ int lu_solve_regs(const double* Wl /*LDS, row-major M
     return sing;
 }
 
+// Expands [Hh | Hd] of a step record into the table hx[i][jr][jc][3] (entry = block of Q^_i between the positions of
+// players jr and jc).  src/sgn are the per-lane loop-invariant source offsets and signs.
+template <class C>
+struct HxMap {
+    static constexpr int SLOTS = (DirLds<C>::NHX + WAVE - 1) / WAVE;
+    int src[SLOTS]; double sgn[SLOTS];
+    __device__ __forceinline__ void init(int lane) {
+        constexpr int P = C::P;
+        using R = Rec<C>;
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++) {
+            const int t = lane + q * WAVE;
+            int so = R::HH; double sg = 0.0;
+            if (P > 1 && t < DirLds<C>::NHX) {
+                const int h = t % 3, jc = (t / 3) % P, jr = (t / (3 * P)) % P, i = t / (3 * P * P);
+                if (jr == i && jc == i) { so = R::HD + 3 * i + h; sg = 1.0; }
+                else if (jr == i) { so = R::HH + 3 * pairq<C>(i, jc) + h; sg = -1.0; }
+                else if (jc == i) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = -1.0; }
+                else if (jr == jc) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = 1.0; }
+            }
+            src[q] = so; sgn[q] = sg;
+        }
+    }
+    __device__ __forceinline__ void expand(int lane, const double* Rc, double* hxt) const {
+        if (C::P == 1) return;
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++) { const int t = lane + q * WAVE; if (t < DirLds<C>::NHX) hxt[t] = sgn[q] * Rc[src[q]]; }
+    }
+};
+
 // Solves J d = -res for the step records left by assemble_pass<C,1> and writes d into the delta buffer
 // (solver_methods.jl:87-88).  Returns ALG_STATUS_*.
 template <class C>
@@ -601,94 +673,101 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     const int N = pr.N, lane = threadIdx.x;
     const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
     const double dt = pr.dt;
-    double* dz = G.z[2];
-    constexpr int RPL = (R::LEN + WAVE - 1) / WAVE;      // record doubles per lane
+    double* __restrict__ dz = G.z[2];
+    constexpr int RPL = (R::LEN_SWEEP + WAVE - 1) / WAVE;      // record doubles per lane
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
-    if (lane == 0) L.singular = 0;
-    for (int e = lane; e < P * C::ni; e += WAVE) L.qd[e] = G.Qd[e];
+    HxMap<C> hxm; hxm.init(lane);
+    for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd[i * C::ni + r / P] : 0.0; }
     for (int e = lane; e < n * 16; e += WAVE) L.Fx[e] = 0.0;
     for (int e = lane; e < P * n * LDP; e += WAVE) L.Pm[e] = 0.0;
-    for (int e = lane; e < R::LEN; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    // ---- loop-invariant lane roles of the MFMA C-init: register r4 holds (row = lq + 4 r4, col = lrow)
+    const bool colP = lrow < n, colS = (lrow == n) && (n < 16), colB = lrow < 2 * P;
+    int hxo[4]; bool rowok[4], diag[4], inb[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+        const int row = lq + 4 * r4;
+        rowok[r4] = row < n; diag[r4] = rowok[r4] && row == lrow; inb[r4] = P > 1 && row < 2 * P && colB;
+        hxo[r4] = inb[r4] ? ((row % P) * P + lrow % P) * 3 + row / P + lrow / P : 0;
+    }
     __syncthreads();
     // ------------------------------------------------------------------ backward sweep
-    int cur = 0;
+    int cur = 0, sing = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
         double pre[RPL];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
-        const int kn = k + 1;
-        const double w = (kn < N - 1) ? dt : 1.0;
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
         const double* coefk = Rc + R::COEF;
-        const double* Hh = Rc + R::HH;
+        hxm.expand(lane, Rc, L.hx);
+        if (n == 16 && k < N - 2) {
+            // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
+            for (int e = lane; e < P * n; e += WAVE) {
+                const int i = e / n, r = e % n; double a = L.s[e];
+                for (int c = 0; c < n; c++) a += L.Pm[i * n * LDP + r * LDP + c] * L.fv[c];
+                L.t[e] = a;
+            }
+        }
+        __syncthreads();
         // ---- P_i <- Q^_i + A_{k+1}' (P_i [F|f] + [0|s_i]) ,  s_i <- rx_i + A_{k+1}' (P_i f + s_i)   via chained f64 MFMAs
+        double4_t acc2[P];
         {
             double bF[KB], aA[KB];
             if (k < N - 2) {
 #pragma unroll
                 for (int kb = 0; kb < KB; kb++) {
                     bF[kb] = L.Fx[(4 * kb + lq) * 16 + lrow];
-                    aA[kb] = lrow < n ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
+                    aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
                 }
             }
-            double4_t acc2[P];
 #pragma unroll
             for (int i = 0; i < P; i++) {
-                // C-init of the second product: [Q^_i | rx_i]
-                double4_t c2;
+                double4_t c2;                                   // C-init of the second product: [Q^_i | rx_i]
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) {
-                    const int row = lq + 4 * r4, col = lrow;
-                    double v = 0.0;
-                    if (row < n) {
-                        if (col < n) v = qhat_entry<C>(L.qd, Hh, i, row, col, w, reg);
-                        else if (col == n) v = Rc[R::RX + i * n + row];
-                    }
+                    const int row = lq + 4 * r4;
+                    double v = diag[r4] ? reg + w * L.qdf[i * n + row] : 0.0;
+                    if (P > 1) { const double hv = L.hx[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
+                    const double rxv = Rc[R::RX + i * n + (rowok[r4] ? row : 0)];
+                    v = (colS && rowok[r4]) ? rxv : v;
                     c2[r4] = v;
                 }
                 if (k < N - 2) {
                     double4_t c1;
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) { const int row = lq + 4 * r4; c1[r4] = (lrow == n && row < n) ? L.s[i * n + row] : 0.0; }
+                    for (int r4 = 0; r4 < 4; r4++) { const int row = lq + 4 * r4; const double sv = L.s[i * n + (rowok[r4] ? row : 0)]; c1[r4] = (colS && rowok[r4]) ? sv : 0.0; }
 #pragma unroll
                     for (int kb = 0; kb < KB; kb++) {
-                        const double aP = lrow < n ? L.Pm[i * n * LDP + lrow * LDP + 4 * kb + lq] : 0.0;
-                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aP, bF[kb], c1, 0, 0, 0);
+                        const double pv = L.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
+                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
                     }
 #pragma unroll
                     for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
                 }
                 acc2[i] = c2;
             }
-            if (n == 16 && k < N - 2) {
-                // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
-                for (int e = lane; e < P * n; e += WAVE) {
-                    const int i = e / n, r = e % n; double a = L.s[e];
-                    for (int c = 0; c < n; c++) a += L.Pm[i * n * LDP + r * LDP + c] * L.fv[c];
-                    L.t[e] = a;
+        }
+        __syncthreads();           // all reads of Pm / s done
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int row = lq + 4 * r4;
+                if (rowok[r4]) {
+                    if (colP) L.Pm[i * n * LDP + row * LDP + lrow] = acc2[i][r4];
+                    else if (colS) L.s[i * n + row] = acc2[i][r4];
                 }
             }
-            __syncthreads();           // all reads of Pm / s done
-#pragma unroll
-            for (int i = 0; i < P; i++) {
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const int row = lq + 4 * r4;
-                    if (row < n) {
-                        if (lrow < n) L.Pm[i * n * LDP + row * LDP + lrow] = acc2[i][r4];
-                        else if (lrow == n && n < 16) L.s[i * n + row] = acc2[i][r4];
-                    }
-                }
-            }
-            if (n == 16) {
-                for (int e = lane; e < P * n; e += WAVE) {
-                    const int i = e / n, r = e % n; const double* ti = &L.t[i * n];
-                    double v = Rc[R::RX + e];
-                    if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
-                    L.s[e] = v;
-                }
+        }
+        if (n == 16) {
+            for (int e = lane; e < P * n; e += WAVE) {
+                const int i = e / n, r = e % n; const double* ti = &L.t[i * n];
+                double v = Rc[R::RX + e];
+                if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
+                L.s[e] = v;
             }
         }
         __syncthreads();
@@ -698,38 +777,41 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             L.V[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
         }
         __syncthreads();
-        // ---- W = diag(R^) + V B (cooperative) ; this lane's right-hand-side column of [ V A_k | V rd + B' s + ru ]
-        for (int e = lane; e < m * m; e += WAVE) {
-            const int c = e / m, c2 = e % m; const double* Vc = &L.V[c * n];
-            L.W[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, c2) + (c == c2 ? Rc[R::RHAT + c] : 0.0);
+        // ---- W = diag(R^) + V B ; g = ru + B' s + V rd (cooperative) ; this lane's column of V A_k
+        for (int e = lane; e < m * m + m; e += WAVE) {
+            if (e < m * m) {
+                const int c = e / m, c2 = e % m; const double* Vc = &L.V[c * n];
+                L.W[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, c2) + (c == c2 ? Rc[R::RHAT + c] : 0.0);
+            } else {
+                const int c = e - m * m; const double* Vc = &L.V[c * n]; const double* si = &L.s[(c % P) * n];
+                double v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return si[rr]; }, c);
+                for (int rr = 0; rr < n; rr++) v += Vc[rr] * Rc[R::RD + rr];
+                L.g[c] = v;
+            }
         }
-        double b[m];
-        const int col = lane <= n ? lane : n;           // lanes > n mirror the last column (results unused)
+        double bcol[m];
+        const int col = lane < n ? lane : n - 1;
 #pragma unroll
         for (int c = 0; c < m; c++) {
             const double* Vc = &L.V[c * n];
-            double v;
-            if (col < n) v = (k >= 1) ? XA_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, col) : 0.0;
-            else {
-                const double* si = &L.s[(c % P) * n];
-                v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return si[rr]; }, c);
-                for (int rr = 0; rr < n; rr++) v += Vc[rr] * Rc[R::RD + rr];
-            }
-            b[c] = v;
+            bcol[c] = (k >= 1) ? XA_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, col) : 0.0;
         }
         __syncthreads();
-        const int sing = lu_solve_regs<m>(L.W, b);
-        if (sing) return ALG_STATUS_SINGULAR;          // wave-uniform
+        if (lane >= n) {
+#pragma unroll
+            for (int c = 0; c < m; c++) bcol[c] = L.g[c];
+        }
+        sing |= lu_solve_regs<m>(L.W, bcol);
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
         if (lane <= n) {
-            double* Kg = G.kgain + (size_t)k * NK + lane * m;
+            double* __restrict__ Kg = G.kgain + (size_t)k * NK + lane * m;
 #pragma unroll
-            for (int c = 0; c < m; c++) { b[c] = -b[c]; Kg[c] = b[c]; }
+            for (int c = 0; c < m; c++) { bcol[c] = -bcol[c]; Kg[c] = bcol[c]; }
 #pragma unroll
             for (int r = 0; r < n; r++) {
-                double v = B_vec<C>(coefk, dt, [&](int cc) { return b[cc]; }, r);
-                if (lane < n) v += (k >= 1) ? A_entry<C>(coefk, dt, r, lane) : 0.0;
-                else v += Rc[R::RD + r];
+                double v = B_vec<C>(coefk, dt, [&](int cc) { return bcol[cc]; }, r);
+                const double av = (k >= 1) ? A_entry<C>(coefk, dt, r, lane < n ? lane : 0) : 0.0;
+                v += (lane < n) ? av : Rc[R::RD + r];
                 if (lane < n || n < 16) L.Fx[r * 16 + lane] = v;
                 if (lane == n) L.fv[r] = v;
             }
@@ -737,13 +819,14 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = coefk[lane];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN) L.rec[cur ^ 1][e] = pre[q]; }
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
         }
         __syncthreads();
     }
+    if (sing) return ALG_STATUS_SINGULAR;              // wave-uniform (every lane factors the same matrix)
     // ------------------------------------------------------------------ forward sweep: dx, du
     if (lane < n) { L.dx[lane] = 0.0; dz[lane] = 0.0; }
-    for (int e = lane; e < R::LEN; e += WAVE) L.rec[0][e] = G.rec[e];
+    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[e];
     for (int e = lane; e < NK; e += WAVE) L.kg[0][e] = G.kgain[e];
     __syncthreads();
     cur = 0;
@@ -752,12 +835,13 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         double pre[RPL], prek[KPL];
         if (k + 1 < N - 1) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN ? G.rec[(size_t)(k + 1) * R::LEN + e] : 0.0; }
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k + 1) * R::LEN + e] : 0.0; }
 #pragma unroll
             for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; prek[q] = e < NK ? G.kgain[(size_t)(k + 1) * NK + e] : 0.0; }
         }
         if (lane < m) {
             double acc = Kl[n * m + lane];
+#pragma unroll
             for (int q = 0; q < n; q++) acc += Kl[q * m + lane] * L.dx[q];
             L.du[lane] = acc;
             dz[n + hu<C>(k, 0) + uoff<C>(lane)] = acc;
@@ -770,7 +854,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         if (lane < n) { L.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; }
         if (k + 1 < N - 1) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN) L.rec[cur ^ 1][e] = pre[q]; }
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
 #pragma unroll
             for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.kg[cur ^ 1][e] = prek[q]; }
         }
@@ -778,7 +862,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     }
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    for (int e = lane; e < R::LEN; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
+    const bool cpos = P > 1 && cr_ < 2 * P;
     __syncthreads();
     cur = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
@@ -786,28 +872,28 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         double pre[RPL];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         if (lane < n) L.dx[lane] = dz[n + hx<C>(k) + lane];
+        hxm.expand(lane, Rc, L.hx);
         __syncthreads();
-        double v[(P * n + WAVE - 1) / WAVE]; int cnt = 0;
-        for (int e = lane; e < P * n; e += WAVE, cnt++) {
-            const int i = e / n, r = e % n;
-            double acc = Rc[R::RX + e];
-            double qd = reg; if (r % P == i) qd += w * L.qd[i * C::ni + r / P];
-            acc += qd * L.dx[r];
-            if (P > 1 && r < 2 * P) for (int c = 0; c < 2 * P; c++) acc += pairblock<C>(Rc + R::HH, i, r, c) * L.dx[c];
-            if (k < N - 2) { const double* dli = &L.dl[i * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, r); }
-            v[cnt] = acc;
+        double acc = 0.0;
+        if (lane < P * n) {
+            acc = Rc[R::RX + lane] + (reg + w * L.qdf[lane]) * L.dx[cr_];
+            if (cpos) {
+                const double* hrow = &L.hx[(ci_ * P + cr_ % P) * P * 3 + cr_ / P];
+#pragma unroll
+                for (int c = 0; c < 2 * P; c++) acc += hrow[(c % P) * 3 + c / P] * L.dx[c];
+            }
+            if (k < N - 2) { const double* dli = &L.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
         __syncthreads();
-        cnt = 0;
-        for (int e = lane; e < P * n; e += WAVE, cnt++) { L.dl[e] = v[cnt]; dz[n + hl<C>(k, 0) + e] = v[cnt]; }
+        if (lane < P * n) { L.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN) L.rec[cur ^ 1][e] = pre[q]; }
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
         }
         __syncthreads();
     }
@@ -861,9 +947,10 @@ __device__ void jacobian_dense(const Params& pr, const Game& G, double reg, doub
 // record! (statistics.jl:44-57): unregularised residual at pdtraj; also leaves the step records (with the Jacobian
 // regularisation jreg folded into R^) for the Newton direction and refreshes G.vals
 template <class C>
-__device__ __forceinline__ alg_record make_record(const Params& pr, const Game& G, double delta, int outer, double jreg, int* nonfinite) {
+__device__ __forceinline__ alg_record make_record(const Params& pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, int* nonfinite) {
     ResOut ro;
-    assemble_pass<C, 1>(pr, G, G.z[0], nullptr, 0.0, jreg, ro);
+    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, jreg, ro);
+    __syncthreads();
     alg_record rc;
     rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
     rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
@@ -873,14 +960,14 @@ __device__ __forceinline__ alg_record make_record(const Params& pr, const Game& 
 
 // line_search (solver_methods.jl:105-125)
 template <class C>
-__device__ void line_search(const Params& pr, const Game& G, double reg, double res_norm0, double* alpha_out, int* j_out) {
+__device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double reg, double res_norm0, double* alpha_out, int* j_out) {
     const alg_options& o = pr.opt;
     int j = 1; double alpha = 1.0;
     while (j < o.ls_iter) {
         update_traj<C>(pr, G.z[1], G.z[0], alpha, G.z[2]);
         __syncthreads();
         ResOut ro;
-        assemble_pass<C, 0>(pr, G, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, ro);
+        assemble_pass<C, 0>(pr, G, L.a, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, ro);
         const double rt = ro.l1 / (double)pr.S;
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
@@ -898,25 +985,25 @@ __device__ __forceinline__ void push_record(const Params& pr, const Game& G, con
 
 // inner_iteration (solver_methods.jl:67-103)
 template <class C>
-__device__ alg_step_info inner_iteration(const Params& pr, const Game& G, DirLds<C>& L, int& LS_count, double& Delta, int k, int l) {
+__device__ alg_step_info inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l) {
     const alg_options& o = pr.opt;
     alg_step_info info;
     info.status = ALG_STATUS_OK; info.control_flow = 0; info.ls_j = 0; info.ls_failed = 0; info.alpha = 0.0; info.delta = 0.0;
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
     int nonfinite = 0;
-    alg_record rc = make_record<C>(pr, G, Delta, k, reg, &nonfinite);      // :73-76 (the regularisation term is zero at pdtraj)
+    alg_record rc = make_record<C>(pr, G, L, Delta, k, reg, &nonfinite);      // :73-76 (the regularisation term is zero at pdtraj)
     const double rn = rc.res;
     info.rec = rc;
     Delta = 0.0;                                                           // :79
     if (nonfinite) { info.status = ALG_STATUS_NAN; info.control_flow = 1; push_record(pr, G, rc); return info; }
     if (rc.opt_vio < o.eps_opt) { info.control_flow = 1; push_record(pr, G, rc); return info; }   // :80-82
     __syncthreads();
-    const int st = newton_direction<C>(pr, G, L, reg);                     // :84-88
+    const int st = newton_direction<C>(pr, G, L.d, reg);                   // :84-88
     if (st != ALG_STATUS_OK) { info.status = st; info.control_flow = 1; push_record(pr, G, rc); return info; }
     __syncthreads();
     double alpha; int j;
-    line_search<C>(pr, G, reg, rn, &alpha, &j);                            // :91
+    line_search<C>(pr, G, L, reg, rn, &alpha, &j);                         // :91
     const int failed = (j == o.ls_iter);                                   // :92
     if (failed) LS_count += 1; else LS_count = 0;                          // :93
     __syncthreads();
@@ -1027,7 +1114,7 @@ __device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t g
 
 // newton_solve! (solver_methods.jl:5-65)
 template <class C>
-__device__ void newton_solve(const Params& pr, const Game& G, DirLds<C>& L, int init, uint64_t game_id) {
+__device__ void newton_solve(const Params& pr, const Game& G, Lds<C>& L, int init, uint64_t game_id) {
     const alg_options& o = pr.opt; const int lane = threadIdx.x;
     if (lane == 0) { alg_game_stats z{}; *G.st = z; }                       // reset!(prob.stats)
     if (init) init_traj<C>(pr, G, G.z[0], game_id, true);                  // :13
@@ -1056,7 +1143,7 @@ __device__ void newton_solve(const Params& pr, const Game& G, DirLds<C>& L, int 
         __syncthreads();
     }
     __syncthreads();
-    alg_record fin = make_record<C>(pr, G, Delta, out, 0.0, nullptr);      // :63
+    alg_record fin = make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);   // :63
     push_record(pr, G, fin);
     if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; G.st->last = fin; }
 }

@@ -15,7 +15,7 @@ using namespace alg;
 // ------------------------------------------------------------------------------------------------
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_newton_solve(Params pr, Buffers bf, int init, uint64_t game_id0) {
-    __shared__ DirLds<C> L;
+    __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g);
@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(WAVE) k_newton_solve(Params pr, Buffers bf, in
 
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_newton_step(Params pr, Buffers bf, int k, int l, alg_step_info* out) {
-    __shared__ DirLds<C> L;
+    __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     int ls = 0; double dl = 0.0;
@@ -33,11 +33,12 @@ __global__ void __launch_bounds__(WAVE) k_newton_step(Params pr, Buffers bf, int
 
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int which, double reg, double* res_out, double* rn_out) {
+    __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     ResOut ro;
     // the proximal term is taken w.r.t. pdtraj (regularize_residual!, global_quantities.jl:67-86)
-    assemble_pass<C, 2>(pr, G, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, 0.0, ro);
+    assemble_pass<C, 2>(pr, G, L.a, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, 0.0, ro);
     __syncthreads();
     if (res_out) for (int e = threadIdx.x; e < pr.S; e += WAVE) res_out[(size_t)g * pr.S + e] = G.res[e];
     if (rn_out && threadIdx.x == 0) rn_out[g] = ro.l1 / (double)pr.S;
@@ -45,32 +46,34 @@ __global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int wh
 
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, Buffers bf, double reg, double* J) {
+    __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     ResOut ro;
-    assemble_pass<C, 1>(pr, G, G.z[0], nullptr, 0.0, reg, ro);
+    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
     __syncthreads();
     jacobian_dense<C>(pr, G, reg, J + (size_t)g * pr.S * pr.S);
 }
 
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_direction(Params pr, Buffers bf, double reg, int* status) {
-    __shared__ DirLds<C> L;
+    __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     ResOut ro;
-    assemble_pass<C, 1>(pr, G, G.z[0], nullptr, 0.0, reg, ro);
+    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
     __syncthreads();
-    const int st = newton_direction<C>(pr, G, L, reg);
+    const int st = newton_direction<C>(pr, G, L.d, reg);
     if (status && threadIdx.x == 0) status[g] = st;
 }
 
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_line_search(Params pr, Buffers bf, double reg, const double* rn, double* alpha, int* j) {
+    __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     double a; int jj;
-    line_search<C>(pr, G, reg, rn[g], &a, &jj);
+    line_search<C>(pr, G, L, reg, rn[g], &a, &jj);
     if (threadIdx.x == 0) { alpha[g] = a; j[g] = jj; }
 }
 
@@ -83,9 +86,10 @@ __global__ void __launch_bounds__(WAVE) k_update(Params pr, Buffers bf, int tgt,
 
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_record(Params pr, Buffers bf, alg_record* out) {
+    __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
-    alg_record rc = make_record<C>(pr, G, 0.0, 0, 0.0, nullptr);
+    alg_record rc = make_record<C>(pr, G, L, 0.0, 0, 0.0, nullptr);
     if (threadIdx.x == 0) out[g] = rc;
 }
 
@@ -150,7 +154,7 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
     {   // Rec<C>::LEN
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : 0;
-        p.rec_len = (p.N - 1) * (nc + 3 * p.npair + p.m + p.p * p.n + p.m + p.n);
+        p.rec_len = (p.N - 1) * (nc + 3 * p.npair + 3 * p.p + p.m + p.p * p.n + p.m + p.n + 2 * p.p * p.p);
     }
     return true;
 }

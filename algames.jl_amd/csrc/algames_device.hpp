@@ -66,6 +66,8 @@ struct Cfg {
     static constexpr int NPAIR = P_ * (P_ - 1);
     static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
     static constexpr int WC = m + n + 1;         // augmented width of the control system
+    // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
+    static constexpr int WPE = (n >= 16) ? 2 : 4;
 };
 
 // ---- index maps (newton_core.jl:40-89), 0-based --------------------------------------------------
@@ -85,6 +87,10 @@ template <class C> __device__ __forceinline__ int con_ctl(const Params& pr, int 
 template <class C> __device__ __forceinline__ const double* zstate(const double* z, int k) { return k == 0 ? z : z + C::n + hx<C>(k - 1); }
 
 // ---- wave reductions ---------------------------------------------------------------------------
+// Opaque copy of the lane id: keeps per-lane role / address computations of a phase from being hoisted out of the
+// solver's outer loops (where every phase's invariants would be live at once).
+__device__ __forceinline__ int phase_lane() { int l = threadIdx.x; asm volatile("" : "+v"(l)); return l; }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
@@ -323,21 +329,24 @@ struct DirLds {
     static constexpr int KB = C::n / 4;                  // k-blocks of the 16x16x4 f64 MFMA
     static constexpr int NHX = C::P * C::P * C::P * 3;   // expanded pair-Hessian table [i][jr][jc][3]
     static_assert(C::n % 4 == 0 && C::n <= 16, "MFMA tile path needs n % 4 == 0 and n <= 16");
-    double Pm[C::P * C::n * LDP];      // P_i, row-major
-    double Fx[C::n * 16];              // [F | f | 0]: n x 16 (f in column n when n < 16)
-    double fv[C::n];
-    double s[C::P * C::n];
-    double t[C::n == 16 ? C::P * C::n : 1];
-    double V[C::m * C::n];
-    double W[C::m * C::m];
-    double g[C::m];
+    struct Bwd {                       // live only during the backward sweep
+        double Pm[C::P * C::n * LDP];  // P_i, row-major
+        double Fx[C::n * 16];          // [F | f | 0]: n x 16 (f in column n when n < 16)
+        double fv[C::n];
+        double s[C::P * C::n];
+        double t[C::P * C::n];         // t_i = P_i f + s_i (n == 16 path) / y_i = P_i rd + s_i
+        double V[C::m * C::n];
+    };
+    struct Fwd {                       // live only during the forward / costate sweeps
+        double kg[2][C::m * (C::n + 1)];
+        double dx[C::n], du[C::m];
+        double dl[C::P * C::n];
+    };
+    union { Bwd bw; Fwd fw; };
     double rec[2][Rec<C>::LEN_SWEEP];
-    double kg[2][C::m * (C::n + 1)];
     double hx[NHX];
     double coefn[C::NC > 0 ? C::NC : 1];
     double qdf[C::P * C::n];           // LQR diagonal of player i padded to joint dims (zero off pz[i])
-    double dx[C::n], du[C::m];
-    double dl[C::P * C::n];
 };
 // LDS of the assemble pass (never live at the same time as DirLds: the kernels hold a union)
 template <class C>
@@ -366,7 +375,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                               const double* __restrict__ zref, double reg, double jreg, ResOut& out) {
     constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b;
     using R = Rec<C>;
-    const int N = pr.N, lane = threadIdx.x;
+    const int N = pr.N, lane = phase_lane();
     const double dt = pr.dt;
     double l1 = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
     // ---------------- phase A ------------------------------------------------------------------------------
@@ -548,13 +557,13 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
 template <class C>
 __device__ __forceinline__ void update_traj(const Params& pr, double* tgt, const double* src, double alpha, const double* dz) {
-    for (int e = threadIdx.x; e < pr.S; e += WAVE) tgt[C::n + e] = src[C::n + e] + alpha * dz[C::n + e];
+    for (int e = phase_lane(); e < pr.S; e += WAVE) tgt[C::n + e] = src[C::n + e] + alpha * dz[C::n + e];
 }
 // Δ_step (primal_dual_traj.jl:130-147)
 template <class C>
 __device__ __forceinline__ double delta_step(const Params& pr, const double* dz, double alpha) {
     double s = 0;
-    for (int e = threadIdx.x; e < (pr.N - 1) * (C::n + C::m); e += WAVE) {
+    for (int e = phase_lane(); e < (pr.N - 1) * (C::n + C::m); e += WAVE) {
         const int k = e / (C::n + C::m), a = e % (C::n + C::m);
         s += fabs(dz[C::n + k * C::b + a]);
     }
@@ -589,49 +598,61 @@ __device__ __forceinline__ double qhat_entry(const double* qd, const double* Hh,
     return e;
 }
 
-// Partial-pivot LU of the m x m control system, done redundantly in the registers of every lane (the pivot choice
-// is wave-uniform), applied to this lane's own right-hand-side column.  Returns 0 or 1 (singular).
+// wave-uniform broadcast of lane `src`'s double
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src); hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+// Partial-pivot Gauss-Jordan of the m x m control system with its n+1 right-hand sides, column-per-lane:
+// lane c < M owns column c of W, lane M + c' owns right-hand-side column c'.  Row operations are lane-local; the
+// pivot column is broadcast with v_readlane, so the pivot choice is wave-uniform.  On exit the right-hand-side
+// lanes hold the solution columns.  Returns 0 or 1 (singular).
 template <int M>
-__device__ __forceinline__ int lu_solve_regs(const double* Wl /*LDS, row-major M x M*/, double* b /*M*/) {
-    double a[M][M];
-#pragma unroll
-    for (int r = 0; r < M; r++)
-#pragma unroll
-        for (int c = 0; c < M; c++) a[r][c] = Wl[r * M + c];
+__device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
     int sing = 0;
 #pragma unroll
     for (int c = 0; c < M; c++) {
-        int piv = c; double best = fabs(a[c][c]);
+        double pc[M];
 #pragma unroll
-        for (int r = c + 1; r < M; r++) { const double v = fabs(a[r][c]); if (v > best) { best = v; piv = r; } }
+        for (int r = 0; r < M; r++) pc[r] = bcast_lane(col[r], c);
+        int piv = c; double best = fabs(pc[c]);
+#pragma unroll
+        for (int r = c + 1; r < M; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
         piv = __builtin_amdgcn_readfirstlane(piv);
         if (!(best > 0.0) || !isfinite(best)) sing = 1;
 #pragma unroll
         for (int r = c + 1; r < M; r++) {
-            if (piv == r) {
-#pragma unroll
-                for (int j = c; j < M; j++) { const double tmp = a[c][j]; a[c][j] = a[r][j]; a[r][j] = tmp; }
-                const double tb = b[c]; b[c] = b[r]; b[r] = tb;
-            }
+            if (piv == r) { double t = col[c]; col[c] = col[r]; col[r] = t; t = pc[c]; pc[c] = pc[r]; pc[r] = t; }
         }
-        const double inv = 1.0 / a[c][c];
-        a[c][c] = inv;
+        const double prow = col[c] * (1.0 / pc[c]);
 #pragma unroll
-        for (int r = c + 1; r < M; r++) {
-            const double f = a[r][c] * inv;
-#pragma unroll
-            for (int j = c + 1; j < M; j++) a[r][j] -= f * a[c][j];
-            b[r] -= f * b[c];
-        }
-    }
-#pragma unroll
-    for (int c = M - 1; c >= 0; c--) {
-        double acc = b[c];
-#pragma unroll
-        for (int j = c + 1; j < M; j++) acc -= a[c][j] * b[j];
-        b[c] = acc * a[c][c];
+        for (int r = 0; r < M; r++) if (r != c) col[r] -= pc[r] * prow;
+        col[c] = prow;
     }
     return sing;
+}
+// Sparse pattern (<= 3 entries) of column `idx` of the n x (m + n) matrix [B_k | A_k]  (idx < m: B column, else A column)
+template <class C>
+__device__ __forceinline__ void col_pattern(const double* coef, double dt, int idx, bool useA, int (&rows)[3], double (&vals)[3]) {
+    constexpr int m = C::m, P = C::P;
+    rows[0] = rows[1] = rows[2] = 0; vals[0] = vals[1] = vals[2] = 0.0;
+    if (idx < m) {
+        if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { rows[0] = idx; vals[0] = 0.5 * dt * dt; rows[1] = idx + m; vals[1] = dt; }
+        else {
+            const int i = idx % P, kind = idx / P;
+            rows[0] = i; rows[1] = P + i; rows[2] = (2 + kind) * P + i;
+            vals[0] = 0.5 * dt * coef[kind * P + i]; vals[1] = 0.5 * dt * coef[(2 + kind) * P + i]; vals[2] = dt;
+        }
+    } else if (useA) {
+        const int c = idx - m;
+        rows[0] = c; vals[0] = 1.0;
+        if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { if (c >= m) { rows[1] = c - m; vals[1] = dt; } }
+        else {
+            const int blk = c / P, i = c % P;
+            if (blk >= 2) { rows[1] = i; vals[1] = coef[(blk - 2) * P + i]; rows[2] = P + i; vals[2] = coef[blk * P + i]; }
+        }
+    }
 }
 
 // Expands [Hh | Hd] of a step record into the table hx[i][jr][jc][3] (entry = block of Q^_i between the positions of
@@ -670,7 +691,7 @@ template <class C>
 __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg) {
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
     using R = Rec<C>;
-    const int N = pr.N, lane = threadIdx.x;
+    const int N = pr.N, lane = phase_lane();
     const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
     const double dt = pr.dt;
     double* __restrict__ dz = G.z[2];
@@ -678,8 +699,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
     HxMap<C> hxm; hxm.init(lane);
     for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd[i * C::ni + r / P] : 0.0; }
-    for (int e = lane; e < n * 16; e += WAVE) L.Fx[e] = 0.0;
-    for (int e = lane; e < P * n * LDP; e += WAVE) L.Pm[e] = 0.0;
+    for (int e = lane; e < n * 16; e += WAVE) L.bw.Fx[e] = 0.0;
+    for (int e = lane; e < P * n * LDP; e += WAVE) L.bw.Pm[e] = 0.0;
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     // ---- loop-invariant lane roles of the MFMA C-init: register r4 holds (row = lq + 4 r4, col = lrow)
     const bool colP = lrow < n, colS = (lrow == n) && (n < 16), colB = lrow < 2 * P;
@@ -706,9 +727,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         if (n == 16 && k < N - 2) {
             // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
             for (int e = lane; e < P * n; e += WAVE) {
-                const int i = e / n, r = e % n; double a = L.s[e];
-                for (int c = 0; c < n; c++) a += L.Pm[i * n * LDP + r * LDP + c] * L.fv[c];
-                L.t[e] = a;
+                const int i = e / n, r = e % n; double a = L.bw.s[e];
+                for (int c = 0; c < n; c++) a += L.bw.Pm[i * n * LDP + r * LDP + c] * L.bw.fv[c];
+                L.bw.t[e] = a;
             }
         }
         __syncthreads();
@@ -719,7 +740,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             if (k < N - 2) {
 #pragma unroll
                 for (int kb = 0; kb < KB; kb++) {
-                    bF[kb] = L.Fx[(4 * kb + lq) * 16 + lrow];
+                    bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
                     aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
                 }
             }
@@ -738,10 +759,10 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 if (k < N - 2) {
                     double4_t c1;
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) { const int row = lq + 4 * r4; const double sv = L.s[i * n + (rowok[r4] ? row : 0)]; c1[r4] = (colS && rowok[r4]) ? sv : 0.0; }
+                    for (int r4 = 0; r4 < 4; r4++) { const int row = lq + 4 * r4; const double sv = L.bw.s[i * n + (rowok[r4] ? row : 0)]; c1[r4] = (colS && rowok[r4]) ? sv : 0.0; }
 #pragma unroll
                     for (int kb = 0; kb < KB; kb++) {
-                        const double pv = L.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
+                        const double pv = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
                         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
                     }
 #pragma unroll
@@ -757,63 +778,61 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             for (int r4 = 0; r4 < 4; r4++) {
                 const int row = lq + 4 * r4;
                 if (rowok[r4]) {
-                    if (colP) L.Pm[i * n * LDP + row * LDP + lrow] = acc2[i][r4];
-                    else if (colS) L.s[i * n + row] = acc2[i][r4];
+                    if (colP) L.bw.Pm[i * n * LDP + row * LDP + lrow] = acc2[i][r4];
+                    else if (colS) L.bw.s[i * n + row] = acc2[i][r4];
                 }
             }
         }
         if (n == 16) {
             for (int e = lane; e < P * n; e += WAVE) {
-                const int i = e / n, r = e % n; const double* ti = &L.t[i * n];
+                const int i = e / n, r = e % n; const double* ti = &L.bw.t[i * n];
                 double v = Rc[R::RX + e];
                 if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
-                L.s[e] = v;
+                L.bw.s[e] = v;
             }
         }
         __syncthreads();
-        // ---- V[c][:] = B[:,c]' P_{i(c)}   (m x n)
+        // ---- V[c][:] = B[:,c]' P_{i(c)}   (m x n)  and  y_i = P_i rd + s_i
         for (int e = lane; e < m * n; e += WAVE) {
-            const int c = e / n, col = e % n; const double* Pi = &L.Pm[(c % P) * n * LDP];
-            L.V[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
+            const int c = e / n, col = e % n; const double* Pi = &L.bw.Pm[(c % P) * n * LDP];
+            L.bw.V[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
+        }
+        for (int e = lane; e < P * n; e += WAVE) {
+            const double* Pr = &L.bw.Pm[(e / n) * n * LDP + (e % n) * LDP];
+            double a = L.bw.s[e];
+#pragma unroll
+            for (int c = 0; c < n; c++) a += Pr[c] * Rc[R::RD + c];
+            L.bw.t[e] = a;
         }
         __syncthreads();
-        // ---- W = diag(R^) + V B ; g = ru + B' s + V rd (cooperative) ; this lane's column of V A_k
-        for (int e = lane; e < m * m + m; e += WAVE) {
-            if (e < m * m) {
-                const int c = e / m, c2 = e % m; const double* Vc = &L.V[c * n];
-                L.W[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, c2) + (c == c2 ? Rc[R::RHAT + c] : 0.0);
-            } else {
-                const int c = e - m * m; const double* Vc = &L.V[c * n]; const double* si = &L.s[(c % P) * n];
-                double v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return si[rr]; }, c);
-                for (int rr = 0; rr < n; rr++) v += Vc[rr] * Rc[R::RD + rr];
-                L.g[c] = v;
+        // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B,  g = ru + B' (P rd + s)
+        double col[m];
+        {
+            int rows[3]; double vals[3];
+            col_pattern<C>(coefk, dt, lane < m + n ? lane : 0, k >= 1, rows, vals);
+#pragma unroll
+            for (int c = 0; c < m; c++) {
+                const double* Vc = &L.bw.V[c * n];
+                double v = vals[0] * Vc[rows[0]] + vals[1] * Vc[rows[1]] + vals[2] * Vc[rows[2]];
+                if (lane == c) v += Rc[R::RHAT + c];
+                if (lane >= m + n) { const double* yi = &L.bw.t[(c % P) * n]; v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
+                col[c] = v;
             }
         }
-        double bcol[m];
-        const int col = lane < n ? lane : n - 1;
-#pragma unroll
-        for (int c = 0; c < m; c++) {
-            const double* Vc = &L.V[c * n];
-            bcol[c] = (k >= 1) ? XA_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, col) : 0.0;
-        }
-        __syncthreads();
-        if (lane >= n) {
-#pragma unroll
-            for (int c = 0; c < m; c++) bcol[c] = L.g[c];
-        }
-        sing |= lu_solve_regs<m>(L.W, bcol);
+        sing |= gj_solve_cols<m>(col);
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
-        if (lane <= n) {
-            double* __restrict__ Kg = G.kgain + (size_t)k * NK + lane * m;
+        if (lane >= m && lane <= m + n) {
+            const int cc = lane - m;
+            double* __restrict__ Kg = G.kgain + (size_t)k * NK + cc * m;
 #pragma unroll
-            for (int c = 0; c < m; c++) { bcol[c] = -bcol[c]; Kg[c] = bcol[c]; }
+            for (int c = 0; c < m; c++) { col[c] = -col[c]; Kg[c] = col[c]; }
 #pragma unroll
             for (int r = 0; r < n; r++) {
-                double v = B_vec<C>(coefk, dt, [&](int cc) { return bcol[cc]; }, r);
-                const double av = (k >= 1) ? A_entry<C>(coefk, dt, r, lane < n ? lane : 0) : 0.0;
-                v += (lane < n) ? av : Rc[R::RD + r];
-                if (lane < n || n < 16) L.Fx[r * 16 + lane] = v;
-                if (lane == n) L.fv[r] = v;
+                double v = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r);
+                const double av = (k >= 1) ? A_entry<C>(coefk, dt, r, cc < n ? cc : 0) : 0.0;
+                v += (cc < n) ? av : Rc[R::RD + r];
+                if (cc < n || n < 16) L.bw.Fx[r * 16 + cc] = v;
+                if (cc == n) L.bw.fv[r] = v;
             }
         }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = coefk[lane];
@@ -825,13 +844,13 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     }
     if (sing) return ALG_STATUS_SINGULAR;              // wave-uniform (every lane factors the same matrix)
     // ------------------------------------------------------------------ forward sweep: dx, du
-    if (lane < n) { L.dx[lane] = 0.0; dz[lane] = 0.0; }
+    if (lane < n) { L.fw.dx[lane] = 0.0; dz[lane] = 0.0; }
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[e];
-    for (int e = lane; e < NK; e += WAVE) L.kg[0][e] = G.kgain[e];
+    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain[e];
     __syncthreads();
     cur = 0;
     for (int k = 0; k < N - 1; k++, cur ^= 1) {
-        const double* Rc = L.rec[cur]; const double* Kl = L.kg[cur];
+        const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
         double pre[RPL], prek[KPL];
         if (k + 1 < N - 1) {
 #pragma unroll
@@ -842,21 +861,21 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         if (lane < m) {
             double acc = Kl[n * m + lane];
 #pragma unroll
-            for (int q = 0; q < n; q++) acc += Kl[q * m + lane] * L.dx[q];
-            L.du[lane] = acc;
+            for (int q = 0; q < n; q++) acc += Kl[q * m + lane] * L.fw.dx[q];
+            L.fw.du[lane] = acc;
             dz[n + hu<C>(k, 0) + uoff<C>(lane)] = acc;
         }
         __syncthreads();
         double dxn = 0.0;
-        if (lane < n) dxn = A_vec<C>(Rc + R::COEF, dt, [&](int rr) { return L.dx[rr]; }, lane)
-                          + B_vec<C>(Rc + R::COEF, dt, [&](int cc) { return L.du[cc]; }, lane) + Rc[R::RD + lane];
+        if (lane < n) dxn = A_vec<C>(Rc + R::COEF, dt, [&](int rr) { return L.fw.dx[rr]; }, lane)
+                          + B_vec<C>(Rc + R::COEF, dt, [&](int cc) { return L.fw.du[cc]; }, lane) + Rc[R::RD + lane];
         __syncthreads();
-        if (lane < n) { L.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; }
+        if (lane < n) { L.fw.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; }
         if (k + 1 < N - 1) {
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
 #pragma unroll
-            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.kg[cur ^ 1][e] = prek[q]; }
+            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.fw.kg[cur ^ 1][e] = prek[q]; }
         }
         __syncthreads();
     }
@@ -875,21 +894,21 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
         const double w = (k + 1 < N - 1) ? dt : 1.0;
-        if (lane < n) L.dx[lane] = dz[n + hx<C>(k) + lane];
+        if (lane < n) L.fw.dx[lane] = dz[n + hx<C>(k) + lane];
         hxm.expand(lane, Rc, L.hx);
         __syncthreads();
         double acc = 0.0;
         if (lane < P * n) {
-            acc = Rc[R::RX + lane] + (reg + w * L.qdf[lane]) * L.dx[cr_];
+            acc = Rc[R::RX + lane] + (reg + w * L.qdf[lane]) * L.fw.dx[cr_];
             if (cpos) {
                 const double* hrow = &L.hx[(ci_ * P + cr_ % P) * P * 3 + cr_ / P];
 #pragma unroll
-                for (int c = 0; c < 2 * P; c++) acc += hrow[(c % P) * 3 + c / P] * L.dx[c];
+                for (int c = 0; c < 2 * P; c++) acc += hrow[(c % P) * 3 + c / P] * L.fw.dx[c];
             }
-            if (k < N - 2) { const double* dli = &L.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
+            if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
         __syncthreads();
-        if (lane < P * n) { L.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; }
+        if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         if (k > 0) {
 #pragma unroll
@@ -944,18 +963,34 @@ __device__ void jacobian_dense(const Params& pr, const Game& G, double reg, doub
 // ================================================================================================
 // Solver control flow (solver_methods.jl:5-125), per game
 // ================================================================================================
+// wave-uniform scalars live in SGPRs
+__device__ __forceinline__ double uni(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+
 // record! (statistics.jl:44-57): unregularised residual at pdtraj; also leaves the step records (with the Jacobian
-// regularisation jreg folded into R^) for the Newton direction and refreshes G.vals
+// regularisation jreg folded into R^) for the Newton direction and refreshes G.vals.  The record is pushed to the
+// game's Statistics history (lane 0); the two scalars the control flow needs are returned.
+struct RecScalars { double res, opt; int nonfinite; };
 template <class C>
-__device__ __forceinline__ alg_record make_record(const Params& pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, int* nonfinite) {
+__device__ __forceinline__ RecScalars make_record(const Params& pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
     ResOut ro;
     assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, jreg, ro);
     __syncthreads();
-    alg_record rc;
-    rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
-    rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
-    if (nonfinite) *nonfinite = ro.nonfinite;
-    return rc;
+    if (threadIdx.x == 0) {
+        alg_record rc;
+        rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
+        rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
+        const int idx = G.st->records;
+        if (idx < pr.hist_max) G.hist[idx] = rc;
+        G.st->records = idx + 1;
+        G.st->last = rc;
+        if (out) *out = rc;
+    }
+    RecScalars r; r.res = uni(ro.l1 / (double)pr.S); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
+    return r;
 }
 
 // line_search (solver_methods.jl:105-125)
@@ -968,54 +1003,45 @@ __device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double r
         __syncthreads();
         ResOut ro;
         assemble_pass<C, 0>(pr, G, L.a, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, ro);
-        const double rt = ro.l1 / (double)pr.S;
+        const double rt = uni(ro.l1 / (double)pr.S);
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
     }
     *alpha_out = alpha; *j_out = j;
 }
 
-__device__ __forceinline__ void push_record(const Params& pr, const Game& G, const alg_record& rc) {
-    if (threadIdx.x == 0) {
-        const int idx = G.st->records;
-        if (idx < pr.hist_max) G.hist[idx] = rc;
-        G.st->records = idx + 1;
-    }
-}
-
-// inner_iteration (solver_methods.jl:67-103)
+// inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
+// the history record / *info (lane 0).
 template <class C>
-__device__ alg_step_info inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l) {
+__device__ int inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l, alg_step_info* info) {
     const alg_options& o = pr.opt;
-    alg_step_info info;
-    info.status = ALG_STATUS_OK; info.control_flow = 0; info.ls_j = 0; info.ls_failed = 0; info.alpha = 0.0; info.delta = 0.0;
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
-    int nonfinite = 0;
-    alg_record rc = make_record<C>(pr, G, L, Delta, k, reg, &nonfinite);      // :73-76 (the regularisation term is zero at pdtraj)
-    const double rn = rc.res;
-    info.rec = rc;
+    if (info && threadIdx.x == 0) { alg_step_info z{}; *info = z; }
+    const RecScalars rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr);   // :73-76 (regularisation term is zero at pdtraj)
     Delta = 0.0;                                                           // :79
-    if (nonfinite) { info.status = ALG_STATUS_NAN; info.control_flow = 1; push_record(pr, G, rc); return info; }
-    if (rc.opt_vio < o.eps_opt) { info.control_flow = 1; push_record(pr, G, rc); return info; }   // :80-82
-    __syncthreads();
+    auto finish = [&](int status, int flow) { if (info && threadIdx.x == 0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
+    if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
+    if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1);              // :80-82
     const int st = newton_direction<C>(pr, G, L.d, reg);                   // :84-88
-    if (st != ALG_STATUS_OK) { info.status = st; info.control_flow = 1; push_record(pr, G, rc); return info; }
+    if (st != ALG_STATUS_OK) return finish(st, 1);
     __syncthreads();
     double alpha; int j;
-    line_search<C>(pr, G, L, reg, rn, &alpha, &j);                         // :91
+    line_search<C>(pr, G, L, reg, rs.res, &alpha, &j);                     // :91
     const int failed = (j == o.ls_iter);                                   // :92
     if (failed) LS_count += 1; else LS_count = 0;                          // :93
     __syncthreads();
     update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);                     // :94
-    Delta = delta_step<C>(pr, G.z[2], alpha);                              // :95
+    Delta = uni(delta_step<C>(pr, G.z[2], alpha));                         // :95
     __syncthreads();
-    info.alpha = alpha; info.ls_j = j; info.ls_failed = failed; info.delta = Delta;
-    rc.alpha = alpha; rc.ls_j = j; info.rec = rc;
-    if (threadIdx.x == 0) { G.st->newton_iters += 1; if (failed) G.st->ls_failures += 1; }
-    push_record(pr, G, rc);
-    if (Delta < o.delta_min) info.control_flow = 1;                        // :96-98
-    return info;
+    if (threadIdx.x == 0) {
+        G.st->newton_iters += 1; if (failed) G.st->ls_failures += 1;
+        const int idx = G.st->records - 1;
+        if (idx < pr.hist_max) { G.hist[idx].alpha = alpha; G.hist[idx].ls_j = j; }
+        G.st->last.alpha = alpha; G.st->last.ls_j = j;
+        if (info) { info->alpha = alpha; info->ls_j = j; info->ls_failed = failed; info->delta = Delta; info->rec.alpha = alpha; info->rec.ls_j = j; }
+    }
+    return finish(ALG_STATUS_OK, Delta < o.delta_min ? 1 : 0);             // :96-98
 }
 
 // reset!(game_con) (constraints_methods.jl:295-327)
@@ -1117,35 +1143,38 @@ template <class C>
 __device__ void newton_solve(const Params& pr, const Game& G, Lds<C>& L, int init, uint64_t game_id) {
     const alg_options& o = pr.opt; const int lane = threadIdx.x;
     if (lane == 0) { alg_game_stats z{}; *G.st = z; }                       // reset!(prob.stats)
+#ifndef ALG_TEST_NOINIT
     if (init) init_traj<C>(pr, G, G.z[0], game_id, true);                  // :13
     else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
     if (lane < C::n) { G.z[1][lane] = G.x0[lane]; G.z[2][lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
     __syncthreads();
     rollout<C>(pr, G.z[0]);                                                // :17
+#endif
     if (o.dual_reset) reset_con(pr, G);                                    // :25
     __syncthreads();
     int out = 0, status = ALG_STATUS_OK, converged = 0; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30
         out = k;
-        int LS_count = 0; alg_record last; bool any = false;
+        int LS_count = 0;
         for (int l = 1; l <= o.inner_iter; l++) {                          // :38
-            alg_step_info info = inner_iteration<C>(pr, G, L, LS_count, Delta, k, l);
-            last = info.rec; any = true;
-            if (info.status != ALG_STATUS_OK) { status = info.status; break; }
-            if (LS_count >= 1 || info.control_flow == 1) break;            // :43
+            const int rcode = inner_iteration<C>(pr, G, L, LS_count, Delta, k, l, nullptr);
+            if ((rcode & 0xff) != ALG_STATUS_OK) { status = rcode & 0xff; break; }
+            if (LS_count >= 1 || (rcode >> 8) == 1) break;                 // :43
         }
         if (status != ALG_STATUS_OK) break;
-        const bool conv = any && last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
-        if (conv) converged = 1;
-        if (k == o.outer_iter || conv) break;                              // :49-55
         __syncthreads();
+        // prob.stats.*_vio[end]: the record made at the top of the last inner iteration (lane 0 wrote it; same wave)
+        const alg_record& last = G.st->last;
+        const bool conv = last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
+        const int convu = __builtin_amdgcn_readfirstlane((int)conv);
+        if (convu) converged = 1;
+        if (k == o.outer_iter || convu) break;                             // :49-55
         dual_penalty_update<C>(pr, G);                                     // :57-61
         __syncthreads();
     }
     __syncthreads();
-    alg_record fin = make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);   // :63
-    push_record(pr, G, fin);
-    if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; G.st->last = fin; }
+    make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);                    // :63
+    if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; }
 }
 
 } // namespace alg

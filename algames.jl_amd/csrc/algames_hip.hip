@@ -14,7 +14,7 @@ using namespace alg;
 // Kernels
 // ------------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_newton_solve(Params pr, Buffers bf, int init, uint64_t game_id0) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr, Buffers bf, int init, uint64_t game_id0) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
@@ -22,13 +22,12 @@ __global__ void __launch_bounds__(WAVE) k_newton_solve(Params pr, Buffers bf, in
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_newton_step(Params pr, Buffers bf, int k, int l, alg_step_info* out) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, Buffers bf, int k, int l, alg_step_info* out) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     int ls = 0; double dl = 0.0;
-    alg_step_info info = inner_iteration<C>(pr, G, L, ls, dl, k, l);
-    if (threadIdx.x == 0 && out) out[g] = info;
+    inner_iteration<C>(pr, G, L, ls, dl, k, l, out + g);
 }
 
 template <class C>
@@ -56,7 +55,7 @@ __global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, Buffers bf, double
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_direction(Params pr, Buffers bf, double reg, int* status) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr, Buffers bf, double reg, int* status) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
@@ -89,8 +88,7 @@ __global__ void __launch_bounds__(WAVE) k_record(Params pr, Buffers bf, alg_reco
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
-    alg_record rc = make_record<C>(pr, G, L, 0.0, 0, 0.0, nullptr);
-    if (threadIdx.x == 0) out[g] = rc;
+    make_record<C>(pr, G, L, 0.0, 0, 0.0, out + g);
 }
 
 template <class C>

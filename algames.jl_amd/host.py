@@ -19,7 +19,7 @@ from ._abi import (ALG_MODEL_DOUBLE_INTEGRATOR, ALG_MODEL_UNICYCLE, ALG_TRAJ_PD,
                    ALG_TRAJ_DELTA, AlgamesError, Batch, CLib)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "lib", "libalgames_hip.so")
+HIP_LIB_PATH = os.environ.get("ALGAMES_HIP_LIB", os.path.join(_HERE, "lib", "libalgames_hip.so"))
 _hip = None
 
 

@@ -198,6 +198,38 @@ def test_newton_solve_parity_c2_full_horizon(alg, orc):
     assert np.all(s["last"]["opt_vio"] < 1e-3) and np.all(s["last"]["sta_vio"] < 1e-3) and np.all(s["last"]["dyn_vio"] < 1e-3)
 
 
+def test_newton_solve_parity_c5_unicycle_constrained(alg, orc):
+    # BASELINE config C5's per-solve problem: 3-player Unicycle, N = 30, collision avoidance + control bounds
+    pg, po = _solve_pair(alg, orc, "C5", np.arange(500, 512))
+    _assert_solve_parity(pg, po)
+    s = pg.stats.summary
+    assert np.all(s["converged"] == 1) and np.all(s["outer_iters"] >= 3)      # the AL loop really iterates
+    lam, _ = pg.batch.get_con_duals()
+    assert lam.max() > 1e-2                                                   # constraints are active
+
+
+def test_newton_solve_parity_c3_unicycle_4_players(alg, orc):
+    # BASELINE config C3: 4-player Unicycle, N = 50 (b = 88 > 64 lanes: exercises the multi-pass row mapping)
+    pg, po = _solve_pair(alg, orc, "C3", np.arange(1016, 1024))
+    _assert_solve_parity(pg, po)
+    assert np.all(pg.stats.summary["converged"] == 1)
+
+
+def test_full_size_c3_properties(alg):
+    """BASELINE config C3 at full size (1024 games): all converge to the reference exit test; deterministic."""
+    prob = alg.scenarios.make_problem("C3", np.arange(1024))
+    alg.newton_solve(prob)
+    s = prob.stats.summary
+    assert np.all(s["status"] == 0) and np.all(s["converged"] == 1)
+    for f in ("opt_vio", "sta_vio", "dyn_vio", "con_vio"):
+        assert np.all(s["last"][f] < 1e-3), f
+    z1 = prob.batch.get_traj()
+    alg.newton_solve(prob)
+    assert np.array_equal(prob.batch.get_traj(), z1)
+    lam, _ = prob.batch.get_con_duals()
+    assert lam.min() >= 0.0 and lam.max() > 1e-2
+
+
 def test_reference_e2e_thresholds_on_gpu(alg):
     """The five newton_solve! problems of test/problem/solver_methods.jl run through the product path."""
     def problem(model, x0, opts, constrained=False):

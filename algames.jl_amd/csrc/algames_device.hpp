@@ -608,6 +608,12 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 // lane c < M owns column c of W, lane M + c' owns right-hand-side column c'.  Row operations are lane-local; the
 // pivot column is broadcast with v_readlane, so the pivot choice is wave-uniform.  On exit the right-hand-side
 // lanes hold the solution columns.  Returns 0 or 1 (singular).
+// 1/x for a pivot (normal, non-zero): hardware reciprocal + one Newton step instead of the IEEE division sequence
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
 template <int M>
 __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
     int sing = 0;
@@ -616,16 +622,23 @@ __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
         double pc[M];
 #pragma unroll
         for (int r = 0; r < M; r++) pc[r] = bcast_lane(col[r], c);
-        int piv = c; double best = fabs(pc[c]);
+        // partial pivoting: the diagonal entry is the usual winner -> one max chain + one uniform test, the index
+        // search and the row swap only run when another row really has the larger magnitude
+        double best = fabs(pc[c]), oth = 0.0;
 #pragma unroll
-        for (int r = c + 1; r < M; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
-        piv = __builtin_amdgcn_readfirstlane(piv);
-        if (!(best > 0.0) || !isfinite(best)) sing = 1;
+        for (int r = c + 1; r < M; r++) oth = fmax(oth, fabs(pc[r]));
+        if (__builtin_amdgcn_readfirstlane((int)(oth > best))) {
+            int piv = c;
 #pragma unroll
-        for (int r = c + 1; r < M; r++) {
-            if (piv == r) { double t = col[c]; col[c] = col[r]; col[r] = t; t = pc[c]; pc[c] = pc[r]; pc[r] = t; }
+            for (int r = c + 1; r < M; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
+            piv = __builtin_amdgcn_readfirstlane(piv);
+#pragma unroll
+            for (int r = c + 1; r < M; r++) {
+                if (piv == r) { double t = col[c]; col[c] = col[r]; col[r] = t; t = pc[c]; pc[c] = pc[r]; pc[r] = t; }
+            }
         }
-        const double prow = col[c] * (1.0 / pc[c]);
+        if (!(best > 0.0) || !isfinite(best)) sing = 1;
+        const double prow = col[c] * fast_rcp(pc[c]);
 #pragma unroll
         for (int r = 0; r < M; r++) if (r != c) col[r] -= pc[r] * prow;
         col[c] = prow;

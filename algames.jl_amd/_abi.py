@@ -101,6 +101,8 @@ SIGNATURES = {
     "get_stats": (C.c_int, [_P, _P]),
     "get_history": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _I]),
     "synchronize": (C.c_int, [_P]),
+    "mpc_advance": (C.c_int, [_P]),
+    "mpc_totals": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
 }
 
 
@@ -326,6 +328,17 @@ class Batch:
 
     def synchronize(self):
         self.lib.check(self.lib.synchronize(self.h))
+
+    def mpc_advance(self):
+        self.lib.check(self.lib.mpc_advance(self.h))
+
+    def mpc_totals(self, reset=False):
+        it = np.zeros(self.B, dtype=np.int64); cv = np.zeros(self.B, dtype=np.int64)
+        self.lib.check(self.lib.mpc_totals(self.h, it.ctypes.data_as(C.POINTER(C.c_int64)), cv.ctypes.data_as(C.POINTER(C.c_int64)), int(reset)))
+        return it, cv
+
+    def get_x0(self):
+        return self.get_traj(ALG_TRAJ_PD)[:, :self.n].copy()
 
     # ---- views of a traj buffer (primal_dual_traj.jl layout) ----------------------------------
     def split_traj(self, z):

@@ -53,6 +53,7 @@ struct Buffers {
     double* kgain;          // B x kscratch_len      feedback gains (backward sweep -> forward sweep)
     alg_game_stats* stats;  // B
     alg_record* hist;       // B x hist_max
+    long long* mpc;         // B x 2 running totals (newton_iters, converged) of the receding-horizon loop
 };
 
 template <int MODEL_, int P_, int D_>

@@ -117,6 +117,24 @@ __global__ void __launch_bounds__(WAVE) k_init(Params pr, Buffers bf, uint64_t g
     }
 }
 
+// builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    Game G = game_view(pr, bf, g);
+    if (lane < C::P) {
+        double x[C::n], u[C::m], xo[C::ni], co[4];
+        for (int j = 0; j < C::ni; j++) x[lane + j * C::P] = G.z[0][lane + j * C::P];
+        for (int j = 0; j < C::mi; j++) u[lane + j * C::P] = G.z[0][C::n + hu<C>(0, lane) + j];
+        model_player<C>(lane, x, u, pr.dt, xo, co);
+        for (int j = 0; j < C::ni; j++) {
+            const int a = lane + j * C::P;
+            bf.x0[(size_t)g * C::n + a] = xo[j]; G.z[0][a] = xo[j]; G.z[1][a] = xo[j];
+        }
+    }
+    if (lane == 0) { bf.mpc[2 * g] += G.st->newton_iters; bf.mpc[2 * g + 1] += G.st->converged; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------------
@@ -265,6 +283,7 @@ int alloc_all(Handle* hd) {
     if ((rc = dalloc(hd, &hd->bf.rec, B * p.rec_len, "bf.rec"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.stats, B, "bf.stats"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max, "bf.hist"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.mpc, 2 * B, "bf.mpc"))) return rc;
     if ((rc = dalloc(hd, &hd->d_tmp, 2 * B, "d_tmp"))) return rc;
     if ((rc = dalloc(hd, &hd->d_itmp, B, "d_itmp"))) return rc;
     if ((rc = dalloc(hd, &hd->d_info, B, "d_info"))) return rc;
@@ -556,5 +575,20 @@ int alg_debug_check_guards(alg_handle* h) {
     return bad;
 }
 int alg_synchronize(alg_handle* h) { int rc = use_device(H); if (rc) return rc; return sync(H); }
+
+int alg_mpc_advance(alg_handle* h) {
+    int rc = use_device(H); if (rc) return rc;
+    LAUNCH(k_mpc_advance, H->pr, H->bf);
+    return ALG_OK;
+}
+int alg_mpc_totals(alg_handle* h, int64_t* it, int64_t* cv, int32_t reset) {
+    int rc = use_device(H); if (rc) return rc;
+    const int B = H->pr.B;
+    std::vector<long long> tmp(2 * (size_t)B);
+    if ((rc = d2h(H, tmp.data(), H->bf.mpc, sizeof(long long) * 2 * B))) return rc;
+    for (int g = 0; g < B; g++) { if (it) it[g] = tmp[2 * g]; if (cv) cv[g] = tmp[2 * g + 1]; }
+    if (reset) { HIPCHK(hipMemsetAsync(H->bf.mpc, 0, sizeof(long long) * 2 * B, H->stream)); return sync(H); }
+    return ALG_OK;
+}
 
 } // extern "C"

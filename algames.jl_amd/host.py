@@ -428,3 +428,32 @@ def state_violation(prob):
 
 def optimality_violation(prob):
     return prob.batch.record()["opt_vio"]
+
+
+# --------------------------------------------------------------------------------------------------
+# Receding-horizon loop (BASELINE config 5).  Not in the reference: Algames.jl v0.1.6 only has the warm-start hooks
+# `opts.shift` / `opts.dual_reset` (options.jl:16-17, primal_dual_traj.jl:35-39, solver_methods.jl:25).  Builder-defined
+# (SURVEY.md 8(d) C5): solve; x0 <- RK2(x_1, u_1); next solve warm-started with shift = 1 and dual_reset = false.
+# --------------------------------------------------------------------------------------------------
+def mpc_solve(prob, steps, record_states=False):
+    """Runs `steps` receding-horizon solves for every game of the batch.  Returns (newton_iters (B,), converged (B,),
+    states (steps+1, B, n) or None).  No host synchronisation happens inside the loop unless record_states is set."""
+    b = prob.batch
+    b.mpc_totals(reset=True)
+    shift0, reset0 = prob.opts.shift, prob.opts.dual_reset
+    states = [b.get_x0()] if record_states else None
+    try:
+        for t in range(steps):
+            if t == 1:
+                prob.opts.shift, prob.opts.dual_reset = 1, False
+                prob._sync_options()
+            elif t == 0:
+                prob._sync_options()
+            b.newton_solve_async(init=True, game_id0=prob.game_id0 + t * 1000003)
+            b.mpc_advance()
+            if record_states:
+                states.append(b.get_x0())
+        it, cv = b.mpc_totals()
+    finally:
+        prob.opts.shift, prob.opts.dual_reset = shift0, reset0
+    return it, cv, (np.stack(states) if record_states else None)

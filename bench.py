@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--games-per-gpu", type=int, default=4096)
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--mpc-steps", type=int, default=0,
+                    help="C5 receding-horizon mode: one bench step = this many warm-started MPC solves per game")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,8 +92,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.mpc_steps:
+        x0_start = prob.x0.copy()
+
     def step():
-        b.newton_solve_async(init=True, game_id0=int(ids[0]))
+        if args.mpc_steps:
+            b.set_x0(x0_start)                                      # restart the same closed-loop rollout
+            alg.mpc_solve(prob, args.mpc_steps)
+        else:
+            b.newton_solve_async(init=True, game_id0=int(ids[0]))
 
     for _ in range(args.warmup):
         step()
@@ -107,8 +116,12 @@ def main():
     kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]   # HIP events on the launch stream
 
     st = b.get_stats()
-    iters_rank = int(st["newton_iters"].sum())
-    conv_rank = int(st["converged"].sum())
+    if args.mpc_steps:
+        it_, cv_ = b.mpc_totals()
+        iters_rank, conv_rank = int(it_.sum()), int(cv_.sum())
+    else:
+        iters_rank = int(st["newton_iters"].sum())
+        conv_rank = int(st["converged"].sum())
     bad_rank = int((st["status"] != 0).sum())
     tot = torch.tensor([iters_rank, conv_rank, bad_rank], dtype=torch.int64, device="cuda")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -133,6 +146,7 @@ def main():
                                     "C3": "C3: 4-player Unicycle, N=50, collision avoidance + control bounds",
                                     "C5": "C5: 3-player Unicycle, N=30, collision avoidance + control bounds"}[args.config],
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
+                       "mpc_steps": args.mpc_steps,
                        "parallelism": f"scenario-sharded x{world}", "solver": "fused per-game newton_solve! kernel, one game per wavefront"},
             "games_to_convergence_per_sec": conv_all * K / elapsed,
             "games_converged": conv_all, "games_failed": bad_all,

@@ -211,6 +211,15 @@ int alg_get_stats(alg_handle* h, alg_game_stats* stats /*B*/);
 int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out);
 int alg_synchronize(alg_handle* h);
 
+/* Receding-horizon (MPC) support for BASELINE config 5.  The reference has no MPC loop, only the warm-start hooks
+ * `opts.shift` (init_traj!, primal_dual_traj.jl:29-44) and `opts.dual_reset` (solver_methods.jl:25); the loop is
+ * builder-defined: after a solve, x0 <- RK2(x_1, u_1) (the discretisation of
+ * local_quantities.jl:13), then the next newton_solve! runs with shift = 1 and dual_reset = false.
+ * alg_mpc_advance performs the x0 update for every game (asynchronously on the handle's stream) and adds the
+ * finished solve's newton_iters / converged flag to per-game running totals. */
+int alg_mpc_advance(alg_handle* h);
+int alg_mpc_totals(alg_handle* h, int64_t* newton_iters /*B or NULL*/, int64_t* converged /*B or NULL*/, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,6 +182,7 @@ struct Game {
     std::vector<double> lam, mu, vals;    // con_len
     std::vector<alg_record> hist;
     alg_game_stats st{};
+    int64_t mpc_iters = 0, mpc_conv = 0;
     // scratch
     std::vector<double> res, jac;
 };
@@ -918,6 +919,26 @@ int orc_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record
     if (n_out) *n_out = c; return ALG_OK;
 }
 int orc_synchronize(alg_handle*) { return ALG_OK; }
+// builder-defined MPC advance: x0 <- RK2(x_1, u_1); totals += finished solve
+int orc_mpc_advance(alg_handle* h) {
+    const Dims& D = H->sh.D;
+    std::vector<double> u(D.m), xn(D.n);
+    for (Game& g : H->g) {
+        get_control(D, g.z[0], 0, u.data());
+        rk2(D, state(D, g.z[0], 0), u.data(), xn.data());
+        g.x0 = xn;
+        for (int t = 0; t < 2; t++) std::copy(xn.begin(), xn.end(), g.z[t].begin());
+        g.mpc_iters += g.st.newton_iters; g.mpc_conv += g.st.converged;
+    }
+    return ALG_OK;
+}
+int orc_mpc_totals(alg_handle* h, int64_t* it, int64_t* cv, int32_t reset) {
+    for (size_t gi = 0; gi < H->g.size(); gi++) {
+        if (it) it[gi] = H->g[gi].mpc_iters; if (cv) cv[gi] = H->g[gi].mpc_conv;
+        if (reset) { H->g[gi].mpc_iters = 0; H->g[gi].mpc_conv = 0; }
+    }
+    return ALG_OK;
+}
 
 // ---- fine-grained pieces exposed for the known-answer tests (Appendix B) ----------------------
 int orc_kat_dynamics(const alg_desc* d, const double* x, const double* u, double* xdot, double* x_rk2, double* x_rk3, double* jac_rk2) {

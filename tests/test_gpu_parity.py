@@ -230,6 +230,22 @@ def test_full_size_c3_properties(alg):
     assert lam.min() >= 0.0 and lam.max() > 1e-2
 
 
+def test_mpc_receding_horizon_parity(alg, orc):
+    """BASELINE config 5 (builder-defined loop): 3-player Unicycle N = 30, shifted warm starts
+    (init_traj! shift = 1, primal_dual_traj.jl:29-44) with dual_reset = false after the first solve."""
+    ids = np.arange(300, 308)
+    pg = alg.scenarios.make_problem("C5", ids)
+    po = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
+    ig, cg, sg = alg.mpc_solve(pg, 6, record_states=True)
+    io, co, so = alg.mpc_solve(po, 6, record_states=True)
+    assert np.array_equal(ig, io) and np.array_equal(cg, co)
+    assert np.abs(sg - so).max() < 1e-7
+    assert np.abs(sg[-1] - sg[0]).max() > 0.1                  # the vehicles really move
+    # asynchronous loop (no host sync inside) gives the same totals
+    ig2, cg2, _ = alg.mpc_solve(pg2 := alg.scenarios.make_problem("C5", ids), 6)
+    assert np.array_equal(ig2, ig) and np.array_equal(cg2, cg)
+
+
 def test_reference_e2e_thresholds_on_gpu(alg):
     """The five newton_solve! problems of test/problem/solver_methods.jl run through the product path."""
     def problem(model, x0, opts, constrained=False):

@@ -184,22 +184,33 @@ def main():
 
 def cpu_baseline(alg, cfg, G):
     """The oracle (literal CPU restatement of the reference algorithm: global KKT assembly + general partial-pivot
-    LU per game, OpenMP over games) timed on a bounded sample of the same workload."""
+    LU per game, OpenMP over games) timed on a bounded sample of the same workload: all host cores, and one core
+    (the closest analogue of the single-threaded Julia solver)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as orc
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    prev = orc.set_threads(cores)
     nsample = int(min(G, max(8, 16 * cores)))
     prob = alg.scenarios.make_problem(cfg, np.arange(nsample), backend=orc.lib())
     t0 = time.perf_counter()
     alg.newton_solve(prob)
     dt = time.perf_counter() - t0
     s = prob.stats.summary
+    orc.set_threads(1)
+    n1 = int(min(G, 24))
+    prob1 = alg.scenarios.make_problem(cfg, np.arange(n1), backend=orc.lib())
+    t0 = time.perf_counter()
+    alg.newton_solve(prob1)
+    dt1 = time.perf_counter() - t0
+    s1 = prob1.stats.summary
+    orc.set_threads(prev)
     return {"value": float(s["newton_iters"].sum() / dt), "unit": "game-Newton-iterations/s", "cores": cores,
             "kind": "port", "sample": f"first {nsample} scenarios of the same {cfg} workload, one newton_solve! each, "
                                       f"{dt:.1f} s wall, OpenMP over games",
-            "games_to_convergence_per_sec": float(s["converged"].sum() / dt)}
+            "games_to_convergence_per_sec": float(s["converged"].sum() / dt),
+            "single_core_value": float(s1["newton_iters"].sum() / dt1),
+            "single_core_sample": f"first {n1} scenarios, 1 thread, {dt1:.1f} s wall"}
 
 
 if __name__ == "__main__":

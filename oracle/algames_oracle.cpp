@@ -28,6 +28,9 @@
 #include "../include/algames_hip.h"
 
 #include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -938,6 +941,17 @@ int orc_mpc_totals(alg_handle* h, int64_t* it, int64_t* cv, int32_t reset) {
         if (reset) { H->g[gi].mpc_iters = 0; H->g[gi].mpc_conv = 0; }
     }
     return ALG_OK;
+}
+
+// number of OpenMP threads used for the loop over games (cpu_baseline: all cores / one core); returns the previous max
+int orc_set_threads(int nthreads) {
+#ifdef _OPENMP
+    int prev = omp_get_max_threads();
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    return prev;
+#else
+    (void)nthreads; return 1;
+#endif
 }
 
 // ---- fine-grained pieces exposed for the known-answer tests (Appendix B) ----------------------

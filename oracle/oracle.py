@@ -44,6 +44,8 @@ def lib():
         d.orc_kat_delta_step.argtypes = [_P, C.c_int32, C.c_double]
         d.orc_counter_uniform.restype = C.c_double
         d.orc_counter_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        d.orc_set_threads.restype = C.c_int
+        d.orc_set_threads.argtypes = [C.c_int]
         d.orc_kat_dense_direction.restype = C.c_int
         d.orc_kat_dense_direction.argtypes = [_P, C.c_int32, C.c_double, C.POINTER(C.c_double)]
     return _lib
@@ -87,3 +89,8 @@ def collision_cost_value(mu, r, xi, xj):
 
 def counter_uniform(seed, game, counter):
     return lib().dll.orc_counter_uniform(seed, game, counter)
+
+
+def set_threads(n):
+    """OpenMP threads for the oracle's loop over games; returns the previous setting."""
+    return lib().dll.orc_set_threads(int(n))

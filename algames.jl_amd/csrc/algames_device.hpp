@@ -54,6 +54,7 @@ struct Buffers {
     alg_game_stats* stats;  // B
     alg_record* hist;       // B x hist_max
     long long* mpc;         // B x 2 running totals (newton_iters, converged) of the receding-horizon loop
+    double* tcache;         // B x 8 statistics of the last line-search trial (reused as the next record!)
 };
 
 template <int MODEL_, int P_, int D_>
@@ -69,6 +70,8 @@ struct Cfg {
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
     static constexpr int WPE = (n >= 16) ? 2 : 4;
+    // reuse the accepted line-search trial as the next record! (costs registers: off for the large configurations)
+    static constexpr bool TRIAL_REUSE = (n < 16);
 };
 
 // ---- index maps (newton_core.jl:40-89), 0-based --------------------------------------------------
@@ -283,7 +286,7 @@ struct Game {
     const double* Qd; const double* Rd; const double* xf; const double* uf;
     double* lam; double* mu; double* vals;
     double* res; double* rec; double* kgain;
-    alg_game_stats* st; alg_record* hist;
+    alg_game_stats* st; alg_record* hist; double* tc;
 };
 __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, int g) {
     Game G;
@@ -294,7 +297,7 @@ __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, i
     G.Rd = bf.Rd + gq * pr.p * pr.mi; G.uf = bf.uf + gq * pr.p * pr.mi;
     G.lam = bf.lam + (size_t)g * pr.con_len; G.mu = bf.mu + (size_t)g * pr.con_len; G.vals = bf.vals + (size_t)g * pr.con_len;
     G.res = bf.res + (size_t)g * pr.S; G.rec = bf.rec + (size_t)g * pr.rec_len; G.kgain = bf.kgain + (size_t)g * pr.kscratch_len;
-    G.st = bf.stats + g; G.hist = bf.hist + (size_t)g * pr.hist_max;
+    G.st = bf.stats + g; G.hist = bf.hist + (size_t)g * pr.hist_max; G.tc = bf.tcache + (size_t)g * 8;
     return G;
 }
 
@@ -368,8 +371,12 @@ template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 //           rows opt_i,x_{k+1} | opt_i,u_{i,k} | dyn_k  -> record [rx | ru | rd], R^, statistics
 //   MODE 0: statistics only (line-search trials)   MODE 1: + step records (Newton direction input)
 //   MODE 2: + residual vector in the reference's vertical order (alg_residual)
+//   MODE 3: line-search trial that doubles as the next record!: statistics and step records of the UNREGULARISED
+//           residual (what record! sees if the trial is accepted) plus the regularised norm l1reg for the acceptance test
+// With zref != nullptr the proximal term reg (x - xref) is added to the rows; out.l1 is the norm of those rows
+// (MODE 0/2) or of the unregularised rows (MODE 3, which also returns out.l1reg).
 // ================================================================================================
-struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; };
+struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; };
 
 template <class C, int MODE>
 __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, const double* __restrict__ z,
@@ -378,7 +385,8 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     using R = Rec<C>;
     const int N = pr.N, lane = phase_lane();
     const double dt = pr.dt;
-    double l1 = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
+    double l1 = 0, l1r = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
+    constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
     // ---------------- phase A ------------------------------------------------------------------------------
     if (C::NC > 0 || (P > 1)) {
         const int items = (N - 1) * P;
@@ -434,10 +442,10 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                     }
                     ga0 += gv0; ga1 += gv1; d0 += H0; d1 += H1; d2 += H2;
                     rec[R::GVT + (i * P + j) * 2 + 0] = -gv0; rec[R::GVT + (i * P + j) * 2 + 1] = -gv1;   // row opt_i at px(j,.)
-                    if (MODE >= 1) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
+                    if (RECS) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
                 }
                 rec[R::GVT + (i * P + i) * 2 + 0] = ga0; rec[R::GVT + (i * P + i) * 2 + 1] = ga1;           // row opt_i at px(i,.)
-                if (MODE >= 1) { rec[R::HD + 3 * i] = d0; rec[R::HD + 3 * i + 1] = d1; rec[R::HD + 3 * i + 2] = d2; }
+                if (RECS) { rec[R::HD + 3 * i] = d0; rec[R::HD + 3 * i + 1] = d1; rec[R::HD + 3 * i + 2] = d2; }
             }
         }
         __syncthreads();
@@ -484,7 +492,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
         for (int q = 0; q < NPASS; q++) {
             const int e = lane + q * WAVE;
             if (e >= b) continue;
-            double r = 0.0, rhat = 0.0; int vrow = 0; bool dynrow = false;
+            double r = 0.0, rhat = 0.0, dprox = 0.0; int vrow = 0; bool dynrow = false;
             if (e < P * n) {
                 // opt_i,x_{k+1}[a] = cost grad + pair terms + A_{k+1}' lambda_{i,k+1} - lambda_{i,k} (+ reg (x - xref))
                 const int i = e / n, a = e % n;
@@ -493,7 +501,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 if (has_next) r += AT_vec<C>(Ax, dt, [&](int rr) { return ln[rr]; }, a);
                 r += w * (L.tq[e] * (Bk[a] - L.tx[e]));
                 if (P > 1 && a < 2 * P) r += Ax[C::NC + (i * P + a % P) * 2 + a / P];
-                if (zref) r += reg * (Bk[a] - Zr[a]);
+                if (zref) dprox = Bk[a] - Zr[a];
                 if (MODE == 2) vrow = vx<C>(N, i, k) + a;
             } else if (e < P * n + m) {
                 // opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
@@ -516,8 +524,8 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                     }
                 }
                 r = dt * (L.tr[c] * (u - L.tu[c])) + g + BT_vec<C>(Ck, dt, [&](int rr) { return lk[rr]; }, c);
-                if (zref) r += reg * (u - Zr[n + uoff<C>(c)]);
-                if (MODE >= 1) G.rec[(size_t)k * R::LEN + R::RHAT + c] = rhat;
+                if (zref) dprox = u - Zr[n + uoff<C>(c)];
+                if (RECS) G.rec[(size_t)k * R::LEN + R::RHAT + c] = rhat;
                 if (MODE == 2) vrow = vu<C>(N, i, k) + c / P;
             } else {
                 // dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint, RobotDynamics 0.3.1)
@@ -537,9 +545,13 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 dynrow = true;
                 if (MODE == 2) vrow = vd<C>(N, k) + a;
             }
+            // regularize_residual! (global_quantities.jl:67-86): proximal term on the opt rows
+            const double rr = zref ? r + reg * dprox : r;
+            if (MODE == 3) { l1r += fabs(rr); }            // statistics / records of the unregularised rows
+            else r = rr;
             l1 += fabs(r); bad |= !isfinite(r);
             if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
-            if (MODE >= 1) G.rec[(size_t)k * R::LEN + R::RX + e] = r;           // rx | ru | rd are contiguous: coalesced
+            if (RECS) G.rec[(size_t)k * R::LEN + R::RX + e] = r;               // rx | ru | rd are contiguous: coalesced
             if (MODE == 2) G.res[vrow] = r;
         }
         const double prea = (k + 1 <= N - 2) ? load_aux(k + 1) : 0.0;
@@ -553,6 +565,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     }
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
     out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
+    out.l1reg = (MODE == 3) ? wave_sum(l1r) : out.l1;
 }
 
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
@@ -988,11 +1001,16 @@ __device__ __forceinline__ double uni(double v) {
 // regularisation jreg folded into R^) for the Newton direction and refreshes G.vals.  The record is pushed to the
 // game's Statistics history (lane 0); the two scalars the control flow needs are returned.
 struct RecScalars { double res, opt; int nonfinite; };
-template <class C>
-__device__ __forceinline__ RecScalars make_record(const Params& pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
-    ResOut ro;
-    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, jreg, ro);
-    __syncthreads();
+// Statistics of an accepted line-search trial = what the next record! would recompute (same point, same arithmetic)
+// (kept in HBM, G.tc, so that it costs no registers across the Newton direction)
+__device__ __forceinline__ void tcache_store(const Game& G, const ResOut& ro) {
+    if (threadIdx.x == 0) { G.tc[0] = ro.l1; G.tc[1] = ro.opt; G.tc[2] = ro.dyn; G.tc[3] = ro.con; G.tc[4] = ro.sta; G.tc[5] = (double)ro.nonfinite; }
+}
+__device__ __forceinline__ void tcache_load(const Game& G, ResOut& ro) {
+    ro.l1 = G.tc[0]; ro.opt = G.tc[1]; ro.dyn = G.tc[2]; ro.con = G.tc[3]; ro.sta = G.tc[4]; ro.nonfinite = (int)G.tc[5]; ro.l1reg = ro.l1;
+}
+
+__device__ __forceinline__ RecScalars push_stats(const Params& pr, const Game& G, const ResOut& ro, double delta, int outer, alg_record* out) {
     if (threadIdx.x == 0) {
         alg_record rc;
         rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
@@ -1006,18 +1024,32 @@ __device__ __forceinline__ RecScalars make_record(const Params& pr, const Game& 
     RecScalars r; r.res = uni(ro.l1 / (double)pr.S); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
     return r;
 }
-
-// line_search (solver_methods.jl:105-125)
 template <class C>
-__device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double reg, double res_norm0, double* alpha_out, int* j_out) {
+__device__ __forceinline__ RecScalars make_record(const Params& pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
+    ResOut ro;
+    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, jreg, ro);
+    __syncthreads();
+    return push_stats(pr, G, ro, delta, outer, out);
+}
+
+// line_search (solver_methods.jl:105-125).  jreg_next >= 0: every trial also leaves the unregularised statistics and
+// step records (R^ with jreg_next) so that an accepted trial can serve as the next iteration's record!.
+template <class C>
+__device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double reg, double res_norm0, double jreg_next,
+                            double* alpha_out, int* j_out) {
     const alg_options& o = pr.opt;
     int j = 1; double alpha = 1.0;
     while (j < o.ls_iter) {
         update_traj<C>(pr, G.z[1], G.z[0], alpha, G.z[2]);
         __syncthreads();
         ResOut ro;
-        assemble_pass<C, 0>(pr, G, L.a, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, ro);
-        const double rt = uni(ro.l1 / (double)pr.S);
+        bool done = false;
+        if constexpr (C::TRIAL_REUSE) {
+            if (jreg_next >= 0.0 && o.regularize) { assemble_pass<C, 3>(pr, G, L.a, G.z[1], G.z[0], reg, jreg_next, ro); done = true; }
+        }
+        if (!done) assemble_pass<C, 0>(pr, G, L.a, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, ro);
+        if (jreg_next >= 0.0) tcache_store(G, ro);
+        const double rt = uni(ro.l1reg / (double)pr.S);
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
     }
@@ -1025,14 +1057,18 @@ __device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double r
 }
 
 // inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
-// the history record / *info (lane 0).
+// the history record / *info (lane 0).  `cache` (optional) carries an accepted trial's statistics to the next call.
 template <class C>
-__device__ int inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l, alg_step_info* info) {
+__device__ int inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l,
+                               alg_step_info* info, int* cache_valid) {
     const alg_options& o = pr.opt;
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
     if (info && threadIdx.x == 0) { alg_step_info z{}; *info = z; }
-    const RecScalars rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr);   // :73-76 (regularisation term is zero at pdtraj)
+    RecScalars rs;                                                         // :73-76 (regularisation term is zero at pdtraj)
+    if (cache_valid && *cache_valid) { ResOut cro; tcache_load(G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }
+    else rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr);
+    if (cache_valid) *cache_valid = 0;
     Delta = 0.0;                                                           // :79
     auto finish = [&](int status, int flow) { if (info && threadIdx.x == 0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
@@ -1041,13 +1077,16 @@ __device__ int inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& 
     if (st != ALG_STATUS_OK) return finish(st, 1);
     __syncthreads();
     double alpha; int j;
-    line_search<C>(pr, G, L, reg, rs.res, &alpha, &j);                     // :91
+    const double lf1 = (double)(l + 1);
+    const bool reuse = C::TRIAL_REUSE && cache_valid && l < o.inner_iter && o.regularize;    // the next inner iteration may reuse the trial
+    line_search<C>(pr, G, L, reg, rs.res, reuse ? o.reg_0 * (lf1 * lf1 * lf1 * lf1) : -1.0, &alpha, &j);   // :91
     const int failed = (j == o.ls_iter);                                   // :92
     if (failed) LS_count += 1; else LS_count = 0;                          // :93
     __syncthreads();
-    update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);                     // :94
+    update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);                     // :94  (== the accepted trial, bit for bit)
     Delta = uni(delta_step<C>(pr, G.z[2], alpha));                         // :95
     __syncthreads();
+    if (reuse && !failed) *cache_valid = 1;
     if (threadIdx.x == 0) {
         G.st->newton_iters += 1; if (failed) G.st->ls_failures += 1;
         const int idx = G.st->records - 1;
@@ -1170,8 +1209,9 @@ __device__ void newton_solve(const Params& pr, const Game& G, Lds<C>& L, int ini
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30
         out = k;
         int LS_count = 0;
+        int cache_valid = 0;
         for (int l = 1; l <= o.inner_iter; l++) {                          // :38
-            const int rcode = inner_iteration<C>(pr, G, L, LS_count, Delta, k, l, nullptr);
+            const int rcode = inner_iteration<C>(pr, G, L, LS_count, Delta, k, l, nullptr, &cache_valid);
             if ((rcode & 0xff) != ALG_STATUS_OK) { status = rcode & 0xff; break; }
             if (LS_count >= 1 || (rcode >> 8) == 1) break;                 // :43
         }

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, Buffers
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     int ls = 0; double dl = 0.0;
-    inner_iteration<C>(pr, G, L, ls, dl, k, l, out + g);
+    inner_iteration<C>(pr, G, L, ls, dl, k, l, out + g, nullptr);
 }
 
 template <class C>
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(WAVE) k_line_search(Params pr, Buffers bf, dou
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     double a; int jj;
-    line_search<C>(pr, G, L, reg, rn[g], &a, &jj);
+    line_search<C>(pr, G, L, reg, rn[g], -1.0, &a, &jj);
     if (threadIdx.x == 0) { alpha[g] = a; j[g] = jj; }
 }
 
@@ -284,6 +284,7 @@ int alloc_all(Handle* hd) {
     if ((rc = dalloc(hd, &hd->bf.stats, B, "bf.stats"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max, "bf.hist"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.mpc, 2 * B, "bf.mpc"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.tcache, 8 * B, "bf.tcache"))) return rc;
     if ((rc = dalloc(hd, &hd->d_tmp, 2 * B, "d_tmp"))) return rc;
     if ((rc = dalloc(hd, &hd->d_itmp, B, "d_itmp"))) return rc;
     if ((rc = dalloc(hd, &hd->d_info, B, "d_info"))) return rc;

@@ -101,6 +101,8 @@ SIGNATURES = {
     "get_stats": (C.c_int, [_P, _P]),
     "get_history": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _I]),
     "synchronize": (C.c_int, [_P]),
+    "ibr_solve_player": (C.c_int, [_P, C.c_int32, _P]),
+    "ibr_newton_solve": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _I, C.c_double, _P]),
     "mpc_advance": (C.c_int, [_P]),
     "mpc_totals": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
 }
@@ -328,6 +330,17 @@ class Batch:
 
     def synchronize(self):
         self.lib.check(self.lib.synchronize(self.h))
+
+    def ibr_solve_player(self, player):
+        st = np.zeros(self.B, dtype=game_stats_dtype)
+        self.lib.check(self.lib.ibr_solve_player(self.h, int(player), st.ctypes.data_as(_P)))
+        return st
+
+    def ibr_newton_solve(self, ibr_iter=100, ordering=None, delta_min=1e-9, init=True, game_id0=0):
+        order = np.ascontiguousarray(np.arange(self.p) if ordering is None else np.asarray(ordering)[:self.p], dtype=np.int32)
+        st = np.zeros(self.B, dtype=game_stats_dtype)
+        self.lib.check(self.lib.ibr_newton_solve(self.h, int(init), game_id0, int(ibr_iter), _iptr(order), float(delta_min), st.ctypes.data_as(_P)))
+        return st
 
     def mpc_advance(self):
         self.lib.check(self.lib.mpc_advance(self.h))

@@ -40,6 +40,7 @@ struct Params {
     int hist_max;
     int kscratch_len;       // per game doubles of gain scratch
     int rec_len;            // per game doubles of step records
+    unsigned long long ibr_ctl_rows[MAXP];   // control-bound rows counted by control_violation(game_con, pdtraj, i) (violations.jl:69-82)
 };
 
 // Device pointers of a handle (all game-major).
@@ -376,16 +377,19 @@ template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 // With zref != nullptr the proximal term reg (x - xref) is added to the rows; out.l1 is the norm of those rows
 // (MODE 0/2) or of the unregularised rows (MODE 3, which also returns out.l1reg).
 // ================================================================================================
-struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; };
+struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; double l1full; };
 
-template <class C, int MODE>
+// IBR = true: best-response statistics of player ip (solver_methods.jl:230-289): norms over the rows of the vertical mask
+// (player ip's opt rows + all dyn rows, newton_core.jl:205-246), player-specific violations (statistics.jl:59-73), the
+// proximal term only on player ip's rows (global_quantities.jl:262-280); out.l1full is the full ||res||_1 for record!.
+template <class C, int MODE, bool IBR = false>
 __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, const double* __restrict__ z,
-                              const double* __restrict__ zref, double reg, double jreg, ResOut& out) {
+                              const double* __restrict__ zref, double reg, double jreg, ResOut& out, int ip = -1) {
     constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b;
     using R = Rec<C>;
     const int N = pr.N, lane = phase_lane();
     const double dt = pr.dt;
-    double l1 = 0, l1r = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
+    double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
     // ---------------- phase A ------------------------------------------------------------------------------
     if (C::NC > 0 || (P > 1)) {
@@ -437,7 +441,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                             const double wl = lm + am * c;
                             gv0 += -2.0 * dl0 * wl; gv1 += -2.0 * dl1 * wl;
                             H0 += am * 4.0 * dl0 * dl0; H1 += am * 4.0 * dl0 * dl1; H2 += am * 4.0 * dl1 * dl1;
-                            G.vals[ci] = c; vsta = fmax(vsta, fmax(0.0, c));
+                            G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                         }
                     }
                     ga0 += gv0; ga1 += gv1; d0 += H0; d1 += H1; d2 += H2;
@@ -492,7 +496,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
         for (int q = 0; q < NPASS; q++) {
             const int e = lane + q * WAVE;
             if (e >= b) continue;
-            double r = 0.0, rhat = 0.0, dprox = 0.0; int vrow = 0; bool dynrow = false;
+            double r = 0.0, rhat = 0.0, dprox = 0.0; int vrow = 0; bool dynrow = false, mine = true;
             if (e < P * n) {
                 // opt_i,x_{k+1}[a] = cost grad + pair terms + A_{k+1}' lambda_{i,k+1} - lambda_{i,k} (+ reg (x - xref))
                 const int i = e / n, a = e % n;
@@ -501,7 +505,8 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 if (has_next) r += AT_vec<C>(Ax, dt, [&](int rr) { return ln[rr]; }, a);
                 r += w * (L.tq[e] * (Bk[a] - L.tx[e]));
                 if (P > 1 && a < 2 * P) r += Ax[C::NC + (i * P + a % P) * 2 + a / P];
-                if (zref) dprox = Bk[a] - Zr[a];
+                if (IBR) mine = (i == ip);
+                if (zref && mine) dprox = Bk[a] - Zr[a];
                 if (MODE == 2) vrow = vx<C>(N, i, k) + a;
             } else if (e < P * n + m) {
                 // opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
@@ -519,12 +524,14 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                             const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
                             const double wl = lm + am * cv;
                             g += (half == 0 ? wl : -wl); rhat += am;
-                            vcon = fmax(vcon, fmax(0.0, cv));
+                            if (!IBR) vcon = fmax(vcon, fmax(0.0, cv));
+                            else if ((pr.ibr_ctl_rows[ip] >> (half * m + c)) & 1ull) vcon = fmax(vcon, fmax(0.0, cv));
                         }
                     }
                 }
                 r = dt * (L.tr[c] * (u - L.tu[c])) + g + BT_vec<C>(Ck, dt, [&](int rr) { return lk[rr]; }, c);
-                if (zref) dprox = u - Zr[n + uoff<C>(c)];
+                if (IBR) mine = (i == ip);
+                if (zref && mine) dprox = u - Zr[n + uoff<C>(c)];
                 if (RECS) G.rec[(size_t)k * R::LEN + R::RHAT + c] = rhat;
                 if (MODE == 2) vrow = vu<C>(N, i, k) + c / P;
             } else {
@@ -543,14 +550,22 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 }
                 r = xn - Bk[a];
                 dynrow = true;
+                if (IBR) mine = (a % P == ip);                 // dynamics_violation(model, pdtraj, i): entries pz[i]
                 if (MODE == 2) vrow = vd<C>(N, k) + a;
             }
             // regularize_residual! (global_quantities.jl:67-86): proximal term on the opt rows
             const double rr = zref ? r + reg * dprox : r;
             if (MODE == 3) { l1r += fabs(rr); }            // statistics / records of the unregularised rows
             else r = rr;
-            l1 += fabs(r); bad |= !isfinite(r);
-            if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
+            bad |= !isfinite(r);
+            if (IBR) {
+                l1f += fabs(r);
+                if (dynrow) { l1 += fabs(r); if (mine) vdyn = fmax(vdyn, fabs(r)); }
+                else if (mine) { l1 += fabs(r); vopt = fmax(vopt, fabs(r)); }
+            } else {
+                l1 += fabs(r);
+                if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
+            }
             if (RECS) G.rec[(size_t)k * R::LEN + R::RX + e] = r;               // rx | ru | rd are contiguous: coalesced
             if (MODE == 2) G.res[vrow] = r;
         }
@@ -566,6 +581,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
     out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
     out.l1reg = (MODE == 3) ? wave_sum(l1r) : out.l1;
+    out.l1full = IBR ? wave_sum(l1f) : out.l1;
 }
 
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
@@ -714,8 +730,10 @@ struct HxMap {
 
 // Solves J d = -res for the step records left by assemble_pass<C,1> and writes d into the delta buffer
 // (solver_methods.jl:87-88).  Returns ALG_STATUS_*.
-template <class C>
-__device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg) {
+// IBR = true: best response of player ip -- only x, u_ip, lambda_ip move (horizontal mask, newton_core.jl:249-294): the other
+// players' value recursions are skipped, their rows of the control system become unit rows (du_j = 0), dlambda_j = 0.
+template <class C, bool IBR = false>
+__device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg, int ip = -1) {
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
     using R = Rec<C>;
     const int N = pr.N, lane = phase_lane();
@@ -773,6 +791,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             }
 #pragma unroll
             for (int i = 0; i < P; i++) {
+                if (IBR && i != ip) continue;
                 double4_t c2;                                   // C-init of the second product: [Q^_i | rx_i]
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) {
@@ -801,6 +820,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         __syncthreads();           // all reads of Pm / s done
 #pragma unroll
         for (int i = 0; i < P; i++) {
+            if (IBR && i != ip) continue;
 #pragma unroll
             for (int r4 = 0; r4 < 4; r4++) {
                 const int row = lq + 4 * r4;
@@ -843,6 +863,10 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 double v = vals[0] * Vc[rows[0]] + vals[1] * Vc[rows[1]] + vals[2] * Vc[rows[2]];
                 if (lane == c) v += Rc[R::RHAT + c];
                 if (lane >= m + n) { const double* yi = &L.bw.t[(c % P) * n]; v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
+                if (IBR) {
+                    if (c % P != ip) v = (lane == c) ? 1.0 : 0.0;               // unit row: du_c = 0
+                    else if (lane < m && lane % P != ip) v = 0.0;               // fixed controls of the other players
+                }
                 col[c] = v;
             }
         }
@@ -925,7 +949,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         hxm.expand(lane, Rc, L.hx);
         __syncthreads();
         double acc = 0.0;
-        if (lane < P * n) {
+        if (lane < P * n && (!IBR || ci_ == ip)) {
             acc = Rc[R::RX + lane] + (reg + w * L.qdf[lane]) * L.fw.dx[cr_];
             if (cpos) {
                 const double* hrow = &L.hx[(ci_ * P + cr_ % P) * P * 3 + cr_ / P];
@@ -1229,6 +1253,133 @@ __device__ void newton_solve(const Params& pr, const Game& G, Lds<C>& L, int ini
     __syncthreads();
     make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);                    // :63
     if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; }
+}
+
+// ================================================================================================
+// Iterated best response (solver_methods.jl:133-289)
+// ================================================================================================
+// record!(stats, ..., k, i) (statistics.jl:59-73): full residual norm + player-specific violations; also tracks
+// maximum(stats.Δ_traj) (G.tc[6]) for the exit test of ibr_newton_solve! (:157).  Returns the masked norm / opt violation.
+template <class C>
+__device__ __forceinline__ RecScalars ibr_push_stats(const Params& pr, const Game& G, const ResOut& ro, double delta, int outer) {
+    const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));            // length(verti_mask)
+    if (threadIdx.x == 0) {
+        alg_record rc;
+        rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1full / (double)pr.S; rc.delta = delta;
+        rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
+        const int idx = G.st->records;
+        if (idx < pr.hist_max) G.hist[idx] = rc;
+        G.st->records = idx + 1;
+        G.st->last = rc;
+        G.tc[6] = fmax(G.tc[6], delta);
+    }
+    RecScalars r; r.res = uni(ro.l1 / sm); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
+    return r;
+}
+// ibr_inner_iteration (solver_methods.jl:230-268)
+template <class C>
+__device__ int ibr_inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l, int ip) {
+    const alg_options& o = pr.opt;
+    const double lf = (double)l;
+    const double reg = o.reg_0 * (lf * lf * lf * lf);
+    const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));
+    ResOut ro;
+    assemble_pass<C, 1, true>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro, ip);        // :236-241
+    __syncthreads();
+    const RecScalars rs = ibr_push_stats<C>(pr, G, ro, Delta, k);
+    Delta = 0.0;
+    if (rs.nonfinite) return ALG_STATUS_NAN | (1 << 8);
+    if (rs.opt < o.eps_opt) return ALG_STATUS_OK | (1 << 8);                       // :245-247
+    const int st = newton_direction<C, true>(pr, G, L.d, reg, ip);                  // :249-252
+    if (st != ALG_STATUS_OK) return st | (1 << 8);
+    __syncthreads();
+    int j = 1; double alpha = 1.0;                                                  // ibr_line_search (:270-289)
+    while (j < o.ls_iter) {
+        update_traj<C>(pr, G.z[1], G.z[0], alpha, G.z[2]);
+        __syncthreads();
+        ResOut rt;
+        assemble_pass<C, 0, true>(pr, G, L.a, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, rt, ip);
+        if (uni(rt.l1 / sm) <= (1.0 - alpha * o.beta) * rs.res) break;
+        alpha *= o.alpha_decrease; j += 1;
+    }
+    const int failed = (j == o.ls_iter);
+    if (failed) LS_count += 1; else LS_count = 0;
+    __syncthreads();
+    update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);                              // :258
+    Delta = uni(delta_step<C>(pr, G.z[2], alpha));                                  // :259
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        G.st->newton_iters += 1; if (failed) G.st->ls_failures += 1;
+        const int idx = G.st->records - 1;
+        if (idx < pr.hist_max) { G.hist[idx].alpha = alpha; G.hist[idx].ls_j = j; }
+        G.st->last.alpha = alpha; G.st->last.ls_j = j;
+    }
+    return ALG_STATUS_OK | ((Delta < o.delta_min ? 1 : 0) << 8);
+}
+// ibr_newton_solve!(prob, i) (solver_methods.jl:171-228)
+template <class C>
+__device__ int ibr_solve_player(const Params& pr, const Game& G, Lds<C>& L, int ip) {
+    const alg_options& o = pr.opt; const int lane = threadIdx.x;
+    if (o.dual_reset) {                                                            // :181-185
+        reset_con(pr, G);
+        for (int e = lane; e < (pr.N - 1) * C::P * C::n; e += WAVE) {              // reset_duals!(pdtraj), reset_duals!(pdtraj_trial)
+            const int k = e / (C::P * C::n), a = e % (C::P * C::n);
+            G.z[0][C::n + hl<C>(k, 0) + a] *= 0.0; G.z[1][C::n + hl<C>(k, 0) + a] *= 0.0;
+        }
+    }
+    __syncthreads();
+    int out = 0, status = ALG_STATUS_OK, converged = 0; double Delta = 0.0;
+    for (int k = 1; k <= o.outer_iter; k++) {
+        out = k; int LS_count = 0;
+        for (int l = 1; l <= o.inner_iter; l++) {
+            const int rcode = ibr_inner_iteration<C>(pr, G, L, LS_count, Delta, k, l, ip);
+            if ((rcode & 0xff) != ALG_STATUS_OK) { status = rcode & 0xff; break; }
+            if (LS_count >= 1 || (rcode >> 8) == 1) break;
+        }
+        if (status != ALG_STATUS_OK) break;
+        __syncthreads();
+        const alg_record& last = G.st->last;
+        const bool conv = last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
+        const int convu = __builtin_amdgcn_readfirstlane((int)conv);
+        converged = convu;
+        if (k == o.outer_iter || convu) break;
+        dual_penalty_update<C>(pr, G);
+        __syncthreads();
+    }
+    __syncthreads();
+    ResOut ro;
+    assemble_pass<C, 1, true>(pr, G, L.a, G.z[0], nullptr, 0.0, 0.0, ro, ip);          // :226
+    __syncthreads();
+    ibr_push_stats<C>(pr, G, ro, Delta, out);
+    if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; }
+    __syncthreads();
+    return status;
+}
+struct IbrOrder { int v[MAXP]; };
+// ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169)
+template <class C>
+__device__ void ibr_newton_solve(const Params& pr, const Game& G, Lds<C>& L, int init, uint64_t game_id, int ibr_iter,
+                                 const IbrOrder& order, double delta_min) {
+    const int lane = threadIdx.x;
+    if (lane == 0) { alg_game_stats z{}; *G.st = z; G.tc[6] = 0.0; }                 // reset!(prob.stats)
+    if (init) init_traj<C>(pr, G, G.z[0], game_id, true);
+    else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
+    __syncthreads();
+    for (int e = lane; e < pr.traj_len; e += WAVE) { G.z[1][e] = G.z[0][e]; G.z[2][e] = 0.0; }   // :142-143 (the trial's duals are reset below)
+    __syncthreads();
+    rollout<C>(pr, G.z[0]);
+    __syncthreads();
+    unsigned change = (1u << C::P) - 1u;                                             // Δ_change = trues(p)
+    for (int q = 0; q < ibr_iter; q++) {
+        for (int id = 0; id < C::P; id++) {
+            const int ip = order.v[id];
+            const int status = ibr_solve_player<C>(pr, G, L, ip);
+            const double mx = uni(G.tc[6]);
+            if (!(delta_min > mx)) change |= (1u << ip); else change &= ~(1u << ip);  // :157
+            if (status != ALG_STATUS_OK) return;
+        }
+        if (change == 0u) break;                                                    // :163
+    }
 }
 
 } // namespace alg

@@ -117,6 +117,17 @@ __global__ void __launch_bounds__(WAVE) k_init(Params pr, Buffers bf, uint64_t g
     }
 }
 
+// mode 0: ibr_newton_solve!(prob, player) on the stored trajectory ; mode 1: ibr_newton_solve!(prob; ibr_opts)
+template <class C>
+__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, Buffers bf, int mode, int player, int init, uint64_t game_id0,
+                                                      int ibr_iter, IbrOrder order, double delta_min) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    if (mode == 0) ibr_solve_player<C>(pr, G, L, player);
+    else ibr_newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g, ibr_iter, order, delta_min);
+}
+
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
 template <class C>
 __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
@@ -409,6 +420,17 @@ int alg_add_control_bound(alg_handle* h, const double* umax, const double* umin)
     if (p.m > MAXM) return fail(ALG_ERR_ARG, "alg_add_control_bound: m too large");
     for (int i = 0; i < p.m; i++) if (!(umax[i] >= umin[i])) return fail(ALG_ERR_ARG, "Upper bounds must be greater than or equal to lower bounds");
     for (int i = 0; i < p.m; i++) { p.umax[i] = umax[i]; p.umin[i] = umin[i]; }
+    // rows counted by control_violation(game_con, pdtraj, i) (violations.jl:69-82): the reference indexes the vector of FINITE
+    // bound rows [u - u_max; u_min - u][inds] with the control indices pu[i]
+    {
+        std::vector<int> fin;
+        for (int r = 0; r < 2 * p.m; r++) { const double b = r < p.m ? umax[r] : umin[r - p.m]; if (std::isfinite(b)) fin.push_back(r); }
+        for (int i = 0; i < p.p; i++) {
+            unsigned long long mask = 0;
+            for (int j = 0; j < p.mi; j++) { const int pos = i + j * p.p; if (pos < (int)fin.size()) mask |= 1ull << fin[pos]; }
+            p.ibr_ctl_rows[i] = mask;
+        }
+    }
     p.has_ctl = 1; return ALG_OK;
 }
 
@@ -576,6 +598,25 @@ int alg_debug_check_guards(alg_handle* h) {
     return bad;
 }
 int alg_synchronize(alg_handle* h) { int rc = use_device(H); if (rc) return rc; return sync(H); }
+
+int alg_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats) {
+    int rc = use_device(H); if (rc) return rc;
+    if (player < 0 || player >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_solve_player: bad player index");
+    IbrOrder order{};
+    LAUNCH(k_ibr, H->pr, H->bf, 0, (int)player, 0, (uint64_t)0, 1, order, 0.0);
+    if (stats) return alg_get_stats(h, stats);
+    return sync(H);
+}
+int alg_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t ibr_iter, const int32_t* ordering, double delta_min, alg_game_stats* stats) {
+    int rc = use_device(H); if (rc) return rc;
+    if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_ibr_newton_solve: x0 / LQR data not set");
+    if (!ordering || ibr_iter < 1) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: bad arguments");
+    IbrOrder order{};
+    for (int i = 0; i < H->pr.p; i++) { if (ordering[i] < 0 || ordering[i] >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: ordering entries must be player ids"); order.v[i] = ordering[i]; }
+    LAUNCH(k_ibr, H->pr, H->bf, 1, 0, (int)init, (uint64_t)game_id0, (int)ibr_iter, order, delta_min);
+    if (stats) return alg_get_stats(h, stats);
+    return sync(H);
+}
 
 int alg_mpc_advance(alg_handle* h) {
     int rc = use_device(H); if (rc) return rc;

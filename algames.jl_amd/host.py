@@ -431,6 +431,31 @@ def optimality_violation(prob):
 
 
 # --------------------------------------------------------------------------------------------------
+# Iterated best response (src/struct/options.jl:123-136, src/problem/solver_methods.jl:133-289)
+# --------------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class IBROptions:
+    ibr_iter: int = 100
+    ordering: list = dataclasses.field(default_factory=lambda: list(range(1, 101)))   # 1-based player ids, like the reference
+    Δ_min: float = 1e-9
+    live_plotting: bool = False
+
+
+def ibr_newton_solve(prob, i=None, ibr_opts=None, init=True):
+    """ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169), or with a 1-based player index `i`
+    ibr_newton_solve!(prob, i) (:171-228) on the stored trajectory."""
+    prob._sync_options()
+    if i is not None:
+        summary = prob.batch.ibr_solve_player(i - 1)
+    else:
+        o = ibr_opts if ibr_opts is not None else IBROptions()
+        order = [j - 1 for j in list(o.ordering)[:prob.probsize.p]]
+        summary = prob.batch.ibr_newton_solve(o.ibr_iter, order, o.Δ_min, init=init, game_id0=prob.game_id0)
+    prob.stats = Statistics(summary, prob.batch.get_history)
+    return None
+
+
+# --------------------------------------------------------------------------------------------------
 # Receding-horizon loop (BASELINE config 5).  Not in the reference: Algames.jl v0.1.6 only has the warm-start hooks
 # `opts.shift` / `opts.dual_reset` (options.jl:16-17, primal_dual_traj.jl:35-39, solver_methods.jl:25).  Builder-defined
 # (SURVEY.md 8(d) C5): solve; x0 <- RK2(x_1, u_1); next solve warm-started with shift = 1 and dual_reset = false.

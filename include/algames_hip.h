@@ -211,6 +211,18 @@ int alg_get_stats(alg_handle* h, alg_game_stats* stats /*B*/);
 int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out);
 int alg_synchronize(alg_handle* h);
 
+/* Iterated best response.
+ * alg_ibr_solve_player: ibr_newton_solve!(prob, i) (solver_methods.jl:171-228) for every game, on the stored trajectory:
+ *   player `player` (0-based) best-responds -- only x, u_player, lambda_player move (masks of newton_core.jl:205-294),
+ *   residual norm over the player's rows + dynamics rows, player-specific violations (statistics.jl:59-73).
+ *   Statistics accumulate (the reference does not reset them between players).
+ * alg_ibr_newton_solve: ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169): reset!(stats), init_traj! + rollout!,
+ *   then up to ibr_iter sweeps over `ordering` (p 0-based player ids), leaving when no player changed
+ *   (delta_min > maximum(stats.Δ_traj), literally as in the reference). init has the meaning of alg_newton_solve. */
+int alg_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats /*B or NULL*/);
+int alg_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t ibr_iter, const int32_t* ordering,
+                         double delta_min, alg_game_stats* stats /*B or NULL*/);
+
 /* Receding-horizon (MPC) support for BASELINE config 5.  The reference has no MPC loop, only the warm-start hooks
  * `opts.shift` (init_traj!, primal_dual_traj.jl:29-44) and `opts.dual_reset` (solver_methods.jl:25); the loop is
  * builder-defined: after a solve, x0 <- RK2(x_1, u_1) (the discretisation of

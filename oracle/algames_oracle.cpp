@@ -186,6 +186,7 @@ struct Game {
     std::vector<alg_record> hist;
     alg_game_stats st{};
     int64_t mpc_iters = 0, mpc_conv = 0;
+    double max_delta = 0.0;       // maximum(prob.stats.Δ_traj) over the Statistics history
     // scratch
     std::vector<double> res, jac;
 };
@@ -725,6 +726,175 @@ void newton_solve(const Shared& sh, Game& g, bool init, uint64_t game_id) {
     g.st.outer_iters = out; g.st.last = fin;
 }
 
+
+// ==========================================================================================================
+// Iterated best response (solver_methods.jl:133-289, global_quantities.jl:199-365, newton_core.jl:205-294)
+// ==========================================================================================================
+// vertical_mask / horizontal_mask (newton_core.jl:205-294, splitted_state = false): positions of the player's
+// rows (opt_i x, opt_i u_i, dyn) and columns (x, u_i, lambda_i) in the masked system; -1 elsewhere.
+void ibr_masks(const Dims& D, int i, std::vector<int>& rmask, std::vector<int>& cmask, int& Sm) {
+    rmask.assign(D.S, -1); cmask.assign(D.S, -1);
+    // time-major order inside the masked system (dyn, opt_u, opt_x | lambda, u, x) keeps it narrow-banded
+    int off = 0;
+    for (int k = 0; k < D.N - 1; k++) {
+        for (int a = 0; a < D.n; a++) rmask[D.vd(k) + a] = off++;
+        for (int j = 0; j < D.mi; j++) rmask[D.vu(i, k) + j] = off++;
+        for (int a = 0; a < D.n; a++) rmask[D.vx(i, k) + a] = off++;
+    }
+    Sm = off; off = 0;
+    for (int k = 0; k < D.N - 1; k++) {
+        for (int a = 0; a < D.n; a++) cmask[D.hl(k, i) + a] = off++;
+        for (int j = 0; j < D.mi; j++) cmask[D.hu(k, i) + j] = off++;
+        for (int a = 0; a < D.n; a++) cmask[D.hx(k) + a] = off++;
+    }
+}
+// norm(core.res[verti_mask], 1) / length(verti_mask)  (solver_methods.jl:241)
+double ibr_res_norm(const Shared& sh, const Game& g, int i) {
+    const Dims& D = sh.D; double s = 0;
+    for (int k = 0; k < D.N - 1; k++) {
+        for (int a = 0; a < D.n; a++) s += std::fabs(g.res[D.vx(i, k) + a]) + std::fabs(g.res[D.vd(k) + a]);
+        for (int j = 0; j < D.mi; j++) s += std::fabs(g.res[D.vu(i, k) + j]);
+    }
+    return s / (double)((D.N - 1) * (2 * D.n + D.mi));
+}
+// ibr_residual! + regularize_ibr_residual! restricted to the mask == the full residual! on the player's rows; the
+// proximal term only touches the player's rows (global_quantities.jl:262-280).  Rows outside the mask are not used.
+void ibr_residual(const Shared& sh, Game& g, const std::vector<double>& z, int i, double reg, const std::vector<double>* zref) {
+    residual(sh, g, z, 0.0, nullptr);
+    if (zref && reg != 0.0) {
+        const Dims& D = sh.D; std::vector<double> u(D.m), ur(D.m);
+        for (int k = 0; k < D.N - 1; k++) {
+            const double* x = state(D, z, k + 1); const double* xr = state(D, *zref, k + 1);
+            get_control(D, z, k, u.data()); get_control(D, *zref, k, ur.data());
+            for (int a = 0; a < D.n; a++) g.res[D.vx(i, k) + a] += reg * (x[a] - xr[a]);
+            for (int j = 0; j < D.mi; j++) { int c = D.pu(i, j); g.res[D.vu(i, k) + j] += reg * (u[c] - ur[c]); }
+        }
+    }
+}
+// record!(stats, prob, model, game_con, pdtraj, t_elap, Δ, k, i) (statistics.jl:59-73): full residual norm, player-specific violations
+alg_record ibr_record(const Shared& sh, Game& g, double delta, int outer, int i) {
+    const Dims& D = sh.D;
+    alg_record rc{}; rc.outer = outer; rc.delta = delta;
+    residual(sh, g, g.z[0], 0.0, nullptr);
+    rc.res = res_norm(sh, g);
+    double dv = 0;                                               // dynamics_violation(model, pdtraj, i): entries pz[i]
+    for (int k = 0; k < D.N - 1; k++) for (int j = 0; j < D.ni; j++) dv = std::max(dv, std::fabs(g.res[D.vd(k) + D.pz(i, j)]));
+    rc.dyn_vio = dv;
+    // control_violation(game_con, pdtraj, i) (violations.jl:69-82): c_max = max(0, maximum(v[pu[i]])) -- v is the vector of
+    // FINITE bound rows [u - u_max; u_min - u][inds] and is indexed by the control indices pu[i] (literal restatement)
+    double cv = 0;
+    if (sh.has_ctl) for (int k = 0; k < D.N - 1; k++) {
+        std::vector<double> fin;
+        for (int r = 0; r < 2 * D.m; r++) if (std::isfinite(g.vals[con_ctl(D, k, r)])) fin.push_back(g.vals[con_ctl(D, k, r)]);
+        double mx = -std::numeric_limits<double>::infinity();
+        for (int j = 0; j < D.mi; j++) { int pos = D.pu(i, j); if (pos < (int)fin.size()) mx = std::max(mx, fin[pos]); }
+        cv = std::max(cv, std::max(0.0, mx));
+    }
+    rc.con_vio = cv;
+    double sv = 0;                                               // state_violation(game_con, pdtraj, i): player i's convals
+    if (sh.has_colavoid) for (int j = 0; j < D.p; j++) if (j != i) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, D.pair(i, j), k)]));
+    rc.sta_vio = sv;
+    double ov = 0;                                               // optimality_violation(core, i)
+    for (int k = 0; k < D.N - 1; k++) { for (int a = 0; a < D.n; a++) ov = std::max(ov, std::fabs(g.res[D.vx(i, k) + a])); for (int j = 0; j < D.mi; j++) ov = std::max(ov, std::fabs(g.res[D.vu(i, k) + j])); }
+    rc.opt_vio = ov;
+    g.max_delta = std::max(g.max_delta, delta);
+    return rc;
+}
+// Δtraj[horiz_mask] = - lu(jac[verti_mask, horiz_mask]) \ res[verti_mask]  (solver_methods.jl:249-251)
+int ibr_direction(const Shared& sh, Game& g, int i, double reg) {
+    const Dims& D = sh.D;
+    std::vector<int> rm, cm; int Sm; ibr_masks(D, i, rm, cm, Sm);
+    int kl = 0, ku = 0;
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double) { if (rm[r] >= 0 && cm[c] >= 0) { int dlt = rm[r] - cm[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); } });
+    Banded B; B.init(Sm, kl, ku);
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double v) { if (rm[r] >= 0 && cm[c] >= 0) B.at(rm[r], cm[c]) += v; });
+    std::vector<double> rhs(Sm);
+    for (int r = 0; r < D.S; r++) if (rm[r] >= 0) rhs[rm[r]] = g.res[r];
+    if (B.factor() != 0) return ALG_STATUS_SINGULAR;
+    B.solve(rhs);
+    std::vector<double>& dz = g.z[2];
+    std::fill(dz.begin(), dz.end(), 0.0);
+    for (int c = 0; c < D.S; c++) if (cm[c] >= 0) { dz[D.n + c] = -rhs[cm[c]]; if (!std::isfinite(dz[D.n + c])) return ALG_STATUS_SINGULAR; }
+    return ALG_STATUS_OK;
+}
+// ibr_line_search (solver_methods.jl:270-289)
+void ibr_line_search(const Shared& sh, Game& g, int i, double reg, double res_norm0, double* alpha_out, int* j_out) {
+    const alg_options& o = sh.opt; int j = 1; double alpha = 1.0;
+    while (j < o.ls_iter) {
+        update_traj(sh, g.z[1], g.z[0], alpha, g.z[2]);
+        ibr_residual(sh, g, g.z[1], i, o.regularize ? reg : 0.0, &g.z[0]);
+        if (ibr_res_norm(sh, g, i) <= (1.0 - alpha * o.beta) * res_norm0) break;
+        alpha *= o.alpha_decrease; j += 1;
+    }
+    *alpha_out = alpha; *j_out = j;
+}
+// ibr_inner_iteration (solver_methods.jl:230-268)
+alg_step_info ibr_inner_iteration(const Shared& sh, Game& g, int& LS_count, double& Delta, int k, int l, int i) {
+    const alg_options& o = sh.opt; alg_step_info info{};
+    const double reg = o.reg_0 * std::pow((double)l, 4);
+    alg_record rc = ibr_record(sh, g, Delta, k, i);                        // :238-240 (leaves the full residual in core.res)
+    const double rn = ibr_res_norm(sh, g, i);                              // :241
+    info.rec = rc; Delta = 0.0;
+    auto done = [&](int status, int flow) { info.status = status; info.control_flow = flow; g.hist.push_back(info.rec); g.st.records++; return info; };
+    if (!std::isfinite(rn)) return done(ALG_STATUS_NAN, 1);
+    if (rc.opt_vio < o.eps_opt) return done(ALG_STATUS_OK, 1);            // :245-247
+    int st = ibr_direction(sh, g, i, reg);                                 // :249-252
+    if (st != ALG_STATUS_OK) return done(st, 1);
+    g.st.newton_iters++;
+    double alpha; int j; ibr_line_search(sh, g, i, reg, rn, &alpha, &j);   // :255
+    const bool failed = (j == o.ls_iter);
+    if (failed) { LS_count += 1; g.st.ls_failures++; } else LS_count = 0;
+    update_traj(sh, g.z[0], g.z[0], alpha, g.z[2]);                        // :258
+    Delta = delta_step(sh, g.z[2], alpha);                                 // :259
+    info.alpha = alpha; info.ls_j = j; info.ls_failed = failed; info.delta = Delta; info.rec.alpha = alpha; info.rec.ls_j = j;
+    return done(ALG_STATUS_OK, Delta < o.delta_min ? 1 : 0);
+}
+// reset_duals!(pdtraj) (primal_dual_traj.jl:149-158)
+void reset_traj_duals(const Dims& D, std::vector<double>& z) {
+    for (int k = 0; k < D.N - 1; k++) for (int i = 0; i < D.p; i++) for (int a = 0; a < D.n; a++) z[D.n + D.hl(k, i) + a] *= 0.0;
+}
+// ibr_newton_solve!(prob, i) (solver_methods.jl:171-228)
+void ibr_solve_player(const Shared& sh, Game& g, int i) {
+    const alg_options& o = sh.opt;
+    if (o.dual_reset) { reset_con(sh, g); reset_traj_duals(sh.D, g.z[0]); reset_traj_duals(sh.D, g.z[1]); }   // :181-185
+    int out = 0; double Delta = 0.0; g.st.status = ALG_STATUS_OK; g.st.converged = 0;
+    for (int k = 1; k <= o.outer_iter; k++) {
+        out = k; int LS_count = 0; alg_record last{}; bool any = false;
+        for (int l = 1; l <= o.inner_iter; l++) {
+            alg_step_info info = ibr_inner_iteration(sh, g, LS_count, Delta, k, l, i);
+            last = info.rec; any = true;
+            if (info.status != ALG_STATUS_OK) { g.st.status = info.status; break; }
+            if (LS_count >= 1 || info.control_flow == 1) break;
+        }
+        if (g.st.status != ALG_STATUS_OK) break;
+        const bool conv = any && last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
+        if (conv) g.st.converged = 1;
+        if (k == o.outer_iter || conv) break;
+        dual_penalty_update(sh, g);
+    }
+    alg_record fin = ibr_record(sh, g, Delta, out, i);                      // :226
+    g.hist.push_back(fin); g.st.records++; g.st.outer_iters = out; g.st.last = fin;
+}
+// ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169)
+void ibr_newton_solve(const Shared& sh, Game& g, bool init, uint64_t game_id, int ibr_iter, const int* ordering, double delta_min) {
+    const Dims& D = sh.D;
+    g.st = alg_game_stats{}; g.hist.clear(); g.max_delta = 0.0;             // reset!(prob.stats)
+    if (init) init_traj(sh, g, g.z[0], game_id, true, false); else for (int a = 0; a < D.n; a++) g.z[0][a] = g.x0[a];
+    g.z[1] = g.z[0]; std::fill(g.z[2].begin(), g.z[2].end(), 0.0);
+    rollout(sh, g.z[0]);
+    std::vector<char> change(D.p, 1);
+    for (int q = 0; q < ibr_iter; q++) {
+        for (int id = 0; id < D.p; id++) {
+            const int i = ordering[id];
+            ibr_solve_player(sh, g, i);
+            change[i] = !(delta_min > g.max_delta);                         // :157 (maximum over the whole Statistics history)
+            if (g.st.status != ALG_STATUS_OK) return;
+        }
+        bool any = false; for (char c : change) any |= (c != 0);
+        if (!any) break;                                                    // :163
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -922,6 +1092,22 @@ int orc_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record
     if (n_out) *n_out = c; return ALG_OK;
 }
 int orc_synchronize(alg_handle*) { return ALG_OK; }
+int orc_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats) {
+    if (player < 0 || player >= H->sh.D.p) return fail(ALG_ERR_ARG, "orc_ibr_solve_player: bad player index");
+    const int B = (int)H->g.size();
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) { ibr_solve_player(H->sh, H->g[gi], player); if (stats) stats[gi] = H->g[gi].st; }
+    return ALG_OK;
+}
+int orc_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t ibr_iter, const int32_t* ordering, double delta_min, alg_game_stats* stats) {
+    const int B = (int)H->g.size(), p = H->sh.D.p;
+    if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "orc_ibr_newton_solve: x0 / LQR data not set");
+    if (!ordering || ibr_iter < 1) return fail(ALG_ERR_ARG, "orc_ibr_newton_solve: bad arguments");
+    for (int i = 0; i < p; i++) if (ordering[i] < 0 || ordering[i] >= p) return fail(ALG_ERR_ARG, "orc_ibr_newton_solve: ordering entries must be player ids");
+#pragma omp parallel for schedule(dynamic)
+    for (int gi = 0; gi < B; gi++) { ibr_newton_solve(H->sh, H->g[gi], init != 0, (uint64_t)(game_id0 + gi), ibr_iter, ordering, delta_min); if (stats) stats[gi] = H->g[gi].st; }
+    return ALG_OK;
+}
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1); totals += finished solve
 int orc_mpc_advance(alg_handle* h) {
     const Dims& D = H->sh.D;

@@ -246,6 +246,63 @@ def test_mpc_receding_horizon_parity(alg, orc):
     assert np.array_equal(ig2, ig) and np.array_equal(cg2, cg)
 
 
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[6], CASES[7], CASES[8]])
+def test_ibr_best_response_step_parity(alg, orc, case):
+    """One ibr_inner_iteration of every player (solver_methods.jl:230-268): masked residual norm, player-specific
+    violations, masked Newton direction, line search, update."""
+    g, o = _pair(alg, orc, *case, B=3, seed=13)
+    for b in (g, o):
+        b.set_options(outer_iter=1, inner_iter=1, dual_reset=0, reg_0=1e-3)
+    for player in range(case[1]):
+        sg, so = g.ibr_solve_player(player), o.ibr_solve_player(player)
+        for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
+            assert np.array_equal(sg[f], so[f]), (player, f, sg[f], so[f])
+        for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+            assert np.allclose(sg["last"][f], so["last"][f], rtol=1e-9, atol=1e-12), (player, f)
+        zg, zo = g.get_traj(0), o.get_traj(0)
+        assert np.abs(zg - zo).max() <= 1e-9 * max(1.0, np.abs(zo).max())
+        dg, do = g.get_traj(2), o.get_traj(2)
+        assert np.abs(dg - do).max() <= 1e-9 * max(1.0, np.abs(do).max())
+        hg, ho = g.get_history(0), o.get_history(0)
+        assert len(hg) == len(ho) and np.array_equal(hg["alpha"], ho["alpha"]) and np.array_equal(hg["ls_j"], ho["ls_j"])
+
+
+def test_ibr_newton_solve_parity_and_reference_thresholds(alg, orc):
+    """ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169) on the reference's IBR problems
+    (test/problem/solver_methods.jl:250-311) and on a constrained 3-player game."""
+    def problem(model, x0, opts, backend=None):
+        N, dt, p = 20, 0.1, model.p
+        obj = alg.GameObjective([np.ones(model.ni[i]) for i in range(p)], [0.5 * np.ones(model.mi[i]) for i in range(p)],
+                                [np.zeros(model.ni[i]) for i in range(p)], [-np.ones(model.mi[i]) for i in range(p)], N, model)
+        con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+        return alg.GameProblem(N, dt, x0, model, opts, obj, con, backend=backend)
+
+    x0 = [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9]
+    for model, outer, inner, ibr_iter in ((alg.DoubleIntegratorGame(p=2), 1, 1, 100), (alg.UnicycleGame(p=2), 7, 20, 12)):
+        sols = []
+        for backend in (None, orc.lib()):
+            opts = alg.Options(inner_print=False, outer_print=False)
+            prob = problem(model, x0, opts, backend)
+            opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = outer, inner, 25, 1e-7, 1e-10, 1e-10
+            alg.ibr_newton_solve(prob, ibr_opts=alg.IBROptions(ibr_iter=ibr_iter))
+            res = alg.residual(prob)
+            assert np.abs(res).sum() / res.shape[1] < 5e-2 and alg.dynamics_violation(prob)[0] < 1e-6
+            sols.append((prob.stats.summary.copy(), prob.batch.get_traj()))
+        (sg, zg), (so, zo) = sols
+        for f in ("status", "newton_iters", "records", "outer_iters", "ls_failures"):
+            assert np.array_equal(sg[f], so[f]), f
+        assert np.abs(zg - zo).max() < 1e-7
+    # constrained 3-player double integrator (C2 ingredients), short IBR run
+    pg = alg.scenarios.make_problem("C2", np.arange(4), N=12)
+    po = alg.scenarios.make_problem("C2", np.arange(4), N=12, backend=orc.lib())
+    io = alg.IBROptions(ibr_iter=3, ordering=[2, 1, 3])
+    alg.ibr_newton_solve(pg, ibr_opts=io); alg.ibr_newton_solve(po, ibr_opts=io)
+    sg, so = pg.stats.summary, po.stats.summary
+    for f in ("status", "newton_iters", "records", "outer_iters", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]), (f, sg[f], so[f])
+    assert np.abs(pg.batch.get_traj() - po.batch.get_traj()).max() < 1e-7
+
+
 def test_reference_e2e_thresholds_on_gpu(alg):
     """The five newton_solve! problems of test/problem/solver_methods.jl run through the product path."""
     def problem(model, x0, opts, constrained=False):

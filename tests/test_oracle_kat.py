@@ -506,3 +506,62 @@ def test_e2e_unicycle_two_players_constrained(alg, orc):
     assert np.abs(res).sum() / res.shape[1] < 1e-3
     for f in ("dyn_vio", "sta_vio", "con_vio", "opt_vio"):
         assert last[f] < 1e-3, (f, last[f])
+
+
+# ---------------------------------------------------------------- iterated best response (test/problem/solver_methods.jl:185-314)
+def test_ibr_mask_sizes_and_structure(alg):
+    # test/core/newton_core.jl:115-160 (p = 5, N = 6): |vertical mask| = |horizontal mask| = (N-1)(2n + mi); with
+    # splitted_state = false the masks are the player's opt rows + all dyn rows / x + u_i + lambda_i columns
+    model = alg.DoubleIntegratorGame(p=5)
+    ps = alg.ProblemSize(6, model)
+    v, h = alg.vertical_indices(ps), alg.horizontal_indices(ps)
+    for i in range(1, 6):
+        vm = sum([v[alg.stampify("opt", i, "x", 1, k)] + v[alg.stampify("opt", i, "u", i, k - 1)] for k in range(2, 7)], []) \
+            + sum([v[alg.stampify("dyn", 1, "x", 1, k)] for k in range(1, 6)], [])
+        hm = sum([h[alg.stampify("x", 1, k)] for k in range(2, 7)], []) + sum([h[alg.stampify("u", i, k)] + h[alg.stampify("λ", i, k)] for k in range(1, 6)], [])
+        assert len(vm) == len(set(vm)) == (ps.N - 1) * (2 * ps.n + ps.mi[i - 1]) == len(hm) == len(set(hm))
+
+
+def _ibr_problem(alg, orc, model, x0, opts):
+    N, dt, p = 20, 0.1, model.p
+    obj = alg.GameObjective([np.ones(model.ni[i]) for i in range(p)], [0.5 * np.ones(model.mi[i]) for i in range(p)],
+                            [np.zeros(model.ni[i]) for i in range(p)], [-np.ones(model.mi[i]) for i in range(p)], N, model)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    return alg.GameProblem(N, dt, x0, model, opts, obj, con, backend=orc.lib())
+
+
+@pytest.mark.parametrize("which", [0, 1, 2, 3])
+def test_ibr_e2e(alg, orc, which):
+    model, x0, outer, inner, single, tol = [
+        (alg.DoubleIntegratorGame(p=1), [1.0, 1.0, 0.0, 0.9], 1, 1, True, 1e-6),                         # :187-216
+        (alg.UnicycleGame(p=1), [1.0, 1.0, 0.0, 0.9], 7, 20, True, 1e-6),                                # :218-247
+        (alg.DoubleIntegratorGame(p=2), [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9], 1, 1, False, 5e-2),    # :250-279
+        (alg.UnicycleGame(p=2), [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9], 7, 20, False, 5e-2)][which]     # :282-311
+    opts = alg.Options(inner_print=False, outer_print=False)
+    prob = _ibr_problem(alg, orc, model, x0, opts)
+    opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = outer, inner, 25, 1e-7, 1e-10, 1e-10
+    if single:
+        alg.ibr_newton_solve(prob, 1)
+    else:
+        alg.ibr_newton_solve(prob)
+    res = alg.residual(prob)
+    assert np.abs(res).sum() / res.shape[1] < tol
+    assert alg.dynamics_violation(prob)[0] < 1e-6
+
+
+def test_ibr_direction_moves_only_the_players_variables(orc):
+    """Δtraj[horiz_mask] = -lu(jac[verti_mask, horiz_mask]) \\ res[verti_mask] (solver_methods.jl:249-251): after one best
+    response of player 2 only x, u_2 and lambda_2 have moved."""
+    b = orc.OracleBatch(UNI, 3, 8, 0.1, 2)
+    rng = np.random.default_rng(21)
+    b.set_lqr(1 + rng.random((3, 4)), 0.5 + rng.random((3, 2)), rng.random((3, 4)), rng.random((3, 2)))
+    x0 = rng.random((2, b.n)); b.set_x0(x0)
+    b.add_collision_avoidance(0.3 * np.ones(3)); b.add_control_bound(0.6 * np.ones(b.m), -0.6 * np.ones(b.m))
+    z = rng.random((2, b.traj_len)); z[:, :b.n] = x0; b.set_traj(z)
+    b.set_options(outer_iter=1, inner_iter=1, dual_reset=0)
+    b.ibr_solve_player(1)
+    X0, U0, L0 = b.split_traj(z); X1, U1, L1 = b.split_traj(b.get_traj())
+    moved_u = np.abs(U1 - U0).max(axis=(0, 1)) > 0
+    assert np.array_equal(moved_u, np.array([False, True, False, False, True, False]))     # pu[2] = {2, 5}
+    assert np.array_equal(L1[:, [0, 2]], L0[:, [0, 2]]) and np.abs(L1[:, 1] - L0[:, 1]).max() > 0
+    assert np.abs(X1[:, 1:] - X0[:, 1:]).max() > 0 and np.array_equal(X1[:, 0], X0[:, 0])

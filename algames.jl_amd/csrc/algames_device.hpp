@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 #include "../../include/algames_hip.h"
 
 namespace alg {
@@ -341,6 +342,7 @@ struct DirLds {
         double s[C::P * C::n];
         double t[C::P * C::n];         // t_i = P_i f + s_i (n == 16 path) / y_i = P_i rd + s_i
         double V[C::m * C::n];
+        double pad[1];                 // dump slot for the masked-off lanes of the MFMA result write-back
     };
     struct Fwd {                       // live only during the forward / costate sweeps
         double kg[2][C::m * (C::n + 1)];
@@ -818,16 +820,20 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             }
         }
         __syncthreads();           // all reads of Pm / s done
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-            if (IBR && i != ip) continue;
+        {
+            // every lane stores its four results per player unconditionally: into P_i, into s_i (tile column n), or into
+            // the dump slot -- one address select per register instead of an exec-mask region per store
+            double* const bwb = reinterpret_cast<double*>(&L.bw);
+            constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oS = (int)(offsetof(typename DirLds<C>::Bwd, s) / 8),
+                          oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
 #pragma unroll
             for (int r4 = 0; r4 < 4; r4++) {
                 const int row = lq + 4 * r4;
-                if (rowok[r4]) {
-                    if (colP) L.bw.Pm[i * n * LDP + row * LDP + lrow] = acc2[i][r4];
-                    else if (colS) L.bw.s[i * n + row] = acc2[i][r4];
-                }
+                const bool toP = rowok[r4] && colP, toS = rowok[r4] && colS;
+                const int slot = toP ? oPm + row * LDP + lrow : (toS ? oS + row : oPad);
+                const int stride = toP ? n * LDP : (toS ? n : 0);
+#pragma unroll
+                for (int i = 0; i < P; i++) { if (IBR && i != ip) continue; bwb[slot + i * stride] = acc2[i][r4]; }
             }
         }
         if (n == 16) {
@@ -882,8 +888,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 double v = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r);
                 const double av = (k >= 1) ? A_entry<C>(coefk, dt, r, cc < n ? cc : 0) : 0.0;
                 v += (cc < n) ? av : Rc[R::RD + r];
-                if (cc < n || n < 16) L.bw.Fx[r * 16 + cc] = v;
-                if (cc == n) L.bw.fv[r] = v;
+                if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = v;              // f rides in tile column n
+                else { if (cc < n) L.bw.Fx[r * 16 + cc] = v; else L.bw.fv[r] = v; }
             }
         }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = coefk[lane];

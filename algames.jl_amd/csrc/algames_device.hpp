@@ -780,8 +780,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             }
         }
         __syncthreads();
-        // ---- P_i <- Q^_i + A_{k+1}' (P_i [F|f] + [0|s_i]) ,  s_i <- rx_i + A_{k+1}' (P_i f + s_i)   via chained f64 MFMAs
-        double4_t acc2[P];
+        // ---- P_i <- Q^_i + A_{k+1}' (P_i [F|f] + [0|s_i]) ,  s_i <- rx_i + A_{k+1}' (P_i f + s_i)   via chained f64 MFMAs.
+        // Player i's chain reads only P_i / s_i (plus the shared F, A), so its result is written back before the next
+        // player starts: one accumulator tile live instead of P.
         {
             double bF[KB], aA[KB];
             if (k < N - 2) {
@@ -791,6 +792,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                     aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
                 }
             }
+            double* const bwb = reinterpret_cast<double*>(&L.bw);
+            constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oS = (int)(offsetof(typename DirLds<C>::Bwd, s) / 8),
+                          oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
 #pragma unroll
             for (int i = 0; i < P; i++) {
                 if (IBR && i != ip) continue;
@@ -816,24 +820,14 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 #pragma unroll
                     for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
                 }
-                acc2[i] = c2;
-            }
-        }
-        __syncthreads();           // all reads of Pm / s done
-        {
-            // every lane stores its four results per player unconditionally: into P_i, into s_i (tile column n), or into
-            // the dump slot -- one address select per register instead of an exec-mask region per store
-            double* const bwb = reinterpret_cast<double*>(&L.bw);
-            constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oS = (int)(offsetof(typename DirLds<C>::Bwd, s) / 8),
-                          oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
+                __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const int row = lq + 4 * r4;
-                const bool toP = rowok[r4] && colP, toS = rowok[r4] && colS;
-                const int slot = toP ? oPm + row * LDP + lrow : (toS ? oS + row : oPad);
-                const int stride = toP ? n * LDP : (toS ? n : 0);
-#pragma unroll
-                for (int i = 0; i < P; i++) { if (IBR && i != ip) continue; bwb[slot + i * stride] = acc2[i][r4]; }
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int row = lq + 4 * r4;
+                    const bool toP = rowok[r4] && colP, toS = rowok[r4] && colS;
+                    const int slot = toP ? oPm + i * n * LDP + row * LDP + lrow : (toS ? oS + i * n + row : oPad);
+                    bwb[slot] = c2[r4];
+                }
             }
         }
         if (n == 16) {

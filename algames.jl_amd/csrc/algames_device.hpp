@@ -763,11 +763,6 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     int cur = 0, sing = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
-        double pre[RPL];
-        if (k > 0) {
-#pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
-        }
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         const double* coefk = Rc + R::COEF;
         hxm.expand(lane, Rc, L.hx);
@@ -839,6 +834,12 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             }
         }
         __syncthreads();
+        // prefetch of the next step's record: issued after the register-hungry MFMA phase, landed by the end of the step
+        double pre[RPL];
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+        }
         // ---- V[c][:] = B[:,c]' P_{i(c)}   (m x n)  and  y_i = P_i rd + s_i
         for (int e = lane; e < m * n; e += WAVE) {
             const int c = e / n, col = e % n; const double* Pi = &L.bw.Pm[(c % P) * n * LDP];

@@ -122,6 +122,69 @@ def test_inner_iteration_parity(alg, orc, case):
         assert np.abs(zg - zo).max() <= 1e-9 * max(1.0, np.abs(zo).max())
 
 
+@pytest.mark.parametrize("ingredients", [(), ("cost",), ("avoid",), ("ctl",), ("cost", "ctl"), ("avoid", "ctl")])
+@pytest.mark.parametrize("case", [CASES[2], CASES[7]])
+def test_ingredient_subsets_parity(alg, orc, case, ingredients):
+    """Every subset of {collision cost, collision avoidance, control bound} (empty constraint lists included):
+    residual, Newton direction and one full inner iteration against the oracle."""
+    g, o = _pair(alg, orc, *case, B=3, seed=17, ingredients=ingredients)
+    rg, ng = g.residual(0, 0.0); ro, no = o.residual(0, 0.0)
+    assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max())
+    dg, sg = g.newton_direction(1e-3); do, so = o.newton_direction(1e-3)
+    assert np.all(sg == 0) and np.all(so == 0)
+    assert (np.abs(dg - do) / np.abs(do).max(axis=1, keepdims=True)).max() < 1e-9
+    ig, io = g.newton_step(1, 1), o.newton_step(1, 1)
+    assert np.array_equal(ig["ls_j"], io["ls_j"]) and np.array_equal(ig["alpha"], io["alpha"])
+    for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+        assert np.allclose(ig["rec"][f], io["rec"][f], rtol=1e-9, atol=1e-14), f
+
+
+def test_edge_cases_minimum_horizon_single_game_infinite_bounds(alg, orc):
+    # N = 2 (a single time step: no interior knot, terminal cost only), batch of one game
+    for model, p in ((DI, 2), (UNI, 3)):
+        g, o = _pair(alg, orc, model, p, 2, 2, B=1, seed=19)
+        rg, _ = g.residual(0, 0.0); ro, _ = o.residual(0, 0.0)
+        assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max())
+        assert np.abs(g.residual_jacobian(1e-3) - o.residual_jacobian(1e-3)).max() <= 1e-12 * np.abs(o.residual_jacobian(1e-3)).max()
+        dg, sg = g.newton_direction(1e-3); do, so = o.newton_direction(1e-3)
+        assert sg[0] == 0 and (np.abs(dg - do) / np.abs(do).max()).max() < 1e-9
+        sg_, so_ = g.newton_solve(init=False), o.newton_solve(init=False)
+        for f in ("status", "outer_iters", "newton_iters", "records", "converged"):
+            assert np.array_equal(sg_[f], so_[f]), f
+        assert np.abs(g.get_traj() - o.get_traj()).max() < 1e-8
+    # control bounds that are all infinite: the reference's constraint has zero rows (control_bound_constraint.jl:35-38)
+    g = alg.Batch(alg.hip_lib(), DI, 2, 6, 0.1, 2); o = orc.OracleBatch(DI, 2, 6, 0.1, 2)
+    rng = np.random.default_rng(23)
+    x0 = rng.random((2, g.n)); z = rng.random((2, g.traj_len)); z[:, :g.n] = x0
+    for b in (g, o):
+        b.set_x0(x0); b.set_lqr(np.ones((2, 4)), np.ones((2, 2)), np.zeros((2, 4)), np.zeros((2, 2)))
+        b.add_control_bound(np.full(b.m, np.inf), np.full(b.m, -np.inf)); b.set_traj(z)
+    assert np.abs(g.residual()[0] - o.residual()[0]).max() < 1e-13
+    assert g.record()["con_vio"].max() == 0.0 and o.record()["con_vio"].max() == 0.0
+    vg, vo = g.dual_penalty_update(), o.dual_penalty_update()
+    off = g.p * (g.p - 1) * (g.N - 1)                                               # control-bound rows follow the collision rows
+    assert np.all(np.isinf(vg[:, off:])) and np.all(np.isinf(vo[:, off:])) and np.all(g.get_con_duals()[0] == 0)
+
+
+def test_numerical_failure_is_reported_per_game_not_as_a_call_error(alg, orc):
+    """Singular KKT (Q = R = 0, no regularisation) -> status SINGULAR for that game only (the reference would throw
+    SingularException out of lu, solver_methods.jl:87); non-finite iterate -> status NAN; the other games of the
+    batch are unaffected."""
+    g = alg.Batch(alg.hip_lib(), DI, 2, 8, 0.1, 3); o = orc.OracleBatch(DI, 2, 8, 0.1, 3)
+    rng = np.random.default_rng(29)
+    x0 = rng.random((3, g.n)); z = 0.1 * rng.random((3, g.traj_len)); z[:, :g.n] = x0
+    Q = np.ones((3, 2, 4)); R = np.ones((3, 2, 2)); R[1] = 0.0; Q[1] = 0.0        # game 1: no cost at all -> zero control Hessian
+    z[2, g.n + 5] = np.nan                                                            # game 2: poisoned iterate
+    for b in (g, o):
+        b.set_x0(x0); b.set_lqr(Q, R, np.zeros((3, 2, 4)), np.zeros((3, 2, 2))); b.set_traj(z)
+        b.set_options(reg_0=0.0, regularize=0, outer_iter=2, inner_iter=3)
+    ig, io = g.newton_step(1, 1), o.newton_step(1, 1)
+    assert ig["status"].tolist() == [0, 1, 2] and io["status"].tolist() == [0, 1, 2]
+    assert ig["control_flow"].tolist() == [0, 1, 1] or ig["control_flow"][0] in (0, 1)
+    b0g, b0o = g.get_traj()[0], o.get_traj()[0]
+    assert np.abs(b0g - b0o).max() < 1e-9                                             # healthy game still parity-exact
+
+
 def test_dual_penalty_update_and_reset_parity(alg, orc):
     for case in (CASES[2], CASES[8]):
         g, o = _pair(alg, orc, *case, B=3, seed=7)

@@ -10,6 +10,7 @@ import numpy as np
 ALG_OK = 0
 ALG_MODEL_DOUBLE_INTEGRATOR = 0
 ALG_MODEL_UNICYCLE = 1
+ALG_MODEL_BICYCLE = 2
 ALG_TRAJ_PD, ALG_TRAJ_TRIAL, ALG_TRAJ_DELTA = 0, 1, 2
 ALG_STATUS_OK, ALG_STATUS_SINGULAR, ALG_STATUS_NAN = 0, 1, 2
 
@@ -81,6 +82,11 @@ SIGNATURES = {
     "add_collision_cost": (C.c_int, [_P, _D, _D]),
     "add_collision_avoidance": (C.c_int, [_P, _D]),
     "add_control_bound": (C.c_int, [_P, _D, _D]),
+    "set_bicycle": (C.c_int, [_P, C.c_double, C.c_double]),
+    "add_state_bound": (C.c_int, [_P, C.c_int32, _D, _D]),
+    "add_wall_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D, _D, _D]),
+    "add_circle_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
+    "get_con_len": (C.c_int, [_P, _I]),
     "set_traj": (C.c_int, [_P, C.c_int32, _D]),
     "get_traj": (C.c_int, [_P, C.c_int32, _D]),
     "set_con_duals": (C.c_int, [_P, _D, _D]),
@@ -239,6 +245,28 @@ class Batch:
 
     def add_control_bound(self, u_max, u_min):
         self.lib.check(self.lib.add_control_bound(self.h, _dptr(_f64(u_max, (self.m,))), _dptr(_f64(u_min, (self.m,)))))
+
+    def _refresh_con_len(self):
+        v = C.c_int32()
+        self.lib.check(self.lib.get_con_len(self.h, C.byref(v)))
+        self.con_len = v.value
+
+    def set_bicycle(self, lf, lr):
+        self.lib.check(self.lib.set_bicycle(self.h, float(lf), float(lr)))
+
+    def add_state_bound(self, player, x_max, x_min):
+        self.lib.check(self.lib.add_state_bound(self.h, int(player), _dptr(_f64(x_max, (self.n,))), _dptr(_f64(x_min, (self.n,)))))
+        self._refresh_con_len()
+
+    def add_wall_constraint(self, x1, y1, x2, y2, xv, yv):
+        arrs = [_f64(a) for a in (x1, y1, x2, y2, xv, yv)]
+        self.lib.check(self.lib.add_wall_constraint(self.h, len(arrs[0]), *[_dptr(a) for a in arrs]))
+        self._refresh_con_len()
+
+    def add_circle_constraint(self, xc, yc, radius):
+        arrs = [_f64(a) for a in (xc, yc, radius)]
+        self.lib.check(self.lib.add_circle_constraint(self.h, len(arrs[0]), *[_dptr(a) for a in arrs]))
+        self._refresh_con_len()
 
     # ---- data movement -----------------------------------------------------------------------
     def set_traj(self, z, which=ALG_TRAJ_PD):

@@ -42,6 +42,9 @@ struct Params {
     int kscratch_len;       // per game doubles of gain scratch
     int rec_len;            // per game doubles of step records
     unsigned long long ibr_ctl_rows[MAXP];   // control-bound rows counted by control_violation(game_con, pdtraj, i) (violations.jl:69-82)
+    // extended ingredient set (Cfg::EXT instantiations only)
+    int ext, has_sb, nwall, ncirc, sb_len, wall_len, circ_len;
+    double lf, lr;          // BicycleGame(lf, lr), bicycle.jl:15
 };
 
 // Device pointers of a handle (all game-major).
@@ -57,18 +60,25 @@ struct Buffers {
     alg_record* hist;       // B x hist_max
     long long* mpc;         // B x 2 running totals (newton_iters, converged) of the receding-horizon loop
     double* tcache;         // B x 8 statistics of the last line-search trial (reused as the next record!)
+    double* extc;           // constants of the extended constraints, shared by all games:
+                            // [x_max (p n) | x_min (p n) | walls x1 y1 x2 y2 xv yv (6 ALG_MAX_WALLS) | circles xc yc r (3 ALG_MAX_CIRCLES)]
 };
 
-template <int MODEL_, int P_, int D_>
+// EXT_ = 1 instantiations carry the extended ingredient set of examples/intro_example.jl (state bounds, walls, circles;
+// the bicycle model is always EXT); the EXT_ = 0 instantiations (the BASELINE configurations) pay nothing for it.
+template <int MODEL_, int P_, int D_, int EXT_ = 0>
 struct Cfg {
     static constexpr int MODEL = MODEL_, P = P_, D = D_;
+    static constexpr bool EXT = EXT_ != 0;
+    static constexpr bool POS = (P_ > 1) || EXT;     // position blocks (pair / wall / circle terms) present in Q^_i
     static constexpr int n = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 * D_ * P_ : 4 * P_;
     static constexpr int m = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? D_ * P_ : 2 * P_;
     static constexpr int mi = m / P_;
     static constexpr int ni = n / P_;
     static constexpr int b = n + m + P_ * n;
     static constexpr int NPAIR = P_ * (P_ - 1);
-    static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
+    static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : (MODEL_ == ALG_MODEL_BICYCLE) ? 10 * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
+    static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : 3;        // max non-zeros of a column of [B_k | A_k]
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
     static constexpr int WPE = (n >= 16) ? 2 : 4;
@@ -138,10 +148,41 @@ __host__ __device__ inline double counter_uniform(uint64_t seed, uint64_t game, 
 //     d x+/d om = dt/2 coef0, d x+/d a = dt/2 coef1, d y+/d om = dt/2 coef2, d y+/d a = dt/2 coef3,
 //     d th+/d om = dt, d v+/d a = dt
 //   double integrator: A = [[I, dt I],[0, I]], B = [[dt^2/2 I],[dt I]] (no state dependence; coef unused)
+//   bicycle (bicycle.jl:28-41; state [x(P) y(P) v(P) psi(P)], control [a(P) delta(P)]), beta = atan(lr tan delta, lr + lf),
+//     sg = sin(beta)/lr, vm = v + dt/2 a, psm = psi + dt/2 v sg, th = beta + psm, beta' = d beta/d delta, sg' = cos(beta) beta'/lr:
+//     coef[0] = d x+/d psi = -dt vm sin th          coef[1] = d x+/d v = dt cos th - dt vm sin th (dt/2 sg)
+//     coef[2] = d y+/d psi =  dt vm cos th          coef[3] = d y+/d v = dt sin th + dt vm cos th (dt/2 sg)
+//     coef[4] = d psi+/d v = dt sg                  coef[5] = dt cos th      coef[6] = dt sin th
+//     coef[7] = d x+/d delta = -dt vm sin th (beta' + dt/2 v sg')   coef[8] = d y+/d delta = dt vm cos th (beta' + dt/2 v sg')
+//     coef[9] = d psi+/d delta = dt vm sg'
+//     d x+/d a = dt/2 coef5, d y+/d a = dt/2 coef6, d v+/d a = dt, d psi+/d a = dt/2 coef4        (each coef[t] at [t*P + i])
 // ================================================================================================
+struct BikeGeom { double beta, sg, dbeta, dsg; };
+__device__ __forceinline__ BikeGeom bike_geom(double delta, double lf, double lr) {
+    const double L = lr + lf, td = tan(delta), y = lr * td;
+    BikeGeom g;
+    g.beta = atan2(y, L);
+    double sb, cb; sincos(g.beta, &sb, &cb);
+    g.sg = sb / lr;
+    g.dbeta = (lr * L) * (1.0 + td * td) / (L * L + y * y);
+    g.dsg = cb * g.dbeta / lr;
+    return g;
+}
+// Jacobian coefficients of player i at a knot with own state (v, psi) and controls (a, delta)
 template <class C>
-__device__ __forceinline__ void model_player(int i, const double* x, const double* u, double dt,
-                                             double* xn /*ni: entries pz(i,j)*/, double* coef /*4: entries j*P+i*/) {
+__device__ __forceinline__ void bike_coefs(const Params& pr, double v, double psi, double a, double delta, double dt, double (&cf)[10]) {
+    const BikeGeom g = bike_geom(delta, pr.lf, pr.lr);
+    const double vm = v + (a * dt) * 0.5, psm = psi + (v * g.sg * dt) * 0.5;
+    double sn, cs; sincos(g.beta + psm, &sn, &cs);
+    const double dth = g.dbeta + 0.5 * dt * v * g.dsg;
+    cf[0] = -dt * vm * sn; cf[1] = dt * cs - dt * vm * sn * (0.5 * dt * g.sg);
+    cf[2] = dt * vm * cs;  cf[3] = dt * sn + dt * vm * cs * (0.5 * dt * g.sg);
+    cf[4] = dt * g.sg; cf[5] = dt * cs; cf[6] = dt * sn;
+    cf[7] = -dt * vm * sn * dth; cf[8] = dt * vm * cs * dth; cf[9] = dt * vm * g.dsg;
+}
+template <class C>
+__device__ __forceinline__ void model_player(const Params& pr, int i, const double* x, const double* u, double dt,
+                                             double* xn /*ni: entries pz(i,j)*/, double* coef /*4: entries j*P+i (unicycle only)*/) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
         for (int j = 0; j < C::D; j++) {
@@ -151,6 +192,17 @@ __device__ __forceinline__ void model_player(int i, const double* x, const doubl
             xn[j] = x[ip] + vm * dt;
             xn[C::D + j] = x[iv] + u[ip] * dt;
         }
+        coef[0] = coef[1] = coef[2] = coef[3] = 0.0;
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P;
+        const double v = x[2 * P + i], psi = x[3 * P + i], a = u[i];
+        const BikeGeom g = bike_geom(u[P + i], pr.lf, pr.lr);
+        const double vm = v + (a * dt) * 0.5, psm = psi + (v * g.sg * dt) * 0.5;
+        double s, c; sincos(g.beta + psm, &s, &c);
+        xn[0] = x[i] + (vm * c) * dt;
+        xn[1] = x[P + i] + (vm * s) * dt;
+        xn[2] = v + a * dt;
+        xn[3] = psi + (vm * g.sg) * dt;
         coef[0] = coef[1] = coef[2] = coef[3] = 0.0;
     } else {
         const int P = C::P;
@@ -167,7 +219,7 @@ __device__ __forceinline__ void model_player(int i, const double* x, const doubl
 }
 // RK3 step of player i (rollout!, solver_methods.jl:17; RobotDynamics 0.3.1 RK3)
 template <class C>
-__device__ __forceinline__ void model_player_rk3(int i, const double* x, const double* u, double dt, double* xn) {
+__device__ __forceinline__ void model_player_rk3(const Params& pr, int i, const double* x, const double* u, double dt, double* xn) {
     double xi[C::ni], k1[C::ni], k2[C::ni], k3[C::ni], t[C::ni], ui[C::mi];
 #pragma unroll
     for (int j = 0; j < C::ni; j++) xi[j] = x[i + j * C::P];
@@ -177,6 +229,10 @@ __device__ __forceinline__ void model_player_rk3(int i, const double* x, const d
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
             for (int j = 0; j < C::D; j++) { o[j] = s[C::D + j]; o[C::D + j] = ui[j]; }
+        } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+            const BikeGeom g = bike_geom(ui[1], pr.lf, pr.lr);
+            double sn, cs; sincos(g.beta + s[3], &sn, &cs);
+            o[0] = s[2] * cs; o[1] = s[2] * sn; o[2] = ui[0]; o[3] = s[2] * g.sg;
         } else {
             double sn, cs; sincos(s[2], &sn, &cs);
             o[0] = cs * s[3]; o[1] = sn * s[3]; o[2] = ui[0]; o[3] = ui[1];
@@ -198,6 +254,11 @@ template <class C, class V>
 __device__ __forceinline__ double AT_vec(const double* coef, double dt, V v, int r) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return r < C::m ? v(r) : v(r) + dt * v(r - C::m);
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P, blk = r / P, i = r % P;
+        if (blk == 2) return v(r) + coef[1 * P + i] * v(i) + coef[3 * P + i] * v(P + i) + coef[4 * P + i] * v(3 * P + i);
+        if (blk == 3) return v(r) + coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i);
+        return v(r);
     } else {
         const int P = C::P, blk = r / P, i = r % P;
         if (blk == 2) return v(r) + coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i);
@@ -210,6 +271,12 @@ template <class C, class V>
 __device__ __forceinline__ double A_vec(const double* coef, double dt, V v, int r) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return r < C::m ? v(r) + dt * v(r + C::m) : v(r);
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P, blk = r / P, i = r % P;
+        if (blk == 0) return v(r) + coef[0 * P + i] * v(3 * P + i) + coef[1 * P + i] * v(2 * P + i);
+        if (blk == 1) return v(r) + coef[2 * P + i] * v(3 * P + i) + coef[3 * P + i] * v(2 * P + i);
+        if (blk == 3) return v(r) + coef[4 * P + i] * v(2 * P + i);
+        return v(r);
     } else {
         const int P = C::P, blk = r / P, i = r % P;
         if (blk == 0) return v(r) + coef[0 * P + i] * v(2 * P + i) + coef[1 * P + i] * v(3 * P + i);
@@ -226,6 +293,11 @@ __device__ __forceinline__ double A_entry(const double* coef, double dt, int r, 
     double e = (r == c) ? 1.0 : 0.0;
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         if (r < C::m && c == r + C::m) e = dt;
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P, br = r / P, i = r % P;
+        if (br == 0) { if (c == 3 * P + i) e = coef[0 * P + i]; else if (c == 2 * P + i) e = coef[1 * P + i]; }
+        else if (br == 1) { if (c == 3 * P + i) e = coef[2 * P + i]; else if (c == 2 * P + i) e = coef[3 * P + i]; }
+        else if (br == 3) { if (c == 2 * P + i) e = coef[4 * P + i]; }
     } else {
         const int P = C::P, br = r / P, i = r % P;
         if (br == 0) { if (c == 2 * P + i) e = coef[0 * P + i]; else if (c == 3 * P + i) e = coef[1 * P + i]; }
@@ -239,6 +311,19 @@ __device__ __forceinline__ double B_entry(const double* coef, double dt, int r, 
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         if (r == c) return 0.5 * dt * dt;
         if (r == c + C::m) return dt;
+        return 0.0;
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P, i = c % P, kind = c / P;   // kind 0: a_i, 1: delta_i
+        if (kind == 0) {
+            if (r == i) return 0.5 * dt * coef[5 * P + i];
+            if (r == P + i) return 0.5 * dt * coef[6 * P + i];
+            if (r == 2 * P + i) return dt;
+            if (r == 3 * P + i) return 0.5 * dt * coef[4 * P + i];
+        } else {
+            if (r == i) return coef[7 * P + i];
+            if (r == P + i) return coef[8 * P + i];
+            if (r == 3 * P + i) return coef[9 * P + i];
+        }
         return 0.0;
     } else {
         const int P = C::P, i = c % P, kind = c / P;   // kind 0: omega_i, 1: a_i
@@ -259,6 +344,10 @@ template <class C, class V>
 __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int c) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return 0.5 * dt * dt * v(c) + dt * v(c + C::m);
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P, i = c % P, kind = c / P;
+        if (kind == 0) return 0.5 * dt * (coef[5 * P + i] * v(i) + coef[6 * P + i] * v(P + i) + coef[4 * P + i] * v(3 * P + i)) + dt * v(2 * P + i);
+        return coef[7 * P + i] * v(i) + coef[8 * P + i] * v(P + i) + coef[9 * P + i] * v(3 * P + i);
     } else {
         const int P = C::P, i = c % P, kind = c / P;
         if (kind == 0) return 0.5 * dt * (coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i)) + dt * v(2 * P + i);
@@ -270,6 +359,12 @@ template <class C, class V>
 __device__ __forceinline__ double B_vec(const double* coef, double dt, V w, int r) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return r < C::m ? 0.5 * dt * dt * w(r) : dt * w(r - C::m);
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P, br = r / P, i = r % P;
+        if (br == 0) return 0.5 * dt * coef[5 * P + i] * w(i) + coef[7 * P + i] * w(P + i);
+        if (br == 1) return 0.5 * dt * coef[6 * P + i] * w(i) + coef[8 * P + i] * w(P + i);
+        if (br == 2) return dt * w(i);
+        return 0.5 * dt * coef[4 * P + i] * w(i) + coef[9 * P + i] * w(P + i);
     } else {
         const int P = C::P, br = r / P, i = r % P;
         if (br == 0) return 0.5 * dt * (coef[0 * P + i] * w(i) + coef[1 * P + i] * w(P + i));
@@ -289,6 +384,7 @@ struct Game {
     double* lam; double* mu; double* vals;
     double* res; double* rec; double* kgain;
     alg_game_stats* st; alg_record* hist; double* tc;
+    const double* extc;
 };
 __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, int g) {
     Game G;
@@ -300,16 +396,42 @@ __device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, i
     G.lam = bf.lam + (size_t)g * pr.con_len; G.mu = bf.mu + (size_t)g * pr.con_len; G.vals = bf.vals + (size_t)g * pr.con_len;
     G.res = bf.res + (size_t)g * pr.S; G.rec = bf.rec + (size_t)g * pr.rec_len; G.kgain = bf.kgain + (size_t)g * pr.kscratch_len;
     G.st = bf.stats + g; G.hist = bf.hist + (size_t)g * pr.hist_max; G.tc = bf.tcache + (size_t)g * 8;
+    G.extc = bf.extc;
     return G;
 }
 
 // Altro 0.3.0 cost_expansion!: a = (c >= 0) | (lambda > 0)  [PINNED test/constraints/constraint_derivatives.jl:28-34]
 __device__ __forceinline__ double al_active_mu(double c, double lam, double mu) { return ((c >= 0.0) || (lam > 0.0)) ? mu : 0.0; }
 
+// ---- extended constraints (all on knots 2..N; `k` below is the 0-based step, i.e. knot k+2 of the reference) ----------
+__device__ __forceinline__ int ext_sb_row(const Params& pr, int i, int k, int row) { return pr.col_len + pr.ctl_len + (i * (pr.N - 1) + k) * 2 * pr.n + row; }
+__device__ __forceinline__ int ext_wall_row(const Params& pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + (i * (pr.N - 1) + k) * pr.nwall + w; }
+__device__ __forceinline__ int ext_circ_row(const Params& pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + (i * (pr.N - 1) + k) * pr.ncirc + c; }
+__device__ __forceinline__ const double* ext_sbmax(const Params& pr, const double* ec) { return ec; }
+__device__ __forceinline__ const double* ext_sbmin(const Params& pr, const double* ec) { return ec + pr.p * pr.n; }
+__device__ __forceinline__ const double* ext_walls(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n; }
+__device__ __forceinline__ const double* ext_circs(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS; }
+// WallConstraint evaluate / jacobian! (wall_constraint.jl:57-96): c = ((x-x1) xv + (y-y1) yv) left right
+__device__ __forceinline__ double wall_val(const double* W, int w, double x, double y, double* gx, double* gy) {
+    const double x1 = W[w], y1 = W[ALG_MAX_WALLS + w], x2 = W[2 * ALG_MAX_WALLS + w], y2 = W[3 * ALG_MAX_WALLS + w];
+    const double xv = W[4 * ALG_MAX_WALLS + w], yv = W[5 * ALG_MAX_WALLS + w];
+    const double left = ((x - x1) * (x2 - x1) + (y - y1) * (y2 - y1) > 0.0) ? 1.0 : 0.0;
+    const double right = ((x - x2) * (x1 - x2) + (y - y2) * (y1 - y2) > 0.0) ? 1.0 : 0.0;
+    *gx = left * right * xv; *gy = left * right * yv;
+    return ((x - x1) * xv + (y - y1) * yv) * left * right;
+}
+// TrajectoryOptimization 0.4.1 CircleConstraint: c = r^2 - (x-xc)^2 - (y-yc)^2
+__device__ __forceinline__ double circ_val(const double* Cc, int c, double x, double y, double* gx, double* gy) {
+    const double dx = x - Cc[c], dy = y - Cc[ALG_MAX_CIRCLES + c], r = Cc[2 * ALG_MAX_CIRCLES + c];
+    *gx = -2.0 * dx; *gy = -2.0 * dy;
+    return -(dx * dx) - (dy * dy) + r * r;
+}
+
 // ================================================================================================
 // Step records.  The assemble pass leaves one compact record per time step k in HBM; the serial sweeps of the Newton
 // direction read nothing else (plus the gains they spill themselves).
 //   [coefk (NC)] [Hh (3 NPAIR): pair Hessian blocks at knot k+1] [Hd (3 P): sum_j Hh(i,j)] [Rhat (m): R^ of knot k incl. reg]
+//   (EXT only: [RQ (P n): diagonal state-bound Hessian of player i at knot k+1])
 //   [rx (P n): rows opt_i,x_{k+1}] [ru (m): rows opt_i,u_{i,k}, joint order] [rd (n): dyn_k]      <- LEN_SWEEP
 //   [gvt (2 P^2): pair gradient table, only used inside the assemble pass]
 // ================================================================================================
@@ -318,7 +440,8 @@ template <class C> struct Rec {
     static constexpr int HH = COEF + C::NC;
     static constexpr int HD = HH + 3 * C::NPAIR;
     static constexpr int RHAT = HD + 3 * C::P;
-    static constexpr int RX = RHAT + C::m;
+    static constexpr int RQ = RHAT + C::m;
+    static constexpr int RX = RQ + (C::EXT ? C::P * C::n : 0);
     static constexpr int RU = RX + C::P * C::n;
     static constexpr int RD = RU + C::m;
     static constexpr int LEN_SWEEP = RD + C::n;
@@ -394,13 +517,19 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
     // ---------------- phase A ------------------------------------------------------------------------------
-    if (C::NC > 0 || (P > 1)) {
+    if (C::NC > 0 || C::POS) {
         const int items = (N - 1) * P;
         const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
         for (int e = lane; e < items; e += WAVE) {
             const int k = e / P, i = e % P, kn = k + 1;
             double* __restrict__ rec = G.rec + (size_t)k * R::LEN;
-            if constexpr (C::NC > 0) {
+            if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                const double* sk = zstate<C>(z, k);
+                double cf[10];
+                bike_coefs<C>(pr, sk[2 * P + i], sk[3 * P + i], z[n + hu<C>(k, i)], z[n + hu<C>(k, i) + 1], dt, cf);
+#pragma unroll
+                for (int t = 0; t < 10; t++) rec[R::COEF + t * P + i] = cf[t];
+            } else if constexpr (C::NC > 0) {
                 // Jacobian coefficients of knot k (A_k, B_k): see the model section
                 const double* sk = zstate<C>(z, k);
                 const double th = sk[2 * P + i], v = sk[3 * P + i];
@@ -410,7 +539,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 rec[R::COEF + 0 * P + i] = -dt * vm * sn; rec[R::COEF + 1 * P + i] = dt * cs;
                 rec[R::COEF + 2 * P + i] = dt * vm * cs;  rec[R::COEF + 3 * P + i] = dt * sn;
             }
-            if constexpr (P > 1) {
+            if constexpr (C::POS) {
                 const double w = (kn < N - 1) ? dt : 1.0;
                 const double* x1 = z + n + hx<C>(k);
                 const double xi0 = x1[i], xi1 = x1[P + i];
@@ -450,6 +579,20 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                     rec[R::GVT + (i * P + j) * 2 + 0] = -gv0; rec[R::GVT + (i * P + j) * 2 + 1] = -gv1;   // row opt_i at px(j,.)
                     if (RECS) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
                 }
+                if constexpr (C::EXT) {
+                    // wall / circle constraints of player i on its own position at knot k+1: AL gradient C'(lambda + a mu c)
+                    // and Gauss-Newton Hessian C' a mu C (constraint_derivatives.jl:10-19,47-58) join the (i,i) position block
+                    auto al_row = [&](int ci, double c, double gx, double gy) {
+                        const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
+                        const double wl = lm + am * c;
+                        ga0 += gx * wl; ga1 += gy * wl;
+                        d0 += am * gx * gx; d1 += am * gx * gy; d2 += am * gy * gy;
+                        G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
+                    };
+                    const double* Wc = ext_walls(pr, G.extc); const double* Cc = ext_circs(pr, G.extc);
+                    for (int wq = 0; wq < pr.nwall; wq++) { double gx, gy; const double c = wall_val(Wc, wq, xi0, xi1, &gx, &gy); al_row(ext_wall_row(pr, i, k, wq), c, gx, gy); }
+                    for (int cq = 0; cq < pr.ncirc; cq++) { double gx, gy; const double c = circ_val(Cc, cq, xi0, xi1, &gx, &gy); al_row(ext_circ_row(pr, i, k, cq), c, gx, gy); }
+                }
                 rec[R::GVT + (i * P + i) * 2 + 0] = ga0; rec[R::GVT + (i * P + i) * 2 + 1] = ga1;           // row opt_i at px(i,.)
                 if (RECS) { rec[R::HD + 3 * i] = d0; rec[R::HD + 3 * i + 1] = d1; rec[R::HD + 3 * i + 2] = d2; }
             }
@@ -468,16 +611,18 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     for (int c = lane; c < m; c += WAVE) { L.tr[c] = G.Rd[(c % P) * mi + c / P]; L.tu[c] = G.uf[(c % P) * mi + c / P]; }
     auto load_block = [&](int kb, int e) -> double { return (e < b && kb >= 0 && kb <= N - 2) ? z[n + (size_t)kb * b + e] : 0.0; };
     auto load_ref = [&](int kb) -> double { return (zref && lane < n + m && kb <= N - 2) ? zref[n + (size_t)kb * b + lane] : 0.0; };
-    auto load_aux = [&](int kb) -> double {      // [coef of knot kb+1 | gvt of step kb]
-        if (lane < C::NC) return (kb + 1 <= N - 2) ? G.rec[(size_t)(kb + 1) * R::LEN + R::COEF + lane] : 0.0;
-        if (lane < AUX) return G.rec[(size_t)kb * R::LEN + R::GVT + (lane - C::NC)];
+    constexpr int NAP = (AUX + WAVE - 1) / WAVE;
+    auto load_aux = [&](int kb, int t) -> double {      // [coef of knot kb+1 | gvt of step kb]
+        if (t < C::NC) return (kb + 1 <= N - 2) ? G.rec[(size_t)(kb + 1) * R::LEN + R::COEF + t] : 0.0;
+        if (t < AUX) return G.rec[(size_t)kb * R::LEN + R::GVT + (t - C::NC)];
         return 0.0;
     };
     if (lane < n) L.blk[0][lane] = z[lane];                                // x_1 sits where block -1's x part would be
 #pragma unroll
     for (int q = 0; q < NPASS; q++) { const int e = lane + q * WAVE; if (e < b) { L.blk[1][e] = load_block(0, e); L.blk[2][e] = load_block(1, e); } }
     if (lane < n + m) L.zr[0][lane] = load_ref(0);
-    if (lane < AUX) L.aux[1][lane] = load_aux(0);                          // aux[(k+1)&1] = [coef of knot k+1 | gvt of step k]
+#pragma unroll
+    for (int q = 0; q < NAP; q++) { const int t = lane + q * WAVE; if (t < AUX) L.aux[1][t] = load_aux(0, t); }   // aux[(k+1)&1] = [coef of knot k+1 | gvt of step k]
     if (C::NC > 0 && lane < C::NC) L.aux[0][lane] = G.rec[R::COEF + lane]; // coef of knot 0
     __syncthreads();
     for (int k = 0; k < N - 1; k++) {
@@ -506,7 +651,27 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 r = -Bk[e + n + m];
                 if (has_next) r += AT_vec<C>(Ax, dt, [&](int rr) { return ln[rr]; }, a);
                 r += w * (L.tq[e] * (Bk[a] - L.tx[e]));
-                if (P > 1 && a < 2 * P) r += Ax[C::NC + (i * P + a % P) * 2 + a / P];
+                if (C::POS && a < 2 * P) r += Ax[C::NC + (i * P + a % P) * 2 + a / P];
+                if constexpr (C::EXT) {
+                    // StateBoundConstraint of player i (state_bound_constraint.jl:85-97): rows (x - x_max)[a], (x_min - x)[a]
+                    double qsb = 0.0;
+                    if (pr.has_sb) {
+                        const double xa = Bk[a];
+#pragma unroll
+                        for (int half = 0; half < 2; half++) {
+                            const int ci = ext_sb_row(pr, i, k, half * n + a);
+                            const double cv = half == 0 ? xa - ext_sbmax(pr, G.extc)[e] : ext_sbmin(pr, G.extc)[e] - xa;
+                            G.vals[ci] = cv;
+                            if (isfinite(cv)) {
+                                const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
+                                const double wl = lm + am * cv;
+                                r += (half == 0 ? wl : -wl); qsb += am;
+                                if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, cv));
+                            }
+                        }
+                    }
+                    if (RECS) G.rec[(size_t)k * R::LEN + R::RQ + e] = qsb;
+                }
                 if (IBR) mine = (i == ip);
                 if (zref && mine) dprox = Bk[a] - Zr[a];
                 if (MODE == 2) vrow = vx<C>(N, i, k) + a;
@@ -543,6 +708,13 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
                     if (a < m) { const double vm = Bp[a + m] + (Bk[n + uoff<C>(a)] * dt) * 0.5; xn = Bp[a] + vm * dt; }
                     else xn = Bp[a] + Bk[n + uoff<C>(a - m)] * dt;
+                } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                    const int blkk = a / P, i = a % P;
+                    if (blkk == 2) xn = Bp[a] + Bk[n + uoff<C>(i)] * dt;
+                    else {
+                        const double vm = Bp[2 * P + i] + (Bk[n + uoff<C>(i)] * dt) * 0.5;
+                        xn = Bp[a] + vm * Ck[(blkk == 0 ? 5 : (blkk == 1 ? 6 : 4)) * P + i];    // dt cos th / dt sin th / dt sin(beta)/lr
+                    }
                 } else {
                     const int blkk = a / P, i = a % P;
                     if (blkk <= 1) {
@@ -571,13 +743,16 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             if (RECS) G.rec[(size_t)k * R::LEN + R::RX + e] = r;               // rx | ru | rd are contiguous: coalesced
             if (MODE == 2) G.res[vrow] = r;
         }
-        const double prea = (k + 1 <= N - 2) ? load_aux(k + 1) : 0.0;
+        double prea[NAP];
+#pragma unroll
+        for (int q = 0; q < NAP; q++) prea[q] = (k + 1 <= N - 2) ? load_aux(k + 1, lane + q * WAVE) : 0.0;
         // rotate the window
 #pragma unroll
         for (int q = 0; q < NPASS; q++) { const int e = lane + q * WAVE; if (e < b) L.blk[s3][e] = pre[q]; }
         if (lane < n + m) L.zr[a0 ^ 1][lane] = prer;
         __syncthreads();                 // everyone is done with aux[a0] (coefficients of knot k) before it is refilled
-        if (lane < AUX) L.aux[a0][lane] = prea;
+#pragma unroll
+        for (int q = 0; q < NAP; q++) { const int t = lane + q * WAVE; if (t < AUX) L.aux[a0][t] = prea[q]; }
         __syncthreads();
     }
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
@@ -612,10 +787,10 @@ __device__ __forceinline__ double delta_step(const Params& pr, const double* dz,
 template <class C>
 __device__ __forceinline__ double pairblock(const double* Hh, int i, int r, int c) {
     constexpr int P = C::P;
-    if (P == 1) return 0.0;
+    if (!C::POS) return 0.0;
     const int jr = r % P, ar = r / P, jc = c % P, ac = c / P, hidx = ar + ac;
     double e = 0.0;
-    if (jr == i && jc == i) { for (int j = 0; j < P; j++) if (j != i) e += Hh[pairq<C>(i, j) * 3 + hidx]; }
+    if (jr == i && jc == i) e = Hh[3 * C::NPAIR + 3 * i + hidx];          // Hd_i = sum_j Hh(i,j) (+ wall / circle terms)
     else if (jr == i) e = -Hh[pairq<C>(i, jc) * 3 + hidx];
     else if (jc == i) e = -Hh[pairq<C>(i, jr) * 3 + hidx];
     else if (jr == jc) e = Hh[pairq<C>(i, jr) * 3 + hidx];
@@ -626,7 +801,7 @@ template <class C>
 __device__ __forceinline__ double qhat_entry(const double* qd, const double* Hh, int i, int r, int c, double w, double reg) {
     double e = 0.0;
     if (r == c) { e = reg; if (r % C::P == i) e += w * qd[i * C::ni + r / C::P]; }
-    if (C::P > 1 && r < 2 * C::P && c < 2 * C::P) e += pairblock<C>(Hh, i, r, c);
+    if (C::POS && r < 2 * C::P && c < 2 * C::P) e += pairblock<C>(Hh, i, r, c);
     return e;
 }
 
@@ -679,12 +854,18 @@ __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
 }
 // Sparse pattern (<= 3 entries) of column `idx` of the n x (m + n) matrix [B_k | A_k]  (idx < m: B column, else A column)
 template <class C>
-__device__ __forceinline__ void col_pattern(const double* coef, double dt, int idx, bool useA, int (&rows)[3], double (&vals)[3]) {
+__device__ __forceinline__ void col_pattern(const double* coef, double dt, int idx, bool useA, int (&rows)[C::NPAT], double (&vals)[C::NPAT]) {
     constexpr int m = C::m, P = C::P;
-    rows[0] = rows[1] = rows[2] = 0; vals[0] = vals[1] = vals[2] = 0.0;
+#pragma unroll
+    for (int t = 0; t < C::NPAT; t++) { rows[t] = 0; vals[t] = 0.0; }
     if (idx < m) {
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { rows[0] = idx; vals[0] = 0.5 * dt * dt; rows[1] = idx + m; vals[1] = dt; }
-        else {
+        else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+            const int i = idx % P, kind = idx / P;
+            rows[0] = i; rows[1] = P + i; rows[2] = 3 * P + i;
+            if (kind == 0) { vals[0] = 0.5 * dt * coef[5 * P + i]; vals[1] = 0.5 * dt * coef[6 * P + i]; vals[2] = 0.5 * dt * coef[4 * P + i]; rows[3] = 2 * P + i; vals[3] = dt; }
+            else { vals[0] = coef[7 * P + i]; vals[1] = coef[8 * P + i]; vals[2] = coef[9 * P + i]; }
+        } else {
             const int i = idx % P, kind = idx / P;
             rows[0] = i; rows[1] = P + i; rows[2] = (2 + kind) * P + i;
             vals[0] = 0.5 * dt * coef[kind * P + i]; vals[1] = 0.5 * dt * coef[(2 + kind) * P + i]; vals[2] = dt;
@@ -693,7 +874,11 @@ __device__ __forceinline__ void col_pattern(const double* coef, double dt, int i
         const int c = idx - m;
         rows[0] = c; vals[0] = 1.0;
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { if (c >= m) { rows[1] = c - m; vals[1] = dt; } }
-        else {
+        else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+            const int blk = c / P, i = c % P;
+            if (blk == 2) { rows[1] = i; vals[1] = coef[1 * P + i]; rows[2] = P + i; vals[2] = coef[3 * P + i]; rows[3] = 3 * P + i; vals[3] = coef[4 * P + i]; }
+            else if (blk == 3) { rows[1] = i; vals[1] = coef[0 * P + i]; rows[2] = P + i; vals[2] = coef[2 * P + i]; }
+        } else {
             const int blk = c / P, i = c % P;
             if (blk >= 2) { rows[1] = i; vals[1] = coef[(blk - 2) * P + i]; rows[2] = P + i; vals[2] = coef[blk * P + i]; }
         }
@@ -713,7 +898,7 @@ struct HxMap {
         for (int q = 0; q < SLOTS; q++) {
             const int t = lane + q * WAVE;
             int so = R::HH; double sg = 0.0;
-            if (P > 1 && t < DirLds<C>::NHX) {
+            if (C::POS && t < DirLds<C>::NHX) {
                 const int h = t % 3, jc = (t / 3) % P, jr = (t / (3 * P)) % P, i = t / (3 * P * P);
                 if (jr == i && jc == i) { so = R::HD + 3 * i + h; sg = 1.0; }
                 else if (jr == i) { so = R::HH + 3 * pairq<C>(i, jc) + h; sg = -1.0; }
@@ -724,7 +909,7 @@ struct HxMap {
         }
     }
     __device__ __forceinline__ void expand(int lane, const double* Rc, double* hxt) const {
-        if (C::P == 1) return;
+        if (!C::POS) return;
 #pragma unroll
         for (int q = 0; q < SLOTS; q++) { const int t = lane + q * WAVE; if (t < DirLds<C>::NHX) hxt[t] = sgn[q] * Rc[src[q]]; }
     }
@@ -755,7 +940,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
         const int row = lq + 4 * r4;
-        rowok[r4] = row < n; diag[r4] = rowok[r4] && row == lrow; inb[r4] = P > 1 && row < 2 * P && colB;
+        rowok[r4] = row < n; diag[r4] = rowok[r4] && row == lrow; inb[r4] = C::POS && row < 2 * P && colB;
         hxo[r4] = inb[r4] ? ((row % P) * P + lrow % P) * 3 + row / P + lrow / P : 0;
     }
     __syncthreads();
@@ -798,7 +983,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 for (int r4 = 0; r4 < 4; r4++) {
                     const int row = lq + 4 * r4;
                     double v = diag[r4] ? reg + w * L.qdf[i * n + row] : 0.0;
-                    if (P > 1) { const double hv = L.hx[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
+                    if constexpr (C::EXT) { const double qv = Rc[R::RQ + i * n + (rowok[r4] ? row : 0)]; v += diag[r4] ? qv : 0.0; }
+                    if (C::POS) { const double hv = L.hx[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
                     const double rxv = Rc[R::RX + i * n + (rowok[r4] ? row : 0)];
                     v = (colS && rowok[r4]) ? rxv : v;
                     c2[r4] = v;
@@ -856,12 +1042,13 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B,  g = ru + B' (P rd + s)
         double col[m];
         {
-            int rows[3]; double vals[3];
+            int rows[C::NPAT]; double vals[C::NPAT];
             col_pattern<C>(coefk, dt, lane < m + n ? lane : 0, k >= 1, rows, vals);
 #pragma unroll
             for (int c = 0; c < m; c++) {
                 const double* Vc = &L.bw.V[c * n];
                 double v = vals[0] * Vc[rows[0]] + vals[1] * Vc[rows[1]] + vals[2] * Vc[rows[2]];
+                if constexpr (C::NPAT > 3) v += vals[3] * Vc[rows[3]];
                 if (lane == c) v += Rc[R::RHAT + c];
                 if (lane >= m + n) { const double* yi = &L.bw.t[(c % P) * n]; v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
                 if (IBR) {
@@ -935,7 +1122,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
-    const bool cpos = P > 1 && cr_ < 2 * P;
+    const bool cpos = C::POS && cr_ < 2 * P;
     __syncthreads();
     cur = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
@@ -951,7 +1138,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         __syncthreads();
         double acc = 0.0;
         if (lane < P * n && (!IBR || ci_ == ip)) {
-            acc = Rc[R::RX + lane] + (reg + w * L.qdf[lane]) * L.fw.dx[cr_];
+            double qd = reg + w * L.qdf[lane];
+            if constexpr (C::EXT) qd += Rc[R::RQ + lane];
+            acc = Rc[R::RX + lane] + qd * L.fw.dx[cr_];
             if (cpos) {
                 const double* hrow = &L.hx[(ci_ * P + cr_ % P) * P * 3 + cr_ / P];
 #pragma unroll
@@ -990,7 +1179,9 @@ __device__ void jacobian_dense(const Params& pr, const Game& G, double reg, doub
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         for (int e = lane; e < P * n * n; e += WAVE) {
             const int i = e / (n * n), r = (e / n) % n, c = e % n;
-            at(vx<C>(N, i, k) + r, hx<C>(k) + c) = qhat_entry<C>(G.Qd, Rc + R::HH, i, r, c, w, reg);
+            double qv = qhat_entry<C>(G.Qd, Rc + R::HH, i, r, c, w, reg);
+            if constexpr (C::EXT) { if (r == c) qv += Rc[R::RQ + i * n + r]; }
+            at(vx<C>(N, i, k) + r, hx<C>(k) + c) = qv;
         }
         for (int c = lane; c < m; c += WAVE) { const int i = c % P, j = c / P; at(vu<C>(N, i, k) + j, hu<C>(k, i) + j) = Rc[R::RHAT + c]; }
         for (int e = lane; e < n * n; e += WAVE) {
@@ -1153,6 +1344,29 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
             if (isfinite(cv)) { const double lb = G.lam[ci] + o.alpha_dual * G.mu[ci] * cv; G.lam[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
         }
     }
+    if constexpr (C::EXT) {
+        // state constraints of player i: dual_update! with alphax_dual[i] (constraints_methods.jl:421-440)
+        const int e0 = pr.col_len + pr.ctl_len, K = N - 1;
+        for (int e = threadIdx.x; e < pr.sb_len + pr.wall_len + pr.circ_len; e += WAVE) {
+            int i, k; double c;
+            if (e < pr.sb_len) {
+                const int row = e % (2 * n); k = (e / (2 * n)) % K; i = e / (2 * n * K);
+                const double* x = zstate<C>(z, k + 1);
+                c = row < n ? x[row] - ext_sbmax(pr, G.extc)[i * n + row] : ext_sbmin(pr, G.extc)[i * n + row - n] - x[row - n];
+            } else if (e < pr.sb_len + pr.wall_len) {
+                const int e2 = e - pr.sb_len, w = e2 % pr.nwall; k = (e2 / pr.nwall) % K; i = e2 / (pr.nwall * K);
+                const double* x = zstate<C>(z, k + 1); double gx, gy;
+                c = wall_val(ext_walls(pr, G.extc), w, x[i], x[P + i], &gx, &gy);
+            } else {
+                const int e2 = e - pr.sb_len - pr.wall_len, cq = e2 % pr.ncirc; k = (e2 / pr.ncirc) % K; i = e2 / (pr.ncirc * K);
+                const double* x = zstate<C>(z, k + 1); double gx, gy;
+                c = circ_val(ext_circs(pr, G.extc), cq, x[i], x[P + i], &gx, &gy);
+            }
+            const int ci = e0 + e;
+            G.vals[ci] = c;
+            if (isfinite(c)) { const double lb = G.lam[ci] + o.alphax_dual[i] * G.mu[ci] * c; G.lam[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
+        }
+    }
     for (int e = threadIdx.x; e < pr.con_len; e += WAVE) G.mu[e] = fmin(fmax(G.mu[e] * o.rho_increase, 0.0), o.rho_max);
 }
 
@@ -1167,7 +1381,7 @@ __device__ void rollout(const Params& pr, double* z) {
         for (int k = 0; k < pr.N - 1; k++) {
             for (int j = 0; j < C::mi; j++) u[lane + j * P] = z[n + hu<C>(k, lane) + j];
             double xn[C::ni];
-            model_player_rk3<C>(lane, x, u, pr.dt, xn);
+            model_player_rk3<C>(pr, lane, x, u, pr.dt, xn);
             for (int j = 0; j < C::ni; j++) { x[lane + j * P] = xn[j]; z[n + hx<C>(k) + lane + j * P] = xn[j]; }
         }
     }

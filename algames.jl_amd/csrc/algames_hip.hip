@@ -1,6 +1,6 @@
 // algames_hip.hip -- kernels and the C ABI (include/algames_hip.h) of libalgames_hip.so.
 // gfx950 only.  One workgroup (= one wavefront) per game; see algames_device.hpp.
-#include "algames_device.hpp"
+#include "algames_kernels.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -8,142 +8,12 @@
 #include <string>
 #include <vector>
 
-using namespace alg;
-
-// ------------------------------------------------------------------------------------------------
-// Kernels
-// ------------------------------------------------------------------------------------------------
-template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr, Buffers bf, int init, uint64_t game_id0) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g);
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, Buffers bf, int k, int l, alg_step_info* out) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    int ls = 0; double dl = 0.0;
-    inner_iteration<C>(pr, G, L, ls, dl, k, l, out + g, nullptr);
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int which, double reg, double* res_out, double* rn_out) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    ResOut ro;
-    // the proximal term is taken w.r.t. pdtraj (regularize_residual!, global_quantities.jl:67-86)
-    assemble_pass<C, 2>(pr, G, L.a, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, 0.0, ro);
-    __syncthreads();
-    if (res_out) for (int e = threadIdx.x; e < pr.S; e += WAVE) res_out[(size_t)g * pr.S + e] = G.res[e];
-    if (rn_out && threadIdx.x == 0) rn_out[g] = ro.l1 / (double)pr.S;
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, Buffers bf, double reg, double* J) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    ResOut ro;
-    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
-    __syncthreads();
-    jacobian_dense<C>(pr, G, reg, J + (size_t)g * pr.S * pr.S);
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr, Buffers bf, double reg, int* status) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    ResOut ro;
-    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
-    __syncthreads();
-    const int st = newton_direction<C>(pr, G, L.d, reg);
-    if (status && threadIdx.x == 0) status[g] = st;
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_line_search(Params pr, Buffers bf, double reg, const double* rn, double* alpha, int* j) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    double a; int jj;
-    line_search<C>(pr, G, L, reg, rn[g], -1.0, &a, &jj);
-    if (threadIdx.x == 0) { alpha[g] = a; j[g] = jj; }
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_update(Params pr, Buffers bf, int tgt, int src, const double* alpha) {
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    update_traj<C>(pr, G.z[tgt], G.z[src], alpha[g], G.z[2]);
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_record(Params pr, Buffers bf, alg_record* out) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    make_record<C>(pr, G, L, 0.0, 0, 0.0, out + g);
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_dual_update(Params pr, Buffers bf) {
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    dual_penalty_update<C>(pr, G);
-}
+// the EXT instantiations are defined in algames_ext_*.hip
+ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
 
 __global__ void __launch_bounds__(WAVE) k_reset_con(Params pr, Buffers bf) {
     Game G = game_view(pr, bf, blockIdx.x);
     reset_con(pr, G);
-}
-
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_init(Params pr, Buffers bf, uint64_t game_id0, int use_shift, int do_init, int which) {
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    if (do_init) {
-        init_traj<C>(pr, G, G.z[0], game_id0 + (uint64_t)g, use_shift != 0);
-        if (threadIdx.x < C::n) G.z[1][threadIdx.x] = G.x0[threadIdx.x];
-        __syncthreads();
-        rollout<C>(pr, G.z[0]);
-    } else {
-        rollout<C>(pr, G.z[which]);
-    }
-}
-
-// mode 0: ibr_newton_solve!(prob, player) on the stored trajectory ; mode 1: ibr_newton_solve!(prob; ibr_opts)
-template <class C>
-__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, Buffers bf, int mode, int player, int init, uint64_t game_id0,
-                                                      int ibr_iter, IbrOrder order, double delta_min) {
-    __shared__ Lds<C> L;
-    const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    if (mode == 0) ibr_solve_player<C>(pr, G, L, player);
-    else ibr_newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g, ibr_iter, order, delta_min);
-}
-
-// builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
-template <class C>
-__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    Game G = game_view(pr, bf, g);
-    if (lane < C::P) {
-        double x[C::n], u[C::m], xo[C::ni], co[4];
-        for (int j = 0; j < C::ni; j++) x[lane + j * C::P] = G.z[0][lane + j * C::P];
-        for (int j = 0; j < C::mi; j++) u[lane + j * C::P] = G.z[0][C::n + hu<C>(0, lane) + j];
-        model_player<C>(lane, x, u, pr.dt, xo, co);
-        for (int j = 0; j < C::ni; j++) {
-            const int a = lane + j * C::P;
-            bf.x0[(size_t)g * C::n + a] = xo[j]; G.z[0][a] = xo[j]; G.z[1][a] = xo[j];
-        }
-    }
-    if (lane == 0) { bf.mpc[2 * g] += G.st->newton_iters; bf.mpc[2 * g + 1] += G.st->converged; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -167,8 +37,9 @@ bool fill_dims(const alg_desc& a, Params& p) {
     if (a.model == ALG_MODEL_DOUBLE_INTEGRATOR) {
         p.d = a.d; if (p.d < 1 || p.d > 3) return false;
         p.n = 2 * p.d * p.p; p.m = p.d * p.p; p.mi = p.d; p.ni = 2 * p.d;
-    } else if (a.model == ALG_MODEL_UNICYCLE) {
+    } else if (a.model == ALG_MODEL_UNICYCLE || a.model == ALG_MODEL_BICYCLE) {
         p.d = 2; p.n = 4 * p.p; p.m = 2 * p.p; p.mi = 2; p.ni = 4;
+        p.lf = p.lr = 0.05;                                              // BicycleGame defaults, bicycle.jl:15
     } else return false;
     p.S = p.n * p.p * (p.N - 1) + p.m * (p.N - 1) + p.n * (p.N - 1);     // problem_size.jl:22
     p.b = p.n + p.m + p.p * p.n;
@@ -177,30 +48,27 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.col_len = p.npair * (p.N - 1);
     p.ctl_len = 2 * p.m * (p.N - 1);
     p.con_len = p.col_len + p.ctl_len;
+    p.ext = (a.model == ALG_MODEL_BICYCLE) ? 1 : 0;                      // the bicycle kernels are EXT instantiations
     p.hist_max = HIST_MAX;
     p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
-    {   // Rec<C>::LEN
-        const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : 0;
-        p.rec_len = (p.N - 1) * (nc + 3 * p.npair + 3 * p.p + p.m + p.p * p.n + p.m + p.n + 2 * p.p * p.p);
+    {   // Rec<C>::LEN of the EXT instantiation (the base one is p n shorter; the buffer is sized for either)
+        const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : 0;
+        p.rec_len = (p.N - 1) * (nc + 3 * p.npair + 3 * p.p + p.m + 2 * p.p * p.n + p.m + p.n + 2 * p.p * p.p);
     }
     return true;
 }
+void recount_con(Params& p) {
+    p.sb_len = p.has_sb ? p.p * 2 * p.n * (p.N - 1) : 0;
+    p.wall_len = p.p * p.nwall * (p.N - 1);
+    p.circ_len = p.p * p.ncirc * (p.N - 1);
+    p.con_len = p.col_len + p.ctl_len + p.sb_len + p.wall_len + p.circ_len;
+}
 
-// supported template instantiations: (model, p, d)
-#define ALG_FOR_EACH_CFG(X)                                   \
-    X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2)                       \
-    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2)                       \
-    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2)                       \
-    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2)                       \
-    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3)                       \
-    X(ALG_MODEL_UNICYCLE, 1, 2)                                \
-    X(ALG_MODEL_UNICYCLE, 2, 2)                                \
-    X(ALG_MODEL_UNICYCLE, 3, 2)                                \
-    X(ALG_MODEL_UNICYCLE, 4, 2)
-
-bool cfg_supported(const Params& p) {
-#define X(M, P, D) if (p.model == (M) && p.p == (P) && p.d == (D)) return true;
-    ALG_FOR_EACH_CFG(X)
+// supported template instantiations: ALG_CFGS_BASE / ALG_CFGS_EXT (algames_kernels.hpp)
+bool cfg_supported(const Params& p, int ext) {
+#define X(M, P, D, E) if (p.model == (M) && p.p == (P) && p.d == (D) && ext == (E)) return true;
+    ALG_CFGS_BASE(X)
+    ALG_CFGS_EXT(X)
 #undef X
     return false;
 }
@@ -220,6 +88,7 @@ struct Handle {
     alg_step_info* d_info = nullptr;
     alg_record* d_rec = nullptr;
     double* d_lqr[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<double> extc;     // host copy of bf.extc
 };
 
 constexpr size_t GUARD = 4096;     // guard zone behind every device buffer (checked by alg_debug_check_guards)
@@ -265,21 +134,33 @@ int launch_check(const char* what) {
         if (rc_ != ALG_OK) return rc_;                                                          \
     } while (0)
 
-#define LAUNCH_ONE_(M, P, D, kernel, ...)                                                       \
-    if (!done_ && pr_.model == (M) && pr_.p == (P) && pr_.d == (D)) {                           \
-        hipLaunchKernelGGL((kernel<Cfg<M, P, D>>), dim3(pr_.B), dim3(WAVE), 0, H->stream, __VA_ARGS__); \
+#define LAUNCH_ONE_(M, P, D, E, kernel, ...)                                                    \
+    if (!done_ && pr_.model == (M) && pr_.p == (P) && pr_.d == (D) && pr_.ext == (E)) {         \
+        hipLaunchKernelGGL((kernel<Cfg<M, P, D, E>>), dim3(pr_.B), dim3(WAVE), 0, H->stream, __VA_ARGS__); \
         done_ = true;                                                                           \
     }
-#define LAUNCH_CASES_(kernel, ...)                                       \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, kernel, __VA_ARGS__)  \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, kernel, __VA_ARGS__)  \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, kernel, __VA_ARGS__)  \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, kernel, __VA_ARGS__)  \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, kernel, __VA_ARGS__)  \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 1, 2, kernel, __VA_ARGS__)           \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 2, 2, kernel, __VA_ARGS__)           \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 3, 2, kernel, __VA_ARGS__)           \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 4, 2, kernel, __VA_ARGS__)
+#define LAUNCH_CASES_(kernel, ...)                                                  \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 1, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 2, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 3, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 4, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 1, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 2, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 3, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 4, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 1, 2, 1, kernel, __VA_ARGS__)                    \
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 2, 2, 1, kernel, __VA_ARGS__)                    \
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 3, 2, 1, kernel, __VA_ARGS__)                    \
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 4, 2, 1, kernel, __VA_ARGS__)
 
 int alloc_all(Handle* hd) {
     int rc;
@@ -296,6 +177,8 @@ int alloc_all(Handle* hd) {
     if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max, "bf.hist"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.mpc, 2 * B, "bf.mpc"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.tcache, 8 * B, "bf.tcache"))) return rc;
+    hd->extc.assign(2 * (size_t)p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES, 0.0);
+    if ((rc = dalloc(hd, &hd->bf.extc, hd->extc.size(), "bf.extc"))) return rc;
     if ((rc = dalloc(hd, &hd->d_tmp, 2 * B, "d_tmp"))) return rc;
     if ((rc = dalloc(hd, &hd->d_itmp, B, "d_itmp"))) return rc;
     if ((rc = dalloc(hd, &hd->d_info, B, "d_info"))) return rc;
@@ -310,6 +193,15 @@ int alloc_all(Handle* hd) {
 }
 
 int sync(Handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); return ALG_OK; }
+
+void dfree(Handle* h, void* q) {
+    for (size_t i = 0; i < h->allocs.size(); i++)
+        if (h->allocs[i] == q) {
+            hipFree(q);
+            h->allocs.erase(h->allocs.begin() + i); h->alloc_bytes.erase(h->alloc_bytes.begin() + i); h->alloc_names.erase(h->alloc_names.begin() + i);
+            return;
+        }
+}
 
 } // namespace
 
@@ -338,7 +230,7 @@ int alg_create(const alg_desc* d, alg_handle** out) {
     if (!d || !out) return fail(ALG_ERR_ARG, "alg_create: null argument");
     Handle* hd = new Handle();
     if (!fill_dims(*d, hd->pr) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "alg_create: unsupported descriptor"); }
-    if (!cfg_supported(hd->pr)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2 p<=4, d=3 p=2; Unicycle p<=4)"); }
+    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2 p<=4, d=3 p=2; Unicycle p<=4; Bicycle p<=4)"); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete hd; return fail(ALG_ERR_DEVICE, "alg_create: no HIP device available (this library has no CPU fallback)"); }
     if (d->device < 0 || d->device >= ndev) { delete hd; return fail(ALG_ERR_ARG, "alg_create: bad device ordinal"); }
@@ -432,6 +324,67 @@ int alg_add_control_bound(alg_handle* h, const double* umax, const double* umin)
         }
     }
     p.has_ctl = 1; return ALG_OK;
+}
+
+// ---- extended ingredient set (examples/intro_example.jl): switches the handle to the EXT kernel instantiation ----------
+static int ext_commit(Handle* hd) {
+    // the constraint vectors grew: re-create lam / mu / vals (mu = rho_0, lam = 0 like a freshly built ALConVal) and push the constants
+    int rc = use_device(hd); if (rc) return rc;
+    if ((rc = sync(hd))) return rc;
+    Params& p = hd->pr;
+    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2, Unicycle, Bicycle; p<=4)");
+    p.ext = 1;
+    recount_con(p);
+    dfree(hd, hd->bf.lam); dfree(hd, hd->bf.mu); dfree(hd, hd->bf.vals);
+    const size_t B = p.B;
+    if ((rc = dalloc(hd, &hd->bf.lam, B * p.con_len, "bf.lam"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.mu, B * p.con_len, "bf.mu"))) return rc;
+    if ((rc = dalloc(hd, &hd->bf.vals, B * p.con_len, "bf.vals"))) return rc;
+    if ((rc = h2d(hd, hd->bf.extc, hd->extc.data(), sizeof(double) * hd->extc.size()))) return rc;
+    hipLaunchKernelGGL(k_reset_con, dim3(p.B), dim3(WAVE), 0, hd->stream, hd->pr, hd->bf);
+    if ((rc = launch_check("k_reset_con"))) return rc;
+    return sync(hd);
+}
+int alg_set_bicycle(alg_handle* h, double lf, double lr) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_set_bicycle: null handle");
+    if (H->pr.model != ALG_MODEL_BICYCLE) return fail(ALG_ERR_ARG, "alg_set_bicycle: not a bicycle model");
+    if (!(lr > 0) || !(lf >= 0)) return fail(ALG_ERR_ARG, "alg_set_bicycle: bad lengths");
+    H->pr.lf = lf; H->pr.lr = lr; return ALG_OK;
+}
+int alg_add_state_bound(alg_handle* h, int32_t player, const double* xmax, const double* xmin) {
+    if (!h || !xmax || !xmin) return fail(ALG_ERR_ARG, "alg_add_state_bound: null argument");
+    Params& p = H->pr;
+    if (player < 0 || player >= p.p) return fail(ALG_ERR_ARG, "alg_add_state_bound: bad player index");
+    for (int a = 0; a < p.n; a++) if (!(xmax[a] >= xmin[a])) return fail(ALG_ERR_ARG, "Upper bounds must be greater than or equal to lower bounds");
+    double* mx = H->extc.data(); double* mn = mx + p.p * p.n;
+    if (!p.has_sb) for (int e = 0; e < p.p * p.n; e++) { mx[e] = INFINITY; mn[e] = -INFINITY; }
+    for (int a = 0; a < p.n; a++) { mx[player * p.n + a] = xmax[a]; mn[player * p.n + a] = xmin[a]; }
+    p.has_sb = 1;
+    return ext_commit(H);
+}
+int alg_add_wall_constraint(alg_handle* h, int32_t nw, const double* x1, const double* y1, const double* x2, const double* y2, const double* xv, const double* yv) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_wall_constraint: null handle");
+    if (nw < 0 || nw > ALG_MAX_WALLS || (nw > 0 && (!x1 || !y1 || !x2 || !y2 || !xv || !yv))) return fail(ALG_ERR_ARG, "alg_add_wall_constraint: bad argument (at most ALG_MAX_WALLS walls)");
+    Params& p = H->pr;
+    double* W = H->extc.data() + 2 * p.p * p.n;
+    const double* src[6] = {x1, y1, x2, y2, xv, yv};
+    for (int f = 0; f < 6; f++) for (int w = 0; w < nw; w++) W[f * ALG_MAX_WALLS + w] = src[f][w];
+    p.nwall = nw;
+    return ext_commit(H);
+}
+int alg_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const double* yc, const double* rad) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_circle_constraint: null handle");
+    if (nc < 0 || nc > ALG_MAX_CIRCLES || (nc > 0 && (!xc || !yc || !rad))) return fail(ALG_ERR_ARG, "alg_add_circle_constraint: bad argument (at most ALG_MAX_CIRCLES circles)");
+    Params& p = H->pr;
+    double* Cc = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS;
+    const double* src[3] = {xc, yc, rad};
+    for (int f = 0; f < 3; f++) for (int c = 0; c < nc; c++) Cc[f * ALG_MAX_CIRCLES + c] = src[f][c];
+    p.ncirc = nc;
+    return ext_commit(H);
+}
+int alg_get_con_len(alg_handle* h, int32_t* n) {
+    if (!h || !n) return fail(ALG_ERR_ARG, "alg_get_con_len: null argument");
+    *n = H->pr.con_len; return ALG_OK;
 }
 
 int alg_set_traj(alg_handle* h, int32_t which, const double* z) {

@@ -1,0 +1,185 @@
+// algames_kernels.hpp -- the __global__ entry points (one workgroup = one wavefront = one game) and the list of compiled
+// (model, p, d, ext) instantiations.  The base instantiations live in algames_hip.hip; the EXT ones (bicycle model, state
+// bounds, walls, circles) are explicitly instantiated in algames_ext_*.hip so that the translation units build in parallel.
+#pragma once
+#include "algames_device.hpp"
+
+using namespace alg;
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr, Buffers bf, int init, uint64_t game_id0) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, Buffers bf, int k, int l, alg_step_info* out) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    int ls = 0; double dl = 0.0;
+    inner_iteration<C>(pr, G, L, ls, dl, k, l, out + g, nullptr);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int which, double reg, double* res_out, double* rn_out) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    ResOut ro;
+    // the proximal term is taken w.r.t. pdtraj (regularize_residual!, global_quantities.jl:67-86)
+    assemble_pass<C, 2>(pr, G, L.a, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, 0.0, ro);
+    __syncthreads();
+    if (res_out) for (int e = threadIdx.x; e < pr.S; e += WAVE) res_out[(size_t)g * pr.S + e] = G.res[e];
+    if (rn_out && threadIdx.x == 0) rn_out[g] = ro.l1 / (double)pr.S;
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, Buffers bf, double reg, double* J) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    ResOut ro;
+    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
+    __syncthreads();
+    jacobian_dense<C>(pr, G, reg, J + (size_t)g * pr.S * pr.S);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr, Buffers bf, double reg, int* status) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    ResOut ro;
+    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
+    __syncthreads();
+    const int st = newton_direction<C>(pr, G, L.d, reg);
+    if (status && threadIdx.x == 0) status[g] = st;
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_line_search(Params pr, Buffers bf, double reg, const double* rn, double* alpha, int* j) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    double a; int jj;
+    line_search<C>(pr, G, L, reg, rn[g], -1.0, &a, &jj);
+    if (threadIdx.x == 0) { alpha[g] = a; j[g] = jj; }
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_update(Params pr, Buffers bf, int tgt, int src, const double* alpha) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    update_traj<C>(pr, G.z[tgt], G.z[src], alpha[g], G.z[2]);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_record(Params pr, Buffers bf, alg_record* out) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    make_record<C>(pr, G, L, 0.0, 0, 0.0, out + g);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_dual_update(Params pr, Buffers bf) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    dual_penalty_update<C>(pr, G);
+}
+
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_init(Params pr, Buffers bf, uint64_t game_id0, int use_shift, int do_init, int which) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    if (do_init) {
+        init_traj<C>(pr, G, G.z[0], game_id0 + (uint64_t)g, use_shift != 0);
+        if (threadIdx.x < C::n) G.z[1][threadIdx.x] = G.x0[threadIdx.x];
+        __syncthreads();
+        rollout<C>(pr, G.z[0]);
+    } else {
+        rollout<C>(pr, G.z[which]);
+    }
+}
+
+// mode 0: ibr_newton_solve!(prob, player) on the stored trajectory ; mode 1: ibr_newton_solve!(prob; ibr_opts)
+template <class C>
+__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, Buffers bf, int mode, int player, int init, uint64_t game_id0,
+                                                      int ibr_iter, IbrOrder order, double delta_min) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    if (mode == 0) ibr_solve_player<C>(pr, G, L, player);
+    else ibr_newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g, ibr_iter, order, delta_min);
+}
+
+// builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    Game G = game_view(pr, bf, g);
+    if (lane < C::P) {
+        double x[C::n], u[C::m], xo[C::ni], co[4];
+        for (int j = 0; j < C::ni; j++) x[lane + j * C::P] = G.z[0][lane + j * C::P];
+        for (int j = 0; j < C::mi; j++) u[lane + j * C::P] = G.z[0][C::n + hu<C>(0, lane) + j];
+        model_player<C>(pr, lane, x, u, pr.dt, xo, co);
+        for (int j = 0; j < C::ni; j++) {
+            const int a = lane + j * C::P;
+            bf.x0[(size_t)g * C::n + a] = xo[j]; G.z[0][a] = xo[j]; G.z[1][a] = xo[j];
+        }
+    }
+    if (lane == 0) { bf.mpc[2 * g] += G.st->newton_iters; bf.mpc[2 * g + 1] += G.st->converged; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Instantiation lists: X(model, p, d, ext)
+// ------------------------------------------------------------------------------------------------
+#define ALG_CFGS_BASE(X)                                    \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, 0)                  \
+    X(ALG_MODEL_UNICYCLE, 1, 2, 0)                           \
+    X(ALG_MODEL_UNICYCLE, 2, 2, 0)                           \
+    X(ALG_MODEL_UNICYCLE, 3, 2, 0)                           \
+    X(ALG_MODEL_UNICYCLE, 4, 2, 0)
+#define ALG_CFGS_EXT_DI(X)                                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 1)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 1)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 1)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, 1)
+#define ALG_CFGS_EXT_UNI(X)                                 \
+    X(ALG_MODEL_UNICYCLE, 1, 2, 1)                           \
+    X(ALG_MODEL_UNICYCLE, 2, 2, 1)                           \
+    X(ALG_MODEL_UNICYCLE, 3, 2, 1)                           \
+    X(ALG_MODEL_UNICYCLE, 4, 2, 1)
+#define ALG_CFGS_EXT_BIC(X)                                 \
+    X(ALG_MODEL_BICYCLE, 1, 2, 1)                            \
+    X(ALG_MODEL_BICYCLE, 2, 2, 1)                            \
+    X(ALG_MODEL_BICYCLE, 3, 2, 1)                            \
+    X(ALG_MODEL_BICYCLE, 4, 2, 1)
+#define ALG_CFGS_EXT(X) ALG_CFGS_EXT_DI(X) ALG_CFGS_EXT_UNI(X) ALG_CFGS_EXT_BIC(X)
+
+// every kernel of one instantiation; PREFIX is `template` (definition) or `extern template` (declaration)
+#define ALG_INSTANTIATE_KERNELS(PREFIX, M, P, D, E)                                                                        \
+    PREFIX __global__ void k_newton_solve<Cfg<M, P, D, E>>(Params, Buffers, int, uint64_t);                                \
+    PREFIX __global__ void k_newton_step<Cfg<M, P, D, E>>(Params, Buffers, int, int, alg_step_info*);                      \
+    PREFIX __global__ void k_residual<Cfg<M, P, D, E>>(Params, Buffers, int, double, double*, double*);                    \
+    PREFIX __global__ void k_jacobian<Cfg<M, P, D, E>>(Params, Buffers, double, double*);                                  \
+    PREFIX __global__ void k_direction<Cfg<M, P, D, E>>(Params, Buffers, double, int*);                                    \
+    PREFIX __global__ void k_line_search<Cfg<M, P, D, E>>(Params, Buffers, double, const double*, double*, int*);          \
+    PREFIX __global__ void k_update<Cfg<M, P, D, E>>(Params, Buffers, int, int, const double*);                            \
+    PREFIX __global__ void k_record<Cfg<M, P, D, E>>(Params, Buffers, alg_record*);                                        \
+    PREFIX __global__ void k_dual_update<Cfg<M, P, D, E>>(Params, Buffers);                                                \
+    PREFIX __global__ void k_init<Cfg<M, P, D, E>>(Params, Buffers, uint64_t, int, int, int);                              \
+    PREFIX __global__ void k_ibr<Cfg<M, P, D, E>>(Params, Buffers, int, int, int, uint64_t, int, IbrOrder, double);        \
+    PREFIX __global__ void k_mpc_advance<Cfg<M, P, D, E>>(Params, Buffers);
+#define ALG_DEFINE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(template, M, P, D, E)
+#define ALG_DECLARE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(extern template, M, P, D, E)

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import (ALG_MODEL_DOUBLE_INTEGRATOR, ALG_MODEL_UNICYCLE, ALG_TRAJ_PD, ALG_TRAJ_TRIAL,
+from ._abi import (ALG_MODEL_BICYCLE, ALG_MODEL_DOUBLE_INTEGRATOR, ALG_MODEL_UNICYCLE, ALG_TRAJ_PD, ALG_TRAJ_TRIAL,
                    ALG_TRAJ_DELTA, AlgamesError, Batch, CLib)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -60,6 +60,21 @@ class UnicycleGame(AbstractGameModel):
 
     def __init__(self, p=2):
         self.p, self.d = p, 2
+        self.n, self.m = 4 * p, 2 * p
+        self.pu = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
+        self.px = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
+        self.pz = [[i + (j - 1) * p for j in range(1, 5)] for i in range(1, p + 1)]
+        self.ni = [4] * p
+        self.mi = [2] * p
+
+
+class BicycleGame(AbstractGameModel):
+    """BicycleGame(p; lf, lr), src/dynamics/bicycle.jl:2-27: X = [x, y, v, psi], U = [a, delta]."""
+    model_id = ALG_MODEL_BICYCLE
+
+    def __init__(self, p=2, lf=0.05, lr=0.05):
+        self.p, self.d = p, 2
+        self.lf, self.lr = float(lf), float(lr)
         self.n, self.m = 4 * p, 2 * p
         self.pu = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
         self.px = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
@@ -263,6 +278,9 @@ class GameConstraintValues:
         self.collision_radius = None     # per player, pair radius = r_i + r_j
         self.u_max = None
         self.u_min = None
+        self.state_bounds = {}           # player (1-based) -> (x_max, x_min) on the joint state
+        self.walls = None
+        self.circles = None
 
 
 def add_collision_avoidance(game_con, radius):
@@ -285,6 +303,46 @@ def add_control_bound(game_con, u_max, u_min):
     if game_con.u_max is not None:
         raise AlgamesError("only one control-bound set per GameConstraintValues is supported")
     game_con.u_max, game_con.u_min = u_max, u_min
+
+
+def add_state_bound(game_con, i, x_max, x_min):
+    """add_state_bound!(game_con, i, x_max, x_min), constraints_methods.jl:87-98 (player i is 1-based; bounds on the
+    joint state, +-inf allowed)."""
+    n, p = game_con.probsize.n, game_con.probsize.p
+    x_max = np.asarray(x_max, dtype=np.float64); x_min = np.asarray(x_min, dtype=np.float64)
+    if x_max.shape != (n,) or x_min.shape != (n,):
+        raise ValueError("state bounds must have length n")
+    if not (1 <= i <= p):
+        raise ValueError("player index out of range")
+    if not np.all(x_max >= x_min):
+        raise ValueError("Upper bounds must be greater than or equal to lower bounds")
+    if i in game_con.state_bounds:
+        raise AlgamesError("only one state-bound set per player is supported")
+    game_con.state_bounds[i] = (x_max, x_min)
+
+
+class Wall:
+    """Wall(p1, p2, v), constraints_methods.jl:155-159: segment p1-p2, v orthogonal to it pointing into the forbidden half space."""
+
+    def __init__(self, p1, p2, v):
+        self.p1, self.p2, self.v = (np.asarray(a, dtype=np.float64) for a in (p1, p2, v))
+
+
+def add_wall_constraint(game_con, walls):
+    """add_wall_constraint!(game_con, walls), constraints_methods.jl:189-195 (every player)."""
+    if game_con.walls is not None:
+        raise AlgamesError("only one wall set per GameConstraintValues is supported")
+    game_con.walls = list(walls)
+
+
+def add_circle_constraint(game_con, xc, yc, radius):
+    """add_circle_constraint!(game_con, xc, yc, radius), constraints_methods.jl:141-148 (every player)."""
+    xc, yc, radius = (np.asarray(a, dtype=np.float64) for a in (xc, yc, radius))
+    if not (xc.shape == yc.shape == radius.shape and xc.ndim == 1):
+        raise ValueError("xc, yc, radius must be vectors of equal length")
+    if game_con.circles is not None:
+        raise AlgamesError("only one circle set per GameConstraintValues is supported")
+    game_con.circles = (xc, yc, radius)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -328,6 +386,8 @@ class GameProblem:
         self.game_id0 = game_id0
         lib = backend if backend is not None else hip_lib()
         self.batch = Batch(lib, model.model_id, model.p, N, dt, self.B, d=model.d, device=device)
+        if isinstance(model, BicycleGame):
+            self.batch.set_bicycle(model.lf, model.lr)
         self.batch.set_x0(self.x0)
         self.batch.set_lqr(game_obj.Qdiag, game_obj.Rdiag, game_obj.xf, game_obj.uf)
         if game_obj.collision_radius is not None:
@@ -336,6 +396,14 @@ class GameProblem:
             self.batch.add_collision_avoidance(game_con.collision_radius)
         if game_con.u_max is not None:
             self.batch.add_control_bound(game_con.u_max, game_con.u_min)
+        for i in sorted(game_con.state_bounds):
+            self.batch.add_state_bound(i - 1, *game_con.state_bounds[i])
+        if game_con.walls:
+            w = game_con.walls
+            self.batch.add_wall_constraint([a.p1[0] for a in w], [a.p1[1] for a in w], [a.p2[0] for a in w],
+                                           [a.p2[1] for a in w], [a.v[0] for a in w], [a.v[1] for a in w])
+        if game_con.circles is not None:
+            self.batch.add_circle_constraint(*game_con.circles)
         self.stats = None
         self._sync_options()       # set_constraint_params!(game_con, opts), problem.jl:49
 

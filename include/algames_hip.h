@@ -33,6 +33,10 @@
  *          [ control bound: for knot k=1..N-1: rows (u-u_max)(m) then (u_min-u)(m) ].
  *          Rows of infinite bounds are kept (the reference drops them,
  *          control_bound_constraint.jl:35-38); they are never active and report value -inf.
+ *          Extended constraints append, in this order and only when added:
+ *          [ state bound: for player i, knot k=2..N: rows (x-x_max)(n) then (x_min-x)(n) ]
+ *          [ wall: for player i, knot k=2..N: one row per wall ] [ circle: for player i, knot k=2..N: one row per circle ]
+ *          alg_get_con_len() returns the current length.
  */
 #ifndef ALGAMES_HIP_H
 #define ALGAMES_HIP_H
@@ -51,6 +55,9 @@ extern "C" {
 /* src/dynamics/double_integrator.jl:13-31, src/dynamics/unicycle.jl:14-32 */
 #define ALG_MODEL_DOUBLE_INTEGRATOR 0
 #define ALG_MODEL_UNICYCLE 1
+#define ALG_MODEL_BICYCLE 2             /* src/dynamics/bicycle.jl:2-41 (lf = lr = 0.05 unless alg_set_bicycle) */
+#define ALG_MAX_WALLS 8
+#define ALG_MAX_CIRCLES 8
 
 /* which trajectory buffer of the problem (problem.jl:27-29) */
 #define ALG_TRAJ_PD 0      /* prob.pdtraj        */
@@ -157,6 +164,20 @@ int alg_add_collision_cost(alg_handle* h, const double* radius /*p*/, const doub
 int alg_add_collision_avoidance(alg_handle* h, const double* radius /*p*/);
 /* add_control_bound!(game_con, u_max, u_min) (constraints_methods.jl:104-115); +-inf allowed */
 int alg_add_control_bound(alg_handle* h, const double* u_max /*m*/, const double* u_min /*m*/);
+
+/* BicycleGame(p; lf, lr) parameters (bicycle.jl:15); only for ALG_MODEL_BICYCLE */
+int alg_set_bicycle(alg_handle* h, double lf, double lr);
+/* add_state_bound!(game_con, i, x_max, x_min) (constraints_methods.jl:86-98; state_bound_constraint.jl): bounds on the joint
+ * state (n each, +-inf allowed) attached to player `player` (0-based), knots 2..N */
+int alg_add_state_bound(alg_handle* h, int32_t player, const double* x_max /*n*/, const double* x_min /*n*/);
+/* add_wall_constraint!(game_con, walls) (constraints_methods.jl:152-195; wall_constraint.jl:30-96): every player, knots 2..N;
+ * wall w: segment (x1,y1)-(x2,y2), normal (xv,yv) pointing into the forbidden half space */
+int alg_add_wall_constraint(alg_handle* h, int32_t n_wall, const double* x1, const double* y1, const double* x2,
+                            const double* y2, const double* xv, const double* yv);
+/* add_circle_constraint!(game_con, xc, yc, radius) (constraints_methods.jl:120-148; TrajOpt CircleConstraint): every player */
+int alg_add_circle_constraint(alg_handle* h, int32_t n_circle, const double* xc, const double* yc, const double* radius);
+/* current length of the constraint dual / penalty / value vectors of one game */
+int alg_get_con_len(alg_handle* h, int32_t* con_len);
 
 /* set_traj!/get_traj! (primal_dual_traj.jl:46-107) over the batch: B x traj_len */
 int alg_set_traj(alg_handle* h, int32_t which, const double* z);

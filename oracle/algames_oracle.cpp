@@ -51,7 +51,8 @@ struct Dims {
     int model = 0, p = 0, d = 0, N = 0;
     int n = 0, m = 0, mi = 0, ni = 0, S = 0, b = 0;
     int traj_len = 0, npair = 0, col_len = 0, ctl_len = 0, con_len = 0;
-    double dt = 0;
+    int nwall = 0, ncirc = 0, has_sb = 0, sb_len = 0, wall_len = 0, circ_len = 0;      // extended constraints
+    double dt = 0, lf = 0.05, lr = 0.05;                                              // BicycleGame(lf, lr), bicycle.jl:15
     // src/struct/problem_size.jl:18-35 ; src/dynamics/double_integrator.jl:13-25 ; unicycle.jl:14-25
     bool init(const alg_desc& a) {
         model = a.model; p = a.p; N = a.N; dt = a.dt;
@@ -59,7 +60,7 @@ struct Dims {
         if (model == ALG_MODEL_DOUBLE_INTEGRATOR) {
             d = a.d; if (d < 1 || d > 3) return false;
             n = 2 * d * p; m = d * p; mi = d; ni = 2 * d;
-        } else if (model == ALG_MODEL_UNICYCLE) {
+        } else if (model == ALG_MODEL_UNICYCLE || model == ALG_MODEL_BICYCLE) {
             d = 2; n = 4 * p; m = 2 * p; mi = 2; ni = 4;
         } else return false;
         S = n * p * (N - 1) + m * (N - 1) + n * (N - 1);   // problem_size.jl:22
@@ -68,9 +69,16 @@ struct Dims {
         npair = p * (p - 1);
         col_len = npair * (N - 1);
         ctl_len = 2 * m * (N - 1);
-        con_len = col_len + ctl_len;
+        recount();
         return true;
     }
+    void recount() {
+        sb_len = has_sb ? p * 2 * n * (N - 1) : 0; wall_len = p * nwall * (N - 1); circ_len = p * ncirc * (N - 1);
+        con_len = col_len + ctl_len + sb_len + wall_len + circ_len;
+    }
+    int o_sb(int i, int k /*knot 1..N-1*/, int row) const { return col_len + ctl_len + (i * (N - 1) + (k - 1)) * 2 * n + row; }
+    int o_wall(int i, int k, int w) const { return col_len + ctl_len + sb_len + (i * (N - 1) + (k - 1)) * nwall + w; }
+    int o_circ(int i, int k, int c) const { return col_len + ctl_len + sb_len + wall_len + (i * (N - 1) + (k - 1)) * ncirc + c; }
     // index sets pu/px/pz = {i + (j-1)p} (double_integrator.jl:18-20), 0-based
     int pu(int i, int j) const { return i + j * p; }
     int pz(int i, int j) const { return i + j * p; }
@@ -102,6 +110,10 @@ inline Dual operator*(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v =
 inline Dual operator*(const Dual& a, double s) { Dual r; r.nd = a.nd; r.v = a.v * s; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * s; return r; }
 inline Dual dcos(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::cos(a.v); double s = -std::sin(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
 inline Dual dsin(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::sin(a.v); double c = std::cos(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = c * a.e[i]; return r; }
+inline Dual dtan(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::tan(a.v); double s = 1.0 + r.v * r.v; for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
+inline Dual datan2(const Dual& y, double x) { Dual r; r.nd = y.nd; r.v = std::atan2(y.v, x); double s = x / (x * x + y.v * y.v); for (int i = 0; i < y.nd; i++) r.e[i] = s * y.e[i]; return r; }
+inline double dtan(double a) { return std::tan(a); }
+inline double datan2(double y, double x) { return std::atan2(y, x); }
 inline double dcos(double a) { return std::cos(a); }
 inline double dsin(double a) { return std::sin(a); }
 
@@ -113,11 +125,22 @@ void dynamics(const Dims& D, const T* x, const T* u, T* xd) {
     if (D.model == ALG_MODEL_DOUBLE_INTEGRATOR) {
         for (int i = 0; i < D.m; i++) xd[i] = x[D.m + i];
         for (int i = 0; i < D.m; i++) xd[D.m + i] = u[i];
-    } else {
+    } else if (D.model == ALG_MODEL_UNICYCLE) {
         const int P = D.p, M = D.m;
         for (int i = 0; i < P; i++) xd[i] = dcos(x[M + i]) * x[M + i + P];
         for (int i = 0; i < P; i++) xd[P + i] = dsin(x[M + i]) * x[M + i + P];
         for (int i = 0; i < M; i++) xd[M + i] = u[i];
+    } else {
+        // BicycleGame (bicycle.jl:28-41): X = [x, y, v, psi] (each block of P), U = [a, delta];
+        // beta = atan(lr tan(delta), lr + lf); Xdot = [v cos(beta+psi), v sin(beta+psi), a, v sin(beta)/lr]
+        const int P = D.p; const double L = D.lr + D.lf;
+        for (int i = 0; i < P; i++) {
+            const T beta = datan2(dtan(u[P + i]) * D.lr, L);
+            xd[i] = x[2 * P + i] * dcos(beta + x[3 * P + i]);
+            xd[P + i] = x[2 * P + i] * dsin(beta + x[3 * P + i]);
+            xd[2 * P + i] = u[i];
+            xd[3 * P + i] = (x[2 * P + i] * dsin(beta)) * (1.0 / D.lr);
+        }
     }
 }
 
@@ -175,6 +198,9 @@ struct Shared {
     std::vector<double> cc_radius, cc_mu;   // collision cost (objective.jl:84-100)
     std::vector<double> ca_radius;          // collision avoidance radii per player
     std::vector<double> umax, umin;         // control bound
+    std::vector<double> sbmax, sbmin;       // state bounds [p][n] (+-inf where absent)
+    std::vector<double> wx1, wy1, wx2, wy2, wxv, wyv;   // walls
+    std::vector<double> cxc, cyc, crad;     // circles
 };
 
 struct Game {
@@ -290,6 +316,44 @@ inline double ctl_val(const Shared& sh, const double* u, int row) {
     const int m = sh.D.m;
     return row < m ? u[row] - sh.umax[row] : sh.umin[row - m] - u[row - m];
 }
+inline double al_active_mu(double c, double lam, double mu);
+// WallConstraint evaluate / jacobian (wall_constraint.jl:68-96): c = ((x-x1) xv + (y-y1) yv) left right, grad = [xv, yv] left right
+inline double wall_val(const Shared& sh, int w, double x, double y, double* gx, double* gy) {
+    const double x1 = sh.wx1[w], y1 = sh.wy1[w], x2 = sh.wx2[w], y2 = sh.wy2[w], xv = sh.wxv[w], yv = sh.wyv[w];
+    const double left = ((x - x1) * (x2 - x1) + (y - y1) * (y2 - y1) > 0) ? 1.0 : 0.0;
+    const double right = ((x - x2) * (x1 - x2) + (y - y2) * (y1 - y2) > 0) ? 1.0 : 0.0;
+    *gx = left * right * xv; *gy = left * right * yv;
+    return ((x - x1) * xv + (y - y1) * yv) * left * right;
+}
+// TrajectoryOptimization 0.4.1 CircleConstraint: c = r^2 - (x-xc)^2 - (y-yc)^2, grad = [-2(x-xc), -2(y-yc)]  [restated; parity unpinned]
+inline double circ_val(const Shared& sh, int c, double x, double y, double* gx, double* gy) {
+    const double dx = x - sh.cxc[c], dy = y - sh.cyc[c];
+    *gx = -2.0 * dx; *gy = -2.0 * dy;
+    return -(dx * dx) - (dy * dy) + sh.crad[c] * sh.crad[c];
+}
+// StateBoundConstraint evaluate (state_bound_constraint.jl:85-87): [x - x_max; x_min - x]
+inline double sb_val(const Shared& sh, int i, const double* x, int row) {
+    const int n = sh.D.n;
+    return row < n ? x[row] - sh.sbmax[i * n + row] : sh.sbmin[i * n + row - n] - x[row - n];
+}
+// Adds the AL gradient (into res rows of player i at knot k) and/or the AL Hessian (through add) of the extended
+// state constraints of player i at knot k (constraint_derivatives.jl:10-19,47-58): all are per-row scalar constraints.
+template <class Add>
+void ext_state_con(const Shared& sh, Game& g, const std::vector<double>& z, int i, int k, double* grad /*n or null*/, Add add) {
+    const Dims& D = sh.D; const double* x = state(D, z, k);
+    auto row = [&](int ci, double c, const int* idx, const double* gv, int cnt) {
+        g.vals[ci] = c;
+        if (!std::isfinite(c)) return;
+        const double am = al_active_mu(c, g.lam[ci], g.mu[ci]);
+        const double w = g.lam[ci] + am * c;
+        for (int a = 0; a < cnt; a++) { if (grad) grad[idx[a]] += gv[a] * w; for (int b2 = 0; b2 < cnt; b2++) if (am != 0.0) add(idx[a], idx[b2], am * gv[a] * gv[b2]); }
+    };
+    if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { int idx[1] = {r % D.n}; double gv[1] = {r < D.n ? 1.0 : -1.0}; row(D.o_sb(i, k, r), sb_val(sh, i, x, r), idx, gv, 1); }
+    const int idx2[2] = {D.px(i, 0), D.px(i, 1)};
+    for (int w = 0; w < D.nwall; w++) { double gv[2]; const double c = wall_val(sh, w, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); row(D.o_wall(i, k, w), c, idx2, gv, 2); }
+    for (int c2 = 0; c2 < D.ncirc; c2++) { double gv[2]; const double c = circ_val(sh, c2, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); row(D.o_circ(i, k, c2), c, idx2, gv, 2); }
+}
+
 // evaluate!(game_con, traj) (constraints_methods.jl:367-379)
 void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
     const Dims& D = sh.D;
@@ -299,6 +363,12 @@ void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
             for (int k = 1; k < D.N; k++) { double dl[2]; g.vals[con_col(D, D.pair(i, j), k)] = colavoid_val(sh, i, j, state(D, z, k), dl); }
     if (sh.has_ctl)
         for (int k = 0; k < D.N - 1; k++) { get_control(D, z, k, u.data()); for (int r = 0; r < 2 * D.m; r++) g.vals[con_ctl(D, k, r)] = ctl_val(sh, u.data(), r); }
+    for (int i = 0; i < D.p; i++) for (int k = 1; k < D.N; k++) {
+        const double* x = state(D, z, k); double gx, gy;
+        if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) g.vals[D.o_sb(i, k, r)] = sb_val(sh, i, x, r);
+        for (int w = 0; w < D.nwall; w++) g.vals[D.o_wall(i, k, w)] = wall_val(sh, w, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
+        for (int c = 0; c < D.ncirc; c++) g.vals[D.o_circ(i, k, c)] = circ_val(sh, c, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
+    }
 }
 // Altro 0.3.0 / TrajOpt cost_expansion!(conval): a = (c >= 0) | (lambda > 0); I_mu = diag(a*mu);
 // grad = C'(lambda + I_mu c); hess = C' I_mu C  [PINNED test/constraints/constraint_derivatives.jl:28-34]
@@ -352,6 +422,8 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
             }
         }
     }
+    if (D.sb_len + D.wall_len + D.circ_len > 0)
+        for (int i = 0; i < p; i++) for (int k = 1; k < N; k++) ext_state_con(sh, g, z, i, k, &res[D.vx(i, k - 1)], [](int, int, double) {});
     if (sh.has_ctl) {
         for (int k = 0; k < N - 1; k++) {
             get_control(D, z, k, u.data());
@@ -428,6 +500,9 @@ void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double re
             }
         }
     }
+    if (D.sb_len + D.wall_len + D.circ_len > 0)
+        for (int i = 0; i < p; i++) for (int k = 1; k < N; k++)
+            ext_state_con(sh, g, z, i, k, nullptr, [&](int a, int c, double v) { add(D.vx(i, k - 1) + a, D.hx(k - 1) + c, v); });
     if (sh.has_ctl) {
         for (int k = 0; k < N - 1; k++) {
             get_control(D, z, k, u.data());
@@ -582,6 +657,7 @@ alg_record record(const Shared& sh, Game& g, double delta, int outer) {
     double cv = 0, sv = 0;
     if (sh.has_ctl) for (int k = 0; k < D.N - 1; k++) for (int r = 0; r < 2 * D.m; r++) cv = std::max(cv, std::max(0.0, g.vals[con_ctl(D, k, r)]));
     if (sh.has_colavoid) for (int q = 0; q < D.npair; q++) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, q, k)]));
+    for (int e = D.col_len + D.ctl_len; e < D.con_len; e++) if (std::isfinite(g.vals[e])) sv = std::max(sv, std::max(0.0, g.vals[e]));
     rc.con_vio = cv; rc.sta_vio = sv;
     // optimality_violation (violations.jl:153-168): max |res| over opt rows
     double ov = 0; const int nopt = D.p * (D.N - 1) * (D.n + D.mi);
@@ -655,6 +731,13 @@ void dual_penalty_update(const Shared& sh, Game& g) {
             const double lb = g.lam[ci] + o.alpha_dual * g.mu[ci] * g.vals[ci];
             g.lam[ci] = std::min(std::max(lb, 0.0), o.lambda_max);
         }
+    for (int e = D.col_len + D.ctl_len; e < D.con_len; e++) {
+        if (!std::isfinite(g.vals[e])) continue;
+        const int e2 = e - D.col_len - D.ctl_len;
+        const int i = e2 < D.sb_len ? e2 / ((D.N - 1) * 2 * D.n) : (e2 < D.sb_len + D.wall_len ? (e2 - D.sb_len) / ((D.N - 1) * D.nwall) : (e2 - D.sb_len - D.wall_len) / ((D.N - 1) * D.ncirc));
+        const double lb = g.lam[e] + o.alphax_dual[i] * g.mu[e] * g.vals[e];
+        g.lam[e] = std::min(std::max(lb, 0.0), o.lambda_max);
+    }
     for (double& v : g.mu) v = std::min(std::max(v * o.rho_increase, 0.0), o.rho_max);
 }
 
@@ -793,6 +876,11 @@ alg_record ibr_record(const Shared& sh, Game& g, double delta, int outer, int i)
     rc.con_vio = cv;
     double sv = 0;                                               // state_violation(game_con, pdtraj, i): player i's convals
     if (sh.has_colavoid) for (int j = 0; j < D.p; j++) if (j != i) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, D.pair(i, j), k)]));
+    for (int k = 1; k < D.N; k++) {
+        if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { double v = g.vals[D.o_sb(i, k, r)]; if (std::isfinite(v)) sv = std::max(sv, std::max(0.0, v)); }
+        for (int w = 0; w < D.nwall; w++) sv = std::max(sv, std::max(0.0, g.vals[D.o_wall(i, k, w)]));
+        for (int c = 0; c < D.ncirc; c++) sv = std::max(sv, std::max(0.0, g.vals[D.o_circ(i, k, c)]));
+    }
     rc.sta_vio = sv;
     double ov = 0;                                               // optimality_violation(core, i)
     for (int k = 0; k < D.N - 1; k++) { for (int a = 0; a < D.n; a++) ov = std::max(ov, std::fabs(g.res[D.vx(i, k) + a])); for (int j = 0; j < D.mi; j++) ov = std::max(ov, std::fabs(g.res[D.vu(i, k) + j])); }
@@ -984,6 +1072,36 @@ int orc_add_control_bound(alg_handle* h, const double* umax, const double* umin)
     for (int i = 0; i < s.D.m; i++) if (!(umax[i] >= umin[i])) return fail(ALG_ERR_ARG, "Upper bounds must be greater than or equal to lower bounds");  // control_bound_constraint.jl:69-75
     s.umax.assign(umax, umax + s.D.m); s.umin.assign(umin, umin + s.D.m); s.has_ctl = true; return ALG_OK;
 }
+static void orc_resize_con(Handle* hd) {
+    hd->sh.D.recount();
+    for (Game& g : hd->g) { g.lam.assign(hd->sh.D.con_len, 0.0); g.mu.assign(hd->sh.D.con_len, hd->sh.opt.rho_0); g.vals.assign(hd->sh.D.con_len, 0.0); }
+}
+int orc_set_bicycle(alg_handle* h, double lf, double lr) {
+    if (H->sh.D.model != ALG_MODEL_BICYCLE) return fail(ALG_ERR_ARG, "orc_set_bicycle: not a bicycle model");
+    if (!(lr > 0) || !(lf >= 0)) return fail(ALG_ERR_ARG, "orc_set_bicycle: bad lengths");
+    H->sh.D.lf = lf; H->sh.D.lr = lr; return ALG_OK;
+}
+int orc_add_state_bound(alg_handle* h, int32_t player, const double* xmax, const double* xmin) {
+    Shared& s = H->sh; const int n = s.D.n, p = s.D.p;
+    if (player < 0 || player >= p || !xmax || !xmin) return fail(ALG_ERR_ARG, "orc_add_state_bound: bad argument");
+    for (int a = 0; a < n; a++) if (!(xmax[a] >= xmin[a])) return fail(ALG_ERR_ARG, "Upper bounds must be greater than or equal to lower bounds");
+    if (!s.D.has_sb) { s.sbmax.assign(p * n, std::numeric_limits<double>::infinity()); s.sbmin.assign(p * n, -std::numeric_limits<double>::infinity()); }
+    for (int a = 0; a < n; a++) { s.sbmax[player * n + a] = xmax[a]; s.sbmin[player * n + a] = xmin[a]; }
+    s.D.has_sb = 1; orc_resize_con(H); return ALG_OK;
+}
+int orc_add_wall_constraint(alg_handle* h, int32_t nw, const double* x1, const double* y1, const double* x2, const double* y2, const double* xv, const double* yv) {
+    Shared& s = H->sh;
+    if (nw < 0 || nw > ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "orc_add_wall_constraint: too many walls");
+    s.wx1.assign(x1, x1 + nw); s.wy1.assign(y1, y1 + nw); s.wx2.assign(x2, x2 + nw); s.wy2.assign(y2, y2 + nw); s.wxv.assign(xv, xv + nw); s.wyv.assign(yv, yv + nw);
+    s.D.nwall = nw; orc_resize_con(H); return ALG_OK;
+}
+int orc_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const double* yc, const double* rad) {
+    Shared& s = H->sh;
+    if (nc < 0 || nc > ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "orc_add_circle_constraint: too many circles");
+    s.cxc.assign(xc, xc + nc); s.cyc.assign(yc, yc + nc); s.crad.assign(rad, rad + nc);
+    s.D.ncirc = nc; orc_resize_con(H); return ALG_OK;
+}
+int orc_get_con_len(alg_handle* h, int32_t* n) { *n = H->sh.D.con_len; return ALG_OK; }
 int orc_set_traj(alg_handle* h, int32_t which, const double* z) {
     if (which < 0 || which > 2) return fail(ALG_ERR_ARG, "bad traj selector");
     const int L = H->sh.D.traj_len;

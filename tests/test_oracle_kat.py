@@ -6,7 +6,7 @@ test/problem/solver_methods.jl are the pinning."""
 import numpy as np
 import pytest
 
-DI, UNI = 0, 1
+DI, UNI, BIC = 0, 1, 2
 
 
 # ---------------------------------------------------------------- layout / indexing (host logic)
@@ -91,6 +91,14 @@ def test_model_index_sets(alg):
     assert u.pu == [[1, 4], [2, 5], [3, 6]]
     assert u.px == [[1, 4], [2, 5], [3, 6]]
     assert u.pz == [[1, 4, 7, 10], [2, 5, 8, 11], [3, 6, 9, 12]]
+    # test/dynamics/bicycle.jl:3-24
+    bm = alg.BicycleGame(p=3, lr=1.0, lf=2.0)
+    assert (bm.lr, bm.lf) == (1.0, 2.0)
+    assert (bm.n, bm.m, bm.p) == (12, 6, 3)
+    assert bm.ni == [4, 4, 4] and bm.mi == [2, 2, 2]
+    assert bm.pu == [[1, 4], [2, 5], [3, 6]]
+    assert bm.px == [[1, 4], [2, 5], [3, 6]]
+    assert bm.pz == [[1, 4, 7, 10], [2, 5, 8, 11], [3, 6, 9, 12]]
     # ProblemSize.S, src/struct/problem_size.jl:22
     assert alg.ProblemSize(40, alg.DoubleIntegratorGame(p=3)).S == 2106
     assert alg.ProblemSize(50, alg.UnicycleGame(p=4)).S == 4312
@@ -175,6 +183,28 @@ def test_dynamics_and_rk2(orc):
     assert np.allclose(x2, x + 0.2 * f(x + 0.1 * f(x)), atol=1e-15)
 
 
+def test_bicycle_dynamics(orc):
+    # src/dynamics/bicycle.jl:28-41 restated independently (lf = lr = 0.05, the BicycleGame defaults)
+    rng = np.random.default_rng(5)
+    b = orc.OracleBatch(BIC, 3, 10, 0.1, 1)
+    x, u = rng.random(b.n), rng.random(b.m) - 0.5
+    lf = lr = 0.05
+
+    def f(xx, uu):
+        beta = np.arctan2(lr * np.tan(uu[3:6]), lr + lf)
+        return np.concatenate([xx[6:9] * np.cos(beta + xx[9:12]), xx[6:9] * np.sin(beta + xx[9:12]), uu[0:3], xx[6:9] * np.sin(beta) / lr])
+    xd, x2, x3, J = b.kat_dynamics(x, u)
+    assert np.allclose(xd, f(x, u), atol=1e-15)
+    assert np.allclose(x2, x + 0.1 * f(x + 0.05 * f(x, u), u), atol=1e-15)
+    k1 = 0.1 * f(x, u); k2 = 0.1 * f(x + k1 / 2, u); k3 = 0.1 * f(x - k1 + 2 * k2, u)
+    assert np.allclose(x3, x + (k1 + 4 * k2 + k3) / 6, atol=1e-15)
+    Jfd = np.zeros_like(J); eps = 1e-6
+    for c in range(b.n + b.m):
+        zp = np.concatenate([x, u]); zm = zp.copy(); zp[c] += eps; zm[c] -= eps
+        Jfd[:, c] = (b.kat_dynamics(zp[:b.n], zp[b.n:])[1] - b.kat_dynamics(zm[:b.n], zm[b.n:])[1]) / (2 * eps)
+    assert np.abs(J - Jfd).sum() < 1e-6
+
+
 # ---------------------------------------------------------------- objective
 def test_lqr_gradient_hessian_scaling(orc):
     # test/objective/objective.jl:11-64: zero cost at (xf, uf) through the pz/pu padding; q=(Qx+q)dt,
@@ -242,6 +272,125 @@ def test_control_bound_evaluate_literal(orc):
     assert np.array_equal(finite, np.array([-1.0, -14.0, 0.0, 0.0, -11.0, 0.0, -4.0, -60.0]))
     with pytest.raises(Exception):              # checkBounds, control_bound_constraint.jl:69-75
         b.add_control_bound(np.zeros(6), np.ones(6))
+
+
+def _ext_off(b):
+    return b.p * (b.p - 1) * (b.N - 1) + 2 * b.m * (b.N - 1)
+
+
+def test_state_bound_evaluate_literal(orc):
+    # test/constraints/state_bound_constraint.jl:3-15 (n = 6 -> one DoubleIntegrator player in d = 3)
+    X6 = np.array([13.0, 1.0, -12.0, 1.0, 2.0, 30.0])
+    x_max = np.array([np.inf, np.inf, -11.0, 15.0, 2.0, 30.0])
+    x_min = np.array([-np.inf, -10.0, -np.inf, 1.0, -2.0, -30.0])
+    b = orc.OracleBatch(DI, 1, 4, 0.1, 1, d=3)
+    b.set_lqr(np.zeros((1, 6)), np.zeros((1, 3)), np.zeros((1, 6)), np.zeros((1, 3)))
+    b.add_state_bound(0, x_max, x_min)
+    assert b.con_len == _ext_off(b) + 12 * (b.N - 1)
+    X, U, L = b.split_traj(b.get_traj())
+    X[0, 1:] = X6
+    b.set_traj(b.join_traj(X, U, L))
+    sb = b.kat_evaluate_con()[0][_ext_off(b):].reshape(b.N - 1, 12)
+    for k in range(b.N - 1):
+        assert np.array_equal(sb[k][np.isfinite(sb[k])], np.array([-1.0, -14.0, 0.0, 0.0, -11.0, 0.0, -4.0, -60.0]))
+    assert np.array_equal(np.nonzero(np.isfinite(sb[0]))[0] + 1, [3, 4, 5, 6, 8, 10, 11, 12])     # con.inds, :16
+    with pytest.raises(Exception):
+        b.add_state_bound(0, np.zeros(6), np.ones(6))
+
+
+def test_wall_evaluate_literal(orc):
+    # test/constraints/wall_constraint.jl:3-18: position (x, y) = (1, 1)
+    s2 = np.sqrt(2.0)
+    x1 = [0.0, 0.0, 1.0, 3.0, -2.0]; y1 = [1.0, -1.0, 2.0, 2.0, 0.0]
+    x2 = [1.0, 1.0, 2.0, 2.0, 0.0]; y2 = [0.0, 0.0, 1.0, 1.0, 0.0]
+    xv = np.array([1.0, 1.0, 1.0, 1.0, 0.0]) / s2; yv = np.array([1.0, -1.0, 1.0, -1.0, s2]) / s2
+    b = orc.OracleBatch(DI, 1, 3, 0.1, 1)
+    b.set_lqr(np.zeros((1, 4)), np.zeros((1, 2)), np.zeros((1, 4)), np.zeros((1, 2)))
+    b.add_wall_constraint(x1, y1, x2, y2, xv, yv)
+    X, U, L = b.split_traj(b.get_traj())
+    X[0, 1:] = [1.0, 1.0, -12.0, 13.0]
+    b.set_traj(b.join_traj(X, U, np.zeros_like(L)))
+    w = b.kat_evaluate_con()[0][_ext_off(b):].reshape(b.N - 1, 5)
+    assert np.abs(w[0] - np.array([s2 / 2, 0.0, -s2 / 2, 0.0, 0.0])).sum() < 1e-10
+    # jacobian (wall_constraint.jl:79-96; test :20-31): opt rows of a pure-constraint problem = C'(lambda + a mu c)
+    lam = np.zeros((1, b.con_len)); mu = np.ones((1, b.con_len))
+    lam[0, _ext_off(b):] = np.tile([0.5, 0.25, 2.0, 1.0, 3.0], b.N - 1)
+    b.set_con_duals(lam, mu)
+    res = b.residual()[0][0]
+    left_right = np.array([1.0, 0.0, 1.0, 0.0, 0.0])           # inside the slab of walls 1 and 3 only
+    wgt = lam[0, _ext_off(b):_ext_off(b) + 5] + 1.0 * w[0]     # a = 1: c >= 0 or lambda > 0 for every row here
+    gx = (left_right * xv * wgt).sum(); gy = (left_right * yv * wgt).sum()
+    assert np.allclose(res[0:4], [gx, gy, 0.0, 0.0], atol=1e-14)
+
+
+def test_circle_and_extended_constraints_fd(orc):
+    # CircleConstraint (TrajectoryOptimization 0.4.1, un-vendored): c = r^2 - (x-xc)^2 - (y-yc)^2 <= 0 keeps the
+    # player outside the disc.  FD check: opt_x rows = d/dx of each player's AL penalty with the active set frozen,
+    # jacobian = its derivative (state bound + wall + circle together, unicycle p = 2).
+    rng = np.random.default_rng(9)
+    N, p = 5, 2
+    b = orc.OracleBatch(UNI, p, N, 0.1, 1)
+    n = b.n
+    b.set_lqr(np.zeros((p, 4)), np.zeros((p, 2)), np.zeros((p, 4)), np.zeros((p, 2)))
+    xmax = np.full(n, np.inf); xmin = np.full(n, -np.inf); xmax[[0, 3, 6]] = [0.5, 0.4, 0.6]; xmin[[1, 7]] = [0.3, 0.55]
+    b.add_state_bound(1, xmax, xmin)
+    b.add_wall_constraint([-1.0], [0.5], [2.0], [0.5], [0.0], [1.0])
+    xc, yc, rad = np.array([0.5, 0.2]), np.array([0.5, 0.9]), np.array([0.4, 0.3])
+    b.add_circle_constraint(xc, yc, rad)
+    z = rng.random((1, b.traj_len)); X, U, L = b.split_traj(z)
+    z = b.join_traj(X, U, np.zeros_like(L)); b.set_traj(z)
+    off = _ext_off(b); K = N - 1
+    vals = b.kat_evaluate_con()[0]
+    circ = vals[off + p * 2 * n * K + p * K:].reshape(p, K, 2)
+    for i in range(p):
+        for k in range(1, N):
+            assert np.allclose(circ[i, k - 1], rad ** 2 - (X[0, k, i] - xc) ** 2 - (X[0, k, i + p] - yc) ** 2, atol=1e-15)
+    lam = rng.random((1, b.con_len)) * (rng.random((1, b.con_len)) > 0.5); mu = np.full((1, b.con_len), 3.0)
+    b.set_con_duals(lam, mu)
+    res0 = b.residual()[0][0]; J = b.residual_jacobian()[0]
+    act = ((vals >= 0) | (lam[0] > 0)) & np.isfinite(vals)
+
+    def pen(xk, i, k):          # player i's AL penalty at knot k (1-based knot index k+1), active set frozen
+        s = 0.0
+        def term(e, c):
+            return lam[0, e] * c + 0.5 * 3.0 * act[e] * c * c if np.isfinite(c) else 0.0
+        if i == 1:
+            for r in range(2 * n):
+                c = xk[r] - xmax[r] if r < n else xmin[r - n] - xk[r - n]
+                s += term(off + (i * K + k - 1) * 2 * n + r, c)
+        inside = -1.0 < xk[i] < 2.0
+        s += term(off + p * 2 * n * K + i * K + (k - 1), (xk[i + p] - 0.5) * inside)
+        for c2 in range(2):
+            s += term(off + p * 2 * n * K + p * K + (i * K + k - 1) * 2 + c2, rad[c2] ** 2 - (xk[i] - xc[c2]) ** 2 - (xk[i + p] - yc[c2]) ** 2)
+        return s
+    eps = 1e-6
+    for i in range(p):
+        for k in range(1, N):
+            rows = i * K * (n + 2) + (k - 1) * (n + 2) + np.arange(n)
+            g = np.zeros(n)
+            for a in range(n):
+                xp, xm = X[0, k].copy(), X[0, k].copy(); xp[a] += eps; xm[a] -= eps
+                g[a] = (pen(xp, i, k) - pen(xm, i, k)) / (2 * eps)
+            assert np.allclose(res0[rows], g, atol=1e-7), (i, k)
+    # jacobian: the Gauss-Newton block C' I_mu C (constraint_derivatives.jl:10-19; no second derivative of c)
+    def grads(xk, i, k):
+        out = []
+        if i == 1:
+            for r in range(2 * n):
+                g = np.zeros(n); g[r % n] = 1.0 if r < n else -1.0
+                out.append((off + (i * K + k - 1) * 2 * n + r, g))
+        g = np.zeros(n); g[i + p] = 1.0 * (-1.0 < xk[i] < 2.0)
+        out.append((off + p * 2 * n * K + i * K + (k - 1), g))
+        for c2 in range(2):
+            g = np.zeros(n); g[i] = -2 * (xk[i] - xc[c2]); g[i + p] = -2 * (xk[i + p] - yc[c2])
+            out.append((off + p * 2 * n * K + p * K + (i * K + k - 1) * 2 + c2, g))
+        return out
+    for i in range(p):
+        for k in range(1, N):
+            rows = i * K * (n + 2) + (k - 1) * (n + 2) + np.arange(n)
+            cols = (k - 1) * b.b + np.arange(n)
+            Hx = sum(3.0 * act[e] * np.outer(g, g) for e, g in grads(X[0, k], i, k))
+            assert np.allclose(J[np.ix_(rows, cols)], Hx, atol=1e-13), (i, k)
 
 
 def test_al_expansion_formula(orc):
@@ -436,7 +585,7 @@ def test_jacobian_is_derivative_of_residual_for_linear_dynamics(orc):
 
 
 # ---------------------------------------------------------------- end-to-end (test/problem/solver_methods.jl)
-def _problem(alg, orc, model, x0, opts, constrained=False):
+def _problem(alg, orc, model, x0, opts, constrained=False, circles=None):
     N, dt, p = 20, 0.1, model.p
     Q = [np.ones(model.ni[i]) for i in range(p)]
     R = [0.5 * np.ones(model.mi[i]) for i in range(p)]
@@ -447,6 +596,8 @@ def _problem(alg, orc, model, x0, opts, constrained=False):
     if constrained:
         alg.add_collision_avoidance(game_con, 0.05)
         alg.add_control_bound(game_con, np.ones(model.m), -np.ones(model.m))
+    if circles is not None:
+        alg.add_circle_constraint(game_con, *circles)
     return alg.GameProblem(N, dt, x0, model, opts, game_obj, game_con, backend=orc.lib())
 
 
@@ -495,8 +646,7 @@ def test_e2e_unicycle_two_players(alg, orc):
 
 def test_e2e_unicycle_two_players_constrained(alg, orc):
     # test/problem/solver_methods.jl:132-182 with its *effective* options (SURVEY.md section 4 warning: the problem is
-    # built with the previous block's opts object).  The circle constraints of :156-160 are outside the
-    # hot-path scope and are omitted.
+    # built with the previous block's opts object).  Without the circle constraints of :156-160 (the C3/C5 ingredient set).
     opts = alg.Options(inner_print=False, outer_print=False)
     opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = 7, 20, 25, 1e-7, 1e-10, 1e-10
     prob = _problem(alg, orc, alg.UnicycleGame(p=2), [1.0, 2.0, 1.1, 2.0, 0.0, 0.0, 0.9, 0.9], opts, constrained=True)
@@ -506,6 +656,59 @@ def test_e2e_unicycle_two_players_constrained(alg, orc):
     assert np.abs(res).sum() / res.shape[1] < 1e-3
     for f in ("dyn_vio", "sta_vio", "con_vio", "opt_vio"):
         assert last[f] < 1e-3, (f, last[f])
+
+
+def test_e2e_unicycle_two_players_constrained_with_circles(alg, orc):
+    # test/problem/solver_methods.jl:132-182 in full: collision avoidance + control bounds + the circle constraints of :156-160
+    opts = alg.Options(inner_print=False, outer_print=False)
+    opts.outer_iter, opts.inner_iter, opts.ls_iter, opts.reg_0, opts.ϵ_dyn, opts.ϵ_opt = 7, 20, 25, 1e-7, 1e-10, 1e-10
+    prob = _problem(alg, orc, alg.UnicycleGame(p=2), [1.0, 2.0, 1.1, 2.0, 0.0, 0.0, 0.9, 0.9], opts, constrained=True,
+                    circles=([1.50, 0.2, 0.3], [1.25, 0.2, 0.3], [0.2, 0.2, 0.3]))
+    alg.newton_solve(prob)
+    last = prob.stats.summary["last"][0]
+    res = alg.residual(prob)
+    assert np.abs(res).sum() / res.shape[1] < 1e-3
+    for f in ("dyn_vio", "sta_vio", "con_vio", "opt_vio"):
+        assert last[f] < 1e-3, (f, last[f])
+    # the circles are felt: player trajectories stay outside every disc
+    X = prob.pdtraj.states[0]
+    for xc, yc, r in zip([1.50, 0.2, 0.3], [1.25, 0.2, 0.3], [0.2, 0.2, 0.3]):
+        for i in range(2):
+            assert np.all((X[1:, i] - xc) ** 2 + (X[1:, i + 2] - yc) ** 2 >= r * r - 2e-3)
+
+
+def _intro_problem(alg, backend, x0=None, device=0):
+    # examples/intro_example.jl:10-74
+    p, N, dt = 3, 20, 0.1
+    model = alg.BicycleGame(p=p)
+    Q = [10.0 * np.ones(4) for _ in range(p)]; R = [0.1 * np.ones(2) for _ in range(p)]
+    xf = [np.array([2, 0.4, 0, 0.0]), np.array([2, 0.0, 0, 0.0]), np.array([3, -0.4, 0, 0.0])]
+    uf = [np.zeros(2) for _ in range(p)]
+    game_obj = alg.GameObjective(Q, R, xf, uf, N, model)
+    alg.add_collision_cost(game_obj, 1.0 * np.ones(p), 5.0 * np.ones(p))
+    game_con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    alg.add_collision_avoidance(game_con, 0.08)
+    alg.add_control_bound(game_con, 5 * np.ones(model.m), -5 * np.ones(model.m))
+    alg.add_state_bound(game_con, 1, 5 * np.ones(model.n), -5 * np.ones(model.n))
+    alg.add_wall_constraint(game_con, [alg.Wall([0.0, -0.4], [1.0, -0.4], [0.0, -1.0])])
+    alg.add_circle_constraint(game_con, [1.0, 2.0, 3.0], [1.0, 2.0, 3.0], [0.1, 0.2, 0.3])
+    if x0 is None:
+        x0 = np.array([0.1, 0.0, 0.5, -0.4, 0.0, 0.7, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    return alg.GameProblem(N, dt, x0, model, alg.Options(inner_print=False, outer_print=False), game_obj, game_con,
+                           backend=backend, device=device)
+
+
+def test_e2e_intro_example(alg, orc):
+    # examples/intro_example.jl with Options() defaults: the solve must converge to the default tolerances (eps = 1e-3)
+    prob = _intro_problem(alg, orc.lib())
+    alg.newton_solve(prob)
+    s = prob.stats.summary
+    last = s["last"][0]
+    assert s["status"][0] == 0
+    for f in ("dyn_vio", "sta_vio", "con_vio", "opt_vio"):
+        assert last[f] < 1e-3, (f, last[f])
+    X = prob.pdtraj.states[0]
+    assert np.all(X[1:, 3:6][(X[1:, 0:3] > 0) & (X[1:, 0:3] < 1)] >= -0.4 - 2e-3)     # wall: y >= -0.4 while 0 < x < 1
 
 
 # ---------------------------------------------------------------- iterated best response (test/problem/solver_methods.jl:185-314)

@@ -278,7 +278,8 @@ class GameConstraintValues:
         self.collision_radius = None     # per player, pair radius = r_i + r_j
         self.u_max = None
         self.u_min = None
-        self.state_bounds = {}           # player (1-based) -> (x_max, x_min) on the joint state
+        self.state_bounds = {}           # player (1-based) -> merged (x_max, x_min) on the joint state
+        self.state_conval = [[] for _ in range(probsize.p)]   # per player: the state-bound sets in the order they were added
         self.walls = None
         self.circles = None
 
@@ -307,18 +308,49 @@ def add_control_bound(game_con, u_max, u_min):
 
 def add_state_bound(game_con, i, x_max, x_min):
     """add_state_bound!(game_con, i, x_max, x_min), constraints_methods.jl:87-98 (player i is 1-based; bounds on the
-    joint state, +-inf allowed)."""
+    joint state, +-inf allowed).  The reference appends one StateBoundConstraint per call; the rows of several calls for
+    the same player are independent scalar constraints, so they are kept as one merged (x_max, x_min) pair -- which
+    requires that no state entry is bounded on the same side by two calls."""
     n, p = game_con.probsize.n, game_con.probsize.p
-    x_max = np.asarray(x_max, dtype=np.float64); x_min = np.asarray(x_min, dtype=np.float64)
+    x_max = np.array(x_max, dtype=np.float64); x_min = np.array(x_min, dtype=np.float64)
     if x_max.shape != (n,) or x_min.shape != (n,):
         raise ValueError("state bounds must have length n")
     if not (1 <= i <= p):
         raise ValueError("player index out of range")
     if not np.all(x_max >= x_min):
-        raise ValueError("Upper bounds must be greater than or equal to lower bounds")
+        raise ValueError("Upper bounds must be greater than or equal to lower bounds")   # checkBounds
+    game_con.state_conval[i - 1].append((x_max.copy(), x_min.copy()))
     if i in game_con.state_bounds:
-        raise AlgamesError("only one state-bound set per player is supported")
+        mx, mn = game_con.state_bounds[i]
+        if np.any(np.isfinite(mx) & np.isfinite(x_max)) or np.any(np.isfinite(mn) & np.isfinite(x_min)):
+            raise AlgamesError("a state entry of one player can carry only one upper and one lower bound")
+        x_max, x_min = np.minimum(mx, x_max), np.maximum(mn, x_min)
     game_con.state_bounds[i] = (x_max, x_min)
+
+
+def velocity_index(model, i):
+    """velocity_index(model, i), velocity_constraint.jl:30-43 (1-based)."""
+    assert 1 <= i <= model.p
+    if isinstance(model, UnicycleGame):
+        return model.pz[i - 1][3]
+    if isinstance(model, BicycleGame):
+        return model.pz[i - 1][2]
+    raise AlgamesError("Velocity Index is not implemented for DoubleIntegratorGame.")
+
+
+def add_velocity_bound(model, game_con, v_max, v_min):
+    """add_velocity_bound!(model, game_con, v_max, v_min), velocity_constraint.jl:1-28: the bound on player i's speed is a
+    state bound added to every player's constraint list."""
+    n, p = model.n, model.p
+    v_max, v_min = np.asarray(v_max, dtype=np.float64), np.asarray(v_min, dtype=np.float64)
+    assert len(v_max) == len(v_min) == p
+    for i in range(1, p + 1):
+        if v_max[i - 1] != np.inf or v_min[i - 1] != -np.inf:
+            x_max = np.full(n, np.inf); x_min = np.full(n, -np.inf)
+            x_max[velocity_index(model, i) - 1] = v_max[i - 1]
+            x_min[velocity_index(model, i) - 1] = v_min[i - 1]
+            for j in range(1, p + 1):
+                add_state_bound(game_con, j, x_max, x_min)
 
 
 class Wall:

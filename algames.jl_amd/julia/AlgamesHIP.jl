@@ -48,6 +48,7 @@ check(rc) = rc == 0 || error(unsafe_string(ccall((:alg_last_error, LIB), Cstring
 
 model_id(::DoubleIntegratorGame) = Int32(0)
 model_id(::UnicycleGame) = Int32(1)
+model_id(::BicycleGame) = Int32(2)
 
 function abi_options(o::Options)
     ax = ntuple(i -> i <= length(o.αx_dual) ? Float64(o.αx_dual[i]) : 1.0, 10)
@@ -60,7 +61,8 @@ end
     newton_solve!(probs::Vector{<:GameProblem}; device=0, game_id0=0)
 
 Batched drop-in for `newton_solve!(prob)` (src/problem/solver_methods.jl:5-65).  All problems must share
-model, N, dt, options and constraint structure (collision avoidance radii, control bounds, collision cost);
+model, N, dt, options and constraint structure (collision avoidance radii, control / state bounds, walls, circles,
+collision cost);
 they may differ in x0 and in the LQR data.
 """
 function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0::Integer=0)
@@ -94,14 +96,35 @@ function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0
             mu = [prob.game_obj.obj[i][2].cost[1].μ for i in 1:p]
             check(ccall((:alg_add_collision_cost, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], rad, mu))
         end
-        # collision avoidance: state_conval[i][q].con.radius = r_i + r_j (constraints_methods.jl:27-29)
-        if p > 1 && !isempty(prob.game_con.state_conval[1])
-            R12 = prob.game_con.state_conval[1][1].con.radius          # r_1 + r_2
-            R1p = p > 2 ? prob.game_con.state_conval[1][2].con.radius : R12
-            R2p = p > 2 ? prob.game_con.state_conval[2][2].con.radius : R12
+        # state constraints of player i, in the order they were added (constraints_methods.jl): dispatch on the type
+        colcons = [cv.con for cv in prob.game_con.state_conval[1] if cv.con isa Algames.TrajectoryOptimization.CollisionConstraint]
+        if p > 1 && !isempty(colcons)
+            # collision avoidance: con.radius = r_i + r_j (constraints_methods.jl:27-29) -> per-player radii
+            col2 = [cv.con for cv in prob.game_con.state_conval[2] if cv.con isa Algames.TrajectoryOptimization.CollisionConstraint]
+            R12 = colcons[1].radius                                     # r_1 + r_2
+            R1p = p > 2 ? colcons[2].radius : R12                       # r_1 + r_3
+            R2p = p > 2 ? col2[2].radius : R12                          # r_2 + r_3
             r1 = p > 2 ? (R12 + R1p - R2p) / 2 : R12 / 2
-            radius = [i == 1 ? r1 : prob.game_con.state_conval[1][i-1].con.radius - r1 for i in 1:p]
+            radius = [i == 1 ? r1 : colcons[i-1].radius - r1 for i in 1:p]
             check(ccall((:alg_add_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], radius))
+        end
+        if prob.model isa BicycleGame
+            check(ccall((:alg_set_bicycle, LIB), Cint, (Ptr{Cvoid}, Float64, Float64), h[], prob.model.lf, prob.model.lr))
+        end
+        for i in 1:p, cv in prob.game_con.state_conval[i]
+            con = cv.con
+            if con isa Algames.StateBoundConstraint                      # add_state_bound!(game_con, i, x_max, x_min)
+                check(ccall((:alg_add_state_bound, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), h[], i - 1,
+                            Vector{Float64}(con.x_max), Vector{Float64}(con.x_min)))
+            elseif i == 1 && con isa Algames.WallConstraint              # add_wall_constraint!(game_con, walls): same set for every player
+                check(ccall((:alg_add_wall_constraint, LIB), Cint,
+                            (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
+                            Vector{Float64}(con.x1), Vector{Float64}(con.y1), Vector{Float64}(con.x2), Vector{Float64}(con.y2),
+                            Vector{Float64}(con.xv), Vector{Float64}(con.yv)))
+            elseif i == 1 && con isa Algames.TrajectoryOptimization.CircleConstraint   # add_circle_constraint!(game_con, xc, yc, radius)
+                check(ccall((:alg_add_circle_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
+                            Vector{Float64}(con.x), Vector{Float64}(con.y), Vector{Float64}(con.radius)))
+            end
         end
         if !isempty(prob.game_con.control_conval)
             con = prob.game_con.control_conval[1].con

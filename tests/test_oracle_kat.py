@@ -323,6 +323,42 @@ def test_wall_evaluate_literal(orc):
     assert np.allclose(res[0:4], [gx, gy, 0.0, 0.0], atol=1e-14)
 
 
+def test_wall_state_violation_literal(orc):
+    # test/struct/violations.jl:36-48: Unicycle p = 3, N = 10, all-ones trajectory from x0 = 0, wall (0,1)-(1,0) with v = (1,1)/sqrt(2)
+    N, p = 10, 3
+    b = orc.OracleBatch(UNI, p, N, 0.1, 1)
+    b.set_lqr(np.zeros((p, 4)), np.zeros((p, 2)), np.zeros((p, 4)), np.zeros((p, 2)))
+    s2 = np.sqrt(2.0)
+    b.add_wall_constraint([0.0], [1.0], [1.0], [0.0], [1 / s2], [1 / s2])
+    z = np.ones((1, b.traj_len)); z[0, :b.n] = 0.0
+    b.set_traj(z)
+    w = b.kat_evaluate_con()[0][_ext_off(b):].reshape(p, N - 1)
+    assert np.abs(w - s2 / 2).sum() <= 1e-10                    # sqrt(2)/2 on knots 2..N for every player (knot 1 carries no constraint)
+    assert abs(b.record()["sta_vio"][0] - s2 / 2) < 1e-10
+
+
+def test_velocity_bound_adders(alg):
+    # test/constraints/velocity_constraint.jl:3-46
+    N = 10
+    model = alg.UnicycleGame(p=3)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    alg.add_velocity_bound(model, con, np.ones(3), -np.ones(3))
+    assert len(con.state_conval) == 3 and len(con.state_conval[0]) == 3
+    assert [alg.velocity_index(model, i) for i in (1, 2, 3)] == [10, 11, 12]
+    mx, mn = con.state_bounds[2]
+    assert np.array_equal(np.nonzero(np.isfinite(mx))[0], [9, 10, 11]) and np.all(mx[9:] == 1) and np.all(mn[9:] == -1)
+    model = alg.BicycleGame(p=3)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    alg.add_velocity_bound(model, con, [1, np.inf, np.inf], [1, -1, -np.inf])
+    assert len(con.state_conval) == 3 and len(con.state_conval[0]) == 2
+    assert [alg.velocity_index(model, i) for i in (1, 2, 3)] == [7, 8, 9]
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    alg.add_velocity_bound(model, con, np.full(3, np.inf), np.full(3, -np.inf))
+    assert len(con.state_conval) == 3 and len(con.state_conval[0]) == 0
+    with pytest.raises(Exception):
+        alg.velocity_index(alg.DoubleIntegratorGame(p=2), 1)
+
+
 def test_circle_and_extended_constraints_fd(orc):
     # CircleConstraint (TrajectoryOptimization 0.4.1, un-vendored): c = r^2 - (x-xc)^2 - (y-yc)^2 <= 0 keeps the
     # player outside the disc.  FD check: opt_x rows = d/dx of each player's AL penalty with the active set frozen,

@@ -78,7 +78,7 @@ struct Cfg {
     static constexpr int b = n + m + P_ * n;
     static constexpr int NPAIR = P_ * (P_ - 1);
     static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : (MODEL_ == ALG_MODEL_BICYCLE) ? 10 * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
-    static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : 3;        // max non-zeros of a column of [B_k | A_k]
+    static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : (MODEL_ == ALG_MODEL_UNICYCLE) ? 3 : 2;   // max non-zeros of a column of [B_k | A_k]
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
     static constexpr int WPE = (n >= 16) ? 2 : 4;
@@ -458,13 +458,15 @@ struct DirLds {
     static constexpr int KB = C::n / 4;                  // k-blocks of the 16x16x4 f64 MFMA
     static constexpr int NHX = C::P * C::P * C::P * 3;   // expanded pair-Hessian table [i][jr][jc][3]
     static_assert(C::n % 4 == 0 && C::n <= 16, "MFMA tile path needs n % 4 == 0 and n <= 16");
+    static constexpr bool AUGS = C::n < 16;              // spare tile column: f and s_i ride through the MFMA products
+    static constexpr int KB1 = AUGS ? (C::n + 4) / 4 : KB;   // k-blocks of the first product ([P_i | s_i]: n + 1 columns)
+    static constexpr int VW = C::n + 1 + C::m;           // row of the extended V: [B' P (n) | g (1) | diag R^ slots (m)]
     struct Bwd {                       // live only during the backward sweep
-        double Pm[C::P * C::n * LDP];  // P_i, row-major
-        double Fx[C::n * 16];          // [F | f | 0]: n x 16 (f in column n when n < 16)
+        double Pm[C::P * C::n * LDP];  // [P_i | s_i], row-major (s_i in the pad column n)
+        double Fx[16 * 16];            // [F | f | 0] (f in column n when n < 16); row n = e_n (n < 16), other rows >= n zero
         double fv[C::n];
-        double s[C::P * C::n];
         double t[C::P * C::n];         // t_i = P_i f + s_i (n == 16 path) / y_i = P_i rd + s_i
-        double V[C::m * C::n];
+        double V[C::m * VW];
         double pad[1];                 // dump slot for the masked-off lanes of the MFMA result write-back
     };
     struct Fwd {                       // live only during the forward / costate sweeps
@@ -854,10 +856,13 @@ __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
 }
 // Sparse pattern (<= 3 entries) of column `idx` of the n x (m + n) matrix [B_k | A_k]  (idx < m: B column, else A column)
 template <class C>
-__device__ __forceinline__ void col_pattern(const double* coef, double dt, int idx, bool useA, int (&rows)[C::NPAT], double (&vals)[C::NPAT]) {
-    constexpr int m = C::m, P = C::P;
+__device__ __forceinline__ void col_pattern(const double* coef, double dt, int idx, bool useA, int (&rows)[C::NPAT + 1], double (&vals)[C::NPAT + 1]) {
+    constexpr int m = C::m, n = C::n, P = C::P;
 #pragma unroll
-    for (int t = 0; t < C::NPAT; t++) { rows[t] = 0; vals[t] = 0.0; }
+    for (int t = 0; t < C::NPAT + 1; t++) { rows[t] = 0; vals[t] = 0.0; }
+    // slot NPAT addresses the extended part of V's rows: lane c < m picks its R^ slot, lane m + n the right-hand side g
+    if (idx < m) { rows[C::NPAT] = n + 1 + idx; vals[C::NPAT] = 1.0; }
+    else if (idx == m + n) { rows[C::NPAT] = n; vals[C::NPAT] = 1.0; }
     if (idx < m) {
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { rows[0] = idx; vals[0] = 0.5 * dt * dt; rows[1] = idx + m; vals[1] = dt; }
         else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
@@ -870,7 +875,7 @@ __device__ __forceinline__ void col_pattern(const double* coef, double dt, int i
             rows[0] = i; rows[1] = P + i; rows[2] = (2 + kind) * P + i;
             vals[0] = 0.5 * dt * coef[kind * P + i]; vals[1] = 0.5 * dt * coef[(2 + kind) * P + i]; vals[2] = dt;
         }
-    } else if (useA) {
+    } else if (useA && idx < m + n) {
         const int c = idx - m;
         rows[0] = c; vals[0] = 1.0;
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { if (c >= m) { rows[1] = c - m; vals[1] = dt; } }
@@ -915,6 +920,63 @@ struct HxMap {
     }
 };
 
+// Non-zeros of [Q^_i | rx_i] (n < 16 path): after the MFMA products wrote A'(P F) back, every lane adds its entries
+//   (r, r): reg + w q_i,r (+ state-bound Hessian) (+ position-block diagonal)   (r, c) r != c < 2P: position block   (r, n): rx_i,r
+// into row block i of Pm.  Per lane and pass: packed (dst | src << 11 | qi << 19), sign of the record source, diagonal flag.
+template <class C>
+struct QaddMap {
+    static constexpr int OFF = C::POS ? 4 * C::P * C::P - 2 * C::P : 0;
+    static constexpr int QE = C::n + OFF + C::n, QTOT = C::P * QE, PASSES = (QTOT + WAVE - 1) / WAVE;
+    unsigned code[PASSES]; float sgn[PASSES], dfl[PASSES];
+    __device__ __forceinline__ static void hxsrc(int i, int jr, int jc, int h, int& so, float& sg) {
+        using R = Rec<C>;
+        so = 0; sg = 0.f;
+        if (jr == i && jc == i) { so = R::HD + 3 * i + h; sg = 1.f; }
+        else if (jr == i) { so = R::HH + 3 * pairq<C>(i, jc) + h; sg = -1.f; }
+        else if (jc == i) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = -1.f; }
+        else if (jr == jc) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = 1.f; }
+    }
+    __device__ __forceinline__ void init(int lane) {
+        constexpr int n = C::n, P = C::P, LDP = n + 1;
+        using R = Rec<C>;
+        static_assert(C::P * n * LDP < 2048 && R::LEN_SWEEP < 256 && P * n < 64, "QaddMap packing");
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) {
+            const int e = lane + q * WAVE;
+            int dst = 0, so = 0, qi = 0; float sg = 0.f, df = 0.f;
+            if (e < QTOT) {
+                const int i = e / QE, t = e % QE;
+                if (t < n) {
+                    dst = i * n * LDP + t * LDP + t; qi = i * n + t; df = 1.f;
+                    if (C::POS && t < 2 * P) hxsrc(i, t % P, t % P, 2 * (t / P), so, sg);
+                } else if (t < n + OFF) {
+                    const int u = t - n, r = u / (2 * P - 1), cc = u % (2 * P - 1), c = cc < r ? cc : cc + 1;
+                    dst = i * n * LDP + r * LDP + c;
+                    hxsrc(i, r % P, c % P, r / P + c / P, so, sg);
+                } else {
+                    const int r = t - n - OFF;
+                    dst = i * n * LDP + r * LDP + n; so = R::RX + i * n + r; sg = 1.f;
+                }
+            }
+            code[q] = (unsigned)dst | ((unsigned)so << 11) | ((unsigned)qi << 19); sgn[q] = sg; dfl[q] = df;
+        }
+    }
+    __device__ __forceinline__ void apply(int lane, const double* Rc, const double* qdf, double* Pm, double reg, double w, int only_player) const {
+        using R = Rec<C>;
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) {
+            const int e = lane + q * WAVE;
+            if (e < QTOT && (only_player < 0 || e / QE == only_player)) {
+                const unsigned u = code[q];
+                const int dst = u & 0x7ff, so = (u >> 11) & 0xff, qi = u >> 19;
+                double dq = reg + w * qdf[qi];
+                if constexpr (C::EXT) dq += Rc[R::RQ + qi];
+                Pm[dst] += fma((double)sgn[q], Rc[so], (double)dfl[q] * dq);
+            }
+        }
+    }
+};
+
 // Solves J d = -res for the step records left by assemble_pass<C,1> and writes d into the delta buffer
 // (solver_methods.jl:87-88).  Returns ALG_STATUS_*.
 // IBR = true: best response of player ip -- only x, u_ip, lambda_ip move (horizontal mask, newton_core.jl:249-294): the other
@@ -929,12 +991,19 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     double* __restrict__ dz = G.z[2];
     constexpr int RPL = (R::LEN_SWEEP + WAVE - 1) / WAVE;      // record doubles per lane
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
-    HxMap<C> hxm; hxm.init(lane);
+    constexpr bool AUGS = DirLds<C>::AUGS;               // s_i rides through the first MFMA product (n < 16)
+    constexpr int KB1 = DirLds<C>::KB1, VW = DirLds<C>::VW;
+    HxMap<C> hxm;
+    if constexpr (!AUGS) hxm.init(lane);
+    QaddMap<C> qam;
+    if constexpr (AUGS) qam.init(lane);
     for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd[i * C::ni + r / P] : 0.0; }
-    for (int e = lane; e < n * 16; e += WAVE) L.bw.Fx[e] = 0.0;
+    for (int e = lane; e < 16 * 16; e += WAVE) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
     for (int e = lane; e < P * n * LDP; e += WAVE) L.bw.Pm[e] = 0.0;
+    for (int e = lane; e < m * VW; e += WAVE) L.bw.V[e] = 0.0;
+    if (lane == 0) L.bw.pad[0] = 0.0;
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
-    // ---- loop-invariant lane roles of the MFMA C-init: register r4 holds (row = lq + 4 r4, col = lrow)
+    // ---- loop-invariant lane roles of the MFMA tiles: register r4 holds (row = lq + 4 r4, col = lrow)
     const bool colP = lrow < n, colS = (lrow == n) && (n < 16), colB = lrow < 2 * P;
     int hxo[4]; bool rowok[4], diag[4], inb[4];
 #pragma unroll
@@ -944,79 +1013,101 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         hxo[r4] = inb[r4] ? ((row % P) * P + lrow % P) * 3 + row / P + lrow / P : 0;
     }
     __syncthreads();
+    double* const bwb = reinterpret_cast<double*>(&L.bw);
+    constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
     // ------------------------------------------------------------------ backward sweep
+    // P_i (n x n) and s_i (column n of the same LDS rows): P_i <- Q^_i + A_{k+1}' P_i F,  s_i <- rx_i + A_{k+1}' (P_i f + s_i)
     int cur = 0, sing = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         const double* coefk = Rc + R::COEF;
-        hxm.expand(lane, Rc, L.hx);
-        if (n == 16 && k < N - 2) {
-            // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
-            for (int e = lane; e < P * n; e += WAVE) {
-                const int i = e / n, r = e % n; double a = L.bw.s[e];
-                for (int c = 0; c < n; c++) a += L.bw.Pm[i * n * LDP + r * LDP + c] * L.bw.fv[c];
-                L.bw.t[e] = a;
-            }
-        }
-        __syncthreads();
-        // ---- P_i <- Q^_i + A_{k+1}' (P_i [F|f] + [0|s_i]) ,  s_i <- rx_i + A_{k+1}' (P_i f + s_i)   via chained f64 MFMAs.
-        // Player i's chain reads only P_i / s_i (plus the shared F, A), so its result is written back before the next
-        // player starts: one accumulator tile live instead of P.
-        {
-            double bF[KB], aA[KB];
+        if constexpr (AUGS) {
+            // ---- [P_i | s_i] [[F f],[0 1]] = [P_i F | P_i f + s_i], then A' x that: two chained f64 MFMA products per player,
+            // accumulators start at zero; the sparse Q^_i / rx_i are added afterwards (Q-add phase).  Player i's chain reads only
+            // row block i of Pm, so its result is written back before the next player starts: one accumulator tile live.
             if (k < N - 2) {
+                double bF[KB1], aA[KB];
 #pragma unroll
-                for (int kb = 0; kb < KB; kb++) {
-                    bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
-                    aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
-                }
-            }
-            double* const bwb = reinterpret_cast<double*>(&L.bw);
-            constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oS = (int)(offsetof(typename DirLds<C>::Bwd, s) / 8),
-                          oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
+                for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                if (IBR && i != ip) continue;
-                double4_t c2;                                   // C-init of the second product: [Q^_i | rx_i]
+                for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
 #pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const int row = lq + 4 * r4;
-                    double v = diag[r4] ? reg + w * L.qdf[i * n + row] : 0.0;
-                    if constexpr (C::EXT) { const double qv = Rc[R::RQ + i * n + (rowok[r4] ? row : 0)]; v += diag[r4] ? qv : 0.0; }
-                    if (C::POS) { const double hv = L.hx[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
-                    const double rxv = Rc[R::RX + i * n + (rowok[r4] ? row : 0)];
-                    v = (colS && rowok[r4]) ? rxv : v;
-                    c2[r4] = v;
-                }
-                if (k < N - 2) {
-                    double4_t c1;
+                for (int i = 0; i < P; i++) {
+                    if (IBR && i != ip) continue;
+                    double4_t c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) { const int row = lq + 4 * r4; const double sv = L.bw.s[i * n + (rowok[r4] ? row : 0)]; c1[r4] = (colS && rowok[r4]) ? sv : 0.0; }
-#pragma unroll
-                    for (int kb = 0; kb < KB; kb++) {
+                    for (int kb = 0; kb < KB1; kb++) {
+                        // columns n+1.. of the last k-block read past the row (finite values) and meet zero rows of Fx
                         const double pv = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
                         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
                     }
 #pragma unroll
                     for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
-                }
-                __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
+                    __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const int row = lq + 4 * r4;
-                    const bool toP = rowok[r4] && colP, toS = rowok[r4] && colS;
-                    const int slot = toP ? oPm + i * n * LDP + row * LDP + lrow : (toS ? oS + i * n + row : oPad);
-                    bwb[slot] = c2[r4];
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const int row = lq + 4 * r4;
+                        const int slot = (rowok[r4] && lrow <= n) ? oPm + i * n * LDP + row * LDP + lrow : oPad;
+                        bwb[slot] = c2[r4];
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
+            qam.apply(lane, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
+        } else {
+            hxm.expand(lane, Rc, L.hx);
+            if (k < N - 2) {
+                // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
+                for (int e = lane; e < P * n; e += WAVE) {
+                    const int i = e / n, r = e % n; double a = L.bw.Pm[i * n * LDP + r * LDP + n];
+                    for (int c = 0; c < n; c++) a += L.bw.Pm[i * n * LDP + r * LDP + c] * L.bw.fv[c];
+                    L.bw.t[e] = a;
                 }
             }
-        }
-        if (n == 16) {
+            __syncthreads();
+            {
+                double bF[KB], aA[KB];
+                if (k < N - 2) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; kb++) {
+                        bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
+                        aA[kb] = A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow);                 // (A')[lrow][k] = A[k][lrow]
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    if (IBR && i != ip) continue;
+                    double4_t c2;                                   // C-init of the second product: Q^_i
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const int row = lq + 4 * r4;
+                        double v = diag[r4] ? reg + w * L.qdf[i * n + row] : 0.0;
+                        if constexpr (C::EXT) { const double qv = Rc[R::RQ + i * n + row]; v += diag[r4] ? qv : 0.0; }
+                        if (C::POS) { const double hv = L.hx[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
+                        c2[r4] = v;
+                    }
+                    if (k < N - 2) {
+                        double4_t c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kb = 0; kb < KB; kb++) {
+                            const double pv = L.bw.Pm[i * n * LDP + lrow * LDP + 4 * kb + lq];
+                            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pv, bF[kb], c1, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) L.bw.Pm[i * n * LDP + (lq + 4 * r4) * LDP + lrow] = c2[r4];
+                }
+            }
             for (int e = lane; e < P * n; e += WAVE) {
                 const int i = e / n, r = e % n; const double* ti = &L.bw.t[i * n];
                 double v = Rc[R::RX + e];
                 if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
-                L.bw.s[e] = v;
+                L.bw.Pm[i * n * LDP + r * LDP + n] = v;
             }
         }
         __syncthreads();
@@ -1026,31 +1117,38 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
-        // ---- V[c][:] = B[:,c]' P_{i(c)}   (m x n)  and  y_i = P_i rd + s_i
+        // ---- V[c][0..n) = B[:,c]' P_{i(c)},  V[c][n+1+c] = R^_c,  y_i = P_i rd + s_i
         for (int e = lane; e < m * n; e += WAVE) {
             const int c = e / n, col = e % n; const double* Pi = &L.bw.Pm[(c % P) * n * LDP];
-            L.bw.V[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
+            L.bw.V[c * VW + col] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
         }
         for (int e = lane; e < P * n; e += WAVE) {
             const double* Pr = &L.bw.Pm[(e / n) * n * LDP + (e % n) * LDP];
-            double a = L.bw.s[e];
+            double a = Pr[n];
 #pragma unroll
             for (int c = 0; c < n; c++) a += Pr[c] * Rc[R::RD + c];
             L.bw.t[e] = a;
         }
+        if (lane < m) L.bw.V[lane * VW + n + 1 + lane] = Rc[R::RHAT + lane];
         __syncthreads();
-        // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B,  g = ru + B' (P rd + s)
+        // ---- V[c][n] = g_c = ru_c + B[:,c]' (P rd + s)
+        if (lane < m) {
+            const double* yi = &L.bw.t[(lane % P) * n];
+            L.bw.V[lane * VW + n] = Rc[R::RU + lane] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, lane);
+        }
+        __syncthreads();
+        // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B: every lane forms its column as the same
+        // short sparse combination of row c of the extended V (lane < m: B column + R^ slot; lane < m+n: A column; lane m+n: g slot)
         double col[m];
         {
-            int rows[C::NPAT]; double vals[C::NPAT];
-            col_pattern<C>(coefk, dt, lane < m + n ? lane : 0, k >= 1, rows, vals);
+            int rows[C::NPAT + 1]; double vals[C::NPAT + 1];
+            col_pattern<C>(coefk, dt, lane, k >= 1, rows, vals);
 #pragma unroll
             for (int c = 0; c < m; c++) {
-                const double* Vc = &L.bw.V[c * n];
-                double v = vals[0] * Vc[rows[0]] + vals[1] * Vc[rows[1]] + vals[2] * Vc[rows[2]];
-                if constexpr (C::NPAT > 3) v += vals[3] * Vc[rows[3]];
-                if (lane == c) v += Rc[R::RHAT + c];
-                if (lane >= m + n) { const double* yi = &L.bw.t[(c % P) * n]; v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
+                const double* Vc = &L.bw.V[c * VW];
+                double v = vals[0] * Vc[rows[0]];
+#pragma unroll
+                for (int t = 1; t < C::NPAT + 1; t++) v = fma(vals[t], Vc[rows[t]], v);
                 if (IBR) {
                     if (c % P != ip) v = (lane == c) ? 1.0 : 0.0;               // unit row: du_c = 0
                     else if (lane < m && lane % P != ip) v = 0.0;               // fixed controls of the other players
@@ -1120,6 +1218,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     }
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
+    if constexpr (AUGS) hxm.init(phase_lane());
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
     const bool cpos = C::POS && cr_ < 2 * P;

@@ -249,21 +249,23 @@ __device__ __forceinline__ void model_player_rk3(const Params& pr, int i, const 
     for (int j = 0; j < C::ni; j++) { k3[j] *= dt; xn[j] = xi[j] + (k1[j] + 4 * k2[j] + k3[j]) / 6; }
 }
 
-// (A^T v)[r] for a vector accessor v(r'): A = I + E
+// (A^T v)[r] for a vector accessor v(r'): A = I + E.  Branch-free: every lane issues the same loads (clamped indices) and
+// masks the coefficients, so that divergent rows do not serialise their memory latencies.
 template <class C, class V>
 __device__ __forceinline__ double AT_vec(const double* coef, double dt, V v, int r) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-        return r < C::m ? v(r) : v(r) + dt * v(r - C::m);
+        const bool hi = r >= C::m;
+        return v(r) + (hi ? dt : 0.0) * v(hi ? r - C::m : r);
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
         const int P = C::P, blk = r / P, i = r % P;
-        if (blk == 2) return v(r) + coef[1 * P + i] * v(i) + coef[3 * P + i] * v(P + i) + coef[4 * P + i] * v(3 * P + i);
-        if (blk == 3) return v(r) + coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i);
-        return v(r);
+        const bool b2 = blk == 2, on = blk >= 2;
+        const double ca = coef[(b2 ? 1 : 0) * P + i], cb = coef[(b2 ? 3 : 2) * P + i], cc = coef[4 * P + i];
+        return v(r) + (on ? ca : 0.0) * v(i) + (on ? cb : 0.0) * v(P + i) + (b2 ? cc : 0.0) * v(3 * P + i);
     } else {
         const int P = C::P, blk = r / P, i = r % P;
-        if (blk == 2) return v(r) + coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i);
-        if (blk == 3) return v(r) + coef[1 * P + i] * v(i) + coef[3 * P + i] * v(P + i);
-        return v(r);
+        const bool b3 = blk == 3, on = blk >= 2;
+        const double ca = coef[(b3 ? 1 : 0) * P + i], cb = coef[(b3 ? 3 : 2) * P + i];
+        return v(r) + (on ? ca : 0.0) * v(i) + (on ? cb : 0.0) * v(P + i);
     }
 }
 // (A v)[r]
@@ -339,19 +341,18 @@ __device__ __forceinline__ double B_entry(const double* coef, double dt, int r, 
         return 0.0;
     }
 }
-// (B^T v)[c] : column c of B has <= 3 non-zeros
+// (B^T v)[c] : column c of B has <= 4 non-zeros (branch-free, see AT_vec)
 template <class C, class V>
 __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int c) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return 0.5 * dt * dt * v(c) + dt * v(c + C::m);
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
-        const int P = C::P, i = c % P, kind = c / P;
-        if (kind == 0) return 0.5 * dt * (coef[5 * P + i] * v(i) + coef[6 * P + i] * v(P + i) + coef[4 * P + i] * v(3 * P + i)) + dt * v(2 * P + i);
-        return coef[7 * P + i] * v(i) + coef[8 * P + i] * v(P + i) + coef[9 * P + i] * v(3 * P + i);
+        const int P = C::P, i = c % P; const bool k0 = (c / P) == 0;
+        const double ca = coef[(k0 ? 5 : 7) * P + i], cb = coef[(k0 ? 6 : 8) * P + i], cc = coef[(k0 ? 4 : 9) * P + i];
+        return (k0 ? 0.5 * dt : 1.0) * (ca * v(i) + cb * v(P + i) + cc * v(3 * P + i)) + (k0 ? dt : 0.0) * v(2 * P + i);
     } else {
         const int P = C::P, i = c % P, kind = c / P;
-        if (kind == 0) return 0.5 * dt * (coef[0 * P + i] * v(i) + coef[2 * P + i] * v(P + i)) + dt * v(2 * P + i);
-        return 0.5 * dt * (coef[1 * P + i] * v(i) + coef[3 * P + i] * v(P + i)) + dt * v(3 * P + i);
+        return 0.5 * dt * (coef[kind * P + i] * v(i) + coef[(2 + kind) * P + i] * v(P + i)) + dt * v((2 + kind) * P + i);
     }
 }
 // (B w)[r] for a control-vector accessor w(c): row r of B has <= 2 non-zeros
@@ -602,160 +603,179 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
         __syncthreads();
     }
     // ---------------- phase B ------------------------------------------------------------------------------
-    // row e of step k: [0, P n) opt_i,x ; [P n, P n + m) opt_i,u ; [P n + m, b) dyn ; lanes take rows e = lane + 64 q
-    constexpr int AUX = C::NC + 2 * P * P;
-    constexpr int NPASS = (b + WAVE - 1) / WAVE;
-    // per-game constant tables: LQR diagonal / targets padded to joint dims
-    for (int e = lane; e < P * n; e += WAVE) {
-        const int i = e / n, a = e % n; const bool own = (a % P == i);
-        L.tq[e] = own ? G.Qd[i * ni + a / P] : 0.0; L.tx[e] = own ? G.xf[i * ni + a / P] : 0.0;
-    }
-    for (int c = lane; c < m; c += WAVE) { L.tr[c] = G.Rd[(c % P) * mi + c / P]; L.tu[c] = G.uf[(c % P) * mi + c / P]; }
-    auto load_block = [&](int kb, int e) -> double { return (e < b && kb >= 0 && kb <= N - 2) ? z[n + (size_t)kb * b + e] : 0.0; };
-    auto load_ref = [&](int kb) -> double { return (zref && lane < n + m && kb <= N - 2) ? zref[n + (size_t)kb * b + lane] : 0.0; };
-    constexpr int NAP = (AUX + WAVE - 1) / WAVE;
-    auto load_aux = [&](int kb, int t) -> double {      // [coef of knot kb+1 | gvt of step kb]
-        if (t < C::NC) return (kb + 1 <= N - 2) ? G.rec[(size_t)(kb + 1) * R::LEN + R::COEF + t] : 0.0;
-        if (t < AUX) return G.rec[(size_t)kb * R::LEN + R::GVT + (t - C::NC)];
-        return 0.0;
+    // Every residual row of every step is independent once phase A has left the coefficients and the pair-gradient table:
+    // three flat row loops (opt_x | opt_u | dyn), work item = one row, operands read straight from the trajectory (the
+    // neighbouring lanes read neighbouring addresses; everything is L1/L2 resident after the first touch).
+    // Index arithmetic is incremental and all offsets are 32-bit unsigned so that the loads use the scalar-base + vector-
+    // offset addressing mode.  Each lane handles two rows per pass (row e and row e + 64): the loads of both are in flight
+    // together, which halves the exposed L2 latency.
+    typedef unsigned uidx;
+    struct Row { double r, dprox; bool mine, ok; uidx rec_off; int vrow; };
+    auto finish_row = [&](const Row& q, bool dynrow) {
+        if (!q.ok) return;
+        double r = q.r;
+        // regularize_residual! (global_quantities.jl:67-86): proximal term on the opt rows
+        const double rr = zref ? r + reg * q.dprox : r;
+        if (MODE == 3) { l1r += fabs(rr); }            // statistics / records of the unregularised rows
+        else r = rr;
+        bad |= !isfinite(r);
+        if (IBR) {
+            l1f += fabs(r);
+            if (dynrow) { l1 += fabs(r); if (q.mine) vdyn = fmax(vdyn, fabs(r)); }
+            else if (q.mine) { l1 += fabs(r); vopt = fmax(vopt, fabs(r)); }
+        } else {
+            l1 += fabs(r);
+            if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
+        }
+        if (RECS) G.rec[q.rec_off] = r;
+        if (MODE == 2) G.res[q.vrow] = r;
     };
-    if (lane < n) L.blk[0][lane] = z[lane];                                // x_1 sits where block -1's x part would be
-#pragma unroll
-    for (int q = 0; q < NPASS; q++) { const int e = lane + q * WAVE; if (e < b) { L.blk[1][e] = load_block(0, e); L.blk[2][e] = load_block(1, e); } }
-    if (lane < n + m) L.zr[0][lane] = load_ref(0);
-#pragma unroll
-    for (int q = 0; q < NAP; q++) { const int t = lane + q * WAVE; if (t < AUX) L.aux[1][t] = load_aux(0, t); }   // aux[(k+1)&1] = [coef of knot k+1 | gvt of step k]
-    if (C::NC > 0 && lane < C::NC) L.aux[0][lane] = G.rec[R::COEF + lane]; // coef of knot 0
-    __syncthreads();
-    for (int k = 0; k < N - 1; k++) {
-        const int s0 = k & 3, s1 = (k + 1) & 3, s2 = (k + 2) & 3, s3 = (k + 3) & 3, a0 = k & 1;
-        const double* Bp = L.blk[s0];     // block k-1 : x_k in [0, n)
-        const double* Bk = L.blk[s1];     // block k   : x_{k+1} | u_k | lambda_k
-        const double* Bn = L.blk[s2];     // block k+1 : .. | lambda_{k+1}
-        const double* Zr = L.zr[a0];
-        const double* Ck = L.aux[a0];         // coefficients of knot k (first NC entries)
-        const double* Ax = L.aux[a0 ^ 1];     // [coefficients of knot k+1 | gvt of step k]
-        double pre[NPASS];
-#pragma unroll
-        for (int q = 0; q < NPASS; q++) pre[q] = load_block(k + 2, lane + q * WAVE);
-        const double prer = load_ref(k + 1);
-        const bool has_next = (k + 1 <= N - 2);
-        const double w = (k + 1 < N - 1) ? dt : 1.0;
-#pragma unroll
-        for (int q = 0; q < NPASS; q++) {
-            const int e = lane + q * WAVE;
-            if (e >= b) continue;
-            double r = 0.0, rhat = 0.0, dprox = 0.0; int vrow = 0; bool dynrow = false, mine = true;
-            if (e < P * n) {
-                // opt_i,x_{k+1}[a] = cost grad + pair terms + A_{k+1}' lambda_{i,k+1} - lambda_{i,k} (+ reg (x - xref))
-                const int i = e / n, a = e % n;
-                const double* ln = Bn + n + m + i * n;
-                r = -Bk[e + n + m];
-                if (has_next) r += AT_vec<C>(Ax, dt, [&](int rr) { return ln[rr]; }, a);
-                r += w * (L.tq[e] * (Bk[a] - L.tx[e]));
-                if (C::POS && a < 2 * P) r += Ax[C::NC + (i * P + a % P) * 2 + a / P];
-                if constexpr (C::EXT) {
-                    // StateBoundConstraint of player i (state_bound_constraint.jl:85-97): rows (x - x_max)[a], (x_min - x)[a]
-                    double qsb = 0.0;
-                    if (pr.has_sb) {
-                        const double xa = Bk[a];
-#pragma unroll
-                        for (int half = 0; half < 2; half++) {
-                            const int ci = ext_sb_row(pr, i, k, half * n + a);
-                            const double cv = half == 0 ? xa - ext_sbmax(pr, G.extc)[e] : ext_sbmin(pr, G.extc)[e] - xa;
-                            G.vals[ci] = cv;
-                            if (isfinite(cv)) {
-                                const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
-                                const double wl = lm + am * cv;
-                                r += (half == 0 ? wl : -wl); qsb += am;
-                                if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, cv));
-                            }
-                        }
-                    }
-                    if (RECS) G.rec[(size_t)k * R::LEN + R::RQ + e] = qsb;
-                }
-                if (IBR) mine = (i == ip);
-                if (zref && mine) dprox = Bk[a] - Zr[a];
-                if (MODE == 2) vrow = vx<C>(N, i, k) + a;
-            } else if (e < P * n + m) {
-                // opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
-                const int c = e - P * n, i = c % P;
-                const double u = Bk[n + uoff<C>(c)];
-                const double* lk = Bk + n + m + i * n;
-                double g = 0.0; rhat = dt * L.tr[c] + jreg;
-                if (pr.has_ctl) {
+    const double* __restrict__ recg = G.rec;
+    // advance (k, j) by 64 rows of a row space with LEN rows per step
+    auto advance = [](int& k, int& j, int LEN) { j += WAVE % LEN; k += WAVE / LEN; if (j >= LEN) { j -= LEN; k += 1; } };
+    // ---- rows opt_i,x_{k+1}[a] = cost grad + pair terms + A_{k+1}' lambda_{i,k+1} - lambda_{i,k} (+ reg (x - xref))
+    {
+        constexpr int RXN = P * n;
+        auto row_x = [&](int k, int ei, bool ok) -> Row {
+            Row q; q.ok = ok;
+            if (!ok) { k = 0; ei = 0; }
+            const int i = ei / n, a = ei % n;
+            const uidx zo = (uidx)(n + k * b);                              // block k: x_{k+1} | u_k | lambda_k
+            const uidx ro = (uidx)(k * R::LEN);
+            const bool has_next = (k + 1 <= N - 2);
+            const double w = (k + 1 < N - 1) ? dt : 1.0;
+            double r = -z[zo + (uidx)(n + m + ei)];
+            {
+                // A_{k+1}' lambda_{i,k+1}: addresses clamped to block k when there is no next block, the term is dropped below
+                const uidx lo = zo + (uidx)((has_next ? b : 0) + n + m + i * n), co = ro + (uidx)((has_next ? R::LEN : 0) + R::COEF);
+                const double t = AT_vec<C>(recg + co, dt, [&](int rr) { return z[lo + (uidx)rr]; }, a);
+                r += has_next ? t : 0.0;
+            }
+            const bool own = (a % P == i);
+            const double tqv = G.Qd[i * ni + a / P], txv = G.xf[i * ni + a / P];
+            const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
+            const double xa = z[zo + (uidx)a];
+            r += w * (tq * (xa - tx));
+            if (C::POS) { const double gv = recg[ro + (uidx)(R::GVT + (i * P + a % P) * 2 + (a < 2 * P ? a / P : 0))]; r += (a < 2 * P) ? gv : 0.0; }
+            if constexpr (C::EXT) {
+                // StateBoundConstraint of player i (state_bound_constraint.jl:85-97): rows (x - x_max)[a], (x_min - x)[a]
+                double qsb = 0.0;
+                if (pr.has_sb && ok) {
 #pragma unroll
                     for (int half = 0; half < 2; half++) {
-                        const int ci = con_ctl<C>(pr, k, half * m + c);
-                        const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                        const int ci = ext_sb_row(pr, i, k, half * n + a);
+                        const double cv = half == 0 ? xa - ext_sbmax(pr, G.extc)[ei] : ext_sbmin(pr, G.extc)[ei] - xa;
                         G.vals[ci] = cv;
                         if (isfinite(cv)) {
                             const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
                             const double wl = lm + am * cv;
-                            g += (half == 0 ? wl : -wl); rhat += am;
-                            if (!IBR) vcon = fmax(vcon, fmax(0.0, cv));
-                            else if ((pr.ibr_ctl_rows[ip] >> (half * m + c)) & 1ull) vcon = fmax(vcon, fmax(0.0, cv));
+                            r += (half == 0 ? wl : -wl); qsb += am;
+                            if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, cv));
                         }
                     }
                 }
-                r = dt * (L.tr[c] * (u - L.tu[c])) + g + BT_vec<C>(Ck, dt, [&](int rr) { return lk[rr]; }, c);
-                if (IBR) mine = (i == ip);
-                if (zref && mine) dprox = u - Zr[n + uoff<C>(c)];
-                if (RECS) G.rec[(size_t)k * R::LEN + R::RHAT + c] = rhat;
-                if (MODE == 2) vrow = vu<C>(N, i, k) + c / P;
-            } else {
-                // dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint, RobotDynamics 0.3.1)
-                const int a = e - P * n - m;
-                double xn;
-                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-                    if (a < m) { const double vm = Bp[a + m] + (Bk[n + uoff<C>(a)] * dt) * 0.5; xn = Bp[a] + vm * dt; }
-                    else xn = Bp[a] + Bk[n + uoff<C>(a - m)] * dt;
-                } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
-                    const int blkk = a / P, i = a % P;
-                    if (blkk == 2) xn = Bp[a] + Bk[n + uoff<C>(i)] * dt;
-                    else {
-                        const double vm = Bp[2 * P + i] + (Bk[n + uoff<C>(i)] * dt) * 0.5;
-                        xn = Bp[a] + vm * Ck[(blkk == 0 ? 5 : (blkk == 1 ? 6 : 4)) * P + i];    // dt cos th / dt sin th / dt sin(beta)/lr
-                    }
-                } else {
-                    const int blkk = a / P, i = a % P;
-                    if (blkk <= 1) {
-                        const double vm = Bp[3 * P + i] + (Bk[n + uoff<C>(P + i)] * dt) * 0.5;
-                        xn = Bp[a] + vm * Ck[(blkk == 0 ? 1 : 3) * P + i];                  // dt cos(thm) / dt sin(thm)
-                    } else xn = Bp[a] + Bk[n + uoff<C>((blkk - 2) * P + i)] * dt;
-                }
-                r = xn - Bk[a];
-                dynrow = true;
-                if (IBR) mine = (a % P == ip);                 // dynamics_violation(model, pdtraj, i): entries pz[i]
-                if (MODE == 2) vrow = vd<C>(N, k) + a;
+                if (RECS && ok) G.rec[ro + (uidx)(R::RQ + ei)] = qsb;
             }
-            // regularize_residual! (global_quantities.jl:67-86): proximal term on the opt rows
-            const double rr = zref ? r + reg * dprox : r;
-            if (MODE == 3) { l1r += fabs(rr); }            // statistics / records of the unregularised rows
-            else r = rr;
-            bad |= !isfinite(r);
-            if (IBR) {
-                l1f += fabs(r);
-                if (dynrow) { l1 += fabs(r); if (mine) vdyn = fmax(vdyn, fabs(r)); }
-                else if (mine) { l1 += fabs(r); vopt = fmax(vopt, fabs(r)); }
-            } else {
-                l1 += fabs(r);
-                if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
-            }
-            if (RECS) G.rec[(size_t)k * R::LEN + R::RX + e] = r;               // rx | ru | rd are contiguous: coalesced
-            if (MODE == 2) G.res[vrow] = r;
+            q.mine = IBR ? (i == ip) : true;
+            q.dprox = 0.0;
+            if (zref) { const double xr = zref[zo + (uidx)a]; q.dprox = q.mine ? xa - xr : 0.0; }
+            q.r = r; q.rec_off = ro + (uidx)(R::RX + ei); q.vrow = MODE == 2 ? vx<C>(N, i, k) + a : 0;
+            return q;
+        };
+        const int total = (N - 1) * RXN;
+        int k0 = lane / RXN, j0 = lane % RXN, k1 = k0, j1 = j0;
+        advance(k1, j1, RXN);
+        for (int e = lane; e < total; e += 2 * WAVE) {
+            const Row qa = row_x(k0, j0, true), qb = row_x(k1, j1, e + WAVE < total);
+            finish_row(qa, false); finish_row(qb, false);
+            advance(k0, j0, RXN); advance(k0, j0, RXN); advance(k1, j1, RXN); advance(k1, j1, RXN);
         }
-        double prea[NAP];
+    }
+    // ---- rows opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
+    {
+        auto row_u = [&](int k, int c, bool ok) -> Row {
+            Row q; q.ok = ok;
+            if (!ok) { k = 0; c = 0; }
+            const int i = c % P;
+            const uidx zo = (uidx)(n + k * b), ro = (uidx)(k * R::LEN);
+            const double u = z[zo + (uidx)(n + uoff<C>(c))];
+            const uidx lo = zo + (uidx)(n + m + i * n);
+            const double tr = G.Rd[(c % P) * mi + c / P], tu = G.uf[(c % P) * mi + c / P];
+            double g = 0.0, rhat = dt * tr + jreg;
+            if (pr.has_ctl && ok) {
 #pragma unroll
-        for (int q = 0; q < NAP; q++) prea[q] = (k + 1 <= N - 2) ? load_aux(k + 1, lane + q * WAVE) : 0.0;
-        // rotate the window
-#pragma unroll
-        for (int q = 0; q < NPASS; q++) { const int e = lane + q * WAVE; if (e < b) L.blk[s3][e] = pre[q]; }
-        if (lane < n + m) L.zr[a0 ^ 1][lane] = prer;
-        __syncthreads();                 // everyone is done with aux[a0] (coefficients of knot k) before it is refilled
-#pragma unroll
-        for (int q = 0; q < NAP; q++) { const int t = lane + q * WAVE; if (t < AUX) L.aux[a0][t] = prea[q]; }
-        __syncthreads();
+                for (int half = 0; half < 2; half++) {
+                    const int ci = con_ctl<C>(pr, k, half * m + c);
+                    const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                    G.vals[ci] = cv;
+                    if (isfinite(cv)) {
+                        const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
+                        const double wl = lm + am * cv;
+                        g += (half == 0 ? wl : -wl); rhat += am;
+                        if (!IBR) vcon = fmax(vcon, fmax(0.0, cv));
+                        else if ((pr.ibr_ctl_rows[ip] >> (half * m + c)) & 1ull) vcon = fmax(vcon, fmax(0.0, cv));
+                    }
+                }
+            }
+            q.r = dt * (tr * (u - tu)) + g + BT_vec<C>(recg + ro + (uidx)R::COEF, dt, [&](int rr) { return z[lo + (uidx)rr]; }, c);
+            q.mine = IBR ? (i == ip) : true;
+            q.dprox = 0.0;
+            if (zref) { const double ur = zref[zo + (uidx)(n + uoff<C>(c))]; q.dprox = q.mine ? u - ur : 0.0; }
+            if (RECS && ok) G.rec[ro + (uidx)(R::RHAT + c)] = rhat;
+            q.rec_off = ro + (uidx)(R::RU + c); q.vrow = MODE == 2 ? vu<C>(N, i, k) + c / P : 0;
+            return q;
+        };
+        const int total = (N - 1) * m;
+        int k0 = lane / m, j0 = lane % m, k1 = k0, j1 = j0;
+        advance(k1, j1, m);
+        for (int e = lane; e < total; e += 2 * WAVE) {
+            const Row qa = row_u(k0, j0, true), qb = row_u(k1, j1, e + WAVE < total);
+            finish_row(qa, false); finish_row(qb, false);
+            advance(k0, j0, m); advance(k0, j0, m); advance(k1, j1, m); advance(k1, j1, m);
+        }
+    }
+    // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint, RobotDynamics 0.3.1)
+    {
+        auto row_d = [&](int k, int a, bool ok) -> Row {
+            Row q; q.ok = ok;
+            if (!ok) { k = 0; a = 0; }
+            const uidx zo = (uidx)(n + k * b), ro = (uidx)(k * R::LEN);
+            const uidx po = (k == 0) ? 0u : zo - (uidx)b;                   // x_k: x_1 sits in front of block 0
+            const double* Ck = recg + ro + (uidx)R::COEF;
+            double xn;
+            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                // position rows: x + (v + dt/2 u) dt ; velocity rows: v + u dt
+                const int j = a < m ? a : a - m;
+                const double uj = z[zo + (uidx)(n + uoff<C>(j))], base = z[po + (uidx)a], vel = z[po + (uidx)(j + m)];
+                const double vm = vel + (uj * dt) * 0.5;
+                xn = base + (a < m ? vm : uj) * dt;
+            } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                const int blkk = a / P, i = a % P;
+                const double ua = z[zo + (uidx)(n + uoff<C>(i))], base = z[po + (uidx)a], vel = z[po + (uidx)(2 * P + i)];
+                const double vm = vel + (ua * dt) * 0.5;
+                const double cf = Ck[(blkk == 0 ? 5 : (blkk == 1 ? 6 : 4)) * P + i];    // dt cos th / dt sin th / dt sin(beta)/lr
+                xn = (blkk == 2) ? base + ua * dt : base + vm * cf;
+            } else {
+                const int blkk = a / P, i = a % P;
+                const double ua = z[zo + (uidx)(n + uoff<C>(P + i))], base = z[po + (uidx)a], vel = z[po + (uidx)(3 * P + i)];
+                const double uo = z[zo + (uidx)(n + uoff<C>((blkk >= 2 ? blkk - 2 : 0) * P + i))];
+                const double vm = vel + (ua * dt) * 0.5;
+                const double cf = Ck[(blkk == 0 ? 1 : 3) * P + i];                      // dt cos(thm) / dt sin(thm)
+                xn = (blkk <= 1) ? base + vm * cf : base + uo * dt;
+            }
+            q.r = xn - z[zo + (uidx)a];
+            q.mine = IBR ? (a % P == ip) : true;                           // dynamics_violation(model, pdtraj, i): entries pz[i]
+            q.dprox = 0.0; q.rec_off = ro + (uidx)(R::RD + a); q.vrow = MODE == 2 ? vd<C>(N, k) + a : 0;
+            return q;
+        };
+        const int total = (N - 1) * n;
+        int k0 = lane / n, j0 = lane % n, k1 = k0, j1 = j0;
+        advance(k1, j1, n);
+        for (int e = lane; e < total; e += 2 * WAVE) {
+            const Row qa = row_d(k0, j0, true), qb = row_d(k1, j1, e + WAVE < total);
+            finish_row(qa, true); finish_row(qb, true);
+            advance(k0, j0, n); advance(k0, j0, n); advance(k1, j1, n); advance(k1, j1, n);
+        }
     }
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
     out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);

@@ -84,6 +84,8 @@ struct Cfg {
     static constexpr int WPE = (n >= 16) ? 2 : 4;
     // reuse the accepted line-search trial as the next record! (costs registers: off for the large configurations)
     static constexpr bool TRIAL_REUSE = (n < 16);
+    // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
+    static constexpr int ASM_UNROLL = 2;
 };
 
 // ---- index maps (newton_core.jl:40-89), 0-based --------------------------------------------------
@@ -468,16 +470,18 @@ struct DirLds {
         double fv[C::n];
         double t[C::P * C::n];         // t_i = P_i f + s_i (n == 16 path) / y_i = P_i rd + s_i
         double V[C::m * VW];
+        double T[C::n * C::n];         // A_k transposed: T[c][r] = A_k[r][c] (column c of A_k contiguous, read by lane m + c)
         double pad[1];                 // dump slot for the masked-off lanes of the MFMA result write-back
     };
     struct Fwd {                       // live only during the forward / costate sweeps
         double kg[2][C::m * (C::n + 1)];
         double dx[C::n], du[C::m];
         double dl[C::P * C::n];
+        double hx[NHX];                // expanded pair-Hessian table of the costate sweep
     };
     union { Bwd bw; Fwd fw; };
     double rec[2][Rec<C>::LEN_SWEEP];
-    double hx[NHX];
+    double hxb[AUGS ? 1 : NHX];        // ... and of the backward sweep when it still needs one (n == 16)
     double coefn[C::NC > 0 ? C::NC : 1];
     double qdf[C::P * C::n];           // LQR diagonal of player i padded to joint dims (zero off pz[i])
 };
@@ -607,7 +611,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     // three flat row loops (opt_x | opt_u | dyn), work item = one row, operands read straight from the trajectory (the
     // neighbouring lanes read neighbouring addresses; everything is L1/L2 resident after the first touch).
     // Index arithmetic is incremental and all offsets are 32-bit unsigned so that the loads use the scalar-base + vector-
-    // offset addressing mode.  Each lane handles two rows per pass (row e and row e + 64): the loads of both are in flight
+    // offset addressing mode.  Each lane handles ASM_UNROLL rows per pass (rows e, e + 64, ...): their loads are in flight
     // together, which halves the exposed L2 latency.
     typedef unsigned uidx;
     struct Row { double r, dprox; bool mine, ok; uidx rec_off; int vrow; };
@@ -632,7 +636,22 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     };
     const double* __restrict__ recg = G.rec;
     // advance (k, j) by 64 rows of a row space with LEN rows per step
-    auto advance = [](int& k, int& j, int LEN) { j += WAVE % LEN; k += WAVE / LEN; if (j >= LEN) { j -= LEN; k += 1; } };
+    constexpr int UR = C::ASM_UNROLL;
+    auto run_rows = [&](auto&& row, int LEN, bool dynrow) {
+        const int total = (N - 1) * LEN, stepk = (UR * WAVE) / LEN, stepj = (UR * WAVE) % LEN;
+        int k[UR], j[UR];
+#pragma unroll
+        for (int t = 0; t < UR; t++) { const int e0 = lane + t * WAVE; k[t] = e0 / LEN; j[t] = e0 % LEN; }
+        for (int e = lane; e < total; e += UR * WAVE) {
+            Row q[UR];
+#pragma unroll
+            for (int t = 0; t < UR; t++) q[t] = row(k[t], j[t], e + t * WAVE < total);
+#pragma unroll
+            for (int t = 0; t < UR; t++) finish_row(q[t], dynrow);
+#pragma unroll
+            for (int t = 0; t < UR; t++) { j[t] += stepj; k[t] += stepk; if (j[t] >= LEN) { j[t] -= LEN; k[t] += 1; } }
+        }
+    };
     // ---- rows opt_i,x_{k+1}[a] = cost grad + pair terms + A_{k+1}' lambda_{i,k+1} - lambda_{i,k} (+ reg (x - xref))
     {
         constexpr int RXN = P * n;
@@ -682,14 +701,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             q.r = r; q.rec_off = ro + (uidx)(R::RX + ei); q.vrow = MODE == 2 ? vx<C>(N, i, k) + a : 0;
             return q;
         };
-        const int total = (N - 1) * RXN;
-        int k0 = lane / RXN, j0 = lane % RXN, k1 = k0, j1 = j0;
-        advance(k1, j1, RXN);
-        for (int e = lane; e < total; e += 2 * WAVE) {
-            const Row qa = row_x(k0, j0, true), qb = row_x(k1, j1, e + WAVE < total);
-            finish_row(qa, false); finish_row(qb, false);
-            advance(k0, j0, RXN); advance(k0, j0, RXN); advance(k1, j1, RXN); advance(k1, j1, RXN);
-        }
+        run_rows(row_x, RXN, false);
     }
     // ---- rows opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
     {
@@ -725,14 +737,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             q.rec_off = ro + (uidx)(R::RU + c); q.vrow = MODE == 2 ? vu<C>(N, i, k) + c / P : 0;
             return q;
         };
-        const int total = (N - 1) * m;
-        int k0 = lane / m, j0 = lane % m, k1 = k0, j1 = j0;
-        advance(k1, j1, m);
-        for (int e = lane; e < total; e += 2 * WAVE) {
-            const Row qa = row_u(k0, j0, true), qb = row_u(k1, j1, e + WAVE < total);
-            finish_row(qa, false); finish_row(qb, false);
-            advance(k0, j0, m); advance(k0, j0, m); advance(k1, j1, m); advance(k1, j1, m);
-        }
+        run_rows(row_u, m, false);
     }
     // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint, RobotDynamics 0.3.1)
     {
@@ -768,14 +773,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             q.dprox = 0.0; q.rec_off = ro + (uidx)(R::RD + a); q.vrow = MODE == 2 ? vd<C>(N, k) + a : 0;
             return q;
         };
-        const int total = (N - 1) * n;
-        int k0 = lane / n, j0 = lane % n, k1 = k0, j1 = j0;
-        advance(k1, j1, n);
-        for (int e = lane; e < total; e += 2 * WAVE) {
-            const Row qa = row_d(k0, j0, true), qb = row_d(k1, j1, e + WAVE < total);
-            finish_row(qa, true); finish_row(qb, true);
-            advance(k0, j0, n); advance(k0, j0, n); advance(k1, j1, n); advance(k1, j1, n);
-        }
+        run_rows(row_d, n, true);
     }
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
     out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
@@ -1021,6 +1019,12 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     for (int e = lane; e < 16 * 16; e += WAVE) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
     for (int e = lane; e < P * n * LDP; e += WAVE) L.bw.Pm[e] = 0.0;
     for (int e = lane; e < m * VW; e += WAVE) L.bw.V[e] = 0.0;
+    for (int e = lane; e < n * n; e += WAVE) {                     // constant part of A' (the coefficient entries follow per step)
+        const int c = e / n, r = e % n;
+        double v = (r == c) ? 1.0 : 0.0;
+        if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { if (r < m && c == r + m) v = dt; }
+        L.bw.T[e] = v;
+    }
     if (lane == 0) L.bw.pad[0] = 0.0;
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     // ---- loop-invariant lane roles of the MFMA tiles: register r4 holds (row = lq + 4 r4, col = lrow)
@@ -1077,7 +1081,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
             qam.apply(lane, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
         } else {
-            hxm.expand(lane, Rc, L.hx);
+            hxm.expand(lane, Rc, L.hxb);
             if (k < N - 2) {
                 // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
                 for (int e = lane; e < P * n; e += WAVE) {
@@ -1105,7 +1109,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                         const int row = lq + 4 * r4;
                         double v = diag[r4] ? reg + w * L.qdf[i * n + row] : 0.0;
                         if constexpr (C::EXT) { const double qv = Rc[R::RQ + i * n + row]; v += diag[r4] ? qv : 0.0; }
-                        if (C::POS) { const double hv = L.hx[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
+                        if (C::POS) { const double hv = L.hxb[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
                         c2[r4] = v;
                     }
                     if (k < N - 2) {
@@ -1137,17 +1141,32 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
-        // ---- V[c][0..n) = B[:,c]' P_{i(c)},  V[c][n+1+c] = R^_c,  y_i = P_i rd + s_i
-        for (int e = lane; e < m * n; e += WAVE) {
-            const int c = e / n, col = e % n; const double* Pi = &L.bw.Pm[(c % P) * n * LDP];
-            L.bw.V[c * VW + col] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
+        // ---- V[c][0..n) = B[:,c]' P_{i(c)},  V[c][n+1+c] = R^_c,  y_i = P_i rd + s_i   (lane = 16 c + col: shifts, no divisions)
+#pragma unroll
+        for (int q = 0; q < (m + 3) / 4; q++) {
+            const int c = 4 * q + lq, col = lrow;
+            if (c < m && col < n) {
+                const double* Pi = &L.bw.Pm[(c % P) * n * LDP];
+                L.bw.V[c * VW + col] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
+            }
         }
-        for (int e = lane; e < P * n; e += WAVE) {
-            const double* Pr = &L.bw.Pm[(e / n) * n * LDP + (e % n) * LDP];
+        static_assert(P * 16 <= WAVE, "one (player, row) per lane");
+        if (lq < P && lrow < n) {
+            const double* Pr = &L.bw.Pm[lq * n * LDP + lrow * LDP];
             double a = Pr[n];
 #pragma unroll
             for (int c = 0; c < n; c++) a += Pr[c] * Rc[R::RD + c];
-            L.bw.t[e] = a;
+            L.bw.t[lq * n + lrow] = a;
+        }
+        // coefficient entries of A_k' (state-dependent models)
+        if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
+            if (lane < 4 * P) { const int kind = lane / P, i = lane % P; L.bw.T[(((kind & 1) ? 3 : 2) * P + i) * n + ((kind >> 1) ? P + i : i)] = coefk[lane]; }
+        } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+            if (lane < 5 * P) {
+                const int kind = lane / P, i = lane % P;        // (x,psi) (x,v) (y,psi) (y,v) (psi,v)
+                const int colb = (kind == 0 || kind == 2) ? 3 : 2, row = kind < 2 ? i : (kind < 4 ? P + i : 3 * P + i);
+                L.bw.T[(colb * P + i) * n + row] = coefk[lane];
+            }
         }
         if (lane < m) L.bw.V[lane * VW + n + 1 + lane] = Rc[R::RHAT + lane];
         __syncthreads();
@@ -1183,11 +1202,11 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             double* __restrict__ Kg = G.kgain + (size_t)k * NK + cc * m;
 #pragma unroll
             for (int c = 0; c < m; c++) { col[c] = -col[c]; Kg[c] = col[c]; }
+            // column cc of [A_k | rd]: contiguous in LDS (T row cc, or the record's rd); A_0 is never used (dx_1 = 0)
+            const double* acol = (cc < n) ? &L.bw.T[cc * n] : Rc + R::RD;
 #pragma unroll
             for (int r = 0; r < n; r++) {
-                double v = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r);
-                const double av = (k >= 1) ? A_entry<C>(coefk, dt, r, cc < n ? cc : 0) : 0.0;
-                v += (cc < n) ? av : Rc[R::RD + r];
+                const double v = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r) + acol[r];
                 if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = v;              // f rides in tile column n
                 else { if (cc < n) L.bw.Fx[r * 16 + cc] = v; else L.bw.fv[r] = v; }
             }
@@ -1253,7 +1272,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         }
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         if (lane < n) L.fw.dx[lane] = dz[n + hx<C>(k) + lane];
-        hxm.expand(lane, Rc, L.hx);
+        hxm.expand(lane, Rc, L.fw.hx);
         __syncthreads();
         double acc = 0.0;
         if (lane < P * n && (!IBR || ci_ == ip)) {
@@ -1261,7 +1280,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             if constexpr (C::EXT) qd += Rc[R::RQ + lane];
             acc = Rc[R::RX + lane] + qd * L.fw.dx[cr_];
             if (cpos) {
-                const double* hrow = &L.hx[(ci_ * P + cr_ % P) * P * 3 + cr_ / P];
+                const double* hrow = &L.fw.hx[(ci_ * P + cr_ % P) * P * 3 + cr_ / P];
 #pragma unroll
                 for (int c = 0; c < 2 * P; c++) acc += hrow[(c % P) * 3 + c / P] * L.fw.dx[c];
             }

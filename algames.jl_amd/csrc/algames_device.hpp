@@ -1000,7 +1000,7 @@ struct QaddMap {
 // IBR = true: best response of player ip -- only x, u_ip, lambda_ip move (horizontal mask, newton_core.jl:249-294): the other
 // players' value recursions are skipped, their rows of the control system become unit rows (du_j = 0), dlambda_j = 0.
 template <class C, bool IBR = false>
-__device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg, int ip = -1) {
+__device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
     using R = Rec<C>;
     const int N = pr.N, lane = phase_lane();
@@ -1225,6 +1225,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain[e];
     __syncthreads();
     cur = 0;
+    double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
+    int bad = 0;                                    // non-finite direction entries (checked where they are produced)
     for (int k = 0; k < N - 1; k++, cur ^= 1) {
         const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
         double pre[RPL], prek[KPL];
@@ -1238,7 +1240,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             double acc = Kl[n * m + lane];
 #pragma unroll
             for (int q = 0; q < n; q++) acc += Kl[q * m + lane] * L.fw.dx[q];
-            L.fw.du[lane] = acc;
+            L.fw.du[lane] = acc; pl1 += fabs(acc); bad |= !isfinite(acc);
             dz[n + hu<C>(k, 0) + uoff<C>(lane)] = acc;
         }
         __syncthreads();
@@ -1246,7 +1248,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         if (lane < n) dxn = A_vec<C>(Rc + R::COEF, dt, [&](int rr) { return L.fw.dx[rr]; }, lane)
                           + B_vec<C>(Rc + R::COEF, dt, [&](int cc) { return L.fw.du[cc]; }, lane) + Rc[R::RD + lane];
         __syncthreads();
-        if (lane < n) { L.fw.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; }
+        if (lane < n) { L.fw.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; pl1 += fabs(dxn); bad |= !isfinite(dxn); }
         if (k + 1 < N - 1) {
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
@@ -1261,17 +1263,19 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
     const bool cpos = C::POS && cr_ < 2 * P;
+    double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched one step ahead like the records
     __syncthreads();
     cur = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
         double pre[RPL];
+        if (lane < n) L.fw.dx[lane] = dxk;
         if (k > 0) {
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+            if (lane < n) dxk = dz[n + hx<C>(k - 1) + lane];
         }
         const double w = (k + 1 < N - 1) ? dt : 1.0;
-        if (lane < n) L.fw.dx[lane] = dz[n + hx<C>(k) + lane];
         hxm.expand(lane, Rc, L.fw.hx);
         __syncthreads();
         double acc = 0.0;
@@ -1287,7 +1291,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
         __syncthreads();
-        if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; }
+        if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; bad |= !isfinite(acc); }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         if (k > 0) {
 #pragma unroll
@@ -1296,8 +1300,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         __syncthreads();
     }
     // non-finite direction -> singular (the reference would throw / propagate NaN)
-    int bad = 0;
-    for (int e = lane; e < pr.S; e += WAVE) bad |= !isfinite(dz[n + e]);
+    if (primal_l1) *primal_l1 = wave_sum(pl1);
     return wave_or(bad) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;
 }
 
@@ -1413,7 +1416,7 @@ __device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double r
 // inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
 // the history record / *info (lane 0).  `cache` (optional) carries an accepted trial's statistics to the next call.
 template <class C>
-__device__ int inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l,
+__device__ int inner_iteration(const Params& pr, Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l,
                                alg_step_info* info, int* cache_valid) {
     const alg_options& o = pr.opt;
     const double lf = (double)l;
@@ -1427,7 +1430,8 @@ __device__ int inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& 
     auto finish = [&](int status, int flow) { if (info && threadIdx.x == 0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
     if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1);              // :80-82
-    const int st = newton_direction<C>(pr, G, L.d, reg);                   // :84-88
+    double pl1;
+    const int st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);         // :84-88
     if (st != ALG_STATUS_OK) return finish(st, 1);
     __syncthreads();
     double alpha; int j;
@@ -1437,8 +1441,11 @@ __device__ int inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& 
     const int failed = (j == o.ls_iter);                                   // :92
     if (failed) LS_count += 1; else LS_count = 0;                          // :93
     __syncthreads();
-    update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);                     // :94  (== the accepted trial, bit for bit)
-    Delta = uni(delta_step<C>(pr, G.z[2], alpha));                         // :95
+    // :94 update_traj!(pdtraj, pdtraj, alpha, delta): the last trial already holds exactly these values unless the search ran
+    // out of trials (alpha was halved once more after the last trial) -> exchange the roles of the two buffers
+    if (!failed) { double* t = G.z[0]; G.z[0] = G.z[1]; G.z[1] = t; }
+    else update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);
+    { double sd = pl1; sd *= alpha; sd /= (double)((pr.N - 1) * (C::n + C::m)); Delta = uni(sd); }     // :95 Delta_step
     __syncthreads();
     if (reuse && !failed) *cache_valid = 1;
     if (threadIdx.x == 0) {
@@ -1568,9 +1575,23 @@ __device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t g
     __syncthreads();
 }
 
+// After an odd number of buffer exchanges pdtraj lives in the trial buffer: move it home (and leave the trial buffer with
+// the previous iterate, as update_traj! would have)
+template <class C>
+__device__ __forceinline__ void settle_traj(const Params& pr, Game& G, double* z_home) {
+    if (G.z[0] != z_home) {
+        __syncthreads();
+        double* a = G.z[0];
+        for (int e = phase_lane(); e < pr.traj_len; e += WAVE) { const double v = a[e]; a[e] = z_home[e]; z_home[e] = v; }
+        G.z[1] = a; G.z[0] = z_home;
+        __syncthreads();
+    }
+}
+
 // newton_solve! (solver_methods.jl:5-65)
 template <class C>
-__device__ void newton_solve(const Params& pr, const Game& G, Lds<C>& L, int init, uint64_t game_id) {
+__device__ void newton_solve(const Params& pr, Game& G, Lds<C>& L, int init, uint64_t game_id) {
+    double* const z_home = G.z[0];
     const alg_options& o = pr.opt; const int lane = threadIdx.x;
     if (lane == 0) { alg_game_stats z{}; *G.st = z; }                       // reset!(prob.stats)
 #ifndef ALG_TEST_NOINIT
@@ -1605,6 +1626,7 @@ __device__ void newton_solve(const Params& pr, const Game& G, Lds<C>& L, int ini
     }
     __syncthreads();
     make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);                    // :63
+    settle_traj<C>(pr, G, z_home);
     if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; }
 }
 

@@ -23,7 +23,9 @@ __global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, Buffers
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
     int ls = 0; double dl = 0.0;
+    double* const z_home = G.z[0];
     inner_iteration<C>(pr, G, L, ls, dl, k, l, out + g, nullptr);
+    settle_traj<C>(pr, G, z_home);
 }
 
 template <class C>

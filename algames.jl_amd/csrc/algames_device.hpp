@@ -1221,7 +1221,11 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     if (sing) return ALG_STATUS_SINGULAR;              // wave-uniform (every lane factors the same matrix)
     // ------------------------------------------------------------------ forward sweep: dx, du
     if (lane < n) { L.fw.dx[lane] = 0.0; dz[lane] = 0.0; }
-    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[e];
+    // the forward sweep reads only [coef | rd] of a record: one load per lane
+    static_assert(C::NC + n <= WAVE, "forward sweep record slice");
+    const int fro = lane < C::NC ? R::COEF + lane : R::RD + (lane - C::NC);      // record offset of this lane's slice entry
+    const bool frok = lane < C::NC + n;
+    if (frok) L.rec[0][fro] = G.rec[fro];
     for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain[e];
     __syncthreads();
     cur = 0;
@@ -1229,10 +1233,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     int bad = 0;                                    // non-finite direction entries (checked where they are produced)
     for (int k = 0; k < N - 1; k++, cur ^= 1) {
         const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
-        double pre[RPL], prek[KPL];
+        double pref = 0.0, prek[KPL];
         if (k + 1 < N - 1) {
-#pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k + 1) * R::LEN + e] : 0.0; }
+            if (frok) pref = G.rec[(size_t)(k + 1) * R::LEN + fro];
 #pragma unroll
             for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; prek[q] = e < NK ? G.kgain[(size_t)(k + 1) * NK + e] : 0.0; }
         }
@@ -1250,8 +1253,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         __syncthreads();
         if (lane < n) { L.fw.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; pl1 += fabs(dxn); bad |= !isfinite(dxn); }
         if (k + 1 < N - 1) {
-#pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
+            if (frok) L.rec[cur ^ 1][fro] = pref;
 #pragma unroll
             for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.fw.kg[cur ^ 1][e] = prek[q]; }
         }

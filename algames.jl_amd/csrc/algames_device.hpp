@@ -433,19 +433,21 @@ __device__ __forceinline__ double circ_val(const double* Cc, int c, double x, do
 // ================================================================================================
 // Step records.  The assemble pass leaves one compact record per time step k in HBM; the serial sweeps of the Newton
 // direction read nothing else (plus the gains they spill themselves).
-//   [coefk (NC)] [Hh (3 NPAIR): pair Hessian blocks at knot k+1] [Hd (3 P): sum_j Hh(i,j)] [Rhat (m): R^ of knot k incl. reg]
+//   [coefk (NC)] [Hh (3 NPAIR): pair Hessian blocks at knot k+1] [Hd (3 P): sum_j Hh(i,j)]
 //   (EXT only: [RQ (P n): diagonal state-bound Hessian of player i at knot k+1])
-//   [rx (P n): rows opt_i,x_{k+1}] [ru (m): rows opt_i,u_{i,k}, joint order] [rd (n): dyn_k]      <- LEN_SWEEP
+//   [rx (P n): rows opt_i,x_{k+1}]                                                                  <- LEN_COSTATE
+//   [Rhat (m): R^ of knot k incl. reg] [ru (m): rows opt_i,u_{i,k}, joint order] [rd (n): dyn_k]      <- LEN_SWEEP
 //   [gvt (2 P^2): pair gradient table, only used inside the assemble pass]
 // ================================================================================================
 template <class C> struct Rec {
     static constexpr int COEF = 0;
     static constexpr int HH = COEF + C::NC;
     static constexpr int HD = HH + 3 * C::NPAIR;
-    static constexpr int RHAT = HD + 3 * C::P;
-    static constexpr int RQ = RHAT + C::m;
+    static constexpr int RQ = HD + 3 * C::P;
     static constexpr int RX = RQ + (C::EXT ? C::P * C::n : 0);
-    static constexpr int RU = RX + C::P * C::n;
+    static constexpr int LEN_COSTATE = RX + C::P * C::n;          // the costate sweep reads [coef | Hh | Hd | RQ | rx] only
+    static constexpr int RHAT = LEN_COSTATE;
+    static constexpr int RU = RHAT + C::m;
     static constexpr int RD = RU + C::m;
     static constexpr int LEN_SWEEP = RD + C::n;
     static constexpr int GVT = LEN_SWEEP;
@@ -1262,7 +1264,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     if constexpr (AUGS) hxm.init(phase_lane());
-    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
+    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
     const bool cpos = C::POS && cr_ < 2 * P;
     double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched one step ahead like the records
@@ -1270,11 +1273,11 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     cur = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
-        double pre[RPL];
+        double pre[RPLC];
         if (lane < n) L.fw.dx[lane] = dxk;
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_COSTATE ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
             if (lane < n) dxk = dz[n + hx<C>(k - 1) + lane];
         }
         const double w = (k + 1 < N - 1) ? dt : 1.0;
@@ -1297,7 +1300,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
+            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) L.rec[cur ^ 1][e] = pre[q]; }
         }
         __syncthreads();
     }

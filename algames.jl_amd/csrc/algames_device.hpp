@@ -483,7 +483,6 @@ struct DirLds {
     };
     union { Bwd bw; Fwd fw; };
     double rec[2][Rec<C>::LEN_SWEEP];
-    double hxb[AUGS ? 1 : NHX];        // ... and of the backward sweep when it still needs one (n == 16)
     double coefn[C::NC > 0 ? C::NC : 1];
     double qdf[C::P * C::n];           // LQR diagonal of player i padded to joint dims (zero off pz[i])
 };
@@ -940,13 +939,14 @@ struct HxMap {
     }
 };
 
-// Non-zeros of [Q^_i | rx_i] (n < 16 path): after the MFMA products wrote A'(P F) back, every lane adds its entries
+// Non-zeros of [Q^_i | rx_i] (rx_i only when s_i rides in tile column n, n < 16): after the MFMA products wrote A'(P F) back, every lane adds its entries
 //   (r, r): reg + w q_i,r (+ state-bound Hessian) (+ position-block diagonal)   (r, c) r != c < 2P: position block   (r, n): rx_i,r
 // into row block i of Pm.  Per lane and pass: packed (dst | src << 11 | qi << 19), sign of the record source, diagonal flag.
 template <class C>
 struct QaddMap {
     static constexpr int OFF = C::POS ? 4 * C::P * C::P - 2 * C::P : 0;
-    static constexpr int QE = C::n + OFF + C::n, QTOT = C::P * QE, PASSES = (QTOT + WAVE - 1) / WAVE;
+    static constexpr bool RXCOL = C::n < 16;             // s_i lives in tile column n (else it is updated on the VALU)
+    static constexpr int QE = C::n + OFF + (RXCOL ? C::n : 0), QTOT = C::P * QE, PASSES = (QTOT + WAVE - 1) / WAVE;
     unsigned code[PASSES]; float sgn[PASSES], dfl[PASSES];
     __device__ __forceinline__ static void hxsrc(int i, int jr, int jc, int h, int& so, float& sg) {
         using R = Rec<C>;
@@ -959,7 +959,7 @@ struct QaddMap {
     __device__ __forceinline__ void init(int lane) {
         constexpr int n = C::n, P = C::P, LDP = n + 1;
         using R = Rec<C>;
-        static_assert(C::P * n * LDP < 2048 && R::LEN_SWEEP < 256 && P * n < 64, "QaddMap packing");
+        static_assert(C::P * n * LDP < 2048 && R::LEN_SWEEP < 256 && P * n <= 64, "QaddMap packing");
 #pragma unroll
         for (int q = 0; q < PASSES; q++) {
             const int e = lane + q * WAVE;
@@ -1013,10 +1013,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
     constexpr bool AUGS = DirLds<C>::AUGS;               // s_i rides through the first MFMA product (n < 16)
     constexpr int KB1 = DirLds<C>::KB1, VW = DirLds<C>::VW;
-    HxMap<C> hxm;
-    if constexpr (!AUGS) hxm.init(lane);
-    QaddMap<C> qam;
-    if constexpr (AUGS) qam.init(lane);
+    HxMap<C> hxm;                                        // costate sweep only (initialised there)
+    QaddMap<C> qam; qam.init(lane);
     for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd[i * C::ni + r / P] : 0.0; }
     for (int e = lane; e < 16 * 16; e += WAVE) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
     for (int e = lane; e < P * n * LDP; e += WAVE) L.bw.Pm[e] = 0.0;
@@ -1030,14 +1028,10 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     if (lane == 0) L.bw.pad[0] = 0.0;
     for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     // ---- loop-invariant lane roles of the MFMA tiles: register r4 holds (row = lq + 4 r4, col = lrow)
-    const bool colP = lrow < n, colS = (lrow == n) && (n < 16), colB = lrow < 2 * P;
-    int hxo[4]; bool rowok[4], diag[4], inb[4];
+    const bool colP = lrow < n;
+    bool rowok[4];
 #pragma unroll
-    for (int r4 = 0; r4 < 4; r4++) {
-        const int row = lq + 4 * r4;
-        rowok[r4] = row < n; diag[r4] = rowok[r4] && row == lrow; inb[r4] = C::POS && row < 2 * P && colB;
-        hxo[r4] = inb[r4] ? ((row % P) * P + lrow % P) * 3 + row / P + lrow / P : 0;
-    }
+    for (int r4 = 0; r4 < 4; r4++) rowok[r4] = (lq + 4 * r4) < n;
     __syncthreads();
     double* const bwb = reinterpret_cast<double*>(&L.bw);
     constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
@@ -1048,88 +1042,51 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         const double* Rc = L.rec[cur];
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         const double* coefk = Rc + R::COEF;
-        if constexpr (AUGS) {
-            // ---- [P_i | s_i] [[F f],[0 1]] = [P_i F | P_i f + s_i], then A' x that: two chained f64 MFMA products per player,
-            // accumulators start at zero; the sparse Q^_i / rx_i are added afterwards (Q-add phase).  Player i's chain reads only
-            // row block i of Pm, so its result is written back before the next player starts: one accumulator tile live.
-            if (k < N - 2) {
-                double bF[KB1], aA[KB];
-#pragma unroll
-                for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
-#pragma unroll
-                for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
-#pragma unroll
-                for (int i = 0; i < P; i++) {
-                    if (IBR && i != ip) continue;
-                    double4_t c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int kb = 0; kb < KB1; kb++) {
-                        // columns n+1.. of the last k-block read past the row (finite values) and meet zero rows of Fx
-                        const double pv = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
-                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
-                    __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) {
-                        const int row = lq + 4 * r4;
-                        const int slot = (rowok[r4] && lrow <= n) ? oPm + i * n * LDP + row * LDP + lrow : oPad;
-                        bwb[slot] = c2[r4];
-                    }
-                }
-                __syncthreads();
-            }
-            // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
-            qam.apply(lane, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
-        } else {
-            hxm.expand(lane, Rc, L.hxb);
-            if (k < N - 2) {
-                // no spare tile column: t_i = P_i f + s_i on the VALU (one (i,r) per lane)
-                for (int e = lane; e < P * n; e += WAVE) {
+        // ---- value recursion.  n < 16: [P_i | s_i] [[F f],[0 1]] = [P_i F | P_i f + s_i], then A' x that -- two chained f64 MFMA
+        // products per player (f and s_i ride in the spare tile column / k-block).  n == 16: the products cover P_i only and
+        // s_i <- rx_i + A'(P_i f + s_i) runs on the VALU.  Accumulators start at zero; the sparse Q^_i (and rx_i) are added
+        // afterwards (Q-add phase).  Player i's chain reads only row block i of Pm, so its result is written back before the
+        // next player starts: one accumulator tile live.
+        if (k < N - 2) {
+            if constexpr (!AUGS) {
+                for (int e = lane; e < P * n; e += WAVE) {                  // t_i = P_i f + s_i (one (i,r) per lane)
                     const int i = e / n, r = e % n; double a = L.bw.Pm[i * n * LDP + r * LDP + n];
                     for (int c = 0; c < n; c++) a += L.bw.Pm[i * n * LDP + r * LDP + c] * L.bw.fv[c];
                     L.bw.t[e] = a;
                 }
+                __syncthreads();
+            }
+            double bF[KB1], aA[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                if (IBR && i != ip) continue;
+                double4_t c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kb = 0; kb < KB1; kb++) {
+                    // n < 16: columns n+1.. of the last k-block read past the row (finite values) and meet zero rows of Fx
+                    const double pv = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
+                __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int row = lq + 4 * r4;
+                    const int slot = (rowok[r4] && lrow < n + (AUGS ? 1 : 0)) ? oPm + i * n * LDP + row * LDP + lrow : oPad;
+                    bwb[slot] = c2[r4];
+                }
             }
             __syncthreads();
-            {
-                double bF[KB], aA[KB];
-                if (k < N - 2) {
-#pragma unroll
-                    for (int kb = 0; kb < KB; kb++) {
-                        bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
-                        aA[kb] = A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow);                 // (A')[lrow][k] = A[k][lrow]
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < P; i++) {
-                    if (IBR && i != ip) continue;
-                    double4_t c2;                                   // C-init of the second product: Q^_i
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) {
-                        const int row = lq + 4 * r4;
-                        double v = diag[r4] ? reg + w * L.qdf[i * n + row] : 0.0;
-                        if constexpr (C::EXT) { const double qv = Rc[R::RQ + i * n + row]; v += diag[r4] ? qv : 0.0; }
-                        if (C::POS) { const double hv = L.hxb[i * P * P * 3 + hxo[r4]]; v += inb[r4] ? hv : 0.0; }
-                        c2[r4] = v;
-                    }
-                    if (k < N - 2) {
-                        double4_t c1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int kb = 0; kb < KB; kb++) {
-                            const double pv = L.bw.Pm[i * n * LDP + lrow * LDP + 4 * kb + lq];
-                            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pv, bF[kb], c1, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) L.bw.Pm[i * n * LDP + (lq + 4 * r4) * LDP + lrow] = c2[r4];
-                }
-            }
-            for (int e = lane; e < P * n; e += WAVE) {
+        }
+        // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
+        qam.apply(lane, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
+        if constexpr (!AUGS) {
+            for (int e = lane; e < P * n; e += WAVE) {                      // s_i <- rx_i + A_{k+1}' t_i
                 const int i = e / n, r = e % n; const double* ti = &L.bw.t[i * n];
                 double v = Rc[R::RX + e];
                 if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
@@ -1263,7 +1220,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     }
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    if constexpr (AUGS) hxm.init(phase_lane());
+    hxm.init(phase_lane());
     constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
     for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane

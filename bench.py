@@ -37,14 +37,25 @@ def survey_balg(N, n, m, p):
     return 8 * (2 * (S + n) + 2 * (N - 1) * (b * b + b * p * n))
 
 
-def structured_bytes(N, n, m, p, newton_iters_per_game, ls_trials_per_iter=1.0):
-    """Algorithmic bytes per game-Newton-iteration of THIS implementation's structured elimination:
-    iterate read by the statistics pass, residual written + read, gains written + read, iterate read by the
-    three sweeps' knot loads (3x), delta written, trial written + read, iterate updated (read + write)."""
+def structured_bytes(cfg, N, n, m, p, ls_trials_per_iter=1.0):
+    """Algorithmic HBM bytes per game-Newton-iteration of THIS implementation ("Roofline accounting"):
+    one line-search trial (axpy), one assemble pass (the accepted trial doubles as the next record!), the three sweeps
+    of the Newton direction with their step-record slices and the spilled gains.  The accepted trial becomes pdtraj by
+    exchanging buffers (no traffic)."""
     S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
-    gains = (N - 1) * m * (n + 1)
-    it = S + n
-    return 8 * (it + 2 * S + 2 * gains + 3 * it + S + ls_trials_per_iter * (2 * it + S) + 2 * it + S)
+    it, K = S + n, N - 1
+    nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p}[cfg]                       # RK2 Jacobian coefficients per step
+    npair = p * (p - 1)
+    len_costate = nc + 3 * npair + 3 * p + p * n                         # [coef | Hh | Hd | rx]
+    len_sweep = len_costate + 2 * m + n                                  # + [R^ | ru | rd]
+    len_rec = len_sweep + 2 * p * p                                      # + pair-gradient table
+    con = K * npair + (2 * m * K if cfg in ("C3", "C5") else 0)          # constraint rows touched (lam, mu read; vals written)
+    gains = K * m * (n + 1)
+    trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec + con))   # axpy + assemble pass
+    backward = K * len_sweep + gains
+    forward = gains + K * (nc + n) + K * (n + m)
+    costate = K * len_costate + K * n + K * p * n
+    return 8 * (trial + backward + forward + costate)
 
 
 def main():
@@ -137,7 +148,7 @@ def main():
         kern_s = float(np.mean(kernel_ms)) * 1e-3
         p, n, m, N = b.p, b.n, b.m, b.N
         balg = survey_balg(N, n, m, p)
-        own = structured_bytes(N, n, m, p, iters_rank / G)
+        own = structured_bytes(args.config, N, n, m, p)
         out = {
             "metric": "newton_iters_per_sec", "value": value, "unit": "game-Newton-iterations/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,

@@ -3,18 +3,20 @@
 // Execution model: ONE GAME PER WAVEFRONT (workgroup = 64 threads = 1 wave).  Games are independent
 // (SURVEY.md 8(e)), so every wave runs its own solver state machine; no inter-workgroup traffic.
 //
-//  * assemble pass (residual / statistics / line-search trials): work item = (knot k, player i); rows are formed in
-//    registers, wave shuffles give ||.||_1 and the violation maxima, and (for the Newton direction) one compact
-//    "step record" per knot is left in HBM: Jacobian coefficients, pair Hessian blocks, R^, and the residual rows.
+//  * assemble pass (residual / statistics / line-search trials): phase A, work item = (knot k, player i): Jacobian
+//    coefficients and pair / wall / circle terms; phase B, work item = one residual row of one step (flat loops over all
+//    rows, operands straight from HBM/L2); wave shuffles give ||.||_1 and the violation maxima, and (for the Newton
+//    direction) one compact "step record" per knot is left in HBM: Jacobian coefficients, pair Hessian blocks, R^, and
+//    the residual rows.
 //  * Newton direction: the KKT system of solver_methods.jl:87 is never materialised.  Its block-tridiagonal
 //    structure is eliminated by a structured block LU in the order (u_k via R^, lambda_k via -I,
 //    x_{k+1} via an m x m pivoted solve) -- a game-theoretic Riccati sweep.  Backward over k: the per-player value
-//    matrices P_i (n x n, LDS) are advanced with two chained v_mfma_f64_16x16x4_f64 products per player
-//    ([P_i F | P_i f + s_i], then A' x that + [Q^_i | rx_i]); the m x m control system is LU-factored with partial
-//    pivoting redundantly in every lane's registers (wave-uniform pivots, no cross-lane traffic) and each lane
-//    back-substitutes its own right-hand-side column; gains go to HBM (m (n+1) doubles per step instead of the
-//    b^2 + b p n of a dense block LU).  Then a forward sweep for (dx, du) and a backward costate sweep for dlambda.
-//    Records and gains are prefetched one step ahead into a double-buffered LDS slot.
+//    matrices [P_i | s_i] (n x (n+1), LDS) are advanced with two chained v_mfma_f64_16x16x4_f64 products per player
+//    ([P_i F | P_i f + s_i], then A' x that) followed by a table-driven sparse add of [Q^_i | rx_i]; the m x m control
+//    system with its n + 1 right-hand sides is solved by a column-per-lane Gauss-Jordan with partial pivoting (lane c
+//    owns column c, the pivot column is broadcast with v_readlane: wave-uniform pivots); gains go to HBM (m (n+1)
+//    doubles per step instead of the b^2 + b p n of a dense block LU).  Then a forward sweep for (dx, du) and a
+//    backward costate sweep for dlambda.  Records and gains are prefetched one step ahead into double-buffered LDS slots.
 //
 // Reference citations are relative to /root/reference.
 #pragma once
@@ -81,7 +83,7 @@ struct Cfg {
     static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : (MODEL_ == ALG_MODEL_UNICYCLE) ? 3 : 2;   // max non-zeros of a column of [B_k | A_k]
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
-    static constexpr int WPE = (n >= 16) ? 2 : 4;
+    static constexpr int WPE = (n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 : 4;
     // reuse the accepted line-search trial as the next record! (costs registers: off for the large configurations)
     static constexpr bool TRIAL_REUSE = (n < 16);
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
@@ -486,23 +488,18 @@ struct DirLds {
     double coefn[C::NC > 0 ? C::NC : 1];
     double qdf[C::P * C::n];           // LQR diagonal of player i padded to joint dims (zero off pz[i])
 };
-// LDS of the assemble pass (never live at the same time as DirLds: the kernels hold a union)
+// The assemble pass works out of registers and HBM/L2 (no LDS staging); the type is kept for the kernels' LDS union.
 template <class C>
-struct AsmLds {
-    double blk[4][C::b];               // rotating window of horizontal-order blocks k-1, k, k+1 (+ prefetch slot)
-    double zr[2][C::n + C::m];         // [x_{k+1} | u_k] of the reference trajectory (proximal term)
-    double aux[2][C::NC + 2 * C::P * C::P + 1];   // [coef of knot k+1 | gvt of step k]
-    double tq[C::P * C::n], tx[C::P * C::n], tr[C::m], tu[C::m];   // LQR diagonals / targets padded to joint dims
-};
+struct AsmLds { double unused[1]; };
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 
 // ================================================================================================
 // Assemble pass: residual! + regularize_residual! + the scalars of record! (+ step records)
 //   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl.
-//   phase A (parallel, work item = (knot, player)): unicycle Jacobian coefficients, collision cost / collision
-//           avoidance terms of the ordered pairs (i, j) -> record [coef | Hh | Hd | gvt], constraint values
-//   phase B (serial over knots, lane = residual row of the step, all loads coalesced and staged through LDS):
-//           rows opt_i,x_{k+1} | opt_i,u_{i,k} | dyn_k  -> record [rx | ru | rd], R^, statistics
+//   phase A (parallel, work item = (knot, player)): RK2 Jacobian coefficients, collision cost / collision avoidance
+//           (/ wall / circle) terms of the ordered pairs (i, j) -> record [coef | Hh | Hd | gvt], constraint values
+//   phase B (parallel, work item = one residual row of one step; three flat row loops):
+//           rows opt_i,x_{k+1} | opt_i,u_{i,k} | dyn_k  -> record [rx | ru | rd], R^ (, RQ), statistics
 //   MODE 0: statistics only (line-search trials)   MODE 1: + step records (Newton direction input)
 //   MODE 2: + residual vector in the reference's vertical order (alg_residual)
 //   MODE 3: line-search trial that doubles as the next record!: statistics and step records of the UNREGULARISED
@@ -1693,24 +1690,29 @@ __device__ int ibr_solve_player(const Params& pr, const Game& G, Lds<C>& L, int 
     return status;
 }
 struct IbrOrder { int v[MAXP]; };
-// ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169)
+// ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169); single = true runs ibr_newton_solve!(prob, player) on the stored
+// trajectory instead (one best response, no initialisation).  One call site of ibr_solve_player: it stays inlined.
 template <class C>
-__device__ void ibr_newton_solve(const Params& pr, const Game& G, Lds<C>& L, int init, uint64_t game_id, int ibr_iter,
-                                 const IbrOrder& order, double delta_min) {
+__device__ void ibr_newton_solve(const Params& pr, const Game& G, Lds<C>& L, bool single, int player, int init, uint64_t game_id,
+                                 int ibr_iter, const IbrOrder& order, double delta_min) {
     const int lane = threadIdx.x;
-    if (lane == 0) { alg_game_stats z{}; *G.st = z; G.tc[6] = 0.0; }                 // reset!(prob.stats)
-    if (init) init_traj<C>(pr, G, G.z[0], game_id, true);
-    else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
-    __syncthreads();
-    for (int e = lane; e < pr.traj_len; e += WAVE) { G.z[1][e] = G.z[0][e]; G.z[2][e] = 0.0; }   // :142-143 (the trial's duals are reset below)
-    __syncthreads();
-    rollout<C>(pr, G.z[0]);
-    __syncthreads();
+    if (!single) {
+        if (lane == 0) { alg_game_stats z{}; *G.st = z; G.tc[6] = 0.0; }             // reset!(prob.stats)
+        if (init) init_traj<C>(pr, G, G.z[0], game_id, true);
+        else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
+        __syncthreads();
+        for (int e = lane; e < pr.traj_len; e += WAVE) { G.z[1][e] = G.z[0][e]; G.z[2][e] = 0.0; }   // :142-143 (the trial's duals are reset below)
+        __syncthreads();
+        rollout<C>(pr, G.z[0]);
+        __syncthreads();
+    }
     unsigned change = (1u << C::P) - 1u;                                             // Δ_change = trues(p)
-    for (int q = 0; q < ibr_iter; q++) {
-        for (int id = 0; id < C::P; id++) {
-            const int ip = order.v[id];
+    const int rounds = single ? 1 : ibr_iter, nplay = single ? 1 : C::P;
+    for (int q = 0; q < rounds; q++) {
+        for (int id = 0; id < nplay; id++) {
+            const int ip = single ? player : order.v[id];
             const int status = ibr_solve_player<C>(pr, G, L, ip);
+            if (single) return;
             const double mx = uni(G.tc[6]);
             if (!(delta_min > mx)) change |= (1u << ip); else change &= ~(1u << ip);  // :157
             if (status != ALG_STATUS_OK) return;

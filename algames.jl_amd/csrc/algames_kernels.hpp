@@ -117,8 +117,7 @@ __global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, Buffers bf, int mode
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
     Game G = game_view(pr, bf, g);
-    if (mode == 0) ibr_solve_player<C>(pr, G, L, player);
-    else ibr_newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g, ibr_iter, order, delta_min);
+    ibr_newton_solve<C>(pr, G, L, mode == 0, player, init, game_id0 + (uint64_t)g, ibr_iter, order, delta_min);
 }
 
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve

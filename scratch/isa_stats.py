@@ -7,6 +7,7 @@ sigs = {
  "k_newton_solve": "(Params, Buffers, int, uint64_t)", "k_direction": "(Params, Buffers, double, int*)",
  "k_record": "(Params, Buffers, alg_record*)", "k_line_search": "(Params, Buffers, double, const double*, double*, int*)",
  "k_newton_step": "(Params, Buffers, int, int, alg_step_info*)",
+ "k_ibr": "(Params, Buffers, int, int, int, uint64_t, int, IbrOrder, double)",
 }
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs("/tmp/isa", exist_ok=True)

@@ -271,6 +271,26 @@ def test_newton_solve_parity_c5_unicycle_constrained(alg, orc):
     assert lam.max() > 1e-2                                                   # constraints are active
 
 
+def test_newton_solve_parity_with_line_search_backtracking_and_failures(alg, orc):
+    """A demanding Armijo constant makes the search backtrack (accepted trials with alpha < 1) and, with a short ls_iter,
+    run out of trials (solver_methods.jl:92-93, 111-124): the accepted step is then NOT the last trial (alpha was halved once
+    more), the inner loop exits on LS_count, and the next outer iteration starts from there.  Exercises the buffer-exchange /
+    recompute split of the fused kernel."""
+    seen_fail = seen_backtrack = False
+    for cfg, ids, kw, ls, beta in (("C2", np.arange(16), dict(N=12), 4, 0.999), ("C5", np.arange(200, 208), {}, 3, 0.99),
+                                   ("C5", np.arange(200, 208), {}, 2, 0.9)):
+        pg = alg.scenarios.make_problem(cfg, ids, **kw)
+        po = alg.scenarios.make_problem(cfg, ids, backend=orc.lib(), **kw)
+        for p_ in (pg, po):
+            p_.opts.ls_iter = ls; p_.opts.β = beta
+        alg.newton_solve(pg); alg.newton_solve(po)
+        _assert_solve_parity(pg, po)
+        seen_fail |= pg.stats.summary["ls_failures"].sum() > 0
+        h = pg.stats.history(0)
+        seen_backtrack |= bool(np.any((h["ls_j"] > 1) & (h["ls_j"] < ls)))
+    assert seen_fail and seen_backtrack
+
+
 def test_newton_solve_parity_c3_unicycle_4_players(alg, orc):
     # BASELINE config C3: 4-player Unicycle, N = 50 (b = 88 > 64 lanes: exercises the multi-pass row mapping)
     pg, po = _solve_pair(alg, orc, "C3", np.arange(1016, 1024))

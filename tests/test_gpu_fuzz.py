@@ -1,0 +1,90 @@
+"""Seeded differential fuzzing of the HIP path against the CPU oracle: random (model, players, horizon, ingredient
+subset, cost scales, options) problems pushed through one inner iteration and a full newton_solve!.  Small costs on
+some controls and strong couplings provoke the rarely taken branches (row exchanges in the pivoted m x m solve,
+backtracking / failing line searches, active-set switches).  Tolerances as in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DI, UNI, BIC = 0, 1, 2
+
+
+def _random_pair(alg, orc, rng, ext):
+    model = int(rng.choice([DI, UNI, BIC] if ext else [DI, UNI]))
+    p = int(rng.integers(1, 5))
+    N = int(rng.integers(2, 16))
+    B = 3
+    dt = float(rng.choice([0.05, 0.1, 0.2]))
+    g = alg.Batch(alg.hip_lib(), model, p, N, dt, B)
+    o = orc.OracleBatch(model, p, N, dt, B)
+    ni = g.n // p
+    Q = 10.0 ** rng.uniform(-2, 1.5, (B, p, ni))
+    R = 10.0 ** rng.uniform(-4, 0.5, (B, p, g.mi))            # tiny control costs -> badly scaled control systems
+    xf, uf = rng.normal(size=(B, p, ni)), 0.3 * rng.normal(size=(B, p, g.mi))
+    x0 = rng.normal(size=(B, g.n))
+    if model != DI:
+        x0[:, 2 * p:] *= 0.3
+    opts = dict(reg_0=float(10.0 ** rng.uniform(-8, -2)), rho_0=float(10.0 ** rng.uniform(-1, 1)),
+                rho_increase=float(rng.choice([2.0, 10.0])), ls_iter=int(rng.integers(2, 12)), beta=float(rng.choice([0.01, 0.5, 0.95])),
+                outer_iter=int(rng.integers(1, 5)), inner_iter=int(rng.integers(1, 8)), regularize=int(rng.random() < 0.85),
+                dual_reset=int(rng.random() < 0.8), alpha_decrease=float(rng.choice([0.5, 0.7])), seed=int(rng.integers(0, 1000)))
+    ing = []
+    for b in (g, o):
+        rs = np.random.default_rng(1234)                       # same choices for both backends
+        if model == BIC:
+            b.set_bicycle(0.03 + 0.1 * rs.random(), 0.03 + 0.1 * rs.random())
+        b.set_x0(x0); b.set_lqr(Q, R, xf, uf); b.set_options(**opts)
+        if p > 1 and rng_flag(rng, b is g, ing, "cost"):
+            b.add_collision_cost(np.full(p, 2.5), 1.0 + np.arange(p))
+        if p > 1 and rng_flag(rng, b is g, ing, "avoid"):
+            b.add_collision_avoidance(0.2 + 0.1 * np.arange(p))
+        if rng_flag(rng, b is g, ing, "ctl"):
+            umax = np.full(b.m, 0.8); umin = np.full(b.m, -0.5); umax[0] = np.inf
+            b.add_control_bound(umax, umin)
+        if ext and rng_flag(rng, b is g, ing, "sb"):
+            xmax = np.full(b.n, np.inf); xmin = np.full(b.n, -np.inf); xmax[::3] = 1.0; xmin[1::4] = -0.8
+            b.add_state_bound(int(rs.integers(0, p)), xmax, xmin)
+        if ext and rng_flag(rng, b is g, ing, "wall"):
+            b.add_wall_constraint([-1.0, 0.5], [0.3, -1.0], [1.0, 0.5], [0.3, 1.0], [0.0, 1.0], [1.0, 0.0])
+        if ext and rng_flag(rng, b is g, ing, "circ"):
+            b.add_circle_constraint([0.4, -0.6], [0.2, 0.7], [0.5, 0.3])
+    return g, o, (model, p, N, dt, tuple(ing), opts)
+
+
+def rng_flag(rng, first, store, name):
+    """Draw the ingredient decision once (for the first backend) and replay it for the second."""
+    if first:
+        on = bool(rng.random() < 0.6)
+        store.append((name, on))
+        return on
+    return dict(store)[name]
+
+
+def _compare_solve(g, o, tag):
+    sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
+    for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]), (tag, f, sg[f], so[f])
+    ok = so["status"] == 0
+    zg, zo = g.get_traj(0), o.get_traj(0)
+    if ok.any():
+        scale = max(1.0, np.abs(zo[ok]).max())
+        assert np.abs(zg[ok] - zo[ok]).max() <= 1e-7 * scale, (tag, np.abs(zg[ok] - zo[ok]).max(), scale)
+        for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+            assert np.allclose(sg["last"][f][ok], so["last"][f][ok], rtol=1e-6, atol=1e-9), (tag, f)
+    hg, ho = g.get_history(0), o.get_history(0)
+    assert len(hg) == len(ho) and np.array_equal(hg["ls_j"], ho["ls_j"]) and np.array_equal(hg["alpha"], ho["alpha"]), tag
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_base_instantiations(alg, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    g, o, tag = _random_pair(alg, orc, rng, ext=False)
+    _compare_solve(g, o, tag)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_extended_instantiations(alg, orc, seed):
+    rng = np.random.default_rng(5000 + seed)
+    g, o, tag = _random_pair(alg, orc, rng, ext=True)
+    _compare_solve(g, o, tag)

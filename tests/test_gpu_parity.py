@@ -442,3 +442,22 @@ def test_full_size_c2_properties(alg):
     # generalized-Nash structure: dynamics satisfied, collision-avoidance multipliers non-negative
     lam, _ = prob.batch.get_con_duals()
     assert lam.min() >= 0.0
+
+
+def test_golden_solutions_gpu(alg):
+    """The HIP path against the committed solution vectors (tests/golden/oracle_solutions.npz): same tolerances as the
+    live oracle comparison, but independent of rebuilding the oracle on the GPU box."""
+    import os, sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    import make_golden
+    ref = np.load(os.path.join(gdir, "oracle_solutions.npz"))
+    for name in ("c2_n12", "c2_n40", "c5", "c3_n20", "intro"):
+        got = make_golden.solve(name, alg, None)
+        for k in ("newton_iters", "outer_iters", "status", "converged"):
+            assert np.array_equal(got[k], ref[f"{name}.{k}"]), (name, k)
+        n_lam = got["z"].shape[1]
+        assert np.abs(got["z"] - ref[f"{name}.z"]).max() <= 1e-6 * max(1.0, np.abs(ref[f"{name}.z"]).max()), name
+        assert np.array_equal(got["mu"], ref[f"{name}.mu"]), name
+        assert np.abs(got["lam"] - ref[f"{name}.lam"]).max() <= 1e-6 * max(1.0, np.abs(ref[f"{name}.lam"]).max()), name
+        assert np.allclose(got["res"], ref[f"{name}.res"], rtol=1e-7, atol=1e-12), name

@@ -804,3 +804,66 @@ def test_ibr_direction_moves_only_the_players_variables(orc):
     assert np.array_equal(moved_u, np.array([False, True, False, False, True, False]))     # pu[2] = {2, 5}
     assert np.array_equal(L1[:, [0, 2]], L0[:, [0, 2]]) and np.abs(L1[:, 1] - L0[:, 1]).max() > 0
     assert np.abs(X1[:, 1:] - X0[:, 1:]).max() > 0 and np.array_equal(X1[:, 0], X0[:, 0])
+
+
+# ---------------------------------------------------------------- committed fixtures (tests/golden/)
+def _golden_literals():
+    import json, os
+    def num(v):
+        return float(v) if isinstance(v, str) else v
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kat_literals.json")) as f:
+        return json.load(f), num
+
+
+def test_golden_reference_literals(alg, orc):
+    """tests/golden/reference_kat_literals.json (the literal values the reference's tests hold) against the oracle / host."""
+    G, num = _golden_literals()
+    # control bound / state bound evaluate
+    for key, add, field in (("control_bound_evaluate", "ctl", "u"), ("state_bound_evaluate", "sb", "x")):
+        g = G[key]
+        b = orc.OracleBatch(DI, 1, 4, 0.1, 1, d=3) if add == "sb" else orc.OracleBatch(DI, 2, 5, 0.1, 1, d=3)
+        b.set_lqr(np.zeros((b.p, 6)), np.zeros((b.p, 3)), np.zeros((b.p, 6)), np.zeros((b.p, 3)))
+        hi = np.array([num(v) for v in g[field + "_max"]]); lo = np.array([num(v) for v in g[field + "_min"]])
+        X, U, L = b.split_traj(b.get_traj())
+        if add == "ctl":
+            b.add_control_bound(hi, lo); U[0, :] = g[field]
+        else:
+            b.add_state_bound(0, hi, lo); X[0, 1:] = g[field]
+        b.set_traj(b.join_traj(X, U, L))
+        vals = b.kat_evaluate_con()[0]
+        rows = vals[b.p * (b.p - 1) * (b.N - 1):][:12] if add == "ctl" else vals[_ext_off(b):][:12]
+        assert np.array_equal(rows[np.isfinite(rows)], np.array(g["finite_values"]))
+        if "finite_indices_1based" in g:
+            assert np.array_equal(np.nonzero(np.isfinite(rows))[0] + 1, g["finite_indices_1based"])
+    # wall evaluate
+    g = G["wall_evaluate"]; s2 = np.sqrt(2.0)
+    b = orc.OracleBatch(DI, 1, 3, 0.1, 1)
+    b.set_lqr(np.zeros((1, 4)), np.zeros((1, 2)), np.zeros((1, 4)), np.zeros((1, 2)))
+    b.add_wall_constraint(g["x1"], g["y1"], g["x2"], g["y2"], np.array(g["xv_times_sqrt2"]) / s2, np.array(g["yv_times_sqrt2"]) / s2)
+    X, U, L = b.split_traj(b.get_traj()); X[0, 1:, 0:2] = g["position"]
+    b.set_traj(b.join_traj(X, U, L))
+    w = b.kat_evaluate_con()[0][_ext_off(b):][:5]
+    assert np.abs(w - np.array(g["values"])).sum() < g["tol_l1"]
+    # layout / index sets
+    assert alg.ProblemSize(40, alg.DoubleIntegratorGame(p=3)).S == G["layout"]["S"]["DoubleIntegrator p=3 d=2 N=40"]
+    assert alg.ProblemSize(50, alg.UnicycleGame(p=4)).S == G["layout"]["S"]["Unicycle p=4 N=50"]
+    for name, model in (("unicycle_p3", alg.UnicycleGame(p=3)), ("bicycle_p3", alg.BicycleGame(p=3)), ("double_integrator_p2_d3", alg.DoubleIntegratorGame(p=2, d=3))):
+        for f in ("pu", "px", "pz"):
+            assert getattr(model, f) == G["model_index_sets"][name][f], (name, f)
+
+
+def test_golden_solutions_oracle(alg, orc):
+    """The oracle reproduces the committed solution vectors (tests/golden/oracle_solutions.npz, made by make_golden.py)."""
+    import os, sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    import make_golden
+    ref = np.load(os.path.join(gdir, "oracle_solutions.npz"))
+    for name in ("c2_n12", "c5", "intro"):
+        got = make_golden.solve(name, alg, orc.lib())
+        for k, v in got.items():
+            r = ref[f"{name}.{k}"]
+            if v.dtype.kind in "iu":
+                assert np.array_equal(v, r), (name, k)
+            else:
+                assert np.allclose(v, r, rtol=1e-9, atol=1e-11), (name, k)

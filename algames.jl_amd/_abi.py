@@ -111,6 +111,7 @@ SIGNATURES = {
     "ibr_newton_solve": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _I, C.c_double, _P]),
     "mpc_advance": (C.c_int, [_P]),
     "mpc_totals": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
+    "mpc_solve": (C.c_int, [_P, C.c_int32, C.c_int64, _D]),
 }
 
 
@@ -372,6 +373,12 @@ class Batch:
 
     def mpc_advance(self):
         self.lib.check(self.lib.mpc_advance(self.h))
+
+    def mpc_solve(self, steps, game_id0=0, record_states=False):
+        """The whole receding-horizon loop in one call; returns the states (steps+1, B, n) or None (asynchronous)."""
+        states = np.empty((steps + 1, self.B, self.n)) if record_states else None
+        self.lib.check(self.lib.mpc_solve(self.h, int(steps), int(game_id0), _dptr(states)))
+        return states
 
     def mpc_totals(self, reset=False):
         it = np.zeros(self.B, dtype=np.int64); cv = np.zeros(self.B, dtype=np.int64)

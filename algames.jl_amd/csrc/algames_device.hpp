@@ -1493,10 +1493,10 @@ __device__ void rollout(const Params& pr, double* z) {
 
 // init_traj! (primal_dual_traj.jl:29-44) with the counter RNG (same element counters as the oracle)
 template <class C>
-__device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t game_id, bool use_shift) {
+__device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t game_id, bool use_shift, int shift = -1) {
     constexpr int n = C::n, m = C::m, P = C::P;
     const int N = pr.N, lane = threadIdx.x; const alg_options& o = pr.opt;
-    const int s = use_shift ? o.shift : (1 << 30);
+    const int s = use_shift ? (shift >= 0 ? shift : o.shift) : (1 << 30);
     if (use_shift && s < N) {
         // in-place shift: element e of step k takes element e of step k+s; ascending k is safe within one wave only
         // with a barrier per step, so stage through the trial buffer
@@ -1549,18 +1549,18 @@ __device__ __forceinline__ void settle_traj(const Params& pr, Game& G, double* z
 
 // newton_solve! (solver_methods.jl:5-65)
 template <class C>
-__device__ void newton_solve(const Params& pr, Game& G, Lds<C>& L, int init, uint64_t game_id) {
+__device__ void newton_solve(const Params& pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
     double* const z_home = G.z[0];
     const alg_options& o = pr.opt; const int lane = threadIdx.x;
     if (lane == 0) { alg_game_stats z{}; *G.st = z; }                       // reset!(prob.stats)
 #ifndef ALG_TEST_NOINIT
-    if (init) init_traj<C>(pr, G, G.z[0], game_id, true);                  // :13
+    if (init) init_traj<C>(pr, G, G.z[0], game_id, true, shift);           // :13
     else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
     if (lane < C::n) { G.z[1][lane] = G.x0[lane]; G.z[2][lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
     __syncthreads();
     rollout<C>(pr, G.z[0]);                                                // :17
 #endif
-    if (o.dual_reset) reset_con(pr, G);                                    // :25
+    if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con(pr, G);     // :25
     __syncthreads();
     int out = 0, status = ALG_STATUS_OK, converged = 0; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30

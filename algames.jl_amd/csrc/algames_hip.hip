@@ -576,6 +576,18 @@ int alg_mpc_advance(alg_handle* h) {
     LAUNCH(k_mpc_advance, H->pr, H->bf);
     return ALG_OK;
 }
+int alg_mpc_solve(alg_handle* h, int32_t steps, int64_t game_id0, double* states) {
+    if (!h || steps < 1) return fail(ALG_ERR_ARG, "alg_mpc_solve: bad argument");
+    int rc = use_device(H); if (rc) return rc;
+    if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_mpc_solve: x0 / LQR data not set");
+    const Params& p = H->pr;
+    double* d_states = nullptr;
+    const size_t cnt = (size_t)(steps + 1) * p.B * p.n;
+    if (states) HIPCHK(hipMalloc((void**)&d_states, sizeof(double) * cnt));
+    LAUNCH(k_mpc_loop, H->pr, H->bf, (int)steps, (uint64_t)game_id0, d_states);
+    if (states) { rc = d2h(H, states, d_states, sizeof(double) * cnt); hipFree(d_states); return rc; }
+    return ALG_OK;
+}
 int alg_mpc_totals(alg_handle* h, int64_t* it, int64_t* cv, int32_t reset) {
     int rc = use_device(H); if (rc) return rc;
     const int B = H->pr.B;

@@ -122,9 +122,8 @@ __global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, Buffers bf, int mode
 
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    Game G = game_view(pr, bf, g);
+__device__ __forceinline__ void mpc_advance(const Params& pr, const Buffers& bf, const Game& G, int g) {
+    const int lane = threadIdx.x;
     if (lane < C::P) {
         double x[C::n], u[C::m], xo[C::ni], co[4];
         for (int j = 0; j < C::ni; j++) x[lane + j * C::P] = G.z[0][lane + j * C::P];
@@ -136,6 +135,32 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
         }
     }
     if (lane == 0) { bf.mpc[2 * g] += G.st->newton_iters; bf.mpc[2 * g + 1] += G.st->converged; }
+}
+template <class C>
+__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
+    const int g = blockIdx.x;
+    Game G = game_view(pr, bf, g);
+    mpc_advance<C>(pr, bf, G, g);
+}
+
+// The whole receding-horizon loop of one game in one wave (BASELINE config 5): `steps` x (newton_solve! from the shifted
+// warm start, advance x0 by one RK2 step).  Games never wait for each other between MPC steps, so a game that needs many
+// Newton iterations at one step only delays itself.  Step 0 uses the handle's shift / dual_reset, later steps shift = 1
+// and dual_reset = false (the reference's warm-start hooks, options.jl / primal_dual_traj.jl:29-44).
+template <class C>
+__global__ void __launch_bounds__(WAVE, C::WPE) k_mpc_loop(Params pr, Buffers bf, int steps, uint64_t game_id0, double* states) {
+    __shared__ Lds<C> L;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    Game G = game_view(pr, bf, g);
+    if (states && lane < C::n) states[(size_t)g * C::n + lane] = G.x0[lane];
+    for (int t = 0; t < steps; t++) {
+        newton_solve<C>(pr, G, L, 1, game_id0 + (uint64_t)t * 1000003ull + (uint64_t)g, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
+        __syncthreads();
+        mpc_advance<C>(pr, bf, G, g);
+        __syncthreads();
+        if (states && lane < C::n) states[((size_t)(t + 1) * pr.B + g) * C::n + lane] = G.z[0][lane];
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -181,6 +206,7 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
     PREFIX __global__ void k_dual_update<Cfg<M, P, D, E>>(Params, Buffers);                                                \
     PREFIX __global__ void k_init<Cfg<M, P, D, E>>(Params, Buffers, uint64_t, int, int, int);                              \
     PREFIX __global__ void k_ibr<Cfg<M, P, D, E>>(Params, Buffers, int, int, int, uint64_t, int, IbrOrder, double);        \
-    PREFIX __global__ void k_mpc_advance<Cfg<M, P, D, E>>(Params, Buffers);
+    PREFIX __global__ void k_mpc_advance<Cfg<M, P, D, E>>(Params, Buffers);                                                \
+    PREFIX __global__ void k_mpc_loop<Cfg<M, P, D, E>>(Params, Buffers, int, uint64_t, double*);
 #define ALG_DEFINE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(template, M, P, D, E)
 #define ALG_DECLARE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(extern template, M, P, D, E)

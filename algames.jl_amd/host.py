@@ -560,19 +560,24 @@ def ibr_newton_solve(prob, i=None, ibr_opts=None, init=True):
 # `opts.shift` / `opts.dual_reset` (options.jl:16-17, primal_dual_traj.jl:35-39, solver_methods.jl:25).  Builder-defined
 # (SURVEY.md 8(d) C5): solve; x0 <- RK2(x_1, u_1); next solve warm-started with shift = 1 and dual_reset = false.
 # --------------------------------------------------------------------------------------------------
-def mpc_solve(prob, steps, record_states=False):
+def mpc_solve(prob, steps, record_states=False, fused=True):
     """Runs `steps` receding-horizon solves for every game of the batch.  Returns (newton_iters (B,), converged (B,),
-    states (steps+1, B, n) or None).  No host synchronisation happens inside the loop unless record_states is set."""
+    states (steps+1, B, n) or None).  fused=True: one launch, every game runs its own loop (alg_mpc_solve); fused=False:
+    one newton_solve! launch + one advance launch per MPC step (the batch waits for its slowest game at every step).
+    No host synchronisation happens inside the loop unless record_states is set."""
     b = prob.batch
     b.mpc_totals(reset=True)
+    prob._sync_options()
+    if fused:
+        states = b.mpc_solve(steps, prob.game_id0, record_states)
+        it, cv = b.mpc_totals()
+        return it, cv, states
     shift0, reset0 = prob.opts.shift, prob.opts.dual_reset
     states = [b.get_x0()] if record_states else None
     try:
         for t in range(steps):
             if t == 1:
                 prob.opts.shift, prob.opts.dual_reset = 1, False
-                prob._sync_options()
-            elif t == 0:
                 prob._sync_options()
             b.newton_solve_async(init=True, game_id0=prob.game_id0 + t * 1000003)
             b.mpc_advance()
@@ -581,4 +586,5 @@ def mpc_solve(prob, steps, record_states=False):
         it, cv = b.mpc_totals()
     finally:
         prob.opts.shift, prob.opts.dual_reset = shift0, reset0
+        prob._sync_options()
     return it, cv, (np.stack(states) if record_states else None)

@@ -158,7 +158,9 @@ def main():
                                     "C5": "C5: 3-player Unicycle, N=30, collision avoidance + control bounds"}[args.config],
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
-                       "parallelism": f"scenario-sharded x{world}", "solver": "fused per-game newton_solve! kernel, one game per wavefront"},
+                       "parallelism": f"scenario-sharded x{world}",
+                       "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve), one game per wavefront" if args.mpc_steps
+                                  else "fused per-game newton_solve! kernel, one game per wavefront")},
             "games_to_convergence_per_sec": conv_all * K / elapsed,
             "games_converged": conv_all, "games_failed": bad_all,
             "roofline": {

@@ -252,6 +252,12 @@ int alg_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t 
  * finished solve's newton_iters / converged flag to per-game running totals. */
 int alg_mpc_advance(alg_handle* h);
 int alg_mpc_totals(alg_handle* h, int64_t* newton_iters /*B or NULL*/, int64_t* converged /*B or NULL*/, int32_t reset);
+/* The whole loop in one launch: `steps` x (newton_solve! with init = 1 and game ids game_id0 + t*1000003 + g, then the
+ * advance above); step 0 uses the handle's shift / dual_reset, later steps shift = 1 and dual_reset = false.  Every game
+ * runs its own loop (one wavefront per game): games do not wait for each other between MPC steps.  Totals accumulate as
+ * with alg_mpc_advance.  states: NULL (asynchronous launch) or host array (steps+1) x B x n receiving x0 before the loop
+ * and after every step (synchronous). */
+int alg_mpc_solve(alg_handle* h, int32_t steps, int64_t game_id0, double* states);
 
 #ifdef __cplusplus
 }

@@ -1239,6 +1239,23 @@ int orc_mpc_advance(alg_handle* h) {
     }
     return ALG_OK;
 }
+// the loop of alg_mpc_solve, literally: per step newton_solve! (shift / dual_reset of the handle at step 0, then 1 / false) + advance
+int orc_mpc_solve(alg_handle* h, int32_t steps, int64_t game_id0, double* states) {
+    if (steps < 1) return fail(ALG_ERR_ARG, "orc_mpc_solve: bad argument");
+    const Dims& D = H->sh.D; const int B = (int)H->g.size();
+    const alg_options saved = H->sh.opt;
+    auto snap = [&](int t) { if (states) for (int gi = 0; gi < B; gi++) std::copy(H->g[gi].x0.begin(), H->g[gi].x0.end(), states + ((size_t)t * B + gi) * D.n); };
+    snap(0);
+    int rc = ALG_OK;
+    for (int t = 0; t < steps && rc == ALG_OK; t++) {
+        if (t >= 1) { H->sh.opt.shift = 1; H->sh.opt.dual_reset = 0; }
+        rc = orc_newton_solve(h, 1, game_id0 + (int64_t)t * 1000003, nullptr);
+        if (rc == ALG_OK) rc = orc_mpc_advance(h);
+        snap(t + 1);
+    }
+    H->sh.opt = saved;
+    return rc;
+}
 int orc_mpc_totals(alg_handle* h, int64_t* it, int64_t* cv, int32_t reset) {
     for (size_t gi = 0; gi < H->g.size(); gi++) {
         if (it) it[gi] = H->g[gi].mpc_iters; if (cv) cv[gi] = H->g[gi].mpc_conv;

@@ -315,18 +315,29 @@ def test_full_size_c3_properties(alg):
 
 def test_mpc_receding_horizon_parity(alg, orc):
     """BASELINE config 5 (builder-defined loop): 3-player Unicycle N = 30, shifted warm starts
-    (init_traj! shift = 1, primal_dual_traj.jl:29-44) with dual_reset = false after the first solve."""
+    (init_traj! shift = 1, primal_dual_traj.jl:29-44) with dual_reset = false after the first solve.  The fused loop
+    (alg_mpc_solve: one launch, every game runs its own loop) against the oracle's loop and against the step-wise launches."""
     ids = np.arange(300, 308)
     pg = alg.scenarios.make_problem("C5", ids)
     po = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
     ig, cg, sg = alg.mpc_solve(pg, 6, record_states=True)
     io, co, so = alg.mpc_solve(po, 6, record_states=True)
     assert np.array_equal(ig, io) and np.array_equal(cg, co)
-    assert np.abs(sg - so).max() < 1e-7
+    assert sg.shape == so.shape == (7, 8, pg.model.n) and np.abs(sg - so).max() < 1e-7
     assert np.abs(sg[-1] - sg[0]).max() > 0.1                  # the vehicles really move
-    # asynchronous loop (no host sync inside) gives the same totals
+    # step-wise launches (newton_solve! + advance per MPC step) give the same loop
+    ps = alg.scenarios.make_problem("C5", ids)
+    is_, cs, ss = alg.mpc_solve(ps, 6, record_states=True, fused=False)
+    assert np.array_equal(is_, ig) and np.array_equal(cs, cg) and np.abs(ss - sg).max() < 1e-9
+    # the oracle's step-wise loop too
+    po2 = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
+    io2, co2, so2 = alg.mpc_solve(po2, 6, record_states=True, fused=False)
+    assert np.array_equal(io2, io) and np.array_equal(co2, co) and np.array_equal(so2, so)
+    # asynchronous fused loop (no states, no host sync inside) gives the same totals; the handle is reusable afterwards
     ig2, cg2, _ = alg.mpc_solve(pg2 := alg.scenarios.make_problem("C5", ids), 6)
     assert np.array_equal(ig2, ig) and np.array_equal(cg2, cg)
+    ig3, cg3, _ = alg.mpc_solve(pg2, 3)
+    assert ig3.sum() > 0
 
 
 @pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[6], CASES[7], CASES[8]])

@@ -867,3 +867,14 @@ def test_golden_solutions_oracle(alg, orc):
                 assert np.array_equal(v, r), (name, k)
             else:
                 assert np.allclose(v, r, rtol=1e-9, atol=1e-11), (name, k)
+
+
+def test_mpc_loop_fused_equals_stepwise_oracle(alg, orc):
+    # builder-defined receding-horizon loop: orc_mpc_solve == per-step newton_solve! + advance
+    ids = np.arange(300, 303)
+    pa = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
+    pb = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
+    ia, ca, sa = alg.mpc_solve(pa, 4, record_states=True)
+    ib, cb, sb = alg.mpc_solve(pb, 4, record_states=True, fused=False)
+    assert np.array_equal(ia, ib) and np.array_equal(ca, cb) and np.array_equal(sa, sb)
+    assert ia.sum() > 0 and np.abs(sa[-1] - sa[0]).max() > 0.05

@@ -782,7 +782,16 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
 template <class C>
 __device__ __forceinline__ void update_traj(const Params& pr, double* tgt, const double* src, double alpha, const double* dz) {
-    for (int e = phase_lane(); e < pr.S; e += WAVE) tgt[C::n + e] = src[C::n + e] + alpha * dz[C::n + e];
+    // four independent load pairs in flight per pass (the pass is pure streaming: latency-bound at one wave per game)
+    constexpr int U = 4;
+    const int S = pr.S;
+    for (int e0 = phase_lane(); e0 < S; e0 += U * WAVE) {
+        double a[U], d[U];
+#pragma unroll
+        for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; const int ec = e < S ? e : e0; a[t] = src[C::n + ec]; d[t] = dz[C::n + ec]; }
+#pragma unroll
+        for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; if (e < S) tgt[C::n + e] = a[t] + alpha * d[t]; }
+    }
 }
 // Δ_step (primal_dual_traj.jl:130-147)
 template <class C>
@@ -1175,6 +1184,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         __syncthreads();
     }
     if (sing) return ALG_STATUS_SINGULAR;              // wave-uniform (every lane factors the same matrix)
+#if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 1
+    return ALG_STATUS_OK;
+#endif
     // ------------------------------------------------------------------ forward sweep: dx, du
     if (lane < n) { L.fw.dx[lane] = 0.0; dz[lane] = 0.0; }
     // the forward sweep reads only [coef | rd] of a record: one load per lane
@@ -1215,6 +1227,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         }
         __syncthreads();
     }
+#if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
+    return ALG_STATUS_OK;
+#endif
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     hxm.init(phase_lane());

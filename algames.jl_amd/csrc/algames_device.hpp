@@ -1195,18 +1195,30 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     const bool frok = lane < C::NC + n;
     if (frok) L.rec[0][fro] = G.rec[fro];
     for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain[e];
+    // Prefetch distance: the configurations with a 256-VGPR budget (one game per SIMD at their BASELINE batch sizes: nothing
+    // else hides HBM latency) keep the data of step k+2 in flight in registers while LDS holds steps k and k+1.
+    constexpr int PFD = (C::WPE == 2) ? 2 : 1;
+    auto fwd_load = [&](int kk, double& rf, double (&rk)[KPL]) {
+        rf = 0.0;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) rk[q] = 0.0;
+        if (kk < N - 1) {
+            if (frok) rf = G.rec[(size_t)kk * R::LEN + fro];
+#pragma unroll
+            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) rk[q] = G.kgain[(size_t)kk * NK + e]; }
+        }
+    };
+    double pref = 0.0, prek[KPL];
+    if constexpr (PFD == 2) fwd_load(1, pref, prek);
     __syncthreads();
     cur = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
     int bad = 0;                                    // non-finite direction entries (checked where they are produced)
     for (int k = 0; k < N - 1; k++, cur ^= 1) {
         const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
-        double pref = 0.0, prek[KPL];
-        if (k + 1 < N - 1) {
-            if (frok) pref = G.rec[(size_t)(k + 1) * R::LEN + fro];
-#pragma unroll
-            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; prek[q] = e < NK ? G.kgain[(size_t)(k + 1) * NK + e] : 0.0; }
-        }
+        double nxf = 0.0, nxk[KPL];
+        if constexpr (PFD == 2) fwd_load(k + 2, nxf, nxk);          // lands during the next step
+        else fwd_load(k + 1, pref, prek);
         if (lane < m) {
             double acc = Kl[n * m + lane];
 #pragma unroll
@@ -1225,6 +1237,11 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 #pragma unroll
             for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.fw.kg[cur ^ 1][e] = prek[q]; }
         }
+        if constexpr (PFD == 2) {
+            pref = nxf;
+#pragma unroll
+            for (int q = 0; q < KPL; q++) prek[q] = nxk[q];
+        }
         __syncthreads();
     }
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
@@ -1237,18 +1254,27 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
     const bool cpos = C::POS && cr_ < 2 * P;
-    double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched one step ahead like the records
+    double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
+    auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
+        rdx = 0.0;
+#pragma unroll
+        for (int q = 0; q < RPLC; q++) rr[q] = 0.0;
+        if (kk >= 0) {
+#pragma unroll
+            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) rr[q] = G.rec[(size_t)kk * R::LEN + e]; }
+            if (lane < n) rdx = dz[n + hx<C>(kk) + lane];
+        }
+    };
+    double pre[RPLC], pdx = 0.0;
+    if constexpr (PFD == 2) cs_load(N - 3, pdx, pre);
     __syncthreads();
     cur = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
-        double pre[RPLC];
         if (lane < n) L.fw.dx[lane] = dxk;
-        if (k > 0) {
-#pragma unroll
-            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_COSTATE ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
-            if (lane < n) dxk = dz[n + hx<C>(k - 1) + lane];
-        }
+        double nx[RPLC], ndx = 0.0;
+        if constexpr (PFD == 2) cs_load(k - 2, ndx, nx);
+        else cs_load(k - 1, pdx, pre);
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         hxm.expand(lane, Rc, L.fw.hx);
         __syncthreads();
@@ -1267,9 +1293,15 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         __syncthreads();
         if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; bad |= !isfinite(acc); }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
+        dxk = pdx;
         if (k > 0) {
 #pragma unroll
             for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) L.rec[cur ^ 1][e] = pre[q]; }
+        }
+        if constexpr (PFD == 2) {
+            pdx = ndx;
+#pragma unroll
+            for (int q = 0; q < RPLC; q++) pre[q] = nx[q];
         }
         __syncthreads();
     }

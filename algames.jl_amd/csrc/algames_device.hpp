@@ -1067,24 +1067,57 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
+            if constexpr (C::WPE == 2 && !IBR) {
+                // 256-VGPR configurations (one game per SIMD at their batch sizes): all players' operands are read first,
+                // the P independent MFMA chains overlap in the matrix pipeline, then all results are written back
+                double pv[P][KB1];
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                if (IBR && i != ip) continue;
-                double4_t c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0};
+                for (int i = 0; i < P; i++)
 #pragma unroll
-                for (int kb = 0; kb < KB1; kb++) {
-                    // n < 16: columns n+1.. of the last k-block read past the row (finite values) and meet zero rows of Fx
-                    const double pv = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
-                }
+                    for (int kb = 0; kb < KB1; kb++) {
+                        const double v = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
+                        pv[i][kb] = colP ? v : 0.0;
+                    }
+                double4_t c1[P], c2[P];
 #pragma unroll
-                for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
-                __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
+                for (int i = 0; i < P; i++) { c1[i] = double4_t{0.0, 0.0, 0.0, 0.0}; c2[i] = double4_t{0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const int row = lq + 4 * r4;
-                    const int slot = (rowok[r4] && lrow < n + (AUGS ? 1 : 0)) ? oPm + i * n * LDP + row * LDP + lrow : oPad;
-                    bwb[slot] = c2[r4];
+                for (int kb = 0; kb < KB1; kb++)
+#pragma unroll
+                    for (int i = 0; i < P; i++) c1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[i][kb], bF[kb], c1[i], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+                    for (int i = 0; i < P; i++) c2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[i][kb], c2[i], 0, 0, 0);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < P; i++)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const int row = lq + 4 * r4;
+                        const int slot = (rowok[r4] && lrow < n + (AUGS ? 1 : 0)) ? oPm + i * n * LDP + row * LDP + lrow : oPad;
+                        bwb[slot] = c2[i][r4];
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    if (IBR && i != ip) continue;
+                    double4_t c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kb = 0; kb < KB1; kb++) {
+                        // n < 16: columns n+1.. of the last k-block read past the row (finite values) and meet zero rows of Fx
+                        const double pv = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
+                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
+                    __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const int row = lq + 4 * r4;
+                        const int slot = (rowok[r4] && lrow < n + (AUGS ? 1 : 0)) ? oPm + i * n * LDP + row * LDP + lrow : oPad;
+                        bwb[slot] = c2[r4];
+                    }
                 }
             }
             __syncthreads();

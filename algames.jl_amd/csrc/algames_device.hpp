@@ -90,6 +90,11 @@ struct Cfg {
     static constexpr int ASM_UNROLL = 2;
 };
 
+// newton_solve / rollout are __forceinline__: they have two callers per instantiation (k_newton_solve, k_mpc_loop) and the
+// inliner would outline the largest instantiations -- a kernel whose callee is outlined gets its by-value Params copied to
+// scratch (1.3 KB per lane) and loses a third of its speed.  (Forcing the other solver-level functions changes the inlining
+// order and costs registers: they are left to the inliner, scratch/isa_stats.py + `grep s_swappc` guard against outlining.)
+
 // ---- index maps (newton_core.jl:40-89), 0-based --------------------------------------------------
 template <class C> __device__ __forceinline__ int hx(int k) { return k * C::b; }
 template <class C> __device__ __forceinline__ int hu(int k, int i) { return k * C::b + C::n + i * C::mi; }
@@ -1067,7 +1072,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
-            if constexpr (C::WPE == 2 && !IBR) {
+            if constexpr (C::WPE == 2 && !IBR && C::MODEL != ALG_MODEL_BICYCLE) {
                 // 256-VGPR configurations (one game per SIMD at their batch sizes): all players' operands are read first,
                 // the P independent MFMA chains overlap in the matrix pipeline, then all results are written back
                 double pv[P][KB1];
@@ -1230,7 +1235,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain[e];
     // Prefetch distance: the configurations with a 256-VGPR budget (one game per SIMD at their BASELINE batch sizes: nothing
     // else hides HBM latency) keep the data of step k+2 in flight in registers while LDS holds steps k and k+1.
-    constexpr int PFD = (C::WPE == 2) ? 2 : 1;
+    constexpr int PFD = (C::WPE == 2 && C::MODEL != ALG_MODEL_BICYCLE) ? 2 : 1;
     auto fwd_load = [&](int kk, double& rf, double (&rk)[KPL]) {
         rf = 0.0;
 #pragma unroll
@@ -1556,7 +1561,7 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
 
 // rollout!(RK3, model, traj) (solver_methods.jl:17): lanes < P integrate their own player (players are decoupled)
 template <class C>
-__device__ void rollout(const Params& pr, double* z) {
+__device__ __forceinline__ void rollout(const Params& pr, double* z) {
     constexpr int n = C::n, m = C::m, P = C::P;
     const int lane = threadIdx.x;
     if (lane < P) {
@@ -1629,7 +1634,7 @@ __device__ __forceinline__ void settle_traj(const Params& pr, Game& G, double* z
 
 // newton_solve! (solver_methods.jl:5-65)
 template <class C>
-__device__ void newton_solve(const Params& pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
+__device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
     double* const z_home = G.z[0];
     const alg_options& o = pr.opt; const int lane = threadIdx.x;
     if (lane == 0) { alg_game_stats z{}; *G.st = z; }                       // reset!(prob.stats)

@@ -864,6 +864,7 @@ __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
         // partial pivoting: the diagonal entry is the usual winner -> one max chain + one uniform test, the index
         // search and the row swap only run when another row really has the larger magnitude
         double best = fabs(pc[c]), oth = 0.0;
+        double rpiv = fast_rcp(pc[c]);          // started before the pivot test: the two dependency chains overlap
 #pragma unroll
         for (int r = c + 1; r < M; r++) oth = fmax(oth, fabs(pc[r]));
         if (__builtin_amdgcn_readfirstlane((int)(oth > best))) {
@@ -875,9 +876,10 @@ __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
             for (int r = c + 1; r < M; r++) {
                 if (piv == r) { double t = col[c]; col[c] = col[r]; col[r] = t; t = pc[c]; pc[c] = pc[r]; pc[r] = t; }
             }
+            rpiv = fast_rcp(pc[c]);
         }
         if (!(best > 0.0) || !isfinite(best)) sing = 1;
-        const double prow = col[c] * fast_rcp(pc[c]);
+        const double prow = col[c] * rpiv;
 #pragma unroll
         for (int r = 0; r < M; r++) if (r != c) col[r] -= pc[r] * prow;
         col[c] = prow;

@@ -785,17 +785,34 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
 }
 
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
+typedef double double2_t __attribute__((ext_vector_type(2)));
 template <class C>
 __device__ __forceinline__ void update_traj(const Params& pr, double* tgt, const double* src, double alpha, const double* dz) {
-    // four independent load pairs in flight per pass (the pass is pure streaming: latency-bound at one wave per game)
+    // pure streaming pass: 16 bytes per lane and four independent load pairs in flight per pass.  Every game's buffers start
+    // 16-byte aligned when traj_len is even (n is always even); otherwise the scalar loop runs.
     constexpr int U = 4;
-    const int S = pr.S;
-    for (int e0 = phase_lane(); e0 < S; e0 += U * WAVE) {
-        double a[U], d[U];
+    const int S = pr.S, lane = phase_lane();
+    if ((pr.traj_len & 1) == 0) {
+        const int S2 = S >> 1;                           // pairs; a last odd element is handled below
+        const double2_t* __restrict__ s2 = reinterpret_cast<const double2_t*>(src + C::n);
+        const double2_t* __restrict__ d2 = reinterpret_cast<const double2_t*>(dz + C::n);
+        double2_t* __restrict__ t2 = reinterpret_cast<double2_t*>(tgt + C::n);
+        for (int e0 = lane; e0 < S2; e0 += U * WAVE) {
+            double2_t a[U], d[U];
 #pragma unroll
-        for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; const int ec = e < S ? e : e0; a[t] = src[C::n + ec]; d[t] = dz[C::n + ec]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; const int ec = e < S2 ? e : e0; a[t] = s2[ec]; d[t] = d2[ec]; }
 #pragma unroll
-        for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; if (e < S) tgt[C::n + e] = a[t] + alpha * d[t]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; if (e < S2) { double2_t v; v.x = a[t].x + alpha * d[t].x; v.y = a[t].y + alpha * d[t].y; t2[e] = v; } }
+        }
+        if ((S & 1) && lane == 0) tgt[C::n + S - 1] = src[C::n + S - 1] + alpha * dz[C::n + S - 1];
+    } else {
+        for (int e0 = lane; e0 < S; e0 += U * WAVE) {
+            double a[U], d[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; const int ec = e < S ? e : e0; a[t] = src[C::n + ec]; d[t] = dz[C::n + ec]; }
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; if (e < S) tgt[C::n + e] = a[t] + alpha * d[t]; }
+        }
     }
 }
 // Δ_step (primal_dual_traj.jl:130-147)

@@ -176,7 +176,7 @@ def main():
                 "note": "achieved/frac follow the contract: SURVEY 8(d) bytes (dense block-LU factor spill) x game-iterations "
                         "per launch / launch time; the structured elimination never performs that spill, so frac > 1 means "
                         "'faster than the HBM ceiling of the dense algorithm'. own_* uses this kernel's own algorithmic bytes; "
-                        "traffic = FETCH_SIZE+WRITE_SIZE PMC bytes per launch (profiles/). The kernel is VALU-issue/latency bound.",
+                        "traffic = 2 x FETCH_SIZE + WRITE_SIZE PMC bytes per launch (L2-fabric side, calibrated with scratch/pmc_calib.hip; profiles/). The kernel is instruction-issue / latency bound.",
             },
         }
         prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))

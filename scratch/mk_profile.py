@@ -18,8 +18,8 @@ out = {
     "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline", "config": "C2", "games_per_gpu": bench["config"]["games_per_gpu"],
     "kernel": "k_newton_solve<Cfg<DI,3,2,0>>", "launches_averaged": nf,
     "fetch_size_kb": fetch["FETCH_SIZE"], "write_size_kb": write["WRITE_SIZE"],
-    "hbm_bytes_per_launch": 1024.0 * (fetch["FETCH_SIZE"] + write["WRITE_SIZE"]),
-    "note": "separate --pmc passes (scratch/prof_run.sh); KB units; FETCH_SIZE not doubled: the 2x gfx950 correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streaming reads, this kernel reads 8 B/lane -> lower bound on read bytes",
+    "hbm_bytes_per_launch": 1024.0 * (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]),
+    "note": "separate --pmc passes (scratch/prof_run.sh); KB units; FETCH_SIZE is doubled (gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE taken as is: calibrated on this box with scratch/pmc_calib.hip (2 GiB streams: FETCH_SIZE = 0.500 x bytes for 8 B/lane and 16 B/lane loads, WRITE_SIZE = 1.000 x bytes for 8 B/lane and 16 B/lane stores); these are L2-fabric-side bytes, Infinity-Cache hits included",
     "sq_per_launch": sq, "bench": bench,
 }
 json.dump(out, open(os.path.join(root, "profiles", tag + "_pmc_traffic.json"), "w"), indent=1)

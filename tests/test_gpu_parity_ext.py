@@ -224,3 +224,41 @@ def test_extended_constraints_unsupported_configuration_fails_loudly(alg):
     b = alg.Batch(alg.hip_lib(), DI, 2, 6, 0.1, 1, d=3)        # no EXT instantiation for d = 3
     with pytest.raises(alg.AlgamesError):
         b.add_circle_constraint([0.0], [0.0], [1.0])
+
+
+def _guards_ok(batch):
+    """Debug aid of libalgames_hip.so (not part of the public header): every device buffer is followed by a 4 KiB guard zone;
+    returns the number of buffers whose guard was overwritten."""
+    import ctypes
+    fn = batch.lib.dll.alg_debug_check_guards
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    return fn(batch.h)
+
+
+@pytest.mark.parametrize("case", [(DI, 1, 5), (DI, 3, 40), (DI, 4, 9), (UNI, 1, 6), (UNI, 3, 30), (UNI, 4, 50), (BIC, 2, 7), (BIC, 3, 20), (BIC, 4, 11)])
+def test_no_kernel_writes_outside_its_buffers(alg, case):
+    """Runs every kernel family of a configuration (solve, step-wise entry points, IBR, receding-horizon loop, dense Jacobian)
+    and checks the guard zones behind all device buffers."""
+    model, p, N = case
+    ext = model == BIC or p != 3
+    g = alg.Batch(alg.hip_lib(), model, p, N, 0.1, 5)
+    rng = np.random.default_rng(3)
+    ni = g.n // p
+    g.set_x0(rng.normal(size=(5, g.n)) * 0.5)
+    g.set_lqr(1 + rng.random((5, p, ni)), 0.5 + rng.random((5, p, g.mi)), rng.normal(size=(5, p, ni)), np.zeros((5, p, g.mi)))
+    if p > 1:
+        g.add_collision_cost(np.full(p, 2.0), np.ones(p)); g.add_collision_avoidance(np.full(p, 0.2))
+    g.add_control_bound(np.full(g.m, 2.0), np.full(g.m, -2.0))
+    if ext:                                                    # p == 3 double integrator / unicycle stay on the base kernels
+        g.add_wall_constraint([0.0], [-2.0], [1.0], [-2.0], [0.0], [-1.0])
+        g.add_circle_constraint([3.0], [3.0], [0.5])
+        g.add_state_bound(0, np.full(g.n, 50.0), np.full(g.n, -50.0))
+    g.set_options(outer_iter=3, inner_iter=4)
+    g.newton_solve(init=True, game_id0=11)
+    g.residual(); g.residual_jacobian(1e-3); g.newton_direction(1e-3); g.record()
+    g.newton_step(1, 1); g.dual_penalty_update(); g.rollout(0)
+    for player in range(p):
+        g.ibr_solve_player(player)
+    g.ibr_newton_solve(init=True, game_id0=3, ibr_iter=2, ordering=list(range(p)), delta_min=1e-9)
+    g.mpc_totals(reset=True); g.mpc_solve(3, 5, record_states=True)
+    assert _guards_ok(g) == 0

@@ -1217,7 +1217,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 col[c] = v;
             }
         }
+#ifndef ALG_NO_GJ
         sing |= gj_solve_cols<m>(col);
+#endif
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
         if (lane >= m && lane <= m + n) {
             const int cc = lane - m;

@@ -854,6 +854,40 @@ __device__ __forceinline__ double qhat_entry(const double* qd, const double* Hh,
     return e;
 }
 
+// the double held by lane ^ 32 (gfx950 v_permlane32_swap: upper half of vdst <-> lower half of src)
+__device__ __forceinline__ double xchg32(double v, bool lower_half) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(lower_half ? b[1] : b[0], lower_half ? a[1] : a[0]);
+}
+// A' X for the double integrator on an MFMA result tile (register r4 = row lq + 4 r4): (A' X)[r] = X[r] + dt X[r - m] for r >= m.
+// Row r - m sits in the same lane (m % 4 == 0) or in lane ^ 32 (m % 4 == 2): a few FMAs instead of a second MFMA product
+// (on MI355X an f64 MFMA holds the matrix pipe as long as sixteen FMAs hold the VALU).
+template <class C>
+__device__ __forceinline__ double4_t di_AT_tile(double4_t x, double dt, int lq) {
+    constexpr int m = C::m, q = m / 4, sh = m % 4;
+    static_assert(sh == 0 || sh == 2, "double-integrator tile shift");
+    double4_t y = x;
+    if constexpr (sh == 0) {
+#pragma unroll
+        for (int r4 = q; r4 < 4; r4++) y[r4] = fma(dt, x[r4 - q], x[r4]);
+    } else {
+        const bool up = lq >= 2;                 // rows of this lane with r >= m: partner register r4 - q (up) or r4 - q - 1
+        double part[4];
+#pragma unroll
+        for (int r4 = 0; r4 + q < 4; r4++) part[r4] = xchg32(x[r4], !up);
+#pragma unroll
+        for (int r4 = q; r4 < 4; r4++) {
+            const double pu = part[r4 - q], pl = (r4 - q - 1 >= 0) ? part[r4 - q - 1] : 0.0;
+            const double src = up ? pu : pl;
+            const double dte = (up || r4 - q - 1 >= 0) ? dt : 0.0;
+            y[r4] = fma(dte, src, x[r4]);
+        }
+    }
+    return y;
+}
+
 // wave-uniform broadcast of lane `src`'s double
 __device__ __forceinline__ double bcast_lane(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1109,10 +1143,15 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 for (int kb = 0; kb < KB1; kb++)
 #pragma unroll
                     for (int i = 0; i < P; i++) c1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[i][kb], bF[kb], c1[i], 0, 0, 0);
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
-                for (int kb = 0; kb < KB; kb++)
+                    for (int i = 0; i < P; i++) c2[i] = di_AT_tile<C>(c1[i], dt, lq);
+                } else {
 #pragma unroll
-                    for (int i = 0; i < P; i++) c2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[i][kb], c2[i], 0, 0, 0);
+                    for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+                        for (int i = 0; i < P; i++) c2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[i][kb], c2[i], 0, 0, 0);
+                }
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < P; i++)
@@ -1133,8 +1172,11 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                         const double pv = L.bw.Pm[i * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
                         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
                     }
+                    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) c2 = di_AT_tile<C>(c1, dt, lq);
+                    else {
 #pragma unroll
-                    for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
+                        for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
+                    }
                     __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; r4++) {

@@ -888,6 +888,23 @@ __device__ __forceinline__ double4_t di_AT_tile(double4_t x, double dt, int lq) 
     return y;
 }
 
+// A' X for the 4-player unicycle / bicycle (n = 16): the state blocks have 4 rows, so register r4 of lane group lq holds
+// block r4 of player lq -- the sparse A' (AT_vec above) is lane-local on the result tile.
+template <class C>
+__device__ __forceinline__ double4_t p4_AT_tile(double4_t x, const double* coef, int lq) {
+    static_assert(C::P == 4 && C::n == 16, "lane-local A' needs 4-row state blocks");
+    constexpr int P = C::P;
+    double4_t y = x;
+    if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
+        y[2] = x[2] + coef[0 * P + lq] * x[0] + coef[2 * P + lq] * x[1];
+        y[3] = x[3] + coef[1 * P + lq] * x[0] + coef[3 * P + lq] * x[1];
+    } else {
+        y[2] = x[2] + coef[1 * P + lq] * x[0] + coef[3 * P + lq] * x[1] + coef[4 * P + lq] * x[3];
+        y[3] = x[3] + coef[0 * P + lq] * x[0] + coef[2 * P + lq] * x[1];
+    }
+    return y;
+}
+
 // wave-uniform broadcast of lane `src`'s double
 __device__ __forceinline__ double bcast_lane(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1146,6 +1163,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
                     for (int i = 0; i < P; i++) c2[i] = di_AT_tile<C>(c1[i], dt, lq);
+                } else if constexpr (C::P == 4) {
+#pragma unroll
+                    for (int i = 0; i < P; i++) c2[i] = p4_AT_tile<C>(c1[i], L.coefn, lq);
                 } else {
 #pragma unroll
                     for (int kb = 0; kb < KB; kb++)
@@ -1173,6 +1193,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(colP ? pv : 0.0, bF[kb], c1, 0, 0, 0);
                     }
                     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) c2 = di_AT_tile<C>(c1, dt, lq);
+                    else if constexpr (C::P == 4) c2 = p4_AT_tile<C>(c1, L.coefn, lq);
                     else {
 #pragma unroll
                         for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);

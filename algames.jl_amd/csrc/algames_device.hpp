@@ -866,19 +866,19 @@ __device__ __forceinline__ double xchg32(double v, bool lower_half) {
 // (on MI355X an f64 MFMA holds the matrix pipe as long as sixteen FMAs hold the VALU).
 template <class C>
 __device__ __forceinline__ double4_t di_AT_tile(double4_t x, double dt, int lq) {
-    constexpr int m = C::m, q = m / 4, sh = m % 4;
+    constexpr int m = C::m, q = m / 4, sh = m % 4, NR = (C::n + 3) / 4;     // registers r4 < NR hold rows < n
     static_assert(sh == 0 || sh == 2, "double-integrator tile shift");
     double4_t y = x;
     if constexpr (sh == 0) {
 #pragma unroll
-        for (int r4 = q; r4 < 4; r4++) y[r4] = fma(dt, x[r4 - q], x[r4]);
+        for (int r4 = q; r4 < NR; r4++) y[r4] = fma(dt, x[r4 - q], x[r4]);
     } else {
         const bool up = lq >= 2;                 // rows of this lane with r >= m: partner register r4 - q (up) or r4 - q - 1
         double part[4];
 #pragma unroll
-        for (int r4 = 0; r4 + q < 4; r4++) part[r4] = xchg32(x[r4], !up);
+        for (int r4 = 0; r4 + q < NR; r4++) part[r4] = xchg32(x[r4], !up);
 #pragma unroll
-        for (int r4 = q; r4 < 4; r4++) {
+        for (int r4 = q; r4 < NR; r4++) {
             const double pu = part[r4 - q], pl = (r4 - q - 1 >= 0) ? part[r4 - q - 1] : 0.0;
             const double src = up ? pu : pl;
             const double dte = (up || r4 - q - 1 >= 0) ? dt : 0.0;

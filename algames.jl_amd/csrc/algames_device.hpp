@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstddef>
+#include <type_traits>
 #include "../../include/algames_hip.h"
 
 namespace alg {
@@ -905,6 +906,42 @@ __device__ __forceinline__ double4_t p4_AT_tile(double4_t x, const double* coef,
     return y;
 }
 
+// A' X for the 3-player unicycle (n = 12) on the result tile: the heading / speed rows 6 + i, 9 + i of player i take c * (row i)
+// + c' * (row 3 + i).  Rows live in (lane group lq = r % 4, register r / 4), so the two source rows of a target row are
+// fetched from other 16-lane groups with ds_bpermute (two rounds: targets in register 1 -- lane groups 2, 3 -- and in register
+// 2 -- all groups); the per-lane source addresses and the four coefficients are the same for every player's tile.
+template <class C>
+struct P3Gather {
+    int aA1, aB1, aA2, aB2;          // byte addresses (4 * source lane) of the x_i / y_i rows for the register-1 / register-2 target
+    int kA1, kB1, kA2, kB2;          // coefficient indices (into the step's coef table) of those targets
+    bool t1;                          // this lane's register 1 is a target (rows 6, 7)
+    __device__ __forceinline__ void init(int lq, int lrow) {
+        static_assert(C::MODEL == ALG_MODEL_UNICYCLE && C::P == 3, "3-player unicycle tile gather");
+        constexpr int P = 3;
+        auto setup = [&](int rt, int& aA, int& aB, int& kA, int& kB) {
+            const int i = (rt - 6) % 3, sB = 3 + i, hi = rt >= 9 ? 1 : 0;
+            aA = 4 * (16 * i + lrow); aB = 4 * (16 * (sB % 4) + lrow);
+            kA = hi * P + i; kB = (2 + hi) * P + i;
+        };
+        t1 = lq >= 2;
+        setup(t1 ? 4 + lq : 6, aA1, aB1, kA1, kB1);
+        setup(8 + lq, aA2, aB2, kA2, kB2);
+    }
+    __device__ __forceinline__ static double gather(int addr, double v) {
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ double4_t apply(double4_t x, const double* coef, int lq) const {
+        const double offB = (lq == 3) ? x[0] : x[1];             // row 3 sits in register 0 of group 3, rows 4, 5 in register 1 of groups 0, 1
+        const double gA1 = gather(aA1, x[0]), gB1 = gather(aB1, offB), gA2 = gather(aA2, x[0]), gB2 = gather(aB2, offB);
+        double4_t y = x;
+        const double u1 = coef[kA1] * gA1 + coef[kB1] * gB1;
+        y[1] = x[1] + (t1 ? u1 : 0.0);
+        y[2] = x[2] + coef[kA2] * gA2 + coef[kB2] * gB2;
+        return y;
+    }
+};
+
 // wave-uniform broadcast of lane `src`'s double
 __device__ __forceinline__ double bcast_lane(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1096,6 +1133,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     constexpr int KB1 = DirLds<C>::KB1, VW = DirLds<C>::VW;
     HxMap<C> hxm;                                        // costate sweep only (initialised there)
     QaddMap<C> qam; qam.init(lane);
+    struct NoGather { __device__ void init(int, int) {} };
+    typename std::conditional<(C::P == 3 && C::MODEL == ALG_MODEL_UNICYCLE), P3Gather<C>, NoGather>::type p3g;
+    p3g.init(lq, lrow);
     for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd[i * C::ni + r / P] : 0.0; }
     for (int e = lane; e < 16 * 16; e += WAVE) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
     for (int e = lane; e < P * n * LDP; e += WAVE) L.bw.Pm[e] = 0.0;
@@ -1166,6 +1206,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 } else if constexpr (C::P == 4) {
 #pragma unroll
                     for (int i = 0; i < P; i++) c2[i] = p4_AT_tile<C>(c1[i], L.coefn, lq);
+                } else if constexpr (C::P == 3 && C::MODEL == ALG_MODEL_UNICYCLE) {
+#pragma unroll
+                    for (int i = 0; i < P; i++) c2[i] = p3g.apply(c1[i], L.coefn, lq);
                 } else {
 #pragma unroll
                     for (int kb = 0; kb < KB; kb++)

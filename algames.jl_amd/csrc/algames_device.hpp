@@ -906,26 +906,32 @@ __device__ __forceinline__ double4_t p4_AT_tile(double4_t x, const double* coef,
     return y;
 }
 
-// A' X for the 3-player unicycle (n = 12) on the result tile: the heading / speed rows 6 + i, 9 + i of player i take c * (row i)
-// + c' * (row 3 + i).  Rows live in (lane group lq = r % 4, register r / 4), so the two source rows of a target row are
-// fetched from other 16-lane groups with ds_bpermute (two rounds: targets in register 1 -- lane groups 2, 3 -- and in register
-// 2 -- all groups); the per-lane source addresses and the four coefficients are the same for every player's tile.
+// A' X for the 3-player unicycle / bicycle (n = 12) on the result tile: rows 6 + i and 9 + i of player i take c * (row i) +
+// c' * (row 3 + i) (the bicycle's speed row 6 + i also c'' * (row 9 + i)).  Rows live in (lane group lq = r % 4, register
+// r / 4), so the source rows of a target row are fetched from other 16-lane groups with ds_bpermute (two rounds: targets in
+// register 1 -- lane groups 2, 3 -- and in register 2 -- all groups); the per-lane source addresses and coefficient indices
+// are the same for every player's tile.
 template <class C>
 struct P3Gather {
-    int aA1, aB1, aA2, aB2;          // byte addresses (4 * source lane) of the x_i / y_i rows for the register-1 / register-2 target
-    int kA1, kB1, kA2, kB2;          // coefficient indices (into the step's coef table) of those targets
-    bool t1;                          // this lane's register 1 is a target (rows 6, 7)
+    static constexpr bool BIC = C::MODEL == ALG_MODEL_BICYCLE;
+    int aA1, aB1, aC1, aA2, aB2, aC2;    // byte addresses (4 * source lane) of rows i, 3 + i, 9 + i for the register-1 / register-2 target
+    int kA1, kB1, kC1, kA2, kB2, kC2;    // coefficient indices (into the step's coef table) of those targets
+    bool t1, c2on;                        // register 1 is a target (rows 6, 7); register 2's target takes the third term (row 8)
     __device__ __forceinline__ void init(int lq, int lrow) {
-        static_assert(C::MODEL == ALG_MODEL_UNICYCLE && C::P == 3, "3-player unicycle tile gather");
+        static_assert(C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR && C::P == 3, "3-player unicycle / bicycle tile gather");
         constexpr int P = 3;
-        auto setup = [&](int rt, int& aA, int& aB, int& kA, int& kB) {
-            const int i = (rt - 6) % 3, sB = 3 + i, hi = rt >= 9 ? 1 : 0;
-            aA = 4 * (16 * i + lrow); aB = 4 * (16 * (sB % 4) + lrow);
-            kA = hi * P + i; kB = (2 + hi) * P + i;
+        auto setup = [&](int rt, int& aA, int& aB, int& aC, int& kA, int& kB, int& kC) {
+            const int i = (rt - 6) % 3, sB = 3 + i, sC = 9 + i, hi = rt >= 9 ? 1 : 0;
+            aA = 4 * (16 * i + lrow); aB = 4 * (16 * (sB % 4) + lrow); aC = 4 * (16 * (sC % 4) + lrow);
+            // unicycle: heading rows (6..8) use coef 0 / 2, speed rows (9..11) coef 1 / 3; bicycle: speed rows (6..8) coef 1 / 3 / 4,
+            // heading rows (9..11) coef 0 / 2
+            const int ta = BIC ? (hi ? 0 : 1) : hi, tb = BIC ? (hi ? 2 : 3) : 2 + hi;
+            kA = ta * P + i; kB = tb * P + i; kC = 4 * P + i;
         };
         t1 = lq >= 2;
-        setup(t1 ? 4 + lq : 6, aA1, aB1, kA1, kB1);
-        setup(8 + lq, aA2, aB2, kA2, kB2);
+        setup(t1 ? 4 + lq : 6, aA1, aB1, aC1, kA1, kB1, kC1);
+        setup(8 + lq, aA2, aB2, aC2, kA2, kB2, kC2);
+        c2on = (lq == 0);
     }
     __device__ __forceinline__ static double gather(int addr, double v) {
         const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
@@ -934,10 +940,14 @@ struct P3Gather {
     __device__ __forceinline__ double4_t apply(double4_t x, const double* coef, int lq) const {
         const double offB = (lq == 3) ? x[0] : x[1];             // row 3 sits in register 0 of group 3, rows 4, 5 in register 1 of groups 0, 1
         const double gA1 = gather(aA1, x[0]), gB1 = gather(aB1, offB), gA2 = gather(aA2, x[0]), gB2 = gather(aB2, offB);
+        double u1 = coef[kA1] * gA1 + coef[kB1] * gB1, u2 = coef[kA2] * gA2 + coef[kB2] * gB2;
+        if constexpr (BIC) {                                      // rows 9 + i: register 2 of groups 1, 2, 3
+            const double gC1 = gather(aC1, x[2]), gC2 = gather(aC2, x[2]);
+            u1 += coef[kC1] * gC1; u2 += c2on ? coef[kC2] * gC2 : 0.0;
+        }
         double4_t y = x;
-        const double u1 = coef[kA1] * gA1 + coef[kB1] * gB1;
         y[1] = x[1] + (t1 ? u1 : 0.0);
-        y[2] = x[2] + coef[kA2] * gA2 + coef[kB2] * gB2;
+        y[2] = x[2] + u2;
         return y;
     }
 };
@@ -1134,7 +1144,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     HxMap<C> hxm;                                        // costate sweep only (initialised there)
     QaddMap<C> qam; qam.init(lane);
     struct NoGather { __device__ void init(int, int) {} };
-    typename std::conditional<(C::P == 3 && C::MODEL == ALG_MODEL_UNICYCLE), P3Gather<C>, NoGather>::type p3g;
+    typename std::conditional<(C::P == 3 && C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR), P3Gather<C>, NoGather>::type p3g;
     p3g.init(lq, lrow);
     for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd[i * C::ni + r / P] : 0.0; }
     for (int e = lane; e < 16 * 16; e += WAVE) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
@@ -1206,7 +1216,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 } else if constexpr (C::P == 4) {
 #pragma unroll
                     for (int i = 0; i < P; i++) c2[i] = p4_AT_tile<C>(c1[i], L.coefn, lq);
-                } else if constexpr (C::P == 3 && C::MODEL == ALG_MODEL_UNICYCLE) {
+                } else if constexpr (C::P == 3) {
 #pragma unroll
                     for (int i = 0; i < P; i++) c2[i] = p3g.apply(c1[i], L.coefn, lq);
                 } else {
@@ -1237,6 +1247,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                     }
                     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) c2 = di_AT_tile<C>(c1, dt, lq);
                     else if constexpr (C::P == 4) c2 = p4_AT_tile<C>(c1, L.coefn, lq);
+                    else if constexpr (C::P == 3) c2 = p3g.apply(c1, L.coefn, lq);
                     else {
 #pragma unroll
                         for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);

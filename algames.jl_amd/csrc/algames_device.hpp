@@ -11,8 +11,8 @@
 //  * Newton direction: the KKT system of solver_methods.jl:87 is never materialised.  Its block-tridiagonal
 //    structure is eliminated by a structured block LU in the order (u_k via R^, lambda_k via -I,
 //    x_{k+1} via an m x m pivoted solve) -- a game-theoretic Riccati sweep.  Backward over k: the per-player value
-//    matrices [P_i | s_i] (n x (n+1), LDS) are advanced with two chained v_mfma_f64_16x16x4_f64 products per player
-//    ([P_i F | P_i f + s_i], then A' x that) followed by a table-driven sparse add of [Q^_i | rx_i]; the m x m control
+//    matrices [P_i | s_i] (n x (n+1), LDS) are advanced with a chain of v_mfma_f64_16x16x4_f64 per player
+//    ([P_i F | P_i f + s_i]; the sparse A' is then applied on the result tile in registers, or by a second MFMA product) followed by a table-driven sparse add of [Q^_i | rx_i]; the m x m control
 //    system with its n + 1 right-hand sides is solved by a column-per-lane Gauss-Jordan with partial pivoting (lane c
 //    owns column c, the pivot column is broadcast with v_readlane: wave-uniform pivots); gains go to HBM (m (n+1)
 //    doubles per step instead of the b^2 + b p n of a dense block LU).  Then a forward sweep for (dx, du) and a
@@ -1173,8 +1173,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         const double* Rc = L.rec[cur];
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         const double* coefk = Rc + R::COEF;
-        // ---- value recursion.  n < 16: [P_i | s_i] [[F f],[0 1]] = [P_i F | P_i f + s_i], then A' x that -- two chained f64 MFMA
-        // products per player (f and s_i ride in the spare tile column / k-block).  n == 16: the products cover P_i only and
+        // ---- value recursion.  n < 16: [P_i | s_i] [[F f],[0 1]] = [P_i F | P_i f + s_i], then A' x that (on the result tile in
+        // registers where the model's row layout allows it, else a second MFMA product) -- f64 MFMA chains per player (f and s_i ride in the spare tile column / k-block).  n == 16: the products cover P_i only and
         // s_i <- rx_i + A'(P_i f + s_i) runs on the VALU.  Accumulators start at zero; the sparse Q^_i (and rx_i) are added
         // afterwards (Q-add phase).  Player i's chain reads only row block i of Pm, so its result is written back before the
         // next player starts: one accumulator tile live.

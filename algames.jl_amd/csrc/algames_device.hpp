@@ -1174,7 +1174,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         const double* coefk = Rc + R::COEF;
         // ---- value recursion.  n < 16: [P_i | s_i] [[F f],[0 1]] = [P_i F | P_i f + s_i], then A' x that (on the result tile in
-        // registers where the model's row layout allows it, else a second MFMA product) -- f64 MFMA chains per player (f and s_i ride in the spare tile column / k-block).  n == 16: the products cover P_i only and
+        // registers where the model's row layout allows it, else a second MFMA product) -- f64 MFMA chains per player (f and s_i
+        // ride in the spare tile column / k-block).  n == 16: the products cover P_i only and
         // s_i <- rx_i + A'(P_i f + s_i) runs on the VALU.  Accumulators start at zero; the sparse Q^_i (and rx_i) are added
         // afterwards (Q-add phase).  Player i's chain reads only row block i of Pm, so its result is written back before the
         // next player starts: one accumulator tile live.

@@ -23,3 +23,8 @@ for seed in [int(a) for a in sys.argv[1:]]:
     hg, ho = g.get_history(0), o.get_history(0)
     print("   rel diff of res per record, game 0:", ["%.1e" % (abs(a - b) / max(abs(b), 1e-300)) for a, b in zip(hg["res"], ho["res"])])
     print("   res:", ["%.3g" % b for b in ho["res"]], "opt_vio", ["%.3g" % b for b in ho["opt_vio"]])
+    zg, zo = g.get_traj(0), o.get_traj(0)
+    print("   max |z_gpu - z_orc| per game:", np.abs(zg - zo).max(axis=1), "scale", np.abs(zo).max(axis=1))
+    for game in range(3):
+        hg, ho = g.get_history(game), o.get_history(game)
+        print("   game", game, "rel diff res:", ["%.1e" % (abs(a - b) / max(abs(b), 1e-300)) for a, b in zip(hg["res"], ho["res"])])

@@ -496,7 +496,15 @@ struct DirLds {
 };
 // The assemble pass works out of registers and HBM/L2 (no LDS staging); the type is kept for the kernels' LDS union.
 template <class C>
-struct AsmLds { double unused[1]; };
+struct AsmLds {
+    // phase A stages the record heads [coef | Hh | Hd] and gradient tables of WAVE / P steps here and writes them out as
+    // contiguous segments (the (step, player) items would otherwise scatter 8..24-byte fragments over 64 records per store)
+    // (only where four games share a SIMD and write traffic matters: the 256-VGPR configurations are latency-bound at their
+    // batch sizes and write directly)
+    static constexpr bool STAGED = (C::WPE == 4);
+    static constexpr int HEAD = Rec<C>::RQ, SL = HEAD + 2 * C::P * C::P, SPP = WAVE / C::P;
+    double stage[STAGED ? SPP * SL : 1];
+};
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 
 // ================================================================================================
@@ -529,11 +537,15 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
     // ---------------- phase A ------------------------------------------------------------------------------
     if (C::NC > 0 || C::POS) {
-        const int items = (N - 1) * P;
         const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
-        for (int e = lane; e < items; e += WAVE) {
-            const int k = e / P, i = e % P, kn = k + 1;
-            double* __restrict__ rec = G.rec + (size_t)k * R::LEN;
+        constexpr int HEAD = AsmLds<C>::HEAD, SL = AsmLds<C>::SL, SPP = AsmLds<C>::SPP, SGVT = HEAD - R::GVT;   // stage offset of the table
+        for (int kA = 0; kA < N - 1; kA += SPP) {
+          const int ks = lane / P, i = lane % P, k = kA + ks, kn = k + 1;
+          constexpr bool STAGED = AsmLds<C>::STAGED;
+          constexpr int SGV = STAGED ? SGVT : 0;
+          if (lane < SPP * P && k < N - 1) {
+            // staged: record head (offsets as in the record) + table at HEAD of this step's LDS slot; else the record itself
+            double* __restrict__ rec = STAGED ? L.stage + ks * SL : G.rec + (size_t)k * R::LEN;
             if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
                 const double* sk = zstate<C>(z, k);
                 double cf[10];
@@ -587,7 +599,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                         }
                     }
                     ga0 += gv0; ga1 += gv1; d0 += H0; d1 += H1; d2 += H2;
-                    rec[R::GVT + (i * P + j) * 2 + 0] = -gv0; rec[R::GVT + (i * P + j) * 2 + 1] = -gv1;   // row opt_i at px(j,.)
+                    rec[SGV + R::GVT + (i * P + j) * 2 + 0] = -gv0; rec[SGV + R::GVT + (i * P + j) * 2 + 1] = -gv1;   // row opt_i at px(j,.)
                     if (RECS) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
                 }
                 if constexpr (C::EXT) {
@@ -604,11 +616,24 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                     for (int wq = 0; wq < pr.nwall; wq++) { double gx, gy; const double c = wall_val(Wc, wq, xi0, xi1, &gx, &gy); al_row(ext_wall_row(pr, i, k, wq), c, gx, gy); }
                     for (int cq = 0; cq < pr.ncirc; cq++) { double gx, gy; const double c = circ_val(Cc, cq, xi0, xi1, &gx, &gy); al_row(ext_circ_row(pr, i, k, cq), c, gx, gy); }
                 }
-                rec[R::GVT + (i * P + i) * 2 + 0] = ga0; rec[R::GVT + (i * P + i) * 2 + 1] = ga1;           // row opt_i at px(i,.)
+                rec[SGV + R::GVT + (i * P + i) * 2 + 0] = ga0; rec[SGV + R::GVT + (i * P + i) * 2 + 1] = ga1;           // row opt_i at px(i,.)
                 if (RECS) { rec[R::HD + 3 * i] = d0; rec[R::HD + 3 * i + 1] = d1; rec[R::HD + 3 * i + 2] = d2; }
             }
+          }
+          if constexpr (STAGED) {
+              __syncthreads();
+              // write-out: contiguous [coef | Hh | Hd] and table segments of the staged steps
+              const int nst = (N - 1 - kA) < SPP ? (N - 1 - kA) : SPP;
+              for (int t = lane; t < nst * SL; t += WAVE) {
+                  const int ks2 = t / SL, o = t % SL;
+                  const size_t base = (size_t)(kA + ks2) * R::LEN;
+                  if (o >= HEAD) G.rec[base + R::GVT + (o - HEAD)] = L.stage[t];
+                  else if (RECS || o < C::NC) G.rec[base + o] = L.stage[t];
+              }
+              __syncthreads();
+          }
         }
-        __syncthreads();
+        if constexpr (!AsmLds<C>::STAGED) __syncthreads();
     }
     // ---------------- phase B ------------------------------------------------------------------------------
     // Every residual row of every step is independent once phase A has left the coefficients and the pair-gradient table:

@@ -515,7 +515,7 @@ template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 //   phase B (parallel, work item = one residual row of one step; three flat row loops):
 //           rows opt_i,x_{k+1} | opt_i,u_{i,k} | dyn_k  -> record [rx | ru | rd], R^ (, RQ), statistics
 //   MODE 0: statistics only (line-search trials)   MODE 1: + step records (Newton direction input)
-//   MODE 2: + residual vector in the reference's vertical order (alg_residual)
+//   MODE 2: + residual vector in the reference's vertical order and the constraint values (alg_residual)
 //   MODE 3: line-search trial that doubles as the next record!: statistics and step records of the UNREGULARISED
 //           residual (what record! sees if the trial is accepted) plus the regularised norm l1reg for the acceptance test
 // With zref != nullptr the proximal term reg (x - xref) is added to the rows; out.l1 is the norm of those rows
@@ -595,7 +595,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                             const double wl = lm + am * c;
                             gv0 += -2.0 * dl0 * wl; gv1 += -2.0 * dl1 * wl;
                             H0 += am * 4.0 * dl0 * dl0; H1 += am * 4.0 * dl0 * dl1; H2 += am * 4.0 * dl1 * dl1;
-                            G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
+                            if (MODE == 2) G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                         }
                     }
                     ga0 += gv0; ga1 += gv1; d0 += H0; d1 += H1; d2 += H2;
@@ -610,7 +610,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                         const double wl = lm + am * c;
                         ga0 += gx * wl; ga1 += gy * wl;
                         d0 += am * gx * gx; d1 += am * gx * gy; d2 += am * gy * gy;
-                        G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
+                        if (MODE == 2) G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                     };
                     const double* Wc = ext_walls(pr, G.extc); const double* Cc = ext_circs(pr, G.extc);
                     for (int wq = 0; wq < pr.nwall; wq++) { double gx, gy; const double c = wall_val(Wc, wq, xi0, xi1, &gx, &gy); al_row(ext_wall_row(pr, i, k, wq), c, gx, gy); }
@@ -713,7 +713,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                     for (int half = 0; half < 2; half++) {
                         const int ci = ext_sb_row(pr, i, k, half * n + a);
                         const double cv = half == 0 ? xa - ext_sbmax(pr, G.extc)[ei] : ext_sbmin(pr, G.extc)[ei] - xa;
-                        G.vals[ci] = cv;
+                        if (MODE == 2) G.vals[ci] = cv;
                         if (isfinite(cv)) {
                             const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
                             const double wl = lm + am * cv;
@@ -748,7 +748,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 for (int half = 0; half < 2; half++) {
                     const int ci = con_ctl<C>(pr, k, half * m + c);
                     const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
-                    G.vals[ci] = cv;
+                    if (MODE == 2) G.vals[ci] = cv;
                     if (isfinite(cv)) {
                         const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
                         const double wl = lm + am * cv;

@@ -149,4 +149,19 @@ function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0
     end
 end
 
+# The other drop-ins bind the same way on a handle prepared as above (same setup calls, then instead of alg_newton_solve):
+#
+#   ibr_newton_solve!(prob; ibr_opts)   (src/problem/solver_methods.jl:133-169)
+#       ordering = Int32.(ibr_opts.ordering .- 1)
+#       check(ccall((:alg_ibr_newton_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Int32, Ptr{Int32}, Float64, Ptr{AlgGameStats}),
+#                   h[], 1, game_id0, ibr_opts.ibr_iter, ordering, ibr_opts.Δ_min, stats))
+#   ibr_newton_solve!(prob, i)          (solver_methods.jl:171-228)
+#       check(ccall((:alg_ibr_solve_player, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{AlgGameStats}), h[], i - 1, stats))
+#   receding-horizon loop of BASELINE config 5 (opts.shift / opts.dual_reset warm starts; `steps` MPC steps per game, one launch)
+#       states = zeros(n, B, steps + 1)
+#       check(ccall((:alg_mpc_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Float64}), h[], steps, game_id0, states))
+#       check(ccall((:alg_mpc_totals, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int32), h[], iters, converged, 0))
+#   step-wise entry points (residual!, residual_jacobian!, inner_iteration, line_search, dual / penalty update):
+#       alg_residual, alg_residual_jacobian, alg_newton_step, alg_line_search, alg_dual_penalty_update (include/algames_hip.h)
+
 end # module

@@ -472,3 +472,22 @@ def test_golden_solutions_gpu(alg):
         assert np.array_equal(got["mu"], ref[f"{name}.mu"]), name
         assert np.abs(got["lam"] - ref[f"{name}.lam"]).max() <= 1e-6 * max(1.0, np.abs(ref[f"{name}.lam"]).max()), name
         assert np.allclose(got["res"], ref[f"{name}.res"], rtol=1e-7, atol=1e-12), name
+
+
+def test_shards_reproduce_the_whole_batch_bitwise(alg):
+    """scenario sharding is the only multi-GPU mechanism, so a shard must produce exactly (bit for bit) what the
+    same scenarios produce inside the whole batch -- inputs are keyed by global scenario id, games never interact, and every
+    game runs the same per-wavefront code whatever its position in the batch."""
+    for cfg, total, kw in (("C2", 12, dict(N=14)), ("C5", 6, {})):
+        whole = alg.scenarios.make_problem(cfg, np.arange(100, 100 + total), **kw)
+        alg.newton_solve(whole)
+        zw, sw = whole.batch.get_traj(), whole.stats.summary
+        for world in (2, 3):
+            parts, iters = [], 0
+            for rank in range(world):
+                lo, hi = alg.scenarios.shard_range(total, rank, world)
+                shard = alg.scenarios.make_problem(cfg, np.arange(100 + lo, 100 + hi), **kw)
+                alg.newton_solve(shard)
+                parts.append(shard.batch.get_traj()); iters += int(shard.stats.summary["newton_iters"].sum())
+            assert np.array_equal(np.concatenate(parts), zw)
+            assert iters == int(sw["newton_iters"].sum())

@@ -31,7 +31,7 @@ namespace alg {
 constexpr int WAVE = 64;
 constexpr int MAXP = 10;    // alphax_dual caps p <= 10 (options.jl:68)
 constexpr int MAXM = 32;
-constexpr int HIST_MAX = 192;
+constexpr int HIST_MAX = ALG_HIST_MAX;
 
 // Everything that is shared by the games of a handle; passed to kernels by value.
 struct Params {

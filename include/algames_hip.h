@@ -228,7 +228,10 @@ int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_sta
  * until alg_get_stats().  Used by the benchmark so that HIP events bracket only device work. */
 int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0);
 int alg_get_stats(alg_handle* h, alg_game_stats* stats /*B*/);
-/* Statistics history of one game (statistics.jl:5-15): up to max_records; returns count in *n_out */
+/* Statistics history of one game (statistics.jl:5-15): up to max_records; returns count in *n_out.
+ * The device keeps the first ALG_HIST_MAX (192) records of a solve (the reference's default options make at most
+ * outer_iter * inner_iter + 1 = 141); alg_game_stats.records counts all of them and .last is always the final record. */
+#define ALG_HIST_MAX 192
 int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out);
 int alg_synchronize(alg_handle* h);
 

@@ -85,8 +85,8 @@ struct Cfg {
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
     static constexpr int WPE = (n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 : 4;
-    // reuse the accepted line-search trial as the next record! (costs registers: off for the large configurations)
-    static constexpr bool TRIAL_REUSE = (n < 16);
+    // reuse the accepted line-search trial as the next record! (one assemble pass less per Newton iteration)
+    static constexpr bool TRIAL_REUSE = true;
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
     static constexpr int ASM_UNROLL = 2;
 };

@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
+import re
 import json
 import os
 import sys
@@ -179,7 +180,8 @@ def main():
                         "traffic = 2 x FETCH_SIZE + WRITE_SIZE PMC bytes per launch (L2-fabric side, calibrated with scratch/pmc_calib.hip; profiles/). The kernel is instruction-issue / latency bound.",
             },
         }
-        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")),
+                      key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])   # r01_v11 after r01_v6
         if prof:
             try:
                 pj = json.load(open(prof[-1]))

@@ -86,6 +86,9 @@ SIGNATURES = {
     "add_state_bound": (C.c_int, [_P, C.c_int32, _D, _D]),
     "add_wall_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D, _D, _D]),
     "add_circle_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
+    "add_spherical_collision_avoidance": (C.c_int, [_P, _D]),
+    "add_wall3d_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D]),
+    "add_cylinder_constraint": (C.c_int, [_P, C.c_int32, _D, _I, _D, _D]),
     "get_con_len": (C.c_int, [_P, _I]),
     "set_traj": (C.c_int, [_P, C.c_int32, _D]),
     "get_traj": (C.c_int, [_P, C.c_int32, _D]),
@@ -267,6 +270,21 @@ class Batch:
     def add_circle_constraint(self, xc, yc, radius):
         arrs = [_f64(a) for a in (xc, yc, radius)]
         self.lib.check(self.lib.add_circle_constraint(self.h, len(arrs[0]), *[_dptr(a) for a in arrs]))
+        self._refresh_con_len()
+
+    def add_spherical_collision_avoidance(self, radius):
+        r = _f64(np.broadcast_to(np.asarray(radius, dtype=np.float64), (self.p,)))
+        self.lib.check(self.lib.add_spherical_collision_avoidance(self.h, _dptr(r)))
+
+    def add_wall3d_constraint(self, p1, p2, p3, v):
+        arrs = [_f64(np.asarray(a, dtype=np.float64).reshape(-1, 3)) for a in (p1, p2, p3, v)]
+        self.lib.check(self.lib.add_wall3d_constraint(self.h, len(arrs[0]), *[_dptr(a) for a in arrs]))
+        self._refresh_con_len()
+
+    def add_cylinder_constraint(self, p, axis, l, r):
+        p = _f64(np.asarray(p, dtype=np.float64).reshape(-1, 3))
+        ax = np.ascontiguousarray(axis, dtype=np.int32)
+        self.lib.check(self.lib.add_cylinder_constraint(self.h, len(p), _dptr(p), ax.ctypes.data_as(_I), _dptr(_f64(l, (len(p),))), _dptr(_f64(r, (len(p),)))))
         self._refresh_con_len()
 
     # ---- data movement -----------------------------------------------------------------------

@@ -47,6 +47,7 @@ struct Params {
     unsigned long long ibr_ctl_rows[MAXP];   // control-bound rows counted by control_violation(game_con, pdtraj, i) (violations.jl:69-82)
     // extended ingredient set (Cfg::EXT instantiations only)
     int ext, has_sb, nwall, ncirc, sb_len, wall_len, circ_len;
+    int nwall3, ncyl, wall3_len, cyl_len, ca_dim;   // 3-D half (Cfg::PD == 3 only): Wall3D, Cylinder, spherical collision avoidance (ca_dim = 3)
     double lf, lr;          // BicycleGame(lf, lr), bicycle.jl:15
 };
 
@@ -64,7 +65,8 @@ struct Buffers {
     long long* mpc;         // B x 2 running totals (newton_iters, converged) of the receding-horizon loop
     double* tcache;         // B x 8 statistics of the last line-search trial (reused as the next record!)
     double* extc;           // constants of the extended constraints, shared by all games:
-                            // [x_max (p n) | x_min (p n) | walls x1 y1 x2 y2 xv yv (6 ALG_MAX_WALLS) | circles xc yc r (3 ALG_MAX_CIRCLES)]
+                            // [x_max (p n) | x_min (p n) | walls x1 y1 x2 y2 xv yv (6 ALG_MAX_WALLS) | circles xc yc r (3 ALG_MAX_CIRCLES)
+                            //  | 3-D walls p1 p2 p3 v (12 per wall, ALG_MAX_WALLS) | cylinders p (3) axis l r (6 per cylinder, ALG_MAX_CIRCLES)]
 };
 
 // EXT_ = 1 instantiations carry the extended ingredient set of examples/intro_example.jl (state bounds, walls, circles;
@@ -80,6 +82,11 @@ struct Cfg {
     static constexpr int ni = n / P_;
     static constexpr int b = n + m + P_ * n;
     static constexpr int NPAIR = P_ * (P_ - 1);
+    // position dimensions that carry pair / wall terms: px[i] = (x, y) everywhere (double_integrator.jl:19, unicycle.jl, bicycle.jl);
+    // the 3-D ingredients (spherical collision avoidance, Wall3D, Cylinder) act on pz[i][1:3] = (x, y, z) of DoubleIntegrator d = 3
+    static constexpr int PD = (EXT_ != 0 && MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR && D_ == 3) ? 3 : 2;
+    static constexpr int NS = PD * (PD + 1) / 2;          // entries of a symmetric PD x PD block: (0,0) (0,1) (1,1) [(0,2) (1,2) (2,2)]
+    __host__ __device__ static constexpr int sym(int a, int c) { return PD == 2 ? a + c : (a > c ? a * (a + 1) / 2 + c : c * (c + 1) / 2 + a); }
     static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : (MODEL_ == ALG_MODEL_BICYCLE) ? 10 * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
     static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : (MODEL_ == ALG_MODEL_UNICYCLE) ? 3 : 2;   // max non-zeros of a column of [B_k | A_k]
     static constexpr int WC = m + n + 1;         // augmented width of the control system
@@ -422,6 +429,10 @@ __device__ __forceinline__ const double* ext_sbmax(const Params& pr, const doubl
 __device__ __forceinline__ const double* ext_sbmin(const Params& pr, const double* ec) { return ec + pr.p * pr.n; }
 __device__ __forceinline__ const double* ext_walls(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n; }
 __device__ __forceinline__ const double* ext_circs(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS; }
+__device__ __forceinline__ const double* ext_walls3(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES; }
+__device__ __forceinline__ const double* ext_cyls(const Params& pr, const double* ec) { return ext_walls3(pr, ec) + 12 * ALG_MAX_WALLS; }
+__device__ __forceinline__ int ext_wall3_row(const Params& pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + (i * (pr.N - 1) + k) * pr.nwall3 + w; }
+__device__ __forceinline__ int ext_cyl_row(const Params& pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + (i * (pr.N - 1) + k) * pr.ncyl + c; }
 // WallConstraint evaluate / jacobian! (wall_constraint.jl:57-96): c = ((x-x1) xv + (y-y1) yv) left right
 __device__ __forceinline__ double wall_val(const double* W, int w, double x, double y, double* gx, double* gy) {
     const double x1 = W[w], y1 = W[ALG_MAX_WALLS + w], x2 = W[2 * ALG_MAX_WALLS + w], y2 = W[3 * ALG_MAX_WALLS + w];
@@ -437,21 +448,43 @@ __device__ __forceinline__ double circ_val(const double* Cc, int c, double x, do
     *gx = -2.0 * dx; *gy = -2.0 * dy;
     return -(dx * dx) - (dy * dy) + r * r;
 }
+// Wall3DConstraint evaluate / jacobian! (wall_constraint.jl:186-236): c = (q - p1).v inside the slab spanned by (p1,p2), (p2,p3)
+__device__ __forceinline__ double wall3_val(const double* W, int w, const double (&q)[3], double (&g)[3]) {
+    const double* p1 = W + 12 * w; const double* p2 = p1 + 3; const double* p3 = p1 + 6; const double* v = p1 + 9;
+    auto dot = [&](const double* a, const double* e, const double* c) { return (q[0] - a[0]) * (e[0] - c[0]) + (q[1] - a[1]) * (e[1] - c[1]) + (q[2] - a[2]) * (e[2] - c[2]); };
+    const double left = dot(p1, p2, p1) > 0.0 ? 1.0 : 0.0, right = dot(p2, p1, p2) > 0.0 ? 1.0 : 0.0;
+    const double bottom = dot(p3, p2, p3) > 0.0 ? 1.0 : 0.0, top = dot(p2, p3, p2) > 0.0 ? 1.0 : 0.0;
+    const double in = left * right * bottom * top;
+    g[0] = in * v[0]; g[1] = in * v[1]; g[2] = in * v[2];
+    return ((q[0] - p1[0]) * v[0] + (q[1] - p1[1]) * v[1] + (q[2] - p1[2]) * v[2]) * in;
+}
+// CylinderConstraint evaluate / jacobian! (cylinder_constraint.jl:68-127): axis-aligned, c = r^2 - (distance to the axis)^2
+// while 0 < (q - p)[axis] < l, else 0
+__device__ __forceinline__ double cyl_val(const double* Y, int c, const double (&q)[3], double (&g)[3]) {
+    const double* p = Y + 6 * c; const int ax = (int)p[3]; const double l = p[4], r = p[5];
+    const double t0[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+    const double ta = ax == 0 ? t0[0] : (ax == 1 ? t0[1] : t0[2]);
+    const double valid = (ta > 0.0 && ta < l) ? 1.0 : 0.0;
+    const double out = r * r - t0[0] * t0[0] - t0[1] * t0[1] - t0[2] * t0[2] + ta * ta;
+#pragma unroll
+    for (int a = 0; a < 3; a++) g[a] = (a == ax) ? 0.0 : -valid * 2 * t0[a];
+    return out * valid;
+}
 
 // ================================================================================================
 // Step records.  The assemble pass leaves one compact record per time step k in HBM; the serial sweeps of the Newton
 // direction read nothing else (plus the gains they spill themselves).
-//   [coefk (NC)] [Hh (3 NPAIR): pair Hessian blocks at knot k+1] [Hd (3 P): sum_j Hh(i,j)]
+//   [coefk (NC)] [Hh (NS NPAIR): pair Hessian blocks at knot k+1] [Hd (NS P): sum_j Hh(i,j)]      (NS = 3, or 6 with 3-D positions)
 //   (EXT only: [RQ (P n): diagonal state-bound Hessian of player i at knot k+1])
 //   [rx (P n): rows opt_i,x_{k+1}]                                                                  <- LEN_COSTATE
 //   [Rhat (m): R^ of knot k incl. reg] [ru (m): rows opt_i,u_{i,k}, joint order] [rd (n): dyn_k]      <- LEN_SWEEP
-//   [gvt (2 P^2): pair gradient table, only used inside the assemble pass]
+//   [gvt (PD P^2): pair gradient table, only used inside the assemble pass]
 // ================================================================================================
 template <class C> struct Rec {
     static constexpr int COEF = 0;
     static constexpr int HH = COEF + C::NC;
-    static constexpr int HD = HH + 3 * C::NPAIR;
-    static constexpr int RQ = HD + 3 * C::P;
+    static constexpr int HD = HH + C::NS * C::NPAIR;
+    static constexpr int RQ = HD + C::NS * C::P;
     static constexpr int RX = RQ + (C::EXT ? C::P * C::n : 0);
     static constexpr int LEN_COSTATE = RX + C::P * C::n;          // the costate sweep reads [coef | Hh | Hd | RQ | rx] only
     static constexpr int RHAT = LEN_COSTATE;
@@ -459,7 +492,7 @@ template <class C> struct Rec {
     static constexpr int RD = RU + C::m;
     static constexpr int LEN_SWEEP = RD + C::n;
     static constexpr int GVT = LEN_SWEEP;
-    static constexpr int LEN = GVT + 2 * C::P * C::P;
+    static constexpr int LEN = GVT + C::PD * C::P * C::P;
 };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -469,7 +502,7 @@ template <class C>
 struct DirLds {
     static constexpr int LDP = C::n + 1;                 // padded row stride of P_i
     static constexpr int KB = C::n / 4;                  // k-blocks of the 16x16x4 f64 MFMA
-    static constexpr int NHX = C::P * C::P * C::P * 3;   // expanded pair-Hessian table [i][jr][jc][3]
+    static constexpr int NHX = C::P * C::P * C::P * C::NS;   // expanded pair-Hessian table [i][jr][jc][NS]
     static_assert(C::n % 4 == 0 && C::n <= 16, "MFMA tile path needs n % 4 == 0 and n <= 16");
     static constexpr bool AUGS = C::n < 16;              // spare tile column: f and s_i ride through the MFMA products
     static constexpr int KB1 = AUGS ? (C::n + 4) / 4 : KB;   // k-blocks of the first product ([P_i | s_i]: n + 1 columns)
@@ -502,7 +535,7 @@ struct AsmLds {
     // (only where four games share a SIMD and write traffic matters: the 256-VGPR configurations are latency-bound at their
     // batch sizes and write directly)
     static constexpr bool STAGED = (C::WPE == 4);
-    static constexpr int HEAD = Rec<C>::RQ, SL = HEAD + 2 * C::P * C::P, SPP = WAVE / C::P;
+    static constexpr int HEAD = Rec<C>::RQ, SL = HEAD + C::PD * C::P * C::P, SPP = WAVE / C::P;
     double stage[STAGED ? SPP * SL : 1];
 };
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
@@ -563,61 +596,97 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 rec[R::COEF + 2 * P + i] = dt * vm * cs;  rec[R::COEF + 3 * P + i] = dt * sn;
             }
             if constexpr (C::POS) {
+                constexpr int PD = C::PD, NS = C::NS;
                 const double w = (kn < N - 1) ? dt : 1.0;
                 const double* x1 = z + n + hx<C>(k);
-                const double xi0 = x1[i], xi1 = x1[P + i];
-                double ga0 = 0, ga1 = 0, d0 = 0, d1 = 0, d2 = 0;
+                double xi[PD], ga[PD], dd[NS];
+#pragma unroll
+                for (int a = 0; a < PD; a++) { xi[a] = x1[a * P + i]; ga[a] = 0.0; }
+#pragma unroll
+                for (int t = 0; t < NS; t++) dd[t] = 0.0;
 #pragma unroll
                 for (int jj = 0; jj < P - 1; jj++) {
                     const int j = jj < i ? jj : jj + 1;
-                    double gv0 = 0, gv1 = 0, H0 = 0, H1 = 0, H2 = 0;
+                    double gv[PD], H[NS];
+#pragma unroll
+                    for (int a = 0; a < PD; a++) gv[a] = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NS; t++) H[t] = 0.0;
                     if (pairs_on) {
-                        const double dl0 = xi0 - x1[j], dl1 = xi1 - x1[P + j];
+                        double dl[PD];
+#pragma unroll
+                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - x1[a * P + j];
+                        const double dl0 = dl[0], dl1 = dl[1];
                         const double s2 = dl0 * dl0 + dl1 * dl1;
-                        if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173
+                        if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173 (planar: px[i])
                             const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
                             if (fmax(0.0, rad - nrm) > 0.0) {
                                 const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
                                 const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
                                 const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
-                                gv0 += w * (-g0); gv1 += w * (-g1);
+                                gv[0] += w * (-g0); gv[1] += w * (-g1);
                                 const double n3 = nrm * nrm * nrm;
-                                H0 += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
-                                H1 += w * (mu * (rad * (dl0 * dl1) / n3));
-                                H2 += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
+                                H[0] += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
+                                H[1] += w * (mu * (rad * (dl0 * dl1) / n3));
+                                H[2] += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
                             }
                         }
                         if (pr.has_colavoid) {                                   // CollisionConstraint + AL expansion
                             const double Rr = pr.ca_radius[i] + pr.ca_radius[j];
-                            const double c = Rr * Rr - s2;
+                            double s2c = s2;
+                            if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c += dl[2] * dl[2]; }   // spherical: pz[i][1:3]
+                            const double c = Rr * Rr - s2c;
                             const int ci = con_col<C>(N, pairq<C>(i, j), kn);
                             const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
                             const double wl = lm + am * c;
-                            gv0 += -2.0 * dl0 * wl; gv1 += -2.0 * dl1 * wl;
-                            H0 += am * 4.0 * dl0 * dl0; H1 += am * 4.0 * dl0 * dl1; H2 += am * 4.0 * dl1 * dl1;
+#pragma unroll
+                            for (int a = 0; a < PD; a++) {
+                                gv[a] += -2.0 * dl[a] * wl;
+#pragma unroll
+                                for (int a2 = 0; a2 <= a; a2++) H[C::sym(a, a2)] += am * 4.0 * dl[a2] * dl[a];
+                            }
                             if (MODE == 2) G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                         }
                     }
-                    ga0 += gv0; ga1 += gv1; d0 += H0; d1 += H1; d2 += H2;
-                    rec[SGV + R::GVT + (i * P + j) * 2 + 0] = -gv0; rec[SGV + R::GVT + (i * P + j) * 2 + 1] = -gv1;   // row opt_i at px(j,.)
-                    if (RECS) { double* hh = rec + R::HH + 3 * pairq<C>(i, j); hh[0] = H0; hh[1] = H1; hh[2] = H2; }
+#pragma unroll
+                    for (int a = 0; a < PD; a++) { ga[a] += gv[a]; rec[SGV + R::GVT + (i * P + j) * PD + a] = -gv[a]; }   // row opt_i at px(j,.)
+#pragma unroll
+                    for (int t = 0; t < NS; t++) dd[t] += H[t];
+                    if (RECS) {
+                        double* hh = rec + R::HH + NS * pairq<C>(i, j);
+#pragma unroll
+                        for (int t = 0; t < NS; t++) hh[t] = H[t];
+                    }
                 }
                 if constexpr (C::EXT) {
                     // wall / circle constraints of player i on its own position at knot k+1: AL gradient C'(lambda + a mu c)
                     // and Gauss-Newton Hessian C' a mu C (constraint_derivatives.jl:10-19,47-58) join the (i,i) position block
-                    auto al_row = [&](int ci, double c, double gx, double gy) {
+                    auto al_row = [&](int ci, double c, const double (&g)[PD]) {
                         const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
                         const double wl = lm + am * c;
-                        ga0 += gx * wl; ga1 += gy * wl;
-                        d0 += am * gx * gx; d1 += am * gx * gy; d2 += am * gy * gy;
+#pragma unroll
+                        for (int a = 0; a < PD; a++) {
+                            ga[a] += g[a] * wl;
+#pragma unroll
+                            for (int a2 = 0; a2 <= a; a2++) dd[C::sym(a, a2)] += am * g[a2] * g[a];
+                        }
                         if (MODE == 2) G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                     };
                     const double* Wc = ext_walls(pr, G.extc); const double* Cc = ext_circs(pr, G.extc);
-                    for (int wq = 0; wq < pr.nwall; wq++) { double gx, gy; const double c = wall_val(Wc, wq, xi0, xi1, &gx, &gy); al_row(ext_wall_row(pr, i, k, wq), c, gx, gy); }
-                    for (int cq = 0; cq < pr.ncirc; cq++) { double gx, gy; const double c = circ_val(Cc, cq, xi0, xi1, &gx, &gy); al_row(ext_circ_row(pr, i, k, cq), c, gx, gy); }
+                    for (int wq = 0; wq < pr.nwall; wq++) { double g[PD] = {}; const double c = wall_val(Wc, wq, xi[0], xi[1], &g[0], &g[1]); al_row(ext_wall_row(pr, i, k, wq), c, g); }
+                    for (int cq = 0; cq < pr.ncirc; cq++) { double g[PD] = {}; const double c = circ_val(Cc, cq, xi[0], xi[1], &g[0], &g[1]); al_row(ext_circ_row(pr, i, k, cq), c, g); }
+                    if constexpr (PD == 3) {
+                        const double* W3 = ext_walls3(pr, G.extc); const double* Yc = ext_cyls(pr, G.extc);
+                        for (int wq = 0; wq < pr.nwall3; wq++) { double g[3]; const double c = wall3_val(W3, wq, xi, g); al_row(ext_wall3_row(pr, i, k, wq), c, g); }
+                        for (int cq = 0; cq < pr.ncyl; cq++) { double g[3]; const double c = cyl_val(Yc, cq, xi, g); al_row(ext_cyl_row(pr, i, k, cq), c, g); }
+                    }
                 }
-                rec[SGV + R::GVT + (i * P + i) * 2 + 0] = ga0; rec[SGV + R::GVT + (i * P + i) * 2 + 1] = ga1;           // row opt_i at px(i,.)
-                if (RECS) { rec[R::HD + 3 * i] = d0; rec[R::HD + 3 * i + 1] = d1; rec[R::HD + 3 * i + 2] = d2; }
+#pragma unroll
+                for (int a = 0; a < PD; a++) rec[SGV + R::GVT + (i * P + i) * PD + a] = ga[a];           // row opt_i at px(i,.)
+                if (RECS) {
+#pragma unroll
+                    for (int t = 0; t < NS; t++) rec[R::HD + NS * i + t] = dd[t];
+                }
             }
           }
           if constexpr (STAGED) {
@@ -704,7 +773,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
             const double xa = z[zo + (uidx)a];
             r += w * (tq * (xa - tx));
-            if (C::POS) { const double gv = recg[ro + (uidx)(R::GVT + (i * P + a % P) * 2 + (a < 2 * P ? a / P : 0))]; r += (a < 2 * P) ? gv : 0.0; }
+            if (C::POS) { const double gv = recg[ro + (uidx)(R::GVT + (i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0))]; r += (a < C::PD * P) ? gv : 0.0; }
             if constexpr (C::EXT) {
                 // StateBoundConstraint of player i (state_bound_constraint.jl:85-97): rows (x - x_max)[a], (x_min - x)[a]
                 double qsb = 0.0;
@@ -863,12 +932,13 @@ template <class C>
 __device__ __forceinline__ double pairblock(const double* Hh, int i, int r, int c) {
     constexpr int P = C::P;
     if (!C::POS) return 0.0;
-    const int jr = r % P, ar = r / P, jc = c % P, ac = c / P, hidx = ar + ac;
+    constexpr int NS = C::NS;
+    const int jr = r % P, ar = r / P, jc = c % P, ac = c / P, hidx = C::sym(ar, ac);
     double e = 0.0;
-    if (jr == i && jc == i) e = Hh[3 * C::NPAIR + 3 * i + hidx];          // Hd_i = sum_j Hh(i,j) (+ wall / circle terms)
-    else if (jr == i) e = -Hh[pairq<C>(i, jc) * 3 + hidx];
-    else if (jc == i) e = -Hh[pairq<C>(i, jr) * 3 + hidx];
-    else if (jr == jc) e = Hh[pairq<C>(i, jr) * 3 + hidx];
+    if (jr == i && jc == i) e = Hh[NS * C::NPAIR + NS * i + hidx];          // Hd_i = sum_j Hh(i,j) (+ wall / circle terms)
+    else if (jr == i) e = -Hh[pairq<C>(i, jc) * NS + hidx];
+    else if (jc == i) e = -Hh[pairq<C>(i, jr) * NS + hidx];
+    else if (jr == jc) e = Hh[pairq<C>(i, jr) * NS + hidx];
     return e;
 }
 // Entry (r,c) of Q^_i = sum_j E[i][j].Q + state-constraint hess + reg I at a knot with stage weight w
@@ -876,7 +946,7 @@ template <class C>
 __device__ __forceinline__ double qhat_entry(const double* qd, const double* Hh, int i, int r, int c, double w, double reg) {
     double e = 0.0;
     if (r == c) { e = reg; if (r % C::P == i) e += w * qd[i * C::ni + r / C::P]; }
-    if (C::POS && r < 2 * C::P && c < 2 * C::P) e += pairblock<C>(Hh, i, r, c);
+    if (C::POS && r < C::PD * C::P && c < C::PD * C::P) e += pairblock<C>(Hh, i, r, c);
     return e;
 }
 
@@ -1076,11 +1146,12 @@ struct HxMap {
             const int t = lane + q * WAVE;
             int so = R::HH; double sg = 0.0;
             if (C::POS && t < DirLds<C>::NHX) {
-                const int h = t % 3, jc = (t / 3) % P, jr = (t / (3 * P)) % P, i = t / (3 * P * P);
-                if (jr == i && jc == i) { so = R::HD + 3 * i + h; sg = 1.0; }
-                else if (jr == i) { so = R::HH + 3 * pairq<C>(i, jc) + h; sg = -1.0; }
-                else if (jc == i) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = -1.0; }
-                else if (jr == jc) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = 1.0; }
+                constexpr int NS = C::NS;
+                const int h = t % NS, jc = (t / NS) % P, jr = (t / (NS * P)) % P, i = t / (NS * P * P);
+                if (jr == i && jc == i) { so = R::HD + NS * i + h; sg = 1.0; }
+                else if (jr == i) { so = R::HH + NS * pairq<C>(i, jc) + h; sg = -1.0; }
+                else if (jc == i) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = -1.0; }
+                else if (jr == jc) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = 1.0; }
             }
             src[q] = so; sgn[q] = sg;
         }
@@ -1097,17 +1168,19 @@ struct HxMap {
 // into row block i of Pm.  Per lane and pass: packed (dst | src << 11 | qi << 19), sign of the record source, diagonal flag.
 template <class C>
 struct QaddMap {
-    static constexpr int OFF = C::POS ? 4 * C::P * C::P - 2 * C::P : 0;
+    static constexpr int NP = C::PD * C::P;                // rows / columns of the position block
+    static constexpr int OFF = C::POS ? NP * NP - NP : 0;
     static constexpr bool RXCOL = C::n < 16;             // s_i lives in tile column n (else it is updated on the VALU)
     static constexpr int QE = C::n + OFF + (RXCOL ? C::n : 0), QTOT = C::P * QE, PASSES = (QTOT + WAVE - 1) / WAVE;
     unsigned code[PASSES]; float sgn[PASSES], dfl[PASSES];
     __device__ __forceinline__ static void hxsrc(int i, int jr, int jc, int h, int& so, float& sg) {
         using R = Rec<C>;
         so = 0; sg = 0.f;
-        if (jr == i && jc == i) { so = R::HD + 3 * i + h; sg = 1.f; }
-        else if (jr == i) { so = R::HH + 3 * pairq<C>(i, jc) + h; sg = -1.f; }
-        else if (jc == i) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = -1.f; }
-        else if (jr == jc) { so = R::HH + 3 * pairq<C>(i, jr) + h; sg = 1.f; }
+        constexpr int NS = C::NS;
+        if (jr == i && jc == i) { so = R::HD + NS * i + h; sg = 1.f; }
+        else if (jr == i) { so = R::HH + NS * pairq<C>(i, jc) + h; sg = -1.f; }
+        else if (jc == i) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = -1.f; }
+        else if (jr == jc) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = 1.f; }
     }
     __device__ __forceinline__ void init(int lane) {
         constexpr int n = C::n, P = C::P, LDP = n + 1;
@@ -1121,11 +1194,11 @@ struct QaddMap {
                 const int i = e / QE, t = e % QE;
                 if (t < n) {
                     dst = i * n * LDP + t * LDP + t; qi = i * n + t; df = 1.f;
-                    if (C::POS && t < 2 * P) hxsrc(i, t % P, t % P, 2 * (t / P), so, sg);
+                    if (C::POS && t < NP) hxsrc(i, t % P, t % P, C::sym(t / P, t / P), so, sg);
                 } else if (t < n + OFF) {
-                    const int u = t - n, r = u / (2 * P - 1), cc = u % (2 * P - 1), c = cc < r ? cc : cc + 1;
+                    const int u = t - n, r = u / (NP - 1), cc = u % (NP - 1), c = cc < r ? cc : cc + 1;
                     dst = i * n * LDP + r * LDP + c;
-                    hxsrc(i, r % P, c % P, r / P + c / P, so, sg);
+                    hxsrc(i, r % P, c % P, C::sym(r / P, c / P), so, sg);
                 } else {
                     const int r = t - n - OFF;
                     dst = i * n * LDP + r * LDP + n; so = R::RX + i * n + r; sg = 1.f;
@@ -1455,7 +1528,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
     for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
-    const bool cpos = C::POS && cr_ < 2 * P;
+    const bool cpos = C::POS && cr_ < C::PD * P;
     double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
     auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
         rdx = 0.0;
@@ -1486,9 +1559,10 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             if constexpr (C::EXT) qd += Rc[R::RQ + lane];
             acc = Rc[R::RX + lane] + qd * L.fw.dx[cr_];
             if (cpos) {
-                const double* hrow = &L.fw.hx[(ci_ * P + cr_ % P) * P * 3 + cr_ / P];
+                const double* hrow = &L.fw.hx[(ci_ * P + cr_ % P) * P * C::NS];
+                const int ar = cr_ / P;
 #pragma unroll
-                for (int c = 0; c < 2 * P; c++) acc += hrow[(c % P) * 3 + c / P] * L.fw.dx[c];
+                for (int c = 0; c < C::PD * P; c++) acc += hrow[(c % P) * C::NS + C::sym(ar, c / P)] * L.fw.dx[c];
             }
             if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
@@ -1681,7 +1755,9 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
             const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / PM1, jj = q % PM1, j = jj < i ? jj : jj + 1;
             const double* x = zstate<C>(z, k);
             const double d0 = x[i] - x[j], d1 = x[P + i] - x[P + j], R = pr.ca_radius[i] + pr.ca_radius[j];
-            const double c = R * R - (d0 * d0 + d1 * d1);
+            double s2 = d0 * d0 + d1 * d1;
+            if constexpr (C::PD == 3) { const double d2 = pr.ca_dim == 3 ? x[2 * P + i] - x[2 * P + j] : 0.0; s2 += d2 * d2; }
+            const double c = R * R - s2;
             G.vals[e] = c;
             const double lb = G.lam[e] + o.alphax_dual[i] * G.mu[e] * c;
             G.lam[e] = fmin(fmax(lb, 0.0), o.lambda_max);
@@ -1700,7 +1776,7 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
     if constexpr (C::EXT) {
         // state constraints of player i: dual_update! with alphax_dual[i] (constraints_methods.jl:421-440)
         const int e0 = pr.col_len + pr.ctl_len, K = N - 1;
-        for (int e = threadIdx.x; e < pr.sb_len + pr.wall_len + pr.circ_len; e += WAVE) {
+        for (int e = threadIdx.x; e < pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + pr.cyl_len; e += WAVE) {
             int i, k; double c;
             if (e < pr.sb_len) {
                 const int row = e % (2 * n); k = (e / (2 * n)) % K; i = e / (2 * n * K);
@@ -1710,10 +1786,21 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
                 const int e2 = e - pr.sb_len, w = e2 % pr.nwall; k = (e2 / pr.nwall) % K; i = e2 / (pr.nwall * K);
                 const double* x = zstate<C>(z, k + 1); double gx, gy;
                 c = wall_val(ext_walls(pr, G.extc), w, x[i], x[P + i], &gx, &gy);
-            } else {
+            } else if (e < pr.sb_len + pr.wall_len + pr.circ_len) {
                 const int e2 = e - pr.sb_len - pr.wall_len, cq = e2 % pr.ncirc; k = (e2 / pr.ncirc) % K; i = e2 / (pr.ncirc * K);
                 const double* x = zstate<C>(z, k + 1); double gx, gy;
                 c = circ_val(ext_circs(pr, G.extc), cq, x[i], x[P + i], &gx, &gy);
+            } else {
+                i = 0; k = 0; c = 0.0;
+                if constexpr (C::PD == 3) {
+                    int e2 = e - pr.sb_len - pr.wall_len - pr.circ_len;
+                    const bool w3 = e2 < pr.wall3_len;
+                    if (!w3) e2 -= pr.wall3_len;
+                    const int cnt = w3 ? pr.nwall3 : pr.ncyl, q = e2 % cnt; k = (e2 / cnt) % K; i = e2 / (cnt * K);
+                    const double* x = zstate<C>(z, k + 1);
+                    const double pos[3] = {x[i], x[P + i], x[2 * P + i]}; double g[3];
+                    c = w3 ? wall3_val(ext_walls3(pr, G.extc), q, pos, g) : cyl_val(ext_cyls(pr, G.extc), q, pos, g);
+                }
             }
             const int ci = e0 + e;
             G.vals[ci] = c;

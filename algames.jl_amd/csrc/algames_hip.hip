@@ -49,11 +49,13 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.ctl_len = 2 * p.m * (p.N - 1);
     p.con_len = p.col_len + p.ctl_len;
     p.ext = (a.model == ALG_MODEL_BICYCLE) ? 1 : 0;                      // the bicycle kernels are EXT instantiations
+    p.ca_dim = 2;
     p.hist_max = HIST_MAX;
     p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
     {   // Rec<C>::LEN of the EXT instantiation (the base one is p n shorter; the buffer is sized for either)
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : 0;
-        p.rec_len = (p.N - 1) * (nc + 3 * p.npair + 3 * p.p + p.m + 2 * p.p * p.n + p.m + p.n + 2 * p.p * p.p);
+        const int pd = (p.model == ALG_MODEL_DOUBLE_INTEGRATOR && p.d == 3) ? 3 : 2, ns = pd * (pd + 1) / 2;   // Cfg::PD / NS of the EXT instantiation
+        p.rec_len = (p.N - 1) * (nc + ns * p.npair + ns * p.p + p.m + 2 * p.p * p.n + p.m + p.n + pd * p.p * p.p);
     }
     return true;
 }
@@ -61,7 +63,9 @@ void recount_con(Params& p) {
     p.sb_len = p.has_sb ? p.p * 2 * p.n * (p.N - 1) : 0;
     p.wall_len = p.p * p.nwall * (p.N - 1);
     p.circ_len = p.p * p.ncirc * (p.N - 1);
-    p.con_len = p.col_len + p.ctl_len + p.sb_len + p.wall_len + p.circ_len;
+    p.wall3_len = p.p * p.nwall3 * (p.N - 1);
+    p.cyl_len = p.p * p.ncyl * (p.N - 1);
+    p.con_len = p.col_len + p.ctl_len + p.sb_len + p.wall_len + p.circ_len + p.wall3_len + p.cyl_len;
 }
 
 // supported template instantiations: ALG_CFGS_BASE / ALG_CFGS_EXT (algames_kernels.hpp)
@@ -149,6 +153,7 @@ int launch_check(const char* what) {
     LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 2, 2, 0, kernel, __VA_ARGS__)                   \
     LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 3, 2, 0, kernel, __VA_ARGS__)                   \
     LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 4, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, 1, kernel, __VA_ARGS__)          \
     LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 1, kernel, __VA_ARGS__)          \
     LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 1, kernel, __VA_ARGS__)          \
     LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 1, kernel, __VA_ARGS__)          \
@@ -177,7 +182,7 @@ int alloc_all(Handle* hd) {
     if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max, "bf.hist"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.mpc, 2 * B, "bf.mpc"))) return rc;
     if ((rc = dalloc(hd, &hd->bf.tcache, 8 * B, "bf.tcache"))) return rc;
-    hd->extc.assign(2 * (size_t)p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES, 0.0);
+    hd->extc.assign(2 * (size_t)p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES + 12 * ALG_MAX_WALLS + 6 * ALG_MAX_CIRCLES, 0.0);
     if ((rc = dalloc(hd, &hd->bf.extc, hd->extc.size(), "bf.extc"))) return rc;
     if ((rc = dalloc(hd, &hd->d_tmp, 2 * B, "d_tmp"))) return rc;
     if ((rc = dalloc(hd, &hd->d_itmp, B, "d_itmp"))) return rc;
@@ -304,7 +309,7 @@ int alg_add_collision_avoidance(alg_handle* h, const double* radius) {
     Params& p = H->pr;
     if (!radius) { p.has_colavoid = 0; return ALG_OK; }
     for (int i = 0; i < p.p; i++) p.ca_radius[i] = radius[i];
-    p.has_colavoid = 1; return ALG_OK;
+    p.has_colavoid = 1; p.ca_dim = 2; return ALG_OK;
 }
 int alg_add_control_bound(alg_handle* h, const double* umax, const double* umin) {
     Params& p = H->pr;
@@ -332,7 +337,7 @@ static int ext_commit(Handle* hd) {
     int rc = use_device(hd); if (rc) return rc;
     if ((rc = sync(hd))) return rc;
     Params& p = hd->pr;
-    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2, Unicycle, Bicycle; p<=4)");
+    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 p<=4 / d=3 p=2, Unicycle, Bicycle p<=4)");
     p.ext = 1;
     recount_con(p);
     dfree(hd, hd->bf.lam); dfree(hd, hd->bf.mu); dfree(hd, hd->bf.vals);
@@ -380,6 +385,43 @@ int alg_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const
     const double* src[3] = {xc, yc, rad};
     for (int f = 0; f < 3; f++) for (int c = 0; c < nc; c++) Cc[f * ALG_MAX_CIRCLES + c] = src[f][c];
     p.ncirc = nc;
+    return ext_commit(H);
+}
+// ---- 3-D half (pz[i][1:3] = positions of DoubleIntegrator d = 3) -------------------------------------------------------
+static int need_3d(Handle* hd, const char* who) {
+    if (hd->pr.model != ALG_MODEL_DOUBLE_INTEGRATOR || hd->pr.d != 3) {
+        return fail(ALG_ERR_ARG, std::string(who) + ": needs a model with three position dimensions (DoubleIntegrator d = 3)");
+    }
+    return ALG_OK;
+}
+int alg_add_spherical_collision_avoidance(alg_handle* h, const double* radius) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_spherical_collision_avoidance: null handle");
+    Params& p = H->pr;
+    if (!radius) { p.has_colavoid = 0; p.ca_dim = 2; return ALG_OK; }
+    if (int rc = need_3d(H, "alg_add_spherical_collision_avoidance")) return rc;
+    for (int i = 0; i < p.p; i++) p.ca_radius[i] = radius[i];
+    p.has_colavoid = 1; p.ca_dim = 3;
+    return ext_commit(H);                      // the 3-D pair blocks live in the EXT instantiation
+}
+int alg_add_wall3d_constraint(alg_handle* h, int32_t nw, const double* p1, const double* p2, const double* p3, const double* v) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_wall3d_constraint: null handle");
+    if (nw < 0 || nw > ALG_MAX_WALLS || (nw > 0 && (!p1 || !p2 || !p3 || !v))) return fail(ALG_ERR_ARG, "alg_add_wall3d_constraint: bad argument (at most ALG_MAX_WALLS walls)");
+    if (int rc = need_3d(H, "alg_add_wall3d_constraint")) return rc;
+    Params& p = H->pr;
+    double* W = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES;
+    for (int w = 0; w < nw; w++) for (int a = 0; a < 3; a++) { W[12 * w + a] = p1[3 * w + a]; W[12 * w + 3 + a] = p2[3 * w + a]; W[12 * w + 6 + a] = p3[3 * w + a]; W[12 * w + 9 + a] = v[3 * w + a]; }
+    p.nwall3 = nw;
+    return ext_commit(H);
+}
+int alg_add_cylinder_constraint(alg_handle* h, int32_t nc, const double* pp, const int32_t* axis, const double* l, const double* r) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint: null handle");
+    if (nc < 0 || nc > ALG_MAX_CIRCLES || (nc > 0 && (!pp || !axis || !l || !r))) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint: bad argument (at most ALG_MAX_CIRCLES cylinders)");
+    if (int rc = need_3d(H, "alg_add_cylinder_constraint")) return rc;
+    for (int c = 0; c < nc; c++) if (axis[c] < 0 || axis[c] > 2) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint: axis must be 0 (:x), 1 (:y) or 2 (:z)");
+    Params& p = H->pr;
+    double* Y = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES + 12 * ALG_MAX_WALLS;
+    for (int c = 0; c < nc; c++) { for (int a = 0; a < 3; a++) Y[6 * c + a] = pp[3 * c + a]; Y[6 * c + 3] = (double)axis[c]; Y[6 * c + 4] = l[c]; Y[6 * c + 5] = r[c]; }
+    p.ncyl = nc;
     return ext_commit(H);
 }
 int alg_get_con_len(alg_handle* h, int32_t* n) {

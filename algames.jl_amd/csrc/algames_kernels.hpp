@@ -191,7 +191,9 @@ __global__ void __launch_bounds__(WAVE, C::WPE) k_mpc_loop(Params pr, Buffers bf
     X(ALG_MODEL_BICYCLE, 2, 2, 1)                            \
     X(ALG_MODEL_BICYCLE, 3, 2, 1)                            \
     X(ALG_MODEL_BICYCLE, 4, 2, 1)
-#define ALG_CFGS_EXT(X) ALG_CFGS_EXT_DI(X) ALG_CFGS_EXT_UNI(X) ALG_CFGS_EXT_BIC(X)
+#define ALG_CFGS_EXT_DI3(X)                                 \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, 1)
+#define ALG_CFGS_EXT(X) ALG_CFGS_EXT_DI(X) ALG_CFGS_EXT_UNI(X) ALG_CFGS_EXT_BIC(X) ALG_CFGS_EXT_DI3(X)
 
 // every kernel of one instantiation; PREFIX is `template` (definition) or `extern template` (declaration)
 #define ALG_INSTANTIATE_KERNELS(PREFIX, M, P, D, E)                                                                        \

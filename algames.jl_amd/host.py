@@ -282,6 +282,9 @@ class GameConstraintValues:
         self.state_conval = [[] for _ in range(probsize.p)]   # per player: the state-bound sets in the order they were added
         self.walls = None
         self.circles = None
+        self.spherical = False           # collision_radius applies to the 3-D distance (add_spherical_collision_avoidance!)
+        self.walls3d = None
+        self.cylinders = None
 
 
 def add_collision_avoidance(game_con, radius):
@@ -294,6 +297,13 @@ def add_collision_avoidance(game_con, radius):
     if game_con.collision_radius is not None:
         raise AlgamesError("only one collision-avoidance set per GameConstraintValues is supported")
     game_con.collision_radius = r
+
+
+def add_spherical_collision_avoidance(game_con, radius):
+    """add_spherical_collision_avoidance!(game_con, radius), constraints_methods.jl:63-81: CollisionConstraint on pz[i][1:3]
+    (the x, y, z positions of a DoubleIntegratorGame with d = 3; other models are rejected when the problem is built)."""
+    add_collision_avoidance(game_con, radius)
+    game_con.spherical = True
 
 
 def add_control_bound(game_con, u_max, u_min):
@@ -360,11 +370,35 @@ class Wall:
         self.p1, self.p2, self.v = (np.asarray(a, dtype=np.float64) for a in (p1, p2, v))
 
 
+class Wall3D:
+    """Wall3D(p1, p2, p3, v), constraints_methods.jl:201-206: parallelogram corners p1, p2, p3 and the normal v of its plane
+    pointing into the forbidden half space."""
+
+    def __init__(self, p1, p2, p3, v):
+        self.p1, self.p2, self.p3, self.v = (np.asarray(a, dtype=np.float64) for a in (p1, p2, p3, v))
+
+
+class CylinderWall:
+    """CylinderWall(p, v, l, r), constraints_methods.jl:249-254: axis-aligned cylinder with origin p, axis v in (:x, :y, :z)
+    (also accepted: "x"/"y"/"z" or 0/1/2), length l, radius r."""
+
+    def __init__(self, p, v, l, r):
+        self.p = np.asarray(p, dtype=np.float64)
+        self.v = {"x": 0, "y": 1, "z": 2, ":x": 0, ":y": 1, ":z": 2, 0: 0, 1: 1, 2: 2}[v]
+        self.l, self.r = float(l), float(r)
+
+
 def add_wall_constraint(game_con, walls):
-    """add_wall_constraint!(game_con, walls), constraints_methods.jl:189-195 (every player)."""
-    if game_con.walls is not None:
-        raise AlgamesError("only one wall set per GameConstraintValues is supported")
-    game_con.walls = list(walls)
+    """add_wall_constraint!(game_con, walls), constraints_methods.jl:189-195 (every player); dispatches on the wall type like the
+    reference's methods for Vector{Wall} (:161), Vector{Wall3D} (:208) and Vector{CylinderWall} (:256)."""
+    walls = list(walls)
+    kinds = {type(w) for w in walls}
+    if len(kinds) != 1:
+        raise TypeError("add_wall_constraint: walls must all be Wall, all Wall3D or all CylinderWall")
+    slot = {Wall: "walls", Wall3D: "walls3d", CylinderWall: "cylinders"}[kinds.pop()]
+    if getattr(game_con, slot) is not None:
+        raise AlgamesError("only one wall set of each kind per GameConstraintValues is supported")
+    setattr(game_con, slot, walls)
 
 
 def add_circle_constraint(game_con, xc, yc, radius):
@@ -425,7 +459,10 @@ class GameProblem:
         if game_obj.collision_radius is not None:
             self.batch.add_collision_cost(game_obj.collision_radius, game_obj.collision_μ)
         if game_con.collision_radius is not None:
-            self.batch.add_collision_avoidance(game_con.collision_radius)
+            if game_con.spherical:
+                self.batch.add_spherical_collision_avoidance(game_con.collision_radius)
+            else:
+                self.batch.add_collision_avoidance(game_con.collision_radius)
         if game_con.u_max is not None:
             self.batch.add_control_bound(game_con.u_max, game_con.u_min)
         for i in sorted(game_con.state_bounds):
@@ -436,6 +473,12 @@ class GameProblem:
                                            [a.p2[1] for a in w], [a.v[0] for a in w], [a.v[1] for a in w])
         if game_con.circles is not None:
             self.batch.add_circle_constraint(*game_con.circles)
+        if game_con.walls3d:
+            w = game_con.walls3d
+            self.batch.add_wall3d_constraint([a.p1 for a in w], [a.p2 for a in w], [a.p3 for a in w], [a.v for a in w])
+        if game_con.cylinders:
+            c = game_con.cylinders
+            self.batch.add_cylinder_constraint([a.p for a in c], [a.v for a in c], [a.l for a in c], [a.r for a in c])
         self.stats = None
         self._sync_options()       # set_constraint_params!(game_con, opts), problem.jl:49
 

@@ -176,6 +176,18 @@ int alg_add_wall_constraint(alg_handle* h, int32_t n_wall, const double* x1, con
                             const double* y2, const double* xv, const double* yv);
 /* add_circle_constraint!(game_con, xc, yc, radius) (constraints_methods.jl:120-148; TrajOpt CircleConstraint): every player */
 int alg_add_circle_constraint(alg_handle* h, int32_t n_circle, const double* xc, const double* yc, const double* radius);
+/* ---- 3-D half of the constraint set.  The reference addresses pz[i][1:3] (constraints_methods.jl:52-53,231-236,275): the
+ * first three state entries of player i, which are its x, y, z positions for DoubleIntegratorGame(d = 3) -- the only model
+ * these three calls accept (ALG_ERR_ARG otherwise). */
+/* add_spherical_collision_avoidance!(game_con, radius) (constraints_methods.jl:45-81): as alg_add_collision_avoidance with the
+ * 3-D distance; replaces a previously added planar collision avoidance (they share the constraint rows) */
+int alg_add_spherical_collision_avoidance(alg_handle* h, const double* radius /*p*/);
+/* add_wall_constraint!(game_con, walls::Vector{Wall3D}) (constraints_methods.jl:201-242; wall_constraint.jl:127-236): every
+ * player, knots 2..N; wall w = parallelogram corner points p1, p2, p3 and normal v into the forbidden half space (n_wall x 3 each) */
+int alg_add_wall3d_constraint(alg_handle* h, int32_t n_wall, const double* p1, const double* p2, const double* p3, const double* v);
+/* add_wall_constraint!(game_con, walls::Vector{CylinderWall}) (constraints_methods.jl:249-284; cylinder_constraint.jl:35-127):
+ * axis-aligned cylinders, origin p (n_cyl x 3), axis 0/1/2 = :x/:y/:z, length l, radius r; every player, knots 2..N */
+int alg_add_cylinder_constraint(alg_handle* h, int32_t n_cyl, const double* p, const int32_t* axis, const double* l, const double* r);
 /* current length of the constraint dual / penalty / value vectors of one game */
 int alg_get_con_len(alg_handle* h, int32_t* con_len);
 

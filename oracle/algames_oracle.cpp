@@ -52,6 +52,7 @@ struct Dims {
     int n = 0, m = 0, mi = 0, ni = 0, S = 0, b = 0;
     int traj_len = 0, npair = 0, col_len = 0, ctl_len = 0, con_len = 0;
     int nwall = 0, ncirc = 0, has_sb = 0, sb_len = 0, wall_len = 0, circ_len = 0;      // extended constraints
+    int nwall3 = 0, ncyl = 0, wall3_len = 0, cyl_len = 0, ca_dim = 2;                  // 3-D half: Wall3D, Cylinder, spherical collision avoidance
     double dt = 0, lf = 0.05, lr = 0.05;                                              // BicycleGame(lf, lr), bicycle.jl:15
     // src/struct/problem_size.jl:18-35 ; src/dynamics/double_integrator.jl:13-25 ; unicycle.jl:14-25
     bool init(const alg_desc& a) {
@@ -74,11 +75,14 @@ struct Dims {
     }
     void recount() {
         sb_len = has_sb ? p * 2 * n * (N - 1) : 0; wall_len = p * nwall * (N - 1); circ_len = p * ncirc * (N - 1);
-        con_len = col_len + ctl_len + sb_len + wall_len + circ_len;
+        wall3_len = p * nwall3 * (N - 1); cyl_len = p * ncyl * (N - 1);
+        con_len = col_len + ctl_len + sb_len + wall_len + circ_len + wall3_len + cyl_len;
     }
     int o_sb(int i, int k /*knot 1..N-1*/, int row) const { return col_len + ctl_len + (i * (N - 1) + (k - 1)) * 2 * n + row; }
     int o_wall(int i, int k, int w) const { return col_len + ctl_len + sb_len + (i * (N - 1) + (k - 1)) * nwall + w; }
     int o_circ(int i, int k, int c) const { return col_len + ctl_len + sb_len + wall_len + (i * (N - 1) + (k - 1)) * ncirc + c; }
+    int o_wall3(int i, int k, int w) const { return col_len + ctl_len + sb_len + wall_len + circ_len + (i * (N - 1) + (k - 1)) * nwall3 + w; }
+    int o_cyl(int i, int k, int c) const { return col_len + ctl_len + sb_len + wall_len + circ_len + wall3_len + (i * (N - 1) + (k - 1)) * ncyl + c; }
     // index sets pu/px/pz = {i + (j-1)p} (double_integrator.jl:18-20), 0-based
     int pu(int i, int j) const { return i + j * p; }
     int pz(int i, int j) const { return i + j * p; }
@@ -201,6 +205,8 @@ struct Shared {
     std::vector<double> sbmax, sbmin;       // state bounds [p][n] (+-inf where absent)
     std::vector<double> wx1, wy1, wx2, wy2, wxv, wyv;   // walls
     std::vector<double> cxc, cyc, crad;     // circles
+    std::vector<double> w3p1, w3p2, w3p3, w3v;   // Wall3D(p1, p2, p3, v): nwall3 x 3 each (constraints_methods.jl:201-206)
+    std::vector<double> cyp, cyl, cyr; std::vector<int> cyax;   // CylinderWall(p, v, l, r): ncyl x 3, axis 0/1/2 = :x/:y/:z (:249-254)
 };
 
 struct Game {
@@ -308,7 +314,8 @@ inline int con_ctl(const Dims& D, int k /*0..N-2*/, int row) { return D.col_len 
 inline double colavoid_val(const Shared& sh, int i, int j, const double* x, double* dl) {
     const Dims& D = sh.D;
     double R = sh.ca_radius[i] + sh.ca_radius[j], s = 0;
-    for (int a = 0; a < 2; a++) { dl[a] = x[D.px(i, a)] - x[D.px(j, a)]; s += dl[a] * dl[a]; }
+    // add_collision_avoidance!: px[i] (2 positions, constraints_methods.jl:13); add_spherical_collision_avoidance!: pz[i][1:3] (:52-54)
+    for (int a = 0; a < D.ca_dim; a++) { dl[a] = x[D.pz(i, a)] - x[D.pz(j, a)]; s += dl[a] * dl[a]; }
     return R * R - s;
 }
 // ControlBoundConstraint evaluate (control_bound_constraint.jl:94-96): [u - u_max; u_min - u]
@@ -331,6 +338,26 @@ inline double circ_val(const Shared& sh, int c, double x, double y, double* gx, 
     *gx = -2.0 * dx; *gy = -2.0 * dy;
     return -(dx * dx) - (dy * dy) + sh.crad[c] * sh.crad[c];
 }
+// Wall3DConstraint evaluate / jacobian! (wall_constraint.jl:186-236): c = (x - p1).v inside the slab spanned by (p1,p2) and (p2,p3)
+inline double wall3_val(const Shared& sh, int w, const double* q /*x y z*/, double* gv /*3*/) {
+    const double* p1 = &sh.w3p1[3 * w]; const double* p2 = &sh.w3p2[3 * w]; const double* p3 = &sh.w3p3[3 * w]; const double* v = &sh.w3v[3 * w];
+    auto dot = [&](const double* a, const double* b2, const double* c) { return (q[0] - a[0]) * (b2[0] - c[0]) + (q[1] - a[1]) * (b2[1] - c[1]) + (q[2] - a[2]) * (b2[2] - c[2]); };
+    const double left = dot(p1, p2, p1) > 0 ? 1.0 : 0.0, right = dot(p2, p1, p2) > 0 ? 1.0 : 0.0;
+    const double bottom = dot(p3, p2, p3) > 0 ? 1.0 : 0.0, top = dot(p2, p3, p2) > 0 ? 1.0 : 0.0;
+    const double in = left * right * bottom * top;
+    for (int a = 0; a < 3; a++) gv[a] = in * v[a];
+    return ((q[0] - p1[0]) * v[0] + (q[1] - p1[1]) * v[1] + (q[2] - p1[2]) * v[2]) * in;
+}
+// CylinderConstraint evaluate / jacobian! (cylinder_constraint.jl:68-127): axis-aligned cylinder of radius r starting at p,
+// length l along axis v; c = r^2 - (squared distance to the axis) while 0 < (q - p)[v] < l, else 0
+inline double cyl_val(const Shared& sh, int c, const double* q, double* gv /*3*/) {
+    const double* p = &sh.cyp[3 * c]; const int ax = sh.cyax[c]; const double l = sh.cyl[c], r = sh.cyr[c];
+    const double t0[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+    const double valid = (t0[ax] > 0.0 && t0[ax] < l) ? 1.0 : 0.0;
+    double out = r * r - t0[0] * t0[0] - t0[1] * t0[1] - t0[2] * t0[2] + t0[ax] * t0[ax];
+    for (int a = 0; a < 3; a++) gv[a] = (a == ax) ? 0.0 : -valid * 2 * t0[a];
+    return out * valid;
+}
 // StateBoundConstraint evaluate (state_bound_constraint.jl:85-87): [x - x_max; x_min - x]
 inline double sb_val(const Shared& sh, int i, const double* x, int row) {
     const int n = sh.D.n;
@@ -352,6 +379,11 @@ void ext_state_con(const Shared& sh, Game& g, const std::vector<double>& z, int 
     const int idx2[2] = {D.px(i, 0), D.px(i, 1)};
     for (int w = 0; w < D.nwall; w++) { double gv[2]; const double c = wall_val(sh, w, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); row(D.o_wall(i, k, w), c, idx2, gv, 2); }
     for (int c2 = 0; c2 < D.ncirc; c2++) { double gv[2]; const double c = circ_val(sh, c2, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); row(D.o_circ(i, k, c2), c, idx2, gv, 2); }
+    // Wall3D / Cylinder act on pz[i][1..3] (constraints_methods.jl:231-236,275)
+    const int idx3[3] = {D.pz(i, 0), D.pz(i, 1), D.pz(i, 2)};
+    const double q3[3] = {x[idx3[0]], x[idx3[1]], x[idx3[2]]};
+    for (int w = 0; w < D.nwall3; w++) { double gv[3]; const double c = wall3_val(sh, w, q3, gv); row(D.o_wall3(i, k, w), c, idx3, gv, 3); }
+    for (int c2 = 0; c2 < D.ncyl; c2++) { double gv[3]; const double c = cyl_val(sh, c2, q3, gv); row(D.o_cyl(i, k, c2), c, idx3, gv, 3); }
 }
 
 // evaluate!(game_con, traj) (constraints_methods.jl:367-379)
@@ -360,7 +392,7 @@ void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
     std::vector<double> u(D.m);
     if (sh.has_colavoid)
         for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i)
-            for (int k = 1; k < D.N; k++) { double dl[2]; g.vals[con_col(D, D.pair(i, j), k)] = colavoid_val(sh, i, j, state(D, z, k), dl); }
+            for (int k = 1; k < D.N; k++) { double dl[3]; g.vals[con_col(D, D.pair(i, j), k)] = colavoid_val(sh, i, j, state(D, z, k), dl); }
     if (sh.has_ctl)
         for (int k = 0; k < D.N - 1; k++) { get_control(D, z, k, u.data()); for (int r = 0; r < 2 * D.m; r++) g.vals[con_ctl(D, k, r)] = ctl_val(sh, u.data(), r); }
     for (int i = 0; i < D.p; i++) for (int k = 1; k < D.N; k++) {
@@ -368,6 +400,11 @@ void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
         if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) g.vals[D.o_sb(i, k, r)] = sb_val(sh, i, x, r);
         for (int w = 0; w < D.nwall; w++) g.vals[D.o_wall(i, k, w)] = wall_val(sh, w, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
         for (int c = 0; c < D.ncirc; c++) g.vals[D.o_circ(i, k, c)] = circ_val(sh, c, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
+        if (D.nwall3 + D.ncyl > 0) {
+            const double q3[3] = {x[D.pz(i, 0)], x[D.pz(i, 1)], x[D.pz(i, 2)]}; double gv[3];
+            for (int w = 0; w < D.nwall3; w++) g.vals[D.o_wall3(i, k, w)] = wall3_val(sh, w, q3, gv);
+            for (int c = 0; c < D.ncyl; c++) g.vals[D.o_cyl(i, k, c)] = cyl_val(sh, c, q3, gv);
+        }
     }
 }
 // Altro 0.3.0 / TrajOpt cost_expansion!(conval): a = (c >= 0) | (lambda > 0); I_mu = diag(a*mu);
@@ -410,19 +447,19 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
         for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i) {
             const int qd = D.pair(i, j);
             for (int k = 1; k < N; k++) {
-                double dl[2];
+                double dl[3];
                 const double c = colavoid_val(sh, i, j, state(D, z, k), dl);
                 const int ci = con_col(D, qd, k);
                 g.vals[ci] = c;
                 const double w = g.lam[ci] + al_active_mu(c, g.lam[ci], g.mu[ci]) * c;
-                for (int a = 0; a < 2; a++) {                                        // grad = C' w, C = [-2d' at px[i], +2d' at px[j]]
-                    res[D.vx(i, k - 1) + D.px(i, a)] += -2 * dl[a] * w;
-                    res[D.vx(i, k - 1) + D.px(j, a)] += 2 * dl[a] * w;
+                for (int a = 0; a < D.ca_dim; a++) {                                 // grad = C' w, C = [-2d' at px[i], +2d' at px[j]]
+                    res[D.vx(i, k - 1) + D.pz(i, a)] += -2 * dl[a] * w;
+                    res[D.vx(i, k - 1) + D.pz(j, a)] += 2 * dl[a] * w;
                 }
             }
         }
     }
-    if (D.sb_len + D.wall_len + D.circ_len > 0)
+    if (D.con_len > D.col_len + D.ctl_len)
         for (int i = 0; i < p; i++) for (int k = 1; k < N; k++) ext_state_con(sh, g, z, i, k, &res[D.vx(i, k - 1)], [](int, int, double) {});
     if (sh.has_ctl) {
         for (int k = 0; k < N - 1; k++) {
@@ -487,20 +524,21 @@ void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double re
         for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i) {
             const int qd = D.pair(i, j);
             for (int k = 1; k < N; k++) {
-                double dl[2];
+                double dl[3];
                 const double c = colavoid_val(sh, i, j, state(D, z, k), dl);
                 const int ci = con_col(D, qd, k);
                 const double am = al_active_mu(c, g.lam[ci], g.mu[ci]);
                 if (am == 0.0) continue;
                 // hess = C' I_mu C with C = [-2d at px[i], 2d at px[j]]
-                int idx[4] = {D.px(i, 0), D.px(i, 1), D.px(j, 0), D.px(j, 1)};
-                double cv[4] = {-2 * dl[0], -2 * dl[1], 2 * dl[0], 2 * dl[1]};
-                for (int a = 0; a < 4; a++) for (int c2 = 0; c2 < 4; c2++)
+                const int cd = D.ca_dim;
+                int idx[6]; double cv[6];
+                for (int a = 0; a < cd; a++) { idx[a] = D.pz(i, a); idx[cd + a] = D.pz(j, a); cv[a] = -2 * dl[a]; cv[cd + a] = 2 * dl[a]; }
+                for (int a = 0; a < 2 * cd; a++) for (int c2 = 0; c2 < 2 * cd; c2++)
                     add(D.vx(i, k - 1) + idx[a], D.hx(k - 1) + idx[c2], am * cv[a] * cv[c2]);
             }
         }
     }
-    if (D.sb_len + D.wall_len + D.circ_len > 0)
+    if (D.con_len > D.col_len + D.ctl_len)
         for (int i = 0; i < p; i++) for (int k = 1; k < N; k++)
             ext_state_con(sh, g, z, i, k, nullptr, [&](int a, int c, double v) { add(D.vx(i, k - 1) + a, D.hx(k - 1) + c, v); });
     if (sh.has_ctl) {
@@ -734,7 +772,12 @@ void dual_penalty_update(const Shared& sh, Game& g) {
     for (int e = D.col_len + D.ctl_len; e < D.con_len; e++) {
         if (!std::isfinite(g.vals[e])) continue;
         const int e2 = e - D.col_len - D.ctl_len;
-        const int i = e2 < D.sb_len ? e2 / ((D.N - 1) * 2 * D.n) : (e2 < D.sb_len + D.wall_len ? (e2 - D.sb_len) / ((D.N - 1) * D.nwall) : (e2 - D.sb_len - D.wall_len) / ((D.N - 1) * D.ncirc));
+        int i, e3 = e2;
+        if (e3 < D.sb_len) i = e3 / ((D.N - 1) * 2 * D.n);
+        else if ((e3 -= D.sb_len) < D.wall_len) i = e3 / ((D.N - 1) * D.nwall);
+        else if ((e3 -= D.wall_len) < D.circ_len) i = e3 / ((D.N - 1) * D.ncirc);
+        else if ((e3 -= D.circ_len) < D.wall3_len) i = e3 / ((D.N - 1) * D.nwall3);
+        else i = (e3 - D.wall3_len) / ((D.N - 1) * D.ncyl);
         const double lb = g.lam[e] + o.alphax_dual[i] * g.mu[e] * g.vals[e];
         g.lam[e] = std::min(std::max(lb, 0.0), o.lambda_max);
     }
@@ -880,6 +923,8 @@ alg_record ibr_record(const Shared& sh, Game& g, double delta, int outer, int i)
         if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { double v = g.vals[D.o_sb(i, k, r)]; if (std::isfinite(v)) sv = std::max(sv, std::max(0.0, v)); }
         for (int w = 0; w < D.nwall; w++) sv = std::max(sv, std::max(0.0, g.vals[D.o_wall(i, k, w)]));
         for (int c = 0; c < D.ncirc; c++) sv = std::max(sv, std::max(0.0, g.vals[D.o_circ(i, k, c)]));
+        for (int w = 0; w < D.nwall3; w++) sv = std::max(sv, std::max(0.0, g.vals[D.o_wall3(i, k, w)]));
+        for (int c = 0; c < D.ncyl; c++) sv = std::max(sv, std::max(0.0, g.vals[D.o_cyl(i, k, c)]));
     }
     rc.sta_vio = sv;
     double ov = 0;                                               // optimality_violation(core, i)
@@ -1064,7 +1109,7 @@ int orc_add_collision_cost(alg_handle* h, const double* radius, const double* mu
 int orc_add_collision_avoidance(alg_handle* h, const double* radius) {
     Shared& s = H->sh;
     if (!radius) { s.has_colavoid = false; return ALG_OK; }
-    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; return ALG_OK;
+    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; s.D.ca_dim = 2; return ALG_OK;
 }
 int orc_add_control_bound(alg_handle* h, const double* umax, const double* umin) {
     Shared& s = H->sh;
@@ -1100,6 +1145,32 @@ int orc_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const
     if (nc < 0 || nc > ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "orc_add_circle_constraint: too many circles");
     s.cxc.assign(xc, xc + nc); s.cyc.assign(yc, yc + nc); s.crad.assign(rad, rad + nc);
     s.D.ncirc = nc; orc_resize_con(H); return ALG_OK;
+}
+// 3-D ingredients: the reference indexes pz[i][1:3]; meaningful (positions) for DoubleIntegratorGame(d = 3) only
+static int need_3d(Handle* hd, const char* who) {
+    if (hd->sh.D.model != ALG_MODEL_DOUBLE_INTEGRATOR || hd->sh.D.d != 3) return fail(ALG_ERR_ARG, std::string(who) + ": needs a model with three position dimensions (DoubleIntegrator d = 3)");
+    return ALG_OK;
+}
+int orc_add_spherical_collision_avoidance(alg_handle* h, const double* radius) {
+    Shared& s = H->sh;
+    if (!radius) { s.has_colavoid = false; s.D.ca_dim = 2; return ALG_OK; }
+    if (int rc = need_3d(H, "orc_add_spherical_collision_avoidance")) return rc;
+    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; s.D.ca_dim = 3; return ALG_OK;
+}
+int orc_add_wall3d_constraint(alg_handle* h, int32_t nw, const double* p1, const double* p2, const double* p3, const double* v) {
+    Shared& s = H->sh;
+    if (nw < 0 || nw > ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "orc_add_wall3d_constraint: too many walls");
+    if (int rc = need_3d(H, "orc_add_wall3d_constraint")) return rc;
+    s.w3p1.assign(p1, p1 + 3 * nw); s.w3p2.assign(p2, p2 + 3 * nw); s.w3p3.assign(p3, p3 + 3 * nw); s.w3v.assign(v, v + 3 * nw);
+    s.D.nwall3 = nw; orc_resize_con(H); return ALG_OK;
+}
+int orc_add_cylinder_constraint(alg_handle* h, int32_t nc, const double* p, const int32_t* axis, const double* l, const double* r) {
+    Shared& s = H->sh;
+    if (nc < 0 || nc > ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "orc_add_cylinder_constraint: too many cylinders");
+    if (int rc = need_3d(H, "orc_add_cylinder_constraint")) return rc;
+    for (int c = 0; c < nc; c++) if (axis[c] < 0 || axis[c] > 2) return fail(ALG_ERR_ARG, "orc_add_cylinder_constraint: axis must be 0 (:x), 1 (:y) or 2 (:z)");
+    s.cyp.assign(p, p + 3 * nc); s.cyax.assign(axis, axis + nc); s.cyl.assign(l, l + nc); s.cyr.assign(r, r + nc);
+    s.D.ncyl = nc; orc_resize_con(H); return ALG_OK;
 }
 int orc_get_con_len(alg_handle* h, int32_t* n) { *n = H->sh.D.con_len; return ALG_OK; }
 int orc_set_traj(alg_handle* h, int32_t which, const double* z) {

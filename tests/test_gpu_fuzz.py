@@ -10,14 +10,15 @@ pytestmark = pytest.mark.gpu
 DI, UNI, BIC = 0, 1, 2
 
 
-def _random_pair(alg, orc, rng, ext):
-    model = int(rng.choice([DI, UNI, BIC] if ext else [DI, UNI]))
-    p = int(rng.integers(1, 5))
+def _random_pair(alg, orc, rng, ext, d3=False):
+    model = DI if d3 else int(rng.choice([DI, UNI, BIC] if ext else [DI, UNI]))
+    p = 2 if d3 else int(rng.integers(1, 5))
     N = int(rng.integers(2, 16))
     B = 3
     dt = float(rng.choice([0.05, 0.1, 0.2]))
-    g = alg.Batch(alg.hip_lib(), model, p, N, dt, B)
-    o = orc.OracleBatch(model, p, N, dt, B)
+    d = 3 if d3 else 2
+    g = alg.Batch(alg.hip_lib(), model, p, N, dt, B, d=d)
+    o = orc.OracleBatch(model, p, N, dt, B, d=d)
     ni = g.n // p
     Q = 10.0 ** rng.uniform(-2, 1.5, (B, p, ni))
     R = 10.0 ** rng.uniform(-4, 0.5, (B, p, g.mi))            # tiny control costs -> badly scaled control systems
@@ -38,7 +39,10 @@ def _random_pair(alg, orc, rng, ext):
         if p > 1 and rng_flag(rng, b is g, ing, "cost"):
             b.add_collision_cost(np.full(p, 2.5), 1.0 + np.arange(p))
         if p > 1 and rng_flag(rng, b is g, ing, "avoid"):
-            b.add_collision_avoidance(0.2 + 0.1 * np.arange(p))
+            if d3 and rng_flag(rng, b is g, ing, "spherical"):
+                b.add_spherical_collision_avoidance(0.2 + 0.1 * np.arange(p))
+            else:
+                b.add_collision_avoidance(0.2 + 0.1 * np.arange(p))
         if rng_flag(rng, b is g, ing, "ctl"):
             umax = np.full(b.m, 0.8); umin = np.full(b.m, -0.5); umax[0] = np.inf
             b.add_control_bound(umax, umin)
@@ -49,6 +53,10 @@ def _random_pair(alg, orc, rng, ext):
             b.add_wall_constraint([-1.0, 0.5], [0.3, -1.0], [1.0, 0.5], [0.3, 1.0], [0.0, 1.0], [1.0, 0.0])
         if ext and rng_flag(rng, b is g, ing, "circ"):
             b.add_circle_constraint([0.4, -0.6], [0.2, 0.7], [0.5, 0.3])
+        if d3 and rng_flag(rng, b is g, ing, "wall3"):
+            b.add_wall3d_constraint([[-1.0, -1.0, 0.4]], [[1.0, -1.0, 0.4]], [[1.0, 1.0, 0.6]], [[0.0, -0.196, 0.981]])
+        if d3 and rng_flag(rng, b is g, ing, "cyl"):
+            b.add_cylinder_constraint([[0.3, 0.2, -1.0], [-1.0, -0.4, 0.1]], [2, 0], [2.0, 2.5], [0.4, 0.3])
     return g, o, (model, p, N, dt, tuple(ing), opts)
 
 
@@ -87,4 +95,12 @@ def test_fuzz_base_instantiations(alg, orc, seed):
 def test_fuzz_extended_instantiations(alg, orc, seed):
     rng = np.random.default_rng(5000 + seed)
     g, o, tag = _random_pair(alg, orc, rng, ext=True)
+    _compare_solve(g, o, tag)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_3d_instantiation(alg, orc, seed):
+    """DoubleIntegrator d = 3, p = 2 with random subsets of every ingredient incl. spherical collision avoidance, Wall3D, Cylinder."""
+    rng = np.random.default_rng(9000 + seed)
+    g, o, tag = _random_pair(alg, orc, rng, ext=True, d3=True)
     _compare_solve(g, o, tag)

@@ -221,9 +221,8 @@ def test_reference_constrained_unicycle_with_circles_on_gpu(alg):
 
 
 def test_extended_constraints_unsupported_configuration_fails_loudly(alg):
-    b = alg.Batch(alg.hip_lib(), DI, 2, 6, 0.1, 1, d=3)        # no EXT instantiation for d = 3
     with pytest.raises(alg.AlgamesError):
-        b.add_circle_constraint([0.0], [0.0], [1.0])
+        alg.Batch(alg.hip_lib(), DI, 1, 6, 0.1, 1, d=3)         # n = 6: no kernel instantiation at all
 
 
 def _guards_ok(batch):

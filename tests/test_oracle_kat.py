@@ -878,3 +878,107 @@ def test_mpc_loop_fused_equals_stepwise_oracle(alg, orc):
     ib, cb, sb = alg.mpc_solve(pb, 4, record_states=True, fused=False)
     assert np.array_equal(ia, ib) and np.array_equal(ca, cb) and np.array_equal(sa, sb)
     assert ia.sum() > 0 and np.abs(sa[-1] - sa[0]).max() > 0.05
+
+
+# ---- 3-D half of SURVEY 8(f) rank 3: Wall3DConstraint, CylinderConstraint, spherical collision avoidance ---------------
+def _one_player_3d(orc, N=3):
+    b = orc.OracleBatch(DI, 1, N, 0.1, 1, d=3)
+    b.set_lqr(np.zeros((1, 6)), np.zeros((1, 3)), np.zeros((1, 6)), np.zeros((1, 3)))
+    return b
+
+
+def _put_position(b, xyz):
+    X, U, L = b.split_traj(b.get_traj())
+    X[0, 1:, :3] = xyz
+    b.set_traj(b.join_traj(X, U, np.zeros_like(L)))
+
+
+def test_wall3d_evaluate_literal(orc):
+    # test/constraints/wall_constraint.jl:34-64; the test's (x, y, z) = X[4], X[2], X[1] become the player's position
+    s2 = np.sqrt(2.0)
+    p1 = np.zeros((5, 3))
+    p2 = np.array([[1.0, 0, 0], [1, 0, 0], [1, 0, 1], [1, 0, 0], [1, 0, 0]])
+    p3 = np.array([[1.0, 1, 0], [1, 1, 1], [1, 1, 1], [0, 1, 0], [0, 1, 1]])
+    v = np.array([[0.0, 0, 1], [0, -1 / s2, 1 / s2], [-1 / s2, 0, 1 / s2], [0, 0, 1], [0, -1 / s2, 1 / s2]])
+    b = _one_player_3d(orc)
+    b.add_wall3d_constraint(p1, p2, p3, v)
+    assert b.con_len == _ext_off(b) + 5 * (b.N - 1)
+    for X6, want in (([0.0, 0.10, -12.0, 0.10, 12.0, 11.0], [0.0, -0.1 / s2, -0.1 / s2, 0.0, -0.1 / s2]),
+                     ([1.0, 0.55, -12.0, 0.55, 12.0, 11.0], [1.0, 0.45 / s2, 0.45 / s2, 1.0, 0.45 / s2]),
+                     ([1.0, 1.25, -12.0, 0.75, 12.0, 11.0], [0.0, 0.0, 0.0, 1.0, -0.25 / s2])):
+        _put_position(b, [X6[3], X6[1], X6[0]])
+        w = b.kat_evaluate_con()[0][_ext_off(b):].reshape(b.N - 1, 5)
+        assert np.abs(w[0] - np.array(want)).sum() < 1e-10 and np.array_equal(w[0], w[1])
+    with pytest.raises(Exception):
+        orc.OracleBatch(DI, 2, 3, 0.1, 1).add_wall3d_constraint(p1, p2, p3, v)      # no third position dimension
+
+
+def test_cylinder_evaluate_literal(orc):
+    # test/constraints/cylinder_constraint.jl:3-22: (x, y, z) = (1, 1, 2)
+    p = np.array([[1.0, 0, 1], [1, 0, 1], [1, 0, 3], [0, 1, 1], [1, 0, 2]])
+    axis = [2, 2, 2, 0, 1]; l = [5.0, 2.0, 0.5, 2.0, 10.0]; r = [3.0, 2.0, 7.0, 3.0, 1.0]
+    b = _one_player_3d(orc)
+    b.add_cylinder_constraint(p, axis, l, r)
+    _put_position(b, [1.0, 1.0, 2.0])
+    c = b.kat_evaluate_con()[0][_ext_off(b):].reshape(b.N - 1, 5)
+    assert np.abs(c[0] - np.array([8.0, 3.0, 0.0, 8.0, 1.0])).sum() < 1e-10
+    with pytest.raises(Exception):
+        b.add_cylinder_constraint(p, [0, 1, 2, 3, 0], l, r)
+
+
+def test_3d_constraints_gradient_and_gauss_newton_block(orc):
+    # jacobian! of both constraints equals ForwardDiff of evaluate (wall_constraint.jl test :67-70, cylinder test :25-34):
+    # opt_x rows = d/dx of the AL penalty with the active set frozen; jacobian = C' I_mu C; spherical collision avoidance on
+    rng = np.random.default_rng(21)
+    N, p = 4, 2
+    b = orc.OracleBatch(DI, p, N, 0.1, 1, d=3)
+    n, K = b.n, N - 1
+    b.set_lqr(np.zeros((p, 6)), np.zeros((p, 3)), np.zeros((p, 6)), np.zeros((p, 3)))
+    b.add_spherical_collision_avoidance([0.4, 0.5])
+    w3 = (np.array([[0.0, 0, 0.2]]), np.array([[1.0, 0, 0.2]]), np.array([[1.0, 1, 0.2]]), np.array([[0.0, 0.6, 0.8]]))
+    b.add_wall3d_constraint(*w3)
+    cy = (np.array([[0.5, 0.5, 0.0], [0.0, 0.4, 0.6]]), [2, 0], [1.5, 2.0], [0.45, 0.5])
+    b.add_cylinder_constraint(*cy)
+    z = rng.random((1, b.traj_len)); X, U, L = b.split_traj(z)
+    z = b.join_traj(X, U, np.zeros_like(L)); b.set_traj(z)
+    vals = b.kat_evaluate_con()[0]
+    lam = rng.random((1, b.con_len)) * (rng.random((1, b.con_len)) > 0.5); mu = np.full((1, b.con_len), 3.0)
+    b.set_con_duals(lam, mu)
+    res0 = b.residual()[0][0]; J = b.residual_jacobian()[0]
+    act = ((vals >= 0) | (lam[0] > 0))
+    off = _ext_off(b)
+
+    def cons(xk, i, k):
+        """(row, value) of every constraint attached to player i at knot k."""
+        out = []
+        q = xk[[i, p + i, 2 * p + i]]
+        j = 1 - i
+        qj = xk[[j, p + j, 2 * p + j]]
+        out.append((i * K + (k - 1), (0.4 + 0.5) ** 2 - ((q - qj) ** 2).sum()))                 # pairq(i, j) = i for p = 2
+        p1, p2, p3, v = (a[0] for a in w3)
+        inside = ((q - p1) @ (p2 - p1) > 0) * ((q - p2) @ (p1 - p2) > 0) * ((q - p3) @ (p2 - p3) > 0) * ((q - p2) @ (p3 - p2) > 0)
+        out.append((off + i * K + (k - 1), ((q - p1) @ v) * inside))
+        for c in range(2):
+            t0 = q - cy[0][c]; ax = cy[1][c]
+            valid = 0.0 < t0[ax] < cy[2][c]
+            out.append((off + p * K + (i * K + k - 1) * 2 + c, (cy[3][c] ** 2 - (t0 ** 2).sum() + t0[ax] ** 2) * valid))
+        return out
+    for i in range(p):
+        for k in range(1, N):
+            for e, c in cons(X[0, k], i, k):
+                assert abs(vals[e] - c) < 1e-14, (i, k, e)
+    eps = 1e-6
+    for i in range(p):
+        for k in range(1, N):
+            rows = i * K * (n + 3) + (k - 1) * (n + 3) + np.arange(n)
+            cols = (k - 1) * b.b + np.arange(n)
+            g = np.zeros(n); Hx = np.zeros((n, n))
+            for idx, (e, c0) in enumerate(cons(X[0, k], i, k)):
+                gc = np.zeros(n)
+                for a in range(n):
+                    xp, xm = X[0, k].copy(), X[0, k].copy(); xp[a] += eps; xm[a] -= eps
+                    gc[a] = (cons(xp, i, k)[idx][1] - cons(xm, i, k)[idx][1]) / (2 * eps)
+                g += gc * (lam[0, e] + 3.0 * act[e] * c0)
+                Hx += 3.0 * act[e] * np.outer(gc, gc)
+            assert np.allclose(res0[rows], g, atol=1e-7), (i, k)
+            assert np.allclose(J[np.ix_(rows, cols)], Hx, atol=1e-6), (i, k)

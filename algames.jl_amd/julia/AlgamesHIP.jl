@@ -106,7 +106,10 @@ function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0
             R2p = p > 2 ? col2[2].radius : R12                          # r_2 + r_3
             r1 = p > 2 ? (R12 + R1p - R2p) / 2 : R12 / 2
             radius = [i == 1 ? r1 : colcons[i-1].radius - r1 for i in 1:p]
-            check(ccall((:alg_add_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], radius))
+            # add_spherical_collision_avoidance! builds the constraint on pz[i][1:3] (three indices) instead of px[i] (two)
+            spherical = length(colcons[1].x1) == 3
+            check(spherical ? ccall((:alg_add_spherical_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], radius) :
+                              ccall((:alg_add_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], radius))
         end
         if prob.model isa BicycleGame
             check(ccall((:alg_set_bicycle, LIB), Cint, (Ptr{Cvoid}, Float64, Float64), h[], prob.model.lf, prob.model.lr))
@@ -124,6 +127,15 @@ function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0
             elseif i == 1 && con isa Algames.TrajectoryOptimization.CircleConstraint   # add_circle_constraint!(game_con, xc, yc, radius)
                 check(ccall((:alg_add_circle_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
                             Vector{Float64}(con.x), Vector{Float64}(con.y), Vector{Float64}(con.radius)))
+            elseif i == 1 && con isa Algames.Wall3DConstraint            # add_wall_constraint!(game_con, walls::Vector{Wall3D}); n_wall x 3 row-major
+                pts(a, b, c) = Vector{Float64}(vec(permutedims(hcat(Vector(a), Vector(b), Vector(c)))))
+                check(ccall((:alg_add_wall3d_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
+                            pts(con.x1, con.y1, con.z1), pts(con.x2, con.y2, con.z2), pts(con.x3, con.y3, con.z3), pts(con.xv, con.yv, con.zv)))
+            elseif i == 1 && con isa Algames.CylinderConstraint          # add_wall_constraint!(game_con, walls::Vector{CylinderWall})
+                pts(a, b, c) = Vector{Float64}(vec(permutedims(hcat(Vector(a), Vector(b), Vector(c)))))
+                axis = Int32[s == :x ? 0 : s == :y ? 1 : 2 for s in con.v]
+                check(ccall((:alg_add_cylinder_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
+                            pts(con.p1, con.p2, con.p3), axis, Vector{Float64}(con.l), Vector{Float64}(con.r)))
             end
         end
         if !isempty(prob.game_con.control_conval)

@@ -36,6 +36,8 @@
  *          Extended constraints append, in this order and only when added:
  *          [ state bound: for player i, knot k=2..N: rows (x-x_max)(n) then (x_min-x)(n) ]
  *          [ wall: for player i, knot k=2..N: one row per wall ] [ circle: for player i, knot k=2..N: one row per circle ]
+ *          [ 3-D wall: for player i, knot k=2..N: one row per Wall3D ] [ cylinder: for player i, knot k=2..N: one row per cylinder ]
+ *          (spherical collision avoidance uses the collision-avoidance rows)
  *          alg_get_con_len() returns the current length.
  */
 #ifndef ALGAMES_HIP_H

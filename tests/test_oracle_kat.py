@@ -982,3 +982,41 @@ def test_3d_constraints_gradient_and_gauss_newton_block(orc):
                 Hx += 3.0 * act[e] * np.outer(gc, gc)
             assert np.allclose(res0[rows], g, atol=1e-7), (i, k)
             assert np.allclose(J[np.ix_(rows, cols)], Hx, atol=1e-6), (i, k)
+
+
+def test_e2e_3d_host_builders_on_the_oracle(alg, orc):
+    """Host mirror of add_spherical_collision_avoidance! / add_wall_constraint!(::Vector{Wall3D}) / (::Vector{CylinderWall})
+    (constraints_methods.jl:45-81,201-284) through GameProblem on the oracle backend: two point masses swap places around a
+    pillar under a ceiling; the solve converges and the solution respects the obstacles."""
+    p, N, dt = 2, 20, 0.1
+    model = alg.DoubleIntegratorGame(p=p, d=3)
+    obj = alg.GameObjective([np.array([10.0, 10, 10, 1, 1, 1])] * p, [0.1 * np.ones(3)] * p,
+                            [np.array([1.0, 0.05, 0.5, 0, 0, 0]), np.array([-1.0, -0.05, 0.5, 0, 0, 0])], [np.zeros(3)] * p, N, model)
+    alg.add_collision_cost(obj, 0.6 * np.ones(p), 2.0 * np.ones(p))
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    alg.add_spherical_collision_avoidance(con, 0.15)
+    alg.add_control_bound(con, 4 * np.ones(model.m), -4 * np.ones(model.m))
+    alg.add_wall_constraint(con, [alg.CylinderWall([0.0, 0.0, 0.0], "z", 2.0, 0.2)])
+    alg.add_wall_constraint(con, [alg.Wall3D([-2.0, -2.0, 0.9], [2.0, -2.0, 0.9], [2.0, 2.0, 0.9], [0.0, 0.0, 1.0])])
+    with pytest.raises(TypeError):
+        alg.add_wall_constraint(con, [alg.Wall([0, 0], [1, 0], [0, 1]), alg.CylinderWall([0, 0, 0], "x", 1, 1)])
+    with pytest.raises(alg.AlgamesError):
+        alg.add_wall_constraint(con, [alg.CylinderWall([0, 0, 0], "x", 1, 1)])           # second cylinder set
+    x0 = np.array([-1.0, 1.0, 0.02, -0.02, 0.5, 0.55, 0, 0, 0, 0, 0, 0])
+    prob = alg.GameProblem(N, dt, x0, model, alg.Options(inner_print=False, outer_print=False), obj, con, backend=orc.lib())
+    assert prob.batch.con_len == 2 * (N - 1) + 2 * model.m * (N - 1) + p * (N - 1) + p * (N - 1)
+    alg.newton_solve(prob)
+    s = prob.stats.summary
+    assert s["converged"][0] == 1 and s["status"][0] == 0
+    X, U, L = prob.batch.split_traj(prob.batch.get_traj())
+    for i in range(2):
+        assert np.all(X[0, 1:, i] ** 2 + X[0, 1:, 2 + i] ** 2 >= 0.2 ** 2 - 2e-3) and np.all(X[0, 1:, 4 + i] <= 0.9 + 1e-3)
+    d = np.sqrt(((X[0, 1:, [0, 2, 4]] - X[0, 1:, [1, 3, 5]]) ** 2).sum(0))
+    assert d.min() >= 0.3 - 2e-3
+    # a 2-D model has no third position dimension: the build of the problem fails loudly
+    con2 = alg.GameConstraintValues(alg.ProblemSize(N, alg.UnicycleGame(p=2)))
+    alg.add_spherical_collision_avoidance(con2, 0.1)
+    m2 = alg.UnicycleGame(p=2)
+    obj2 = alg.GameObjective([np.ones(4)] * 2, [np.ones(2)] * 2, [np.zeros(4)] * 2, [np.zeros(2)] * 2, N, m2)
+    with pytest.raises(alg.AlgamesError):
+        alg.GameProblem(N, dt, np.zeros(8), m2, alg.Options(inner_print=False, outer_print=False), obj2, con2, backend=orc.lib())

@@ -208,3 +208,22 @@ def test_no_kernel_writes_outside_its_buffers_3d(alg):
     fn = g.lib.dll.alg_debug_check_guards
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
     assert fn(g.h) == 0
+
+
+def test_3d_receding_horizon_and_ibr_solve_parity(alg, orc):
+    """The fused receding-horizon loop (k_mpc_loop) and the iterated-best-response solve of the 3-D instantiation."""
+    x0 = np.array([-1.0, 1.0, 0.02, -0.02, 0.5, 0.55, 0, 0, 0, 0, 0, 0])
+    X0 = np.tile(x0, (6, 1)); X0[1:, :6] += 0.1 * (np.random.default_rng(6).random((5, 6)) - 0.5)
+    pg, po = _drone_problem(alg, None, X0), _drone_problem(alg, orc.lib(), X0)
+    ig, cg, sg = alg.mpc_solve(pg, 5, record_states=True)
+    io, co, so = alg.mpc_solve(po, 5, record_states=True)
+    assert np.array_equal(ig, io) and np.array_equal(cg, co) and np.abs(sg - so).max() < 1e-7
+    assert np.abs(sg[-1] - sg[0]).max() > 0.05
+    pg, po = _drone_problem(alg, None, X0), _drone_problem(alg, orc.lib(), X0)
+    ibr = alg.IBROptions(); ibr.ibr_iter = 3
+    alg.ibr_newton_solve(pg, ibr_opts=ibr); alg.ibr_newton_solve(po, ibr_opts=ibr)
+    sg, so = pg.stats.summary, po.stats.summary
+    for f in ("status", "newton_iters", "records", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]), (f, sg[f], so[f])
+    zg, zo = pg.batch.get_traj(), po.batch.get_traj()
+    assert np.abs(zg - zo).max() <= 1e-7 * max(1.0, np.abs(zo).max())

@@ -1227,6 +1227,17 @@ struct QaddMap {
 // (solver_methods.jl:87-88).  Returns ALG_STATUS_*.
 // IBR = true: best response of player ip -- only x, u_ip, lambda_ip move (horizontal mask, newton_core.jl:249-294): the other
 // players' value recursions are skipped, their rows of the control system become unit rows (du_j = 0), dlambda_j = 0.
+// Scratch instrumentation (-DALG_PHASE_PROF, scratch/phase_prof.sh): shader-clock cycles per phase of the sweeps, accumulated
+// into G.res[0..] (unused by the fused solver).  Never defined in the product build.
+#ifdef ALG_PHASE_PROF
+#define ALG_PROF_DECL unsigned long long prof_t_ = __builtin_readcyclecounter(), prof_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ALG_PROF(j) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc_[j] += t_ - prof_t_; prof_t_ = t_; }
+#define ALG_PROF_FLUSH if (threadIdx.x == 0) { for (int j_ = 0; j_ < 12; j_++) G.res[j_] += (double)prof_acc_[j_]; }
+#else
+#define ALG_PROF_DECL
+#define ALG_PROF(j)
+#define ALG_PROF_FLUSH
+#endif
 template <class C, bool IBR = false>
 __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
@@ -1267,6 +1278,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     // ------------------------------------------------------------------ backward sweep
     // P_i (n x n) and s_i (column n of the same LDS rows): P_i <- Q^_i + A_{k+1}' P_i F,  s_i <- rx_i + A_{k+1}' (P_i f + s_i)
     int cur = 0, sing = 0;
+    ALG_PROF_DECL
+    ALG_PROF(11)
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
         const double w = (k + 1 < N - 1) ? dt : 1.0;
@@ -1362,6 +1375,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             }
             __syncthreads();
         }
+        ALG_PROF(0)
         // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
         qam.apply(lane, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
         if constexpr (!AUGS) {
@@ -1373,6 +1387,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             }
         }
         __syncthreads();
+        ALG_PROF(1)
         // prefetch of the next step's record: issued after the register-hungry MFMA phase, landed by the end of the step
         double pre[RPL];
         if (k > 0) {
@@ -1408,12 +1423,14 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         }
         if (lane < m) L.bw.V[lane * VW + n + 1 + lane] = Rc[R::RHAT + lane];
         __syncthreads();
+        ALG_PROF(2)
         // ---- V[c][n] = g_c = ru_c + B[:,c]' (P rd + s)
         if (lane < m) {
             const double* yi = &L.bw.t[(lane % P) * n];
             L.bw.V[lane * VW + n] = Rc[R::RU + lane] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, lane);
         }
         __syncthreads();
+        ALG_PROF(3)
         // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B: every lane forms its column as the same
         // short sparse combination of row c of the extended V (lane < m: B column + R^ slot; lane < m+n: A column; lane m+n: g slot)
         double col[m];
@@ -1433,9 +1450,11 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
                 col[c] = v;
             }
         }
+        ALG_PROF(4)
 #ifndef ALG_NO_GJ
         sing |= gj_solve_cols<m>(col);
 #endif
+        ALG_PROF(5)
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
         if (lane >= m && lane <= m + n) {
             const int cc = lane - m;
@@ -1457,6 +1476,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
         }
         __syncthreads();
+        ALG_PROF(6)
     }
     if (sing) return ALG_STATUS_SINGULAR;              // wave-uniform (every lane factors the same matrix)
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 1
@@ -1522,6 +1542,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
     return ALG_STATUS_OK;
 #endif
+    ALG_PROF(7)
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     hxm.init(phase_lane());
@@ -1581,6 +1602,8 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         }
         __syncthreads();
     }
+    ALG_PROF(8)
+    ALG_PROF_FLUSH
     // non-finite direction -> singular (the reference would throw / propagate NaN)
     if (primal_l1) *primal_l1 = wave_sum(pl1);
     return wave_or(bad) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;

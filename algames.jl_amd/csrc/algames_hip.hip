@@ -592,6 +592,15 @@ int alg_debug_check_guards(alg_handle* h) {
     }
     return bad;
 }
+#ifdef ALG_PHASE_PROF
+// scratch instrumentation: first `cnt` doubles of every game's res buffer (cycle accumulators of the sweeps)
+extern "C" int alg_debug_read_res(alg_handle* h, double* out, int cnt) {
+    int rc = use_device(H); if (rc) return rc;
+    if ((rc = sync(H))) return rc;
+    for (int g = 0; g < H->pr.B; g++) if (hipMemcpy(out + (size_t)g * cnt, H->bf.res + (size_t)g * H->pr.S, sizeof(double) * cnt, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 int alg_synchronize(alg_handle* h) { int rc = use_device(H); if (rc) return rc; return sync(H); }
 
 int alg_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats) {

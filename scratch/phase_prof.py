@@ -1,0 +1,21 @@
+"""Per-phase cycle profile of the Newton-direction sweeps (library built with -DALG_PHASE_PROF: scratch/phase_prof.sh).
+usage: python scratch/phase_prof.py CONFIG GAMES"""
+import sys, os, ctypes
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, root)
+import numpy as np
+import algames_jl_amd as alg
+cfg, G = sys.argv[1], int(sys.argv[2])
+prob = alg.scenarios.make_problem(cfg, np.arange(G))
+alg.newton_solve(prob)
+b = prob.batch
+fn = b.lib.dll.alg_debug_read_res; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+out = np.zeros((G, 12)); assert fn(b.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 12) == 0
+it = prob.stats.summary["newton_iters"].astype(float)
+names = ["value recursion (MFMA + A' + write-back)", "Q-add (+ s_i)", "V rows, y_i, A' table", "g_c", "column build", "pivoted solve", "gains out + closed loop + record copy",
+         "forward sweep", "costate sweep", "-", "-", "set-up before the backward loop"]
+steps = (b.N - 1)
+tot = out[:, :9].sum(1) + out[:, 11]
+print(f"{cfg} {G} games: cycles per Newton iteration in newton_direction (mean over games) = {np.mean(tot / it):.0f}")
+for j in list(range(9)) + [11]:
+    per_it = np.mean(out[:, j] / it)
+    print(f"  {names[j]:45s} {per_it:9.0f} cycles/iter  {100 * per_it / np.mean(tot / it):5.1f} %   {per_it / steps:7.0f} per step")

@@ -1209,16 +1209,25 @@ struct QaddMap {
     }
     __device__ __forceinline__ void apply(int lane, const double* Rc, const double* qdf, double* Pm, double reg, double w, int only_player) const {
         using R = Rec<C>;
+        // every pass touches distinct entries of Pm: all loads first, then all stores (the compiler has to assume that a
+        // pass's store aliases the next pass's loads and would serialise one LDS round trip per pass)
+        double nv[PASSES];
 #pragma unroll
         for (int q = 0; q < PASSES; q++) {
             const int e = lane + q * WAVE;
+            nv[q] = 0.0;
             if (e < QTOT && (only_player < 0 || e / QE == only_player)) {
                 const unsigned u = code[q];
                 const int dst = u & 0x7ff, so = (u >> 11) & 0xff, qi = u >> 19;
                 double dq = reg + w * qdf[qi];
                 if constexpr (C::EXT) dq += Rc[R::RQ + qi];
-                Pm[dst] += fma((double)sgn[q], Rc[so], (double)dfl[q] * dq);
+                nv[q] = Pm[dst] + fma((double)sgn[q], Rc[so], (double)dfl[q] * dq);
             }
+        }
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) {
+            const int e = lane + q * WAVE;
+            if (e < QTOT && (only_player < 0 || e / QE == only_player)) Pm[code[q] & 0x7ff] = nv[q];
         }
     }
 };
@@ -1458,22 +1467,35 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
         if (lane >= m && lane <= m + n) {
             const int cc = lane - m;
-            double* __restrict__ Kg = G.kgain + (size_t)k * NK + cc * m;
 #pragma unroll
-            for (int c = 0; c < m; c++) { col[c] = -col[c]; Kg[c] = col[c]; }
+            for (int c = 0; c < m; c++) col[c] = -col[c];
             // column cc of [A_k | rd]: contiguous in LDS (T row cc, or the record's rd); A_0 is never used (dx_1 = 0)
             const double* acol = (cc < n) ? &L.bw.T[cc * n] : Rc + R::RD;
+            // all LDS reads first, then all writes: the compiler cannot prove that the Fx stores do not alias the T / record
+            // loads and would otherwise serialise one LDS round trip per row
+            double fxv[n];
+#pragma unroll
+            for (int r = 0; r < n; r++) fxv[r] = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r) + acol[r];
 #pragma unroll
             for (int r = 0; r < n; r++) {
-                const double v = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r) + acol[r];
-                if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = v;              // f rides in tile column n
-                else { if (cc < n) L.bw.Fx[r * 16 + cc] = v; else L.bw.fv[r] = v; }
+                if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];         // f rides in tile column n
+                else { if (cc < n) L.bw.Fx[r * 16 + cc] = fxv[r]; else L.bw.fv[r] = fxv[r]; }
             }
         }
+        ALG_PROF(9)
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = coefk[lane];
         if (k > 0) {
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
+        }
+        ALG_PROF(10)
+        // the gains go out last (gfx9 counts loads and stores in one vmcnt: the wait for the prefetched record above should not
+        // meet stores that were just issued; measured neutral, the phase profile shows no exposed wait either way)
+        asm volatile("" ::: "memory");
+        if (lane >= m && lane <= m + n) {
+            double* __restrict__ Kg = G.kgain + (size_t)k * NK + (lane - m) * m;
+#pragma unroll
+            for (int c = 0; c < m; c++) Kg[c] = col[c];
         }
         __syncthreads();
         ALG_PROF(6)

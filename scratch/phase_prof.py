@@ -12,10 +12,10 @@ fn = b.lib.dll.alg_debug_read_res; fn.restype = ctypes.c_int; fn.argtypes = [cty
 out = np.zeros((G, 12)); assert fn(b.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 12) == 0
 it = prob.stats.summary["newton_iters"].astype(float)
 names = ["value recursion (MFMA + A' + write-back)", "Q-add (+ s_i)", "V rows, y_i, A' table", "g_c", "column build", "pivoted solve", "gains out + closed loop + record copy",
-         "forward sweep", "costate sweep", "-", "-", "set-up before the backward loop"]
+         "forward sweep", "costate sweep", "  (closed loop: K negate, B K + A -> Fx)", "  (record copy: wait for the prefetch)", "set-up before the backward loop"]
 steps = (b.N - 1)
-tot = out[:, :9].sum(1) + out[:, 11]
+tot = out[:, :11].sum(1) + out[:, 11]
 print(f"{cfg} {G} games: cycles per Newton iteration in newton_direction (mean over games) = {np.mean(tot / it):.0f}")
-for j in list(range(9)) + [11]:
+for j in list(range(12)):
     per_it = np.mean(out[:, j] / it)
     print(f"  {names[j]:45s} {per_it:9.0f} cycles/iter  {100 * per_it / np.mean(tot / it):5.1f} %   {per_it / steps:7.0f} per step")

@@ -1236,6 +1236,45 @@ struct QaddMap {
 // (solver_methods.jl:87-88).  Returns ALG_STATUS_*.
 // IBR = true: best response of player ip -- only x, u_ip, lambda_ip move (horizontal mask, newton_core.jl:249-294): the other
 // players' value recursions are skipped, their rows of the control system become unit rows (du_j = 0), dlambda_j = 0.
+// the double held by lane `src` (ds_bpermute; every lane has to execute it: a disabled source lane reads as garbage)
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    const int a = src << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// Row `lane` of A_k dx + B_k du with dx / du held one entry per lane (dx: lanes 0..n-1, du: lanes 0..m-1, joint control order):
+// the forward sweep's state update without a trip through LDS.  Branch-free (the shuffles need all lanes); the entries are
+// those of A_vec / B_vec.
+template <class C>
+__device__ __forceinline__ double fwd_next(const double* coef, double dt, double dxr, double duv, int lane) {
+    constexpr int n = C::n, m = C::m, P = C::P;
+    const int r = lane < n ? lane : 0;
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        const bool lo = r < m;
+        const double other = shfl_d(dxr, lo ? r + m : r), uu = shfl_d(duv, lo ? r : r - m);
+        const double a = lo ? dxr + dt * other : dxr;
+        const double b = lo ? 0.5 * dt * dt * uu : dt * uu;
+        return a + b;
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int blk = r / P, i = r % P;
+        const double ps = shfl_d(dxr, 3 * P + i), vv = shfl_d(dxr, 2 * P + i), w0 = shfl_d(duv, i), w1 = shfl_d(duv, P + i);
+        const double c1v = coef[(blk == 1 ? 2 : 0) * P + i], c2v = coef[(blk == 1 ? 3 : (blk == 3 ? 4 : 1)) * P + i];
+        const double a1 = blk < 2 ? c1v : 0.0, a2 = blk != 2 ? c2v : 0.0;
+        const double a = dxr + a1 * ps + a2 * vv;
+        const double c0v = coef[(blk == 0 ? 5 : (blk == 1 ? 6 : 4)) * P + i], c3v = coef[(blk == 0 ? 7 : (blk == 1 ? 8 : 9)) * P + i];
+        const double b0 = blk == 2 ? dt : 0.5 * dt * c0v, b1 = blk == 2 ? 0.0 : c3v;
+        return a + (b0 * w0 + b1 * w1);
+    } else {
+        const int blk = r / P, i = r % P;
+        const double th = shfl_d(dxr, 2 * P + i), vv = shfl_d(dxr, 3 * P + i), w0 = shfl_d(duv, i), w1 = shfl_d(duv, P + i);
+        const bool pos = blk < 2;
+        const double ca = coef[(pos ? 2 * blk : 0) * P + i], cb = coef[(pos ? 2 * blk + 1 : 1) * P + i];
+        const double a = pos ? dxr + ca * th + cb * vv : dxr;
+        const double b = pos ? 0.5 * dt * (ca * w0 + cb * w1) : dt * (blk == 2 ? w0 : w1);
+        return a + b;
+    }
+}
+
 // Scratch instrumentation (-DALG_PHASE_PROF, scratch/phase_prof.sh): shader-clock cycles per phase of the sweeps, accumulated
 // into G.res[0..] (unused by the fused solver).  Never defined in the product build.
 #ifdef ALG_PHASE_PROF
@@ -1259,7 +1298,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
     constexpr bool AUGS = DirLds<C>::AUGS;               // s_i rides through the first MFMA product (n < 16)
     constexpr int KB1 = DirLds<C>::KB1, VW = DirLds<C>::VW;
-    HxMap<C> hxm;                                        // costate sweep only (initialised there)
+    HxMap<C> hxm;
     QaddMap<C> qam; qam.init(lane);
     struct NoGather { __device__ void init(int, int) {} };
     typename std::conditional<(C::P == 3 && C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR), P3Gather<C>, NoGather>::type p3g;
@@ -1505,66 +1544,65 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     return ALG_STATUS_OK;
 #endif
     // ------------------------------------------------------------------ forward sweep: dx, du
-    if (lane < n) { L.fw.dx[lane] = 0.0; dz[lane] = 0.0; }
+    if (lane < n) dz[lane] = 0.0;
     // the forward sweep reads only [coef | rd] of a record: one load per lane
     static_assert(C::NC + n <= WAVE, "forward sweep record slice");
     const int fro = lane < C::NC ? R::COEF + lane : R::RD + (lane - C::NC);      // record offset of this lane's slice entry
     const bool frok = lane < C::NC + n;
     if (frok) L.rec[0][fro] = G.rec[fro];
     for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain[e];
-    // Prefetch distance: the configurations with a 256-VGPR budget (one game per SIMD at their BASELINE batch sizes: nothing
-    // else hides HBM latency) keep the data of step k+2 in flight in registers while LDS holds steps k and k+1.
-    constexpr int PFD = (C::WPE == 2 && C::MODEL != ALG_MODEL_BICYCLE) ? 2 : 1;
+    // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
+    // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
+    // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
+    // addresses, and everything at the tail of the step in the order (1) land the data of step k+1 (requested one step ago) in
+    // LDS, (2) issue this step's result stores, (3) request the data of step k+2 -- the single wait of a step meets loads and
+    // stores that have been in flight for a whole step.
+    const int froc = frok ? fro : R::RD;                                       // lanes without a slice entry duplicate rd[0]
     auto fwd_load = [&](int kk, double& rf, double (&rk)[KPL]) {
-        rf = 0.0;
+        const int kc = kk < N - 1 ? kk : N - 2;
+        rf = G.rec[(size_t)kc * R::LEN + froc];
 #pragma unroll
-        for (int q = 0; q < KPL; q++) rk[q] = 0.0;
-        if (kk < N - 1) {
-            if (frok) rf = G.rec[(size_t)kk * R::LEN + fro];
-#pragma unroll
-            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) rk[q] = G.kgain[(size_t)kk * NK + e]; }
-        }
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = G.kgain[(size_t)kc * NK + (e < NK ? e : NK - 1)]; }
     };
-    double pref = 0.0, prek[KPL];
-    if constexpr (PFD == 2) fwd_load(1, pref, prek);
+    double pref, prek[KPL];
+    fwd_load(1, pref, prek);
     __syncthreads();
     cur = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
     int bad = 0;                                    // non-finite direction entries (checked where they are produced)
+    // dx_k lives one entry per lane (lanes 0..n-1) and is broadcast with v_readlane; du and dx_{k+1} never pass through LDS:
+    // one LDS round trip (gain rows, record slice) per step instead of three.
+    double dxr = 0.0;
     for (int k = 0; k < N - 1; k++, cur ^= 1) {
         const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
-        double nxf = 0.0, nxk[KPL];
-        if constexpr (PFD == 2) fwd_load(k + 2, nxf, nxk);          // lands during the next step
-        else fwd_load(k + 1, pref, prek);
-        if (lane < m) {
-            double acc = Kl[n * m + lane];
+        const int cl = lane < m ? lane : 0;
+        double acc = Kl[n * m + cl];
 #pragma unroll
-            for (int q = 0; q < n; q++) acc += Kl[q * m + lane] * L.fw.dx[q];
-            L.fw.du[lane] = acc; pl1 += fabs(acc); bad |= !isfinite(acc);
-            dz[n + hu<C>(k, 0) + uoff<C>(lane)] = acc;
-        }
-        __syncthreads();
-        double dxn = 0.0;
-        if (lane < n) dxn = A_vec<C>(Rc + R::COEF, dt, [&](int rr) { return L.fw.dx[rr]; }, lane)
-                          + B_vec<C>(Rc + R::COEF, dt, [&](int cc) { return L.fw.du[cc]; }, lane) + Rc[R::RD + lane];
-        __syncthreads();
-        if (lane < n) { L.fw.dx[lane] = dxn; dz[n + hx<C>(k) + lane] = dxn; pl1 += fabs(dxn); bad |= !isfinite(dxn); }
-        if (k + 1 < N - 1) {
-            if (frok) L.rec[cur ^ 1][fro] = pref;
+        for (int q = 0; q < n; q++) acc += Kl[q * m + cl] * bcast_lane(dxr, q);
+        const double duv = lane < m ? acc : 0.0;
+        const double rdv = Rc[R::RD + (lane < n ? lane : 0)];
+        double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, lane) + rdv;
+        dxn = lane < n ? dxn : 0.0;
+        if (lane < m) { pl1 += fabs(duv); bad |= !isfinite(duv); }
+        if (lane < n) { pl1 += fabs(dxn); bad |= !isfinite(dxn); }
+        dxr = dxn;
+        // (1) data of step k+1 -> LDS (clamped duplicates at the last step are never read)
+        L.rec[cur ^ 1][froc] = pref;
 #pragma unroll
-            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.fw.kg[cur ^ 1][e] = prek[q]; }
-        }
-        if constexpr (PFD == 2) {
-            pref = nxf;
-#pragma unroll
-            for (int q = 0; q < KPL; q++) prek[q] = nxk[q];
-        }
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[q]; }
+        asm volatile("" ::: "memory");
+        // (2) results out
+        if (lane < m) dz[n + hu<C>(k, 0) + uoff<C>(lane)] = duv;
+        if (lane < n) dz[n + hx<C>(k) + lane] = dxn;
+        // (3) request step k+2
+        fwd_load(k + 2, pref, prek);
         __syncthreads();
     }
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
     return ALG_STATUS_OK;
 #endif
     ALG_PROF(7)
+    constexpr int PFD = (C::WPE == 2 && C::MODEL != ALG_MODEL_BICYCLE) ? 2 : 1;
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     hxm.init(phase_lane());

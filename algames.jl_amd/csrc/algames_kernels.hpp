@@ -147,8 +147,12 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
 // warm start, advance x0 by one RK2 step).  Games never wait for each other between MPC steps, so a game that needs many
 // Newton iterations at one step only delays itself.  Step 0 uses the handle's shift / dual_reset, later steps shift = 1
 // and dual_reset = false (the reference's warm-start hooks, options.jl / primal_dual_traj.jl:29-44).
+// Register budget of the 256-VGPR class for every configuration: the loop carries more live state (step counter, state log,
+// totals) than a single solve; at 128 VGPRs the DoubleIntegrator instantiations spilled SGPRs so heavily that the 2-player
+// one faulted on a null base pointer (tests/test_gpu_parity_ext.py::test_no_kernel_writes_outside_its_buffers runs this
+// kernel for every instantiation).
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_mpc_loop(Params pr, Buffers bf, int steps, uint64_t game_id0, double* states) {
+__global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr, Buffers bf, int steps, uint64_t game_id0, double* states) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x, lane = threadIdx.x;
     Game G = game_view(pr, bf, g);

@@ -184,6 +184,7 @@ def test_3d_builders_reject_models_without_three_position_dimensions(alg):
         b3.add_cylinder_constraint([[0, 0, 0]], [3], [1.0], [0.1])
 
 
+@pytest.mark.timeout(120)
 def test_no_kernel_writes_outside_its_buffers_3d(alg):
     import ctypes
     g, _ = None, None

@@ -234,12 +234,18 @@ def _guards_ok(batch):
     return fn(batch.h)
 
 
-@pytest.mark.parametrize("case", [(DI, 1, 5), (DI, 3, 40), (DI, 4, 9), (UNI, 1, 6), (UNI, 3, 30), (UNI, 4, 50), (BIC, 2, 7), (BIC, 3, 20), (BIC, 4, 11)])
+# every compiled kernel instantiation (ALG_CFGS_BASE / ALG_CFGS_EXT of algames_kernels.hpp): (model, p, N, extended constraints)
+ALL_INSTANTIATIONS = ([(DI, p, N, False) for p, N in ((1, 5), (2, 13), (3, 40), (4, 9))] + [(UNI, p, N, False) for p, N in ((1, 6), (2, 12), (3, 30), (4, 50))]
+                      + [(DI, p, N, True) for p, N in ((1, 7), (2, 9), (3, 12), (4, 6))] + [(UNI, p, N, True) for p, N in ((1, 9), (2, 8), (3, 11), (4, 7))]
+                      + [(BIC, p, N, True) for p, N in ((1, 8), (2, 7), (3, 20), (4, 11))])
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("case", ALL_INSTANTIATIONS)
 def test_no_kernel_writes_outside_its_buffers(alg, case):
-    """Runs every kernel family of a configuration (solve, step-wise entry points, IBR, receding-horizon loop, dense Jacobian)
-    and checks the guard zones behind all device buffers."""
-    model, p, N = case
-    ext = model == BIC or p != 3
+    """Runs every kernel family of every instantiation (solve, step-wise entry points, IBR, receding-horizon loop, dense Jacobian)
+    and checks the guard zones behind all device buffers; the timeout turns a kernel that never returns into a failure."""
+    model, p, N, ext = case
     g = alg.Batch(alg.hip_lib(), model, p, N, 0.1, 5)
     rng = np.random.default_rng(3)
     ni = g.n // p
@@ -248,7 +254,7 @@ def test_no_kernel_writes_outside_its_buffers(alg, case):
     if p > 1:
         g.add_collision_cost(np.full(p, 2.0), np.ones(p)); g.add_collision_avoidance(np.full(p, 0.2))
     g.add_control_bound(np.full(g.m, 2.0), np.full(g.m, -2.0))
-    if ext:                                                    # p == 3 double integrator / unicycle stay on the base kernels
+    if ext:
         g.add_wall_constraint([0.0], [-2.0], [1.0], [-2.0], [0.0], [-1.0])
         g.add_circle_constraint([3.0], [3.0], [0.5])
         g.add_state_bound(0, np.full(g.n, 50.0), np.full(g.n, -50.0))

@@ -1518,7 +1518,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
 #pragma unroll
             for (int r = 0; r < n; r++) {
                 if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];         // f rides in tile column n
-                else { if (cc < n) L.bw.Fx[r * 16 + cc] = fxv[r]; else L.bw.fv[r] = fxv[r]; }
+                else { double* dst = cc < n ? &L.bw.Fx[r * 16 + cc] : &L.bw.fv[r]; *dst = fxv[r]; }   // one store, selected address (no exec-mask flip per row)
             }
         }
         ALG_PROF(9)

@@ -182,14 +182,15 @@ def main():
         }
         prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")),
                       key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])   # r01_v11 after r01_v6
-        if prof:
+        for pf in reversed(prof):                                                                   # newest profile of this workload
             try:
-                pj = json.load(open(prof[-1]))
-                if pj.get("config") == args.config and pj.get("games_per_gpu") == G:
-                    out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = os.path.relpath(prof[-1], ROOT)
+                pj = json.load(open(pf))
             except Exception:
-                pass
+                continue
+            if pj.get("config") == args.config and pj.get("games_per_gpu") == G and not args.mpc_steps:
+                out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = os.path.relpath(pf, ROOT)
+                break
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alg, args.config, G)
         print(json.dumps(out))

@@ -423,7 +423,9 @@ class PrimalDualTraj:
 
 
 class Statistics:
-    """Per-game `Statistics` history (src/struct/statistics.jl:5-15) as numpy record arrays."""
+    """Per-game `Statistics` history (src/struct/statistics.jl:5-15) as numpy record arrays; the reference's field names
+    (`outer_iter`, `res`, `Δ_traj`, `dyn_vio`, `con_vio`, `sta_vio`, `opt_vio`) are views of game 0's history, the `*_vio`
+    entries being the `.max` of the reference's violation objects.  `t_elap` is not recorded on the device (zeros)."""
 
     def __init__(self, summary, history_fn):
         self.summary = summary
@@ -435,6 +437,61 @@ class Statistics:
     @property
     def iter(self):
         return self.summary["records"]
+
+    def _col(self, name, game=0):
+        return np.array(self.history(game)[name])
+
+    outer_iter = property(lambda self: self._col("outer"))
+    res = property(lambda self: self._col("res"))
+    Δ_traj = property(lambda self: self._col("delta"))
+    dyn_vio = property(lambda self: self._col("dyn_vio"))
+    con_vio = property(lambda self: self._col("con_vio"))
+    sta_vio = property(lambda self: self._col("sta_vio"))
+    opt_vio = property(lambda self: self._col("opt_vio"))
+    t_elap = property(lambda self: np.zeros(len(self.history(0))))
+
+
+# --------------------------------------------------------------------------------------------------
+# Printers (src/utils.jl:37-84).  The solver runs on the device, so the per-iteration table of `opts.inner_print` is printed
+# from the recorded history after the solve (game 0), one line per Newton iteration as solver_methods.jl:100 prints them.
+# --------------------------------------------------------------------------------------------------
+def scn(a, digits=1):
+    """scn(a; digits), utils.jl:63-84: mantissa/exponent string such as ' 1.2e+3'."""
+    assert digits >= 0
+    if a == 0:
+        e, m = 0, 0.0
+    else:
+        e = int(np.floor(np.log(abs(a)) / np.log(10)))
+        m = a * np.exp(-e * np.log(10))
+    m = round(m, digits)
+    if digits == 0:
+        strm = str(int(np.floor(m)))
+    else:
+        strm = str(float(m))
+        strm = strm + "0" * abs(2 + digits + (m < 0) - len(strm))
+    return f"{' ' if a >= 0 else ''}{strm}e{'+' if e >= 0 else ''}{e}"
+
+
+def display_solver_header():
+    print("%-3s %-2s %-2s %-6s %-6s %-6s " % ("out", "in", "α", "Δ", "res", "reg"))
+
+
+def display_solver_data(k, l, j, Δ, res_norm, reg):
+    reg_x = reg.x if hasattr(reg, "x") else reg
+    print("%-3s %-2s %-2s %-6s %-6s %-6s " % (k, l, j, "%.0e" % Δ, "%.0e" % res_norm, "%.0e" % reg_x))
+
+
+def _print_history(prob):
+    """What `opts.inner_print` shows (solver_methods.jl:36,100), replayed from game 0's history: a record is written at the
+    top of every inner iteration; the line of an iteration carries that iteration's step (Δ is the next record's Δ_traj)."""
+    h = prob.stats.history(0)
+    display_solver_header()
+    l = 0
+    for idx in range(len(h) - 1):
+        l = l + 1 if idx > 0 and h["outer"][idx] == h["outer"][idx - 1] else 1
+        if h["ls_j"][idx] == 0:
+            continue                                       # a record without a Newton step (gate / final record)
+        display_solver_data(int(h["outer"][idx]), l, int(h["ls_j"][idx]), h["delta"][idx + 1], h["res"][idx], prob.opts.reg_0 * l ** 4)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -519,6 +576,8 @@ def newton_solve(prob, init=True):
     prob._sync_options()
     summary = prob.batch.newton_solve(init=init, game_id0=prob.game_id0)
     prob.stats = Statistics(summary, prob.batch.get_history)
+    if prob.opts.inner_print:
+        _print_history(prob)
     return None
 
 

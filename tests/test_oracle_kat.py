@@ -1020,3 +1020,27 @@ def test_e2e_3d_host_builders_on_the_oracle(alg, orc):
     obj2 = alg.GameObjective([np.ones(4)] * 2, [np.ones(2)] * 2, [np.zeros(4)] * 2, [np.zeros(2)] * 2, N, m2)
     with pytest.raises(alg.AlgamesError):
         alg.GameProblem(N, dt, np.zeros(8), m2, alg.Options(inner_print=False, outer_print=False), obj2, con2, backend=orc.lib())
+
+
+def test_scn_and_printers(alg, orc, capsys):
+    # test/problem/global_quantities.jl:30-40 (literal strings)
+    assert alg.scn(1234.0) == " 1.2e+3" and alg.scn(-1234.0) == "-1.2e+3" and alg.scn(-0.1234) == "-1.2e-1" and alg.scn(0.1234) == " 1.2e-1"
+    assert alg.scn(0) == " 0.0e+0" and alg.scn(-0) == " 0.0e+0" and alg.scn(0, digits=3) == " 0.000e+0"
+    assert alg.scn(1234, digits=3) == " 1.234e+3" and alg.scn(1234, digits=0) == " 1e+3"
+    with pytest.raises(AssertionError):
+        alg.scn(1234, digits=-1)
+    # opts.inner_print (solver_methods.jl:36,100): header + one line per Newton iteration, replayed from the history
+    N, model = 10, alg.DoubleIntegratorGame(p=2)
+    opts = alg.Options(outer_print=False)                      # inner_print defaults to true like the reference
+    obj = alg.GameObjective([np.ones(4)] * 2, [0.5 * np.ones(2)] * 2, [np.zeros(4)] * 2, [-np.ones(2)] * 2, N, model)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    prob = alg.GameProblem(N, 0.1, [1.0, 2.0, 1.0, 2.0, 0.0, 0.0, 0.9, 0.9], model, opts, obj, con, backend=orc.lib())
+    alg.newton_solve(prob)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].split() == ["out", "in", "α", "Δ", "res", "reg"]
+    assert len(out) - 1 == int(prob.stats.summary["newton_iters"][0]) >= 1
+    k, l, j = out[1].split()[:3]
+    assert (k, l, j) == ("1", "1", "1")
+    st = prob.stats
+    assert len(st.res) == int(st.iter[0]) == len(st.outer_iter) == len(st.Δ_traj) == len(st.dyn_vio) == len(st.t_elap)
+    assert st.res[-1] < 1e-3 and st.res[-1] < st.res[0] and st.outer_iter[0] == 1

@@ -481,6 +481,35 @@ def display_solver_data(k, l, j, Δ, res_norm, reg):
     print("%-3s %-2s %-2s %-6s %-6s %-6s " % (k, l, j, "%.0e" % Δ, "%.0e" % res_norm, "%.0e" % reg_x))
 
 
+# Plot recipes (src/plots/solver_plots.jl:18-37,83-125) as plain data: what the recipes hand to Plots.jl, no drawing here.
+def recipe_traj(model, states):
+    """recipe_traj(model, traj): per player the x and y series (state entries pz[i][1], pz[i][2]) of a (N, n) state array;
+    returned twice like the recipe (scatter + path series)."""
+    states = np.asarray(states)
+    x = [states[:, i] for i in range(model.p)]
+    y = [states[:, model.p + i] for i in range(model.p)]
+    return [x, x], [y, y]
+
+
+def recipe_violation(stats, game=0):
+    """recipe_violation(stats): log10 of the four violation histories clipped at 1e-10 and the outer-iteration epochs; returns
+    (series_x, series_y, labels) with one shaded band per outer iteration followed by dyn / con / sta / opt."""
+    h = stats.history(game)
+    it = len(h)
+    ser = {k: np.log10(np.maximum(1e-10, h[k + "_vio"])) for k in ("dyn", "con", "sta", "opt")}
+    y_max = max(v.max() for v in ser.values())
+    epochs = np.asarray(h["outer"])
+    xs, ys, labels, i_start = [], [], [], 1
+    for k in range(1, int(epochs[-1]) + 1):
+        i_end = int(np.nonzero(epochs == k)[0][-1]) + 1
+        xs.append(np.linspace(i_start, i_end, it)); ys.append(np.full(it, y_max)); labels.append("")
+        i_start = i_end + 1
+    x = np.arange(1, it + 1)
+    for k in ("dyn", "con", "sta", "opt"):
+        xs.append(x); ys.append(ser[k]); labels.append(k)
+    return xs, ys, labels
+
+
 def _print_history(prob):
     """What `opts.inner_print` shows (solver_methods.jl:36,100), replayed from game 0's history: a record is written at the
     top of every inner iteration; the line of an iteration carries that iteration's step (Δ is the next record's Δ_traj)."""

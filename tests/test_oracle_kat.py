@@ -1044,3 +1044,10 @@ def test_scn_and_printers(alg, orc, capsys):
     st = prob.stats
     assert len(st.res) == int(st.iter[0]) == len(st.outer_iter) == len(st.Δ_traj) == len(st.dyn_vio) == len(st.t_elap)
     assert st.res[-1] < 1e-3 and st.res[-1] < st.res[0] and st.outer_iter[0] == 1
+    # plot recipes as data (src/plots/solver_plots.jl; test/plots/solver_plots.jl only checks that they run)
+    X = prob.pdtraj.states[0]
+    (x1, x2), (y1, y2) = alg.recipe_traj(model, X)
+    assert len(x1) == 2 and np.array_equal(x1[1], X[:, 1]) and np.array_equal(y1[0], X[:, 2]) and x2 is x1
+    xs, ys, labels = alg.recipe_violation(st)
+    assert labels[-4:] == ["dyn", "con", "sta", "opt"] and len(xs) == len(ys) == int(st.outer_iter[-1]) + 4
+    assert np.all(ys[-4] >= -10) and len(ys[-1]) == int(st.iter[0])

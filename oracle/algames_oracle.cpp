@@ -103,12 +103,18 @@ struct Dims {
 // Forward-mode dual numbers (stand-in for ForwardDiff 0.10 used by discrete_jacobian!)
 // ------------------------------------------------------------------------------------------
 constexpr int MAXD = 96;
+// Per-thread grow-only scratch (keeps the allocator out of the OpenMP loop over games: the band matrix alone is
+// several MB per Newton iteration).  Contents are unspecified on entry; every user writes before it reads.
+#define TL_VEC(T, name, count)                                                  \
+    thread_local std::vector<T> name##_tl;                                      \
+    if (name##_tl.size() < (size_t)(count)) name##_tl.resize((size_t)(count)); \
+    std::vector<T>& name = name##_tl
 struct Dual {
     double v = 0;
-    std::array<double, MAXD> e{};
+    std::array<double, MAXD> e;            // only e[0 .. nd) is ever written or read
     int nd = 0;
 };
-inline Dual dconst(double v, int nd) { Dual r; r.v = v; r.nd = nd; return r; }
+inline Dual dconst(double v, int nd) { Dual r; r.v = v; r.nd = nd; for (int i = 0; i < nd; i++) r.e[i] = 0.0; return r; }
 inline Dual operator+(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v + b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] + b.e[i]; return r; }
 inline Dual operator*(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v * b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * b.v + a.v * b.e[i]; return r; }
 inline Dual operator*(const Dual& a, double s) { Dual r; r.nd = a.nd; r.v = a.v * s; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * s; return r; }
@@ -152,7 +158,7 @@ void dynamics(const Dims& D, const T* x, const T* u, T* xd) {
 // [restated from the published source; parity unpinned, see header]
 template <class T>
 void rk2(const Dims& D, const T* x, const T* u, T* xn) {
-    std::vector<T> k1(D.n), xm(D.n), k2(D.n);
+    TL_VEC(T, k1, D.n); TL_VEC(T, xm, D.n); TL_VEC(T, k2, D.n);
     dynamics(D, x, u, k1.data());
     for (int i = 0; i < D.n; i++) xm[i] = x[i] + k1[i] * (D.dt * 0.5);
     dynamics(D, xm.data(), u, k2.data());
@@ -160,7 +166,7 @@ void rk2(const Dims& D, const T* x, const T* u, T* xn) {
 }
 // RobotDynamics 0.3.1 discrete_dynamics(RK3,...) used by rollout! (solver_methods.jl:17)
 void rk3(const Dims& D, const double* x, const double* u, double* xn) {
-    std::vector<double> k1(D.n), k2(D.n), k3(D.n), t(D.n);
+    TL_VEC(double, k1, D.n); TL_VEC(double, k2, D.n); TL_VEC(double, k3, D.n); TL_VEC(double, t, D.n);
     dynamics(D, x, u, k1.data());
     for (int i = 0; i < D.n; i++) { k1[i] *= D.dt; t[i] = x[i] + k1[i] / 2; }
     dynamics(D, t.data(), u, k2.data());
@@ -171,7 +177,7 @@ void rk3(const Dims& D, const double* x, const double* u, double* xn) {
 // ∇dynamics! (local_quantities.jl:20-27): n x (n+m) Jacobian [A B] of the RK2 map, row-major J[r*(n+m)+c]
 void rk2_jacobian(const Dims& D, const double* x, const double* u, double* J) {
     const int nd = D.n + D.m;
-    std::vector<Dual> xd(D.n), ud(D.m), xn(D.n);
+    TL_VEC(Dual, xd, D.n); TL_VEC(Dual, ud, D.m); TL_VEC(Dual, xn, D.n);
     for (int i = 0; i < D.n; i++) { xd[i] = dconst(x[i], nd); xd[i].e[i] = 1.0; }
     for (int i = 0; i < D.m; i++) { ud[i] = dconst(u[i], nd); ud[i].e[D.n + i] = 1.0; }
     rk2(D, xd.data(), ud.data(), xn.data());
@@ -417,7 +423,7 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
     const int n = D.n, m = D.m, p = D.p, N = D.N, nd = n + m;
     std::vector<double>& res = g.res;
     res.assign(D.S, 0.0);                                                            // :18
-    std::vector<double> q(n), r(D.mi), u(m), J(n * nd), xn(n), uref(m);
+    TL_VEC(double, q, n); TL_VEC(double, r, D.mi); TL_VEC(double, u, m); TL_VEC(double, J, n * nd); TL_VEC(double, xn, n); TL_VEC(double, uref, m);
     // Cost (:23-41).  stamp (opt,i,x,k) is invalid for the first knot (stamp.jl:203).
     for (int i = 0; i < p; i++) {
         for (int k = 1; k < N; k++) {
@@ -509,7 +515,7 @@ template <class Add>
 void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double reg, Add add) {
     const Dims& D = sh.D;
     const int n = D.n, m = D.m, p = D.p, N = D.N, nd = n + m;
-    std::vector<double> Qm(n * n), u(m), J(n * nd);
+    TL_VEC(double, Qm, n * n); TL_VEC(double, u, m); TL_VEC(double, J, n * nd);
     // Cost (:128-145)
     for (int i = 0; i < p; i++) {
         for (int k = 1; k < N; k++) {
@@ -647,12 +653,12 @@ void build_perms(const Dims& D, std::vector<int>& rpos, std::vector<int>& cpos) 
 // Δtraj = - lu(jac) \ res ; set_traj!(core, Δpdtraj, Δtraj)  (solver_methods.jl:87-88)
 int newton_direction(const Shared& sh, Game& g, double reg) {
     const Dims& D = sh.D;
-    std::vector<int> rpos, cpos; build_perms(D, rpos, cpos);
+    thread_local std::vector<int> rpos, cpos; build_perms(D, rpos, cpos);
     int kl = 0, ku = 0;
     jacobian(sh, g, g.z[0], reg, [&](int r, int c, double) { int dlt = rpos[r] - cpos[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); });
-    Banded B; B.init(D.S, kl, ku);
+    thread_local Banded B; B.init(D.S, kl, ku);           // per-thread storage, zero-filled by init (no allocation after the first call)
     jacobian(sh, g, g.z[0], reg, [&](int r, int c, double v) { B.at(rpos[r], cpos[c]) += v; });
-    std::vector<double> rhs(D.S);
+    TL_VEC(double, rhs, D.S);
     for (int r = 0; r < D.S; r++) rhs[rpos[r]] = g.res[r];
     if (B.factor() != 0) return ALG_STATUS_SINGULAR;
     B.solve(rhs);
@@ -936,12 +942,12 @@ alg_record ibr_record(const Shared& sh, Game& g, double delta, int outer, int i)
 // Δtraj[horiz_mask] = - lu(jac[verti_mask, horiz_mask]) \ res[verti_mask]  (solver_methods.jl:249-251)
 int ibr_direction(const Shared& sh, Game& g, int i, double reg) {
     const Dims& D = sh.D;
-    std::vector<int> rm, cm; int Sm; ibr_masks(D, i, rm, cm, Sm);
+    thread_local std::vector<int> rm, cm; int Sm; ibr_masks(D, i, rm, cm, Sm);
     int kl = 0, ku = 0;
     jacobian(sh, g, g.z[0], reg, [&](int r, int c, double) { if (rm[r] >= 0 && cm[c] >= 0) { int dlt = rm[r] - cm[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); } });
-    Banded B; B.init(Sm, kl, ku);
+    thread_local Banded B; B.init(Sm, kl, ku);
     jacobian(sh, g, g.z[0], reg, [&](int r, int c, double v) { if (rm[r] >= 0 && cm[c] >= 0) B.at(rm[r], cm[c]) += v; });
-    std::vector<double> rhs(Sm);
+    TL_VEC(double, rhs, Sm);
     for (int r = 0; r < D.S; r++) if (rm[r] >= 0) rhs[rm[r]] = g.res[r];
     if (B.factor() != 0) return ALG_STATUS_SINGULAR;
     B.solve(rhs);

@@ -112,9 +112,9 @@ def c3_unicycle(ids, N=50, seed=100, p=4, target_offset=0.1):
 
 
 def make_problem(cfg, ids, backend=None, device=0, **kw):
-    """cfg in {'C2','C3','C5'} -> GameProblem over the scenarios `ids` (global scenario ids)."""
+    """cfg in {'C2','C3','C4','C5'} -> GameProblem over the scenarios `ids` (global scenario ids)."""
     ids = np.asarray(ids, dtype=np.int64)
-    if cfg == "C2":
+    if cfg in ("C2", "C4"):                      # C4 = the C2 problem, 65 536 scenarios sharded over 8 GPUs
         model, N, dt, x0, obj, con, opts = c2_double_integrator(ids, **kw)
     elif cfg == "C3":
         model, N, dt, x0, obj, con, opts = c3_unicycle(ids, N=50, p=4, **kw)

@@ -1,27 +1,34 @@
 #!/usr/bin/env python
 """Benchmark of the batched ALGAMES Newton / augmented-Lagrangian hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches its own N ranks (it re-executes itself
+under torch.distributed.run on 127.0.0.1) and FAILS -- it never degrades to fewer GPUs -- when the node has fewer
+than N devices.
+
 A "step" is one pass of the hot path over one batch: a full batched `newton_solve!` (init_traj! + RK3 rollout,
-AL outer loop, Newton inner loop, structured KKT solve, line search, dual/penalty updates) of the BASELINE
-config C2 -- 3-player DoubleIntegrator, N = 40, 4096 synthetic scenarios per GPU -- with all
-inputs already resident in HBM.  Every step re-initialises the iterate from the counter RNG, so all K steps do
-identical work.  metric = game-Newton-iterations per second (inner iterations that performed a linear
-solve, summed over games and ranks) -- BASELINE.json's "Newton iters/sec (batch)"; games-to-convergence/s is
-reported next to it.  Weak scaling: the scenario batch is sharded by contiguous global scenario ids, one
-rank per GPU, no data-path collective (games are independent); the only collectives are the timing
-barrier / max and the final count reduction.
+AL outer loop, Newton inner loop, structured KKT solve, line search, dual/penalty updates) with all inputs
+already resident in HBM.  Default workload = BASELINE config C2: 3-player DoubleIntegrator, N = 40, 4096
+synthetic scenarios per GPU; C4 is the same problem with 8192 scenarios per GPU (65 536 over
+8 GPUs); C3 = 4-player Unicycle N = 50 (1024 per GPU); C5 = 3-player Unicycle N = 30 (with --mpc-steps T one
+step is a T-step receding-horizon loop per scenario).  Every step re-initialises the iterate from the counter
+RNG, so all K steps do identical work.  metric = game-Newton-iterations per second (inner iterations that
+performed a linear solve, summed over games and ranks) -- BASELINE.json's "Newton iters/sec (batch)";
+games-to-convergence/s is reported next to it.  Weak scaling: the scenario batch is sharded by contiguous
+global scenario ids, one rank per GPU, no data-path collective (games are independent); the only collectives
+are the timing barrier / max and the final count reduction.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
-import re
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,34 +36,111 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+F64_PEAK = 78.6e12         # FLOP/s, dense f64 vector = f64 MFMA peak (same guide)
+
+# configuration -> (scenario family of algames.jl_amd/scenarios.py, default scenarios per GPU)
+CONFIGS = {"C2": ("C2", 4096), "C3": ("C3", 1024), "C4": ("C2", 8192), "C5": ("C5", 64)}
+WORKLOADS = {"C2": "C2: 3-player DoubleIntegrator (d=2), N=40, collision cost + collision avoidance, 4096 scenarios/GPU",
+             "C3": "C3: 4-player Unicycle, N=50, collision avoidance + control bounds, 1024 scenarios/GPU",
+             "C4": "C4: 3-player DoubleIntegrator (d=2), N=40, 65536 scenarios sharded over 8 GPUs (8192/GPU)",
+             "C5": "C5: 3-player Unicycle, N=30, collision avoidance + control bounds, receding-horizon seeds"}
 
 
 def survey_balg(N, n, m, p):
-    """Algorithmic bytes per game-Newton-iteration, SURVEY.md 8(d): 8*[2(S+n) + 2(N-1)(b^2 + b*p*n)]."""
+    """bytes per game-Newton-iteration of the dense block-tridiagonal LU the survey priced,
+    8*[2(S+n) + 2(N-1)(b^2 + b*p*n)].  Context only: the structured elimination never performs that spill."""
     b = n + m + p * n
     S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
     return 8 * (2 * (S + n) + 2 * (N - 1) * (b * b + b * p * n))
 
 
-def structured_bytes(cfg, N, n, m, p, ls_trials_per_iter=1.0):
-    """Algorithmic HBM bytes per game-Newton-iteration of THIS implementation ("Roofline accounting"):
-    one line-search trial (axpy), one assemble pass (the accepted trial doubles as the next record!), the three sweeps
-    of the Newton direction with their step-record slices and the spilled gains.  The accepted trial becomes pdtraj by
-    exchanging buffers (no traffic)."""
+def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0):
+    """Algorithmic HBM bytes per game-Newton-iteration of THIS implementation ("Roofline
+    accounting"): one line-search trial (axpy), one assemble pass (the accepted trial doubles as the next record!),
+    the three sweeps of the Newton direction with their step-record slices and the spilled gains.  The accepted
+    trial becomes pdtraj by exchanging buffers (no traffic).  Every array is counted once per pass that has to
+    touch it: this is the floor for this algorithm, re-reads are not included."""
     S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
     it, K = S + n, N - 1
-    nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p}[cfg]                       # RK2 Jacobian coefficients per step
+    nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p}[family]                    # RK2 Jacobian coefficients per step
     npair = p * (p - 1)
     len_costate = nc + 3 * npair + 3 * p + p * n                         # [coef | Hh | Hd | rx]
     len_sweep = len_costate + 2 * m + n                                  # + [R^ | ru | rd]
     len_rec = len_sweep + 2 * p * p                                      # + pair-gradient table
-    con = K * npair + (2 * m * K if cfg in ("C3", "C5") else 0)          # constraint rows touched (lam, mu read; vals written)
+    con = K * npair + (2 * m * K if family in ("C3", "C5") else 0)       # constraint rows touched (lam, mu read)
     gains = K * m * (n + 1)
-    trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec + con))   # axpy + assemble pass
+    trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec))   # axpy + assemble pass
     backward = K * len_sweep + gains
     forward = gains + K * (nc + n) + K * (n + m)
     costate = K * len_costate + K * n + K * p * n
     return 8 * (trial + backward + forward + costate)
+
+
+# --------------------------------------------------------------------------------------------------
+# Sharding + reduction: the N > 1 path.  tests/test_sharding_gloo.py runs exactly these two functions with
+# world_size 2 on the gloo backend (the CPU oracle standing in for the device there).
+# --------------------------------------------------------------------------------------------------
+def make_shard(alg, config, games_per_rank, rank, world, backend=None, device=0, **kw):
+    """Rank `rank` of `world` owns the contiguous global scenario ids [rank*G, (rank+1)*G): all
+    random inputs are keyed by global id, so the shard layout does not change them."""
+    import numpy as np
+    family = CONFIGS[config][0]
+    lo, hi = alg.scenarios.shard_range(games_per_rank * world, rank, world)
+    ids = np.arange(lo, hi)
+    prob = alg.scenarios.make_problem(family, ids, backend=backend, device=device, **kw)
+    return prob, ids
+
+
+def reduce_counters(counts, elapsed, world, device):
+    """Sum of the per-rank integer counters and max of the per-rank wall time (the only collectives of the run)."""
+    import torch
+    import torch.distributed as dist
+    tot = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device)
+    tmax = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return [int(v) for v in tot.tolist()], float(tmax.item())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(ngpu):
+    """Re-executes this script as `ngpu` ranks (one per GPU) under torch.distributed.run.  Fails when the node cannot
+    supply `ngpu` devices."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < ngpu:
+        raise SystemExit(f"bench.py: --gpus {ngpu} requested but this node exposes {have} GPU(s); refusing to run a "
+                         f"smaller job under the same label")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpu}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def committed_profile(config, games_per_gpu, mpc_steps):
+    """Newest committed PMC summary (profiles/rNN_*_pmc*.json) of this workload, or None.  These numbers come from
+    separate rocprofv3 --pmc passes of this same command and are labelled as such in the output."""
+    import re
+    best = None
+    for pf in glob.glob(os.path.join(ROOT, "profiles", "*_pmc*.json")):
+        try:
+            pj = json.load(open(pf))
+        except Exception:
+            continue
+        if pj.get("config") != config or pj.get("games_per_gpu") != games_per_gpu or int(pj.get("mpc_steps", 0)) != mpc_steps:
+            continue
+        key = [int(t) for t in re.findall(r"\d+", os.path.basename(pf))]
+        if best is None or key > best[0]:
+            best = (key, pf, pj)
+    return best
 
 
 def main():
@@ -64,35 +148,44 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--games-per-gpu", type=int, default=4096)
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--games-per-gpu", type=int, default=0, help="scenarios per GPU (default: the config's BASELINE batch)")
     ap.add_argument("--mpc-steps", type=int, default=0,
                     help="C5 receding-horizon mode: one bench step = this many warm-started MPC solves per game")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.mpc_steps and args.config != "C5":
+        raise SystemExit("bench.py: --mpc-steps is the C5 receding-horizon mode")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        launch_ranks(args.gpus)                                     # does not return
+    world = int(world_env) if world_env is not None else 1
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or without torchrun: bench.py starts its own ranks)")
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import algames_jl_amd as alg
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} (node exposes {torch.cuda.device_count()})")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
 
-    G = args.games_per_gpu
-    ids = np.arange(rank * G, (rank + 1) * G)                       # contiguous global scenario ids
-    prob = alg.scenarios.make_problem(args.config, ids, device=local_rank)
+    family, default_games = CONFIGS[args.config]
+    G = args.games_per_gpu or default_games
+    prob, ids = make_shard(alg, args.config, G, rank, world, device=local_rank)
     b = prob.batch
     stream = torch.cuda.Stream()                                    # a real (non-NULL) HIP stream owned by torch
     torch.cuda.set_stream(stream)
@@ -135,70 +228,58 @@ def main():
         iters_rank = int(st["newton_iters"].sum())
         conv_rank = int(st["converged"].sum())
     bad_rank = int((st["status"] != 0).sum())
-    tot = torch.tensor([iters_rank, conv_rank, bad_rank], dtype=torch.int64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    iters_all, conv_all, bad_all = [int(v) for v in tot.tolist()]
-    elapsed = float(tmax.item())
+    (iters_all, conv_all, bad_all), elapsed = reduce_counters([iters_rank, conv_rank, bad_rank], elapsed, world, "cuda")
 
     if rank == 0:
         K = args.steps
         value = iters_all * K / elapsed
         kern_s = float(np.mean(kernel_ms)) * 1e-3
         p, n, m, N = b.p, b.n, b.m, b.N
-        balg = survey_balg(N, n, m, p)
-        own = structured_bytes(args.config, N, n, m, p)
+        own = structured_bytes(family, N, n, m, p)
+        kernel = "k_mpc_loop" if args.mpc_steps else "k_newton_solve"
+        achieved = own * iters_rank / kern_s                         # B/s of this rank's launch
+        roof = {
+            # the contract's bound is the HBM roofline: achieved = algorithmic bytes per launch / launch duration, where
+            # the algorithmic bytes are THIS kernel's (DESIGN.md "Roofline accounting": structured_bytes(), per
+            # game-Newton-iteration) x the game-iterations one launch performs; frac <= 1 by construction.
+            "bound": "hbm", "kernel": kernel,
+            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "bytes_per_game_iter": own, "game_iters_per_launch": iters_rank, "kernel_ms_avg": 1e3 * kern_s,
+            "traffic": None,
+            "limiter": "instruction issue + dependency latency (not HBM): see valu_issue_frac / mfma_frac",
+            # context only (SURVEY.md 8(d) priced a dense block-LU with factor spill; this kernel never performs it)
+            "survey_dense_lu_bytes_per_game_iter": survey_balg(N, n, m, p),
+        }
+        prof = committed_profile(args.config, G, args.mpc_steps)
+        if prof is not None:
+            _, pf, pj = prof
+            roof["traffic"] = pj.get("hbm_bytes_per_launch")
+            for k in ("valu_issue_frac", "mfma_frac", "wave_issue_frac", "traffic_over_model"):
+                if k in pj:
+                    roof[k] = pj[k]
+            roof["pmc_source"] = os.path.relpath(pf, ROOT) + " (separate rocprofv3 --pmc passes of this command; not re-measured in this run)"
         out = {
             "metric": "newton_iters_per_sec", "value": value, "unit": "game-Newton-iterations/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": {"C2": "C2: 3-player DoubleIntegrator (d=2), N=40, collision cost + collision avoidance",
-                                    "C3": "C3: 4-player Unicycle, N=50, collision avoidance + control bounds",
-                                    "C5": "C5: 3-player Unicycle, N=30, collision avoidance + control bounds"}[args.config],
+            "config": {"workload": WORKLOADS[args.config], "name": args.config,
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
                        "parallelism": f"scenario-sharded x{world}",
-                       "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve), one game per wavefront" if args.mpc_steps
-                                  else "fused per-game newton_solve! kernel, one game per wavefront")},
+                       "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve)" if args.mpc_steps
+                                  else "fused per-game newton_solve! kernel")},
             "games_to_convergence_per_sec": conv_all * K / elapsed,
             "games_converged": conv_all, "games_failed": bad_all,
-            "roofline": {
-                "bound": "hbm", "kernel": "k_newton_solve",
-                # contract: SURVEY 8(d) algorithmic bytes per game-iteration x game-iterations per launch / launch duration
-                "achieved": balg * iters_rank / kern_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": balg * iters_rank / kern_s / HBM_PEAK,
-                "survey_bytes_per_game_iter": balg,
-                # the structured elimination never spills b x b factors: its own algorithmic bytes
-                "own_bytes_per_game_iter": own, "own_achieved": own * iters_rank / kern_s / 1e9,
-                "own_frac": own * iters_rank / kern_s / HBM_PEAK,
-                "kernel_ms_avg": 1e3 * kern_s, "traffic": None,
-                "note": "achieved/frac follow the contract: SURVEY 8(d) bytes (dense block-LU factor spill) x game-iterations "
-                        "per launch / launch time; the structured elimination never performs that spill, so frac > 1 means "
-                        "'faster than the HBM ceiling of the dense algorithm'. own_* uses this kernel's own algorithmic bytes; "
-                        "traffic = 2 x FETCH_SIZE + WRITE_SIZE PMC bytes per launch (L2-fabric side, calibrated with scratch/pmc_calib.hip; profiles/). The kernel is instruction-issue / latency bound.",
-            },
+            "roofline": roof,
         }
-        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")),
-                      key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])   # r01_v11 after r01_v6
-        for pf in reversed(prof):                                                                   # newest profile of this workload
-            try:
-                pj = json.load(open(pf))
-            except Exception:
-                continue
-            if pj.get("config") == args.config and pj.get("games_per_gpu") == G and not args.mpc_steps:
-                out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
-                out["roofline"]["traffic_source"] = os.path.relpath(pf, ROOT)
-                break
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(alg, args.config, G)
+            out["cpu_baseline"] = cpu_baseline(alg, family, G, args.mpc_steps)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(alg, cfg, G):
+def cpu_baseline(alg, family, G, mpc_steps=0):
     """The oracle (literal CPU restatement of the reference algorithm: global KKT assembly + general partial-pivot
     LU per game, OpenMP over games) timed on a bounded sample of the same workload: all host cores, and one core
     (the closest analogue of the single-threaded Julia solver)."""
@@ -207,26 +288,35 @@ def cpu_baseline(alg, cfg, G):
     import oracle as orc
     cores = os.cpu_count() or 1
     prev = orc.set_threads(cores)
-    nsample = int(min(G, max(8, 16 * cores)))
-    prob = alg.scenarios.make_problem(cfg, np.arange(nsample), backend=orc.lib())
-    t0 = time.perf_counter()
-    alg.newton_solve(prob)
-    dt = time.perf_counter() - t0
-    s = prob.stats.summary
+
+    def run(nsample):
+        prob = alg.scenarios.make_problem(family, np.arange(nsample), backend=orc.lib())
+        t0 = time.perf_counter()
+        if mpc_steps:
+            steps = min(mpc_steps, 8)
+            it, cv, _ = alg.mpc_solve(prob, steps)
+            dt = time.perf_counter() - t0
+            return int(it.sum()), int(cv.sum()), dt, f"{steps} receding-horizon steps each"
+        alg.newton_solve(prob)
+        dt = time.perf_counter() - t0
+        s = prob.stats.summary
+        return int(s["newton_iters"].sum()), int(s["converged"].sum()), dt, "one newton_solve! each"
+
+    nsample = int(max(8, 16 * cores))
+    it, cv, dt, what = run(nsample)
+    if dt < 4.0:                                                    # aim at ~10 s of wall time on all cores, bounded
+        nsample = int(min(64 * cores, max(nsample, nsample * 10.0 / max(dt, 1e-3))))
+        it, cv, dt, what = run(nsample)
     orc.set_threads(1)
-    n1 = int(min(G, 24))
-    prob1 = alg.scenarios.make_problem(cfg, np.arange(n1), backend=orc.lib())
-    t0 = time.perf_counter()
-    alg.newton_solve(prob1)
-    dt1 = time.perf_counter() - t0
-    s1 = prob1.stats.summary
+    n1 = 24 if not mpc_steps else 8
+    it1, cv1, dt1, _ = run(n1)
     orc.set_threads(prev)
-    return {"value": float(s["newton_iters"].sum() / dt), "unit": "game-Newton-iterations/s", "cores": cores,
-            "kind": "port", "sample": f"first {nsample} scenarios of the same {cfg} workload, one newton_solve! each, "
-                                      f"{dt:.1f} s wall, OpenMP over games",
-            "games_to_convergence_per_sec": float(s["converged"].sum() / dt),
-            "single_core_value": float(s1["newton_iters"].sum() / dt1),
-            "single_core_sample": f"first {n1} scenarios, 1 thread, {dt1:.1f} s wall"}
+    return {"value": float(it / dt), "unit": "game-Newton-iterations/s", "cores": cores, "threads_used": cores,
+            "kind": "port", "sample": f"first {nsample} scenarios of the same workload, {what}, {dt:.1f} s wall, OpenMP over games",
+            "games_to_convergence_per_sec": float(cv / dt),
+            "single_core_value": float(it1 / dt1),
+            "single_core_sample": f"first {n1} scenarios, 1 thread, {dt1:.1f} s wall",
+            "scaling_all_cores_over_one": float((it / dt) / (it1 / dt1))}
 
 
 if __name__ == "__main__":

@@ -20,12 +20,15 @@ import algames_jl_amd as alg, oracle as orc
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 TOTAL = 10
-lo, hi = alg.scenarios.shard_range(TOTAL, rank, world)
-prob = alg.scenarios.make_problem("C2", np.arange(lo, hi), N=10, backend=orc.lib())
+import bench                                   # the N > 1 path under test is bench.py's own sharding + reduction
+prob, ids = bench.make_shard(alg, "C4", TOTAL // world, rank, world, backend=orc.lib(), N=10)
+lo, hi = int(ids[0]), int(ids[-1]) + 1
+assert (lo, hi) == alg.scenarios.shard_range(TOTAL, rank, world)
 alg.newton_solve(prob)
 s = prob.stats.summary
-cnt = torch.tensor([int(s["newton_iters"].sum()), int(s["converged"].sum()), hi - lo], dtype=torch.int64)
-dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+cnt, tmax = bench.reduce_counters([int(s["newton_iters"].sum()), int(s["converged"].sum()), hi - lo], 1.0 + rank, world, "cpu")
+assert tmax == float(world)                    # max over ranks of the per-rank time
+cnt = torch.tensor(cnt)
 z = torch.from_numpy(prob.batch.get_traj())
 per = (TOTAL + world - 1) // world
 pad = torch.zeros(per, z.shape[1], dtype=torch.float64); pad[: z.shape[0]] = z
@@ -60,6 +63,21 @@ def test_scenarios_depend_only_on_global_id():
     c = alg.scenarios.c3_unicycle(np.arange(5, 9))[3]
     d = alg.scenarios.c3_unicycle(np.arange(0, 9))[3]
     assert np.array_equal(c, d[5:])
+
+
+def test_bench_refuses_to_degrade_the_gpu_count():
+    """`python bench.py --gpus 2` with no torchrun environment starts its own ranks -- and must fail (not run a smaller
+    job) when the node has fewer devices; under torchrun a WORLD_SIZE that disagrees with --gpus is an error too."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    assert out.returncode != 0 and "refusing" in out.stderr, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr, out.stderr[-2000:]
 
 
 def test_world_size_2_gloo_sharded_solve(orc):

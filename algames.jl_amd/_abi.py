@@ -104,12 +104,13 @@ SIGNATURES = {
     "record_stats": (C.c_int, [_P, _P]),
     "reset_con": (C.c_int, [_P]),
     "dual_penalty_update": (C.c_int, [_P, _D]),
-    "newton_step": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "newton_step": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "newton_solve": (C.c_int, [_P, C.c_int32, C.c_int64, _P]),
     "newton_solve_async": (C.c_int, [_P, C.c_int32, C.c_int64]),
     "get_stats": (C.c_int, [_P, _P]),
     "get_history": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _I]),
     "synchronize": (C.c_int, [_P]),
+    "debug_check_guards": (C.c_int, [_P]),
     "ibr_solve_player": (C.c_int, [_P, C.c_int32, _P]),
     "ibr_newton_solve": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _I, C.c_double, _P]),
     "mpc_advance": (C.c_int, [_P]),
@@ -352,9 +353,11 @@ class Batch:
         self.lib.check(self.lib.dual_penalty_update(self.h, _dptr(vals)))
         return vals
 
-    def newton_step(self, k_outer=1, l_inner=1):
+    def newton_step(self, k_outer=1, l_inner=1, delta=None):
+        """inner_iteration for every game; `delta` (B,) is the caller's Δ that record! stores (solver_methods.jl:75), default 0."""
         info = np.zeros(self.B, dtype=step_info_dtype)
-        self.lib.check(self.lib.newton_step(self.h, k_outer, l_inner, info.ctypes.data_as(_P)))
+        d = None if delta is None else _f64(np.broadcast_to(np.asarray(delta, dtype=np.float64), (self.B,)))
+        self.lib.check(self.lib.newton_step(self.h, k_outer, l_inner, None if d is None else _dptr(d), info.ctypes.data_as(_P)))
         return info
 
     def newton_solve(self, init=True, game_id0=0):

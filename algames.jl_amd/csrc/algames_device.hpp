@@ -49,24 +49,23 @@ struct Params {
     int ext, has_sb, nwall, ncirc, sb_len, wall_len, circ_len;
     int nwall3, ncyl, wall3_len, cyl_len, ca_dim;   // 3-D half (Cfg::PD == 3 only): Wall3D, Cylinder, spherical collision avoidance (ca_dim = 3)
     double lf, lr;          // BicycleGame(lf, lr), bicycle.jl:15
-};
-
-// Device pointers of a handle (all game-major).
-struct Buffers {
-    double* traj[3];        // B x traj_len : pdtraj, trial, delta
-    double* x0;             // B x n
-    double* Qd; double* Rd; double* xf; double* uf;   // [B|1] x p x ni / mi (compact, own indices)
-    double* lam; double* mu; double* vals;            // B x con_len
-    double* res;            // B x S     residual in vertical order (alg_residual output only)
-    double* rec;            // B x (N-1) x Rec::LEN  step records (assemble pass -> direction sweeps)
-    double* kgain;          // B x kscratch_len      feedback gains (backward sweep -> forward sweep)
-    alg_game_stats* stats;  // B
-    alg_record* hist;       // B x hist_max
-    long long* mpc;         // B x 2 running totals (newton_iters, converged) of the receding-horizon loop
-    double* tcache;         // B x 8 statistics of the last line-search trial (reused as the next record!)
-    double* extc;           // constants of the extended constraints, shared by all games:
-                            // [x_max (p n) | x_min (p n) | walls x1 y1 x2 y2 xv yv (6 ALG_MAX_WALLS) | circles xc yc r (3 ALG_MAX_CIRCLES)
-                            //  | 3-D walls p1 p2 p3 v (12 per wall, ALG_MAX_WALLS) | cylinders p (3) axis l r (6 per cylinder, ALG_MAX_CIRCLES)]
+    // ---- device memory of the handle (filled in by the host; see the "Per-game data view" section) ----------------------
+    // main arena: B x stride doubles; one contiguous, 128-byte aligned chunk per game holding every per-game array at the
+    // offsets below (doubles, multiples of 16): [pdtraj | trial | delta | x0 | res | rec | kgain | tcache | stats | mpc totals]
+    double* arena;
+    int stride, o_z1, o_z2, o_x0, o_res, o_rec, o_kgain, o_tc, o_st, o_mpc;
+    // constraint arena: B x con_stride doubles, per game [lam | mu | vals] (con_pad doubles each; re-created when extended
+    // constraints are added)
+    double* con;
+    int con_stride, con_pad;
+    // LQR block [Qd (p ni) | xf (p ni) | Rd (p mi) | uf (p mi)] (compact, own indices): per game (lqr_stride > 0) or shared (0)
+    const double* lqr;
+    int lqr_stride;
+    // constants of the extended constraints, shared by all games:
+    // [x_max (p n) | x_min (p n) | walls x1 y1 x2 y2 xv yv (6 ALG_MAX_WALLS) | circles xc yc r (3 ALG_MAX_CIRCLES)
+    //  | 3-D walls p1 p2 p3 v (12 per wall, ALG_MAX_WALLS) | cylinders p (3) axis l r (6 per cylinder, ALG_MAX_CIRCLES)]
+    const double* extc;
+    alg_record* hist;       // B x hist_max Statistics records
 };
 
 // EXT_ = 1 instantiations carry the extended ingredient set of examples/intro_example.jl (state bounds, walls, circles;
@@ -123,6 +122,11 @@ template <class C> __device__ __forceinline__ const double* zstate(const double*
 // Opaque copy of the lane id: keeps per-lane role / address computations of a phase from being hoisted out of the
 // solver's outer loops (where every phase's invariants would be live at once).
 __device__ __forceinline__ int phase_lane() { int l = threadIdx.x; asm volatile("" : "+v"(l)); return l; }
+// Opaque copies of wave-uniform loop invariants (problem sizes, dt, base pointers), taken at the start of a phase: whatever is
+// derived from them (row counts, address vectors, dt^2 / 2, (double)S ...) is recomputed inside the phase with a handful of
+// scalar instructions instead of being hoisted in front of the solver's outer loops and kept alive -- or spilled -- there.
+__device__ __forceinline__ int phase_int(int v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ double phase_f64(double v) { asm volatile("" : "+s"(v)); return v; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -395,26 +399,39 @@ __device__ __forceinline__ double B_vec(const double* coef, double dt, V w, int 
 // ================================================================================================
 // Per-game data view
 // ================================================================================================
+// One base pointer per game (the game's chunk of the main arena) plus 32-bit offsets: every other address is derived from
+// the kernel arguments where it is used, so that a solver kernel does not carry eighteen 64-bit base pointers in SGPRs
+// through all of its phases.
 struct Game {
-    double* z[3];
-    const double* x0;
-    const double* Qd; const double* Rd; const double* xf; const double* uf;
-    double* lam; double* mu; double* vals;
-    double* res; double* rec; double* kgain;
-    alg_game_stats* st; alg_record* hist; double* tc;
-    const double* extc;
+    double* base;           // this game's chunk of the main arena
+    int g;                  // game index inside the handle's batch
+    int zo[3];              // offsets of pdtraj / trial / delta inside the chunk (the line search exchanges the first two)
+    // Opaque copy for one phase of the solver: addresses derived from it cannot be hoisted out of the solver's outer loops
+    // (where the base pointers of every phase would be live -- and spilled -- at once); they are recomputed per phase with a
+    // few scalar instructions instead.
+    __device__ __forceinline__ Game fresh() const { Game H = *this; asm volatile("" : "+s"(H.base), "+s"(H.g)); return H; }
+    __device__ __forceinline__ double* z(int t) const { return base + zo[t]; }
+    __device__ __forceinline__ const double* x0(const Params& pr) const { return base + pr.o_x0; }
+    __device__ __forceinline__ double* x0w(const Params& pr) const { return base + pr.o_x0; }
+    __device__ __forceinline__ double* res(const Params& pr) const { return base + pr.o_res; }
+    __device__ __forceinline__ double* rec(const Params& pr) const { return base + pr.o_rec; }
+    __device__ __forceinline__ double* kgain(const Params& pr) const { return base + pr.o_kgain; }
+    __device__ __forceinline__ double* tc(const Params& pr) const { return base + pr.o_tc; }
+    __device__ __forceinline__ alg_game_stats* st(const Params& pr) const { return reinterpret_cast<alg_game_stats*>(base + pr.o_st); }
+    __device__ __forceinline__ long long* mpc(const Params& pr) const { return reinterpret_cast<long long*>(base + pr.o_mpc); }
+    __device__ __forceinline__ double* lam(const Params& pr) const { return pr.con + (size_t)g * pr.con_stride; }
+    __device__ __forceinline__ double* mu(const Params& pr) const { return lam(pr) + pr.con_pad; }
+    __device__ __forceinline__ double* vals(const Params& pr) const { return lam(pr) + 2 * pr.con_pad; }
+    __device__ __forceinline__ const double* Qd(const Params& pr) const { return pr.lqr + (size_t)g * pr.lqr_stride; }
+    __device__ __forceinline__ const double* xf(const Params& pr) const { return Qd(pr) + pr.p * pr.ni; }
+    __device__ __forceinline__ const double* Rd(const Params& pr) const { return Qd(pr) + 2 * pr.p * pr.ni; }
+    __device__ __forceinline__ const double* uf(const Params& pr) const { return Qd(pr) + 2 * pr.p * pr.ni + pr.p * pr.mi; }
+    __device__ __forceinline__ alg_record* hist(const Params& pr) const { return pr.hist + (size_t)g * pr.hist_max; }
 };
-__device__ __forceinline__ Game game_view(const Params& pr, const Buffers& bf, int g) {
+__device__ __forceinline__ Game game_view(const Params& pr, int g) {
     Game G;
-    for (int t = 0; t < 3; t++) G.z[t] = bf.traj[t] + (size_t)g * pr.traj_len;
-    G.x0 = bf.x0 + (size_t)g * pr.n;
-    const size_t gq = pr.lqr_per_game ? (size_t)g : 0;
-    G.Qd = bf.Qd + gq * pr.p * pr.ni; G.xf = bf.xf + gq * pr.p * pr.ni;
-    G.Rd = bf.Rd + gq * pr.p * pr.mi; G.uf = bf.uf + gq * pr.p * pr.mi;
-    G.lam = bf.lam + (size_t)g * pr.con_len; G.mu = bf.mu + (size_t)g * pr.con_len; G.vals = bf.vals + (size_t)g * pr.con_len;
-    G.res = bf.res + (size_t)g * pr.S; G.rec = bf.rec + (size_t)g * pr.rec_len; G.kgain = bf.kgain + (size_t)g * pr.kscratch_len;
-    G.st = bf.stats + g; G.hist = bf.hist + (size_t)g * pr.hist_max; G.tc = bf.tcache + (size_t)g * 8;
-    G.extc = bf.extc;
+    G.base = pr.arena + (size_t)g * pr.stride; G.g = g;
+    G.zo[0] = 0; G.zo[1] = pr.o_z1; G.zo[2] = pr.o_z2;
     return G;
 }
 
@@ -560,12 +577,15 @@ struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; doub
 // (player ip's opt rows + all dyn rows, newton_core.jl:205-246), player-specific violations (statistics.jl:59-73), the
 // proximal term only on player ip's rows (global_quantities.jl:262-280); out.l1full is the full ||res||_1 for record!.
 template <class C, int MODE, bool IBR = false>
-__device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, const double* __restrict__ z,
-                              const double* __restrict__ zref, double reg, double jreg, ResOut& out, int ip = -1) {
+__device__ void assemble_pass(const Params& pr, const Game& G0, AsmLds<C>& L, int zsel, int zrefsel, double reg, double jreg,
+                              ResOut& out, int ip = -1) {
+    const Game G = G0.fresh();
+    const double* __restrict__ z = G.z(zsel);
+    const double* __restrict__ zref = zrefsel >= 0 ? G.z(zrefsel) : nullptr;
     constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b;
     using R = Rec<C>;
-    const int N = pr.N, lane = phase_lane();
-    const double dt = pr.dt;
+    const int N = phase_int(pr.N), lane = phase_lane();
+    const double dt = phase_f64(pr.dt);
     double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
     // ---------------- phase A ------------------------------------------------------------------------------
@@ -578,7 +598,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
           constexpr int SGV = STAGED ? SGVT : 0;
           if (lane < SPP * P && k < N - 1) {
             // staged: record head (offsets as in the record) + table at HEAD of this step's LDS slot; else the record itself
-            double* __restrict__ rec = STAGED ? L.stage + ks * SL : G.rec + (size_t)k * R::LEN;
+            double* __restrict__ rec = STAGED ? L.stage + ks * SL : G.rec(pr) + (size_t)k * R::LEN;
             if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
                 const double* sk = zstate<C>(z, k);
                 double cf[10];
@@ -637,7 +657,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                             if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c += dl[2] * dl[2]; }   // spherical: pz[i][1:3]
                             const double c = Rr * Rr - s2c;
                             const int ci = con_col<C>(N, pairq<C>(i, j), kn);
-                            const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
+                            const double lm = G.lam(pr)[ci], am = al_active_mu(c, lm, G.mu(pr)[ci]);
                             const double wl = lm + am * c;
 #pragma unroll
                             for (int a = 0; a < PD; a++) {
@@ -645,7 +665,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
 #pragma unroll
                                 for (int a2 = 0; a2 <= a; a2++) H[C::sym(a, a2)] += am * 4.0 * dl[a2] * dl[a];
                             }
-                            if (MODE == 2) G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
+                            if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                         }
                     }
 #pragma unroll
@@ -662,7 +682,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                     // wall / circle constraints of player i on its own position at knot k+1: AL gradient C'(lambda + a mu c)
                     // and Gauss-Newton Hessian C' a mu C (constraint_derivatives.jl:10-19,47-58) join the (i,i) position block
                     auto al_row = [&](int ci, double c, const double (&g)[PD]) {
-                        const double lm = G.lam[ci], am = al_active_mu(c, lm, G.mu[ci]);
+                        const double lm = G.lam(pr)[ci], am = al_active_mu(c, lm, G.mu(pr)[ci]);
                         const double wl = lm + am * c;
 #pragma unroll
                         for (int a = 0; a < PD; a++) {
@@ -670,13 +690,13 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
 #pragma unroll
                             for (int a2 = 0; a2 <= a; a2++) dd[C::sym(a, a2)] += am * g[a2] * g[a];
                         }
-                        if (MODE == 2) G.vals[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
+                        if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                     };
-                    const double* Wc = ext_walls(pr, G.extc); const double* Cc = ext_circs(pr, G.extc);
+                    const double* Wc = ext_walls(pr, pr.extc); const double* Cc = ext_circs(pr, pr.extc);
                     for (int wq = 0; wq < pr.nwall; wq++) { double g[PD] = {}; const double c = wall_val(Wc, wq, xi[0], xi[1], &g[0], &g[1]); al_row(ext_wall_row(pr, i, k, wq), c, g); }
                     for (int cq = 0; cq < pr.ncirc; cq++) { double g[PD] = {}; const double c = circ_val(Cc, cq, xi[0], xi[1], &g[0], &g[1]); al_row(ext_circ_row(pr, i, k, cq), c, g); }
                     if constexpr (PD == 3) {
-                        const double* W3 = ext_walls3(pr, G.extc); const double* Yc = ext_cyls(pr, G.extc);
+                        const double* W3 = ext_walls3(pr, pr.extc); const double* Yc = ext_cyls(pr, pr.extc);
                         for (int wq = 0; wq < pr.nwall3; wq++) { double g[3]; const double c = wall3_val(W3, wq, xi, g); al_row(ext_wall3_row(pr, i, k, wq), c, g); }
                         for (int cq = 0; cq < pr.ncyl; cq++) { double g[3]; const double c = cyl_val(Yc, cq, xi, g); al_row(ext_cyl_row(pr, i, k, cq), c, g); }
                     }
@@ -696,8 +716,8 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
               for (int t = lane; t < nst * SL; t += WAVE) {
                   const int ks2 = t / SL, o = t % SL;
                   const size_t base = (size_t)(kA + ks2) * R::LEN;
-                  if (o >= HEAD) G.rec[base + R::GVT + (o - HEAD)] = L.stage[t];
-                  else if (RECS || o < C::NC) G.rec[base + o] = L.stage[t];
+                  if (o >= HEAD) G.rec(pr)[base + R::GVT + (o - HEAD)] = L.stage[t];
+                  else if (RECS || o < C::NC) G.rec(pr)[base + o] = L.stage[t];
               }
               __syncthreads();
           }
@@ -729,10 +749,10 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             l1 += fabs(r);
             if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
         }
-        if (RECS) G.rec[q.rec_off] = r;
-        if (MODE == 2) G.res[q.vrow] = r;
+        if (RECS) G.rec(pr)[q.rec_off] = r;
+        if (MODE == 2) G.res(pr)[q.vrow] = r;
     };
-    const double* __restrict__ recg = G.rec;
+    const double* __restrict__ recg = G.rec(pr);
     // advance (k, j) by 64 rows of a row space with LEN rows per step
     constexpr int UR = C::ASM_UNROLL;
     auto run_rows = [&](auto&& row, int LEN, bool dynrow) {
@@ -769,7 +789,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
                 r += has_next ? t : 0.0;
             }
             const bool own = (a % P == i);
-            const double tqv = G.Qd[i * ni + a / P], txv = G.xf[i * ni + a / P];
+            const double tqv = G.Qd(pr)[i * ni + a / P], txv = G.xf(pr)[i * ni + a / P];
             const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
             const double xa = z[zo + (uidx)a];
             r += w * (tq * (xa - tx));
@@ -781,17 +801,17 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
 #pragma unroll
                     for (int half = 0; half < 2; half++) {
                         const int ci = ext_sb_row(pr, i, k, half * n + a);
-                        const double cv = half == 0 ? xa - ext_sbmax(pr, G.extc)[ei] : ext_sbmin(pr, G.extc)[ei] - xa;
-                        if (MODE == 2) G.vals[ci] = cv;
+                        const double cv = half == 0 ? xa - ext_sbmax(pr, pr.extc)[ei] : ext_sbmin(pr, pr.extc)[ei] - xa;
+                        if (MODE == 2) G.vals(pr)[ci] = cv;
                         if (isfinite(cv)) {
-                            const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
+                            const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
                             const double wl = lm + am * cv;
                             r += (half == 0 ? wl : -wl); qsb += am;
                             if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, cv));
                         }
                     }
                 }
-                if (RECS && ok) G.rec[ro + (uidx)(R::RQ + ei)] = qsb;
+                if (RECS && ok) G.rec(pr)[ro + (uidx)(R::RQ + ei)] = qsb;
             }
             q.mine = IBR ? (i == ip) : true;
             q.dprox = 0.0;
@@ -810,16 +830,16 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             const uidx zo = (uidx)(n + k * b), ro = (uidx)(k * R::LEN);
             const double u = z[zo + (uidx)(n + uoff<C>(c))];
             const uidx lo = zo + (uidx)(n + m + i * n);
-            const double tr = G.Rd[(c % P) * mi + c / P], tu = G.uf[(c % P) * mi + c / P];
+            const double tr = G.Rd(pr)[(c % P) * mi + c / P], tu = G.uf(pr)[(c % P) * mi + c / P];
             double g = 0.0, rhat = dt * tr + jreg;
             if (pr.has_ctl && ok) {
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     const int ci = con_ctl<C>(pr, k, half * m + c);
                     const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
-                    if (MODE == 2) G.vals[ci] = cv;
+                    if (MODE == 2) G.vals(pr)[ci] = cv;
                     if (isfinite(cv)) {
-                        const double lm = G.lam[ci], am = al_active_mu(cv, lm, G.mu[ci]);
+                        const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
                         const double wl = lm + am * cv;
                         g += (half == 0 ? wl : -wl); rhat += am;
                         if (!IBR) vcon = fmax(vcon, fmax(0.0, cv));
@@ -831,7 +851,7 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
             q.mine = IBR ? (i == ip) : true;
             q.dprox = 0.0;
             if (zref) { const double ur = zref[zo + (uidx)(n + uoff<C>(c))]; q.dprox = q.mine ? u - ur : 0.0; }
-            if (RECS && ok) G.rec[ro + (uidx)(R::RHAT + c)] = rhat;
+            if (RECS && ok) G.rec(pr)[ro + (uidx)(R::RHAT + c)] = rhat;
             q.rec_off = ro + (uidx)(R::RU + c); q.vrow = MODE == 2 ? vu<C>(N, i, k) + c / P : 0;
             return q;
         };
@@ -882,11 +902,13 @@ __device__ void assemble_pass(const Params& pr, const Game& G, AsmLds<C>& L, con
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
 typedef double double2_t __attribute__((ext_vector_type(2)));
 template <class C>
-__device__ __forceinline__ void update_traj(const Params& pr, double* tgt, const double* src, double alpha, const double* dz) {
+__device__ __forceinline__ void update_traj(const Params& pr, const Game& G0, int tsel, int ssel, double alpha) {
+    const Game G = G0.fresh();
+    double* tgt = G.z(tsel); const double* src = G.z(ssel); const double* dz = G.z(2);
     // pure streaming pass: 16 bytes per lane and four independent load pairs in flight per pass.  Every game's buffers start
     // 16-byte aligned when traj_len is even (n is always even); otherwise the scalar loop runs.
     constexpr int U = 4;
-    const int S = pr.S, lane = phase_lane();
+    const int S = phase_int(pr.S), lane = phase_lane();
     if ((pr.traj_len & 1) == 0) {
         const int S2 = S >> 1;                           // pairs; a last odd element is handled below
         const double2_t* __restrict__ s2 = reinterpret_cast<const double2_t*>(src + C::n);
@@ -1276,24 +1298,24 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
 }
 
 // Scratch instrumentation (-DALG_PHASE_PROF, scratch/phase_prof.sh): shader-clock cycles per phase of the sweeps, accumulated
-// into G.res[0..] (unused by the fused solver).  Never defined in the product build.
+// into G.res(pr)[0..] (unused by the fused solver).  Never defined in the product build.
 #ifdef ALG_PHASE_PROF
 #define ALG_PROF_DECL unsigned long long prof_t_ = __builtin_readcyclecounter(), prof_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define ALG_PROF(j) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc_[j] += t_ - prof_t_; prof_t_ = t_; }
-#define ALG_PROF_FLUSH if (threadIdx.x == 0) { for (int j_ = 0; j_ < 12; j_++) G.res[j_] += (double)prof_acc_[j_]; }
+#define ALG_PROF_FLUSH if (threadIdx.x == 0) { for (int j_ = 0; j_ < 12; j_++) G.res(pr)[j_] += (double)prof_acc_[j_]; }
 #else
 #define ALG_PROF_DECL
 #define ALG_PROF(j)
 #define ALG_PROF_FLUSH
 #endif
 template <class C, bool IBR = false>
-__device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
+__device__ int newton_direction(const Params& pr, const Game& G0, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
+    Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
     using R = Rec<C>;
-    const int N = pr.N, lane = phase_lane();
+    const int N = phase_int(pr.N), lane = phase_lane();
     const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
-    const double dt = pr.dt;
-    double* __restrict__ dz = G.z[2];
+    const double dt = phase_f64(pr.dt);
     constexpr int RPL = (R::LEN_SWEEP + WAVE - 1) / WAVE;      // record doubles per lane
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
     constexpr bool AUGS = DirLds<C>::AUGS;               // s_i rides through the first MFMA product (n < 16)
@@ -1303,7 +1325,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     struct NoGather { __device__ void init(int, int) {} };
     typename std::conditional<(C::P == 3 && C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR), P3Gather<C>, NoGather>::type p3g;
     p3g.init(lq, lrow);
-    for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd[i * C::ni + r / P] : 0.0; }
+    for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd(pr)[i * C::ni + r / P] : 0.0; }
     for (int e = lane; e < 16 * 16; e += WAVE) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
     for (int e = lane; e < P * n * LDP; e += WAVE) L.bw.Pm[e] = 0.0;
     for (int e = lane; e < m * VW; e += WAVE) L.bw.V[e] = 0.0;
@@ -1314,7 +1336,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         L.bw.T[e] = v;
     }
     if (lane == 0) L.bw.pad[0] = 0.0;
-    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
     // ---- loop-invariant lane roles of the MFMA tiles: register r4 holds (row = lq + 4 r4, col = lrow)
     const bool colP = lrow < n;
     bool rowok[4];
@@ -1440,7 +1462,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         double pre[RPL];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
         // ---- V[c][0..n) = B[:,c]' P_{i(c)},  V[c][n+1+c] = R^_c,  y_i = P_i rd + s_i   (lane = 16 c + col: shifts, no divisions)
 #pragma unroll
@@ -1532,7 +1554,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         // meet stores that were just issued; measured neutral, the phase profile shows no exposed wait either way)
         asm volatile("" ::: "memory");
         if (lane >= m && lane <= m + n) {
-            double* __restrict__ Kg = G.kgain + (size_t)k * NK + (lane - m) * m;
+            double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (lane - m) * m;
 #pragma unroll
             for (int c = 0; c < m; c++) Kg[c] = col[c];
         }
@@ -1544,13 +1566,15 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     return ALG_STATUS_OK;
 #endif
     // ------------------------------------------------------------------ forward sweep: dx, du
+    G = G0.fresh();
+    double* __restrict__ dz = G.z(2);
     if (lane < n) dz[lane] = 0.0;
     // the forward sweep reads only [coef | rd] of a record: one load per lane
     static_assert(C::NC + n <= WAVE, "forward sweep record slice");
     const int fro = lane < C::NC ? R::COEF + lane : R::RD + (lane - C::NC);      // record offset of this lane's slice entry
     const bool frok = lane < C::NC + n;
-    if (frok) L.rec[0][fro] = G.rec[fro];
-    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain[e];
+    if (frok) L.rec[0][fro] = G.rec(pr)[fro];
+    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain(pr)[e];
     // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
     // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
     // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
@@ -1560,9 +1584,9 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     const int froc = frok ? fro : R::RD;                                       // lanes without a slice entry duplicate rd[0]
     auto fwd_load = [&](int kk, double& rf, double (&rk)[KPL]) {
         const int kc = kk < N - 1 ? kk : N - 2;
-        rf = G.rec[(size_t)kc * R::LEN + froc];
+        rf = G.rec(pr)[(size_t)kc * R::LEN + froc];
 #pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = G.kgain[(size_t)kc * NK + (e < NK ? e : NK - 1)]; }
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = G.kgain(pr)[(size_t)kc * NK + (e < NK ? e : NK - 1)]; }
     };
     double pref, prek[KPL];
     fwd_load(1, pref, prek);
@@ -1606,8 +1630,10 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     hxm.init(phase_lane());
+    G = G0.fresh();
+    dz = G.z(2);
     constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
-    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec[(size_t)(N - 2) * R::LEN + e];
+    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
     const bool cpos = C::POS && cr_ < C::PD * P;
     double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
@@ -1617,7 +1643,7 @@ __device__ int newton_direction(const Params& pr, const Game& G, DirLds<C>& L, d
         for (int q = 0; q < RPLC; q++) rr[q] = 0.0;
         if (kk >= 0) {
 #pragma unroll
-            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) rr[q] = G.rec[(size_t)kk * R::LEN + e]; }
+            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) rr[q] = G.rec(pr)[(size_t)kk * R::LEN + e]; }
             if (lane < n) rdx = dz[n + hx<C>(kk) + lane];
         }
     };
@@ -1680,12 +1706,12 @@ __device__ void jacobian_dense(const Params& pr, const Game& G, double reg, doub
     __syncthreads();
     auto at = [&](int r, int c) -> double& { return J[(size_t)c * S + r]; };
     for (int k = 0; k < N - 1; k++) {
-        const double* Rc = G.rec + (size_t)k * R::LEN;
+        const double* Rc = G.rec(pr) + (size_t)k * R::LEN;
         const double* coefk = Rc + R::COEF;
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         for (int e = lane; e < P * n * n; e += WAVE) {
             const int i = e / (n * n), r = (e / n) % n, c = e % n;
-            double qv = qhat_entry<C>(G.Qd, Rc + R::HH, i, r, c, w, reg);
+            double qv = qhat_entry<C>(G.Qd(pr), Rc + R::HH, i, r, c, w, reg);
             if constexpr (C::EXT) { if (r == c) qv += Rc[R::RQ + i * n + r]; }
             at(vx<C>(N, i, k) + r, hx<C>(k) + c) = qv;
         }
@@ -1720,27 +1746,28 @@ __device__ __forceinline__ double uni(double v) {
 }
 
 // record! (statistics.jl:44-57): unregularised residual at pdtraj; also leaves the step records (with the Jacobian
-// regularisation jreg folded into R^) for the Newton direction and refreshes G.vals.  The record is pushed to the
+// regularisation jreg folded into R^) for the Newton direction and refreshes G.vals(pr).  The record is pushed to the
 // game's Statistics history (lane 0); the two scalars the control flow needs are returned.
 struct RecScalars { double res, opt; int nonfinite; };
 // Statistics of an accepted line-search trial = what the next record! would recompute (same point, same arithmetic)
-// (kept in HBM, G.tc, so that it costs no registers across the Newton direction)
-__device__ __forceinline__ void tcache_store(const Game& G, const ResOut& ro) {
-    if (threadIdx.x == 0) { G.tc[0] = ro.l1; G.tc[1] = ro.opt; G.tc[2] = ro.dyn; G.tc[3] = ro.con; G.tc[4] = ro.sta; G.tc[5] = (double)ro.nonfinite; }
+// (kept in HBM, G.tc(pr), so that it costs no registers across the Newton direction)
+__device__ __forceinline__ void tcache_store(const Params& pr, const Game& G, const ResOut& ro) {
+    if (threadIdx.x == 0) { G.tc(pr)[0] = ro.l1; G.tc(pr)[1] = ro.opt; G.tc(pr)[2] = ro.dyn; G.tc(pr)[3] = ro.con; G.tc(pr)[4] = ro.sta; G.tc(pr)[5] = (double)ro.nonfinite; }
 }
-__device__ __forceinline__ void tcache_load(const Game& G, ResOut& ro) {
-    ro.l1 = G.tc[0]; ro.opt = G.tc[1]; ro.dyn = G.tc[2]; ro.con = G.tc[3]; ro.sta = G.tc[4]; ro.nonfinite = (int)G.tc[5]; ro.l1reg = ro.l1;
+__device__ __forceinline__ void tcache_load(const Params& pr, const Game& G, ResOut& ro) {
+    ro.l1 = G.tc(pr)[0]; ro.opt = G.tc(pr)[1]; ro.dyn = G.tc(pr)[2]; ro.con = G.tc(pr)[3]; ro.sta = G.tc(pr)[4]; ro.nonfinite = (int)G.tc(pr)[5]; ro.l1reg = ro.l1;
 }
 
-__device__ __forceinline__ RecScalars push_stats(const Params& pr, const Game& G, const ResOut& ro, double delta, int outer, alg_record* out) {
+__device__ __forceinline__ RecScalars push_stats(const Params& pr, const Game& G0, const ResOut& ro, double delta, int outer, alg_record* out) {
+    const Game G = G0.fresh();
     if (threadIdx.x == 0) {
         alg_record rc;
         rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
         rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
-        const int idx = G.st->records;
-        if (idx < pr.hist_max) G.hist[idx] = rc;
-        G.st->records = idx + 1;
-        G.st->last = rc;
+        const int idx = G.st(pr)->records;
+        if (idx < pr.hist_max) G.hist(pr)[idx] = rc;
+        G.st(pr)->records = idx + 1;
+        G.st(pr)->last = rc;
         if (out) *out = rc;
     }
     RecScalars r; r.res = uni(ro.l1 / (double)pr.S); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
@@ -1749,7 +1776,7 @@ __device__ __forceinline__ RecScalars push_stats(const Params& pr, const Game& G
 template <class C>
 __device__ __forceinline__ RecScalars make_record(const Params& pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
     ResOut ro;
-    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, jreg, ro);
+    assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, jreg, ro);
     __syncthreads();
     return push_stats(pr, G, ro, delta, outer, out);
 }
@@ -1762,15 +1789,15 @@ __device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double r
     const alg_options& o = pr.opt;
     int j = 1; double alpha = 1.0;
     while (j < o.ls_iter) {
-        update_traj<C>(pr, G.z[1], G.z[0], alpha, G.z[2]);
+        update_traj<C>(pr, G, 1, 0, alpha);
         __syncthreads();
         ResOut ro;
         bool done = false;
         if constexpr (C::TRIAL_REUSE) {
-            if (jreg_next >= 0.0 && o.regularize) { assemble_pass<C, 3>(pr, G, L.a, G.z[1], G.z[0], reg, jreg_next, ro); done = true; }
+            if (jreg_next >= 0.0 && o.regularize) { assemble_pass<C, 3>(pr, G, L.a, 1, 0, reg, jreg_next, ro); done = true; }
         }
-        if (!done) assemble_pass<C, 0>(pr, G, L.a, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, ro);
-        if (jreg_next >= 0.0) tcache_store(G, ro);
+        if (!done) assemble_pass<C, 0>(pr, G, L.a, 1, o.regularize ? 0 : -1, reg, 0.0, ro);
+        if (jreg_next >= 0.0) tcache_store(pr, G, ro);
         const double rt = uni(ro.l1reg / (double)pr.S);
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
@@ -1788,7 +1815,7 @@ __device__ int inner_iteration(const Params& pr, Game& G, Lds<C>& L, int& LS_cou
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
     if (info && threadIdx.x == 0) { alg_step_info z{}; *info = z; }
     RecScalars rs;                                                         // :73-76 (regularisation term is zero at pdtraj)
-    if (cache_valid && *cache_valid) { ResOut cro; tcache_load(G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }
+    if (cache_valid && *cache_valid) { ResOut cro; tcache_load(pr, G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }
     else rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr);
     if (cache_valid) *cache_valid = 0;
     Delta = 0.0;                                                           // :79
@@ -1808,16 +1835,16 @@ __device__ int inner_iteration(const Params& pr, Game& G, Lds<C>& L, int& LS_cou
     __syncthreads();
     // :94 update_traj!(pdtraj, pdtraj, alpha, delta): the last trial already holds exactly these values unless the search ran
     // out of trials (alpha was halved once more after the last trial) -> exchange the roles of the two buffers
-    if (!failed) { double* t = G.z[0]; G.z[0] = G.z[1]; G.z[1] = t; }
-    else update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);
+    if (!failed) { const int t = G.zo[0]; G.zo[0] = G.zo[1]; G.zo[1] = t; }
+    else update_traj<C>(pr, G, 0, 0, alpha);
     { double sd = pl1; sd *= alpha; sd /= (double)((pr.N - 1) * (C::n + C::m)); Delta = uni(sd); }     // :95 Delta_step
     __syncthreads();
     if (reuse && !failed) *cache_valid = 1;
     if (threadIdx.x == 0) {
-        G.st->newton_iters += 1; if (failed) G.st->ls_failures += 1;
-        const int idx = G.st->records - 1;
-        if (idx < pr.hist_max) { G.hist[idx].alpha = alpha; G.hist[idx].ls_j = j; }
-        G.st->last.alpha = alpha; G.st->last.ls_j = j;
+        G.st(pr)->newton_iters += 1; if (failed) G.st(pr)->ls_failures += 1;
+        const int idx = G.st(pr)->records - 1;
+        if (idx < pr.hist_max) { G.hist(pr)[idx].alpha = alpha; G.hist(pr)[idx].ls_j = j; }
+        G.st(pr)->last.alpha = alpha; G.st(pr)->last.ls_j = j;
         if (info) { info->alpha = alpha; info->ls_j = j; info->ls_failed = failed; info->delta = Delta; info->rec.alpha = alpha; info->rec.ls_j = j; }
     }
     return finish(ALG_STATUS_OK, Delta < o.delta_min ? 1 : 0);             // :96-98
@@ -1825,13 +1852,13 @@ __device__ int inner_iteration(const Params& pr, Game& G, Lds<C>& L, int& LS_cou
 
 // reset!(game_con) (constraints_methods.jl:295-327)
 __device__ __forceinline__ void reset_con(const Params& pr, const Game& G) {
-    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) { G.lam[e] = 0.0; G.mu[e] = pr.opt.rho_0; }
+    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) { G.lam(pr)[e] = 0.0; G.mu(pr)[e] = pr.opt.rho_0; }
 }
 // evaluate! + dual_update! + penalty_update! (solver_methods.jl:57-61; constraints_methods.jl:329-379,421-440)
 template <class C>
 __device__ void dual_penalty_update(const Params& pr, const Game& G) {
     constexpr int n = C::n, m = C::m, P = C::P;
-    const int N = pr.N; const alg_options& o = pr.opt; const double* z = G.z[0];
+    const int N = pr.N; const alg_options& o = pr.opt; const double* z = G.z(0);
     if (pr.has_colavoid) {
         for (int e = threadIdx.x; e < pr.col_len; e += WAVE) {
             constexpr int PM1 = P > 1 ? P - 1 : 1;
@@ -1841,9 +1868,9 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
             double s2 = d0 * d0 + d1 * d1;
             if constexpr (C::PD == 3) { const double d2 = pr.ca_dim == 3 ? x[2 * P + i] - x[2 * P + j] : 0.0; s2 += d2 * d2; }
             const double c = R * R - s2;
-            G.vals[e] = c;
-            const double lb = G.lam[e] + o.alphax_dual[i] * G.mu[e] * c;
-            G.lam[e] = fmin(fmax(lb, 0.0), o.lambda_max);
+            G.vals(pr)[e] = c;
+            const double lb = G.lam(pr)[e] + o.alphax_dual[i] * G.mu(pr)[e] * c;
+            G.lam(pr)[e] = fmin(fmax(lb, 0.0), o.lambda_max);
         }
     }
     if (pr.has_ctl) {
@@ -1852,8 +1879,8 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
             const double u = z[n + hu<C>(k, 0) + uoff<C>(c)];
             const double cv = row < m ? u - pr.umax[c] : pr.umin[c] - u;
             const int ci = pr.col_len + e;
-            G.vals[ci] = cv;
-            if (isfinite(cv)) { const double lb = G.lam[ci] + o.alpha_dual * G.mu[ci] * cv; G.lam[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
+            G.vals(pr)[ci] = cv;
+            if (isfinite(cv)) { const double lb = G.lam(pr)[ci] + o.alpha_dual * G.mu(pr)[ci] * cv; G.lam(pr)[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
         }
     }
     if constexpr (C::EXT) {
@@ -1864,15 +1891,15 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
             if (e < pr.sb_len) {
                 const int row = e % (2 * n); k = (e / (2 * n)) % K; i = e / (2 * n * K);
                 const double* x = zstate<C>(z, k + 1);
-                c = row < n ? x[row] - ext_sbmax(pr, G.extc)[i * n + row] : ext_sbmin(pr, G.extc)[i * n + row - n] - x[row - n];
+                c = row < n ? x[row] - ext_sbmax(pr, pr.extc)[i * n + row] : ext_sbmin(pr, pr.extc)[i * n + row - n] - x[row - n];
             } else if (e < pr.sb_len + pr.wall_len) {
                 const int e2 = e - pr.sb_len, w = e2 % pr.nwall; k = (e2 / pr.nwall) % K; i = e2 / (pr.nwall * K);
                 const double* x = zstate<C>(z, k + 1); double gx, gy;
-                c = wall_val(ext_walls(pr, G.extc), w, x[i], x[P + i], &gx, &gy);
+                c = wall_val(ext_walls(pr, pr.extc), w, x[i], x[P + i], &gx, &gy);
             } else if (e < pr.sb_len + pr.wall_len + pr.circ_len) {
                 const int e2 = e - pr.sb_len - pr.wall_len, cq = e2 % pr.ncirc; k = (e2 / pr.ncirc) % K; i = e2 / (pr.ncirc * K);
                 const double* x = zstate<C>(z, k + 1); double gx, gy;
-                c = circ_val(ext_circs(pr, G.extc), cq, x[i], x[P + i], &gx, &gy);
+                c = circ_val(ext_circs(pr, pr.extc), cq, x[i], x[P + i], &gx, &gy);
             } else {
                 i = 0; k = 0; c = 0.0;
                 if constexpr (C::PD == 3) {
@@ -1882,15 +1909,15 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
                     const int cnt = w3 ? pr.nwall3 : pr.ncyl, q = e2 % cnt; k = (e2 / cnt) % K; i = e2 / (cnt * K);
                     const double* x = zstate<C>(z, k + 1);
                     const double pos[3] = {x[i], x[P + i], x[2 * P + i]}; double g[3];
-                    c = w3 ? wall3_val(ext_walls3(pr, G.extc), q, pos, g) : cyl_val(ext_cyls(pr, G.extc), q, pos, g);
+                    c = w3 ? wall3_val(ext_walls3(pr, pr.extc), q, pos, g) : cyl_val(ext_cyls(pr, pr.extc), q, pos, g);
                 }
             }
             const int ci = e0 + e;
-            G.vals[ci] = c;
-            if (isfinite(c)) { const double lb = G.lam[ci] + o.alphax_dual[i] * G.mu[ci] * c; G.lam[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
+            G.vals(pr)[ci] = c;
+            if (isfinite(c)) { const double lb = G.lam(pr)[ci] + o.alphax_dual[i] * G.mu(pr)[ci] * c; G.lam(pr)[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
         }
     }
-    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) G.mu[e] = fmin(fmax(G.mu[e] * o.rho_increase, 0.0), o.rho_max);
+    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) G.mu(pr)[e] = fmin(fmax(G.mu(pr)[e] * o.rho_increase, 0.0), o.rho_max);
 }
 
 // rollout!(RK3, model, traj) (solver_methods.jl:17): lanes < P integrate their own player (players are decoupled)
@@ -1919,7 +1946,7 @@ __device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t g
     if (use_shift && s < N) {
         // in-place shift: element e of step k takes element e of step k+s; ascending k is safe within one wave only
         // with a barrier per step, so stage through the trial buffer
-        double* tmp = G.z[1];
+        double* tmp = G.z(1);
         for (int e = lane; e < pr.traj_len; e += WAVE) tmp[e] = z[e];
         __syncthreads();
         z = z; // (same buffer)
@@ -1949,19 +1976,19 @@ __device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t g
             z[n + e] = o.amplitude_init * counter_uniform(o.seed, game_id, ctr);
         }
     }
-    if (lane < n) z[lane] = G.x0[lane];
+    if (lane < n) z[lane] = G.x0(pr)[lane];
     __syncthreads();
 }
 
 // After an odd number of buffer exchanges pdtraj lives in the trial buffer: move it home (and leave the trial buffer with
 // the previous iterate, as update_traj! would have)
 template <class C>
-__device__ __forceinline__ void settle_traj(const Params& pr, Game& G, double* z_home) {
-    if (G.z[0] != z_home) {
+__device__ __forceinline__ void settle_traj(const Params& pr, Game& G) {
+    if (G.zo[0] != 0) {
         __syncthreads();
-        double* a = G.z[0];
+        double* a = G.z(0); double* z_home = G.base;
         for (int e = phase_lane(); e < pr.traj_len; e += WAVE) { const double v = a[e]; a[e] = z_home[e]; z_home[e] = v; }
-        G.z[1] = a; G.z[0] = z_home;
+        G.zo[1] = G.zo[0]; G.zo[0] = 0;
         __syncthreads();
     }
 }
@@ -1969,15 +1996,14 @@ __device__ __forceinline__ void settle_traj(const Params& pr, Game& G, double* z
 // newton_solve! (solver_methods.jl:5-65)
 template <class C>
 __device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
-    double* const z_home = G.z[0];
     const alg_options& o = pr.opt; const int lane = threadIdx.x;
-    if (lane == 0) { alg_game_stats z{}; *G.st = z; }                       // reset!(prob.stats)
+    if (lane == 0) { alg_game_stats z{}; *G.st(pr) = z; }                       // reset!(prob.stats)
 #ifndef ALG_TEST_NOINIT
-    if (init) init_traj<C>(pr, G, G.z[0], game_id, true, shift);           // :13
-    else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
-    if (lane < C::n) { G.z[1][lane] = G.x0[lane]; G.z[2][lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
+    if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
+    else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
+    if (lane < C::n) { G.z(1)[lane] = G.x0(pr)[lane]; G.z(2)[lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
     __syncthreads();
-    rollout<C>(pr, G.z[0]);                                                // :17
+    rollout<C>(pr, G.z(0));                                                // :17
 #endif
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con(pr, G);     // :25
     __syncthreads();
@@ -1994,7 +2020,7 @@ __device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& 
         if (status != ALG_STATUS_OK) break;
         __syncthreads();
         // prob.stats.*_vio[end]: the record made at the top of the last inner iteration (lane 0 wrote it; same wave)
-        const alg_record& last = G.st->last;
+        const alg_record& last = G.st(pr)->last;
         const bool conv = last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
         const int convu = __builtin_amdgcn_readfirstlane((int)conv);
         if (convu) converged = 1;
@@ -2004,15 +2030,15 @@ __device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& 
     }
     __syncthreads();
     make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);                    // :63
-    settle_traj<C>(pr, G, z_home);
-    if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; }
+    settle_traj<C>(pr, G);
+    if (lane == 0) { G.st(pr)->status = status; G.st(pr)->outer_iters = out; G.st(pr)->converged = converged; }
 }
 
 // ================================================================================================
 // Iterated best response (solver_methods.jl:133-289)
 // ================================================================================================
 // record!(stats, ..., k, i) (statistics.jl:59-73): full residual norm + player-specific violations; also tracks
-// maximum(stats.Δ_traj) (G.tc[6]) for the exit test of ibr_newton_solve! (:157).  Returns the masked norm / opt violation.
+// maximum(stats.Δ_traj) (G.tc(pr)[6]) for the exit test of ibr_newton_solve! (:157).  Returns the masked norm / opt violation.
 template <class C>
 __device__ __forceinline__ RecScalars ibr_push_stats(const Params& pr, const Game& G, const ResOut& ro, double delta, int outer) {
     const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));            // length(verti_mask)
@@ -2020,11 +2046,11 @@ __device__ __forceinline__ RecScalars ibr_push_stats(const Params& pr, const Gam
         alg_record rc;
         rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1full / (double)pr.S; rc.delta = delta;
         rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
-        const int idx = G.st->records;
-        if (idx < pr.hist_max) G.hist[idx] = rc;
-        G.st->records = idx + 1;
-        G.st->last = rc;
-        G.tc[6] = fmax(G.tc[6], delta);
+        const int idx = G.st(pr)->records;
+        if (idx < pr.hist_max) G.hist(pr)[idx] = rc;
+        G.st(pr)->records = idx + 1;
+        G.st(pr)->last = rc;
+        G.tc(pr)[6] = fmax(G.tc(pr)[6], delta);
     }
     RecScalars r; r.res = uni(ro.l1 / sm); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
     return r;
@@ -2037,7 +2063,7 @@ __device__ int ibr_inner_iteration(const Params& pr, const Game& G, Lds<C>& L, i
     const double reg = o.reg_0 * (lf * lf * lf * lf);
     const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));
     ResOut ro;
-    assemble_pass<C, 1, true>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro, ip);        // :236-241
+    assemble_pass<C, 1, true>(pr, G, L.a, 0, -1, 0.0, reg, ro, ip);        // :236-241
     __syncthreads();
     const RecScalars rs = ibr_push_stats<C>(pr, G, ro, Delta, k);
     Delta = 0.0;
@@ -2048,24 +2074,24 @@ __device__ int ibr_inner_iteration(const Params& pr, const Game& G, Lds<C>& L, i
     __syncthreads();
     int j = 1; double alpha = 1.0;                                                  // ibr_line_search (:270-289)
     while (j < o.ls_iter) {
-        update_traj<C>(pr, G.z[1], G.z[0], alpha, G.z[2]);
+        update_traj<C>(pr, G, 1, 0, alpha);
         __syncthreads();
         ResOut rt;
-        assemble_pass<C, 0, true>(pr, G, L.a, G.z[1], o.regularize ? G.z[0] : nullptr, reg, 0.0, rt, ip);
+        assemble_pass<C, 0, true>(pr, G, L.a, 1, o.regularize ? 0 : -1, reg, 0.0, rt, ip);
         if (uni(rt.l1 / sm) <= (1.0 - alpha * o.beta) * rs.res) break;
         alpha *= o.alpha_decrease; j += 1;
     }
     const int failed = (j == o.ls_iter);
     if (failed) LS_count += 1; else LS_count = 0;
     __syncthreads();
-    update_traj<C>(pr, G.z[0], G.z[0], alpha, G.z[2]);                              // :258
-    Delta = uni(delta_step<C>(pr, G.z[2], alpha));                                  // :259
+    update_traj<C>(pr, G, 0, 0, alpha);                              // :258
+    Delta = uni(delta_step<C>(pr, G.z(2), alpha));                                  // :259
     __syncthreads();
     if (threadIdx.x == 0) {
-        G.st->newton_iters += 1; if (failed) G.st->ls_failures += 1;
-        const int idx = G.st->records - 1;
-        if (idx < pr.hist_max) { G.hist[idx].alpha = alpha; G.hist[idx].ls_j = j; }
-        G.st->last.alpha = alpha; G.st->last.ls_j = j;
+        G.st(pr)->newton_iters += 1; if (failed) G.st(pr)->ls_failures += 1;
+        const int idx = G.st(pr)->records - 1;
+        if (idx < pr.hist_max) { G.hist(pr)[idx].alpha = alpha; G.hist(pr)[idx].ls_j = j; }
+        G.st(pr)->last.alpha = alpha; G.st(pr)->last.ls_j = j;
     }
     return ALG_STATUS_OK | ((Delta < o.delta_min ? 1 : 0) << 8);
 }
@@ -2077,7 +2103,7 @@ __device__ int ibr_solve_player(const Params& pr, const Game& G, Lds<C>& L, int 
         reset_con(pr, G);
         for (int e = lane; e < (pr.N - 1) * C::P * C::n; e += WAVE) {              // reset_duals!(pdtraj), reset_duals!(pdtraj_trial)
             const int k = e / (C::P * C::n), a = e % (C::P * C::n);
-            G.z[0][C::n + hl<C>(k, 0) + a] *= 0.0; G.z[1][C::n + hl<C>(k, 0) + a] *= 0.0;
+            G.z(0)[C::n + hl<C>(k, 0) + a] *= 0.0; G.z(1)[C::n + hl<C>(k, 0) + a] *= 0.0;
         }
     }
     __syncthreads();
@@ -2091,7 +2117,7 @@ __device__ int ibr_solve_player(const Params& pr, const Game& G, Lds<C>& L, int 
         }
         if (status != ALG_STATUS_OK) break;
         __syncthreads();
-        const alg_record& last = G.st->last;
+        const alg_record& last = G.st(pr)->last;
         const bool conv = last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
         const int convu = __builtin_amdgcn_readfirstlane((int)conv);
         converged = convu;
@@ -2101,10 +2127,10 @@ __device__ int ibr_solve_player(const Params& pr, const Game& G, Lds<C>& L, int 
     }
     __syncthreads();
     ResOut ro;
-    assemble_pass<C, 1, true>(pr, G, L.a, G.z[0], nullptr, 0.0, 0.0, ro, ip);          // :226
+    assemble_pass<C, 1, true>(pr, G, L.a, 0, -1, 0.0, 0.0, ro, ip);          // :226
     __syncthreads();
     ibr_push_stats<C>(pr, G, ro, Delta, out);
-    if (lane == 0) { G.st->status = status; G.st->outer_iters = out; G.st->converged = converged; }
+    if (lane == 0) { G.st(pr)->status = status; G.st(pr)->outer_iters = out; G.st(pr)->converged = converged; }
     __syncthreads();
     return status;
 }
@@ -2116,13 +2142,13 @@ __device__ void ibr_newton_solve(const Params& pr, const Game& G, Lds<C>& L, boo
                                  int ibr_iter, const IbrOrder& order, double delta_min) {
     const int lane = threadIdx.x;
     if (!single) {
-        if (lane == 0) { alg_game_stats z{}; *G.st = z; G.tc[6] = 0.0; }             // reset!(prob.stats)
-        if (init) init_traj<C>(pr, G, G.z[0], game_id, true);
-        else { if (lane < C::n) G.z[0][lane] = G.x0[lane]; }
+        if (lane == 0) { alg_game_stats z{}; *G.st(pr) = z; G.tc(pr)[6] = 0.0; }             // reset!(prob.stats)
+        if (init) init_traj<C>(pr, G, G.z(0), game_id, true);
+        else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
         __syncthreads();
-        for (int e = lane; e < pr.traj_len; e += WAVE) { G.z[1][e] = G.z[0][e]; G.z[2][e] = 0.0; }   // :142-143 (the trial's duals are reset below)
+        for (int e = lane; e < pr.traj_len; e += WAVE) { G.z(1)[e] = G.z(0)[e]; G.z(2)[e] = 0.0; }   // :142-143 (the trial's duals are reset below)
         __syncthreads();
-        rollout<C>(pr, G.z[0]);
+        rollout<C>(pr, G.z(0));
         __syncthreads();
     }
     unsigned change = (1u << C::P) - 1u;                                             // Δ_change = trues(p)
@@ -2132,7 +2158,7 @@ __device__ void ibr_newton_solve(const Params& pr, const Game& G, Lds<C>& L, boo
             const int ip = single ? player : order.v[id];
             const int status = ibr_solve_player<C>(pr, G, L, ip);
             if (single) return;
-            const double mx = uni(G.tc[6]);
+            const double mx = uni(G.tc(pr)[6]);
             if (!(delta_min > mx)) change |= (1u << ip); else change &= ~(1u << ip);  // :157
             if (status != ALG_STATUS_OK) return;
         }

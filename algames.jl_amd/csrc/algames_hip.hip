@@ -11,8 +11,8 @@
 // the EXT instantiations are defined in algames_ext_*.hip
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
 
-__global__ void __launch_bounds__(WAVE) k_reset_con(Params pr, Buffers bf) {
-    Game G = game_view(pr, bf, blockIdx.x);
+__global__ void __launch_bounds__(WAVE) k_reset_con(Params pr) {
+    Game G = game_view(pr, blockIdx.x);
     reset_con(pr, G);
 }
 
@@ -77,9 +77,22 @@ bool cfg_supported(const Params& p, int ext) {
     return false;
 }
 
+int pad16(int x) { return (x + 15) & ~15; }        // per-game segments start on 128-byte lines
+
+// Per-game layout of the main arena (Params::o_*, doubles).  Everything a solver wavefront touches for its game sits in one
+// contiguous chunk: [pdtraj | trial | delta | x0 | res | step records | gains | trial cache | stats | mpc totals].
+void layout_arena(Params& p) {
+    int o = 0;
+    auto seg = [&](int len) { const int at = o; o += pad16(std::max(len, 1)); return at; };
+    seg(p.traj_len); p.o_z1 = seg(p.traj_len); p.o_z2 = seg(p.traj_len);
+    p.o_x0 = seg(p.n); p.o_res = seg(p.S); p.o_rec = seg(p.rec_len); p.o_kgain = seg(p.kscratch_len);
+    p.o_tc = seg(8); p.o_st = seg((int)((sizeof(alg_game_stats) + 7) / 8)); p.o_mpc = seg(2);
+    p.stride = o;
+}
+int lqr_block(const Params& p) { return 2 * p.p * p.ni + 2 * p.p * p.mi; }
+
 struct Handle {
     Params pr;
-    Buffers bf;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool x0_set = false, lqr_set = false;
@@ -91,8 +104,11 @@ struct Handle {
     int* d_itmp = nullptr;        // B ints
     alg_step_info* d_info = nullptr;
     alg_record* d_rec = nullptr;
-    double* d_lqr[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<double> extc;     // host copy of bf.extc
+    double* d_lqr = nullptr;      // B x lqr_block (sized for the per-game case)
+    double* d_extc = nullptr;
+    std::vector<double> extc;     // host copy of pr.extc
+    void* d_scratch = nullptr;    // grow-only scratch of the inspection entry points (dense Jacobians, MPC state logs)
+    size_t scratch_bytes = 0;
 };
 
 constexpr size_t GUARD = 4096;     // guard zone behind every device buffer (checked by alg_debug_check_guards)
@@ -167,38 +183,6 @@ int launch_check(const char* what) {
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 3, 2, 1, kernel, __VA_ARGS__)                    \
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 4, 2, 1, kernel, __VA_ARGS__)
 
-int alloc_all(Handle* hd) {
-    int rc;
-    const Params& p = hd->pr; const size_t B = p.B;
-    for (int t = 0; t < 3; t++) if ((rc = dalloc(hd, &hd->bf.traj[t], B * p.traj_len, "bf.traj[t]"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.x0, B * p.n, "bf.x0"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.lam, B * p.con_len, "bf.lam"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.mu, B * p.con_len, "bf.mu"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.vals, B * p.con_len, "bf.vals"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.res, B * p.S, "bf.res"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.kgain, B * p.kscratch_len, "bf.kgain"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.rec, B * p.rec_len, "bf.rec"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.stats, B, "bf.stats"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.hist, B * p.hist_max, "bf.hist"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.mpc, 2 * B, "bf.mpc"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.tcache, 8 * B, "bf.tcache"))) return rc;
-    hd->extc.assign(2 * (size_t)p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES + 12 * ALG_MAX_WALLS + 6 * ALG_MAX_CIRCLES, 0.0);
-    if ((rc = dalloc(hd, &hd->bf.extc, hd->extc.size(), "bf.extc"))) return rc;
-    if ((rc = dalloc(hd, &hd->d_tmp, 2 * B, "d_tmp"))) return rc;
-    if ((rc = dalloc(hd, &hd->d_itmp, B, "d_itmp"))) return rc;
-    if ((rc = dalloc(hd, &hd->d_info, B, "d_info"))) return rc;
-    if ((rc = dalloc(hd, &hd->d_rec, B, "d_rec"))) return rc;
-    // LQR buffers sized for the per-game case
-    if ((rc = dalloc(hd, &hd->d_lqr[0], B * p.p * p.ni, "d_lqr[0]"))) return rc;
-    if ((rc = dalloc(hd, &hd->d_lqr[1], B * p.p * p.mi, "d_lqr[1]"))) return rc;
-    if ((rc = dalloc(hd, &hd->d_lqr[2], B * p.p * p.ni, "d_lqr[2]"))) return rc;
-    if ((rc = dalloc(hd, &hd->d_lqr[3], B * p.p * p.mi, "d_lqr[3]"))) return rc;
-    hd->bf.Qd = hd->d_lqr[0]; hd->bf.Rd = hd->d_lqr[1]; hd->bf.xf = hd->d_lqr[2]; hd->bf.uf = hd->d_lqr[3];
-    return ALG_OK;
-}
-
-int sync(Handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); return ALG_OK; }
-
 void dfree(Handle* h, void* q) {
     for (size_t i = 0; i < h->allocs.size(); i++)
         if (h->allocs[i] == q) {
@@ -208,7 +192,75 @@ void dfree(Handle* h, void* q) {
         }
 }
 
+// strided copies between the dense host layout (B x width) and a per-game segment of an arena (pitch = arena stride)
+int h2d_seg(Handle* h, double* dseg, size_t dpitch_d, const void* src, size_t width_bytes) {
+    if (width_bytes == 0) return ALG_OK;
+    HIPCHK(hipMemcpy2DAsync(dseg, dpitch_d * sizeof(double), src, width_bytes, width_bytes, h->pr.B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ALG_OK;
+}
+int d2h_seg(Handle* h, void* dst, const void* dseg, size_t spitch_d, size_t width_bytes) {
+    if (width_bytes == 0) return ALG_OK;
+    HIPCHK(hipMemcpy2DAsync(dst, width_bytes, dseg, spitch_d * sizeof(double), width_bytes, h->pr.B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ALG_OK;
+}
+double* zseg(Handle* h, int which) { return h->pr.arena + (which == 0 ? 0 : which == 1 ? h->pr.o_z1 : h->pr.o_z2); }
+
+int alloc_con(Handle* hd) {
+    Params& p = hd->pr;
+    p.con_pad = pad16(std::max(p.con_len, 1)); p.con_stride = 3 * p.con_pad;
+    return dalloc(hd, &p.con, (size_t)p.B * p.con_stride, "con arena [lam | mu | vals]");
+}
+// Statistics history: outer_iter * inner_iter + 1 records per newton_solve! (statistics.jl:44-57); the IBR entry points ask for
+// their own bound.  Capped so that the whole buffer stays below 1 GiB; alg_game_stats.records keeps counting beyond the cap
+// (alg_get_history reports the truncation).
+int ensure_hist(Handle* hd, long long need) {
+    Params& p = hd->pr;
+    const long long cap = std::max<long long>(HIST_MAX, (1ll << 30) / (long long)(sizeof(alg_record) * (size_t)p.B));
+    need = std::min(std::max<long long>(need, HIST_MAX), cap);
+    if (p.hist && need <= p.hist_max) return ALG_OK;
+    HIPCHK(hipStreamSynchronize(hd->stream));
+    if (p.hist) dfree(hd, p.hist);
+    p.hist = nullptr; p.hist_max = (int)need;
+    return dalloc(hd, &p.hist, (size_t)p.B * p.hist_max, "Statistics history");
+}
+int ensure_scratch(Handle* hd, size_t bytes) {
+    if (bytes <= hd->scratch_bytes) return ALG_OK;
+    HIPCHK(hipStreamSynchronize(hd->stream));
+    if (hd->d_scratch) dfree(hd, hd->d_scratch);
+    hd->d_scratch = nullptr; hd->scratch_bytes = 0;
+    char* q = nullptr;
+    int rc = dalloc(hd, &q, bytes, "inspection scratch"); if (rc) return rc;
+    hd->d_scratch = q; hd->scratch_bytes = bytes;
+    return ALG_OK;
+}
+
+int alloc_all(Handle* hd) {
+    int rc;
+    Params& p = hd->pr; const size_t B = p.B;
+    layout_arena(p);
+    if ((rc = dalloc(hd, &p.arena, B * p.stride, "main arena"))) return rc;
+    if ((rc = alloc_con(hd))) return rc;
+    p.hist = nullptr;
+    if ((rc = ensure_hist(hd, (long long)p.opt.outer_iter * p.opt.inner_iter + 1))) return rc;
+    hd->extc.assign(2 * (size_t)p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES + 12 * ALG_MAX_WALLS + 6 * ALG_MAX_CIRCLES, 0.0);
+    if ((rc = dalloc(hd, &hd->d_extc, hd->extc.size(), "extended-constraint constants"))) return rc;
+    p.extc = hd->d_extc;
+    if ((rc = dalloc(hd, &hd->d_tmp, 2 * B, "d_tmp"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_itmp, B, "d_itmp"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_info, B, "d_info"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_rec, B, "d_rec"))) return rc;
+    if ((rc = dalloc(hd, &hd->d_lqr, B * lqr_block(p), "LQR blocks"))) return rc;   // sized for the per-game case
+    p.lqr = hd->d_lqr; p.lqr_stride = 0;
+    return ALG_OK;
+}
+
+int sync(Handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); return ALG_OK; }
+
 } // namespace
+
+#define NEED_HANDLE(name) do { if (!h) return fail(ALG_ERR_ARG, name ": null handle"); } while (0)
 
 extern "C" {
 
@@ -247,7 +299,7 @@ int alg_create(const alg_desc* d, alg_handle** out) {
     alg_default_options(&hd->pr.opt);
     if ((rc = alloc_all(hd))) goto bad;
     // mu starts at rho_0 like a freshly built ALConVal after set_constraint_params!/reset
-    hipLaunchKernelGGL(k_reset_con, dim3(hd->pr.B), dim3(WAVE), 0, hd->stream, hd->pr, hd->bf);
+    hipLaunchKernelGGL(k_reset_con, dim3(hd->pr.B), dim3(WAVE), 0, hd->stream, hd->pr);
     if ((rc = sync(hd))) goto bad;
     *out = h;
     return ALG_OK;
@@ -268,50 +320,59 @@ void alg_destroy(alg_handle* h) {
 int alg_set_options(alg_handle* h, const alg_options* o) {
     if (!h || !o) return fail(ALG_ERR_ARG, "alg_set_options: null argument");
     if (o->ls_iter < 1 || o->outer_iter < 1 || o->inner_iter < 1) return fail(ALG_ERR_ARG, "alg_set_options: iteration counts must be >= 1");
+    int rc = use_device(H); if (rc) return rc;
     H->pr.opt = *o;
-    return ALG_OK;
+    return ensure_hist(H, (long long)o->outer_iter * o->inner_iter + 1);     // every record! of a solve is kept
 }
-int alg_get_options(alg_handle* h, alg_options* o) { *o = H->pr.opt; return ALG_OK; }
-int alg_set_stream(alg_handle* h, void* s) { H->stream = s ? (hipStream_t)s : H->own_stream; return ALG_OK; }
+int alg_get_options(alg_handle* h, alg_options* o) {
+    if (!h || !o) return fail(ALG_ERR_ARG, "alg_get_options: null argument");
+    *o = H->pr.opt; return ALG_OK;
+}
+int alg_set_stream(alg_handle* h, void* s) { NEED_HANDLE("alg_set_stream"); H->stream = s ? (hipStream_t)s : H->own_stream; return ALG_OK; }
 
 int alg_set_x0(alg_handle* h, const double* x0) {
     if (!h || !x0) return fail(ALG_ERR_ARG, "alg_set_x0: null argument");
     int rc = use_device(H); if (rc) return rc;
     const Params& p = H->pr;
-    if ((rc = h2d(H, H->bf.x0, x0, sizeof(double) * p.B * p.n))) return rc;
-    // x_1 of every trajectory buffer (set_state!(pdtraj.pr[1], x0))
-    for (int t = 0; t < 2; t++)
-        HIPCHK(hipMemcpy2DAsync(H->bf.traj[t], sizeof(double) * p.traj_len, H->bf.x0, sizeof(double) * p.n, sizeof(double) * p.n, p.B, hipMemcpyDeviceToDevice, H->stream));
+    // x0 and x_1 of pdtraj / trial (set_state!(pdtraj.pr[1], x0))
+    if ((rc = h2d_seg(H, p.arena + p.o_x0, p.stride, x0, sizeof(double) * p.n))) return rc;
+    if ((rc = h2d_seg(H, zseg(H, 0), p.stride, x0, sizeof(double) * p.n))) return rc;
+    if ((rc = h2d_seg(H, zseg(H, 1), p.stride, x0, sizeof(double) * p.n))) return rc;
     H->x0_set = true;
-    return sync(H);
+    return ALG_OK;
 }
 
 int alg_set_lqr(alg_handle* h, const double* Qd, const double* Rd, const double* xf, const double* uf, int32_t per_game) {
     if (!h || !Qd || !Rd || !xf || !uf) return fail(ALG_ERR_ARG, "alg_set_lqr: null argument");
     int rc = use_device(H); if (rc) return rc;
-    const Params& p = H->pr; const size_t nb = per_game ? p.B : 1;
-    if ((rc = h2d(H, H->d_lqr[0], Qd, sizeof(double) * nb * p.p * p.ni))) return rc;
-    if ((rc = h2d(H, H->d_lqr[1], Rd, sizeof(double) * nb * p.p * p.mi))) return rc;
-    if ((rc = h2d(H, H->d_lqr[2], xf, sizeof(double) * nb * p.p * p.ni))) return rc;
-    if ((rc = h2d(H, H->d_lqr[3], uf, sizeof(double) * nb * p.p * p.mi))) return rc;
-    H->pr.lqr_per_game = per_game ? 1 : 0;
+    Params& p = H->pr; const size_t nb = per_game ? p.B : 1;
+    // device block per game (or one shared block): [Qd (p ni) | xf (p ni) | Rd (p mi) | uf (p mi)]
+    const int blk = lqr_block(p), wq = p.p * p.ni, wr = p.p * p.mi;
+    const double* src[4] = {Qd, xf, Rd, uf}; const int off[4] = {0, wq, 2 * wq, 2 * wq + wr}, wid[4] = {wq, wq, wr, wr};
+    for (int t = 0; t < 4; t++)
+        HIPCHK(hipMemcpy2DAsync(H->d_lqr + off[t], sizeof(double) * blk, src[t], sizeof(double) * wid[t], sizeof(double) * wid[t], nb, hipMemcpyHostToDevice, H->stream));
+    if ((rc = sync(H))) return rc;
+    p.lqr_per_game = per_game ? 1 : 0; p.lqr_stride = per_game ? blk : 0;
     H->lqr_set = true;
     return ALG_OK;
 }
 
 int alg_add_collision_cost(alg_handle* h, const double* radius, const double* mu) {
+    NEED_HANDLE("alg_add_collision_cost");
     Params& p = H->pr;
     if (!radius || !mu) { p.has_colcost = 0; return ALG_OK; }
     for (int i = 0; i < p.p; i++) { p.cc_radius[i] = radius[i]; p.cc_mu[i] = mu[i]; }
     p.has_colcost = 1; return ALG_OK;
 }
 int alg_add_collision_avoidance(alg_handle* h, const double* radius) {
+    NEED_HANDLE("alg_add_collision_avoidance");
     Params& p = H->pr;
     if (!radius) { p.has_colavoid = 0; return ALG_OK; }
     for (int i = 0; i < p.p; i++) p.ca_radius[i] = radius[i];
     p.has_colavoid = 1; p.ca_dim = 2; return ALG_OK;
 }
 int alg_add_control_bound(alg_handle* h, const double* umax, const double* umin) {
+    NEED_HANDLE("alg_add_control_bound");
     Params& p = H->pr;
     if (!umax || !umin) { p.has_ctl = 0; return ALG_OK; }
     if (p.m > MAXM) return fail(ALG_ERR_ARG, "alg_add_control_bound: m too large");
@@ -333,20 +394,17 @@ int alg_add_control_bound(alg_handle* h, const double* umax, const double* umin)
 
 // ---- extended ingredient set (examples/intro_example.jl): switches the handle to the EXT kernel instantiation ----------
 static int ext_commit(Handle* hd) {
-    // the constraint vectors grew: re-create lam / mu / vals (mu = rho_0, lam = 0 like a freshly built ALConVal) and push the constants
+    // the constraint vectors grew: re-create the constraint arena (mu = rho_0, lam = 0 like a freshly built ALConVal) and push the constants
     int rc = use_device(hd); if (rc) return rc;
     if ((rc = sync(hd))) return rc;
     Params& p = hd->pr;
     if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 p<=4 / d=3 p=2, Unicycle, Bicycle p<=4)");
     p.ext = 1;
     recount_con(p);
-    dfree(hd, hd->bf.lam); dfree(hd, hd->bf.mu); dfree(hd, hd->bf.vals);
-    const size_t B = p.B;
-    if ((rc = dalloc(hd, &hd->bf.lam, B * p.con_len, "bf.lam"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.mu, B * p.con_len, "bf.mu"))) return rc;
-    if ((rc = dalloc(hd, &hd->bf.vals, B * p.con_len, "bf.vals"))) return rc;
-    if ((rc = h2d(hd, hd->bf.extc, hd->extc.data(), sizeof(double) * hd->extc.size()))) return rc;
-    hipLaunchKernelGGL(k_reset_con, dim3(p.B), dim3(WAVE), 0, hd->stream, hd->pr, hd->bf);
+    dfree(hd, p.con); p.con = nullptr;
+    if ((rc = alloc_con(hd))) return rc;
+    if ((rc = h2d(hd, hd->d_extc, hd->extc.data(), sizeof(double) * hd->extc.size()))) return rc;
+    hipLaunchKernelGGL(k_reset_con, dim3(p.B), dim3(WAVE), 0, hd->stream, hd->pr);
     if ((rc = launch_check("k_reset_con"))) return rc;
     return sync(hd);
 }
@@ -430,132 +488,134 @@ int alg_get_con_len(alg_handle* h, int32_t* n) {
 }
 
 int alg_set_traj(alg_handle* h, int32_t which, const double* z) {
-    if (which < 0 || which > 2 || !z) return fail(ALG_ERR_ARG, "alg_set_traj: bad argument");
+    if (!h || which < 0 || which > 2 || !z) return fail(ALG_ERR_ARG, "alg_set_traj: bad argument");
     int rc = use_device(H); if (rc) return rc;
-    return h2d(H, H->bf.traj[which], z, sizeof(double) * H->pr.B * H->pr.traj_len);
+    return h2d_seg(H, zseg(H, which), H->pr.stride, z, sizeof(double) * H->pr.traj_len);
 }
 int alg_get_traj(alg_handle* h, int32_t which, double* z) {
-    if (which < 0 || which > 2 || !z) return fail(ALG_ERR_ARG, "alg_get_traj: bad argument");
+    if (!h || which < 0 || which > 2 || !z) return fail(ALG_ERR_ARG, "alg_get_traj: bad argument");
     int rc = use_device(H); if (rc) return rc;
-    return d2h(H, z, H->bf.traj[which], sizeof(double) * H->pr.B * H->pr.traj_len);
+    return d2h_seg(H, z, zseg(H, which), H->pr.stride, sizeof(double) * H->pr.traj_len);
 }
 int alg_set_con_duals(alg_handle* h, const double* lam, const double* mu) {
+    NEED_HANDLE("alg_set_con_duals");
     int rc = use_device(H); if (rc) return rc;
-    const size_t bytes = sizeof(double) * H->pr.B * H->pr.con_len;
-    if (bytes == 0) return ALG_OK;
-    if (lam && (rc = h2d(H, H->bf.lam, lam, bytes))) return rc;
-    if (mu && (rc = h2d(H, H->bf.mu, mu, bytes))) return rc;
+    const Params& p = H->pr; const size_t w = sizeof(double) * p.con_len;
+    if (lam && (rc = h2d_seg(H, p.con, p.con_stride, lam, w))) return rc;
+    if (mu && (rc = h2d_seg(H, p.con + p.con_pad, p.con_stride, mu, w))) return rc;
     return ALG_OK;
 }
 int alg_get_con_duals(alg_handle* h, double* lam, double* mu) {
+    NEED_HANDLE("alg_get_con_duals");
     int rc = use_device(H); if (rc) return rc;
-    const size_t bytes = sizeof(double) * H->pr.B * H->pr.con_len;
-    if (bytes == 0) return ALG_OK;
-    if (lam && (rc = d2h(H, lam, H->bf.lam, bytes))) return rc;
-    if (mu && (rc = d2h(H, mu, H->bf.mu, bytes))) return rc;
+    const Params& p = H->pr; const size_t w = sizeof(double) * p.con_len;
+    if (lam && (rc = d2h_seg(H, lam, p.con, p.con_stride, w))) return rc;
+    if (mu && (rc = d2h_seg(H, mu, p.con + p.con_pad, p.con_stride, w))) return rc;
     return ALG_OK;
 }
 
 int alg_init_traj(alg_handle* h, int64_t game_id0, int32_t use_shift) {
+    NEED_HANDLE("alg_init_traj");
     int rc = use_device(H); if (rc) return rc;
     if (!H->x0_set) return fail(ALG_ERR_STATE, "alg_init_traj: x0 not set");
-    LAUNCH(k_init, H->pr, H->bf, (uint64_t)game_id0, (int)use_shift, 1, 0);
+    LAUNCH(k_init, H->pr, (uint64_t)game_id0, (int)use_shift, 1, 0);
     return sync(H);
 }
 int alg_rollout(alg_handle* h, int32_t which) {
-    if (which < 0 || which > 1) return fail(ALG_ERR_ARG, "alg_rollout: bad traj selector");
+    if (!h || which < 0 || which > 1) return fail(ALG_ERR_ARG, "alg_rollout: bad argument");
     int rc = use_device(H); if (rc) return rc;
-    LAUNCH(k_init, H->pr, H->bf, (uint64_t)0, 0, 0, (int)which);
+    LAUNCH(k_init, H->pr, (uint64_t)0, 0, 0, (int)which);
     return sync(H);
 }
 
 int alg_residual(alg_handle* h, int32_t which, double reg, double* res, double* rn) {
-    if (which < 0 || which > 1) return fail(ALG_ERR_ARG, "alg_residual: bad traj selector");
+    if (!h || which < 0 || which > 1) return fail(ALG_ERR_ARG, "alg_residual: bad argument");
     int rc = use_device(H); if (rc) return rc;
     const Params& p = H->pr;
-    double* d_res = nullptr;
-    if (res) HIPCHK(hipMalloc((void**)&d_res, sizeof(double) * p.B * p.S));
-    LAUNCH(k_residual, H->pr, H->bf, (int)which, reg, d_res, H->d_tmp);
-    if (res) { rc = d2h(H, res, d_res, sizeof(double) * p.B * p.S); hipFree(d_res); if (rc) return rc; }
+    LAUNCH(k_residual, H->pr, (int)which, reg, H->d_tmp);
+    if (res && (rc = d2h_seg(H, res, p.arena + p.o_res, p.stride, sizeof(double) * p.S))) return rc;
     if (rn && (rc = d2h(H, rn, H->d_tmp, sizeof(double) * p.B))) return rc;
     return sync(H);
 }
 
 int alg_residual_jacobian(alg_handle* h, double reg, double* jac) {
-    if (!jac) return fail(ALG_ERR_ARG, "alg_residual_jacobian: null output");
+    if (!h || !jac) return fail(ALG_ERR_ARG, "alg_residual_jacobian: null argument");
     int rc = use_device(H); if (rc) return rc;
     const Params& p = H->pr;
     const size_t bytes = sizeof(double) * (size_t)p.B * p.S * p.S;
-    double* d_j = nullptr;
-    HIPCHK(hipMalloc((void**)&d_j, bytes));
-    LAUNCH(k_jacobian, H->pr, H->bf, reg, d_j);
-    rc = d2h(H, jac, d_j, bytes);
-    hipFree(d_j);
-    return rc;
+    if ((rc = ensure_scratch(H, bytes))) return rc;
+    LAUNCH(k_jacobian, H->pr, reg, (double*)H->d_scratch);
+    return d2h(H, jac, H->d_scratch, bytes);
 }
 
 int alg_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status) {
+    NEED_HANDLE("alg_newton_direction");
     int rc = use_device(H); if (rc) return rc;
     const Params& p = H->pr;
-    LAUNCH(k_direction, H->pr, H->bf, reg, H->d_itmp);
+    LAUNCH(k_direction, H->pr, reg, H->d_itmp);
     if (status && (rc = d2h(H, status, H->d_itmp, sizeof(int) * p.B))) return rc;
-    if (delta) {
-        // strip the x_1 slot: delta is B x S in horizontal order
-        HIPCHK(hipMemcpy2DAsync(delta, sizeof(double) * p.S, H->bf.traj[2] + p.n, sizeof(double) * p.traj_len, sizeof(double) * p.S, p.B, hipMemcpyDeviceToHost, H->stream));
-    }
+    // strip the x_1 slot: delta is B x S in horizontal order
+    if (delta && (rc = d2h_seg(H, delta, zseg(H, 2) + p.n, p.stride, sizeof(double) * p.S))) return rc;
     return sync(H);
 }
 
 int alg_line_search(alg_handle* h, double reg, const double* rn, double* alpha, int32_t* j) {
-    if (!rn || !alpha || !j) return fail(ALG_ERR_ARG, "alg_line_search: null argument");
+    if (!h || !rn || !alpha || !j) return fail(ALG_ERR_ARG, "alg_line_search: null argument");
     int rc = use_device(H); if (rc) return rc;
     const Params& p = H->pr;
     if ((rc = h2d(H, H->d_tmp, rn, sizeof(double) * p.B))) return rc;
-    LAUNCH(k_line_search, H->pr, H->bf, reg, (const double*)H->d_tmp, H->d_tmp + p.B, H->d_itmp);
+    LAUNCH(k_line_search, H->pr, reg, (const double*)H->d_tmp, H->d_tmp + p.B, H->d_itmp);
     if ((rc = d2h(H, alpha, H->d_tmp + p.B, sizeof(double) * p.B))) return rc;
     return d2h(H, j, H->d_itmp, sizeof(int) * p.B);
 }
 
 int alg_update_traj(alg_handle* h, int32_t target, int32_t source, const double* alpha) {
-    if (target < 0 || target > 1 || source < 0 || source > 1 || !alpha) return fail(ALG_ERR_ARG, "alg_update_traj: bad argument");
+    if (!h || target < 0 || target > 1 || source < 0 || source > 1 || !alpha) return fail(ALG_ERR_ARG, "alg_update_traj: bad argument");
     int rc = use_device(H); if (rc) return rc;
     if ((rc = h2d(H, H->d_tmp, alpha, sizeof(double) * H->pr.B))) return rc;
-    LAUNCH(k_update, H->pr, H->bf, (int)target, (int)source, (const double*)H->d_tmp);
+    LAUNCH(k_update, H->pr, (int)target, (int)source, (const double*)H->d_tmp);
     return sync(H);
 }
 
 int alg_record_stats(alg_handle* h, alg_record* rec) {
-    if (!rec) return fail(ALG_ERR_ARG, "alg_record_stats: null output");
+    if (!h || !rec) return fail(ALG_ERR_ARG, "alg_record_stats: null argument");
     int rc = use_device(H); if (rc) return rc;
-    LAUNCH(k_record, H->pr, H->bf, H->d_rec);
+    LAUNCH(k_record, H->pr, H->d_rec);
     return d2h(H, rec, H->d_rec, sizeof(alg_record) * H->pr.B);
 }
 
 int alg_reset_con(alg_handle* h) {
+    NEED_HANDLE("alg_reset_con");
     int rc = use_device(H); if (rc) return rc;
-    hipLaunchKernelGGL(k_reset_con, dim3(H->pr.B), dim3(WAVE), 0, H->stream, H->pr, H->bf);
+    hipLaunchKernelGGL(k_reset_con, dim3(H->pr.B), dim3(WAVE), 0, H->stream, H->pr);
     if ((rc = launch_check("k_reset_con"))) return rc;
     return sync(H);
 }
 
 int alg_dual_penalty_update(alg_handle* h, double* vals) {
+    NEED_HANDLE("alg_dual_penalty_update");
     int rc = use_device(H); if (rc) return rc;
-    LAUNCH(k_dual_update, H->pr, H->bf);
-    if (vals && H->pr.con_len > 0) return d2h(H, vals, H->bf.vals, sizeof(double) * H->pr.B * H->pr.con_len);
+    const Params& p = H->pr;
+    LAUNCH(k_dual_update, H->pr);
+    if (vals && p.con_len > 0) return d2h_seg(H, vals, p.con + 2 * p.con_pad, p.con_stride, sizeof(double) * p.con_len);
     return sync(H);
 }
 
-int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, alg_step_info* info) {
+int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, const double* delta_in, alg_step_info* info) {
+    NEED_HANDLE("alg_newton_step");
     int rc = use_device(H); if (rc) return rc;
-    LAUNCH(k_newton_step, H->pr, H->bf, (int)k_outer, (int)l_inner, H->d_info);
+    const double* d_delta = nullptr;
+    if (delta_in) { if ((rc = h2d(H, H->d_tmp, delta_in, sizeof(double) * H->pr.B))) return rc; d_delta = H->d_tmp; }
+    LAUNCH(k_newton_step, H->pr, (int)k_outer, (int)l_inner, d_delta, H->d_info);
     if (info) return d2h(H, info, H->d_info, sizeof(alg_step_info) * H->pr.B);
     return sync(H);
 }
 
 int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) {
+    NEED_HANDLE("alg_newton_solve");
     int rc = use_device(H); if (rc) return rc;
     if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_newton_solve: x0 / LQR data not set");
-    LAUNCH(k_newton_solve, H->pr, H->bf, (int)init, (uint64_t)game_id0);
+    LAUNCH(k_newton_solve, H->pr, (int)init, (uint64_t)game_id0);
     return ALG_OK;
 }
 int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats) {
@@ -564,22 +624,25 @@ int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_sta
     return sync(H);
 }
 int alg_get_stats(alg_handle* h, alg_game_stats* stats) {
-    if (!stats) return fail(ALG_ERR_ARG, "alg_get_stats: null output");
+    if (!h || !stats) return fail(ALG_ERR_ARG, "alg_get_stats: null argument");
     int rc = use_device(H); if (rc) return rc;
-    return d2h(H, stats, H->bf.stats, sizeof(alg_game_stats) * H->pr.B);
+    return d2h_seg(H, stats, H->pr.arena + H->pr.o_st, H->pr.stride, sizeof(alg_game_stats));
 }
 int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out) {
-    if (game < 0 || game >= H->pr.B || !out) return fail(ALG_ERR_ARG, "alg_get_history: bad argument");
+    if (!h || game < 0 || game >= H->pr.B || !out) return fail(ALG_ERR_ARG, "alg_get_history: bad argument");
     int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr;
     alg_game_stats st;
-    if ((rc = d2h(H, &st, H->bf.stats + game, sizeof(st)))) return rc;
-    int c = std::min(std::min(st.records, H->pr.hist_max), (int)max_records);
-    if (c > 0 && (rc = d2h(H, out, H->bf.hist + (size_t)game * H->pr.hist_max, sizeof(alg_record) * c))) return rc;
+    if ((rc = d2h(H, &st, p.arena + (size_t)game * p.stride + p.o_st, sizeof(st)))) return rc;
+    int c = std::min(std::min(st.records, p.hist_max), (int)max_records);
+    if (c > 0 && (rc = d2h(H, out, p.hist + (size_t)game * p.hist_max, sizeof(alg_record) * c))) return rc;
     if (n_out) *n_out = c;
     return ALG_OK;
 }
-// debug aid (not part of the public header): returns the number of device buffers whose guard zone was overwritten
+// Diagnostic: number of device allocations whose 4 KiB guard zone was overwritten, plus per-game arena chunks (first 64 games)
+// whose inter-segment padding is no longer zero.
 int alg_debug_check_guards(alg_handle* h) {
+    NEED_HANDLE("alg_debug_check_guards");
     int rc = use_device(H); if (rc) return rc;
     if ((rc = sync(H))) return rc;
     int bad = 0; std::vector<unsigned char> g(GUARD);
@@ -587,9 +650,20 @@ int alg_debug_check_guards(alg_handle* h) {
         if (hipMemcpy(g.data(), (char*)H->allocs[i] + H->alloc_bytes[i], GUARD, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         size_t first = GUARD, cnt = 0;
         for (size_t j = 0; j < GUARD; j++) if (g[j] != 0xAB) { if (first == GUARD) first = j; cnt++; }
-        if (cnt) { const double* gd = (const double*)g.data(); for (int j = 0; j < 128; j++) fprintf(stderr, "%s%.4g", j % 8 ? " " : "\n  ", gd[j]); fprintf(stderr, "\n"); }
         if (cnt) { bad++; fprintf(stderr, "[alg guard] buffer %s (%zu bytes) overrun: %zu bytes touched, first at +%zu\n", H->alloc_names[i], H->alloc_bytes[i], cnt, first); }
     }
+    const Params& p = H->pr;
+    const int ng = std::min(p.B, 64);
+    std::vector<double> chunk((size_t)ng * p.stride);
+    if (hipMemcpy(chunk.data(), p.arena, sizeof(double) * chunk.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const int segs[][2] = {{0, p.traj_len}, {p.o_z1, p.traj_len}, {p.o_z2, p.traj_len}, {p.o_x0, p.n}, {p.o_res, p.S}, {p.o_rec, p.rec_len},
+                           {p.o_kgain, p.kscratch_len}, {p.o_tc, 8}, {p.o_st, (int)((sizeof(alg_game_stats) + 7) / 8)}, {p.o_mpc, 2}};
+    for (int gi = 0; gi < ng; gi++)
+        for (auto& sg : segs)
+            for (int e = sg[0] + sg[1]; e < sg[0] + pad16(std::max(sg[1], 1)); e++) {
+                unsigned long long bits; std::memcpy(&bits, &chunk[(size_t)gi * p.stride + e], 8);
+                if (bits != 0) { bad++; fprintf(stderr, "[alg guard] game %d: padding behind the arena segment at +%d (len %d) was written (offset %d)\n", gi, sg[0], sg[1], e); break; }
+            }
     return bad;
 }
 #ifdef ALG_PHASE_PROF
@@ -597,34 +671,40 @@ int alg_debug_check_guards(alg_handle* h) {
 extern "C" int alg_debug_read_res(alg_handle* h, double* out, int cnt) {
     int rc = use_device(H); if (rc) return rc;
     if ((rc = sync(H))) return rc;
-    for (int g = 0; g < H->pr.B; g++) if (hipMemcpy(out + (size_t)g * cnt, H->bf.res + (size_t)g * H->pr.S, sizeof(double) * cnt, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return 0;
+    return d2h_seg(H, out, H->pr.arena + H->pr.o_res, H->pr.stride, sizeof(double) * cnt);
 }
 #endif
-int alg_synchronize(alg_handle* h) { int rc = use_device(H); if (rc) return rc; return sync(H); }
+int alg_synchronize(alg_handle* h) { NEED_HANDLE("alg_synchronize"); int rc = use_device(H); if (rc) return rc; return sync(H); }
 
 int alg_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats) {
+    NEED_HANDLE("alg_ibr_solve_player");
     int rc = use_device(H); if (rc) return rc;
     if (player < 0 || player >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_solve_player: bad player index");
+    // statistics accumulate over the players' solves (the reference does not reset them): room for p more solves
+    if ((rc = ensure_hist(H, (long long)H->pr.hist_max + (long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1))) return rc;
     IbrOrder order{};
-    LAUNCH(k_ibr, H->pr, H->bf, 0, (int)player, 0, (uint64_t)0, 1, order, 0.0);
+    LAUNCH(k_ibr, H->pr, 0, (int)player, 0, (uint64_t)0, 1, order, 0.0);
     if (stats) return alg_get_stats(h, stats);
     return sync(H);
 }
 int alg_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t ibr_iter, const int32_t* ordering, double delta_min, alg_game_stats* stats) {
+    NEED_HANDLE("alg_ibr_newton_solve");
     int rc = use_device(H); if (rc) return rc;
     if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_ibr_newton_solve: x0 / LQR data not set");
     if (!ordering || ibr_iter < 1) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: bad arguments");
     IbrOrder order{};
     for (int i = 0; i < H->pr.p; i++) { if (ordering[i] < 0 || ordering[i] >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: ordering entries must be player ids"); order.v[i] = ordering[i]; }
-    LAUNCH(k_ibr, H->pr, H->bf, 1, 0, (int)init, (uint64_t)game_id0, (int)ibr_iter, order, delta_min);
+    // records accumulate over rounds and players: ibr_iter * p * (outer_iter * inner_iter + 1) at most
+    if ((rc = ensure_hist(H, (long long)ibr_iter * H->pr.p * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
+    LAUNCH(k_ibr, H->pr, 1, 0, (int)init, (uint64_t)game_id0, (int)ibr_iter, order, delta_min);
     if (stats) return alg_get_stats(h, stats);
     return sync(H);
 }
 
 int alg_mpc_advance(alg_handle* h) {
+    NEED_HANDLE("alg_mpc_advance");
     int rc = use_device(H); if (rc) return rc;
-    LAUNCH(k_mpc_advance, H->pr, H->bf);
+    LAUNCH(k_mpc_advance, H->pr);
     return ALG_OK;
 }
 int alg_mpc_solve(alg_handle* h, int32_t steps, int64_t game_id0, double* states) {
@@ -632,21 +712,20 @@ int alg_mpc_solve(alg_handle* h, int32_t steps, int64_t game_id0, double* states
     int rc = use_device(H); if (rc) return rc;
     if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_mpc_solve: x0 / LQR data not set");
     const Params& p = H->pr;
-    double* d_states = nullptr;
     const size_t cnt = (size_t)(steps + 1) * p.B * p.n;
-    if (states) HIPCHK(hipMalloc((void**)&d_states, sizeof(double) * cnt));
-    LAUNCH(k_mpc_loop, H->pr, H->bf, (int)steps, (uint64_t)game_id0, d_states);
-    if (states) { rc = d2h(H, states, d_states, sizeof(double) * cnt); hipFree(d_states); return rc; }
+    if (states && (rc = ensure_scratch(H, sizeof(double) * cnt))) return rc;
+    LAUNCH(k_mpc_loop, H->pr, (int)steps, (uint64_t)game_id0, states ? (double*)H->d_scratch : (double*)nullptr);
+    if (states) return d2h(H, states, H->d_scratch, sizeof(double) * cnt);
     return ALG_OK;
 }
 int alg_mpc_totals(alg_handle* h, int64_t* it, int64_t* cv, int32_t reset) {
+    NEED_HANDLE("alg_mpc_totals");
     int rc = use_device(H); if (rc) return rc;
-    const int B = H->pr.B;
+    const Params& p = H->pr; const int B = p.B;
     std::vector<long long> tmp(2 * (size_t)B);
-    if ((rc = d2h(H, tmp.data(), H->bf.mpc, sizeof(long long) * 2 * B))) return rc;
+    if ((rc = d2h_seg(H, tmp.data(), p.arena + p.o_mpc, p.stride, sizeof(long long) * 2))) return rc;
     for (int g = 0; g < B; g++) { if (it) it[g] = tmp[2 * g]; if (cv) cv[g] = tmp[2 * g + 1]; }
-    if (reset) { HIPCHK(hipMemsetAsync(H->bf.mpc, 0, sizeof(long long) * 2 * B, H->stream)); return sync(H); }
+    if (reset) { HIPCHK(hipMemset2DAsync(p.arena + p.o_mpc, sizeof(double) * p.stride, 0, sizeof(long long) * 2, B, H->stream)); return sync(H); }
     return ALG_OK;
 }
-
 } // extern "C"

@@ -10,137 +10,135 @@ using namespace alg;
 // Kernels
 // ------------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr, Buffers bf, int init, uint64_t game_id0) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr, int init, uint64_t game_id0) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, Buffers bf, int k, int l, alg_step_info* out) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, int k, int l, const double* delta_in, alg_step_info* out) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    int ls = 0; double dl = 0.0;
-    double* const z_home = G.z[0];
+    Game G = game_view(pr, g);
+    int ls = 0; double dl = delta_in ? delta_in[g] : 0.0;          // the caller's Δ goes into record! (solver_methods.jl:75)
     inner_iteration<C>(pr, G, L, ls, dl, k, l, out + g, nullptr);
-    settle_traj<C>(pr, G, z_home);
+    settle_traj<C>(pr, G);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_residual(Params pr, Buffers bf, int which, double reg, double* res_out, double* rn_out) {
+__global__ void __launch_bounds__(WAVE) k_residual(Params pr, int which, double reg, double* rn_out) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     ResOut ro;
     // the proximal term is taken w.r.t. pdtraj (regularize_residual!, global_quantities.jl:67-86)
-    assemble_pass<C, 2>(pr, G, L.a, G.z[which], reg != 0.0 ? G.z[0] : nullptr, reg, 0.0, ro);
+    assemble_pass<C, 2>(pr, G, L.a, which, reg != 0.0 ? 0 : -1, reg, 0.0, ro);
     __syncthreads();
-    if (res_out) for (int e = threadIdx.x; e < pr.S; e += WAVE) res_out[(size_t)g * pr.S + e] = G.res[e];
     if (rn_out && threadIdx.x == 0) rn_out[g] = ro.l1 / (double)pr.S;
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, Buffers bf, double reg, double* J) {
+__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, double reg, double* J) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     ResOut ro;
-    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
+    assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, reg, ro);
     __syncthreads();
     jacobian_dense<C>(pr, G, reg, J + (size_t)g * pr.S * pr.S);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr, Buffers bf, double reg, int* status) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr, double reg, int* status) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     ResOut ro;
-    assemble_pass<C, 1>(pr, G, L.a, G.z[0], nullptr, 0.0, reg, ro);
+    assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, reg, ro);
     __syncthreads();
     const int st = newton_direction<C>(pr, G, L.d, reg);
     if (status && threadIdx.x == 0) status[g] = st;
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_line_search(Params pr, Buffers bf, double reg, const double* rn, double* alpha, int* j) {
+__global__ void __launch_bounds__(WAVE) k_line_search(Params pr, double reg, const double* rn, double* alpha, int* j) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     double a; int jj;
     line_search<C>(pr, G, L, reg, rn[g], -1.0, &a, &jj);
     if (threadIdx.x == 0) { alpha[g] = a; j[g] = jj; }
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_update(Params pr, Buffers bf, int tgt, int src, const double* alpha) {
+__global__ void __launch_bounds__(WAVE) k_update(Params pr, int tgt, int src, const double* alpha) {
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    update_traj<C>(pr, G.z[tgt], G.z[src], alpha[g], G.z[2]);
+    Game G = game_view(pr, g);
+    update_traj<C>(pr, G, tgt, src, alpha[g]);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_record(Params pr, Buffers bf, alg_record* out) {
+__global__ void __launch_bounds__(WAVE) k_record(Params pr, alg_record* out) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     make_record<C>(pr, G, L, 0.0, 0, 0.0, out + g);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_dual_update(Params pr, Buffers bf) {
+__global__ void __launch_bounds__(WAVE) k_dual_update(Params pr) {
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     dual_penalty_update<C>(pr, G);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_init(Params pr, Buffers bf, uint64_t game_id0, int use_shift, int do_init, int which) {
+__global__ void __launch_bounds__(WAVE) k_init(Params pr, uint64_t game_id0, int use_shift, int do_init, int which) {
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     if (do_init) {
-        init_traj<C>(pr, G, G.z[0], game_id0 + (uint64_t)g, use_shift != 0);
-        if (threadIdx.x < C::n) G.z[1][threadIdx.x] = G.x0[threadIdx.x];
+        init_traj<C>(pr, G, G.z(0), game_id0 + (uint64_t)g, use_shift != 0);
+        if (threadIdx.x < C::n) G.z(1)[threadIdx.x] = G.x0(pr)[threadIdx.x];
         __syncthreads();
-        rollout<C>(pr, G.z[0]);
+        rollout<C>(pr, G.z(0));
     } else {
-        rollout<C>(pr, G.z[which]);
+        rollout<C>(pr, G.z(which));
     }
 }
 
 // mode 0: ibr_newton_solve!(prob, player) on the stored trajectory ; mode 1: ibr_newton_solve!(prob; ibr_opts)
 template <class C>
-__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, Buffers bf, int mode, int player, int init, uint64_t game_id0,
+__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, int mode, int player, int init, uint64_t game_id0,
                                                       int ibr_iter, IbrOrder order, double delta_min) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
+    Game G = game_view(pr, g);
     ibr_newton_solve<C>(pr, G, L, mode == 0, player, init, game_id0 + (uint64_t)g, ibr_iter, order, delta_min);
 }
 
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
 template <class C>
-__device__ __forceinline__ void mpc_advance(const Params& pr, const Buffers& bf, const Game& G, int g) {
+__device__ __forceinline__ void mpc_advance(const Params& pr, const Game& G) {
     const int lane = threadIdx.x;
     if (lane < C::P) {
         double x[C::n], u[C::m], xo[C::ni], co[4];
-        for (int j = 0; j < C::ni; j++) x[lane + j * C::P] = G.z[0][lane + j * C::P];
-        for (int j = 0; j < C::mi; j++) u[lane + j * C::P] = G.z[0][C::n + hu<C>(0, lane) + j];
+        for (int j = 0; j < C::ni; j++) x[lane + j * C::P] = G.z(0)[lane + j * C::P];
+        for (int j = 0; j < C::mi; j++) u[lane + j * C::P] = G.z(0)[C::n + hu<C>(0, lane) + j];
         model_player<C>(pr, lane, x, u, pr.dt, xo, co);
         for (int j = 0; j < C::ni; j++) {
             const int a = lane + j * C::P;
-            bf.x0[(size_t)g * C::n + a] = xo[j]; G.z[0][a] = xo[j]; G.z[1][a] = xo[j];
+            G.x0w(pr)[a] = xo[j]; G.z(0)[a] = xo[j]; G.z(1)[a] = xo[j];
         }
     }
-    if (lane == 0) { bf.mpc[2 * g] += G.st->newton_iters; bf.mpc[2 * g + 1] += G.st->converged; }
+    if (lane == 0) { G.mpc(pr)[0] += G.st(pr)->newton_iters; G.mpc(pr)[1] += G.st(pr)->converged; }
 }
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
+__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr) {
     const int g = blockIdx.x;
-    Game G = game_view(pr, bf, g);
-    mpc_advance<C>(pr, bf, G, g);
+    Game G = game_view(pr, g);
+    mpc_advance<C>(pr, G);
 }
 
 // The whole receding-horizon loop of one game in one wave (BASELINE config 5): `steps` x (newton_solve! from the shifted
@@ -152,17 +150,17 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr, Buffers bf) {
 // one faulted on a null base pointer (tests/test_gpu_parity_ext.py::test_no_kernel_writes_outside_its_buffers runs this
 // kernel for every instantiation).
 template <class C>
-__global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr, Buffers bf, int steps, uint64_t game_id0, double* states) {
+__global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr, int steps, uint64_t game_id0, double* states) {
     __shared__ Lds<C> L;
     const int g = blockIdx.x, lane = threadIdx.x;
-    Game G = game_view(pr, bf, g);
-    if (states && lane < C::n) states[(size_t)g * C::n + lane] = G.x0[lane];
+    Game G = game_view(pr, g);
+    if (states && lane < C::n) states[(size_t)g * C::n + lane] = G.x0(pr)[lane];
     for (int t = 0; t < steps; t++) {
         newton_solve<C>(pr, G, L, 1, game_id0 + (uint64_t)t * 1000003ull + (uint64_t)g, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
         __syncthreads();
-        mpc_advance<C>(pr, bf, G, g);
+        mpc_advance<C>(pr, G);
         __syncthreads();
-        if (states && lane < C::n) states[((size_t)(t + 1) * pr.B + g) * C::n + lane] = G.z[0][lane];
+        if (states && lane < C::n) states[((size_t)(t + 1) * pr.B + g) * C::n + lane] = G.z(0)[lane];
         __syncthreads();
     }
 }
@@ -201,18 +199,18 @@ __global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr, Buffers bf, int
 
 // every kernel of one instantiation; PREFIX is `template` (definition) or `extern template` (declaration)
 #define ALG_INSTANTIATE_KERNELS(PREFIX, M, P, D, E)                                                                        \
-    PREFIX __global__ void k_newton_solve<Cfg<M, P, D, E>>(Params, Buffers, int, uint64_t);                                \
-    PREFIX __global__ void k_newton_step<Cfg<M, P, D, E>>(Params, Buffers, int, int, alg_step_info*);                      \
-    PREFIX __global__ void k_residual<Cfg<M, P, D, E>>(Params, Buffers, int, double, double*, double*);                    \
-    PREFIX __global__ void k_jacobian<Cfg<M, P, D, E>>(Params, Buffers, double, double*);                                  \
-    PREFIX __global__ void k_direction<Cfg<M, P, D, E>>(Params, Buffers, double, int*);                                    \
-    PREFIX __global__ void k_line_search<Cfg<M, P, D, E>>(Params, Buffers, double, const double*, double*, int*);          \
-    PREFIX __global__ void k_update<Cfg<M, P, D, E>>(Params, Buffers, int, int, const double*);                            \
-    PREFIX __global__ void k_record<Cfg<M, P, D, E>>(Params, Buffers, alg_record*);                                        \
-    PREFIX __global__ void k_dual_update<Cfg<M, P, D, E>>(Params, Buffers);                                                \
-    PREFIX __global__ void k_init<Cfg<M, P, D, E>>(Params, Buffers, uint64_t, int, int, int);                              \
-    PREFIX __global__ void k_ibr<Cfg<M, P, D, E>>(Params, Buffers, int, int, int, uint64_t, int, IbrOrder, double);        \
-    PREFIX __global__ void k_mpc_advance<Cfg<M, P, D, E>>(Params, Buffers);                                                \
-    PREFIX __global__ void k_mpc_loop<Cfg<M, P, D, E>>(Params, Buffers, int, uint64_t, double*);
+    PREFIX __global__ void k_newton_solve<Cfg<M, P, D, E>>(Params, int, uint64_t);                                \
+    PREFIX __global__ void k_newton_step<Cfg<M, P, D, E>>(Params, int, int, const double*, alg_step_info*);                      \
+    PREFIX __global__ void k_residual<Cfg<M, P, D, E>>(Params, int, double, double*);                    \
+    PREFIX __global__ void k_jacobian<Cfg<M, P, D, E>>(Params, double, double*);                                  \
+    PREFIX __global__ void k_direction<Cfg<M, P, D, E>>(Params, double, int*);                                    \
+    PREFIX __global__ void k_line_search<Cfg<M, P, D, E>>(Params, double, const double*, double*, int*);          \
+    PREFIX __global__ void k_update<Cfg<M, P, D, E>>(Params, int, int, const double*);                            \
+    PREFIX __global__ void k_record<Cfg<M, P, D, E>>(Params, alg_record*);                                        \
+    PREFIX __global__ void k_dual_update<Cfg<M, P, D, E>>(Params);                                                \
+    PREFIX __global__ void k_init<Cfg<M, P, D, E>>(Params, uint64_t, int, int, int);                              \
+    PREFIX __global__ void k_ibr<Cfg<M, P, D, E>>(Params, int, int, int, uint64_t, int, IbrOrder, double);        \
+    PREFIX __global__ void k_mpc_advance<Cfg<M, P, D, E>>(Params);                                                \
+    PREFIX __global__ void k_mpc_loop<Cfg<M, P, D, E>>(Params, int, uint64_t, double*);
 #define ALG_DEFINE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(template, M, P, D, E)
 #define ALG_DECLARE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(extern template, M, P, D, E)

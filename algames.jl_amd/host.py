@@ -632,7 +632,7 @@ def inner_iteration(prob, LS_count, t_elap, Δ, k, l):
     """inner_iteration(prob, LS_count, t_elap, Δ, k, l) (solver_methods.jl:67-103).
     Returns (LS_count (B,), control_flow (B,) of 'continue'/'break', Δ (B,), info)."""
     prob._sync_options()
-    info = prob.batch.newton_step(k, l)
+    info = prob.batch.newton_step(k, l, delta=Δ)
     LS = np.where(info["ls_failed"] == 1, np.asarray(LS_count) + 1, 0)
     LS = np.where(info["ls_j"] == 0, np.asarray(LS_count), LS)
     flow = np.where(info["control_flow"] == 1, "break", "continue")

@@ -279,6 +279,33 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """CPUs this process may actually run on: min(logical CPUs, affinity mask, cgroup CPU quota).  The GPU boxes expose 256
+    logical CPUs but run the container under a cgroup quota (cpu.max = 16 CPUs); more OpenMP threads than that only add
+    throttling."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota)))
+    return n, (os.cpu_count() or 1), quota
+
+
 def cpu_baseline(alg, family, G, mpc_steps=0):
     """The oracle (literal CPU restatement of the reference algorithm: global KKT assembly + general partial-pivot
     LU per game, OpenMP over games) timed on a bounded sample of the same workload: all host cores, and one core
@@ -286,7 +313,7 @@ def cpu_baseline(alg, family, G, mpc_steps=0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as orc
-    cores = os.cpu_count() or 1
+    cores, logical, quota = usable_cpus()
     prev = orc.set_threads(cores)
 
     def run(nsample):
@@ -312,6 +339,7 @@ def cpu_baseline(alg, family, G, mpc_steps=0):
     it1, cv1, dt1, _ = run(n1)
     orc.set_threads(prev)
     return {"value": float(it / dt), "unit": "game-Newton-iterations/s", "cores": cores, "threads_used": cores,
+            "host_logical_cpus": logical, "cgroup_cpu_quota": quota,
             "kind": "port", "sample": f"first {nsample} scenarios of the same workload, {what}, {dt:.1f} s wall, OpenMP over games",
             "games_to_convergence_per_sec": float(cv / dt),
             "single_core_value": float(it1 / dt1),

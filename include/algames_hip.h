@@ -232,8 +232,10 @@ int alg_reset_con(alg_handle* h);
 int alg_dual_penalty_update(alg_handle* h, double* vals);
 
 /* inner_iteration(prob, LS_count, t_elap, Δ, k, l) (solver_methods.jl:67-103) for every game;
- * reg is set to reg_0*l^4 as in solver_methods.jl:39. */
-int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, alg_step_info* info /*B*/);
+ * reg is set to reg_0*l^4 as in solver_methods.jl:39.  delta_in (B or NULL = zeros) is the caller's Δ, which record! stores
+ * in the Statistics record made at the top of the iteration (solver_methods.jl:75). */
+int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, const double* delta_in /*B or NULL*/,
+                    alg_step_info* info /*B*/);
 /* newton_solve!(prob) (solver_methods.jl:5-65) for every game.  init!=0: run alg_init_traj first
  * (game ids game_id0+g); init==0: keep the stored controls/duals as the initial guess, still
  * rolling out the states (solver_methods.jl:17).  stats: B or NULL. */
@@ -243,11 +245,16 @@ int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_sta
 int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0);
 int alg_get_stats(alg_handle* h, alg_game_stats* stats /*B*/);
 /* Statistics history of one game (statistics.jl:5-15): up to max_records; returns count in *n_out.
- * The device keeps the first ALG_HIST_MAX (192) records of a solve (the reference's default options make at most
- * outer_iter * inner_iter + 1 = 141); alg_game_stats.records counts all of them and .last is always the final record. */
+ * The history buffer is sized from the options (alg_set_options: outer_iter * inner_iter + 1 records per newton_solve!, never
+ * fewer than ALG_HIST_MAX; the IBR entry points size it for ibr_iter * p solves) so that every record! of a solve is kept.
+ * Only a request beyond 1 GiB of history for the whole batch is capped: alg_game_stats.records then exceeds *n_out (records
+ * past the capacity are dropped, .last is always the final record) -- callers must treat n_out < records as truncation. */
 #define ALG_HIST_MAX 192
 int alg_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out);
 int alg_synchronize(alg_handle* h);
+/* Diagnostic (tests): every device allocation is followed by a 4 KiB guard zone and the per-game segments of the arenas are
+ * padded to 128-byte lines; returns the number of guard zones / paddings a kernel has written to (0 = clean, <0 = error). */
+int alg_debug_check_guards(alg_handle* h);
 
 /* Iterated best response.
  * alg_ibr_solve_player: ibr_newton_solve!(prob, i) (solver_methods.jl:171-228) for every game, on the stored trajectory:

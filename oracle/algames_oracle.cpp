@@ -1265,10 +1265,10 @@ int orc_dual_penalty_update(alg_handle* h, double* vals) {
     for (size_t gi = 0; gi < H->g.size(); gi++) { Game& g = H->g[gi]; dual_penalty_update(H->sh, g); if (vals) std::copy(g.vals.begin(), g.vals.end(), vals + gi * L); }
     return ALG_OK;
 }
-int orc_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, alg_step_info* info) {
+int orc_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, const double* delta_in, alg_step_info* info) {
     const int B = (int)H->g.size();
 #pragma omp parallel for schedule(dynamic)
-    for (int gi = 0; gi < B; gi++) { int ls = 0; double dl = 0; alg_step_info si = inner_iteration(H->sh, H->g[gi], ls, dl, k_outer, l_inner); if (info) info[gi] = si; }
+    for (int gi = 0; gi < B; gi++) { int ls = 0; double dl = delta_in ? delta_in[gi] : 0.0; alg_step_info si = inner_iteration(H->sh, H->g[gi], ls, dl, k_outer, l_inner); if (info) info[gi] = si; }
     return ALG_OK;
 }
 int orc_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats) {
@@ -1278,6 +1278,7 @@ int orc_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_sta
     for (int gi = 0; gi < B; gi++) { newton_solve(H->sh, H->g[gi], init != 0, (uint64_t)(game_id0 + gi)); if (stats) stats[gi] = H->g[gi].st; }
     return ALG_OK;
 }
+int orc_debug_check_guards(alg_handle*) { return 0; }      // host vectors: nothing to check (ABI mirror)
 int orc_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) { return orc_newton_solve(h, init, game_id0, nullptr); }
 int orc_get_stats(alg_handle* h, alg_game_stats* stats) { for (size_t gi = 0; gi < H->g.size(); gi++) stats[gi] = H->g[gi].st; return ALG_OK; }
 int orc_get_history(alg_handle* h, int32_t game, int32_t max_records, alg_record* out, int32_t* n_out) {

@@ -4,10 +4,10 @@ import re, subprocess, sys, os, collections
 kern = sys.argv[1] if len(sys.argv) > 1 else "k_newton_solve"
 cfg = sys.argv[2:6] if len(sys.argv) > 5 else ["ALG_MODEL_DOUBLE_INTEGRATOR", "3", "2", "0"]
 sigs = {
- "k_newton_solve": "(Params, Buffers, int, uint64_t)", "k_direction": "(Params, Buffers, double, int*)",
- "k_record": "(Params, Buffers, alg_record*)", "k_line_search": "(Params, Buffers, double, const double*, double*, int*)",
- "k_newton_step": "(Params, Buffers, int, int, alg_step_info*)",
- "k_ibr": "(Params, Buffers, int, int, int, uint64_t, int, IbrOrder, double)",
+ "k_newton_solve": "(Params, int, uint64_t)", "k_direction": "(Params, double, int*)",
+ "k_record": "(Params, alg_record*)", "k_line_search": "(Params, double, const double*, double*, int*)",
+ "k_newton_step": "(Params, int, int, alg_step_info*)",
+ "k_ibr": "(Params, int, int, int, uint64_t, int, IbrOrder, double)",
 }
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs("/tmp/isa", exist_ok=True)

@@ -206,8 +206,7 @@ def test_no_kernel_writes_outside_its_buffers_3d(alg):
         g.ibr_solve_player(player)
     g.ibr_newton_solve(init=True, game_id0=3, ibr_iter=2, ordering=[0, 1], delta_min=1e-9)
     g.mpc_totals(reset=True); g.mpc_solve(3, 5, record_states=True)
-    fn = g.lib.dll.alg_debug_check_guards
-    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    fn = g.lib.debug_check_guards
     assert fn(g.h) == 0
 
 

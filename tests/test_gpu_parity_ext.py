@@ -226,11 +226,10 @@ def test_extended_constraints_unsupported_configuration_fails_loudly(alg):
 
 
 def _guards_ok(batch):
-    """Debug aid of libalgames_hip.so (not part of the public header): every device buffer is followed by a 4 KiB guard zone;
+    """Diagnostic entry of the ABI (alg_debug_check_guards): every device buffer is followed by a 4 KiB guard zone;
     returns the number of buffers whose guard was overwritten."""
     import ctypes
-    fn = batch.lib.dll.alg_debug_check_guards
-    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    fn = batch.lib.debug_check_guards
     return fn(batch.h)
 
 

@@ -1,0 +1,68 @@
+"""Register / spill report of the kernels inside the built libalgames_hip.so (build check, no GPU needed).
+
+The library is a HIP fat binary: every translation unit contributes one clang offload bundle to the `.hip_fatbin` section.
+This module extracts the gfx950 code objects and reads the AMDGPU kernel metadata (`llvm-readelf --notes`): VGPR / SGPR counts,
+scratch bytes and the spill counts of every kernel.  tests/test_abi.py uses it to keep the solver kernels spill-free."""
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def code_objects(lib_path, arch="gfx950"):
+    """Yields the device ELF images (bytes) for `arch` contained in the fat binary."""
+    blob = open(lib_path, "rb").read()
+    pos = 0
+    while True:
+        pos = blob.find(MAGIC, pos)
+        if pos < 0:
+            return
+        n = struct.unpack_from("<Q", blob, pos + len(MAGIC))[0]
+        cur = pos + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, cur)
+            triple = blob[cur + 24:cur + 24 + tlen].decode()
+            cur += 24 + tlen
+            if arch in triple and size > 0:
+                yield blob[pos + off:pos + off + size]
+        pos = cur
+
+
+def kernel_resources(lib_path):
+    """{demangled kernel name: dict(vgpr, sgpr, scratch, vgpr_spill, sgpr_spill, lds)} over all code objects."""
+    out = {}
+    for img in code_objects(lib_path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(img)
+            f.flush()
+            txt = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True).stdout
+        for blk in txt.split("- .agpr_count:")[1:]:
+            def g(key):
+                m = re.search(r"\." + key + r":\s*(\S+)", blk)
+                return m.group(1) if m else None
+            name = g("name")
+            if not name:
+                continue
+            out[name] = dict(vgpr=int(g("vgpr_count")), sgpr=int(g("sgpr_count")), scratch=int(g("private_segment_fixed_size")),
+                             vgpr_spill=int(g("vgpr_spill_count")), sgpr_spill=int(g("sgpr_spill_count")),
+                             lds=int(g("group_segment_fixed_size")))
+    names = list(out)
+    if names:
+        dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n")
+        out = {re.sub(r"^void |alg::|\(.*$", "", d): v for d, v in zip(dem, out.values())}
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = kernel_resources(sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "lib", "libalgames_hip.so"))
+    pat = sys.argv[2] if len(sys.argv) > 2 else "k_newton_solve|k_ibr|k_mpc_loop"
+    for k in sorted(res):
+        if re.search(pat, k):
+            v = res[k]
+            print("%-52s vgpr %3d sgpr %3d scratch %4d vgpr_spill %3d sgpr_spill %3d lds %5d" % (k, v["vgpr"], v["sgpr"], v["scratch"], v["vgpr_spill"], v["sgpr_spill"], v["lds"]))

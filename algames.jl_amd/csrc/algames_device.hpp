@@ -68,6 +68,22 @@ struct Params {
     alg_record* hist;       // B x hist_max Statistics records
 };
 
+// The handle's parameters are read straight from the kernel-argument segment (constant address space, scalar loads): the
+// kernels take `Params` by value as their FIRST argument and the device code refers to it through this reference type, never
+// through the by-value copy (whose address, once taken, would force a 1.3 KB scratch copy per lane).
+#define ALG_AS4 __attribute__((address_space(4)))
+typedef const ALG_AS4 Params& CPR;
+__device__ __forceinline__ CPR kernel_params() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const ALG_AS4 Params*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return *(const ALG_AS4 Params*)(unsigned long)64;      // host pass: never executed
+#endif
+}
+// Opaque copy of the reference for one phase of the solver (see phase_int below): nothing that is derived from the
+// parameters inside the phase can be hoisted in front of the solver's outer loops.
+__device__ __forceinline__ CPR phase_params(CPR pr) { const ALG_AS4 Params* q = &pr; asm volatile("" : "+s"(q)); return *q; }
+
 // EXT_ = 1 instantiations carry the extended ingredient set of examples/intro_example.jl (state bounds, walls, circles;
 // the bicycle model is always EXT); the EXT_ = 0 instantiations (the BASELINE configurations) pay nothing for it.
 template <int MODEL_, int P_, int D_, int EXT_ = 0>
@@ -90,7 +106,8 @@ struct Cfg {
     static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : (MODEL_ == ALG_MODEL_UNICYCLE) ? 3 : 2;   // max non-zeros of a column of [B_k | A_k]
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
-    static constexpr int WPE = (n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 : 4;
+    // (the 3-D EXT instantiation carries 3 x 3 position blocks and does not fit 128 VGPRs without scratch)
+    static constexpr int WPE = (n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3)) ? 2 : 4;
     // reuse the accepted line-search trial as the next record! (one assemble pass less per Newton iteration)
     static constexpr bool TRIAL_REUSE = true;
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
@@ -113,7 +130,7 @@ template <class C> __device__ __forceinline__ int vd(int N, int k) { return C::P
 template <class C> __device__ __forceinline__ int uoff(int c) { return (c % C::P) * C::mi + c / C::P; }
 template <class C> __device__ __forceinline__ int pairq(int i, int j) { return i * (C::P - 1) + (j < i ? j : j - 1); }
 template <class C> __device__ __forceinline__ int con_col(int N, int q, int k /*knot 1..N-1*/) { return q * (N - 1) + (k - 1); }
-template <class C> __device__ __forceinline__ int con_ctl(const Params& pr, int k, int row) { return pr.col_len + k * 2 * C::m + row; }
+template <class C> __device__ __forceinline__ int con_ctl(CPR pr, int k, int row) { return pr.col_len + k * 2 * C::m + row; }
 
 // state of knot k (0-based) inside a traj buffer
 template <class C> __device__ __forceinline__ const double* zstate(const double* z, int k) { return k == 0 ? z : z + C::n + hx<C>(k - 1); }
@@ -125,7 +142,7 @@ __device__ __forceinline__ int phase_lane() { int l = threadIdx.x; asm volatile(
 // Opaque copies of wave-uniform loop invariants (problem sizes, dt, base pointers), taken at the start of a phase: whatever is
 // derived from them (row counts, address vectors, dt^2 / 2, (double)S ...) is recomputed inside the phase with a handful of
 // scalar instructions instead of being hoisted in front of the solver's outer loops and kept alive -- or spilled -- there.
-__device__ __forceinline__ int phase_int(int v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ int phase_int(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ double phase_f64(double v) { asm volatile("" : "+s"(v)); return v; }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -191,7 +208,7 @@ __device__ __forceinline__ BikeGeom bike_geom(double delta, double lf, double lr
 }
 // Jacobian coefficients of player i at a knot with own state (v, psi) and controls (a, delta)
 template <class C>
-__device__ __forceinline__ void bike_coefs(const Params& pr, double v, double psi, double a, double delta, double dt, double (&cf)[10]) {
+__device__ __forceinline__ void bike_coefs(CPR pr, double v, double psi, double a, double delta, double dt, double (&cf)[10]) {
     const BikeGeom g = bike_geom(delta, pr.lf, pr.lr);
     const double vm = v + (a * dt) * 0.5, psm = psi + (v * g.sg * dt) * 0.5;
     double sn, cs; sincos(g.beta + psm, &sn, &cs);
@@ -202,7 +219,7 @@ __device__ __forceinline__ void bike_coefs(const Params& pr, double v, double ps
     cf[7] = -dt * vm * sn * dth; cf[8] = dt * vm * cs * dth; cf[9] = dt * vm * g.dsg;
 }
 template <class C>
-__device__ __forceinline__ void model_player(const Params& pr, int i, const double* x, const double* u, double dt,
+__device__ __forceinline__ void model_player(CPR pr, int i, const double* x, const double* u, double dt,
                                              double* xn /*ni: entries pz(i,j)*/, double* coef /*4: entries j*P+i (unicycle only)*/) {
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
@@ -240,7 +257,7 @@ __device__ __forceinline__ void model_player(const Params& pr, int i, const doub
 }
 // RK3 step of player i (rollout!, solver_methods.jl:17; RobotDynamics 0.3.1 RK3)
 template <class C>
-__device__ __forceinline__ void model_player_rk3(const Params& pr, int i, const double* x, const double* u, double dt, double* xn) {
+__device__ __forceinline__ void model_player_rk3(CPR pr, int i, const double* x, const double* u, double dt, double* xn) {
     double xi[C::ni], k1[C::ni], k2[C::ni], k3[C::ni], t[C::ni], ui[C::mi];
 #pragma unroll
     for (int j = 0; j < C::ni; j++) xi[j] = x[i + j * C::P];
@@ -411,24 +428,24 @@ struct Game {
     // few scalar instructions instead.
     __device__ __forceinline__ Game fresh() const { Game H = *this; asm volatile("" : "+s"(H.base), "+s"(H.g)); return H; }
     __device__ __forceinline__ double* z(int t) const { return base + zo[t]; }
-    __device__ __forceinline__ const double* x0(const Params& pr) const { return base + pr.o_x0; }
-    __device__ __forceinline__ double* x0w(const Params& pr) const { return base + pr.o_x0; }
-    __device__ __forceinline__ double* res(const Params& pr) const { return base + pr.o_res; }
-    __device__ __forceinline__ double* rec(const Params& pr) const { return base + pr.o_rec; }
-    __device__ __forceinline__ double* kgain(const Params& pr) const { return base + pr.o_kgain; }
-    __device__ __forceinline__ double* tc(const Params& pr) const { return base + pr.o_tc; }
-    __device__ __forceinline__ alg_game_stats* st(const Params& pr) const { return reinterpret_cast<alg_game_stats*>(base + pr.o_st); }
-    __device__ __forceinline__ long long* mpc(const Params& pr) const { return reinterpret_cast<long long*>(base + pr.o_mpc); }
-    __device__ __forceinline__ double* lam(const Params& pr) const { return pr.con + (size_t)g * pr.con_stride; }
-    __device__ __forceinline__ double* mu(const Params& pr) const { return lam(pr) + pr.con_pad; }
-    __device__ __forceinline__ double* vals(const Params& pr) const { return lam(pr) + 2 * pr.con_pad; }
-    __device__ __forceinline__ const double* Qd(const Params& pr) const { return pr.lqr + (size_t)g * pr.lqr_stride; }
-    __device__ __forceinline__ const double* xf(const Params& pr) const { return Qd(pr) + pr.p * pr.ni; }
-    __device__ __forceinline__ const double* Rd(const Params& pr) const { return Qd(pr) + 2 * pr.p * pr.ni; }
-    __device__ __forceinline__ const double* uf(const Params& pr) const { return Qd(pr) + 2 * pr.p * pr.ni + pr.p * pr.mi; }
-    __device__ __forceinline__ alg_record* hist(const Params& pr) const { return pr.hist + (size_t)g * pr.hist_max; }
+    __device__ __forceinline__ const double* x0(CPR pr) const { return base + pr.o_x0; }
+    __device__ __forceinline__ double* x0w(CPR pr) const { return base + pr.o_x0; }
+    __device__ __forceinline__ double* res(CPR pr) const { return base + pr.o_res; }
+    __device__ __forceinline__ double* rec(CPR pr) const { return base + pr.o_rec; }
+    __device__ __forceinline__ double* kgain(CPR pr) const { return base + pr.o_kgain; }
+    __device__ __forceinline__ double* tc(CPR pr) const { return base + pr.o_tc; }
+    __device__ __forceinline__ alg_game_stats* st(CPR pr) const { return reinterpret_cast<alg_game_stats*>(base + pr.o_st); }
+    __device__ __forceinline__ long long* mpc(CPR pr) const { return reinterpret_cast<long long*>(base + pr.o_mpc); }
+    __device__ __forceinline__ double* lam(CPR pr) const { return pr.con + (size_t)g * pr.con_stride; }
+    __device__ __forceinline__ double* mu(CPR pr) const { return lam(pr) + pr.con_pad; }
+    __device__ __forceinline__ double* vals(CPR pr) const { return lam(pr) + 2 * pr.con_pad; }
+    __device__ __forceinline__ const double* Qd(CPR pr) const { return pr.lqr + (size_t)g * pr.lqr_stride; }
+    __device__ __forceinline__ const double* xf(CPR pr) const { return Qd(pr) + pr.p * pr.ni; }
+    __device__ __forceinline__ const double* Rd(CPR pr) const { return Qd(pr) + 2 * pr.p * pr.ni; }
+    __device__ __forceinline__ const double* uf(CPR pr) const { return Qd(pr) + 2 * pr.p * pr.ni + pr.p * pr.mi; }
+    __device__ __forceinline__ alg_record* hist(CPR pr) const { return pr.hist + (size_t)g * pr.hist_max; }
 };
-__device__ __forceinline__ Game game_view(const Params& pr, int g) {
+__device__ __forceinline__ Game game_view(CPR pr, int g) {
     Game G;
     G.base = pr.arena + (size_t)g * pr.stride; G.g = g;
     G.zo[0] = 0; G.zo[1] = pr.o_z1; G.zo[2] = pr.o_z2;
@@ -439,17 +456,17 @@ __device__ __forceinline__ Game game_view(const Params& pr, int g) {
 __device__ __forceinline__ double al_active_mu(double c, double lam, double mu) { return ((c >= 0.0) || (lam > 0.0)) ? mu : 0.0; }
 
 // ---- extended constraints (all on knots 2..N; `k` below is the 0-based step, i.e. knot k+2 of the reference) ----------
-__device__ __forceinline__ int ext_sb_row(const Params& pr, int i, int k, int row) { return pr.col_len + pr.ctl_len + (i * (pr.N - 1) + k) * 2 * pr.n + row; }
-__device__ __forceinline__ int ext_wall_row(const Params& pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + (i * (pr.N - 1) + k) * pr.nwall + w; }
-__device__ __forceinline__ int ext_circ_row(const Params& pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + (i * (pr.N - 1) + k) * pr.ncirc + c; }
-__device__ __forceinline__ const double* ext_sbmax(const Params& pr, const double* ec) { return ec; }
-__device__ __forceinline__ const double* ext_sbmin(const Params& pr, const double* ec) { return ec + pr.p * pr.n; }
-__device__ __forceinline__ const double* ext_walls(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n; }
-__device__ __forceinline__ const double* ext_circs(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS; }
-__device__ __forceinline__ const double* ext_walls3(const Params& pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES; }
-__device__ __forceinline__ const double* ext_cyls(const Params& pr, const double* ec) { return ext_walls3(pr, ec) + 12 * ALG_MAX_WALLS; }
-__device__ __forceinline__ int ext_wall3_row(const Params& pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + (i * (pr.N - 1) + k) * pr.nwall3 + w; }
-__device__ __forceinline__ int ext_cyl_row(const Params& pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + (i * (pr.N - 1) + k) * pr.ncyl + c; }
+__device__ __forceinline__ int ext_sb_row(CPR pr, int i, int k, int row) { return pr.col_len + pr.ctl_len + (i * (pr.N - 1) + k) * 2 * pr.n + row; }
+__device__ __forceinline__ int ext_wall_row(CPR pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + (i * (pr.N - 1) + k) * pr.nwall + w; }
+__device__ __forceinline__ int ext_circ_row(CPR pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + (i * (pr.N - 1) + k) * pr.ncirc + c; }
+__device__ __forceinline__ const double* ext_sbmax(CPR pr, const double* ec) { return ec; }
+__device__ __forceinline__ const double* ext_sbmin(CPR pr, const double* ec) { return ec + pr.p * pr.n; }
+__device__ __forceinline__ const double* ext_walls(CPR pr, const double* ec) { return ec + 2 * pr.p * pr.n; }
+__device__ __forceinline__ const double* ext_circs(CPR pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS; }
+__device__ __forceinline__ const double* ext_walls3(CPR pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES; }
+__device__ __forceinline__ const double* ext_cyls(CPR pr, const double* ec) { return ext_walls3(pr, ec) + 12 * ALG_MAX_WALLS; }
+__device__ __forceinline__ int ext_wall3_row(CPR pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + (i * (pr.N - 1) + k) * pr.nwall3 + w; }
+__device__ __forceinline__ int ext_cyl_row(CPR pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + (i * (pr.N - 1) + k) * pr.ncyl + c; }
 // WallConstraint evaluate / jacobian! (wall_constraint.jl:57-96): c = ((x-x1) xv + (y-y1) yv) left right
 __device__ __forceinline__ double wall_val(const double* W, int w, double x, double y, double* gx, double* gy) {
     const double x1 = W[w], y1 = W[ALG_MAX_WALLS + w], x2 = W[2 * ALG_MAX_WALLS + w], y2 = W[3 * ALG_MAX_WALLS + w];
@@ -577,8 +594,9 @@ struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; doub
 // (player ip's opt rows + all dyn rows, newton_core.jl:205-246), player-specific violations (statistics.jl:59-73), the
 // proximal term only on player ip's rows (global_quantities.jl:262-280); out.l1full is the full ||res||_1 for record!.
 template <class C, int MODE, bool IBR = false>
-__device__ void assemble_pass(const Params& pr, const Game& G0, AsmLds<C>& L, int zsel, int zrefsel, double reg, double jreg,
+__device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, int zrefsel, double reg, double jreg,
                               ResOut& out, int ip = -1) {
+    CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
     const double* __restrict__ z = G.z(zsel);
     const double* __restrict__ zref = zrefsel >= 0 ? G.z(zrefsel) : nullptr;
@@ -902,7 +920,8 @@ __device__ void assemble_pass(const Params& pr, const Game& G0, AsmLds<C>& L, in
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
 typedef double double2_t __attribute__((ext_vector_type(2)));
 template <class C>
-__device__ __forceinline__ void update_traj(const Params& pr, const Game& G0, int tsel, int ssel, double alpha) {
+__device__ __forceinline__ void update_traj(CPR pr0, const Game& G0, int tsel, int ssel, double alpha) {
+    CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
     double* tgt = G.z(tsel); const double* src = G.z(ssel); const double* dz = G.z(2);
     // pure streaming pass: 16 bytes per lane and four independent load pairs in flight per pass.  Every game's buffers start
@@ -934,7 +953,7 @@ __device__ __forceinline__ void update_traj(const Params& pr, const Game& G0, in
 }
 // Δ_step (primal_dual_traj.jl:130-147)
 template <class C>
-__device__ __forceinline__ double delta_step(const Params& pr, const double* dz, double alpha) {
+__device__ __forceinline__ double delta_step(CPR pr, const double* dz, double alpha) {
     double s = 0;
     for (int e = phase_lane(); e < (pr.N - 1) * (C::n + C::m); e += WAVE) {
         const int k = e / (C::n + C::m), a = e % (C::n + C::m);
@@ -1309,7 +1328,8 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
 #define ALG_PROF_FLUSH
 #endif
 template <class C, bool IBR = false>
-__device__ int newton_direction(const Params& pr, const Game& G0, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
+__device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
+    CPR pr = phase_params(pr0);
     Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
     using R = Rec<C>;
@@ -1561,7 +1581,7 @@ __device__ int newton_direction(const Params& pr, const Game& G0, DirLds<C>& L, 
         __syncthreads();
         ALG_PROF(6)
     }
-    if (sing) return ALG_STATUS_SINGULAR;              // wave-uniform (every lane factors the same matrix)
+    if (__builtin_amdgcn_readfirstlane(sing)) return ALG_STATUS_SINGULAR;      // wave-uniform (every lane factors the same matrix)
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 1
     return ALG_STATUS_OK;
 #endif
@@ -1692,13 +1712,13 @@ __device__ int newton_direction(const Params& pr, const Game& G0, DirLds<C>& L, 
     ALG_PROF_FLUSH
     // non-finite direction -> singular (the reference would throw / propagate NaN)
     if (primal_l1) *primal_l1 = wave_sum(pl1);
-    return wave_or(bad) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;
+    return __builtin_amdgcn_readfirstlane(wave_or(bad)) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;     // scalar: the solver's control flow stays on the SALU
 }
 
 // residual_jacobian! + regularize_residual_jacobian! into a dense S x S column-major matrix (global_quantities.jl:109-193).
 // Parity / inspection entry point; built from the same step records and block functions the solver uses.
 template <class C>
-__device__ void jacobian_dense(const Params& pr, const Game& G, double reg, double* J) {
+__device__ void jacobian_dense(CPR pr, const Game& G, double reg, double* J) {
     constexpr int n = C::n, m = C::m, P = C::P;
     using R = Rec<C>;
     const int N = pr.N, lane = threadIdx.x; const size_t S = pr.S; const double dt = pr.dt;
@@ -1751,16 +1771,21 @@ __device__ __forceinline__ double uni(double v) {
 struct RecScalars { double res, opt; int nonfinite; };
 // Statistics of an accepted line-search trial = what the next record! would recompute (same point, same arithmetic)
 // (kept in HBM, G.tc(pr), so that it costs no registers across the Newton direction)
-__device__ __forceinline__ void tcache_store(const Params& pr, const Game& G, const ResOut& ro) {
-    if (threadIdx.x == 0) { G.tc(pr)[0] = ro.l1; G.tc(pr)[1] = ro.opt; G.tc(pr)[2] = ro.dyn; G.tc(pr)[3] = ro.con; G.tc(pr)[4] = ro.sta; G.tc(pr)[5] = (double)ro.nonfinite; }
+__device__ __forceinline__ void tcache_store(CPR pr0, const Game& G0, const ResOut& ro) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    if (phase_lane() == 0) { G.tc(pr)[0] = ro.l1; G.tc(pr)[1] = ro.opt; G.tc(pr)[2] = ro.dyn; G.tc(pr)[3] = ro.con; G.tc(pr)[4] = ro.sta; G.tc(pr)[5] = (double)ro.nonfinite; }
 }
-__device__ __forceinline__ void tcache_load(const Params& pr, const Game& G, ResOut& ro) {
+__device__ __forceinline__ void tcache_load(CPR pr0, const Game& G0, ResOut& ro) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
     ro.l1 = G.tc(pr)[0]; ro.opt = G.tc(pr)[1]; ro.dyn = G.tc(pr)[2]; ro.con = G.tc(pr)[3]; ro.sta = G.tc(pr)[4]; ro.nonfinite = (int)G.tc(pr)[5]; ro.l1reg = ro.l1;
 }
 
-__device__ __forceinline__ RecScalars push_stats(const Params& pr, const Game& G0, const ResOut& ro, double delta, int outer, alg_record* out) {
+__device__ __forceinline__ RecScalars push_stats(CPR pr0, const Game& G0, const ResOut& ro, double delta, int outer, alg_record* out) {
+    CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
-    if (threadIdx.x == 0) {
+    if (phase_lane() == 0) {
         alg_record rc;
         rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
         rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
@@ -1770,11 +1795,11 @@ __device__ __forceinline__ RecScalars push_stats(const Params& pr, const Game& G
         G.st(pr)->last = rc;
         if (out) *out = rc;
     }
-    RecScalars r; r.res = uni(ro.l1 / (double)pr.S); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
+    RecScalars r; r.res = uni(ro.l1 / (double)phase_int(pr.S)); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
     return r;
 }
 template <class C>
-__device__ __forceinline__ RecScalars make_record(const Params& pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
+__device__ __forceinline__ RecScalars make_record(CPR pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
     ResOut ro;
     assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, jreg, ro);
     __syncthreads();
@@ -1784,11 +1809,11 @@ __device__ __forceinline__ RecScalars make_record(const Params& pr, const Game& 
 // line_search (solver_methods.jl:105-125).  jreg_next >= 0: every trial also leaves the unregularised statistics and
 // step records (R^ with jreg_next) so that an accepted trial can serve as the next iteration's record!.
 template <class C>
-__device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double reg, double res_norm0, double jreg_next,
+__device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double res_norm0, double jreg_next,
                             double* alpha_out, int* j_out) {
-    const alg_options& o = pr.opt;
     int j = 1; double alpha = 1.0;
-    while (j < o.ls_iter) {
+    while (j < pr.opt.ls_iter) {
+        const auto& o = phase_params(pr).opt;
         update_traj<C>(pr, G, 1, 0, alpha);
         __syncthreads();
         ResOut ro;
@@ -1798,7 +1823,7 @@ __device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double r
         }
         if (!done) assemble_pass<C, 0>(pr, G, L.a, 1, o.regularize ? 0 : -1, reg, 0.0, ro);
         if (jreg_next >= 0.0) tcache_store(pr, G, ro);
-        const double rt = uni(ro.l1reg / (double)pr.S);
+        const double rt = uni(ro.l1reg / (double)phase_int(phase_params(pr).S));
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
     }
@@ -1808,18 +1833,21 @@ __device__ void line_search(const Params& pr, const Game& G, Lds<C>& L, double r
 // inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
 // the history record / *info (lane 0).  `cache` (optional) carries an accepted trial's statistics to the next call.
 template <class C>
-__device__ int inner_iteration(const Params& pr, Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l,
+__device__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int& LS_count, double& Delta, int k, int l,
                                alg_step_info* info, int* cache_valid) {
-    const alg_options& o = pr.opt;
+    Game& G = G_;
+    CPR pr = phase_params(pr0);
+    const bool lane0 = phase_lane() == 0;
+    const auto& o = pr.opt;
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
-    if (info && threadIdx.x == 0) { alg_step_info z{}; *info = z; }
+    if (info && lane0) { alg_step_info z{}; *info = z; }
     RecScalars rs;                                                         // :73-76 (regularisation term is zero at pdtraj)
     if (cache_valid && *cache_valid) { ResOut cro; tcache_load(pr, G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }
     else rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr);
     if (cache_valid) *cache_valid = 0;
     Delta = 0.0;                                                           // :79
-    auto finish = [&](int status, int flow) { if (info && threadIdx.x == 0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
+    auto finish = [&](int status, int flow) { if (info && lane0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
     if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1);              // :80-82
     double pl1;
@@ -1837,10 +1865,11 @@ __device__ int inner_iteration(const Params& pr, Game& G, Lds<C>& L, int& LS_cou
     // out of trials (alpha was halved once more after the last trial) -> exchange the roles of the two buffers
     if (!failed) { const int t = G.zo[0]; G.zo[0] = G.zo[1]; G.zo[1] = t; }
     else update_traj<C>(pr, G, 0, 0, alpha);
-    { double sd = pl1; sd *= alpha; sd /= (double)((pr.N - 1) * (C::n + C::m)); Delta = uni(sd); }     // :95 Delta_step
+    { double sd = pl1; sd *= alpha; sd /= (double)((phase_int(pr.N) - 1) * (C::n + C::m)); Delta = uni(sd); }     // :95 Delta_step
     __syncthreads();
     if (reuse && !failed) *cache_valid = 1;
-    if (threadIdx.x == 0) {
+    if (lane0) {
+        const Game G = G_.fresh();
         G.st(pr)->newton_iters += 1; if (failed) G.st(pr)->ls_failures += 1;
         const int idx = G.st(pr)->records - 1;
         if (idx < pr.hist_max) { G.hist(pr)[idx].alpha = alpha; G.hist(pr)[idx].ls_j = j; }
@@ -1851,16 +1880,20 @@ __device__ int inner_iteration(const Params& pr, Game& G, Lds<C>& L, int& LS_cou
 }
 
 // reset!(game_con) (constraints_methods.jl:295-327)
-__device__ __forceinline__ void reset_con(const Params& pr, const Game& G) {
-    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) { G.lam(pr)[e] = 0.0; G.mu(pr)[e] = pr.opt.rho_0; }
+__device__ __forceinline__ void reset_con(CPR pr0, const Game& G0) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    for (int e = phase_lane(); e < pr.con_len; e += WAVE) { G.lam(pr)[e] = 0.0; G.mu(pr)[e] = pr.opt.rho_0; }
 }
 // evaluate! + dual_update! + penalty_update! (solver_methods.jl:57-61; constraints_methods.jl:329-379,421-440)
 template <class C>
-__device__ void dual_penalty_update(const Params& pr, const Game& G) {
+__device__ void dual_penalty_update(CPR pr0, const Game& G0) {
+    CPR pr = phase_params(pr0);
     constexpr int n = C::n, m = C::m, P = C::P;
-    const int N = pr.N; const alg_options& o = pr.opt; const double* z = G.z(0);
+    const Game G = G0.fresh();
+    const int N = phase_int(pr.N), tid = phase_lane(); const auto& o = pr.opt; const double* z = G.z(0);
     if (pr.has_colavoid) {
-        for (int e = threadIdx.x; e < pr.col_len; e += WAVE) {
+        for (int e = tid; e < pr.col_len; e += WAVE) {
             constexpr int PM1 = P > 1 ? P - 1 : 1;
             const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / PM1, jj = q % PM1, j = jj < i ? jj : jj + 1;
             const double* x = zstate<C>(z, k);
@@ -1874,7 +1907,7 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
         }
     }
     if (pr.has_ctl) {
-        for (int e = threadIdx.x; e < pr.ctl_len; e += WAVE) {
+        for (int e = tid; e < pr.ctl_len; e += WAVE) {
             const int k = e / (2 * m), row = e % (2 * m), c = row % m;
             const double u = z[n + hu<C>(k, 0) + uoff<C>(c)];
             const double cv = row < m ? u - pr.umax[c] : pr.umin[c] - u;
@@ -1886,7 +1919,7 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
     if constexpr (C::EXT) {
         // state constraints of player i: dual_update! with alphax_dual[i] (constraints_methods.jl:421-440)
         const int e0 = pr.col_len + pr.ctl_len, K = N - 1;
-        for (int e = threadIdx.x; e < pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + pr.cyl_len; e += WAVE) {
+        for (int e = tid; e < pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + pr.cyl_len; e += WAVE) {
             int i, k; double c;
             if (e < pr.sb_len) {
                 const int row = e % (2 * n); k = (e / (2 * n)) % K; i = e / (2 * n * K);
@@ -1917,12 +1950,12 @@ __device__ void dual_penalty_update(const Params& pr, const Game& G) {
             if (isfinite(c)) { const double lb = G.lam(pr)[ci] + o.alphax_dual[i] * G.mu(pr)[ci] * c; G.lam(pr)[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
         }
     }
-    for (int e = threadIdx.x; e < pr.con_len; e += WAVE) G.mu(pr)[e] = fmin(fmax(G.mu(pr)[e] * o.rho_increase, 0.0), o.rho_max);
+    for (int e = tid; e < pr.con_len; e += WAVE) G.mu(pr)[e] = fmin(fmax(G.mu(pr)[e] * o.rho_increase, 0.0), o.rho_max);
 }
 
 // rollout!(RK3, model, traj) (solver_methods.jl:17): lanes < P integrate their own player (players are decoupled)
 template <class C>
-__device__ __forceinline__ void rollout(const Params& pr, double* z) {
+__device__ __forceinline__ void rollout(CPR pr, double* z) {
     constexpr int n = C::n, m = C::m, P = C::P;
     const int lane = threadIdx.x;
     if (lane < P) {
@@ -1939,9 +1972,9 @@ __device__ __forceinline__ void rollout(const Params& pr, double* z) {
 
 // init_traj! (primal_dual_traj.jl:29-44) with the counter RNG (same element counters as the oracle)
 template <class C>
-__device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t game_id, bool use_shift, int shift = -1) {
+__device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bool use_shift, int shift = -1) {
     constexpr int n = C::n, m = C::m, P = C::P;
-    const int N = pr.N, lane = threadIdx.x; const alg_options& o = pr.opt;
+    const int N = pr.N, lane = threadIdx.x; const auto& o = pr.opt;
     const int s = use_shift ? (shift >= 0 ? shift : o.shift) : (1 << 30);
     if (use_shift && s < N) {
         // in-place shift: element e of step k takes element e of step k+s; ascending k is safe within one wave only
@@ -1983,10 +2016,11 @@ __device__ void init_traj(const Params& pr, const Game& G, double* z, uint64_t g
 // After an odd number of buffer exchanges pdtraj lives in the trial buffer: move it home (and leave the trial buffer with
 // the previous iterate, as update_traj! would have)
 template <class C>
-__device__ __forceinline__ void settle_traj(const Params& pr, Game& G) {
+__device__ __forceinline__ void settle_traj(CPR pr, Game& G) {
     if (G.zo[0] != 0) {
         __syncthreads();
-        double* a = G.z(0); double* z_home = G.base;
+        const Game H = G.fresh();
+        double* a = H.z(0); double* z_home = H.base;
         for (int e = phase_lane(); e < pr.traj_len; e += WAVE) { const double v = a[e]; a[e] = z_home[e]; z_home[e] = v; }
         G.zo[1] = G.zo[0]; G.zo[0] = 0;
         __syncthreads();
@@ -1995,9 +2029,9 @@ __device__ __forceinline__ void settle_traj(const Params& pr, Game& G) {
 
 // newton_solve! (solver_methods.jl:5-65)
 template <class C>
-__device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
-    const alg_options& o = pr.opt; const int lane = threadIdx.x;
-    if (lane == 0) { alg_game_stats z{}; *G.st(pr) = z; }                       // reset!(prob.stats)
+__device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
+    const auto& o = pr.opt; const int lane = phase_lane();
+    if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; } // reset!(prob.stats)
 #ifndef ALG_TEST_NOINIT
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
     else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
@@ -2007,7 +2041,7 @@ __device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& 
 #endif
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con(pr, G);     // :25
     __syncthreads();
-    int out = 0, status = ALG_STATUS_OK, converged = 0; double Delta = 0.0;
+    int out = 0, status = ALG_STATUS_OK; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30
         out = k;
         int LS_count = 0;
@@ -2020,10 +2054,11 @@ __device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& 
         if (status != ALG_STATUS_OK) break;
         __syncthreads();
         // prob.stats.*_vio[end]: the record made at the top of the last inner iteration (lane 0 wrote it; same wave)
-        const alg_record& last = G.st(pr)->last;
+        alg_game_stats* const stk = G.fresh().st(phase_params(pr));
+        const alg_record& last = stk->last;
         const bool conv = last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
         const int convu = __builtin_amdgcn_readfirstlane((int)conv);
-        if (convu) converged = 1;
+        if (convu && phase_lane() == 0) stk->converged = 1;          // written where it is decided (one loop-carried scalar less)
         if (k == o.outer_iter || convu) break;                             // :49-55
         dual_penalty_update<C>(pr, G);                                     // :57-61
         __syncthreads();
@@ -2031,7 +2066,7 @@ __device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& 
     __syncthreads();
     make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);                    // :63
     settle_traj<C>(pr, G);
-    if (lane == 0) { G.st(pr)->status = status; G.st(pr)->outer_iters = out; G.st(pr)->converged = converged; }
+    if (phase_lane() == 0) { alg_game_stats* st = G.fresh().st(phase_params(pr)); st->status = status; st->outer_iters = out; }
 }
 
 // ================================================================================================
@@ -2040,7 +2075,7 @@ __device__ __forceinline__ void newton_solve(const Params& pr, Game& G, Lds<C>& 
 // record!(stats, ..., k, i) (statistics.jl:59-73): full residual norm + player-specific violations; also tracks
 // maximum(stats.Δ_traj) (G.tc(pr)[6]) for the exit test of ibr_newton_solve! (:157).  Returns the masked norm / opt violation.
 template <class C>
-__device__ __forceinline__ RecScalars ibr_push_stats(const Params& pr, const Game& G, const ResOut& ro, double delta, int outer) {
+__device__ __forceinline__ RecScalars ibr_push_stats(CPR pr, const Game& G, const ResOut& ro, double delta, int outer) {
     const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));            // length(verti_mask)
     if (threadIdx.x == 0) {
         alg_record rc;
@@ -2057,8 +2092,8 @@ __device__ __forceinline__ RecScalars ibr_push_stats(const Params& pr, const Gam
 }
 // ibr_inner_iteration (solver_methods.jl:230-268)
 template <class C>
-__device__ int ibr_inner_iteration(const Params& pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l, int ip) {
-    const alg_options& o = pr.opt;
+__device__ int ibr_inner_iteration(CPR pr, const Game& G, Lds<C>& L, int& LS_count, double& Delta, int k, int l, int ip) {
+    const auto& o = pr.opt;
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);
     const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));
@@ -2097,8 +2132,8 @@ __device__ int ibr_inner_iteration(const Params& pr, const Game& G, Lds<C>& L, i
 }
 // ibr_newton_solve!(prob, i) (solver_methods.jl:171-228)
 template <class C>
-__device__ int ibr_solve_player(const Params& pr, const Game& G, Lds<C>& L, int ip) {
-    const alg_options& o = pr.opt; const int lane = threadIdx.x;
+__device__ int ibr_solve_player(CPR pr, const Game& G, Lds<C>& L, int ip) {
+    const auto& o = pr.opt; const int lane = threadIdx.x;
     if (o.dual_reset) {                                                            // :181-185
         reset_con(pr, G);
         for (int e = lane; e < (pr.N - 1) * C::P * C::n; e += WAVE) {              // reset_duals!(pdtraj), reset_duals!(pdtraj_trial)
@@ -2138,7 +2173,7 @@ struct IbrOrder { int v[MAXP]; };
 // ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169); single = true runs ibr_newton_solve!(prob, player) on the stored
 // trajectory instead (one best response, no initialisation).  One call site of ibr_solve_player: it stays inlined.
 template <class C>
-__device__ void ibr_newton_solve(const Params& pr, const Game& G, Lds<C>& L, bool single, int player, int init, uint64_t game_id,
+__device__ void ibr_newton_solve(CPR pr, const Game& G, Lds<C>& L, bool single, int player, int init, uint64_t game_id,
                                  int ibr_iter, const IbrOrder& order, double delta_min) {
     const int lane = threadIdx.x;
     if (!single) {

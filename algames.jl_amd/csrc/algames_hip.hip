@@ -11,7 +11,8 @@
 // the EXT instantiations are defined in algames_ext_*.hip
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
 
-__global__ void __launch_bounds__(WAVE) k_reset_con(Params pr) {
+__global__ void __launch_bounds__(WAVE) k_reset_con(Params pr_arg) {
+    CPR pr = kernel_params();
     Game G = game_view(pr, blockIdx.x);
     reset_con(pr, G);
 }

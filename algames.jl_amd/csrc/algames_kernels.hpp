@@ -10,16 +10,18 @@ using namespace alg;
 // Kernels
 // ------------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr, int init, uint64_t game_id0) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr_arg, int init, uint64_t game_id0) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, int k, int l, const double* delta_in, alg_step_info* out) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr_arg, int k, int l, const double* delta_in, alg_step_info* out) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     int ls = 0; double dl = delta_in ? delta_in[g] : 0.0;          // the caller's Δ goes into record! (solver_methods.jl:75)
@@ -28,8 +30,9 @@ __global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr, int k, 
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_residual(Params pr, int which, double reg, double* rn_out) {
+__global__ void __launch_bounds__(WAVE) k_residual(Params pr_arg, int which, double reg, double* rn_out) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     ResOut ro;
@@ -40,8 +43,9 @@ __global__ void __launch_bounds__(WAVE) k_residual(Params pr, int which, double 
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, double reg, double* J) {
+__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr_arg, double reg, double* J) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     ResOut ro;
@@ -51,8 +55,9 @@ __global__ void __launch_bounds__(WAVE) k_jacobian(Params pr, double reg, double
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr, double reg, int* status) {
+__global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr_arg, double reg, int* status) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     ResOut ro;
@@ -63,8 +68,9 @@ __global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr, double re
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_line_search(Params pr, double reg, const double* rn, double* alpha, int* j) {
+__global__ void __launch_bounds__(WAVE) k_line_search(Params pr_arg, double reg, const double* rn, double* alpha, int* j) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     double a; int jj;
@@ -73,29 +79,33 @@ __global__ void __launch_bounds__(WAVE) k_line_search(Params pr, double reg, con
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_update(Params pr, int tgt, int src, const double* alpha) {
+__global__ void __launch_bounds__(WAVE) k_update(Params pr_arg, int tgt, int src, const double* alpha) {
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     update_traj<C>(pr, G, tgt, src, alpha[g]);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_record(Params pr, alg_record* out) {
+__global__ void __launch_bounds__(WAVE) k_record(Params pr_arg, alg_record* out) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     make_record<C>(pr, G, L, 0.0, 0, 0.0, out + g);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_dual_update(Params pr) {
+__global__ void __launch_bounds__(WAVE) k_dual_update(Params pr_arg) {
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     dual_penalty_update<C>(pr, G);
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_init(Params pr, uint64_t game_id0, int use_shift, int do_init, int which) {
+__global__ void __launch_bounds__(WAVE) k_init(Params pr_arg, uint64_t game_id0, int use_shift, int do_init, int which) {
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     if (do_init) {
@@ -110,9 +120,10 @@ __global__ void __launch_bounds__(WAVE) k_init(Params pr, uint64_t game_id0, int
 
 // mode 0: ibr_newton_solve!(prob, player) on the stored trajectory ; mode 1: ibr_newton_solve!(prob; ibr_opts)
 template <class C>
-__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, int mode, int player, int init, uint64_t game_id0,
+__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr_arg, int mode, int player, int init, uint64_t game_id0,
                                                       int ibr_iter, IbrOrder order, double delta_min) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     ibr_newton_solve<C>(pr, G, L, mode == 0, player, init, game_id0 + (uint64_t)g, ibr_iter, order, delta_min);
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr, int mode, int player
 
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
 template <class C>
-__device__ __forceinline__ void mpc_advance(const Params& pr, const Game& G) {
+__device__ __forceinline__ void mpc_advance(CPR pr, const Game& G) {
     const int lane = threadIdx.x;
     if (lane < C::P) {
         double x[C::n], u[C::m], xo[C::ni], co[4];
@@ -135,7 +146,8 @@ __device__ __forceinline__ void mpc_advance(const Params& pr, const Game& G) {
     if (lane == 0) { G.mpc(pr)[0] += G.st(pr)->newton_iters; G.mpc(pr)[1] += G.st(pr)->converged; }
 }
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr) {
+__global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr_arg) {
+    CPR pr = kernel_params();
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
     mpc_advance<C>(pr, G);
@@ -150,8 +162,9 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr) {
 // one faulted on a null base pointer (tests/test_gpu_parity_ext.py::test_no_kernel_writes_outside_its_buffers runs this
 // kernel for every instantiation).
 template <class C>
-__global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr, int steps, uint64_t game_id0, double* states) {
+__global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr_arg, int steps, uint64_t game_id0, double* states) {
     __shared__ Lds<C> L;
+    CPR pr = kernel_params();
     const int g = blockIdx.x, lane = threadIdx.x;
     Game G = game_view(pr, g);
     if (states && lane < C::n) states[(size_t)g * C::n + lane] = G.x0(pr)[lane];

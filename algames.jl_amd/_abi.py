@@ -86,6 +86,8 @@ SIGNATURES = {
     "add_state_bound": (C.c_int, [_P, C.c_int32, _D, _D]),
     "add_wall_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D, _D, _D]),
     "add_circle_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
+    "add_wall_constraint_player": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D, _D, _D, _D, _D]),
+    "add_circle_constraint_player": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D, _D]),
     "add_spherical_collision_avoidance": (C.c_int, [_P, _D]),
     "add_wall3d_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D]),
     "add_cylinder_constraint": (C.c_int, [_P, C.c_int32, _D, _I, _D, _D]),
@@ -271,6 +273,16 @@ class Batch:
     def add_circle_constraint(self, xc, yc, radius):
         arrs = [_f64(a) for a in (xc, yc, radius)]
         self.lib.check(self.lib.add_circle_constraint(self.h, len(arrs[0]), *[_dptr(a) for a in arrs]))
+        self._refresh_con_len()
+
+    def add_wall_constraint_player(self, player, x1, y1, x2, y2, xv, yv):
+        arrs = [_f64(a) for a in (x1, y1, x2, y2, xv, yv)]
+        self.lib.check(self.lib.add_wall_constraint_player(self.h, int(player), len(arrs[0]), *[_dptr(a) for a in arrs]))
+        self._refresh_con_len()
+
+    def add_circle_constraint_player(self, player, xc, yc, radius):
+        arrs = [_f64(a) for a in (xc, yc, radius)]
+        self.lib.check(self.lib.add_circle_constraint_player(self.h, int(player), len(arrs[0]), *[_dptr(a) for a in arrs]))
         self._refresh_con_len()
 
     def add_spherical_collision_avoidance(self, radius):

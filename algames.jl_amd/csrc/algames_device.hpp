@@ -49,6 +49,10 @@ struct Params {
     int ext, has_sb, nwall, ncirc, sb_len, wall_len, circ_len;
     int nwall3, ncyl, wall3_len, cyl_len, ca_dim;   // 3-D half (Cfg::PD == 3 only): Wall3D, Cylinder, spherical collision avoidance (ca_dim = 3)
     double lf, lr;          // BicycleGame(lf, lr), bicycle.jl:15
+    // per-player wall / circle sets (add_wall_constraint!(game_con, i, walls), add_circle_constraint!(game_con, i, ...),
+    // constraints_methods.jl:121-139, 161-187): bit w of wall_mask[i] = table entry w constrains player i.  A row whose bit is
+    // clear evaluates to c = 0 with a zero Jacobian -- exactly inert in the AL terms, the violations and the dual update.
+    unsigned wall_mask[MAXP], circ_mask[MAXP];
     // ---- device memory of the handle (filled in by the host; see the "Per-game data view" section) ----------------------
     // main arena: B x stride doubles; one contiguous, 128-byte aligned chunk per game holding every per-game array at the
     // offsets below (doubles, multiples of 16): [pdtraj | trial | delta | x0 | res | rec | kgain | tcache | stats | mpc totals]
@@ -82,7 +86,15 @@ __device__ __forceinline__ CPR kernel_params() {
 }
 // Opaque copy of the reference for one phase of the solver (see phase_int below): nothing that is derived from the
 // parameters inside the phase can be hoisted in front of the solver's outer loops.
-__device__ __forceinline__ CPR phase_params(CPR pr) { const ALG_AS4 Params* q = &pr; asm volatile("" : "+s"(q)); return *q; }
+// (readfirstlane first: inside a function the inliner left out of line, arguments arrive in VGPRs; on a value that already
+// lives in SGPRs the compiler folds it away)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    v = ((unsigned long long)hi << 32) | lo;
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ CPR phase_params(CPR pr) { return *(const ALG_AS4 Params*)uniform_u64((unsigned long long)&pr); }
 
 // EXT_ = 1 instantiations carry the extended ingredient set of examples/intro_example.jl (state bounds, walls, circles;
 // the bicycle model is always EXT); the EXT_ = 0 instantiations (the BASELINE configurations) pay nothing for it.
@@ -143,7 +155,7 @@ __device__ __forceinline__ int phase_lane() { int l = threadIdx.x; asm volatile(
 // derived from them (row counts, address vectors, dt^2 / 2, (double)S ...) is recomputed inside the phase with a handful of
 // scalar instructions instead of being hoisted in front of the solver's outer loops and kept alive -- or spilled -- there.
 __device__ __forceinline__ int phase_int(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
-__device__ __forceinline__ double phase_f64(double v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ double phase_f64(double v) { return __longlong_as_double((long long)uniform_u64((unsigned long long)__double_as_longlong(v))); }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -426,7 +438,12 @@ struct Game {
     // Opaque copy for one phase of the solver: addresses derived from it cannot be hoisted out of the solver's outer loops
     // (where the base pointers of every phase would be live -- and spilled -- at once); they are recomputed per phase with a
     // few scalar instructions instead.
-    __device__ __forceinline__ Game fresh() const { Game H = *this; asm volatile("" : "+s"(H.base), "+s"(H.g)); return H; }
+    __device__ __forceinline__ Game fresh() const {
+        Game H = *this;
+        H.base = reinterpret_cast<double*>(uniform_u64(reinterpret_cast<unsigned long long>(base)));
+        H.g = __builtin_amdgcn_readfirstlane(g); asm volatile("" : "+s"(H.g));
+        return H;
+    }
     __device__ __forceinline__ double* z(int t) const { return base + zo[t]; }
     __device__ __forceinline__ const double* x0(CPR pr) const { return base + pr.o_x0; }
     __device__ __forceinline__ double* x0w(CPR pr) const { return base + pr.o_x0; }
@@ -711,8 +728,17 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                         if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
                     };
                     const double* Wc = ext_walls(pr, pr.extc); const double* Cc = ext_circs(pr, pr.extc);
-                    for (int wq = 0; wq < pr.nwall; wq++) { double g[PD] = {}; const double c = wall_val(Wc, wq, xi[0], xi[1], &g[0], &g[1]); al_row(ext_wall_row(pr, i, k, wq), c, g); }
-                    for (int cq = 0; cq < pr.ncirc; cq++) { double g[PD] = {}; const double c = circ_val(Cc, cq, xi[0], xi[1], &g[0], &g[1]); al_row(ext_circ_row(pr, i, k, cq), c, g); }
+                    const unsigned wmask = pr.wall_mask[i], cmask = pr.circ_mask[i];
+                    for (int wq = 0; wq < pr.nwall; wq++) {
+                        double g[PD] = {}; const double on = (double)((wmask >> wq) & 1u);
+                        const double c = on * wall_val(Wc, wq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
+                        al_row(ext_wall_row(pr, i, k, wq), c, g);
+                    }
+                    for (int cq = 0; cq < pr.ncirc; cq++) {
+                        double g[PD] = {}; const double on = (double)((cmask >> cq) & 1u);
+                        const double c = on * circ_val(Cc, cq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
+                        al_row(ext_circ_row(pr, i, k, cq), c, g);
+                    }
                     if constexpr (PD == 3) {
                         const double* W3 = ext_walls3(pr, pr.extc); const double* Yc = ext_cyls(pr, pr.extc);
                         for (int wq = 0; wq < pr.nwall3; wq++) { double g[3]; const double c = wall3_val(W3, wq, xi, g); al_row(ext_wall3_row(pr, i, k, wq), c, g); }
@@ -1928,11 +1954,11 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
             } else if (e < pr.sb_len + pr.wall_len) {
                 const int e2 = e - pr.sb_len, w = e2 % pr.nwall; k = (e2 / pr.nwall) % K; i = e2 / (pr.nwall * K);
                 const double* x = zstate<C>(z, k + 1); double gx, gy;
-                c = wall_val(ext_walls(pr, pr.extc), w, x[i], x[P + i], &gx, &gy);
+                c = (double)((pr.wall_mask[i] >> w) & 1u) * wall_val(ext_walls(pr, pr.extc), w, x[i], x[P + i], &gx, &gy);
             } else if (e < pr.sb_len + pr.wall_len + pr.circ_len) {
                 const int e2 = e - pr.sb_len - pr.wall_len, cq = e2 % pr.ncirc; k = (e2 / pr.ncirc) % K; i = e2 / (pr.ncirc * K);
                 const double* x = zstate<C>(z, k + 1); double gx, gy;
-                c = circ_val(ext_circs(pr, pr.extc), cq, x[i], x[P + i], &gx, &gy);
+                c = (double)((pr.circ_mask[i] >> cq) & 1u) * circ_val(ext_circs(pr, pr.extc), cq, x[i], x[P + i], &gx, &gy);
             } else {
                 i = 0; k = 0; c = 0.0;
                 if constexpr (C::PD == 3) {

@@ -50,6 +50,7 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.ctl_len = 2 * p.m * (p.N - 1);
     p.con_len = p.col_len + p.ctl_len;
     p.ext = (a.model == ALG_MODEL_BICYCLE) ? 1 : 0;                      // the bicycle kernels are EXT instantiations
+    for (int i = 0; i < MAXP; i++) p.wall_mask[i] = p.circ_mask[i] = 0xffffffffu;
     p.ca_dim = 2;
     p.hist_max = HIST_MAX;
     p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
@@ -108,6 +109,7 @@ struct Handle {
     double* d_lqr = nullptr;      // B x lqr_block (sized for the per-game case)
     double* d_extc = nullptr;
     std::vector<double> extc;     // host copy of pr.extc
+    long long solves_since_reset = 0;   // solves whose records share the Statistics history (best responses accumulate)
     void* d_scratch = nullptr;    // grow-only scratch of the inspection entry points (dense Jacobians, MPC state logs)
     size_t scratch_bytes = 0;
 };
@@ -222,9 +224,17 @@ int ensure_hist(Handle* hd, long long need) {
     need = std::min(std::max<long long>(need, HIST_MAX), cap);
     if (p.hist && need <= p.hist_max) return ALG_OK;
     HIPCHK(hipStreamSynchronize(hd->stream));
-    if (p.hist) dfree(hd, p.hist);
-    p.hist = nullptr; p.hist_max = (int)need;
-    return dalloc(hd, &p.hist, (size_t)p.B * p.hist_max, "Statistics history");
+    alg_record* old = p.hist; const int old_max = p.hist_max;
+    alg_record* fresh = nullptr;
+    int rc = dalloc(hd, &fresh, (size_t)p.B * (size_t)need, "Statistics history"); if (rc) return rc;
+    if (old) {                                      // records accumulate over best-response solves: keep what is there
+        HIPCHK(hipMemcpy2DAsync(fresh, sizeof(alg_record) * (size_t)need, old, sizeof(alg_record) * (size_t)old_max,
+                                sizeof(alg_record) * (size_t)old_max, p.B, hipMemcpyDeviceToDevice, hd->stream));
+        HIPCHK(hipStreamSynchronize(hd->stream));
+        dfree(hd, old);
+    }
+    p.hist = fresh; p.hist_max = (int)need;
+    return ALG_OK;
 }
 int ensure_scratch(Handle* hd, size_t bytes) {
     if (bytes <= hd->scratch_bytes) return ALG_OK;
@@ -434,6 +444,31 @@ int alg_add_wall_constraint(alg_handle* h, int32_t nw, const double* x1, const d
     const double* src[6] = {x1, y1, x2, y2, xv, yv};
     for (int f = 0; f < 6; f++) for (int w = 0; w < nw; w++) W[f * ALG_MAX_WALLS + w] = src[f][w];
     p.nwall = nw;
+    for (int i = 0; i < MAXP; i++) p.wall_mask[i] = 0xffffffffu;      // one set, every player
+    return ext_commit(H);
+}
+// add_wall_constraint!(game_con, i, walls) (constraints_methods.jl:161-187): the walls join the table (an entry that is already
+// there is shared) and constrain player `player` only
+int alg_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t nw, const double* x1, const double* y1, const double* x2, const double* y2, const double* xv, const double* yv) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: null handle");
+    Params& p = H->pr;
+    if (player < 0 || player >= p.p) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: bad player index");
+    if (nw < 0 || (nw > 0 && (!x1 || !y1 || !x2 || !y2 || !xv || !yv))) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: bad argument");
+    double* W = H->extc.data() + 2 * p.p * p.n;
+    const double* src[6] = {x1, y1, x2, y2, xv, yv};
+    if (p.nwall == 0) for (int i = 0; i < MAXP; i++) p.wall_mask[i] = 0u;       // first per-player set: nothing applies yet
+    Params q = p;                                                               // commit only if every wall fits
+    for (int w = 0; w < nw; w++) {
+        int at = -1;
+        for (int e = 0; e < q.nwall && at < 0; e++) { bool same = true; for (int f = 0; f < 6; f++) same &= (W[f * ALG_MAX_WALLS + e] == src[f][w]); if (same) at = e; }
+        if (at < 0) {
+            if (q.nwall >= ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: more than ALG_MAX_WALLS distinct walls");
+            at = q.nwall++;
+            for (int f = 0; f < 6; f++) W[f * ALG_MAX_WALLS + at] = src[f][w];
+        }
+        q.wall_mask[player] |= 1u << at;
+    }
+    p.nwall = q.nwall; for (int i = 0; i < MAXP; i++) p.wall_mask[i] = q.wall_mask[i];
     return ext_commit(H);
 }
 int alg_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const double* yc, const double* rad) {
@@ -444,6 +479,30 @@ int alg_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const
     const double* src[3] = {xc, yc, rad};
     for (int f = 0; f < 3; f++) for (int c = 0; c < nc; c++) Cc[f * ALG_MAX_CIRCLES + c] = src[f][c];
     p.ncirc = nc;
+    for (int i = 0; i < MAXP; i++) p.circ_mask[i] = 0xffffffffu;      // one set, every player
+    return ext_commit(H);
+}
+// add_circle_constraint!(game_con, i, xc, yc, radius) (constraints_methods.jl:121-139): as alg_add_wall_constraint_player
+int alg_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t nc, const double* xc, const double* yc, const double* rad) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_circle_constraint_player: null handle");
+    Params& p = H->pr;
+    if (player < 0 || player >= p.p) return fail(ALG_ERR_ARG, "alg_add_circle_constraint_player: bad player index");
+    if (nc < 0 || (nc > 0 && (!xc || !yc || !rad))) return fail(ALG_ERR_ARG, "alg_add_circle_constraint_player: bad argument");
+    double* Cc = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS;
+    const double* src[3] = {xc, yc, rad};
+    if (p.ncirc == 0) for (int i = 0; i < MAXP; i++) p.circ_mask[i] = 0u;
+    Params q = p;
+    for (int c = 0; c < nc; c++) {
+        int at = -1;
+        for (int e = 0; e < q.ncirc && at < 0; e++) { bool same = true; for (int f = 0; f < 3; f++) same &= (Cc[f * ALG_MAX_CIRCLES + e] == src[f][c]); if (same) at = e; }
+        if (at < 0) {
+            if (q.ncirc >= ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "alg_add_circle_constraint_player: more than ALG_MAX_CIRCLES distinct circles");
+            at = q.ncirc++;
+            for (int f = 0; f < 3; f++) Cc[f * ALG_MAX_CIRCLES + at] = src[f][c];
+        }
+        q.circ_mask[player] |= 1u << at;
+    }
+    p.ncirc = q.ncirc; for (int i = 0; i < MAXP; i++) p.circ_mask[i] = q.circ_mask[i];
     return ext_commit(H);
 }
 // ---- 3-D half (pz[i][1:3] = positions of DoubleIntegrator d = 3) -------------------------------------------------------
@@ -605,6 +664,8 @@ int alg_dual_penalty_update(alg_handle* h, double* vals) {
 int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, const double* delta_in, alg_step_info* info) {
     NEED_HANDLE("alg_newton_step");
     int rc = use_device(H); if (rc) return rc;
+    H->solves_since_reset += 1;                   // one more record! in the shared Statistics history
+    if ((rc = ensure_hist(H, H->solves_since_reset * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
     const double* d_delta = nullptr;
     if (delta_in) { if ((rc = h2d(H, H->d_tmp, delta_in, sizeof(double) * H->pr.B))) return rc; d_delta = H->d_tmp; }
     LAUNCH(k_newton_step, H->pr, (int)k_outer, (int)l_inner, d_delta, H->d_info);
@@ -616,6 +677,7 @@ int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) {
     NEED_HANDLE("alg_newton_solve");
     int rc = use_device(H); if (rc) return rc;
     if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_newton_solve: x0 / LQR data not set");
+    H->solves_since_reset = 1;                    // newton_solve! starts with reset!(prob.stats)
     LAUNCH(k_newton_solve, H->pr, (int)init, (uint64_t)game_id0);
     return ALG_OK;
 }
@@ -681,8 +743,9 @@ int alg_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats) {
     NEED_HANDLE("alg_ibr_solve_player");
     int rc = use_device(H); if (rc) return rc;
     if (player < 0 || player >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_solve_player: bad player index");
-    // statistics accumulate over the players' solves (the reference does not reset them): room for p more solves
-    if ((rc = ensure_hist(H, (long long)H->pr.hist_max + (long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1))) return rc;
+    // statistics accumulate over the players' solves (the reference does not reset them between players): room for one more
+    H->solves_since_reset += 1;
+    if ((rc = ensure_hist(H, (long long)(H->solves_since_reset + 1) * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
     IbrOrder order{};
     LAUNCH(k_ibr, H->pr, 0, (int)player, 0, (uint64_t)0, 1, order, 0.0);
     if (stats) return alg_get_stats(h, stats);
@@ -697,6 +760,7 @@ int alg_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t 
     for (int i = 0; i < H->pr.p; i++) { if (ordering[i] < 0 || ordering[i] >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: ordering entries must be player ids"); order.v[i] = ordering[i]; }
     // records accumulate over rounds and players: ibr_iter * p * (outer_iter * inner_iter + 1) at most
     if ((rc = ensure_hist(H, (long long)ibr_iter * H->pr.p * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
+    H->solves_since_reset = (long long)ibr_iter * H->pr.p;
     LAUNCH(k_ibr, H->pr, 1, 0, (int)init, (uint64_t)game_id0, (int)ibr_iter, order, delta_min);
     if (stats) return alg_get_stats(h, stats);
     return sync(H);

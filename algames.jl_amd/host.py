@@ -282,6 +282,8 @@ class GameConstraintValues:
         self.state_conval = [[] for _ in range(probsize.p)]   # per player: the state-bound sets in the order they were added
         self.walls = None
         self.circles = None
+        self.player_walls = {}           # player (1-based) -> list of Wall (add_wall_constraint!(game_con, i, walls))
+        self.player_circles = {}         # player (1-based) -> (xc, yc, radius) (add_circle_constraint!(game_con, i, ...))
         self.spherical = False           # collision_radius applies to the 3-D distance (add_spherical_collision_avoidance!)
         self.walls3d = None
         self.cylinders = None
@@ -388,25 +390,49 @@ class CylinderWall:
         self.l, self.r = float(l), float(r)
 
 
-def add_wall_constraint(game_con, walls):
-    """add_wall_constraint!(game_con, walls), constraints_methods.jl:189-195 (every player); dispatches on the wall type like the
-    reference's methods for Vector{Wall} (:161), Vector{Wall3D} (:208) and Vector{CylinderWall} (:256)."""
+def add_wall_constraint(game_con, *args):
+    """add_wall_constraint!(game_con, walls) (constraints_methods.jl:189-195, every player) or add_wall_constraint!(game_con, i, walls)
+    (:161-187, player i only, 1-based); dispatches on the wall type like the reference's methods for Vector{Wall} (:161),
+    Vector{Wall3D} (:208) and Vector{CylinderWall} (:256)."""
+    if len(args) == 2:
+        i, walls = int(args[0]), list(args[1])
+        if not 1 <= i <= game_con.probsize.p:
+            raise ValueError("add_wall_constraint: player index out of range")
+        if not all(isinstance(w, Wall) for w in walls):
+            raise TypeError("add_wall_constraint(game_con, i, walls): planar Wall objects only (the reference defines this method for Vector{Wall})")
+        if game_con.walls is not None:
+            raise AlgamesError("per-player walls cannot be combined with an all-player wall set")
+        game_con.player_walls.setdefault(i, []).extend(walls)
+        return
+    (walls,) = args
     walls = list(walls)
     kinds = {type(w) for w in walls}
     if len(kinds) != 1:
         raise TypeError("add_wall_constraint: walls must all be Wall, all Wall3D or all CylinderWall")
     slot = {Wall: "walls", Wall3D: "walls3d", CylinderWall: "cylinders"}[kinds.pop()]
-    if getattr(game_con, slot) is not None:
+    if getattr(game_con, slot) is not None or (slot == "walls" and game_con.player_walls):
         raise AlgamesError("only one wall set of each kind per GameConstraintValues is supported")
     setattr(game_con, slot, walls)
 
 
-def add_circle_constraint(game_con, xc, yc, radius):
-    """add_circle_constraint!(game_con, xc, yc, radius), constraints_methods.jl:141-148 (every player)."""
-    xc, yc, radius = (np.asarray(a, dtype=np.float64) for a in (xc, yc, radius))
+def add_circle_constraint(game_con, *args):
+    """add_circle_constraint!(game_con, xc, yc, radius) (constraints_methods.jl:141-148, every player) or
+    add_circle_constraint!(game_con, i, xc, yc, radius) (:121-139, player i only, 1-based)."""
+    player = None
+    if len(args) == 4:
+        player, args = int(args[0]), args[1:]
+        if not 1 <= player <= game_con.probsize.p:
+            raise ValueError("add_circle_constraint: player index out of range")
+    xc, yc, radius = (np.asarray(a, dtype=np.float64) for a in args)
     if not (xc.shape == yc.shape == radius.shape and xc.ndim == 1):
         raise ValueError("xc, yc, radius must be vectors of equal length")
-    if game_con.circles is not None:
+    if player is not None:
+        if game_con.circles is not None:
+            raise AlgamesError("per-player circles cannot be combined with an all-player circle set")
+        old = game_con.player_circles.get(player)
+        game_con.player_circles[player] = (xc, yc, radius) if old is None else tuple(np.concatenate([o, a]) for o, a in zip(old, (xc, yc, radius)))
+        return
+    if game_con.circles is not None or game_con.player_circles:
         raise AlgamesError("only one circle set per GameConstraintValues is supported")
     game_con.circles = (xc, yc, radius)
 
@@ -559,6 +585,12 @@ class GameProblem:
                                            [a.p2[1] for a in w], [a.v[0] for a in w], [a.v[1] for a in w])
         if game_con.circles is not None:
             self.batch.add_circle_constraint(*game_con.circles)
+        for i in sorted(game_con.player_walls):
+            w = game_con.player_walls[i]
+            self.batch.add_wall_constraint_player(i - 1, [a.p1[0] for a in w], [a.p1[1] for a in w], [a.p2[0] for a in w],
+                                                  [a.p2[1] for a in w], [a.v[0] for a in w], [a.v[1] for a in w])
+        for i in sorted(game_con.player_circles):
+            self.batch.add_circle_constraint_player(i - 1, *game_con.player_circles[i])
         if game_con.walls3d:
             w = game_con.walls3d
             self.batch.add_wall3d_constraint([a.p1 for a in w], [a.p2 for a in w], [a.p3 for a in w], [a.v for a in w])

@@ -1,19 +1,25 @@
 # AlgamesHIP.jl -- Julia host shim over the C ABI of libalgames_hip.so (include/algames_hip.h).
 #
-# UNEXECUTED IN THIS ENVIRONMENT: neither the build container nor the GPU box has a `julia` binary
-# (SURVEY.md section 0), so this file is the binding a maintainer of Algames.jl would add; every call it makes
-# is exercised through the identical ctypes binding (algames.jl_amd/_abi.py) by the test-suite.
+# UNTESTED IN THIS ENVIRONMENT: neither the build container nor the GPU box has a `julia` binary (SURVEY.md section 0), so
+# this file is the binding a maintainer of Algames.jl would add.  Every ABI call it makes, in the order it makes them, is
+# mirrored through the identical ctypes binding by tests/test_gpu_boundary.py (same layouts, same write-back arithmetic).
 #
-# It keeps the reference API surface for the hot path: `GameProblem` / `Options` are the reference's own
-# types; `newton_solve!(probs::Vector{<:GameProblem})` solves a batch of structurally identical problems
-# on one MI355X and writes the results back into each `prob.pdtraj`, the constraint multipliers and
-# `prob.stats` -- replacing src/problem/solver_methods.jl:5-65 for that batch.
+# It keeps the reference API surface for the hot path.  `GameProblem` / `Options` are the reference's own types;
+#   bp = BatchedGameProblem(probs; device=0)          one device handle for a batch of structurally identical problems
+#   newton_solve!(bp)                                 src/problem/solver_methods.jl:5-65 for every problem of the batch
+#   ibr_newton_solve!(bp; ibr_opts), ibr_newton_solve!(bp, i)     solver_methods.jl:133-228
+#   mpc_solve!(bp, steps)                             receding-horizon loop of BASELINE config 5 (opts.shift / opts.dual_reset)
+#   newton_solve!(probs::Vector{<:GameProblem})       convenience: build a handle, solve, release
+# After a solve every `prob.pdtraj`, the multipliers / penalties / values of every constraint (`conval.λ`, `.μ`, `.vals`,
+# constraints_methods.jl:329-379) and `prob.stats` (struct/statistics.jl:5-57) hold what the reference's solver would have left.
 module AlgamesHIP
 
 using Algames
+using LinearAlgebra
 using StaticArrays
-import Algames: newton_solve!
+import Algames: newton_solve!, ibr_newton_solve!
 
+const TO = Algames.TrajectoryOptimization
 const LIB = get(ENV, "ALGAMES_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libalgames_hip.so"))
 
 struct AlgDesc
@@ -58,15 +64,36 @@ function abi_options(o::Options)
 end
 
 """
-    newton_solve!(probs::Vector{<:GameProblem}; device=0, game_id0=0)
-
-Batched drop-in for `newton_solve!(prob)` (src/problem/solver_methods.jl:5-65).  All problems must share
-model, N, dt, options and constraint structure (collision avoidance radii, control / state bounds, walls, circles,
-collision cost);
-they may differ in x0 and in the LQR data.
+A batch of structurally identical `GameProblem`s bound to one device handle (`alg_create` ... `alg_destroy`).
+All problems must share model, N, dt, options and constraint structure (collision-avoidance radii, control / state bounds,
+walls, circles, collision cost); they may differ in x0 and in the LQR data.  The handle lives until `close(bp)` or finalisation,
+so repeated solves (warm starts with `opts.dual_reset = false`, MPC loops) reuse the device buffers.
 """
-function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0::Integer=0)
-    prob = probs[1]; ps = prob.probsize; B = length(probs)
+mutable struct BatchedGameProblem{P<:GameProblem}
+    probs::Vector{P}
+    h::Ptr{Cvoid}
+    con_len::Int
+    function BatchedGameProblem(probs::Vector{P}; device::Integer=0) where {P<:GameProblem}
+        bp = new{P}(probs, C_NULL, 0)
+        setup!(bp, device)
+        finalizer(close, bp)
+        return bp
+    end
+end
+
+function Base.close(bp::BatchedGameProblem)
+    if bp.h != C_NULL
+        ccall((:alg_destroy, LIB), Cvoid, (Ptr{Cvoid},), bp.h)
+        bp.h = C_NULL
+    end
+    return nothing
+end
+
+sync_options!(bp::BatchedGameProblem) =       # `opts` is shared by reference and read at solve time, like the reference does
+    check(ccall((:alg_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{AlgOptions}), bp.h, Ref(abi_options(bp.probs[1].opts))))
+
+function setup!(bp::BatchedGameProblem, device)
+    probs = bp.probs; prob = probs[1]; ps = prob.probsize; B = length(probs)
     N, n, m, p = ps.N, ps.n, ps.m, ps.p
     ni, mi = ps.ni[1], ps.mi[1]
     d = prob.model isa DoubleIntegratorGame ? mi : 2
@@ -74,106 +101,281 @@ function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0
     desc = Ref(AlgDesc(model_id(prob.model), p, d, N, dt, B, device))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:alg_create, LIB), Cint, (Ref{AlgDesc}, Ref{Ptr{Cvoid}}), desc, h))
-    try
-        check(ccall((:alg_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{AlgOptions}), h[], Ref(abi_options(prob.opts))))
-        # x0: B x n, game-major (Julia is column-major: build n x B)
-        x0 = hcat([Vector(pr.x0) for pr in probs]...)
-        check(ccall((:alg_set_x0, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], x0))
-        # LQR data from game_obj.obj[i][1] (LQRCost: Q diagonal, q = -Q xf), per game: (ni x p x B) in memory order
-        Qd = zeros(ni, p, B); Rd = zeros(mi, p, B); xf = zeros(ni, p, B); uf = zeros(mi, p, B)
-        for (g, pr) in enumerate(probs), i in 1:p
-            c = pr.game_obj.obj[i][1].cost[1]
-            Qfull = diag(c.Q); Rfull = diag(c.R)
-            Qd[:, i, g] = Qfull[ps.pz[i]]; Rd[:, i, g] = Rfull[ps.pu[i]]
-            xf[:, i, g] = -(c.q ./ map(x -> x == 0 ? 1.0 : x, Qfull))[ps.pz[i]]
-            uf[:, i, g] = -(c.r ./ map(x -> x == 0 ? 1.0 : x, Rfull))[ps.pu[i]]
+    bp.h = h[]
+    sync_options!(bp)
+    # x0: B x n, game-major (Julia is column-major: build n x B)
+    x0 = hcat([Vector(pr.x0) for pr in probs]...)
+    check(ccall((:alg_set_x0, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), bp.h, x0))
+    # LQR data from game_obj.obj[i][1] (LQRCost: Q diagonal, q = -Q xf), per game: (ni x p x B) in memory order
+    Qd = zeros(ni, p, B); Rd = zeros(mi, p, B); xf = zeros(ni, p, B); uf = zeros(mi, p, B)
+    for (g, pr) in enumerate(probs), i in 1:p
+        c = pr.game_obj.obj[i][1].cost[1]
+        Qfull = diag(c.Q); Rfull = diag(c.R)
+        Qd[:, i, g] = Qfull[ps.pz[i]]; Rd[:, i, g] = Rfull[ps.pu[i]]
+        xf[:, i, g] = -(c.q ./ map(x -> x == 0 ? 1.0 : x, Qfull))[ps.pz[i]]
+        uf[:, i, g] = -(c.r ./ map(x -> x == 0 ? 1.0 : x, Rfull))[ps.pu[i]]
+    end
+    check(ccall((:alg_set_lqr, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32),
+                bp.h, Qd, Rd, xf, uf, 1))
+    # collision costs: game_obj.obj[i][2:end] are CollisionCost objectives (objective.jl:84-100)
+    if length(prob.game_obj.obj[1]) > 1
+        rad = [prob.game_obj.obj[i][2].cost[1].r for i in 1:p]
+        mu = [prob.game_obj.obj[i][2].cost[1].μ for i in 1:p]
+        check(ccall((:alg_add_collision_cost, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), bp.h, rad, mu))
+    end
+    # state constraints of player i, in the order they were added (constraints_methods.jl): dispatch on the type
+    colcons = [cv.con for cv in prob.game_con.state_conval[1] if cv.con isa TO.CollisionConstraint]
+    if p > 1 && !isempty(colcons)
+        # collision avoidance: con.radius = r_i + r_j (constraints_methods.jl:27-29) -> per-player radii
+        col2 = [cv.con for cv in prob.game_con.state_conval[2] if cv.con isa TO.CollisionConstraint]
+        R12 = colcons[1].radius                                     # r_1 + r_2
+        R1p = p > 2 ? colcons[2].radius : R12                       # r_1 + r_3
+        R2p = p > 2 ? col2[2].radius : R12                          # r_2 + r_3
+        r1 = p > 2 ? (R12 + R1p - R2p) / 2 : R12 / 2
+        radius = [i == 1 ? r1 : colcons[i-1].radius - r1 for i in 1:p]
+        # add_spherical_collision_avoidance! builds the constraint on pz[i][1:3] (three indices) instead of px[i] (two)
+        spherical = length(colcons[1].x1) == 3
+        check(spherical ? ccall((:alg_add_spherical_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), bp.h, radius) :
+                          ccall((:alg_add_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), bp.h, radius))
+    end
+    if prob.model isa BicycleGame
+        check(ccall((:alg_set_bicycle, LIB), Cint, (Ptr{Cvoid}, Float64, Float64), bp.h, prob.model.lf, prob.model.lr))
+    end
+    pts(a, b, c) = Vector{Float64}(vec(permutedims(hcat(Vector(a), Vector(b), Vector(c)))))      # n x 3, row-major
+    for i in 1:p, cv in prob.game_con.state_conval[i]
+        con = cv.con
+        if con isa Algames.StateBoundConstraint                      # add_state_bound!(game_con, i, x_max, x_min)
+            check(ccall((:alg_add_state_bound, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), bp.h, i - 1,
+                        Vector{Float64}(con.x_max), Vector{Float64}(con.x_min)))
+        elseif con isa Algames.WallConstraint                        # add_wall_constraint!(game_con, walls) / (game_con, i, walls)
+            check(ccall((:alg_add_wall_constraint_player, LIB), Cint,
+                        (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), bp.h, i - 1, length(con),
+                        Vector{Float64}(con.x1), Vector{Float64}(con.y1), Vector{Float64}(con.x2), Vector{Float64}(con.y2),
+                        Vector{Float64}(con.xv), Vector{Float64}(con.yv)))
+        elseif con isa TO.CircleConstraint                           # add_circle_constraint!(game_con, xc, yc, radius) / (game_con, i, ...)
+            check(ccall((:alg_add_circle_constraint_player, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), bp.h, i - 1, length(con),
+                        Vector{Float64}(con.x), Vector{Float64}(con.y), Vector{Float64}(con.radius)))
+        elseif i == 1 && con isa Algames.Wall3DConstraint            # add_wall_constraint!(game_con, walls::Vector{Wall3D})
+            check(ccall((:alg_add_wall3d_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), bp.h, length(con),
+                        pts(con.x1, con.y1, con.z1), pts(con.x2, con.y2, con.z2), pts(con.x3, con.y3, con.z3), pts(con.xv, con.yv, con.zv)))
+        elseif i == 1 && con isa Algames.CylinderConstraint          # add_wall_constraint!(game_con, walls::Vector{CylinderWall})
+            axis = Int32[s == :x ? 0 : s == :y ? 1 : 2 for s in con.v]
+            check(ccall((:alg_add_cylinder_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), bp.h, length(con),
+                        pts(con.p1, con.p2, con.p3), axis, Vector{Float64}(con.l), Vector{Float64}(con.r)))
         end
-        check(ccall((:alg_set_lqr, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32),
-                    h[], Qd, Rd, xf, uf, 1))
-        # collision costs: game_obj.obj[i][2:end] are CollisionCost objectives (objective.jl:84-100)
-        if length(prob.game_obj.obj[1]) > 1
-            rad = [prob.game_obj.obj[i][2].cost[1].r for i in 1:p]
-            mu = [prob.game_obj.obj[i][2].cost[1].μ for i in 1:p]
-            check(ccall((:alg_add_collision_cost, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], rad, mu))
-        end
-        # state constraints of player i, in the order they were added (constraints_methods.jl): dispatch on the type
-        colcons = [cv.con for cv in prob.game_con.state_conval[1] if cv.con isa Algames.TrajectoryOptimization.CollisionConstraint]
-        if p > 1 && !isempty(colcons)
-            # collision avoidance: con.radius = r_i + r_j (constraints_methods.jl:27-29) -> per-player radii
-            col2 = [cv.con for cv in prob.game_con.state_conval[2] if cv.con isa Algames.TrajectoryOptimization.CollisionConstraint]
-            R12 = colcons[1].radius                                     # r_1 + r_2
-            R1p = p > 2 ? colcons[2].radius : R12                       # r_1 + r_3
-            R2p = p > 2 ? col2[2].radius : R12                          # r_2 + r_3
-            r1 = p > 2 ? (R12 + R1p - R2p) / 2 : R12 / 2
-            radius = [i == 1 ? r1 : colcons[i-1].radius - r1 for i in 1:p]
-            # add_spherical_collision_avoidance! builds the constraint on pz[i][1:3] (three indices) instead of px[i] (two)
-            spherical = length(colcons[1].x1) == 3
-            check(spherical ? ccall((:alg_add_spherical_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], radius) :
-                              ccall((:alg_add_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], radius))
-        end
-        if prob.model isa BicycleGame
-            check(ccall((:alg_set_bicycle, LIB), Cint, (Ptr{Cvoid}, Float64, Float64), h[], prob.model.lf, prob.model.lr))
-        end
-        for i in 1:p, cv in prob.game_con.state_conval[i]
-            con = cv.con
-            if con isa Algames.StateBoundConstraint                      # add_state_bound!(game_con, i, x_max, x_min)
-                check(ccall((:alg_add_state_bound, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), h[], i - 1,
-                            Vector{Float64}(con.x_max), Vector{Float64}(con.x_min)))
-            elseif i == 1 && con isa Algames.WallConstraint              # add_wall_constraint!(game_con, walls): same set for every player
-                check(ccall((:alg_add_wall_constraint, LIB), Cint,
-                            (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
-                            Vector{Float64}(con.x1), Vector{Float64}(con.y1), Vector{Float64}(con.x2), Vector{Float64}(con.y2),
-                            Vector{Float64}(con.xv), Vector{Float64}(con.yv)))
-            elseif i == 1 && con isa Algames.TrajectoryOptimization.CircleConstraint   # add_circle_constraint!(game_con, xc, yc, radius)
-                check(ccall((:alg_add_circle_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
-                            Vector{Float64}(con.x), Vector{Float64}(con.y), Vector{Float64}(con.radius)))
-            elseif i == 1 && con isa Algames.Wall3DConstraint            # add_wall_constraint!(game_con, walls::Vector{Wall3D}); n_wall x 3 row-major
-                pts(a, b, c) = Vector{Float64}(vec(permutedims(hcat(Vector(a), Vector(b), Vector(c)))))
-                check(ccall((:alg_add_wall3d_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
-                            pts(con.x1, con.y1, con.z1), pts(con.x2, con.y2, con.z2), pts(con.x3, con.y3, con.z3), pts(con.xv, con.yv, con.zv)))
-            elseif i == 1 && con isa Algames.CylinderConstraint          # add_wall_constraint!(game_con, walls::Vector{CylinderWall})
-                pts(a, b, c) = Vector{Float64}(vec(permutedims(hcat(Vector(a), Vector(b), Vector(c)))))
-                axis = Int32[s == :x ? 0 : s == :y ? 1 : 2 for s in con.v]
-                check(ccall((:alg_add_cylinder_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), h[], length(con),
-                            pts(con.p1, con.p2, con.p3), axis, Vector{Float64}(con.l), Vector{Float64}(con.r)))
+    end
+    if !isempty(prob.game_con.control_conval)
+        con = prob.game_con.control_conval[1].con
+        check(ccall((:alg_add_control_bound, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), bp.h,
+                    Vector(con.u_max), Vector(con.u_min)))
+    end
+    cl = Ref{Int32}(0)
+    check(ccall((:alg_get_con_len, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), bp.h, cl))
+    bp.con_len = cl[]
+    return bp
+end
+
+# ---- layout of the ABI's constraint vectors (include/algames_hip.h "Layouts") -----------------------------------------------
+# Returns, for constraint value object `cv` of player i (0 = shared control constraint), a function (l, r) -> 1-based position in
+# the ABI vector of row r (1-based, in the conval's own row numbering) at the l-th knot index of the conval.
+function abi_position(bp::BatchedGameProblem, cv, i::Int)
+    prob = bp.probs[1]; ps = prob.probsize; N, n, m, p = ps.N, ps.n, ps.m, ps.p
+    K = N - 1
+    con = cv.con
+    col_len = p > 1 && any(c -> c.con isa TO.CollisionConstraint, prob.game_con.state_conval[1]) ? p * (p - 1) * K : 0
+    ctl_len = isempty(prob.game_con.control_conval) ? 0 : 2m * K
+    has_sb = any(c -> c.con isa Algames.StateBoundConstraint, vcat(prob.game_con.state_conval...))
+    sb_len = has_sb ? p * 2n * K : 0
+    nwall = maximum([sum(Int[length(c.con) for c in prob.game_con.state_conval[q] if c.con isa Algames.WallConstraint]) for q in 1:p])
+    ncirc = maximum([sum(Int[length(c.con) for c in prob.game_con.state_conval[q] if c.con isa TO.CircleConstraint]) for q in 1:p])
+    if con isa TO.CollisionConstraint                               # rows: pair q = (i, j), knot k = 2..N
+        j = findfirst(q -> all(con.x2 .== ps.px[q][1:length(con.x2)]) || all(con.x2 .== ps.pz[q][1:length(con.x2)]), 1:p)
+        q = (i - 1) * (p - 1) + (j < i ? j : j - 1) - 1
+        return (l, r) -> q * K + (cv.inds[l] - 2) + 1
+    elseif con isa Algames.ControlBoundConstraint                   # knot k = 1..N-1: (u - u_max)(m) then (u_min - u)(m); the reference keeps finite rows only
+        fin = con.inds                                              # control_bound_constraint.jl:35-38
+        return (l, r) -> col_len + (cv.inds[l] - 1) * 2m + fin[r]
+    elseif con isa Algames.StateBoundConstraint                     # player i, knot k = 2..N: (x - x_max)(n) then (x_min - x)(n), finite rows
+        fin = con.inds
+        return (l, r) -> col_len + ctl_len + ((i - 1) * K + (cv.inds[l] - 2)) * 2n + fin[r]
+    elseif con isa Algames.WallConstraint
+        return (l, r) -> col_len + ctl_len + sb_len + ((i - 1) * K + (cv.inds[l] - 2)) * nwall + r
+    elseif con isa TO.CircleConstraint
+        return (l, r) -> col_len + ctl_len + sb_len + p * nwall * K + ((i - 1) * K + (cv.inds[l] - 2)) * ncirc + r
+    elseif con isa Algames.Wall3DConstraint || con isa Algames.CylinderConstraint
+        nw3 = sum(Int[length(c.con) for c in prob.game_con.state_conval[1] if c.con isa Algames.Wall3DConstraint])
+        ncy = sum(Int[length(c.con) for c in prob.game_con.state_conval[1] if c.con isa Algames.CylinderConstraint])
+        base = col_len + ctl_len + sb_len + p * nwall * K + p * ncirc * K
+        con isa Algames.Wall3DConstraint && return (l, r) -> base + ((i - 1) * K + (cv.inds[l] - 2)) * nw3 + r
+        return (l, r) -> base + p * nw3 * K + ((i - 1) * K + (cv.inds[l] - 2)) * ncy + r
+    end
+    error("AlgamesHIP: constraint type $(typeof(con)) is not bound")
+end
+
+each_conval(f, game_con) = begin
+    for (i, list) in enumerate(game_con.state_conval), cv in list; f(cv, i); end
+    for cv in game_con.control_conval; f(cv, 0); end
+end
+
+"Push the multipliers / penalties the Julia side holds to the device (warm starts with opts.dual_reset = false)."
+function push_duals!(bp::BatchedGameProblem)
+    bp.con_len == 0 && return
+    B = length(bp.probs)
+    lam = zeros(bp.con_len, B); mu = fill(Float64(bp.probs[1].opts.ρ_0), bp.con_len, B)
+    for (g, pr) in enumerate(bp.probs)
+        each_conval(pr.game_con) do cv, i
+            pos = abi_position(bp, cv, i)
+            for l in eachindex(cv.inds), r in eachindex(cv.λ[l])
+                lam[pos(l, r), g] = cv.λ[l][r]; mu[pos(l, r), g] = cv.μ[l][r]
             end
         end
-        if !isempty(prob.game_con.control_conval)
-            con = prob.game_con.control_conval[1].con
-            check(ccall((:alg_add_control_bound, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[],
-                        Vector(con.u_max), Vector(con.u_min)))
+    end
+    check(ccall((:alg_set_con_duals, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), bp.h, lam, mu))
+end
+
+"Write back what a solve left on the device: pdtraj, constraint values / multipliers / penalties, Statistics."
+function pull_results!(bp::BatchedGameProblem, stats::Vector{AlgGameStats})
+    prob = bp.probs[1]; ps = prob.probsize; B = length(bp.probs)
+    N, n, S = ps.N, ps.n, ps.S
+    # pdtraj: [x_1 | horizontal-order vector] per game (primal_dual_traj.jl:46-75)
+    z = zeros(n + S, B)
+    check(ccall((:alg_get_traj, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), bp.h, 0, z))
+    for (g, pr) in enumerate(bp.probs)
+        Algames.set_traj!(pr.core, pr.pdtraj, view(z, n+1:n+S, g))
+        Algames.RobotDynamics.set_state!(pr.pdtraj.pr[1], SVector{n}(z[1:n, g]))
+    end
+    # constraint multipliers and penalties (dual_update!, penalty_update!, constraints_methods.jl:329-379, 421-440)
+    if bp.con_len > 0
+        lam = zeros(bp.con_len, B); mu = zeros(bp.con_len, B)
+        check(ccall((:alg_get_con_duals, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), bp.h, lam, mu))
+        for (g, pr) in enumerate(bp.probs)
+            each_conval(pr.game_con) do cv, i
+                pos = abi_position(bp, cv, i)
+                for l in eachindex(cv.inds)
+                    cv.λ[l] .= [lam[pos(l, r), g] for r in eachindex(cv.λ[l])]
+                    cv.μ[l] .= [mu[pos(l, r), g] for r in eachindex(cv.μ[l])]
+                end
+            end
+            Algames.evaluate!(pr.game_con, pr.pdtraj.pr)             # conval.vals at the final iterate, as solver_methods.jl:57 leaves them
         end
-        stats = Vector{AlgGameStats}(undef, B)
-        check(ccall((:alg_newton_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{AlgGameStats}), h[], 1, game_id0, stats))
-        # write back: pdtraj (x_1 | horizontal-order vector, primal_dual_traj.jl:46-75), multipliers, stats
-        S = ps.S
-        z = zeros(n + S, B)
-        check(ccall((:alg_get_traj, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), h[], 0, z))
-        for (g, pr) in enumerate(probs)
-            Algames.set_traj!(pr.core, pr.pdtraj, view(z, n+1:n+S, g))
-            Algames.RobotDynamics.set_state!(pr.pdtraj.pr[1], SVector{n}(z[1:n, g]))
+    end
+    # prob.stats: one record! per stored record (statistics.jl:30-57); the violation objects carry the recorded maxima (what the
+    # solver's exit test and the plot recipes read, solver_plots.jl:83-125); per-knot profiles are recomputed for the final record
+    cap = max(Int(maximum(s.records for s in stats)), 1)
+    rec = Vector{AlgRecord}(undef, cap); cnt = Ref{Int32}(0)
+    for (g, pr) in enumerate(bp.probs)
+        check(ccall((:alg_get_history, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{AlgRecord}, Ref{Int32}), bp.h, g - 1, cap, rec, cnt))
+        cnt[] < stats[g].records && @warn "AlgamesHIP: Statistics history truncated" game = g kept = cnt[] records = stats[g].records
+        Algames.reset!(pr.stats)
+        for t in 1:cnt[]
+            r = rec[t]
+            dv = Algames.DynamicsViolation(N); dv.max = r.dyn_vio
+            cvv = Algames.ControlViolation(N); cvv.max = r.con_vio
+            sv = Algames.StateViolation(N); sv.max = r.sta_vio
+            ov = Algames.OptimalityViolation(N); ov.max = r.opt_vio
+            Algames.record!(pr.stats, 0.0, r.res, r.delta, dv, cvv, sv, ov, Int(r.outer))
         end
-        # (constraint multipliers lambda / mu: alg_get_con_duals, layout documented in include/algames_hip.h;
-        #  Statistics history: alg_get_history -> record!(stats, ...) with the stored scalars)
-        return stats
+        if cnt[] > 0                                                # final record (solver_methods.jl:63): full per-knot profiles
+            Algames.residual!(pr, pr.pdtraj)
+            pr.stats.dyn_vio[end] = Algames.dynamics_violation(pr.model, pr.pdtraj)
+            pr.stats.con_vio[end] = Algames.control_violation(pr.game_con, pr.pdtraj)
+            pr.stats.sta_vio[end] = Algames.state_violation(pr.game_con, pr.pdtraj)
+            pr.stats.opt_vio[end] = Algames.optimality_violation(pr.core)
+        end
+    end
+    return stats
+end
+
+"""
+    newton_solve!(bp::BatchedGameProblem; game_id0=0, init=true)
+
+Batched drop-in for `newton_solve!(prob)` (src/problem/solver_methods.jl:5-65).  `init=false` keeps the controls / duals the
+problems currently hold as the initial guess (`alg_set_traj`); with `opts.dual_reset == false` the constraint multipliers and
+penalties the problems hold are pushed first (warm start).  Returns the per-game `AlgGameStats`.
+"""
+function newton_solve!(bp::BatchedGameProblem; game_id0::Integer=0, init::Bool=true)
+    sync_options!(bp)
+    B = length(bp.probs); ps = bp.probs[1].probsize
+    bp.probs[1].opts.dual_reset || push_duals!(bp)
+    if !init || bp.probs[1].opts.shift < ps.N                       # explicit initial guess / shifted warm start: upload pdtraj
+        z = zeros(ps.n + ps.S, B)
+        for (g, pr) in enumerate(bp.probs)
+            z[1:ps.n, g] = Vector(Algames.RobotDynamics.state(pr.pdtraj.pr[1]))
+            Algames.get_traj!(pr.core, view(z, ps.n+1:ps.n+ps.S, g), pr.pdtraj)
+        end
+        check(ccall((:alg_set_traj, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), bp.h, 0, z))
+    end
+    stats = Vector{AlgGameStats}(undef, B)
+    check(ccall((:alg_newton_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{AlgGameStats}), bp.h, init ? 1 : 0, game_id0, stats))
+    return pull_results!(bp, stats)
+end
+
+function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0::Integer=0)
+    bp = BatchedGameProblem(probs; device=device)
+    try
+        return newton_solve!(bp; game_id0=game_id0)
     finally
-        ccall((:alg_destroy, LIB), Cvoid, (Ptr{Cvoid},), h[])
+        close(bp)
     end
 end
 
-# The other drop-ins bind the same way on a handle prepared as above (same setup calls, then instead of alg_newton_solve):
-#
-#   ibr_newton_solve!(prob; ibr_opts)   (src/problem/solver_methods.jl:133-169)
-#       ordering = Int32.(ibr_opts.ordering .- 1)
-#       check(ccall((:alg_ibr_newton_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Int32, Ptr{Int32}, Float64, Ptr{AlgGameStats}),
-#                   h[], 1, game_id0, ibr_opts.ibr_iter, ordering, ibr_opts.Δ_min, stats))
-#   ibr_newton_solve!(prob, i)          (solver_methods.jl:171-228)
-#       check(ccall((:alg_ibr_solve_player, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{AlgGameStats}), h[], i - 1, stats))
-#   receding-horizon loop of BASELINE config 5 (opts.shift / opts.dual_reset warm starts; `steps` MPC steps per game, one launch)
-#       states = zeros(n, B, steps + 1)
-#       check(ccall((:alg_mpc_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Float64}), h[], steps, game_id0, states))
-#       check(ccall((:alg_mpc_totals, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int32), h[], iters, converged, 0))
-#   step-wise entry points (residual!, residual_jacobian!, inner_iteration, line_search, dual / penalty update):
-#       alg_residual, alg_residual_jacobian, alg_newton_step, alg_line_search, alg_dual_penalty_update (include/algames_hip.h)
+"ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169) for every problem of the batch."
+function ibr_newton_solve!(bp::BatchedGameProblem; ibr_opts::IBROptions=IBROptions(), game_id0::Integer=0)
+    sync_options!(bp)
+    p = bp.probs[1].probsize.p
+    ordering = Int32.(ibr_opts.ordering[1:p] .- 1)
+    stats = Vector{AlgGameStats}(undef, length(bp.probs))
+    check(ccall((:alg_ibr_newton_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Int32, Ptr{Int32}, Float64, Ptr{AlgGameStats}),
+                bp.h, 1, game_id0, ibr_opts.ibr_iter, ordering, ibr_opts.Δ_min, stats))
+    return pull_results!(bp, stats)
+end
+
+"ibr_newton_solve!(prob, i) (solver_methods.jl:171-228): player i best-responds on the stored trajectories."
+function ibr_newton_solve!(bp::BatchedGameProblem, i::Int)
+    sync_options!(bp)
+    stats = Vector{AlgGameStats}(undef, length(bp.probs))
+    check(ccall((:alg_ibr_solve_player, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{AlgGameStats}), bp.h, i - 1, stats))
+    return pull_results!(bp, stats)
+end
+
+"""
+    mpc_solve!(bp, steps; game_id0=0) -> (newton_iters, converged, states)
+
+Receding-horizon loop of BASELINE config 5, one launch: `steps` x (newton_solve! from the shifted warm start, x0 <- RK2(x_1, u_1)),
+first solve with the handle's shift / dual_reset, later ones with shift = 1 and dual_reset = false (the reference's hooks,
+options.jl:16-17, primal_dual_traj.jl:29-44, solver_methods.jl:25).  `states` is n x B x (steps + 1).
+"""
+function mpc_solve!(bp::BatchedGameProblem, steps::Integer; game_id0::Integer=0)
+    sync_options!(bp)
+    B = length(bp.probs); n = bp.probs[1].probsize.n
+    iters = zeros(Int64, B); conv = zeros(Int64, B)
+    check(ccall((:alg_mpc_totals, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int32), bp.h, iters, conv, 1))      # reset the totals
+    states = zeros(n, B, steps + 1)
+    check(ccall((:alg_mpc_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{Float64}), bp.h, steps, game_id0, states))
+    check(ccall((:alg_mpc_totals, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int32), bp.h, iters, conv, 0))
+    stats = Vector{AlgGameStats}(undef, B)
+    check(ccall((:alg_get_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{AlgGameStats}), bp.h, stats))
+    pull_results!(bp, stats)                                        # the last solve's iterate, multipliers and statistics
+    for (g, pr) in enumerate(bp.probs)
+        pr.x0 = SVector{n}(states[:, g, end])
+    end
+    return iters, conv, states
+end
+
+# ---- step-wise entry points on a handle (same names as the reference's functions they batch) ------------------------------------
+"residual!(prob, pdtraj) + residual_norm (global_quantities.jl:9-97): S x B residuals in vertical order and ||res||_1 / S per game."
+function residual(bp::BatchedGameProblem; reg::Float64=0.0)
+    S = bp.probs[1].probsize.S; B = length(bp.probs)
+    res = zeros(S, B); rn = zeros(B)
+    check(ccall((:alg_residual, LIB), Cint, (Ptr{Cvoid}, Int32, Float64, Ptr{Float64}, Ptr{Float64}), bp.h, 0, reg, res, rn))
+    return res, rn
+end
+"residual_jacobian! + regularisation (global_quantities.jl:109-193): S x S x B dense, rows vertical order, columns horizontal order."
+function residual_jacobian(bp::BatchedGameProblem; reg::Float64=0.0)
+    S = bp.probs[1].probsize.S; B = length(bp.probs)
+    jac = zeros(S, S, B)
+    check(ccall((:alg_residual_jacobian, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}), bp.h, reg, jac))
+    return jac
+end
 
 end # module

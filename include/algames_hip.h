@@ -178,6 +178,15 @@ int alg_add_wall_constraint(alg_handle* h, int32_t n_wall, const double* x1, con
                             const double* y2, const double* xv, const double* yv);
 /* add_circle_constraint!(game_con, xc, yc, radius) (constraints_methods.jl:120-148; TrajOpt CircleConstraint): every player */
 int alg_add_circle_constraint(alg_handle* h, int32_t n_circle, const double* xc, const double* yc, const double* radius);
+/* Per-player variants: add_wall_constraint!(game_con, i, walls) (constraints_methods.jl:161-187) and
+ * add_circle_constraint!(game_con, i, xc, yc, radius) (:121-139).  The walls / circles join the handle's table (at most
+ * ALG_MAX_WALLS / ALG_MAX_CIRCLES distinct entries; an entry that is already there is shared) and constrain player `player`
+ * (0-based) only.  The constraint rows keep the layout [player][knot][table entry]: the rows of entries that do not constrain
+ * a player exist but are inert (value 0, multiplier 0).  The all-player calls above replace the table. */
+int alg_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t n_wall, const double* x1, const double* y1,
+                                   const double* x2, const double* y2, const double* xv, const double* yv);
+int alg_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t n_circle, const double* xc, const double* yc,
+                                     const double* radius);
 /* ---- 3-D half of the constraint set.  The reference addresses pz[i][1:3] (constraints_methods.jl:52-53,231-236,275): the
  * first three state entries of player i, which are its x, y, z positions for DoubleIntegratorGame(d = 3) -- the only model
  * these three calls accept (ALG_ERR_ARG otherwise). */

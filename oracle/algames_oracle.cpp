@@ -211,6 +211,11 @@ struct Shared {
     std::vector<double> sbmax, sbmin;       // state bounds [p][n] (+-inf where absent)
     std::vector<double> wx1, wy1, wx2, wy2, wxv, wyv;   // walls
     std::vector<double> cxc, cyc, crad;     // circles
+    // per-player sets (add_wall_constraint!(game_con, i, walls) / add_circle_constraint!(game_con, i, ...), constraints_methods.jl:121-187):
+    // the reference pushes the constraint object to state_conval[i] only; here the table is shared and bit w of wall_mask[i] says
+    // whether entry w constrains player i -- a row whose bit is clear evaluates to c = 0 with a zero Jacobian (inert)
+    unsigned wall_mask[10], circ_mask[10];
+    Shared() { for (int i = 0; i < 10; i++) wall_mask[i] = circ_mask[i] = 0xffffffffu; }
     std::vector<double> w3p1, w3p2, w3p3, w3v;   // Wall3D(p1, p2, p3, v): nwall3 x 3 each (constraints_methods.jl:201-206)
     std::vector<double> cyp, cyl, cyr; std::vector<int> cyax;   // CylinderWall(p, v, l, r): ncyl x 3, axis 0/1/2 = :x/:y/:z (:249-254)
 };
@@ -383,8 +388,16 @@ void ext_state_con(const Shared& sh, Game& g, const std::vector<double>& z, int 
     };
     if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { int idx[1] = {r % D.n}; double gv[1] = {r < D.n ? 1.0 : -1.0}; row(D.o_sb(i, k, r), sb_val(sh, i, x, r), idx, gv, 1); }
     const int idx2[2] = {D.px(i, 0), D.px(i, 1)};
-    for (int w = 0; w < D.nwall; w++) { double gv[2]; const double c = wall_val(sh, w, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); row(D.o_wall(i, k, w), c, idx2, gv, 2); }
-    for (int c2 = 0; c2 < D.ncirc; c2++) { double gv[2]; const double c = circ_val(sh, c2, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); row(D.o_circ(i, k, c2), c, idx2, gv, 2); }
+    for (int w = 0; w < D.nwall; w++) {
+        double gv[2]; const double on = (double)((sh.wall_mask[i] >> w) & 1u);
+        const double c = on * wall_val(sh, w, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); gv[0] *= on; gv[1] *= on;
+        row(D.o_wall(i, k, w), c, idx2, gv, 2);
+    }
+    for (int c2 = 0; c2 < D.ncirc; c2++) {
+        double gv[2]; const double on = (double)((sh.circ_mask[i] >> c2) & 1u);
+        const double c = on * circ_val(sh, c2, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); gv[0] *= on; gv[1] *= on;
+        row(D.o_circ(i, k, c2), c, idx2, gv, 2);
+    }
     // Wall3D / Cylinder act on pz[i][1..3] (constraints_methods.jl:231-236,275)
     const int idx3[3] = {D.pz(i, 0), D.pz(i, 1), D.pz(i, 2)};
     const double q3[3] = {x[idx3[0]], x[idx3[1]], x[idx3[2]]};
@@ -404,8 +417,8 @@ void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
     for (int i = 0; i < D.p; i++) for (int k = 1; k < D.N; k++) {
         const double* x = state(D, z, k); double gx, gy;
         if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) g.vals[D.o_sb(i, k, r)] = sb_val(sh, i, x, r);
-        for (int w = 0; w < D.nwall; w++) g.vals[D.o_wall(i, k, w)] = wall_val(sh, w, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
-        for (int c = 0; c < D.ncirc; c++) g.vals[D.o_circ(i, k, c)] = circ_val(sh, c, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
+        for (int w = 0; w < D.nwall; w++) g.vals[D.o_wall(i, k, w)] = (double)((sh.wall_mask[i] >> w) & 1u) * wall_val(sh, w, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
+        for (int c = 0; c < D.ncirc; c++) g.vals[D.o_circ(i, k, c)] = (double)((sh.circ_mask[i] >> c) & 1u) * circ_val(sh, c, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
         if (D.nwall3 + D.ncyl > 0) {
             const double q3[3] = {x[D.pz(i, 0)], x[D.pz(i, 1)], x[D.pz(i, 2)]}; double gv[3];
             for (int w = 0; w < D.nwall3; w++) g.vals[D.o_wall3(i, k, w)] = wall3_val(sh, w, q3, gv);
@@ -1144,13 +1157,49 @@ int orc_add_wall_constraint(alg_handle* h, int32_t nw, const double* x1, const d
     Shared& s = H->sh;
     if (nw < 0 || nw > ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "orc_add_wall_constraint: too many walls");
     s.wx1.assign(x1, x1 + nw); s.wy1.assign(y1, y1 + nw); s.wx2.assign(x2, x2 + nw); s.wy2.assign(y2, y2 + nw); s.wxv.assign(xv, xv + nw); s.wyv.assign(yv, yv + nw);
-    s.D.nwall = nw; orc_resize_con(H); return ALG_OK;
+    s.D.nwall = nw; for (int i = 0; i < 10; i++) s.wall_mask[i] = 0xffffffffu; orc_resize_con(H); return ALG_OK;
+}
+int orc_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t nw, const double* x1, const double* y1, const double* x2, const double* y2, const double* xv, const double* yv) {
+    Shared& s = H->sh;
+    if (player < 0 || player >= s.D.p || nw < 0) return fail(ALG_ERR_ARG, "orc_add_wall_constraint_player: bad argument");
+    if (s.D.nwall == 0) for (int i = 0; i < 10; i++) s.wall_mask[i] = 0u;
+    std::vector<double>* tab[6] = {&s.wx1, &s.wy1, &s.wx2, &s.wy2, &s.wxv, &s.wyv}; const double* src[6] = {x1, y1, x2, y2, xv, yv};
+    for (int f = 0; f < 6; f++) tab[f]->resize(s.D.nwall);
+    for (int w = 0; w < nw; w++) {
+        int at = -1;
+        for (int e = 0; e < s.D.nwall && at < 0; e++) { bool same = true; for (int f = 0; f < 6; f++) same &= ((*tab[f])[e] == src[f][w]); if (same) at = e; }
+        if (at < 0) {
+            if (s.D.nwall >= ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "orc_add_wall_constraint_player: too many walls");
+            at = s.D.nwall++;
+            for (int f = 0; f < 6; f++) tab[f]->push_back(src[f][w]);
+        }
+        s.wall_mask[player] |= 1u << at;
+    }
+    orc_resize_con(H); return ALG_OK;
 }
 int orc_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const double* yc, const double* rad) {
     Shared& s = H->sh;
     if (nc < 0 || nc > ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "orc_add_circle_constraint: too many circles");
     s.cxc.assign(xc, xc + nc); s.cyc.assign(yc, yc + nc); s.crad.assign(rad, rad + nc);
-    s.D.ncirc = nc; orc_resize_con(H); return ALG_OK;
+    s.D.ncirc = nc; for (int i = 0; i < 10; i++) s.circ_mask[i] = 0xffffffffu; orc_resize_con(H); return ALG_OK;
+}
+int orc_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t nc, const double* xc, const double* yc, const double* rad) {
+    Shared& s = H->sh;
+    if (player < 0 || player >= s.D.p || nc < 0) return fail(ALG_ERR_ARG, "orc_add_circle_constraint_player: bad argument");
+    if (s.D.ncirc == 0) for (int i = 0; i < 10; i++) s.circ_mask[i] = 0u;
+    std::vector<double>* tab[3] = {&s.cxc, &s.cyc, &s.crad}; const double* src[3] = {xc, yc, rad};
+    for (int f = 0; f < 3; f++) tab[f]->resize(s.D.ncirc);
+    for (int c = 0; c < nc; c++) {
+        int at = -1;
+        for (int e = 0; e < s.D.ncirc && at < 0; e++) { bool same = true; for (int f = 0; f < 3; f++) same &= ((*tab[f])[e] == src[f][c]); if (same) at = e; }
+        if (at < 0) {
+            if (s.D.ncirc >= ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "orc_add_circle_constraint_player: too many circles");
+            at = s.D.ncirc++;
+            for (int f = 0; f < 3; f++) tab[f]->push_back(src[f][c]);
+        }
+        s.circ_mask[player] |= 1u << at;
+    }
+    orc_resize_con(H); return ALG_OK;
 }
 // 3-D ingredients: the reference indexes pz[i][1:3]; meaningful (positions) for DoubleIntegratorGame(d = 3) only
 static int need_3d(Handle* hd, const char* who) {

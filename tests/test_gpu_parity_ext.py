@@ -266,3 +266,55 @@ def test_no_kernel_writes_outside_its_buffers(alg, case):
     g.ibr_newton_solve(init=True, game_id0=3, ibr_iter=2, ordering=list(range(p)), delta_min=1e-9)
     g.mpc_totals(reset=True); g.mpc_solve(3, 5, record_states=True)
     assert _guards_ok(g) == 0
+
+
+@pytest.mark.parametrize("model,p,N", [(UNI, 3, 9), (BIC, 2, 8), (DI, 4, 6)])
+def test_per_player_wall_and_circle_parity(alg, orc, model, p, N):
+    """add_wall_constraint!(game_con, i, walls) / add_circle_constraint!(game_con, i, ...) (constraints_methods.jl:121-139, 161-187):
+    different sets for different players (one shared entry), HIP path vs oracle: residual, Jacobian, direction, an inner iteration,
+    the dual / penalty update and a short full solve."""
+    B = 3
+    g = alg.Batch(alg.hip_lib(), model, p, N, 0.1, B)
+    o = orc.OracleBatch(model, p, N, 0.1, B)
+    rng = np.random.default_rng(21)
+    ni = g.n // p
+    Q, R = 1 + rng.random((B, p, ni)), 0.5 + rng.random((B, p, g.mi))
+    xf, uf = rng.random((B, p, ni)), rng.random((B, p, g.mi)) - 0.5
+    x0 = rng.random((B, g.n))
+    for b in (g, o):
+        b.set_x0(x0); b.set_lqr(Q, R, xf, uf)
+        if p > 1:
+            b.add_collision_avoidance(0.3 + 0.1 * np.arange(p))
+        b.add_wall_constraint_player(0, [0.0, 0.2], [0.5, 1.0], [1.0, 0.9], [0.5, 0.1], [0.0, 0.6], [1.0, 0.8])
+        b.add_wall_constraint_player(p - 1, [0.2, -1.0], [1.0, 0.3], [0.9, 2.0], [0.1, 0.3], [0.6, 0.0], [0.8, 1.0])   # shares the second wall
+        b.add_circle_constraint_player(p - 1, [0.5], [0.5], [0.3])
+        if p > 2:
+            b.add_circle_constraint_player(1, [0.2, 0.5], [0.8, 0.5], [0.25, 0.3])
+    assert g.con_len == o.con_len
+    z = rng.random((B, g.traj_len)); z[:, :g.n] = x0
+    lam, mu = rng.random((B, g.con_len)), 1.0 + 2.0 * rng.random((B, g.con_len))
+    lam[rng.random((B, g.con_len)) < 0.3] = 0.0
+    for b in (g, o):
+        b.set_traj(z); b.set_con_duals(lam, mu)
+    rg, ng = g.residual(0, 0.0); ro, no = o.residual(0, 0.0)
+    assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max()) and np.allclose(ng, no, rtol=1e-13, atol=0)
+    Jg, Jo = g.residual_jacobian(1e-3), o.residual_jacobian(1e-3)
+    assert np.abs(Jg - Jo).max() <= 1e-12 * np.abs(Jo).max()
+    dg, sg = g.newton_direction(1e-3); do, so = o.newton_direction(1e-3)
+    assert np.all(sg == 0) and np.all(so == 0)
+    assert (np.abs(dg - do) / np.abs(do).max(axis=1, keepdims=True)).max() < 1e-9
+    ig, io = g.newton_step(1, 1), o.newton_step(1, 1)
+    assert np.array_equal(ig["ls_j"], io["ls_j"]) and np.array_equal(ig["alpha"], io["alpha"])
+    for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+        assert np.allclose(ig["rec"][f], io["rec"][f], rtol=1e-9, atol=1e-14), f
+    vg, vo = g.dual_penalty_update(), o.dual_penalty_update()
+    assert np.abs(vg - vo).max() <= 1e-9 * max(1.0, np.abs(vo).max())
+    (lg, mg), (lo, mo) = g.get_con_duals(), o.get_con_duals()
+    assert np.array_equal(mg, mo) and np.abs(lg - lo).max() <= 1e-9 * max(1.0, np.abs(lo).max())
+    for b in (g, o):
+        b.set_options(outer_iter=3, inner_iter=5)
+    sg, so = g.newton_solve(init=True, game_id0=5), o.newton_solve(init=True, game_id0=5)
+    for f in ("status", "outer_iters", "newton_iters", "records", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]), f
+    assert np.abs(g.get_traj() - o.get_traj()).max() <= 1e-7 * max(1.0, np.abs(o.get_traj()).max())
+    assert _guards_ok(g) == 0

@@ -1051,3 +1051,69 @@ def test_scn_and_printers(alg, orc, capsys):
     xs, ys, labels = alg.recipe_violation(st)
     assert labels[-4:] == ["dyn", "con", "sta", "opt"] and len(xs) == len(ys) == int(st.outer_iter[-1]) + 4
     assert np.all(ys[-4] >= -10) and len(ys[-1]) == int(st.iter[0])
+
+
+def test_per_player_wall_and_circle_sets(alg, orc):
+    """add_wall_constraint!(game_con, i, walls) / add_circle_constraint!(game_con, i, ...) (constraints_methods.jl:121-139, 161-187):
+    the constraint object is pushed to state_conval[i] only.  (1) giving every player the same set one by one equals the
+    all-player call; (2) a set given to one player leaves the other players' rows inert: residual rows, constraint values and
+    dual updates of the others equal those of the problem without the set."""
+    p, N = 3, 6
+    walls = ([0.0, 0.2], [0.5, 1.0], [1.0, 0.9], [0.5, 0.1], [0.0, 0.6], [1.0, 0.8])
+    circ = ([0.5, 0.2], [0.5, 0.8], [0.3, 0.25])
+    rng = np.random.default_rng(3)
+
+    def batch(setup):
+        b = orc.OracleBatch(UNI, p, N, 0.1, 2)
+        b.set_x0(rng_state["x0"]); b.set_lqr(*rng_state["lqr"])
+        setup(b)
+        z = rng_state["z"].copy()
+        b.set_traj(z)
+        lam = np.full((2, b.con_len), 0.3); mu = np.full((2, b.con_len), 1.5)
+        b.set_con_duals(lam, mu)
+        return b
+
+    n = 4 * p
+    rng_state = dict(x0=rng.random((2, n)), z=None,
+                     lqr=(1 + rng.random((2, p, 4)), 1 + rng.random((2, p, 2)), rng.random((2, p, 4)), rng.random((2, p, 2))))
+    probe = orc.OracleBatch(UNI, p, N, 0.1, 2)
+    z = rng.random((2, probe.traj_len)); z[:, :n] = rng_state["x0"]; rng_state["z"] = z
+
+    everyone = batch(lambda b: (b.add_wall_constraint(*walls), b.add_circle_constraint(*circ)))
+    one_by_one = batch(lambda b: [(b.add_wall_constraint_player(i, *walls), b.add_circle_constraint_player(i, *circ)) for i in range(p)])
+    assert everyone.con_len == one_by_one.con_len
+    assert np.array_equal(everyone.residual()[0], one_by_one.residual()[0])
+    assert np.array_equal(everyone.residual_jacobian(1e-3), one_by_one.residual_jacobian(1e-3))
+
+    plain = batch(lambda b: None)
+    only1 = batch(lambda b: (b.add_wall_constraint_player(1, *walls), b.add_circle_constraint_player(1, *circ)))
+    r0, r1 = plain.residual()[0], only1.residual()[0]
+    S = r0.shape[1]; rows_per_player = (N - 1) * (n + 2)
+    other = np.r_[0:rows_per_player, 2 * rows_per_player:S]            # opt rows of players 0 and 2, dynamics rows
+    assert np.array_equal(r0[:, other], r1[:, other])
+    mine = np.arange(rows_per_player, 2 * rows_per_player)
+    assert np.abs(r0[:, mine] - r1[:, mine]).max() > 1e-3             # player 1 feels its walls / circles
+    vals = only1.dual_penalty_update()
+    lam, mu = only1.get_con_duals()
+    ext = vals[:, plain.con_len:].reshape(2, 2, p, N - 1, 2) if False else vals[:, plain.con_len:]
+    nw, nc = 2, 2
+    wall_rows = ext[:, :p * (N - 1) * nw].reshape(2, p, N - 1, nw)
+    circ_rows = ext[:, p * (N - 1) * nw:].reshape(2, p, N - 1, nc)
+    assert np.all(wall_rows[:, [0, 2]] == 0.0) and np.all(circ_rows[:, [0, 2]] == 0.0)        # inert rows: value 0
+    assert np.abs(circ_rows[:, 1]).min() > 0.0
+    lam_ext = lam[:, plain.con_len:]
+    lw = lam_ext[:, :p * (N - 1) * nw].reshape(2, p, N - 1, nw)
+    assert np.all(lw[:, [0, 2]] == 0.3)                                # lambda + mu * 0, clamped: unchanged
+    # a third distinct wall for player 0, then too many
+    b = batch(lambda b: b.add_wall_constraint_player(1, *walls))
+    b.add_wall_constraint_player(0, [9.0], [9.0], [8.0], [8.0], [0.0], [1.0])
+    assert b.con_len == plain.con_len + p * (N - 1) * 3
+    with pytest.raises(alg.AlgamesError):
+        b.add_wall_constraint_player(0, *[np.arange(6.0) + 20 + f for f in range(6)])
+    # host mirror: add_wall_constraint(game_con, i, walls) / add_circle_constraint(game_con, i, ...)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, alg.UnicycleGame(p=p)))
+    alg.add_wall_constraint(con, 2, [alg.Wall([0.0, 0.5], [1.0, 0.5], [0.0, 1.0])])
+    alg.add_circle_constraint(con, 3, [0.5], [0.5], [0.2])
+    assert list(con.player_walls) == [2] and list(con.player_circles) == [3]
+    with pytest.raises(alg.AlgamesError):
+        alg.add_wall_constraint(con, [alg.Wall([0.0, 0.5], [1.0, 0.5], [0.0, 1.0])])

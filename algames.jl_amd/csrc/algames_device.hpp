@@ -1859,7 +1859,7 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
 // inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
 // the history record / *info (lane 0).  `cache` (optional) carries an accepted trial's statistics to the next call.
 template <class C>
-__device__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int& LS_count, double& Delta, int k, int l,
+__device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int& LS_count, double& Delta, int k, int l,
                                alg_step_info* info, int* cache_valid) {
     Game& G = G_;
     CPR pr = phase_params(pr0);

@@ -117,9 +117,9 @@ def make_problem(cfg, ids, backend=None, device=0, **kw):
     if cfg in ("C2", "C4"):                      # C4 = the C2 problem, 65 536 scenarios sharded over 8 GPUs
         model, N, dt, x0, obj, con, opts = c2_double_integrator(ids, **kw)
     elif cfg == "C3":
-        model, N, dt, x0, obj, con, opts = c3_unicycle(ids, N=50, p=4, **kw)
+        model, N, dt, x0, obj, con, opts = c3_unicycle(ids, **{"N": 50, "p": 4, **kw})
     elif cfg == "C5":
-        model, N, dt, x0, obj, con, opts = c3_unicycle(ids, N=30, p=3, **kw)
+        model, N, dt, x0, obj, con, opts = c3_unicycle(ids, **{"N": 30, "p": 3, **kw})
     else:
         raise ValueError(cfg)
     contiguous = len(ids) > 0 and np.array_equal(ids, ids[0] + np.arange(len(ids)))

@@ -9,3 +9,4 @@ from ._abi import Batch, CLib, AlgamesError  # noqa: F401
 from .host import *  # noqa: F401,F403
 from .host import hip_lib, HIP_LIB_PATH  # noqa: F401
 from . import scenarios  # noqa: F401,E402
+from . import active_set  # noqa: F401,E402

@@ -275,6 +275,7 @@ class GameConstraintValues:
         self.probsize = probsize
         self.α_dual = 1.0
         self.αx_dual = [1.0] * probsize.p
+        self.active_set_tolerance = 0.0  # game_constraints.jl:23; set_constraint_params! copies opts.active_set_tolerance (:37)
         self.collision_radius = None     # per player, pair radius = r_i + r_j
         self.u_max = None
         self.u_min = None
@@ -598,6 +599,7 @@ class GameProblem:
             c = game_con.cylinders
             self.batch.add_cylinder_constraint([a.p for a in c], [a.v for a in c], [a.l for a in c], [a.r for a in c])
         self.stats = None
+        game_con.active_set_tolerance = opts.active_set_tolerance      # set_constraint_params!, game_constraints.jl:37
         self._sync_options()       # set_constraint_params!(game_con, opts), problem.jl:49
 
     def _sync_options(self):

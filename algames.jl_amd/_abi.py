@@ -77,6 +77,8 @@ SIGNATURES = {
     "set_options": (C.c_int, [_P, C.POINTER(alg_options)]),
     "get_options": (C.c_int, [_P, C.POINTER(alg_options)]),
     "set_stream": (C.c_int, [_P, _P]),
+    "set_waves_per_game": (C.c_int, [_P, C.c_int32]),
+    "get_waves_per_game": (C.c_int, [_P, _I]),
     "set_x0": (C.c_int, [_P, _D]),
     "set_lqr": (C.c_int, [_P, _D, _D, _D, _D, C.c_int32]),
     "add_collision_cost": (C.c_int, [_P, _D, _D]),
@@ -224,6 +226,15 @@ class Batch:
                     raise AttributeError(k)
                 setattr(self.opts, k, v)
         self.lib.check(self.lib.set_options(self.h, C.byref(self.opts)))
+
+    def set_waves_per_game(self, nw):
+        """0 = automatic, 1 = one game per wavefront, 2 / 4 = a team of wavefronts per game (fused solver kernels)."""
+        self.lib.check(self.lib.set_waves_per_game(self.h, int(nw)))
+
+    def get_waves_per_game(self):
+        v = C.c_int32()
+        self.lib.check(self.lib.get_waves_per_game(self.h, C.byref(v)))
+        return v.value
 
     def set_stream(self, stream_ptr):
         self.lib.check(self.lib.set_stream(self.h, _P(stream_ptr)))

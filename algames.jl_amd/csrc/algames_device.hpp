@@ -98,9 +98,13 @@ __device__ __forceinline__ CPR phase_params(CPR pr) { return *(const ALG_AS4 Par
 
 // EXT_ = 1 instantiations carry the extended ingredient set of examples/intro_example.jl (state bounds, walls, circles;
 // the bicycle model is always EXT); the EXT_ = 0 instantiations (the BASELINE configurations) pay nothing for it.
-template <int MODEL_, int P_, int D_, int EXT_ = 0>
+// NW_ > 1: NW_ wavefronts work on one game (workgroup = NW_ x 64 threads; small batches that leave most SIMDs empty): the
+// streaming phases (assemble pass, trajectory updates, dual updates) are spread over all of them, the serial Newton-direction
+// sweeps run on wavefront 0.  NW_ = 1 is the one-game-per-wavefront kernel of the large batches.
+template <int MODEL_, int P_, int D_, int EXT_ = 0, int NW_ = 1>
 struct Cfg {
     static constexpr int MODEL = MODEL_, P = P_, D = D_;
+    static constexpr int NW = NW_, NT = NW_ * 64;          // wavefronts / threads per game
     static constexpr bool EXT = EXT_ != 0;
     static constexpr bool POS = (P_ > 1) || EXT;     // position blocks (pair / wall / circle terms) present in Q^_i
     static constexpr int n = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 * D_ * P_ : 4 * P_;
@@ -173,6 +177,15 @@ __device__ __forceinline__ int wave_or(int v) {
     for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o);
     return v;
 }
+
+// ---- wavefront team of one game (Cfg::NW) ----------------------------------------------------------------------------------
+// Synchronisation inside the Newton-direction sweeps, which only wavefront 0 of a team executes: a wave-local fence (the same
+// fences __syncthreads() carries, without the workgroup barrier).  NW == 1: the workgroup is the wavefront, plain __syncthreads().
+template <class C> __device__ __forceinline__ void dir_sync() {
+    if constexpr (C::NW == 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+}
+template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---- counter RNG shared bit-for-bit with the oracle ------------------------------
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
@@ -585,8 +598,8 @@ struct AsmLds {
     // contiguous segments (the (step, player) items would otherwise scatter 8..24-byte fragments over 64 records per store)
     // (only where four games share a SIMD and write traffic matters: the 256-VGPR configurations are latency-bound at their
     // batch sizes and write directly)
-    static constexpr bool STAGED = (C::WPE == 4);
-    static constexpr int HEAD = Rec<C>::RQ, SL = HEAD + C::PD * C::P * C::P, SPP = WAVE / C::P;
+    static constexpr bool STAGED = (C::WPE == 4 && C::NW == 1);
+    static constexpr int HEAD = Rec<C>::RQ, SL = HEAD + C::PD * C::P * C::P, SPP = C::NT / C::P;
     double stage[STAGED ? SPP * SL : 1];
 };
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
@@ -606,6 +619,23 @@ template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 // (MODE 0/2) or of the unregularised rows (MODE 3, which also returns out.l1reg).
 // ================================================================================================
 struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; double l1full; };
+// Combines the per-wavefront statistics of a team (fixed order: deterministic); every thread leaves with the same values.
+template <class C> __device__ __forceinline__ void team_combine(ResOut& o) {
+    if constexpr (C::NW > 1) {
+        __shared__ double red[C::NW][8];
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l == 0) { red[w][0] = o.l1; red[w][1] = o.opt; red[w][2] = o.dyn; red[w][3] = o.con; red[w][4] = o.sta; red[w][5] = (double)o.nonfinite; red[w][6] = o.l1reg; red[w][7] = o.l1full; }
+        __syncthreads();
+        ResOut r = {0.0, 0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < C::NW; q++) {
+            r.l1 += red[q][0]; r.opt = fmax(r.opt, red[q][1]); r.dyn = fmax(r.dyn, red[q][2]); r.con = fmax(r.con, red[q][3]); r.sta = fmax(r.sta, red[q][4]);
+            r.nonfinite |= (int)red[q][5]; r.l1reg += red[q][6]; r.l1full += red[q][7];
+        }
+        __syncthreads();                         // red[] may be rewritten by the next pass
+        o = r;
+    }
+}
 
 // IBR = true: best-response statistics of player ip (solver_methods.jl:230-289): norms over the rows of the vertical mask
 // (player ip's opt rows + all dyn rows, newton_core.jl:205-246), player-specific violations (statistics.jl:59-73), the
@@ -757,7 +787,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
               __syncthreads();
               // write-out: contiguous [coef | Hh | Hd] and table segments of the staged steps
               const int nst = (N - 1 - kA) < SPP ? (N - 1 - kA) : SPP;
-              for (int t = lane; t < nst * SL; t += WAVE) {
+              for (int t = lane; t < nst * SL; t += C::NT) {
                   const int ks2 = t / SL, o = t % SL;
                   const size_t base = (size_t)(kA + ks2) * R::LEN;
                   if (o >= HEAD) G.rec(pr)[base + R::GVT + (o - HEAD)] = L.stage[t];
@@ -800,14 +830,14 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
     // advance (k, j) by 64 rows of a row space with LEN rows per step
     constexpr int UR = C::ASM_UNROLL;
     auto run_rows = [&](auto&& row, int LEN, bool dynrow) {
-        const int total = (N - 1) * LEN, stepk = (UR * WAVE) / LEN, stepj = (UR * WAVE) % LEN;
+        const int total = (N - 1) * LEN, stepk = (UR * C::NT) / LEN, stepj = (UR * C::NT) % LEN;
         int k[UR], j[UR];
 #pragma unroll
-        for (int t = 0; t < UR; t++) { const int e0 = lane + t * WAVE; k[t] = e0 / LEN; j[t] = e0 % LEN; }
-        for (int e = lane; e < total; e += UR * WAVE) {
+        for (int t = 0; t < UR; t++) { const int e0 = lane + t * C::NT; k[t] = e0 / LEN; j[t] = e0 % LEN; }
+        for (int e = lane; e < total; e += UR * C::NT) {
             Row q[UR];
 #pragma unroll
-            for (int t = 0; t < UR; t++) q[t] = row(k[t], j[t], e + t * WAVE < total);
+            for (int t = 0; t < UR; t++) q[t] = row(k[t], j[t], e + t * C::NT < total);
 #pragma unroll
             for (int t = 0; t < UR; t++) finish_row(q[t], dynrow);
 #pragma unroll
@@ -941,6 +971,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
     out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
     out.l1reg = (MODE == 3) ? wave_sum(l1r) : out.l1;
     out.l1full = IBR ? wave_sum(l1f) : out.l1;
+    team_combine<C>(out);
 }
 
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
@@ -959,21 +990,21 @@ __device__ __forceinline__ void update_traj(CPR pr0, const Game& G0, int tsel, i
         const double2_t* __restrict__ s2 = reinterpret_cast<const double2_t*>(src + C::n);
         const double2_t* __restrict__ d2 = reinterpret_cast<const double2_t*>(dz + C::n);
         double2_t* __restrict__ t2 = reinterpret_cast<double2_t*>(tgt + C::n);
-        for (int e0 = lane; e0 < S2; e0 += U * WAVE) {
+        for (int e0 = lane; e0 < S2; e0 += U * C::NT) {
             double2_t a[U], d[U];
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; const int ec = e < S2 ? e : e0; a[t] = s2[ec]; d[t] = d2[ec]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S2 ? e : e0; a[t] = s2[ec]; d[t] = d2[ec]; }
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; if (e < S2) { double2_t v; v.x = a[t].x + alpha * d[t].x; v.y = a[t].y + alpha * d[t].y; t2[e] = v; } }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S2) { double2_t v; v.x = a[t].x + alpha * d[t].x; v.y = a[t].y + alpha * d[t].y; t2[e] = v; } }
         }
         if ((S & 1) && lane == 0) tgt[C::n + S - 1] = src[C::n + S - 1] + alpha * dz[C::n + S - 1];
     } else {
-        for (int e0 = lane; e0 < S; e0 += U * WAVE) {
+        for (int e0 = lane; e0 < S; e0 += U * C::NT) {
             double a[U], d[U];
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; const int ec = e < S ? e : e0; a[t] = src[C::n + ec]; d[t] = dz[C::n + ec]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S ? e : e0; a[t] = src[C::n + ec]; d[t] = dz[C::n + ec]; }
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * WAVE; if (e < S) tgt[C::n + e] = a[t] + alpha * d[t]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S) tgt[C::n + e] = a[t] + alpha * d[t]; }
         }
     }
 }
@@ -1388,7 +1419,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
     bool rowok[4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) rowok[r4] = (lq + 4 * r4) < n;
-    __syncthreads();
+    dir_sync<C>();
     double* const bwb = reinterpret_cast<double*>(&L.bw);
     constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
     // ------------------------------------------------------------------ backward sweep
@@ -1413,7 +1444,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
                     for (int c = 0; c < n; c++) a += L.bw.Pm[i * n * LDP + r * LDP + c] * L.bw.fv[c];
                     L.bw.t[e] = a;
                 }
-                __syncthreads();
+                dir_sync<C>();
             }
             double bF[KB1], aA[KB];
 #pragma unroll
@@ -1453,7 +1484,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
 #pragma unroll
                         for (int i = 0; i < P; i++) c2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[i][kb], c2[i], 0, 0, 0);
                 }
-                __syncthreads();
+                dir_sync<C>();
 #pragma unroll
                 for (int i = 0; i < P; i++)
 #pragma unroll
@@ -1480,7 +1511,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
 #pragma unroll
                         for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
                     }
-                    __syncthreads();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
+                    dir_sync<C>();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; r4++) {
                         const int row = lq + 4 * r4;
@@ -1489,7 +1520,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
                     }
                 }
             }
-            __syncthreads();
+            dir_sync<C>();
         }
         ALG_PROF(0)
         // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
@@ -1502,7 +1533,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
                 L.bw.Pm[i * n * LDP + r * LDP + n] = v;
             }
         }
-        __syncthreads();
+        dir_sync<C>();
         ALG_PROF(1)
         // prefetch of the next step's record: issued after the register-hungry MFMA phase, landed by the end of the step
         double pre[RPL];
@@ -1538,14 +1569,14 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
             }
         }
         if (lane < m) L.bw.V[lane * VW + n + 1 + lane] = Rc[R::RHAT + lane];
-        __syncthreads();
+        dir_sync<C>();
         ALG_PROF(2)
         // ---- V[c][n] = g_c = ru_c + B[:,c]' (P rd + s)
         if (lane < m) {
             const double* yi = &L.bw.t[(lane % P) * n];
             L.bw.V[lane * VW + n] = Rc[R::RU + lane] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, lane);
         }
-        __syncthreads();
+        dir_sync<C>();
         ALG_PROF(3)
         // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B: every lane forms its column as the same
         // short sparse combination of row c of the extended V (lane < m: B column + R^ slot; lane < m+n: A column; lane m+n: g slot)
@@ -1604,7 +1635,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
 #pragma unroll
             for (int c = 0; c < m; c++) Kg[c] = col[c];
         }
-        __syncthreads();
+        dir_sync<C>();
         ALG_PROF(6)
     }
     if (__builtin_amdgcn_readfirstlane(sing)) return ALG_STATUS_SINGULAR;      // wave-uniform (every lane factors the same matrix)
@@ -1636,7 +1667,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
     };
     double pref, prek[KPL];
     fwd_load(1, pref, prek);
-    __syncthreads();
+    dir_sync<C>();
     cur = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
     int bad = 0;                                    // non-finite direction entries (checked where they are produced)
@@ -1666,7 +1697,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
         if (lane < n) dz[n + hx<C>(k) + lane] = dxn;
         // (3) request step k+2
         fwd_load(k + 2, pref, prek);
-        __syncthreads();
+        dir_sync<C>();
     }
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
     return ALG_STATUS_OK;
@@ -1695,7 +1726,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
     };
     double pre[RPLC], pdx = 0.0;
     if constexpr (PFD == 2) cs_load(N - 3, pdx, pre);
-    __syncthreads();
+    dir_sync<C>();
     cur = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
@@ -1705,7 +1736,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
         else cs_load(k - 1, pdx, pre);
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         hxm.expand(lane, Rc, L.fw.hx);
-        __syncthreads();
+        dir_sync<C>();
         double acc = 0.0;
         if (lane < P * n && (!IBR || ci_ == ip)) {
             double qd = reg + w * L.qdf[lane];
@@ -1719,7 +1750,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
             }
             if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
-        __syncthreads();
+        dir_sync<C>();
         if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; bad |= !isfinite(acc); }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         dxk = pdx;
@@ -1732,7 +1763,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
 #pragma unroll
             for (int q = 0; q < RPLC; q++) pre[q] = nx[q];
         }
-        __syncthreads();
+        dir_sync<C>();
     }
     ALG_PROF(8)
     ALG_PROF_FLUSH
@@ -1876,8 +1907,19 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     auto finish = [&](int status, int flow) { if (info && lane0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
     if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1);              // :80-82
-    double pl1;
-    const int st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);         // :84-88
+    double pl1; int st;
+    if constexpr (C::NW == 1) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);         // :84-88
+    else {
+        // team: the serial sweeps run on wavefront 0; status and sum |d_primal| reach the other wavefronts through LDS
+        __shared__ double dir_out[2];
+        __syncthreads();
+        if (team_wave<C>() == 0) {
+            st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);
+            if ((threadIdx.x & 63) == 0) { dir_out[0] = (double)st; dir_out[1] = pl1; }
+        }
+        __syncthreads();
+        st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1 = uni(dir_out[1]);
+    }
     if (st != ALG_STATUS_OK) return finish(st, 1);
     __syncthreads();
     double alpha; int j;
@@ -1906,10 +1948,11 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
 }
 
 // reset!(game_con) (constraints_methods.jl:295-327)
+template <int NT = WAVE>
 __device__ __forceinline__ void reset_con(CPR pr0, const Game& G0) {
     CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
-    for (int e = phase_lane(); e < pr.con_len; e += WAVE) { G.lam(pr)[e] = 0.0; G.mu(pr)[e] = pr.opt.rho_0; }
+    for (int e = phase_lane(); e < pr.con_len; e += NT) { G.lam(pr)[e] = 0.0; G.mu(pr)[e] = pr.opt.rho_0; }
 }
 // evaluate! + dual_update! + penalty_update! (solver_methods.jl:57-61; constraints_methods.jl:329-379,421-440)
 template <class C>
@@ -1919,7 +1962,7 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
     const Game G = G0.fresh();
     const int N = phase_int(pr.N), tid = phase_lane(); const auto& o = pr.opt; const double* z = G.z(0);
     if (pr.has_colavoid) {
-        for (int e = tid; e < pr.col_len; e += WAVE) {
+        for (int e = tid; e < pr.col_len; e += C::NT) {
             constexpr int PM1 = P > 1 ? P - 1 : 1;
             const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / PM1, jj = q % PM1, j = jj < i ? jj : jj + 1;
             const double* x = zstate<C>(z, k);
@@ -1933,7 +1976,7 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
         }
     }
     if (pr.has_ctl) {
-        for (int e = tid; e < pr.ctl_len; e += WAVE) {
+        for (int e = tid; e < pr.ctl_len; e += C::NT) {
             const int k = e / (2 * m), row = e % (2 * m), c = row % m;
             const double u = z[n + hu<C>(k, 0) + uoff<C>(c)];
             const double cv = row < m ? u - pr.umax[c] : pr.umin[c] - u;
@@ -1945,7 +1988,7 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
     if constexpr (C::EXT) {
         // state constraints of player i: dual_update! with alphax_dual[i] (constraints_methods.jl:421-440)
         const int e0 = pr.col_len + pr.ctl_len, K = N - 1;
-        for (int e = tid; e < pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + pr.cyl_len; e += WAVE) {
+        for (int e = tid; e < pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + pr.cyl_len; e += C::NT) {
             int i, k; double c;
             if (e < pr.sb_len) {
                 const int row = e % (2 * n); k = (e / (2 * n)) % K; i = e / (2 * n * K);
@@ -1976,7 +2019,7 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
             if (isfinite(c)) { const double lb = G.lam(pr)[ci] + o.alphax_dual[i] * G.mu(pr)[ci] * c; G.lam(pr)[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
         }
     }
-    for (int e = tid; e < pr.con_len; e += WAVE) G.mu(pr)[e] = fmin(fmax(G.mu(pr)[e] * o.rho_increase, 0.0), o.rho_max);
+    for (int e = tid; e < pr.con_len; e += C::NT) G.mu(pr)[e] = fmin(fmax(G.mu(pr)[e] * o.rho_increase, 0.0), o.rho_max);
 }
 
 // rollout!(RK3, model, traj) (solver_methods.jl:17): lanes < P integrate their own player (players are decoupled)
@@ -2006,10 +2049,10 @@ __device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bo
         // in-place shift: element e of step k takes element e of step k+s; ascending k is safe within one wave only
         // with a barrier per step, so stage through the trial buffer
         double* tmp = G.z(1);
-        for (int e = lane; e < pr.traj_len; e += WAVE) tmp[e] = z[e];
+        for (int e = lane; e < pr.traj_len; e += C::NT) tmp[e] = z[e];
         __syncthreads();
         z = z; // (same buffer)
-        for (int e = lane; e < pr.S; e += WAVE) {
+        for (int e = lane; e < pr.S; e += C::NT) {
             const int k = e / C::b, a = e % C::b;
             double v;
             if (a < n) {           // x_{k+1}: knot kn = k+1
@@ -2026,7 +2069,7 @@ __device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bo
             z[n + e] = v;
         }
     } else {
-        for (int e = lane; e < pr.S; e += WAVE) {
+        for (int e = lane; e < pr.S; e += C::NT) {
             const int k = e / C::b, a = e % C::b;
             uint64_t ctr;
             if (a < n) ctr = (uint64_t)(k + 1) * (n + m) + a;
@@ -2047,7 +2090,7 @@ __device__ __forceinline__ void settle_traj(CPR pr, Game& G) {
         __syncthreads();
         const Game H = G.fresh();
         double* a = H.z(0); double* z_home = H.base;
-        for (int e = phase_lane(); e < pr.traj_len; e += WAVE) { const double v = a[e]; a[e] = z_home[e]; z_home[e] = v; }
+        for (int e = phase_lane(); e < pr.traj_len; e += C::NT) { const double v = a[e]; a[e] = z_home[e]; z_home[e] = v; }
         G.zo[1] = G.zo[0]; G.zo[0] = 0;
         __syncthreads();
     }
@@ -2065,7 +2108,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     __syncthreads();
     rollout<C>(pr, G.z(0));                                                // :17
 #endif
-    if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con(pr, G);     // :25
+    if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con<C::NT>(pr, G);     // :25
     __syncthreads();
     int out = 0, status = ALG_STATUS_OK; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30

@@ -8,8 +8,9 @@
 #include <string>
 #include <vector>
 
-// the EXT instantiations are defined in algames_ext_*.hip
+// the EXT instantiations are defined in algames_ext_*.hip, the team kernels in algames_mw.hip
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
+ALG_CFGS_MW(ALG_DECLARE_MW)
 
 __global__ void __launch_bounds__(WAVE) k_reset_con(Params pr_arg) {
     CPR pr = kernel_params();
@@ -109,6 +110,7 @@ struct Handle {
     double* d_lqr = nullptr;      // B x lqr_block (sized for the per-game case)
     double* d_extc = nullptr;
     std::vector<double> extc;     // host copy of pr.extc
+    int waves_per_game = 0;       // 0 = automatic (alg_set_waves_per_game)
     long long solves_since_reset = 0;   // solves whose records share the Statistics history (best responses accumulate)
     void* d_scratch = nullptr;    // grow-only scratch of the inspection entry points (dense Jacobians, MPC state logs)
     size_t scratch_bytes = 0;
@@ -247,6 +249,41 @@ int ensure_scratch(Handle* hd, size_t bytes) {
     return ALG_OK;
 }
 
+// Wavefronts per game for the fused solver kernels.  Automatic: a team kernel when one is compiled for the configuration and
+// the batch is so small that B x NW wavefronts still fit the device at two wavefronts per SIMD (1024 SIMDs on MI355X).
+int team_width(const Handle* hd) {
+    const Params& p = hd->pr;
+    int best = 1;
+#define X(M, P, D, E, W) if (p.model == (M) && p.p == (P) && p.d == (D) && p.ext == (E)) {                         \
+        if (hd->waves_per_game == (W)) return (W);                                                                    \
+        if (hd->waves_per_game == 0 && (long long)p.B * (W) <= 2048 && (W) > best) best = (W); }
+    ALG_CFGS_MW(X)
+#undef X
+    return hd->waves_per_game > 1 ? -1 : best;
+}
+int launch_newton_solve(Handle* h, int init, uint64_t game_id0) {
+    const int nw = team_width(h);
+    if (nw < 0) return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration");
+    if (nw == 1) { LAUNCH(k_newton_solve, h->pr, init, game_id0); return ALG_OK; }
+    const Params& pr = h->pr; bool done = false;
+#define X(M, P, D, E, W) if (!done && nw == (W) && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                   \
+        hipLaunchKernelGGL((k_newton_solve<Cfg<M, P, D, E, W>>), dim3(pr.B), dim3(WAVE * (W)), 0, h->stream, h->pr, init, game_id0); done = true; }
+    ALG_CFGS_MW(X)
+#undef X
+    return launch_check("k_newton_solve (team)");
+}
+int launch_mpc_loop(Handle* h, int steps, uint64_t game_id0, double* d_states) {
+    const int nw = team_width(h);
+    if (nw < 0) return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration");
+    if (nw == 1) { LAUNCH(k_mpc_loop, h->pr, steps, game_id0, d_states); return ALG_OK; }
+    const Params& pr = h->pr; bool done = false;
+#define X(M, P, D, E, W) if (!done && nw == (W) && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                   \
+        hipLaunchKernelGGL((k_mpc_loop<Cfg<M, P, D, E, W>>), dim3(pr.B), dim3(WAVE * (W)), 0, h->stream, h->pr, steps, game_id0, d_states); done = true; }
+    ALG_CFGS_MW(X)
+#undef X
+    return launch_check("k_mpc_loop (team)");
+}
+
 int alloc_all(Handle* hd) {
     int rc;
     Params& p = hd->pr; const size_t B = p.B;
@@ -338,6 +375,18 @@ int alg_set_options(alg_handle* h, const alg_options* o) {
 int alg_get_options(alg_handle* h, alg_options* o) {
     if (!h || !o) return fail(ALG_ERR_ARG, "alg_get_options: null argument");
     *o = H->pr.opt; return ALG_OK;
+}
+int alg_set_waves_per_game(alg_handle* h, int32_t nw) {
+    NEED_HANDLE("alg_set_waves_per_game");
+    if (nw != 0 && nw != 1 && nw != 2 && nw != 4) return fail(ALG_ERR_ARG, "alg_set_waves_per_game: 0 (automatic), 1, 2 or 4");
+    const int prev = H->waves_per_game;
+    H->waves_per_game = nw;
+    if (team_width(H) < 0) { H->waves_per_game = prev; return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration"); }
+    return ALG_OK;
+}
+int alg_get_waves_per_game(alg_handle* h, int32_t* nw) {
+    if (!h || !nw) return fail(ALG_ERR_ARG, "alg_get_waves_per_game: null argument");
+    *nw = team_width(H); return ALG_OK;
 }
 int alg_set_stream(alg_handle* h, void* s) { NEED_HANDLE("alg_set_stream"); H->stream = s ? (hipStream_t)s : H->own_stream; return ALG_OK; }
 
@@ -678,8 +727,7 @@ int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) {
     int rc = use_device(H); if (rc) return rc;
     if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_newton_solve: x0 / LQR data not set");
     H->solves_since_reset = 1;                    // newton_solve! starts with reset!(prob.stats)
-    LAUNCH(k_newton_solve, H->pr, (int)init, (uint64_t)game_id0);
-    return ALG_OK;
+    return launch_newton_solve(H, (int)init, (uint64_t)game_id0);
 }
 int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats) {
     int rc = alg_newton_solve_async(h, init, game_id0); if (rc) return rc;
@@ -779,7 +827,7 @@ int alg_mpc_solve(alg_handle* h, int32_t steps, int64_t game_id0, double* states
     const Params& p = H->pr;
     const size_t cnt = (size_t)(steps + 1) * p.B * p.n;
     if (states && (rc = ensure_scratch(H, sizeof(double) * cnt))) return rc;
-    LAUNCH(k_mpc_loop, H->pr, (int)steps, (uint64_t)game_id0, states ? (double*)H->d_scratch : (double*)nullptr);
+    if ((rc = launch_mpc_loop(H, (int)steps, (uint64_t)game_id0, states ? (double*)H->d_scratch : (double*)nullptr))) return rc;
     if (states) return d2h(H, states, H->d_scratch, sizeof(double) * cnt);
     return ALG_OK;
 }

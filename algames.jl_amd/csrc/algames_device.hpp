@@ -1264,12 +1264,12 @@ struct HxMap {
 // Non-zeros of [Q^_i | rx_i] (rx_i only when s_i rides in tile column n, n < 16): after the MFMA products wrote A'(P F) back, every lane adds its entries
 //   (r, r): reg + w q_i,r (+ state-bound Hessian) (+ position-block diagonal)   (r, c) r != c < 2P: position block   (r, n): rx_i,r
 // into row block i of Pm.  Per lane and pass: packed (dst | src << 11 | qi << 19), sign of the record source, diagonal flag.
-template <class C>
+template <class C, int NTQ = WAVE>
 struct QaddMap {
     static constexpr int NP = C::PD * C::P;                // rows / columns of the position block
     static constexpr int OFF = C::POS ? NP * NP - NP : 0;
     static constexpr bool RXCOL = C::n < 16;             // s_i lives in tile column n (else it is updated on the VALU)
-    static constexpr int QE = C::n + OFF + (RXCOL ? C::n : 0), QTOT = C::P * QE, PASSES = (QTOT + WAVE - 1) / WAVE;
+    static constexpr int QE = C::n + OFF + (RXCOL ? C::n : 0), QTOT = C::P * QE, PASSES = (QTOT + NTQ - 1) / NTQ;
     unsigned code[PASSES]; float sgn[PASSES], dfl[PASSES];
     __device__ __forceinline__ static void hxsrc(int i, int jr, int jc, int h, int& so, float& sg) {
         using R = Rec<C>;
@@ -1286,7 +1286,7 @@ struct QaddMap {
         static_assert(C::P * n * LDP < 2048 && R::LEN_SWEEP < 256 && P * n <= 64, "QaddMap packing");
 #pragma unroll
         for (int q = 0; q < PASSES; q++) {
-            const int e = lane + q * WAVE;
+            const int e = lane + q * NTQ;
             int dst = 0, so = 0, qi = 0; float sg = 0.f, df = 0.f;
             if (e < QTOT) {
                 const int i = e / QE, t = e % QE;
@@ -1312,7 +1312,7 @@ struct QaddMap {
         double nv[PASSES];
 #pragma unroll
         for (int q = 0; q < PASSES; q++) {
-            const int e = lane + q * WAVE;
+            const int e = lane + q * NTQ;
             nv[q] = 0.0;
             if (e < QTOT && (only_player < 0 || e / QE == only_player)) {
                 const unsigned u = code[q];
@@ -1324,7 +1324,7 @@ struct QaddMap {
         }
 #pragma unroll
         for (int q = 0; q < PASSES; q++) {
-            const int e = lane + q * WAVE;
+            const int e = lane + q * NTQ;
             if (e < QTOT && (only_player < 0 || e / QE == only_player)) Pm[code[q] & 0x7ff] = nv[q];
         }
     }
@@ -1390,36 +1390,47 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
     Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
     using R = Rec<C>;
-    const int N = phase_int(pr.N), lane = phase_lane();
+    // Team kernels (Cfg::NW wavefronts per game): the backward sweep runs on the whole team -- player i's value recursion on
+    // wavefront i % NW, the table-driven phases strided over all threads, the column build and the pivoted solve redundantly in
+    // every wavefront (their result is needed everywhere for the closed-loop rows), real workgroup barriers between the phases;
+    // the forward and costate sweeps then run on wavefront 0 alone.
+    // (a team of two gains less from the split than its barriers cost -- measured on C3 at 1024 games: 2.35 M/s with the whole
+    // direction on wavefront 0, 2.30 M/s with the split -- so only teams of four or more split the backward sweep)
+    constexpr bool TEAM = C::NW >= 4 && !IBR;
+    constexpr int BT = TEAM ? C::NT : WAVE;               // threads of the backward sweep
+    const int N = phase_int(pr.N), tid = phase_lane();
+    const int lane = TEAM ? (tid & 63) : tid;             // lane inside the wavefront
+    const int tw = TEAM ? team_wave<C>() : 0;
+    auto bsync = [&]() { if constexpr (TEAM) __syncthreads(); else dir_sync<C>(); };
     const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
     const double dt = phase_f64(pr.dt);
-    constexpr int RPL = (R::LEN_SWEEP + WAVE - 1) / WAVE;      // record doubles per lane
+    constexpr int RPL = (R::LEN_SWEEP + BT - 1) / BT;          // record doubles per thread
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
     constexpr bool AUGS = DirLds<C>::AUGS;               // s_i rides through the first MFMA product (n < 16)
     constexpr int KB1 = DirLds<C>::KB1, VW = DirLds<C>::VW;
     HxMap<C> hxm;
-    QaddMap<C> qam; qam.init(lane);
+    QaddMap<C, BT> qam; qam.init(tid);
     struct NoGather { __device__ void init(int, int) {} };
     typename std::conditional<(C::P == 3 && C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR), P3Gather<C>, NoGather>::type p3g;
     p3g.init(lq, lrow);
-    for (int e = lane; e < P * n; e += WAVE) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd(pr)[i * C::ni + r / P] : 0.0; }
-    for (int e = lane; e < 16 * 16; e += WAVE) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
-    for (int e = lane; e < P * n * LDP; e += WAVE) L.bw.Pm[e] = 0.0;
-    for (int e = lane; e < m * VW; e += WAVE) L.bw.V[e] = 0.0;
-    for (int e = lane; e < n * n; e += WAVE) {                     // constant part of A' (the coefficient entries follow per step)
+    for (int e = tid; e < P * n; e += BT) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd(pr)[i * C::ni + r / P] : 0.0; }
+    for (int e = tid; e < 16 * 16; e += BT) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
+    for (int e = tid; e < P * n * LDP; e += BT) L.bw.Pm[e] = 0.0;
+    for (int e = tid; e < m * VW; e += BT) L.bw.V[e] = 0.0;
+    for (int e = tid; e < n * n; e += BT) {                     // constant part of A' (the coefficient entries follow per step)
         const int c = e / n, r = e % n;
         double v = (r == c) ? 1.0 : 0.0;
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { if (r < m && c == r + m) v = dt; }
         L.bw.T[e] = v;
     }
-    if (lane == 0) L.bw.pad[0] = 0.0;
-    for (int e = lane; e < R::LEN_SWEEP; e += WAVE) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
+    if (tid == 0) L.bw.pad[0] = 0.0;
+    for (int e = tid; e < R::LEN_SWEEP; e += BT) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
     // ---- loop-invariant lane roles of the MFMA tiles: register r4 holds (row = lq + 4 r4, col = lrow)
     const bool colP = lrow < n;
     bool rowok[4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) rowok[r4] = (lq + 4 * r4) < n;
-    dir_sync<C>();
+    bsync();
     double* const bwb = reinterpret_cast<double*>(&L.bw);
     constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
     // ------------------------------------------------------------------ backward sweep
@@ -1439,19 +1450,19 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
         // next player starts: one accumulator tile live.
         if (k < N - 2) {
             if constexpr (!AUGS) {
-                for (int e = lane; e < P * n; e += WAVE) {                  // t_i = P_i f + s_i (one (i,r) per lane)
+                for (int e = tid; e < P * n; e += BT) {                     // t_i = P_i f + s_i (one (i,r) per thread)
                     const int i = e / n, r = e % n; double a = L.bw.Pm[i * n * LDP + r * LDP + n];
                     for (int c = 0; c < n; c++) a += L.bw.Pm[i * n * LDP + r * LDP + c] * L.bw.fv[c];
                     L.bw.t[e] = a;
                 }
-                dir_sync<C>();
+                bsync();
             }
             double bF[KB1], aA[KB];
 #pragma unroll
             for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
-            if constexpr (C::WPE == 2 && !IBR && C::MODEL != ALG_MODEL_BICYCLE) {
+            if constexpr (C::WPE == 2 && !IBR && !TEAM && C::MODEL != ALG_MODEL_BICYCLE) {
                 // 256-VGPR configurations (one game per SIMD at their batch sizes): all players' operands are read first,
                 // the P independent MFMA chains overlap in the matrix pipeline, then all results are written back
                 double pv[P][KB1];
@@ -1497,6 +1508,7 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
 #pragma unroll
                 for (int i = 0; i < P; i++) {
                     if (IBR && i != ip) continue;
+                    if (TEAM && (i % C::NW) != tw) continue;        // this player belongs to another wavefront of the team
                     double4_t c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int kb = 0; kb < KB1; kb++) {
@@ -1520,63 +1532,65 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
                     }
                 }
             }
-            dir_sync<C>();
+            bsync();
         }
         ALG_PROF(0)
         // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
-        qam.apply(lane, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
+        qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
         if constexpr (!AUGS) {
-            for (int e = lane; e < P * n; e += WAVE) {                      // s_i <- rx_i + A_{k+1}' t_i
+            for (int e = tid; e < P * n; e += BT) {                         // s_i <- rx_i + A_{k+1}' t_i
                 const int i = e / n, r = e % n; const double* ti = &L.bw.t[i * n];
                 double v = Rc[R::RX + e];
                 if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
                 L.bw.Pm[i * n * LDP + r * LDP + n] = v;
             }
         }
-        dir_sync<C>();
+        bsync();
         ALG_PROF(1)
         // prefetch of the next step's record: issued after the register-hungry MFMA phase, landed by the end of the step
         double pre[RPL];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; pre[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+            for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; pre[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
         // ---- V[c][0..n) = B[:,c]' P_{i(c)},  V[c][n+1+c] = R^_c,  y_i = P_i rd + s_i   (lane = 16 c + col: shifts, no divisions)
+        constexpr int CPP = BT / 16;                                   // control rows of V per pass
 #pragma unroll
-        for (int q = 0; q < (m + 3) / 4; q++) {
-            const int c = 4 * q + lq, col = lrow;
+        for (int q = 0; q < (m + CPP - 1) / CPP; q++) {
+            const int c = CPP * q + (tid >> 4), col = tid & 15;
             if (c < m && col < n) {
                 const double* Pi = &L.bw.Pm[(c % P) * n * LDP];
                 L.bw.V[c * VW + col] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
             }
         }
         static_assert(P * 16 <= WAVE, "one (player, row) per lane");
-        if (lq < P && lrow < n) {
-            const double* Pr = &L.bw.Pm[lq * n * LDP + lrow * LDP];
+        if ((tid >> 4) < P && (tid & 15) < n) {
+            const int yp = tid >> 4, yr = tid & 15;
+            const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
             double a = Pr[n];
 #pragma unroll
             for (int c = 0; c < n; c++) a += Pr[c] * Rc[R::RD + c];
-            L.bw.t[lq * n + lrow] = a;
+            L.bw.t[yp * n + yr] = a;
         }
         // coefficient entries of A_k' (state-dependent models)
         if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
-            if (lane < 4 * P) { const int kind = lane / P, i = lane % P; L.bw.T[(((kind & 1) ? 3 : 2) * P + i) * n + ((kind >> 1) ? P + i : i)] = coefk[lane]; }
+            if (tid < 4 * P) { const int kind = tid / P, i = tid % P; L.bw.T[(((kind & 1) ? 3 : 2) * P + i) * n + ((kind >> 1) ? P + i : i)] = coefk[tid]; }
         } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
-            if (lane < 5 * P) {
-                const int kind = lane / P, i = lane % P;        // (x,psi) (x,v) (y,psi) (y,v) (psi,v)
+            if (tid < 5 * P) {
+                const int kind = tid / P, i = tid % P;          // (x,psi) (x,v) (y,psi) (y,v) (psi,v)
                 const int colb = (kind == 0 || kind == 2) ? 3 : 2, row = kind < 2 ? i : (kind < 4 ? P + i : 3 * P + i);
-                L.bw.T[(colb * P + i) * n + row] = coefk[lane];
+                L.bw.T[(colb * P + i) * n + row] = coefk[tid];
             }
         }
-        if (lane < m) L.bw.V[lane * VW + n + 1 + lane] = Rc[R::RHAT + lane];
-        dir_sync<C>();
+        if (tid < m) L.bw.V[tid * VW + n + 1 + tid] = Rc[R::RHAT + tid];
+        bsync();
         ALG_PROF(2)
         // ---- V[c][n] = g_c = ru_c + B[:,c]' (P rd + s)
-        if (lane < m) {
-            const double* yi = &L.bw.t[(lane % P) * n];
-            L.bw.V[lane * VW + n] = Rc[R::RU + lane] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, lane);
+        if (tid < m) {
+            const double* yi = &L.bw.t[(tid % P) * n];
+            L.bw.V[tid * VW + n] = Rc[R::RU + tid] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, tid);
         }
-        dir_sync<C>();
+        bsync();
         ALG_PROF(3)
         // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B: every lane forms its column as the same
         // short sparse combination of row c of the extended V (lane < m: B column + R^ slot; lane < m+n: A column; lane m+n: g slot)
@@ -1611,34 +1625,37 @@ __device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double re
             const double* acol = (cc < n) ? &L.bw.T[cc * n] : Rc + R::RD;
             // all LDS reads first, then all writes: the compiler cannot prove that the Fx stores do not alias the T / record
             // loads and would otherwise serialise one LDS round trip per row
+            // (team: wavefront tw forms the rows r = tw (mod NW); every wavefront holds the solved columns)
             double fxv[n];
 #pragma unroll
-            for (int r = 0; r < n; r++) fxv[r] = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r) + acol[r];
+            for (int r = 0; r < n; r++) { if (!TEAM || (r % C::NW) == tw) fxv[r] = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r) + acol[r]; }
 #pragma unroll
             for (int r = 0; r < n; r++) {
+                if (TEAM && (r % C::NW) != tw) continue;
                 if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];         // f rides in tile column n
                 else { double* dst = cc < n ? &L.bw.Fx[r * 16 + cc] : &L.bw.fv[r]; *dst = fxv[r]; }   // one store, selected address (no exec-mask flip per row)
             }
         }
         ALG_PROF(9)
-        if (C::NC > 0 && lane < C::NC) L.coefn[lane] = coefk[lane];
+        if (C::NC > 0 && tid < C::NC) L.coefn[tid] = coefk[tid];
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = lane + q * WAVE; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
+            for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
         }
         ALG_PROF(10)
         // the gains go out last (gfx9 counts loads and stores in one vmcnt: the wait for the prefetched record above should not
         // meet stores that were just issued; measured neutral, the phase profile shows no exposed wait either way)
         asm volatile("" ::: "memory");
-        if (lane >= m && lane <= m + n) {
+        if (tw == 0 && lane >= m && lane <= m + n) {
             double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (lane - m) * m;
 #pragma unroll
             for (int c = 0; c < m; c++) Kg[c] = col[c];
         }
-        dir_sync<C>();
+        bsync();
         ALG_PROF(6)
     }
     if (__builtin_amdgcn_readfirstlane(sing)) return ALG_STATUS_SINGULAR;      // wave-uniform (every lane factors the same matrix)
+    if (TEAM && tw != 0) return ALG_STATUS_OK;         // the serial sweeps below belong to wavefront 0 (the caller holds a barrier)
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 1
     return ALG_STATUS_OK;
 #endif
@@ -1913,10 +1930,9 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
         // team: the serial sweeps run on wavefront 0; status and sum |d_primal| reach the other wavefronts through LDS
         __shared__ double dir_out[2];
         __syncthreads();
-        if (team_wave<C>() == 0) {
-            st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);
-            if ((threadIdx.x & 63) == 0) { dir_out[0] = (double)st; dir_out[1] = pl1; }
-        }
+        // teams of >= 4: backward sweep on the whole team, forward / costate on wavefront 0; team of 2: wavefront 0 does it all
+        if (C::NW >= 4 || team_wave<C>() == 0) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);
+        if (threadIdx.x == 0) { dir_out[0] = (double)st; dir_out[1] = pl1; }
         __syncthreads();
         st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1 = uni(dir_out[1]);
     }

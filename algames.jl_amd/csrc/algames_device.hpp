@@ -26,6 +26,14 @@
 #include <type_traits>
 #include "../../include/algames_hip.h"
 
+// tunables (scratch/build_variant.sh builds A/B variants of the library with other values)
+#ifndef ALG_ASM_UNROLL
+#define ALG_ASM_UNROLL 2
+#endif
+#ifndef ALG_AXPY_U
+#define ALG_AXPY_U 4
+#endif
+
 namespace alg {
 
 constexpr int WAVE = 64;
@@ -127,7 +135,7 @@ struct Cfg {
     // reuse the accepted line-search trial as the next record! (one assemble pass less per Newton iteration)
     static constexpr bool TRIAL_REUSE = true;
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
-    static constexpr int ASM_UNROLL = 2;
+    static constexpr int ASM_UNROLL = ALG_ASM_UNROLL;
 };
 
 // newton_solve / rollout are __forceinline__: they have two callers per instantiation (k_newton_solve, k_mpc_loop) and the
@@ -983,7 +991,7 @@ __device__ __forceinline__ void update_traj(CPR pr0, const Game& G0, int tsel, i
     double* tgt = G.z(tsel); const double* src = G.z(ssel); const double* dz = G.z(2);
     // pure streaming pass: 16 bytes per lane and four independent load pairs in flight per pass.  Every game's buffers start
     // 16-byte aligned when traj_len is even (n is always even); otherwise the scalar loop runs.
-    constexpr int U = 4;
+    constexpr int U = ALG_AXPY_U;
     const int S = phase_int(pr.S), lane = phase_lane();
     if ((pr.traj_len & 1) == 0) {
         const int S2 = S >> 1;                           // pairs; a last odd element is handled below
@@ -2035,6 +2043,9 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
             if (isfinite(c)) { const double lb = G.lam(pr)[ci] + o.alphax_dual[i] * G.mu(pr)[ci] * c; G.lam(pr)[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
         }
     }
+    // penalty_update! rewrites mu of EVERY row: in a team, another wavefront may still be in the dual-update loops above, which
+    // read mu of rows this thread is about to scale (one wavefront alone runs the loops in program order)
+    if constexpr (C::NW > 1) __syncthreads();
     for (int e = tid; e < pr.con_len; e += C::NT) G.mu(pr)[e] = fmin(fmax(G.mu(pr)[e] * o.rho_increase, 0.0), o.rho_max);
 }
 

@@ -1,0 +1,31 @@
+"""Tail / imbalance behaviour of the one-game-per-wavefront design: a batch whose games need different numbers
+of Newton iterations.  C5 problems (3-player Unicycle, N=30) at 4096 games: iteration counts spread; compare the measured rate with
+the rate the same kernel reaches on a homogeneous batch (every game = a copy of one median game)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import algames_jl_amd as alg
+def rate(prob, reps=5):
+    b = prob.batch; prob._sync_options()
+    for _ in range(2): b.newton_solve_async(init=True, game_id0=prob.game_id0)
+    torch.cuda.synchronize(); b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): b.newton_solve_async(init=True, game_id0=prob.game_id0)
+    b.synchronize(); dt = (time.perf_counter() - t0) / reps
+    it = b.get_stats()["newton_iters"]
+    return it, dt
+for cfg, B, spread in (("C2", 4096, 0.0), ("C2", 4096, 0.3), ("C2", 4096, 0.6), ("C5", 4096, 0.3), ("C5", 4096, 0.6)):
+    prob = alg.scenarios.make_problem(cfg, np.arange(B)); prob.batch.set_waves_per_game(1)
+    if spread:
+        rng = np.random.default_rng(5)
+        x0 = prob.x0.copy(); npos = 2 * prob.model.p
+        x0[:, :npos] += rng.uniform(-spread, spread, (B, npos))
+        prob.batch.set_x0(x0)
+    print("spread", spread, end=" ")
+    it, dt = rate(prob)
+    st = prob.batch.get_stats(); print("converged %d / %d, status!=0: %d" % (st["converged"].sum(), B, (st["status"] != 0).sum()), end=" ")
+    print("%s B=%d: iterations min %d median %d mean %.1f max %d | %.3f ms per solve | %.3g game-iterations/s | ideal if the slowest game alone set the time: mean/max = %.2f"
+          % (cfg, B, it.min(), np.median(it), it.mean(), it.max(), dt * 1e3, it.sum() / dt, it.mean() / it.max()))
+    hist = np.bincount(it)
+    print("   histogram (iters:count)", {int(k): int(v) for k, v in enumerate(hist) if v})

@@ -34,6 +34,7 @@
 #define ALG_AXPY_U 4
 #endif
 
+
 namespace alg {
 
 constexpr int WAVE = 64;

@@ -1932,7 +1932,7 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     Delta = 0.0;                                                           // :79
     auto finish = [&](int status, int flow) { if (info && lane0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
-    if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1);              // :80-82
+    if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1) | (1 << 16);  // :80-82 (bit 16: pdtraj untouched since this record!)
     double pl1; int st;
     if constexpr (C::NW == 1) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);         // :84-88
     else {
@@ -2138,15 +2138,16 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
 #endif
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con<C::NT>(pr, G);     // :25
     __syncthreads();
-    int out = 0, status = ALG_STATUS_OK; double Delta = 0.0;
+    int out = 0, status = ALG_STATUS_OK, fresh = 0; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30
         out = k;
         int LS_count = 0;
         int cache_valid = 0;
         for (int l = 1; l <= o.inner_iter; l++) {                          // :38
             const int rcode = inner_iteration<C>(pr, G, L, LS_count, Delta, k, l, nullptr, &cache_valid);
+            fresh = (rcode >> 16) & 1;
             if ((rcode & 0xff) != ALG_STATUS_OK) { status = rcode & 0xff; break; }
-            if (LS_count >= 1 || (rcode >> 8) == 1) break;                 // :43
+            if (LS_count >= 1 || ((rcode >> 8) & 0xff) == 1) break;        // :43
         }
         if (status != ALG_STATUS_OK) break;
         __syncthreads();
@@ -2161,7 +2162,23 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
         __syncthreads();
     }
     __syncthreads();
-    make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);                    // :63
+    // :63 record! at the final iterate.  When the solver left its loops at the optimality test of an inner iteration (the usual
+    // exit) that iteration's record! was made at this very iterate with these very multipliers: the same numbers, so the
+    // assemble pass is not repeated, the record is pushed again (with the Delta and outer index this call passes)
+    if (fresh && status == ALG_STATUS_OK) {
+        if (phase_lane() == 0) {
+            CPR prs = phase_params(pr); const Game Gs = G.fresh();
+            alg_game_stats* st = Gs.st(prs);
+            st->last.outer = out; st->last.delta = Delta; st->last.alpha = 0.0; st->last.ls_j = 0;
+            const int idx = st->records;
+            if (idx < prs.hist_max) {
+                alg_record* dst = Gs.hist(prs) + idx; const alg_record* src = &st->last;
+                dst->outer = src->outer; dst->ls_j = src->ls_j; dst->alpha = src->alpha; dst->res = src->res; dst->delta = src->delta;
+                dst->dyn_vio = src->dyn_vio; dst->con_vio = src->con_vio; dst->sta_vio = src->sta_vio; dst->opt_vio = src->opt_vio;
+            }
+            st->records = idx + 1;
+        }
+    } else make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);
     settle_traj<C>(pr, G);
     if (phase_lane() == 0) { alg_game_stats* st = G.fresh().st(phase_params(pr)); st->status = status; st->outer_iters = out; }
 }

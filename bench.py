@@ -228,9 +228,13 @@ def main():
     if args.mpc_steps:
         it_, cv_ = b.mpc_totals()
         iters_rank, conv_rank = int(it_.sum()), int(cv_.sum())
+        per_game = it_
     else:
         iters_rank = int(st["newton_iters"].sum())
         conv_rank = int(st["converged"].sum())
+        per_game = st["newton_iters"]
+    # one launch lasts as long as its slowest game: mean / max of the per-game iteration counts (1.0 = homogeneous batch)
+    balance = float(per_game.mean() / max(1, per_game.max()))
     bad_rank = int((st["status"] != 0).sum())
     (iters_all, conv_all, bad_all), elapsed = reduce_counters([iters_rank, conv_rank, bad_rank], elapsed, world, "cuda")
 
@@ -270,6 +274,7 @@ def main():
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
                        "parallelism": f"scenario-sharded x{world}", "wavefronts_per_game": waves_per_game,
+                       "iters_per_game_mean_over_max_rank0": balance,
                        "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve)" if args.mpc_steps
                                   else "fused per-game newton_solve! kernel")},
             "games_to_convergence_per_sec": conv_all * K / elapsed,

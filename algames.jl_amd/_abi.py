@@ -11,6 +11,7 @@ ALG_OK = 0
 ALG_MODEL_DOUBLE_INTEGRATOR = 0
 ALG_MODEL_UNICYCLE = 1
 ALG_MODEL_BICYCLE = 2
+ALG_MODEL_QUADROTOR = 3
 ALG_TRAJ_PD, ALG_TRAJ_TRIAL, ALG_TRAJ_DELTA = 0, 1, 2
 ALG_STATUS_OK, ALG_STATUS_SINGULAR, ALG_STATUS_NAN = 0, 1, 2
 

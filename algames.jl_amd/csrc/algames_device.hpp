@@ -116,23 +116,29 @@ struct Cfg {
     static constexpr int NW = NW_, NT = NW_ * 64;          // wavefronts / threads per game
     static constexpr bool EXT = EXT_ != 0;
     static constexpr bool POS = (P_ > 1) || EXT;     // position blocks (pair / wall / circle terms) present in Q^_i
-    static constexpr int n = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 * D_ * P_ : 4 * P_;
-    static constexpr int m = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? D_ * P_ : 2 * P_;
+    // QuadrotorGame (quadrotor.jl:20-46): dense 12 x 12 / 12 x 4 Jacobian blocks per player, n up to 48 -- its Newton direction is
+    // the LDS-resident dense variant (newton_direction_dense) instead of the single 16 x 16 tile path
+    static constexpr bool DENSE = MODEL_ == ALG_MODEL_QUADROTOR;
+    static constexpr int n = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 * D_ * P_ : DENSE ? 12 * P_ : 4 * P_;
+    static constexpr int m = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? D_ * P_ : DENSE ? 4 * P_ : 2 * P_;
     static constexpr int mi = m / P_;
     static constexpr int ni = n / P_;
     static constexpr int b = n + m + P_ * n;
     static constexpr int NPAIR = P_ * (P_ - 1);
     // position dimensions that carry pair / wall terms: px[i] = (x, y) everywhere (double_integrator.jl:19, unicycle.jl, bicycle.jl);
     // the 3-D ingredients (spherical collision avoidance, Wall3D, Cylinder) act on pz[i][1:3] = (x, y, z) of DoubleIntegrator d = 3
-    static constexpr int PD = (EXT_ != 0 && MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR && D_ == 3) ? 3 : 2;
+    static constexpr int PD = (EXT_ != 0 && ((MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR && D_ == 3) || DENSE)) ? 3 : 2;
     static constexpr int NS = PD * (PD + 1) / 2;          // entries of a symmetric PD x PD block: (0,0) (0,1) (1,1) [(0,2) (1,2) (2,2)]
     __host__ __device__ static constexpr int sym(int a, int c) { return PD == 2 ? a + c : (a > c ? a * (a + 1) / 2 + c : c * (c + 1) / 2 + a); }
-    static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : (MODEL_ == ALG_MODEL_BICYCLE) ? 10 * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
+    // quadrotor: per player [A_i (12 x 12, row-major) | B_i (12 x 4) | RK2(x_k, u_k) entries of the player (12)]
+    static constexpr int QA = 0, QB = 144, QX = 192, QS = 204;
+    static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : (MODEL_ == ALG_MODEL_BICYCLE) ? 10 * P_ : DENSE ? QS * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
     static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : (MODEL_ == ALG_MODEL_UNICYCLE) ? 3 : 2;   // max non-zeros of a column of [B_k | A_k]
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
     // (the 3-D EXT instantiation carries 3 x 3 position blocks and does not fit 128 VGPRs without scratch)
-    static constexpr int WPE = (n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3)) ? 2 : 4;
+    // (the 4-player quadrotor's LDS-resident direction leaves room for one workgroup per CU)
+    static constexpr int WPE = (DENSE && P_ >= 4) ? 1 : (n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3)) ? 2 : 4;
     // reuse the accepted line-search trial as the next record! (one assemble pass less per Newton iteration)
     static constexpr bool TRIAL_REUSE = true;
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
@@ -229,6 +235,71 @@ __host__ __device__ inline double counter_uniform(uint64_t seed, uint64_t game, 
 //     coef[9] = d psi+/d delta = dt vm sg'
 //     d x+/d a = dt/2 coef5, d y+/d a = dt/2 coef6, d v+/d a = dt, d psi+/d a = dt/2 coef4        (each coef[t] at [t*P + i])
 // ================================================================================================
+// ---- QuadrotorGame (quadrotor.jl:49-121).  Player-local state [r (0..2) | MRP g (3..5) | v (6..8) | omega (9..11)], rotor commands
+// w1..w4.  Rotations.jl 1.0 MRP: rotation matrix I + (4 (1 - s) [g x] + 8 [g x]^2) / (1 + s)^2, s = |g|^2 (only its third column is
+// needed: the rotor force acts along body z); kinematics(g, w) = 1/4 ((1 - s) w + 2 g x w + 2 (g . w) g).  Written once for a
+// scalar type T: double for the value, Jet (value + one directional derivative) for a column of the RK2 Jacobian -- the
+// forward-mode AD of discrete_jacobian! (local_quantities.jl:20-27) with one seed direction per lane.
+struct Jet { double v, d; };
+__device__ __forceinline__ Jet operator+(const Jet& a, const Jet& b) { return Jet{a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Jet operator-(const Jet& a, const Jet& b) { return Jet{a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Jet operator*(const Jet& a, const Jet& b) { return Jet{a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Jet operator/(const Jet& a, const Jet& b) { const double q = a.v / b.v; return Jet{q, (a.d - q * b.d) * (1.0 / b.v)}; }
+__device__ __forceinline__ Jet operator*(const Jet& a, double s) { return Jet{a.v * s, a.d * s}; }
+__device__ __forceinline__ Jet operator+(const Jet& a, double s) { return Jet{a.v + s, a.d}; }
+__device__ __forceinline__ Jet max0(const Jet& a) { return a.v > 0.0 ? a : Jet{0.0, 0.0}; }      // ForwardDiff: derivative of the selected branch
+__device__ __forceinline__ double max0(double a) { return a > 0.0 ? a : 0.0; }
+template <class T>
+__device__ __forceinline__ void quad_f(const T (&x)[12], const T (&u)[4], T (&xd)[12]) {
+    const double mass = 0.5, J0 = 0.0023, J1 = 0.0023, J2 = 0.004, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
+    const T g0 = x[3], g1 = x[4], g2 = x[5], w0 = x[9], w1 = x[10], w2 = x[11];
+    const T F1 = max0(u[0] * kf), F2 = max0(u[1] * kf), F3 = max0(u[2] * kf), F4 = max0(u[3] * kf);
+    const T Ft = F1 + F2 + F3 + F4;
+    const T s = g0 * g0 + g1 * g1 + g2 * g2;
+    const T den = (s + 1.0) * (s + 1.0);
+    const T c4 = ((s * (-1.0)) + 1.0) * 4.0;
+    const T r02 = (c4 * g1 + (g0 * g2) * 8.0) / den;
+    const T r12 = ((c4 * g0) * (-1.0) + (g1 * g2) * 8.0) / den;
+    const T r22 = (((g0 * g0 + g1 * g1) * (-8.0)) / den) + 1.0;
+    const T t0 = (F2 - F4) * L, t1 = (F3 - F1) * L, t2 = (u[0] - u[1] + u[2] - u[3]) * km;
+    xd[0] = x[6]; xd[1] = x[7]; xd[2] = x[8];
+    const T gw = g0 * w0 + g1 * w1 + g2 * w2, oms = (s * (-1.0)) + 1.0;
+    xd[3] = (oms * w0 + (g1 * w2 - g2 * w1) * 2.0 + (gw * g0) * 2.0) * 0.25;
+    xd[4] = (oms * w1 + (g2 * w0 - g0 * w2) * 2.0 + (gw * g1) * 2.0) * 0.25;
+    xd[5] = (oms * w2 + (g0 * w1 - g1 * w0) * 2.0 + (gw * g2) * 2.0) * 0.25;
+    xd[6] = (r02 * Ft) * (1.0 / mass);
+    xd[7] = (r12 * Ft) * (1.0 / mass);
+    xd[8] = ((r22 * Ft) * (1.0 / mass)) + grav;
+    xd[9] = (t0 - (w1 * w2) * (J2 - J1)) * (1.0 / J0);
+    xd[10] = (t1 - (w2 * w0) * (J0 - J2)) * (1.0 / J1);
+    xd[11] = (t2 - (w0 * w1) * (J1 - J0)) * (1.0 / J2);
+}
+// RobotDynamics 0.3.1 RK2 (explicit midpoint) of one quadrotor
+template <class T>
+__device__ __forceinline__ void quad_rk2(const T (&x)[12], const T (&u)[4], double dt, T (&xn)[12]) {
+    T k[12], xm[12];
+    quad_f(x, u, k);
+#pragma unroll
+    for (int j = 0; j < 12; j++) xm[j] = x[j] + k[j] * (dt * 0.5);
+    quad_f(xm, u, k);
+#pragma unroll
+    for (int j = 0; j < 12; j++) xn[j] = x[j] + k[j] * dt;
+}
+
+// RobotDynamics 0.3.1 RK3 of one quadrotor (rollout!, solver_methods.jl:17)
+__device__ __forceinline__ void quad_rk3(const double (&x)[12], const double (&u)[4], double dt, double (&xn)[12]) {
+    double k1[12], k2[12], k3[12], t[12];
+    quad_f(x, u, k1);
+#pragma unroll
+    for (int j = 0; j < 12; j++) { k1[j] *= dt; t[j] = x[j] + k1[j] / 2; }
+    quad_f(t, u, k2);
+#pragma unroll
+    for (int j = 0; j < 12; j++) { k2[j] *= dt; t[j] = x[j] - k1[j] + 2 * k2[j]; }
+    quad_f(t, u, k3);
+#pragma unroll
+    for (int j = 0; j < 12; j++) { k3[j] *= dt; xn[j] = x[j] + (k1[j] + 4 * k2[j] + k3[j]) / 6; }
+}
+
 struct BikeGeom { double beta, sg, dbeta, dsg; };
 __device__ __forceinline__ BikeGeom bike_geom(double delta, double lf, double lr) {
     const double L = lr + lf, td = tan(delta), y = lr * td;
@@ -255,7 +326,17 @@ __device__ __forceinline__ void bike_coefs(CPR pr, double v, double psi, double 
 template <class C>
 __device__ __forceinline__ void model_player(CPR pr, int i, const double* x, const double* u, double dt,
                                              double* xn /*ni: entries pz(i,j)*/, double* coef /*4: entries j*P+i (unicycle only)*/) {
-    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+    if constexpr (C::DENSE) {
+        double xi[12], ui[4], xo[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) xi[j] = x[i + j * C::P];
+#pragma unroll
+        for (int j = 0; j < 4; j++) ui[j] = u[i + j * C::P];
+        quad_rk2(xi, ui, dt, xo);
+#pragma unroll
+        for (int j = 0; j < 12; j++) xn[j] = xo[j];
+        coef[0] = coef[1] = coef[2] = coef[3] = 0.0;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
         for (int j = 0; j < C::D; j++) {
             const int ip = i + j * C::P, iv = C::m + i + j * C::P;
@@ -325,7 +406,13 @@ __device__ __forceinline__ void model_player_rk3(CPR pr, int i, const double* x,
 // masks the coefficients, so that divergent rows do not serialise their memory latencies.
 template <class C, class V>
 __device__ __forceinline__ double AT_vec(const double* coef, double dt, V v, int r) {
-    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+    if constexpr (C::DENSE) {
+        const int P = C::P, i = r % P, a = r / P; const double* Ai = coef + i * C::QS + C::QA;
+        double acc = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 < 12; a2++) acc += Ai[a2 * 12 + a] * v(a2 * P + i);
+        return acc;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         const bool hi = r >= C::m;
         return v(r) + (hi ? dt : 0.0) * v(hi ? r - C::m : r);
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
@@ -343,7 +430,13 @@ __device__ __forceinline__ double AT_vec(const double* coef, double dt, V v, int
 // (A v)[r]
 template <class C, class V>
 __device__ __forceinline__ double A_vec(const double* coef, double dt, V v, int r) {
-    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+    if constexpr (C::DENSE) {
+        const int P = C::P, i = r % P, a = r / P; const double* Ai = coef + i * C::QS + C::QA;
+        double acc = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 < 12; a2++) acc += Ai[a * 12 + a2] * v(a2 * P + i);
+        return acc;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return r < C::m ? v(r) + dt * v(r + C::m) : v(r);
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
         const int P = C::P, blk = r / P, i = r % P;
@@ -365,7 +458,9 @@ __device__ __forceinline__ double XA_vec(const double* coef, double dt, V X, int
 template <class C>
 __device__ __forceinline__ double A_entry(const double* coef, double dt, int r, int c) {
     double e = (r == c) ? 1.0 : 0.0;
-    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+    if constexpr (C::DENSE) {
+        e = (r % C::P == c % C::P) ? coef[(r % C::P) * C::QS + C::QA + (r / C::P) * 12 + c / C::P] : 0.0;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         if (r < C::m && c == r + C::m) e = dt;
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
         const int P = C::P, br = r / P, i = r % P;
@@ -382,7 +477,9 @@ __device__ __forceinline__ double A_entry(const double* coef, double dt, int r, 
 // B[r][c]  (c: joint control index)
 template <class C>
 __device__ __forceinline__ double B_entry(const double* coef, double dt, int r, int c) {
-    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+    if constexpr (C::DENSE) {
+        return (r % C::P == c % C::P) ? coef[(r % C::P) * C::QS + C::QB + (r / C::P) * 4 + c / C::P] : 0.0;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         if (r == c) return 0.5 * dt * dt;
         if (r == c + C::m) return dt;
         return 0.0;
@@ -416,7 +513,13 @@ __device__ __forceinline__ double B_entry(const double* coef, double dt, int r, 
 // (B^T v)[c] : column c of B has <= 4 non-zeros (branch-free, see AT_vec)
 template <class C, class V>
 __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int c) {
-    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+    if constexpr (C::DENSE) {
+        const int P = C::P, i = c % P, j = c / P; const double* Bi = coef + i * C::QS + C::QB;
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 12; a++) acc += Bi[a * 4 + j] * v(a * P + i);
+        return acc;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return 0.5 * dt * dt * v(c) + dt * v(c + C::m);
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
         const int P = C::P, i = c % P; const bool k0 = (c / P) == 0;
@@ -430,7 +533,13 @@ __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int
 // (B w)[r] for a control-vector accessor w(c): row r of B has <= 2 non-zeros
 template <class C, class V>
 __device__ __forceinline__ double B_vec(const double* coef, double dt, V w, int r) {
-    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+    if constexpr (C::DENSE) {
+        const int P = C::P, i = r % P, a = r / P; const double* Bi = coef + i * C::QS + C::QB;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc += Bi[a * 4 + j] * w(j * P + i);
+        return acc;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         return r < C::m ? 0.5 * dt * dt * w(r) : dt * w(r - C::m);
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
         const int P = C::P, br = r / P, i = r % P;
@@ -571,8 +680,26 @@ template <class C> struct Rec {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // LDS of the Newton-direction sweeps
+template <class C, bool DENSE = C::DENSE> struct DirLds;
+// dense variant (newton_direction_dense): everything of one backward step LDS-resident, records and gains read from HBM / L2
 template <class C>
-struct DirLds {
+struct DirLds<C, true> {
+    static constexpr int LDP = C::n + 1;                 // row stride of [P_i | s_i] and of [F | f] (odd: conflict-free column reads)
+    static constexpr int WC = C::m + C::n + 1;           // [W | V A_k | g]
+    struct Bwd {
+        double Pm[C::P * C::n * LDP];                    // [P_i | s_i], row-major
+        double Tm[C::n * LDP];                           // [P_i F | P_i f + s_i] of the player being advanced
+        double Fx[(C::n + 1) * LDP];                     // [[F f],[0 1]]
+        double V[C::m * C::n];                           // V[c][:] = B[:,c]' P_i(c)
+        double y[C::P * C::n];                           // y_i = P_i rd + s_i
+        double Wm[C::m * WC];                            // augmented control system, row-major
+    };
+    struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n]; };
+    union { Bwd bw; Fwd fw; };
+    double red[8];
+};
+template <class C>
+struct DirLds<C, false> {
     static constexpr int LDP = C::n + 1;                 // padded row stride of P_i
     static constexpr int KB = C::n / 4;                  // k-blocks of the 16x16x4 f64 MFMA
     static constexpr int NHX = C::P * C::P * C::P * C::NS;   // expanded pair-Hessian table [i][jr][jc][NS]
@@ -663,6 +790,29 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
     double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
     // ---------------- phase A ------------------------------------------------------------------------------
+    if constexpr (C::DENSE) {
+        // quadrotor: work item = (knot k, player i, seed direction c of the player's 12 states + 4 rotor commands): column c of
+        // [A_i | B_i] = d RK2 / d (x_i, u_i)[c] by forward-mode differentiation along e_c; the item with c = 0 also leaves the
+        // RK2 value (the dyn rows of phase B read it)
+        for (int e = lane; e < (N - 1) * P * 16; e += C::NT) {
+            const int c = e & 15, i = (e >> 4) % P, k = (e >> 4) / P;
+            const double* sk = zstate<C>(z, k);
+            Jet xj[12], uj[4], xo[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) xj[j] = Jet{sk[i + j * P], c == j ? 1.0 : 0.0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) uj[j] = Jet{z[n + hu<C>(k, i) + j], c == 12 + j ? 1.0 : 0.0};
+            quad_rk2(xj, uj, dt, xo);
+            double* __restrict__ rc = G.rec(pr) + (size_t)k * R::LEN + R::COEF + i * C::QS;
+            const int o = c < 12 ? C::QA + c : C::QB + (c - 12), ld = c < 12 ? 12 : 4;
+#pragma unroll
+            for (int j = 0; j < 12; j++) rc[o + j * ld] = xo[j].d;
+            if (c == 0) {
+#pragma unroll
+                for (int j = 0; j < 12; j++) rc[C::QX + j] = xo[j].v;
+            }
+        }
+    }
     if (C::NC > 0 || C::POS) {
         const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
         constexpr int HEAD = AsmLds<C>::HEAD, SL = AsmLds<C>::SL, SPP = AsmLds<C>::SPP, SGVT = HEAD - R::GVT;   // stage offset of the table
@@ -679,7 +829,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                 bike_coefs<C>(pr, sk[2 * P + i], sk[3 * P + i], z[n + hu<C>(k, i)], z[n + hu<C>(k, i) + 1], dt, cf);
 #pragma unroll
                 for (int t = 0; t < 10; t++) rec[R::COEF + t * P + i] = cf[t];
-            } else if constexpr (C::NC > 0) {
+            } else if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
                 // Jacobian coefficients of knot k (A_k, B_k): see the model section
                 const double* sk = zstate<C>(z, k);
                 const double th = sk[2 * P + i], v = sk[3 * P + i];
@@ -949,7 +1099,9 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             const uidx po = (k == 0) ? 0u : zo - (uidx)b;                   // x_k: x_1 sits in front of block 0
             const double* Ck = recg + ro + (uidx)R::COEF;
             double xn;
-            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+            if constexpr (C::DENSE) {
+                xn = Ck[(a % P) * C::QS + C::QX + a / P];                    // RK2 value left by phase A
+            } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
                 // position rows: x + (v + dt/2 u) dt ; velocity rows: v + u dt
                 const int j = a < m ? a : a - m;
                 const double uj = z[zo + (uidx)(n + uoff<C>(j))], base = z[po + (uidx)a], vel = z[po + (uidx)(j + m)];
@@ -1393,8 +1545,216 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
 #define ALG_PROF(j)
 #define ALG_PROF_FLUSH
 #endif
+// ---- dense variant (Cfg::DENSE: QuadrotorGame, n = 12 p up to 48, dense 12 x 12 / 12 x 4 Jacobian blocks per player) ------------
+// The same structured elimination with everything of one backward step LDS-resident and all threads of the workgroup on every
+// phase: [P_i | s_i] [[F f],[0 1]] as ceil(n/16) x ceil((n+1)/16) tiles of v_mfma_f64_16x16x4_f64 chains (the tiles of a player are
+// spread over the wavefronts), the block-diagonal A_{k+1}' applied from LDS, the m x (m + n + 1) control system solved by a
+// partially pivoted Gauss-Jordan in LDS (one column per thread); records and gains are read from / written to HBM (L2) directly.
+template <class C, bool IBR>
+__device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip, double* primal_l1) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, WC = DirLds<C>::WC, NK = m * (n + 1);
+    constexpr int BT = C::NT, NWV = BT / WAVE;
+    constexpr int TR = (n + 15) / 16, TC = (n + 1 + 15) / 16, KBN = (n + 1 + 3) / 4;
+    static_assert(NWV <= 4, "cross-wavefront reduction slots");
+    using R = Rec<C>;
+    const int N = phase_int(pr.N), tid = phase_lane(), lane = tid & 63, wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
+    const double dt = phase_f64(pr.dt);
+    const double* __restrict__ recs = G.rec(pr);
+    const double* __restrict__ Qd = G.Qd(pr);
+    double* __restrict__ kg = G.kgain(pr);
+    auto& B = L.bw;
+    for (int e = tid; e < (n + 1) * LDP; e += BT) B.Fx[e] = (e == n * LDP + n) ? 1.0 : 0.0;     // last row e_n: passes s_i through the product
+    for (int e = tid; e < P * n * LDP; e += BT) B.Pm[e] = 0.0;
+    int sing = 0;
+    __syncthreads();
+    // ------------------------------------------------------------------ backward sweep
+    for (int k = N - 2; k >= 0; k--) {
+        const double* Rc = recs + (size_t)k * R::LEN;
+        const double* coefk = Rc + R::COEF;
+        const double* coefn = Rc + R::LEN + R::COEF;                        // A_{k+1} (only read while k < N - 2)
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
+        // ---- value recursion: [P_i | s_i] <- A_{k+1}' ([P_i | s_i] [[F f],[0 1]])
+        if (k < N - 2) {
+            for (int i = 0; i < P; i++) {
+                if (IBR && i != ip) continue;
+                double* Pi = &B.Pm[i * n * LDP];
+                for (int t = wv; t < TR * TC; t += NWV) {
+                    const int tr = t / TC, tc = t % TC, arow = 16 * tr + lrow, bcol = 16 * tc + lrow;
+                    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kb = 0; kb < KBN; kb++) {
+                        const int kk = 4 * kb + lq;
+                        const bool aok = arow < n && kk <= n, bok = kk <= n && bcol <= n;
+                        const double av = Pi[aok ? arow * LDP + kk : 0], bv = B.Fx[bok ? kk * LDP + bcol : 0];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? av : 0.0, bok ? bv : 0.0, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) { const int row = 16 * tr + lq + 4 * r4; if (row < n && bcol <= n) B.Tm[row * LDP + bcol] = acc[r4]; }
+                }
+                __syncthreads();
+                for (int e = tid; e < n * LDP; e += BT) {
+                    const int r = e / LDP, c = e % LDP;
+                    Pi[e] = AT_vec<C>(coefn, dt, [&](int rr) { return B.Tm[rr * LDP + c]; }, r);
+                }
+                __syncthreads();
+            }
+        }
+        // ---- + [Q^_i | rx_i]: diagonal, position block, column n
+        for (int e = tid; e < P * n; e += BT) {
+            const int i = e / n, r = e % n;
+            if (IBR && i != ip) continue;
+            double* row = &B.Pm[i * n * LDP + r * LDP];
+            double qd = reg + ((r % P == i) ? w * Qd[i * C::ni + r / P] : 0.0);
+            if constexpr (C::EXT) qd += Rc[R::RQ + e];
+            row[r] += qd;
+            row[n] += Rc[R::RX + e];
+            if (C::POS && r < C::PD * P) {
+                for (int c = 0; c < C::PD * P; c++) row[c] += pairblock<C>(Rc + R::HH, i, r, c);
+            }
+        }
+        __syncthreads();
+        // ---- V[c][:] = B[:,c]' P_i(c),  y_i = P_i rd + s_i
+        for (int e = tid; e < m * n; e += BT) {
+            const int c = e / n, col = e % n; const double* Pi = &B.Pm[(c % P) * n * LDP];
+            B.V[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
+        }
+        for (int e = tid; e < P * n; e += BT) {
+            const double* Pr = &B.Pm[e * LDP];
+            double a = Pr[n];
+            for (int c = 0; c < n; c++) a += Pr[c] * Rc[R::RD + c];
+            B.y[e] = a;
+        }
+        __syncthreads();
+        // ---- [ W | V A_k | g ],  W = diag(R^) + V B,  g_c = ru_c + B[:,c]' y_i(c)
+        for (int e = tid; e < m * WC; e += BT) {
+            const int c = e / WC, t = e % WC;
+            const double* Vc = &B.V[c * n];
+            double v;
+            if (t < m) v = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rc[R::RHAT + c] : 0.0);
+            else if (t < m + n) v = (k >= 1) ? AT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t - m) : 0.0;     // dx_1 = 0: A_0 never acts
+            else { const double* yi = &B.y[(c % P) * n]; v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
+            if (IBR) {
+                if (c % P != ip) v = (t == c) ? 1.0 : 0.0;                   // unit row: du_c = 0
+                else if (t < m && t % P != ip) v = 0.0;                      // fixed controls of the other players
+            }
+            B.Wm[e] = v;
+        }
+        __syncthreads();
+        // ---- partially pivoted Gauss-Jordan (pivot rule and row operations of gj_solve_cols); thread t owns column t
+        for (int c = 0; c < m; c++) {
+            double pc[m];
+            double best = fabs(B.Wm[c * WC + c]); int piv = c;
+            for (int r = c + 1; r < m; r++) { const double v = fabs(B.Wm[r * WC + c]); if (v > best) { best = v; piv = r; } }
+            if (!(best > 0.0) || !isfinite(best)) sing = 1;
+            __syncthreads();
+            if (piv != c) {
+                for (int t = tid; t < WC; t += BT) { const double a = B.Wm[c * WC + t]; B.Wm[c * WC + t] = B.Wm[piv * WC + t]; B.Wm[piv * WC + t] = a; }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int r = 0; r < m; r++) pc[r] = B.Wm[r * WC + c];
+            const double rpiv = fast_rcp(pc[c]);
+            __syncthreads();
+            for (int t = tid; t < WC; t += BT) {
+                const double prow = B.Wm[c * WC + t] * rpiv;
+#pragma unroll
+                for (int r = 0; r < m; r++) if (r != c) B.Wm[r * WC + t] -= pc[r] * prow;
+                B.Wm[c * WC + t] = prow;
+            }
+            __syncthreads();
+        }
+        // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
+        for (int e = tid; e < NK; e += BT) { const int col = e / m, c = e % m; kg[(size_t)k * NK + e] = -B.Wm[c * WC + m + col]; }
+        if (k > 0) {
+            for (int e = tid; e < n * LDP; e += BT) {
+                const int r = e / LDP, col = e % LDP;
+                const double base = col < n ? A_entry<C>(coefk, dt, r, col) : Rc[R::RD + r];
+                B.Fx[e] = base + B_vec<C>(coefk, dt, [&](int c2) { return -B.Wm[c2 * WC + m + col]; }, r);
+            }
+        }
+        __syncthreads();
+    }
+    if (sing) return ALG_STATUS_SINGULAR;                  // uniform: every thread saw the same pivots
+    // ------------------------------------------------------------------ forward sweep: dx, du
+    double* __restrict__ dz = G.z(2);
+    auto& F = L.fw;
+    for (int e = tid; e < n; e += BT) { F.dx[e] = 0.0; dz[e] = 0.0; }
+    __syncthreads();
+    double pl1 = 0.0; int bad = 0;
+    constexpr int XPT = (n + BT - 1) / BT;
+    for (int k = 0; k < N - 1; k++) {
+        const double* Rc = recs + (size_t)k * R::LEN;
+        const double* coefk = Rc + R::COEF;
+        const double* Kg = kg + (size_t)k * NK;
+        for (int c = tid; c < m; c += BT) {
+            double a = Kg[n * m + c];
+            for (int q = 0; q < n; q++) a += Kg[q * m + c] * F.dx[q];
+            F.du[c] = a; dz[n + hu<C>(k, 0) + uoff<C>(c)] = a;
+            pl1 += fabs(a); bad |= !isfinite(a);
+        }
+        __syncthreads();
+        double nx[XPT];
+#pragma unroll
+        for (int q = 0; q < XPT; q++) {
+            const int r = tid + q * BT; nx[q] = 0.0;
+            if (r < n) nx[q] = (A_vec<C>(coefk, dt, [&](int rr) { return F.dx[rr]; }, r) + B_vec<C>(coefk, dt, [&](int cc) { return F.du[cc]; }, r)) + Rc[R::RD + r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < XPT; q++) {
+            const int r = tid + q * BT;
+            if (r < n) { F.dx[r] = nx[q]; dz[n + hx<C>(k) + r] = nx[q]; pl1 += fabs(nx[q]); bad |= !isfinite(nx[q]); }
+        }
+        __syncthreads();
+    }
+    // ------------------------------------------------------------------ costate sweep:
+    //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
+    for (int k = N - 2; k >= 0; k--) {
+        const double* Rc = recs + (size_t)k * R::LEN;
+        const double* coefn = Rc + R::LEN + R::COEF;
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
+        const int cur = k & 1;
+        for (int e = tid; e < n; e += BT) F.dx[e] = dz[n + hx<C>(k) + e];
+        __syncthreads();
+        for (int e = tid; e < P * n; e += BT) {
+            const int i = e / n, r = e % n;
+            double acc = 0.0;
+            if (!IBR || i == ip) {
+                double qd = reg + ((r % P == i) ? w * Qd[i * C::ni + r / P] : 0.0);
+                if constexpr (C::EXT) qd += Rc[R::RQ + e];
+                acc = Rc[R::RX + e] + qd * F.dx[r];
+                if (C::POS && r < C::PD * P) {
+                    for (int c = 0; c < C::PD * P; c++) acc += pairblock<C>(Rc + R::HH, i, r, c) * F.dx[c];
+                }
+                if (k < N - 2) { const double* dli = &F.dl[cur ^ 1][i * n]; acc += AT_vec<C>(coefn, dt, [&](int rr) { return dli[rr]; }, r); }
+            }
+            F.dl[cur][e] = acc; dz[n + hl<C>(k, 0) + e] = acc; bad |= !isfinite(acc);
+        }
+        __syncthreads();
+    }
+    pl1 = wave_sum(pl1); bad = wave_or(bad);
+    if constexpr (NWV > 1) {
+        if (lane == 0) { L.red[wv] = pl1; L.red[4 + wv] = (double)bad; }
+        __syncthreads();
+        pl1 = 0.0; bad = 0;
+#pragma unroll
+        for (int q = 0; q < NWV; q++) { pl1 += L.red[q]; bad |= (int)L.red[4 + q]; }
+    }
+    if (primal_l1) *primal_l1 = pl1;
+    return __builtin_amdgcn_readfirstlane(bad) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;
+}
+
+template <class C, bool IBR>
+__device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip, double* primal_l1);
 template <class C, bool IBR = false>
-__device__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
+__device__ __forceinline__ int newton_direction(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip = -1, double* primal_l1 = nullptr) {
+    if constexpr (C::DENSE) return newton_direction_dense<C, IBR>(pr0, G0, L, reg, ip, primal_l1);
+    else return newton_direction_tile<C, IBR>(pr0, G0, L, reg, ip, primal_l1);
+}
+template <class C, bool IBR>
+__device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip, double* primal_l1) {
     CPR pr = phase_params(pr0);
     Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);
@@ -2055,6 +2415,21 @@ template <class C>
 __device__ __forceinline__ void rollout(CPR pr, double* z) {
     constexpr int n = C::n, m = C::m, P = C::P;
     const int lane = threadIdx.x;
+    if constexpr (C::DENSE) {
+        if (lane < P) {
+            double xi[12], ui[4], xo[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) xi[j] = z[lane + j * P];
+            for (int k = 0; k < pr.N - 1; k++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) ui[j] = z[n + hu<C>(k, lane) + j];
+                quad_rk3(xi, ui, pr.dt, xo);
+#pragma unroll
+                for (int j = 0; j < 12; j++) { xi[j] = xo[j]; z[n + hx<C>(k) + lane + j * P] = xo[j]; }
+            }
+        }
+        return;
+    }
     if (lane < P) {
         double x[n], u[m];     // only this player's entries are used
         for (int j = 0; j < C::ni; j++) x[lane + j * P] = z[lane + j * P];

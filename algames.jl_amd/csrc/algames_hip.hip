@@ -10,6 +10,7 @@
 
 // the EXT instantiations are defined in algames_ext_*.hip, the team kernels in algames_mw.hip
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
+ALG_CFGS_QUAD(ALG_DECLARE_KERNELS)
 ALG_CFGS_MW(ALG_DECLARE_MW)
 
 __global__ void __launch_bounds__(WAVE) k_reset_con(Params pr_arg) {
@@ -42,6 +43,9 @@ bool fill_dims(const alg_desc& a, Params& p) {
     } else if (a.model == ALG_MODEL_UNICYCLE || a.model == ALG_MODEL_BICYCLE) {
         p.d = 2; p.n = 4 * p.p; p.m = 2 * p.p; p.mi = 2; p.ni = 4;
         p.lf = p.lr = 0.05;                                              // BicycleGame defaults, bicycle.jl:15
+    } else if (a.model == ALG_MODEL_QUADROTOR) {                          // quadrotor.jl:20-46
+        if (a.p > 4) return false;
+        p.d = 3; p.n = 12 * p.p; p.m = 4 * p.p; p.mi = 4; p.ni = 12;
     } else return false;
     p.S = p.n * p.p * (p.N - 1) + p.m * (p.N - 1) + p.n * (p.N - 1);     // problem_size.jl:22
     p.b = p.n + p.m + p.p * p.n;
@@ -56,8 +60,8 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.hist_max = HIST_MAX;
     p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
     {   // Rec<C>::LEN of the EXT instantiation (the base one is p n shorter; the buffer is sized for either)
-        const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : 0;
-        const int pd = (p.model == ALG_MODEL_DOUBLE_INTEGRATOR && p.d == 3) ? 3 : 2, ns = pd * (pd + 1) / 2;   // Cfg::PD / NS of the EXT instantiation
+        const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : (p.model == ALG_MODEL_QUADROTOR) ? 204 * p.p : 0;
+        const int pd = (p.d == 3) ? 3 : 2, ns = pd * (pd + 1) / 2;   // Cfg::PD / NS of the EXT instantiation
         p.rec_len = (p.N - 1) * (nc + ns * p.npair + ns * p.p + p.m + 2 * p.p * p.n + p.m + p.n + pd * p.p * p.p);
     }
     return true;
@@ -76,6 +80,7 @@ bool cfg_supported(const Params& p, int ext) {
 #define X(M, P, D, E) if (p.model == (M) && p.p == (P) && p.d == (D) && ext == (E)) return true;
     ALG_CFGS_BASE(X)
     ALG_CFGS_EXT(X)
+    ALG_CFGS_QUAD(X)
 #undef X
     return false;
 }
@@ -186,7 +191,11 @@ int launch_check(const char* what) {
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 1, 2, 1, kernel, __VA_ARGS__)                    \
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 2, 2, 1, kernel, __VA_ARGS__)                    \
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 3, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 4, 2, 1, kernel, __VA_ARGS__)
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 4, 2, 1, kernel, __VA_ARGS__)                    \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 1, 3, 0, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 2, 3, 0, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 3, 3, 0, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 4, 3, 0, kernel, __VA_ARGS__)
 
 void dfree(Handle* h, void* q) {
     for (size_t i = 0; i < h->allocs.size(); i++)
@@ -335,7 +344,7 @@ int alg_create(const alg_desc* d, alg_handle** out) {
     if (!d || !out) return fail(ALG_ERR_ARG, "alg_create: null argument");
     Handle* hd = new Handle();
     if (!fill_dims(*d, hd->pr) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "alg_create: unsupported descriptor"); }
-    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2 p<=4, d=3 p=2; Unicycle p<=4; Bicycle p<=4)"); }
+    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2 p<=4, d=3 p=2; Unicycle p<=4; Bicycle p<=4; Quadrotor p<=4)"); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete hd; return fail(ALG_ERR_DEVICE, "alg_create: no HIP device available (this library has no CPU fallback)"); }
     if (d->device < 0 || d->device >= ndev) { delete hd; return fail(ALG_ERR_ARG, "alg_create: bad device ordinal"); }
@@ -458,7 +467,7 @@ static int ext_commit(Handle* hd) {
     int rc = use_device(hd); if (rc) return rc;
     if ((rc = sync(hd))) return rc;
     Params& p = hd->pr;
-    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 p<=4 / d=3 p=2, Unicycle, Bicycle p<=4)");
+    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 p<=4 / d=3 p=2, Unicycle, Bicycle p<=4; the Quadrotor kernels carry collision avoidance / collision cost / control bounds only)");
     p.ext = 1;
     recount_con(p);
     dfree(hd, p.con); p.con = nullptr;

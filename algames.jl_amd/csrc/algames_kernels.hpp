@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(WAVE) k_init(Params pr_arg, uint64_t game_id0,
 
 // mode 0: ibr_newton_solve!(prob, player) on the stored trajectory ; mode 1: ibr_newton_solve!(prob; ibr_opts)
 template <class C>
-__global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr_arg, int mode, int player, int init, uint64_t game_id0,
+__global__ void __launch_bounds__(WAVE, (C::WPE < 2 ? C::WPE : 2)) k_ibr(Params pr_arg, int mode, int player, int init, uint64_t game_id0,
                                                       int ibr_iter, IbrOrder order, double delta_min) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
@@ -133,7 +133,18 @@ __global__ void __launch_bounds__(WAVE, 2) k_ibr(Params pr_arg, int mode, int pl
 template <class C>
 __device__ __forceinline__ void mpc_advance(CPR pr, const Game& G) {
     const int lane = threadIdx.x;
-    if (lane < C::P) {
+    if constexpr (C::DENSE) {
+        if (lane < C::P) {
+            double xi[12], ui[4], xo[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) xi[j] = G.z(0)[lane + j * C::P];
+#pragma unroll
+            for (int j = 0; j < 4; j++) ui[j] = G.z(0)[C::n + hu<C>(0, lane) + j];
+            quad_rk2(xi, ui, pr.dt, xo);
+#pragma unroll
+            for (int j = 0; j < 12; j++) { const int a = lane + j * C::P; G.x0w(pr)[a] = xo[j]; G.z(0)[a] = xo[j]; G.z(1)[a] = xo[j]; }
+        }
+    } else if (lane < C::P) {
         double x[C::n], u[C::m], xo[C::ni], co[4];
         for (int j = 0; j < C::ni; j++) x[lane + j * C::P] = G.z(0)[lane + j * C::P];
         for (int j = 0; j < C::mi; j++) u[lane + j * C::P] = G.z(0)[C::n + hu<C>(0, lane) + j];
@@ -162,7 +173,7 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr_arg) {
 // one faulted on a null base pointer (tests/test_gpu_parity_ext.py::test_no_kernel_writes_outside_its_buffers runs this
 // kernel for every instantiation).
 template <class C>
-__global__ void __launch_bounds__(C::NT, 2) k_mpc_loop(Params pr_arg, int steps, uint64_t game_id0, double* states) {
+__global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(Params pr_arg, int steps, uint64_t game_id0, double* states) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -208,6 +219,12 @@ __global__ void __launch_bounds__(C::NT, 2) k_mpc_loop(Params pr_arg, int steps,
     X(ALG_MODEL_BICYCLE, 4, 2, 1)
 #define ALG_CFGS_EXT_DI3(X)                                 \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, 1)
+// QuadrotorGame (quadrotor.jl:22: p <= 4), dense Newton direction (algames_quad.hip)
+#define ALG_CFGS_QUAD(X)                                    \
+    X(ALG_MODEL_QUADROTOR, 1, 3, 0)                          \
+    X(ALG_MODEL_QUADROTOR, 2, 3, 0)                          \
+    X(ALG_MODEL_QUADROTOR, 3, 3, 0)                          \
+    X(ALG_MODEL_QUADROTOR, 4, 3, 0)
 #define ALG_CFGS_EXT(X) ALG_CFGS_EXT_DI(X) ALG_CFGS_EXT_UNI(X) ALG_CFGS_EXT_BIC(X) ALG_CFGS_EXT_DI3(X)
 
 // every kernel of one instantiation; PREFIX is `template` (definition) or `extern template` (declaration)

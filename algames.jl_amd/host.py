@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import (ALG_MODEL_BICYCLE, ALG_MODEL_DOUBLE_INTEGRATOR, ALG_MODEL_UNICYCLE, ALG_TRAJ_PD, ALG_TRAJ_TRIAL,
+from ._abi import (ALG_MODEL_BICYCLE, ALG_MODEL_DOUBLE_INTEGRATOR, ALG_MODEL_QUADROTOR, ALG_MODEL_UNICYCLE, ALG_TRAJ_PD, ALG_TRAJ_TRIAL,
                    ALG_TRAJ_DELTA, AlgamesError, Batch, CLib)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -83,7 +83,27 @@ class BicycleGame(AbstractGameModel):
         self.mi = [2] * p
 
 
+class QuadrotorGame(AbstractGameModel):
+    """QuadrotorGame(; p, mass), src/dynamics/quadrotor.jl:3-46: per player 12 states [x, y, z | MRP q1 q2 q3 | vx vy vz | wx wy wz]
+    and 4 rotor commands; the constructor's constants (J, gravity, motor_dist, kf, km) are fixed in the reference."""
+    model_id = ALG_MODEL_QUADROTOR
+
+    def __init__(self, p=2, mass=0.5):
+        assert p <= 4                      # quadrotor.jl:22
+        if mass != 0.5:
+            raise AlgamesError("QuadrotorGame: only the default mass = 0.5 is bound")
+        self.p, self.d, self.mass = p, 3, float(mass)
+        self.n, self.m = 12 * p, 4 * p
+        self.pu = [[i + (j - 1) * p for j in range(1, 5)] for i in range(1, p + 1)]
+        self.px = [[i + (j - 1) * p for j in range(1, 3)] for i in range(1, p + 1)]
+        self.pz = [[i + (j - 1) * p for j in range(1, 13)] for i in range(1, p + 1)]
+        self.ni = [12] * p
+        self.mi = [4] * p
+
+
 def dim(model):
+    if isinstance(model, QuadrotorGame):
+        return 3                           # quadrotor.jl:208
     return model.mi[0] if isinstance(model, DoubleIntegratorGame) else 2
 
 

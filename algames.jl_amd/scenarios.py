@@ -111,8 +111,44 @@ def c3_unicycle(ids, N=50, seed=100, p=4, target_offset=0.1):
     return model, N, dt, x0, game_obj, game_con, opts
 
 
+def quadrotor_crossing(ids, N=20, seed=100, p=2):
+    """'Q' (not a BASELINE configuration): p quadrotors (src/dynamics/quadrotor.jl) start at rest on a circle of
+    radius 0.6 m at height 0.5 m, +- 5 cm, and fly to the opposite side rotated by 0.3 rad while holding height: hover thrust
+    reference uf = m g / (4 kf), planar collision avoidance on px[i] = (x, y) (quadrotor.jl:34) with radius 0.1 m, rotor
+    commands bounded to [0, 3]."""
+    ids = np.asarray(ids, dtype=np.int64)
+    model = host.QuadrotorGame(p=p)
+    dt = 0.1
+    B = len(ids)
+    hover = 0.5 * 9.81 / 4 / 1.245
+    ang = 2 * np.pi * np.arange(p) / p + _uniform(seed, ids, p, -0.1, 0.1)
+    jit = _uniform(seed + 1, ids, 3 * p, -0.05, 0.05).reshape(B, 3, p)
+    x0 = np.zeros((B, model.n))
+    x0[:, 0:p] = 0.6 * np.cos(ang) + jit[:, 0]
+    x0[:, p:2 * p] = 0.6 * np.sin(ang) + jit[:, 1]
+    x0[:, 2 * p:3 * p] = 0.5 + jit[:, 2]
+    Q = [np.concatenate([np.ones(3), 0.5 * np.ones(3), 0.2 * np.ones(3), 0.2 * np.ones(3)]) for _ in range(p)]
+    R = [0.1 * np.ones(4) for _ in range(p)]
+    game_obj = host.GameObjective(Q, R, [np.zeros(12)] * p, [hover * np.ones(4)] * p, N, model)
+    xf = np.zeros((B, p, 12))
+    xf[:, :, 0], xf[:, :, 1], xf[:, :, 2] = 0.6 * np.cos(ang + np.pi + 0.3), 0.6 * np.sin(ang + np.pi + 0.3), 0.5
+    game_obj.xf = xf
+    game_obj.Qdiag = np.broadcast_to(game_obj.Qdiag, (B, p, 12)).copy()
+    game_obj.Rdiag = np.broadcast_to(game_obj.Rdiag, (B, p, 4)).copy()
+    game_obj.uf = np.broadcast_to(game_obj.uf, (B, p, 4)).copy()
+    game_con = host.GameConstraintValues(host.ProblemSize(N, model))
+    if p > 1:
+        host.add_collision_avoidance(game_con, 0.1)
+    host.add_control_bound(game_con, 3.0 * np.ones(model.m), np.zeros(model.m))
+    # reg_0 = 1e-5: with the default 1e-3 the proximal term reg_0 l^4 of the later inner iterations holds the attitude states back
+    # and the optimality test is not met within the default iteration limits (the CPU oracle behaves the same way)
+    opts = host.Options(inner_print=False, outer_print=False, seed=seed, reg_0=1e-5)
+    return model, N, dt, x0, game_obj, game_con, opts
+
+
 def make_problem(cfg, ids, backend=None, device=0, **kw):
-    """cfg in {'C2','C3','C4','C5'} -> GameProblem over the scenarios `ids` (global scenario ids)."""
+    """cfg in {'C2','C3','C4','C5'} (BASELINE configurations) or 'Q' (quadrotors) -> GameProblem over the scenarios `ids`
+    (global scenario ids)."""
     ids = np.asarray(ids, dtype=np.int64)
     if cfg in ("C2", "C4"):                      # C4 = the C2 problem, 65 536 scenarios sharded over 8 GPUs
         model, N, dt, x0, obj, con, opts = c2_double_integrator(ids, **kw)
@@ -120,6 +156,8 @@ def make_problem(cfg, ids, backend=None, device=0, **kw):
         model, N, dt, x0, obj, con, opts = c3_unicycle(ids, **{"N": 50, "p": 4, **kw})
     elif cfg == "C5":
         model, N, dt, x0, obj, con, opts = c3_unicycle(ids, **{"N": 30, "p": 3, **kw})
+    elif cfg == "Q":
+        model, N, dt, x0, obj, con, opts = quadrotor_crossing(ids, **kw)
     else:
         raise ValueError(cfg)
     contiguous = len(ids) > 0 and np.array_equal(ids, ids[0] + np.arange(len(ids)))

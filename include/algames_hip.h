@@ -58,6 +58,9 @@ extern "C" {
 #define ALG_MODEL_DOUBLE_INTEGRATOR 0
 #define ALG_MODEL_UNICYCLE 1
 #define ALG_MODEL_BICYCLE 2             /* src/dynamics/bicycle.jl:2-41 (lf = lr = 0.05 unless alg_set_bicycle) */
+#define ALG_MODEL_QUADROTOR 3           /* src/dynamics/quadrotor.jl:3-206: n = 12 p, m = 4 p; per player [x(3) | MRP attitude (3) | v(3) | omega(3)],
+                                           rotor commands w1..w4; mass 0.5, J = diag(0.0023, 0.0023, 0.004), g = (0, 0, -9.81),
+                                           motor_dist 0.175, kf 1.245, km 1.0 (the constructor's values) */
 #define ALG_MAX_WALLS 8
 #define ALG_MAX_CIRCLES 8
 

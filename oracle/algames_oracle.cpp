@@ -63,6 +63,9 @@ struct Dims {
             n = 2 * d * p; m = d * p; mi = d; ni = 2 * d;
         } else if (model == ALG_MODEL_UNICYCLE || model == ALG_MODEL_BICYCLE) {
             d = 2; n = 4 * p; m = 2 * p; mi = 2; ni = 4;
+        } else if (model == ALG_MODEL_QUADROTOR) {           // quadrotor.jl:20-46
+            if (p > 4) return false;
+            d = 3; n = 12 * p; m = 4 * p; mi = 4; ni = 12;
         } else return false;
         S = n * p * (N - 1) + m * (N - 1) + n * (N - 1);   // problem_size.jl:22
         b = n + m + p * n;
@@ -117,11 +120,19 @@ struct Dual {
 inline Dual dconst(double v, int nd) { Dual r; r.v = v; r.nd = nd; for (int i = 0; i < nd; i++) r.e[i] = 0.0; return r; }
 inline Dual operator+(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v + b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] + b.e[i]; return r; }
 inline Dual operator*(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v * b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * b.v + a.v * b.e[i]; return r; }
+inline Dual operator-(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v - b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] - b.e[i]; return r; }
+inline Dual operator+(const Dual& a, double s) { Dual r = a; r.v = a.v + s; return r; }
+inline Dual operator*(double s, const Dual& a);
+inline Dual operator/(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v / b.v; const double ib = 1.0 / b.v; for (int i = 0; i < a.nd; i++) r.e[i] = (a.e[i] - r.v * b.e[i]) * ib; return r; }
+// max(0, a) as ForwardDiff differentiates it (derivative of the selected branch)
+inline Dual dmax0(const Dual& a) { if (a.v > 0.0) return a; Dual r; r.nd = a.nd; r.v = 0.0; for (int i = 0; i < a.nd; i++) r.e[i] = 0.0; return r; }
+inline double dmax0(double a) { return a > 0.0 ? a : 0.0; }
 inline Dual operator*(const Dual& a, double s) { Dual r; r.nd = a.nd; r.v = a.v * s; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * s; return r; }
 inline Dual dcos(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::cos(a.v); double s = -std::sin(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
 inline Dual dsin(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::sin(a.v); double c = std::cos(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = c * a.e[i]; return r; }
 inline Dual dtan(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::tan(a.v); double s = 1.0 + r.v * r.v; for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
 inline Dual datan2(const Dual& y, double x) { Dual r; r.nd = y.nd; r.v = std::atan2(y.v, x); double s = x / (x * x + y.v * y.v); for (int i = 0; i < y.nd; i++) r.e[i] = s * y.e[i]; return r; }
+inline Dual operator*(double s, const Dual& a) { return a * s; }
 inline double dtan(double a) { return std::tan(a); }
 inline double datan2(double y, double x) { return std::atan2(y, x); }
 inline double dcos(double a) { return std::cos(a); }
@@ -140,6 +151,42 @@ void dynamics(const Dims& D, const T* x, const T* u, T* xd) {
         for (int i = 0; i < P; i++) xd[i] = dcos(x[M + i]) * x[M + i + P];
         for (int i = 0; i < P; i++) xd[P + i] = dsin(x[M + i]) * x[M + i + P];
         for (int i = 0; i < M; i++) xd[M + i] = u[i];
+    } else if (D.model == ALG_MODEL_QUADROTOR) {
+        // QuadrotorGame (quadrotor.jl:49-121), player i: r = x[(0..2)P+i], MRP g = x[(3..5)P+i], v = x[(6..8)P+i], w = x[(9..11)P+i];
+        // Rotations.jl 1.0 MRP [restated from the published source; parity unpinned]: rotation matrix of g (via the unit quaternion
+        // ((1 - |g|^2), 2 g) / (1 + |g|^2)), kinematics(g, w) = 1/4 ((1 - |g|^2) w + 2 g x w + 2 (g . w) g)
+        const int P = D.p;
+        const double mass = 0.5, Jd[3] = {0.0023, 0.0023, 0.004}, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
+        for (int i = 0; i < P; i++) {
+            const T g0 = x[3 * P + i], g1 = x[4 * P + i], g2 = x[5 * P + i];
+            const T w0 = x[9 * P + i], w1 = x[10 * P + i], w2 = x[11 * P + i];
+            const T F1 = dmax0(u[0 * P + i] * kf), F2 = dmax0(u[1 * P + i] * kf), F3 = dmax0(u[2 * P + i] * kf), F4 = dmax0(u[3 * P + i] * kf);
+            const T Ft = F1 + F2 + F3 + F4;                                   // total rotor force along body z (forces, :51-69)
+            const T s = g0 * g0 + g1 * g1 + g2 * g2;
+            const T den = (s + 1.0) * (s + 1.0);
+            // third column of R = I + (4 (1 - s) [g x] + 8 [g x]^2) / (1 + s)^2
+            const T c4 = ((s * (-1.0)) + 1.0) * 4.0;
+            const T r02 = (c4 * g1 + (g0 * g2) * 8.0) / den;
+            const T r12 = ((c4 * g0) * (-1.0) + (g1 * g2) * 8.0) / den;
+            const T r22 = (((g0 * g0 + g1 * g1) * (-8.0)) / den) + 1.0;
+            // moments (:71-94): tau = [L (F2 - F4), L (F3 - F1), km (w1 - w2 + w3 - w4)]
+            const T t0 = (F2 - F4) * L, t1 = (F3 - F1) * L, t2 = (u[0 * P + i] - u[1 * P + i] + u[2 * P + i] - u[3 * P + i]) * km;
+            // xdot = v
+            for (int a = 0; a < 3; a++) xd[a * P + i] = x[(6 + a) * P + i];
+            // qdot = kinematics(MRP, w)
+            const T gw = g0 * w0 + g1 * w1 + g2 * w2, oms = (s * (-1.0)) + 1.0;
+            xd[3 * P + i] = (oms * w0 + (g1 * w2 - g2 * w1) * 2.0 + (gw * g0) * 2.0) * 0.25;
+            xd[4 * P + i] = (oms * w1 + (g2 * w0 - g0 * w2) * 2.0 + (gw * g1) * 2.0) * 0.25;
+            xd[5 * P + i] = (oms * w2 + (g0 * w1 - g1 * w0) * 2.0 + (gw * g2) * 2.0) * 0.25;
+            // vdot = (m g + R F) / m
+            xd[6 * P + i] = (r02 * Ft) * (1.0 / mass);
+            xd[7 * P + i] = (r12 * Ft) * (1.0 / mass);
+            xd[8 * P + i] = ((r22 * Ft) * (1.0 / mass)) + grav;
+            // wdot = Jinv (tau - w x (J w))
+            xd[9 * P + i] = (t0 - (w1 * w2) * (Jd[2] - Jd[1])) * (1.0 / Jd[0]);
+            xd[10 * P + i] = (t1 - (w2 * w0) * (Jd[0] - Jd[2])) * (1.0 / Jd[1]);
+            xd[11 * P + i] = (t2 - (w0 * w1) * (Jd[1] - Jd[0])) * (1.0 / Jd[2]);
+        }
     } else {
         // BicycleGame (bicycle.jl:28-41): X = [x, y, v, psi] (each block of P), U = [a, delta];
         // beta = atan(lr tan(delta), lr + lf); Xdot = [v cos(beta+psi), v sin(beta+psi), a, v sin(beta)/lr]
@@ -1203,7 +1250,7 @@ int orc_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t nc, 
 }
 // 3-D ingredients: the reference indexes pz[i][1:3]; meaningful (positions) for DoubleIntegratorGame(d = 3) only
 static int need_3d(Handle* hd, const char* who) {
-    if (hd->sh.D.model != ALG_MODEL_DOUBLE_INTEGRATOR || hd->sh.D.d != 3) return fail(ALG_ERR_ARG, std::string(who) + ": needs a model with three position dimensions (DoubleIntegrator d = 3)");
+    if (!(hd->sh.D.model == ALG_MODEL_QUADROTOR || (hd->sh.D.model == ALG_MODEL_DOUBLE_INTEGRATOR && hd->sh.D.d == 3))) return fail(ALG_ERR_ARG, std::string(who) + ": needs a model with three position dimensions (DoubleIntegrator d = 3, Quadrotor)");
     return ALG_OK;
 }
 int orc_add_spherical_collision_avoidance(alg_handle* h, const double* radius) {

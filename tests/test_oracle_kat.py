@@ -6,7 +6,7 @@ test/problem/solver_methods.jl are the pinning."""
 import numpy as np
 import pytest
 
-DI, UNI, BIC = 0, 1, 2
+DI, UNI, BIC, QUAD = 0, 1, 2, 3
 
 
 # ---------------------------------------------------------------- layout / indexing (host logic)
@@ -203,6 +203,85 @@ def test_bicycle_dynamics(orc):
         zp = np.concatenate([x, u]); zm = zp.copy(); zp[c] += eps; zm[c] -= eps
         Jfd[:, c] = (b.kat_dynamics(zp[:b.n], zp[b.n:])[1] - b.kat_dynamics(zm[:b.n], zm[b.n:])[1]) / (2 * eps)
     assert np.abs(J - Jfd).sum() < 1e-6
+
+
+def test_quadrotor_index_literals(alg):
+    # test/dynamics/quadrotor.jl:4-25
+    p = 3
+    model = alg.QuadrotorGame(p=p)
+    assert (model.n, model.m, model.p) == (12 * p, 4 * p, p)
+    assert model.ni == [12] * p and model.mi == [4] * p
+    assert model.pu == [[1, 4, 7, 10], [2, 5, 8, 11], [3, 6, 9, 12]]
+    assert model.px == [[1, 4], [2, 5], [3, 6]]
+    assert model.pz[0] == [1, 4, 7, 10, 13, 16, 19, 22, 25, 28, 31, 34]
+    assert model.pz[1] == [2, 5, 8, 11, 14, 17, 20, 23, 26, 29, 32, 35]
+    assert model.pz[2] == [3, 6, 9, 12, 15, 18, 21, 24, 27, 30, 33, 36]
+    assert alg.dim(model) == 3                                  # quadrotor.jl:208
+    with pytest.raises(AssertionError):
+        alg.QuadrotorGame(p=5)                                   # quadrotor.jl:22
+
+
+def _quad_f(x, u, P):
+    """src/dynamics/quadrotor.jl:49-121 restated independently: attitude through the unit quaternion of the MRP
+    (Rotations.jl 1.0: q = ((1 - |g|^2), 2 g) / (1 + |g|^2)) and the generic quaternion rotation matrix, MRP rate through
+    B(g) w / 4 with B = (1 - |g|^2) I + 2 [g x] + 2 g g'."""
+    mass, J, grav, L, kf, km = 0.5, np.array([0.0023, 0.0023, 0.004]), np.array([0, 0, -9.81]), 0.175, 1.245, 1.0
+    xd = np.zeros_like(x)
+    for i in range(P):
+        g = x[[3 * P + i, 4 * P + i, 5 * P + i]]; v = x[[6 * P + i, 7 * P + i, 8 * P + i]]; w = x[[9 * P + i, 10 * P + i, 11 * P + i]]
+        wm = u[[i, P + i, 2 * P + i, 3 * P + i]]
+        s = g @ g
+        qw, qv = (1 - s) / (1 + s), 2 * g / (1 + s)
+        K = np.array([[0, -qv[2], qv[1]], [qv[2], 0, -qv[0]], [-qv[1], qv[0], 0]])
+        Rm = np.eye(3) + 2 * qw * K + 2 * K @ K
+        F = np.maximum(0, kf * wm)
+        f = mass * grav + Rm @ np.array([0, 0, F.sum()])
+        tau = np.array([L * (F[1] - F[3]), L * (F[2] - F[0]), km * (wm[0] - wm[1] + wm[2] - wm[3])])
+        G = np.array([[0, -g[2], g[1]], [g[2], 0, -g[0]], [-g[1], g[0], 0]])
+        qd = 0.25 * ((1 - s) * np.eye(3) + 2 * G + 2 * np.outer(g, g)) @ w
+        wd = (tau - np.cross(w, J * w)) / J
+        for a in range(3):
+            xd[a * P + i] = v[a]; xd[(3 + a) * P + i] = qd[a]; xd[(6 + a) * P + i] = f[a] / mass; xd[(9 + a) * P + i] = wd[a]
+    return xd
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_quadrotor_dynamics(orc, p):
+    rng = np.random.default_rng(40 + p)
+    dt = 0.05
+    b = orc.OracleBatch(QUAD, p, 6, dt, 1)
+    assert (b.n, b.m) == (12 * p, 4 * p)
+    x, u = rng.random(b.n) - 0.3, rng.random(b.m) - 0.2       # some rotor commands negative: the max(0, .) branch
+    xd, x2, x3, J = b.kat_dynamics(x, u)
+    assert np.allclose(xd, _quad_f(x, u, p), rtol=1e-13, atol=1e-13)
+    f = lambda xx: _quad_f(xx, u, p)
+    assert np.allclose(x2, x + dt * f(x + dt / 2 * f(x)), rtol=1e-13, atol=1e-13)
+    k1 = dt * f(x); k2 = dt * f(x + k1 / 2); k3 = dt * f(x - k1 + 2 * k2)
+    assert np.allclose(x3, x + (k1 + 4 * k2 + k3) / 6, rtol=1e-13, atol=1e-13)
+    # discrete_jacobian!(RK2) == derivative of discrete_dynamics(RK2) (test/problem/local_quantities.jl:24-57 pattern)
+    Jfd = np.zeros_like(J); eps = 1e-6
+    for c in range(b.n + b.m):
+        zp = np.concatenate([x, u]); zm = zp.copy(); zp[c] += eps; zm[c] -= eps
+        Jfd[:, c] = (b.kat_dynamics(zp[:b.n], zp[b.n:])[1] - b.kat_dynamics(zm[:b.n], zm[b.n:])[1]) / (2 * eps)
+    assert np.abs(J - Jfd).max() < 1e-6
+    # hover: identity attitude, zero rates, each rotor carrying a quarter of the weight -> xdot = 0
+    x = np.zeros(b.n); u = np.full(b.m, 0.5 * 9.81 / 4 / 1.245)
+    assert np.abs(b.kat_dynamics(x, u)[0]).max() < 1e-14
+
+
+def test_quadrotor_rotation_is_orthogonal():
+    # the restated MRP rotation (oracle: I + (4 (1 - s) [g x] + 8 [g x]^2) / (1 + s)^2) is a proper rotation and matches
+    # Rodrigues for angle 4 atan(|g|) about g / |g|
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        g = rng.normal(size=3) * 0.6
+        s = g @ g
+        G = np.array([[0, -g[2], g[1]], [g[2], 0, -g[0]], [-g[1], g[0], 0]])
+        Rm = np.eye(3) + (4 * (1 - s) * G + 8 * G @ G) / (1 + s) ** 2
+        assert np.allclose(Rm @ Rm.T, np.eye(3), atol=1e-13) and abs(np.linalg.det(Rm) - 1) < 1e-13
+        th, ax = 4 * np.arctan(np.sqrt(s)), g / np.sqrt(s)
+        A = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        assert np.allclose(Rm, np.eye(3) + np.sin(th) * A + (1 - np.cos(th)) * A @ A, atol=1e-13)
 
 
 # ---------------------------------------------------------------- objective

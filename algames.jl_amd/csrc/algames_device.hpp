@@ -116,29 +116,31 @@ struct Cfg {
     static constexpr int NW = NW_, NT = NW_ * 64;          // wavefronts / threads per game
     static constexpr bool EXT = EXT_ != 0;
     static constexpr bool POS = (P_ > 1) || EXT;     // position blocks (pair / wall / circle terms) present in Q^_i
-    // QuadrotorGame (quadrotor.jl:20-46): dense 12 x 12 / 12 x 4 Jacobian blocks per player, n up to 48 -- its Newton direction is
-    // the LDS-resident dense variant (newton_direction_dense) instead of the single 16 x 16 tile path
-    static constexpr bool DENSE = MODEL_ == ALG_MODEL_QUADROTOR;
-    static constexpr int n = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 * D_ * P_ : DENSE ? 12 * P_ : 4 * P_;
-    static constexpr int m = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? D_ * P_ : DENSE ? 4 * P_ : 2 * P_;
+    // QuadrotorGame (quadrotor.jl:20-46): dense 12 x 12 / 12 x 4 Jacobian blocks per player, n up to 48
+    static constexpr bool QUAD = MODEL_ == ALG_MODEL_QUADROTOR;
+    static constexpr int n = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? 2 * D_ * P_ : QUAD ? 12 * P_ : 4 * P_;
+    static constexpr int m = (MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR) ? D_ * P_ : QUAD ? 4 * P_ : 2 * P_;
+    // Newton direction variant: the single 16 x 16 tile path needs n <= 16 and n % 4 == 0; everything else (the quadrotor, the
+    // double integrator in three dimensions with p = 1, 3, 4) takes the LDS-resident dense variant (newton_direction_dense)
+    static constexpr bool DENSE = QUAD || n > 16 || (n % 4) != 0;
     static constexpr int mi = m / P_;
     static constexpr int ni = n / P_;
     static constexpr int b = n + m + P_ * n;
     static constexpr int NPAIR = P_ * (P_ - 1);
     // position dimensions that carry pair / wall terms: px[i] = (x, y) everywhere (double_integrator.jl:19, unicycle.jl, bicycle.jl);
     // the 3-D ingredients (spherical collision avoidance, Wall3D, Cylinder) act on pz[i][1:3] = (x, y, z) of DoubleIntegrator d = 3
-    static constexpr int PD = (EXT_ != 0 && ((MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR && D_ == 3) || DENSE)) ? 3 : 2;
+    static constexpr int PD = (EXT_ != 0 && ((MODEL_ == ALG_MODEL_DOUBLE_INTEGRATOR && D_ == 3) || QUAD)) ? 3 : 2;
     static constexpr int NS = PD * (PD + 1) / 2;          // entries of a symmetric PD x PD block: (0,0) (0,1) (1,1) [(0,2) (1,2) (2,2)]
     __host__ __device__ static constexpr int sym(int a, int c) { return PD == 2 ? a + c : (a > c ? a * (a + 1) / 2 + c : c * (c + 1) / 2 + a); }
     // quadrotor: per player [A_i (12 x 12, row-major) | B_i (12 x 4) | RK2(x_k, u_k) entries of the player (12)]
     static constexpr int QA = 0, QB = 144, QX = 192, QS = 204;
-    static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : (MODEL_ == ALG_MODEL_BICYCLE) ? 10 * P_ : DENSE ? QS * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
+    static constexpr int NC = (MODEL_ == ALG_MODEL_UNICYCLE) ? 4 * P_ : (MODEL_ == ALG_MODEL_BICYCLE) ? 10 * P_ : QUAD ? QS * P_ : 0;   // state-dependent RK2 Jacobian coefficients per knot
     static constexpr int NPAT = (MODEL_ == ALG_MODEL_BICYCLE) ? 4 : (MODEL_ == ALG_MODEL_UNICYCLE) ? 3 : 2;   // max non-zeros of a column of [B_k | A_k]
     static constexpr int WC = m + n + 1;         // augmented width of the control system
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
     // (the 3-D EXT instantiation carries 3 x 3 position blocks and does not fit 128 VGPRs without scratch)
-    // (the 4-player quadrotor's LDS-resident direction leaves room for one workgroup per CU)
-    static constexpr int WPE = (DENSE && P_ >= 4) ? 1 : (n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3)) ? 2 : 4;
+    // (the LDS-resident dense direction of the larger configurations leaves room for less than one wavefront per SIMD)
+    static constexpr int WPE = (DENSE && n >= 24) ? 1 : (DENSE || n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3)) ? 2 : 4;
     // reuse the accepted line-search trial as the next record! (one assemble pass less per Newton iteration)
     static constexpr bool TRIAL_REUSE = true;
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
@@ -326,7 +328,7 @@ __device__ __forceinline__ void bike_coefs(CPR pr, double v, double psi, double 
 template <class C>
 __device__ __forceinline__ void model_player(CPR pr, int i, const double* x, const double* u, double dt,
                                              double* xn /*ni: entries pz(i,j)*/, double* coef /*4: entries j*P+i (unicycle only)*/) {
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         double xi[12], ui[4], xo[12];
 #pragma unroll
         for (int j = 0; j < 12; j++) xi[j] = x[i + j * C::P];
@@ -406,7 +408,7 @@ __device__ __forceinline__ void model_player_rk3(CPR pr, int i, const double* x,
 // masks the coefficients, so that divergent rows do not serialise their memory latencies.
 template <class C, class V>
 __device__ __forceinline__ double AT_vec(const double* coef, double dt, V v, int r) {
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         const int P = C::P, i = r % P, a = r / P; const double* Ai = coef + i * C::QS + C::QA;
         double acc = 0.0;
 #pragma unroll
@@ -430,7 +432,7 @@ __device__ __forceinline__ double AT_vec(const double* coef, double dt, V v, int
 // (A v)[r]
 template <class C, class V>
 __device__ __forceinline__ double A_vec(const double* coef, double dt, V v, int r) {
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         const int P = C::P, i = r % P, a = r / P; const double* Ai = coef + i * C::QS + C::QA;
         double acc = 0.0;
 #pragma unroll
@@ -458,7 +460,7 @@ __device__ __forceinline__ double XA_vec(const double* coef, double dt, V X, int
 template <class C>
 __device__ __forceinline__ double A_entry(const double* coef, double dt, int r, int c) {
     double e = (r == c) ? 1.0 : 0.0;
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         e = (r % C::P == c % C::P) ? coef[(r % C::P) * C::QS + C::QA + (r / C::P) * 12 + c / C::P] : 0.0;
     } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         if (r < C::m && c == r + C::m) e = dt;
@@ -477,7 +479,7 @@ __device__ __forceinline__ double A_entry(const double* coef, double dt, int r, 
 // B[r][c]  (c: joint control index)
 template <class C>
 __device__ __forceinline__ double B_entry(const double* coef, double dt, int r, int c) {
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         return (r % C::P == c % C::P) ? coef[(r % C::P) * C::QS + C::QB + (r / C::P) * 4 + c / C::P] : 0.0;
     } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
         if (r == c) return 0.5 * dt * dt;
@@ -513,7 +515,7 @@ __device__ __forceinline__ double B_entry(const double* coef, double dt, int r, 
 // (B^T v)[c] : column c of B has <= 4 non-zeros (branch-free, see AT_vec)
 template <class C, class V>
 __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int c) {
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         const int P = C::P, i = c % P, j = c / P; const double* Bi = coef + i * C::QS + C::QB;
         double acc = 0.0;
 #pragma unroll
@@ -533,7 +535,7 @@ __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int
 // (B w)[r] for a control-vector accessor w(c): row r of B has <= 2 non-zeros
 template <class C, class V>
 __device__ __forceinline__ double B_vec(const double* coef, double dt, V w, int r) {
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         const int P = C::P, i = r % P, a = r / P; const double* Bi = coef + i * C::QS + C::QB;
         double acc = 0.0;
 #pragma unroll
@@ -790,7 +792,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
     double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
     // ---------------- phase A ------------------------------------------------------------------------------
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         // quadrotor: work item = (knot k, player i, seed direction c of the player's 12 states + 4 rotor commands): column c of
         // [A_i | B_i] = d RK2 / d (x_i, u_i)[c] by forward-mode differentiation along e_c; the item with c = 0 also leaves the
         // RK2 value (the dyn rows of phase B read it)
@@ -1099,7 +1101,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             const uidx po = (k == 0) ? 0u : zo - (uidx)b;                   // x_k: x_1 sits in front of block 0
             const double* Ck = recg + ro + (uidx)R::COEF;
             double xn;
-            if constexpr (C::DENSE) {
+            if constexpr (C::QUAD) {
                 xn = Ck[(a % P) * C::QS + C::QX + a / P];                    // RK2 value left by phase A
             } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
                 // position rows: x + (v + dt/2 u) dt ; velocity rows: v + u dt
@@ -2415,7 +2417,7 @@ template <class C>
 __device__ __forceinline__ void rollout(CPR pr, double* z) {
     constexpr int n = C::n, m = C::m, P = C::P;
     const int lane = threadIdx.x;
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         if (lane < P) {
             double xi[12], ui[4], xo[12];
 #pragma unroll

@@ -10,7 +10,7 @@
 
 // the EXT instantiations are defined in algames_ext_*.hip, the team kernels in algames_mw.hip
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
-ALG_CFGS_QUAD(ALG_DECLARE_KERNELS)
+ALG_CFGS_DENSE(ALG_DECLARE_KERNELS)
 ALG_CFGS_MW(ALG_DECLARE_MW)
 
 __global__ void __launch_bounds__(WAVE) k_reset_con(Params pr_arg) {
@@ -80,7 +80,7 @@ bool cfg_supported(const Params& p, int ext) {
 #define X(M, P, D, E) if (p.model == (M) && p.p == (P) && p.d == (D) && ext == (E)) return true;
     ALG_CFGS_BASE(X)
     ALG_CFGS_EXT(X)
-    ALG_CFGS_QUAD(X)
+    ALG_CFGS_DENSE(X)
 #undef X
     return false;
 }
@@ -195,7 +195,17 @@ int launch_check(const char* what) {
     LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 1, 3, 0, kernel, __VA_ARGS__)                  \
     LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 2, 3, 0, kernel, __VA_ARGS__)                  \
     LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 3, 3, 0, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 4, 3, 0, kernel, __VA_ARGS__)
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 4, 3, 0, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 1, 3, 1, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 2, 3, 1, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 3, 3, 1, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 4, 3, 1, kernel, __VA_ARGS__)                  \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 1, kernel, __VA_ARGS__)
 
 void dfree(Handle* h, void* q) {
     for (size_t i = 0; i < h->allocs.size(); i++)
@@ -344,7 +354,7 @@ int alg_create(const alg_desc* d, alg_handle** out) {
     if (!d || !out) return fail(ALG_ERR_ARG, "alg_create: null argument");
     Handle* hd = new Handle();
     if (!fill_dims(*d, hd->pr) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "alg_create: unsupported descriptor"); }
-    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2 p<=4, d=3 p=2; Unicycle p<=4; Bicycle p<=4; Quadrotor p<=4)"); }
+    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2, 3 with p<=4; Unicycle p<=4; Bicycle p<=4; Quadrotor p<=4)"); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete hd; return fail(ALG_ERR_DEVICE, "alg_create: no HIP device available (this library has no CPU fallback)"); }
     if (d->device < 0 || d->device >= ndev) { delete hd; return fail(ALG_ERR_ARG, "alg_create: bad device ordinal"); }
@@ -467,7 +477,7 @@ static int ext_commit(Handle* hd) {
     int rc = use_device(hd); if (rc) return rc;
     if ((rc = sync(hd))) return rc;
     Params& p = hd->pr;
-    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 p<=4 / d=3 p=2, Unicycle, Bicycle p<=4; the Quadrotor kernels carry collision avoidance / collision cost / control bounds only)");
+    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2, 3, Unicycle, Bicycle, Quadrotor with p<=4)");
     p.ext = 1;
     recount_con(p);
     dfree(hd, p.con); p.con = nullptr;
@@ -565,8 +575,8 @@ int alg_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t nc, 
 }
 // ---- 3-D half (pz[i][1:3] = positions of DoubleIntegrator d = 3) -------------------------------------------------------
 static int need_3d(Handle* hd, const char* who) {
-    if (hd->pr.model != ALG_MODEL_DOUBLE_INTEGRATOR || hd->pr.d != 3) {
-        return fail(ALG_ERR_ARG, std::string(who) + ": needs a model with three position dimensions (DoubleIntegrator d = 3)");
+    if (!(hd->pr.model == ALG_MODEL_QUADROTOR || (hd->pr.model == ALG_MODEL_DOUBLE_INTEGRATOR && hd->pr.d == 3))) {
+        return fail(ALG_ERR_ARG, std::string(who) + ": needs a model with three position dimensions (DoubleIntegrator d = 3, Quadrotor)");
     }
     return ALG_OK;
 }

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(WAVE, (C::WPE < 2 ? C::WPE : 2)) k_ibr(Params 
 template <class C>
 __device__ __forceinline__ void mpc_advance(CPR pr, const Game& G) {
     const int lane = threadIdx.x;
-    if constexpr (C::DENSE) {
+    if constexpr (C::QUAD) {
         if (lane < C::P) {
             double xi[12], ui[4], xo[12];
 #pragma unroll
@@ -225,6 +225,20 @@ __global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(P
     X(ALG_MODEL_QUADROTOR, 2, 3, 0)                          \
     X(ALG_MODEL_QUADROTOR, 3, 3, 0)                          \
     X(ALG_MODEL_QUADROTOR, 4, 3, 0)
+#define ALG_CFGS_QUAD_EXT(X)                                \
+    X(ALG_MODEL_QUADROTOR, 1, 3, 1)                          \
+    X(ALG_MODEL_QUADROTOR, 2, 3, 1)                          \
+    X(ALG_MODEL_QUADROTOR, 3, 3, 1)                          \
+    X(ALG_MODEL_QUADROTOR, 4, 3, 1)
+// DoubleIntegrator in three dimensions with p = 1, 3, 4 (n = 6, 18, 24: dense Newton direction; algames_di3.hip)
+#define ALG_CFGS_DI3D(X)                                    \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 1)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 1)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 1)
+#define ALG_CFGS_DENSE(X) ALG_CFGS_QUAD(X) ALG_CFGS_QUAD_EXT(X) ALG_CFGS_DI3D(X)
 #define ALG_CFGS_EXT(X) ALG_CFGS_EXT_DI(X) ALG_CFGS_EXT_UNI(X) ALG_CFGS_EXT_BIC(X) ALG_CFGS_EXT_DI3(X)
 
 // every kernel of one instantiation; PREFIX is `template` (definition) or `extern template` (declaration)

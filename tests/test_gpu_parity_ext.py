@@ -222,7 +222,7 @@ def test_reference_constrained_unicycle_with_circles_on_gpu(alg):
 
 def test_extended_constraints_unsupported_configuration_fails_loudly(alg):
     with pytest.raises(alg.AlgamesError):
-        alg.Batch(alg.hip_lib(), DI, 1, 6, 0.1, 1, d=3)         # n = 6: no kernel instantiation at all
+        alg.Batch(alg.hip_lib(), DI, 5, 6, 0.1, 1, d=2)         # five players: no kernel instantiation at all
 
 
 def _guards_ok(batch):

@@ -192,9 +192,6 @@ def test_ibr_and_mpc_parity_quadrotor(alg, orc):
 
 
 def test_quadrotor_rejections(alg):
-    """What the Quadrotor kernels do not carry is refused with a message, never computed on another path."""
-    g = alg.Batch(alg.hip_lib(), QUAD, 2, 6, 0.1, 2, d=3)
-    with pytest.raises(alg.AlgamesError, match="EXT"):
-        g.add_state_bound(0, np.full(g.n, 1.0), np.full(g.n, -1.0))
+    """quadrotor.jl:22: at most four players; anything else is refused with a message."""
     with pytest.raises(alg.AlgamesError):
         alg.Batch(alg.hip_lib(), QUAD, 5, 6, 0.1, 2, d=3)

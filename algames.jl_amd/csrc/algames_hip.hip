@@ -12,6 +12,7 @@
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
 ALG_CFGS_DENSE(ALG_DECLARE_KERNELS)
 ALG_CFGS_MW(ALG_DECLARE_MW)
+ALG_CFGS_MW_DENSE(ALG_DECLARE_MW)
 
 __global__ void __launch_bounds__(WAVE) k_reset_con(Params pr_arg) {
     CPR pr = kernel_params();
@@ -278,6 +279,15 @@ int team_width(const Handle* hd) {
         if (hd->waves_per_game == 0 && (long long)p.B * (W) <= 2048 && (W) > best) best = (W); }
     ALG_CFGS_MW(X)
 #undef X
+#define X(M, P, D, E, W) if (p.model == (M) && p.p == (P) && p.d == (D) && p.ext == (E)) {                         \
+        if (hd->waves_per_game == (W)) return (W);                                                                    \
+        if (hd->waves_per_game == 0 && (lds_bound || (long long)p.B * (W) <= 2048) && (W) > best) best = (W); }
+    // dense direction: once the value matrices alone take more than 16 KB of LDS per game, fewer than one wavefront per SIMD is
+    // resident at any batch size and the team of four wins everywhere (measured: quadrotor p = 3 1.7x, p = 4 2.1x at 1024-2048
+    // games; p = 2 -- 9.6 KB -- loses 27 % at 4096 games and gains 56 % at 256)
+    const bool lds_bound = (long long)p.p * p.n * (p.n + 1) * 8 > 16384;
+    ALG_CFGS_MW_DENSE(X)
+#undef X
     return hd->waves_per_game > 1 ? -1 : best;
 }
 int launch_newton_solve(Handle* h, int init, uint64_t game_id0) {
@@ -288,6 +298,7 @@ int launch_newton_solve(Handle* h, int init, uint64_t game_id0) {
 #define X(M, P, D, E, W) if (!done && nw == (W) && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                   \
         hipLaunchKernelGGL((k_newton_solve<Cfg<M, P, D, E, W>>), dim3(pr.B), dim3(WAVE * (W)), 0, h->stream, h->pr, init, game_id0); done = true; }
     ALG_CFGS_MW(X)
+    ALG_CFGS_MW_DENSE(X)
 #undef X
     return launch_check("k_newton_solve (team)");
 }
@@ -299,6 +310,7 @@ int launch_mpc_loop(Handle* h, int steps, uint64_t game_id0, double* d_states) {
 #define X(M, P, D, E, W) if (!done && nw == (W) && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                   \
         hipLaunchKernelGGL((k_mpc_loop<Cfg<M, P, D, E, W>>), dim3(pr.B), dim3(WAVE * (W)), 0, h->stream, h->pr, steps, game_id0, d_states); done = true; }
     ALG_CFGS_MW(X)
+    ALG_CFGS_MW_DENSE(X)
 #undef X
     return launch_check("k_mpc_loop (team)");
 }

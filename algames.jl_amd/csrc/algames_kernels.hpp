@@ -263,6 +263,19 @@ __global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(P
     X(ALG_MODEL_UNICYCLE, 3, 2, 0, 4)                        \
     X(ALG_MODEL_UNICYCLE, 4, 2, 0, 2)                        \
     X(ALG_MODEL_UNICYCLE, 4, 2, 0, 4)
+// Team kernels of the dense-direction configurations (algames_mw_dense.hip): where the LDS footprint leaves room for few
+// workgroups per CU at any batch size the automatic choice is the team of four regardless of the batch (team_width, algames_hip.hip)
+#define ALG_CFGS_MW_DENSE(X)                                \
+    X(ALG_MODEL_QUADROTOR, 2, 3, 0, 4)                       \
+    X(ALG_MODEL_QUADROTOR, 3, 3, 0, 4)                       \
+    X(ALG_MODEL_QUADROTOR, 4, 3, 0, 4)                       \
+    X(ALG_MODEL_QUADROTOR, 2, 3, 1, 4)                       \
+    X(ALG_MODEL_QUADROTOR, 3, 3, 1, 4)                       \
+    X(ALG_MODEL_QUADROTOR, 4, 3, 1, 4)                       \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 0, 4)               \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 0, 4)               \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 1, 4)               \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 1, 4)
 #define ALG_INSTANTIATE_MW(PREFIX, M, P, D, E, W)                                                                         \
     PREFIX __global__ void k_newton_solve<Cfg<M, P, D, E, W>>(Params, int, uint64_t);                                     \
     PREFIX __global__ void k_mpc_loop<Cfg<M, P, D, E, W>>(Params, int, uint64_t, double*);

@@ -55,6 +55,7 @@ check(rc) = rc == 0 || error(unsafe_string(ccall((:alg_last_error, LIB), Cstring
 model_id(::DoubleIntegratorGame) = Int32(0)
 model_id(::UnicycleGame) = Int32(1)
 model_id(::BicycleGame) = Int32(2)
+model_id(::QuadrotorGame) = Int32(3)      # src/dynamics/quadrotor.jl (the constructor's constants; mass = 0.5 only)
 
 function abi_options(o::Options)
     ax = ntuple(i -> i <= length(o.αx_dual) ? Float64(o.αx_dual[i]) : 1.0, 10)
@@ -96,7 +97,7 @@ function setup!(bp::BatchedGameProblem, device)
     probs = bp.probs; prob = probs[1]; ps = prob.probsize; B = length(probs)
     N, n, m, p = ps.N, ps.n, ps.m, ps.p
     ni, mi = ps.ni[1], ps.mi[1]
-    d = prob.model isa DoubleIntegratorGame ? mi : 2
+    d = prob.model isa DoubleIntegratorGame ? mi : (prob.model isa QuadrotorGame ? 3 : 2)
     dt = prob.pdtraj.pr[1].dt
     desc = Ref(AlgDesc(model_id(prob.model), p, d, N, dt, B, device))
     h = Ref{Ptr{Cvoid}}(C_NULL)

@@ -10,10 +10,14 @@ pytestmark = pytest.mark.gpu
 DI, UNI, BIC = 0, 1, 2
 
 
-def _random_pair(alg, orc, rng, ext, d3=False):
+def _random_pair(alg, orc, rng, ext, d3=False, force=None):
     model = DI if d3 else int(rng.choice([DI, UNI, BIC] if ext else [DI, UNI]))
     p = 2 if d3 else int(rng.integers(1, 5))
     N = int(rng.integers(2, 16))
+    if force is not None:                                      # (model, p) of a dense-direction family: three position dimensions
+        model, p = force
+        d3 = True
+        N = min(N, 9)
     B = 3
     dt = float(rng.choice([0.05, 0.1, 0.2]))
     d = 3 if d3 else 2
@@ -95,6 +99,21 @@ def test_fuzz_base_instantiations(alg, orc, seed):
 def test_fuzz_extended_instantiations(alg, orc, seed):
     rng = np.random.default_rng(5000 + seed)
     g, o, tag = _random_pair(alg, orc, rng, ext=True)
+    _compare_solve(g, o, tag)
+
+
+DENSE_FAMILIES = [(DI, 1), (DI, 3), (DI, 4), (3, 1), (3, 2), (3, 3), (3, 4)]      # DoubleIntegrator d = 3 / QuadrotorGame (model id 3)
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_fuzz_dense_direction_instantiations(alg, orc, seed):
+    """The configurations outside the 16 x 16 tile (dense Newton direction): DoubleIntegrator d = 3 with p = 1, 3, 4 and the
+    QuadrotorGame with p = 1..4, base or extended set, random subsets of every ingredient, both kernel shapes."""
+    rng = np.random.default_rng(13000 + seed)
+    fam = DENSE_FAMILIES[seed % len(DENSE_FAMILIES)]
+    g, o, tag = _random_pair(alg, orc, rng, ext=bool(seed % 2), force=fam)
+    if seed % 3 == 0:
+        g.set_waves_per_game(1)
     _compare_solve(g, o, tag)
 
 

@@ -112,6 +112,9 @@ def test_inner_iteration_dual_update_and_solve_parity(alg, orc, case):
     # a short fused solve from the current iterate (two outer iterations): identical control flow, same iterate
     for b in (g, o):
         b.set_options(outer_iter=2, inner_iter=3, dual_reset=0, rho_increase=10.0, rho_max=1e7, lambda_max=1e7, alpha_dual=1.0, alphax_dual=[1.0] * 10)
+    if p == 3:
+        g.set_waves_per_game(1)            # p = 3: one wavefront per game; p = 2, 4: the automatic team of four (p = 1 has no team kernel)
+    assert g.get_waves_per_game() == (4 if p in (2, 4) else 1)
     sg, so = g.newton_solve(init=False), o.newton_solve(init=False)
     for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
         assert np.array_equal(sg[f], so[f]), (f, sg[f], so[f])

@@ -145,13 +145,17 @@ def _assert_solve_parity(pg, po):
         assert np.allclose(hg["res"], ho["res"], rtol=1e-7, atol=1e-12)
 
 
+@pytest.mark.parametrize("nw", [0, 1])
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
-def test_newton_solve_parity_quadrotor_crossing(alg, orc, p):
+def test_newton_solve_parity_quadrotor_crossing(alg, orc, p, nw):
     """scenarios.quadrotor_crossing: p quadrotors fly across a circle holding height, planar collision avoidance on px[i],
     rotor commands in [0, 3]: the fused solver against the oracle, converged to the reference's exit test."""
     ids = np.arange(16, 16 + (12 if p < 4 else 6))
     pg = alg.scenarios.make_problem("Q", ids, p=p)
     po = alg.scenarios.make_problem("Q", ids, p=p, backend=orc.lib())
+    # kernel shape: automatic (a team of four wavefronts per game for p >= 2 at this batch size) or one wavefront per game
+    pg.batch.set_waves_per_game(nw)
+    assert pg.batch.get_waves_per_game() == (1 if nw == 1 or p == 1 else 4)
     alg.newton_solve(pg); alg.newton_solve(po)
     _assert_solve_parity(pg, po)
     s = pg.stats.summary

@@ -688,6 +688,7 @@ template <class C>
 struct DirLds<C, true> {
     static constexpr int LDP = C::n + 1;                 // row stride of [P_i | s_i] and of [F | f] (odd: conflict-free column reads)
     static constexpr int WC = C::m + C::n + 1;           // [W | V A_k | g]
+    static constexpr int CFL = C::NC > 0 ? C::NC : 1;
     struct Bwd {
         double Pm[C::P * C::n * LDP];                    // [P_i | s_i], row-major
         double Tm[C::n * LDP];                           // [P_i F | P_i f + s_i] of the player being advanced
@@ -695,8 +696,11 @@ struct DirLds<C, true> {
         double V[C::m * C::n];                           // V[c][:] = B[:,c]' P_i(c)
         double y[C::P * C::n];                           // y_i = P_i rd + s_i
         double Wm[C::m * WC];                            // augmented control system, row-major
+        double cf[2][CFL];                               // Jacobian coefficient blocks of steps k and k + 1 (slot = step & 1)
+        double pcol[2][C::m];                            // pivot column of the Gauss-Jordan (double-buffered)
+        double rs[Rec<C>::LEN_SWEEP - C::NC];            // the step record behind the coefficient block ([Hh | Hd | RQ | rx | R^ | ru | rd])
     };
-    struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n]; };
+    struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n], cf[2][CFL], rs[Rec<C>::LEN_SWEEP - C::NC]; };
     union { Bwd bw; Fwd fw; };
     double red[8];
 };
@@ -1558,6 +1562,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     const Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, WC = DirLds<C>::WC, NK = m * (n + 1);
     constexpr int BT = C::NT, NWV = BT / WAVE;
+    constexpr int RSL = Rec<C>::LEN_SWEEP - C::NC;            // record fields behind the coefficient block
     constexpr int TR = (n + 15) / 16, TC = (n + 1 + 15) / 16, KBN = (n + 1 + 3) / 4;
     static_assert(NWV <= 4, "cross-wavefront reduction slots");
     using R = Rec<C>;
@@ -1571,52 +1576,93 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     for (int e = tid; e < P * n * LDP; e += BT) B.Pm[e] = 0.0;
     int sing = 0;
     __syncthreads();
+    ALG_PROF_DECL
     // ------------------------------------------------------------------ backward sweep
     for (int k = N - 2; k >= 0; k--) {
         const double* Rc = recs + (size_t)k * R::LEN;
-        const double* coefk = Rc + R::COEF;
-        const double* coefn = Rc + R::LEN + R::COEF;                        // A_{k+1} (only read while k < N - 2)
+        // the step's Jacobian coefficient block -> LDS (slot k & 1; slot (k + 1) & 1 still holds step k + 1's, which the value
+        // recursion applies); first read after the barriers below
+        for (int e = tid; e < C::NC; e += BT) B.cf[k & 1][e] = Rc[R::COEF + e];
+        for (int e = tid; e < RSL; e += BT) B.rs[e] = Rc[C::NC + e];         // the rest of the record's sweep slice
+        const double* Rl = B.rs - C::NC;                                     // record offsets >= NC address the staged copy
+        const double* coefk = B.cf[k & 1];
+        const double* coefn = B.cf[(k + 1) & 1];                           // A_{k+1} (only read while k < N - 2)
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         // ---- value recursion: [P_i | s_i] <- A_{k+1}' ([P_i | s_i] [[F f],[0 1]])
         if (k < N - 2) {
             for (int i = 0; i < P; i++) {
                 if (IBR && i != ip) continue;
                 double* Pi = &B.Pm[i * n * LDP];
-                for (int t = wv; t < TR * TC; t += NWV) {
-                    const int tr = t / TC, tc = t % TC, arow = 16 * tr + lrow, bcol = 16 * tc + lrow;
-                    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                // work item = column tile; its TR row tiles advance together (independent accumulator chains, one B operand load
+                // per k-block for all of them)
+                for (int tc = wv; tc < TC; tc += NWV) {
+                    const int bcol = 16 * tc + lrow;
+                    double4_t acc[TR];
+#pragma unroll
+                    for (int tr = 0; tr < TR; tr++) acc[tr] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int kb = 0; kb < KBN; kb++) {
                         const int kk = 4 * kb + lq;
-                        const bool aok = arow < n && kk <= n, bok = kk <= n && bcol <= n;
-                        const double av = Pi[aok ? arow * LDP + kk : 0], bv = B.Fx[bok ? kk * LDP + bcol : 0];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? av : 0.0, bok ? bv : 0.0, acc, 0, 0, 0);
+                        const bool kok = kk <= n, bok = kok && bcol <= n;
+                        const double bv = B.Fx[bok ? kk * LDP + bcol : 0];
+#pragma unroll
+                        for (int tr = 0; tr < TR; tr++) {
+                            const int arow = 16 * tr + lrow;
+                            const bool aok = kok && arow < n;
+                            const double av = Pi[aok ? arow * LDP + kk : 0];
+                            acc[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? av : 0.0, bok ? bv : 0.0, acc[tr], 0, 0, 0);
+                        }
                     }
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) { const int row = 16 * tr + lq + 4 * r4; if (row < n && bcol <= n) B.Tm[row * LDP + bcol] = acc[r4]; }
+                    for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) { const int row = 16 * tr + lq + 4 * r4; if (row < n && bcol <= n) B.Tm[row * LDP + bcol] = acc[tr][r4]; }
                 }
                 __syncthreads();
-                for (int e = tid; e < n * LDP; e += BT) {
-                    const int r = e / LDP, c = e % LDP;
-                    Pi[e] = AT_vec<C>(coefn, dt, [&](int rr) { return B.Tm[rr * LDP + c]; }, r);
+                ALG_PROF(0)
+                if constexpr (C::QUAD) {
+                    // block-diagonal A' (dense 12 x 12 block per player j) as MFMA products too: rows (., j) of the result =
+                    // A_j' x rows (., j) of the product; work item = (block j, column tile)
+                    for (int t = wv; t < P * TC; t += NWV) {
+                        const int j = t / TC, tc = t % TC, bcol = 16 * tc + lrow;
+                        const bool aok = lrow < 12, bok = bcol <= n;
+                        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kb = 0; kb < 3; kb++) {
+                            const int a2 = 4 * kb + lq;                    // A'[a][a2] = A_j[a2][a]
+                            const double av = coefn[j * C::QS + C::QA + a2 * 12 + (aok ? lrow : 0)];
+                            const double bv = B.Tm[(a2 * P + j) * LDP + (bok ? bcol : 0)];
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? av : 0.0, bok ? bv : 0.0, acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r4 = 0; r4 < 3; r4++) { const int a = lq + 4 * r4; if (bok) Pi[(a * P + j) * LDP + bcol] = acc[r4]; }
+                    }
+                } else {
+                    for (int e = tid; e < n * LDP; e += BT) {
+                        const int r = e / LDP, c = e % LDP;
+                        Pi[e] = AT_vec<C>(coefn, dt, [&](int rr) { return B.Tm[rr * LDP + c]; }, r);
+                    }
                 }
                 __syncthreads();
+                ALG_PROF(1)
             }
         }
+        if (k == N - 2) __syncthreads();                                    // (the recursion's barriers cover the staged record otherwise)
         // ---- + [Q^_i | rx_i]: diagonal, position block, column n
         for (int e = tid; e < P * n; e += BT) {
             const int i = e / n, r = e % n;
             if (IBR && i != ip) continue;
             double* row = &B.Pm[i * n * LDP + r * LDP];
             double qd = reg + ((r % P == i) ? w * Qd[i * C::ni + r / P] : 0.0);
-            if constexpr (C::EXT) qd += Rc[R::RQ + e];
+            if constexpr (C::EXT) qd += Rl[R::RQ + e];
             row[r] += qd;
-            row[n] += Rc[R::RX + e];
+            row[n] += Rl[R::RX + e];
             if (C::POS && r < C::PD * P) {
-                for (int c = 0; c < C::PD * P; c++) row[c] += pairblock<C>(Rc + R::HH, i, r, c);
+                for (int c = 0; c < C::PD * P; c++) row[c] += pairblock<C>(Rl + R::HH, i, r, c);
             }
         }
         __syncthreads();
+        ALG_PROF(2)
         // ---- V[c][:] = B[:,c]' P_i(c),  y_i = P_i rd + s_i
         for (int e = tid; e < m * n; e += BT) {
             const int c = e / n, col = e % n; const double* Pi = &B.Pm[(c % P) * n * LDP];
@@ -1625,18 +1671,19 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         for (int e = tid; e < P * n; e += BT) {
             const double* Pr = &B.Pm[e * LDP];
             double a = Pr[n];
-            for (int c = 0; c < n; c++) a += Pr[c] * Rc[R::RD + c];
+            for (int c = 0; c < n; c++) a += Pr[c] * Rl[R::RD + c];
             B.y[e] = a;
         }
         __syncthreads();
+        ALG_PROF(3)
         // ---- [ W | V A_k | g ],  W = diag(R^) + V B,  g_c = ru_c + B[:,c]' y_i(c)
         for (int e = tid; e < m * WC; e += BT) {
             const int c = e / WC, t = e % WC;
             const double* Vc = &B.V[c * n];
             double v;
-            if (t < m) v = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rc[R::RHAT + c] : 0.0);
+            if (t < m) v = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rl[R::RHAT + c] : 0.0);
             else if (t < m + n) v = (k >= 1) ? AT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t - m) : 0.0;     // dx_1 = 0: A_0 never acts
-            else { const double* yi = &B.y[(c % P) * n]; v = Rc[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
+            else { const double* yi = &B.y[(c % P) * n]; v = Rl[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
             if (IBR) {
                 if (c % P != ip) v = (t == c) ? 1.0 : 0.0;                   // unit row: du_c = 0
                 else if (t < m && t % P != ip) v = 0.0;                      // fixed controls of the other players
@@ -1644,39 +1691,75 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             B.Wm[e] = v;
         }
         __syncthreads();
-        // ---- partially pivoted Gauss-Jordan (pivot rule and row operations of gj_solve_cols); thread t owns column t
-        for (int c = 0; c < m; c++) {
-            double pc[m];
-            double best = fabs(B.Wm[c * WC + c]); int piv = c;
-            for (int r = c + 1; r < m; r++) { const double v = fabs(B.Wm[r * WC + c]); if (v > best) { best = v; piv = r; } }
-            if (!(best > 0.0) || !isfinite(best)) sing = 1;
-            __syncthreads();
-            if (piv != c) {
-                for (int t = tid; t < WC; t += BT) { const double a = B.Wm[c * WC + t]; B.Wm[c * WC + t] = B.Wm[piv * WC + t]; B.Wm[piv * WC + t] = a; }
-                __syncthreads();
+        ALG_PROF(4)
+        // ---- partially pivoted Gauss-Jordan (pivot rule and row operations of gj_solve_cols): thread t holds columns t, t + BT, ...
+        // in registers; per pivot only the pivot column travels through LDS (double-buffered: one barrier per pivot)
+        {
+            constexpr int XC = (WC + BT - 1) / BT;
+            double col[XC][m];
+#pragma unroll
+            for (int x = 0; x < XC; x++) {
+                const int t = tid + x * BT;
+#pragma unroll
+                for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
             }
 #pragma unroll
-            for (int r = 0; r < m; r++) pc[r] = B.Wm[r * WC + c];
-            const double rpiv = fast_rcp(pc[c]);
-            __syncthreads();
-            for (int t = tid; t < WC; t += BT) {
-                const double prow = B.Wm[c * WC + t] * rpiv;
+            for (int c = 0; c < m; c++) {
+                if (tid == c) {
 #pragma unroll
-                for (int r = 0; r < m; r++) if (r != c) B.Wm[r * WC + t] -= pc[r] * prow;
-                B.Wm[c * WC + t] = prow;
+                    for (int r = 0; r < m; r++) B.pcol[c & 1][r] = col[0][r];
+                }
+                __syncthreads();
+                double pc[m];
+#pragma unroll
+                for (int r = 0; r < m; r++) pc[r] = B.pcol[c & 1][r];
+                double best = fabs(pc[c]); int piv = c;
+#pragma unroll
+                for (int r = c + 1; r < m; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
+                if (!(best > 0.0) || !isfinite(best)) sing = 1;
+                piv = __builtin_amdgcn_readfirstlane(piv);
+                if (piv != c) {
+#pragma unroll
+                    for (int r = c + 1; r < m; r++) {
+                        if (piv == r) {
+                            double t2 = pc[c]; pc[c] = pc[r]; pc[r] = t2;
+#pragma unroll
+                            for (int x = 0; x < XC; x++) { t2 = col[x][c]; col[x][c] = col[x][r]; col[x][r] = t2; }
+                        }
+                    }
+                }
+                const double rpiv = fast_rcp(pc[c]);
+#pragma unroll
+                for (int x = 0; x < XC; x++) {
+                    const double prow = col[x][c] * rpiv;
+#pragma unroll
+                    for (int r = 0; r < m; r++) if (r != c) col[x][r] -= pc[r] * prow;
+                    col[x][c] = prow;
+                }
+            }
+            // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
+#pragma unroll
+            for (int x = 0; x < XC; x++) {
+                const int t = tid + x * BT;
+                if (t >= m && t < WC) {
+#pragma unroll
+                    for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                }
             }
             __syncthreads();
         }
+        ALG_PROF(5)
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
         for (int e = tid; e < NK; e += BT) { const int col = e / m, c = e % m; kg[(size_t)k * NK + e] = -B.Wm[c * WC + m + col]; }
         if (k > 0) {
             for (int e = tid; e < n * LDP; e += BT) {
                 const int r = e / LDP, col = e % LDP;
-                const double base = col < n ? A_entry<C>(coefk, dt, r, col) : Rc[R::RD + r];
+                const double base = col < n ? A_entry<C>(coefk, dt, r, col) : Rl[R::RD + r];
                 B.Fx[e] = base + B_vec<C>(coefk, dt, [&](int c2) { return -B.Wm[c2 * WC + m + col]; }, r);
             }
         }
         __syncthreads();
+        ALG_PROF(6)
     }
     if (sing) return ALG_STATUS_SINGULAR;                  // uniform: every thread saw the same pivots
     // ------------------------------------------------------------------ forward sweep: dx, du
@@ -1688,7 +1771,9 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     constexpr int XPT = (n + BT - 1) / BT;
     for (int k = 0; k < N - 1; k++) {
         const double* Rc = recs + (size_t)k * R::LEN;
-        const double* coefk = Rc + R::COEF;
+        for (int e = tid; e < C::NC; e += BT) F.cf[0][e] = Rc[R::COEF + e];      // read after the barrier below
+        if (tid < n) F.rs[R::RD - C::NC + tid] = Rc[R::RD + tid];
+        const double* coefk = F.cf[0];
         const double* Kg = kg + (size_t)k * NK;
         for (int c = tid; c < m; c += BT) {
             double a = Kg[n * m + c];
@@ -1701,7 +1786,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
 #pragma unroll
         for (int q = 0; q < XPT; q++) {
             const int r = tid + q * BT; nx[q] = 0.0;
-            if (r < n) nx[q] = (A_vec<C>(coefk, dt, [&](int rr) { return F.dx[rr]; }, r) + B_vec<C>(coefk, dt, [&](int cc) { return F.du[cc]; }, r)) + Rc[R::RD + r];
+            if (r < n) nx[q] = (A_vec<C>(coefk, dt, [&](int rr) { return F.dx[rr]; }, r) + B_vec<C>(coefk, dt, [&](int cc) { return F.du[cc]; }, r)) + F.rs[R::RD - C::NC + r];
         }
         __syncthreads();
 #pragma unroll
@@ -1711,13 +1796,18 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         }
         __syncthreads();
     }
+    ALG_PROF(7)
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     for (int k = N - 2; k >= 0; k--) {
         const double* Rc = recs + (size_t)k * R::LEN;
-        const double* coefn = Rc + R::LEN + R::COEF;
-        const double w = (k + 1 < N - 1) ? dt : 1.0;
         const int cur = k & 1;
+        // this step's coefficients go to slot cur for the next (earlier) step; slot cur ^ 1 holds step k + 1's
+        for (int e = tid; e < C::NC; e += BT) F.cf[cur][e] = Rc[R::COEF + e];
+        for (int e = tid; e < R::LEN_COSTATE - C::NC; e += BT) F.rs[e] = Rc[C::NC + e];
+        const double* Rl = F.rs - C::NC;
+        const double* coefn = F.cf[cur ^ 1];
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
         for (int e = tid; e < n; e += BT) F.dx[e] = dz[n + hx<C>(k) + e];
         __syncthreads();
         for (int e = tid; e < P * n; e += BT) {
@@ -1725,10 +1815,10 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             double acc = 0.0;
             if (!IBR || i == ip) {
                 double qd = reg + ((r % P == i) ? w * Qd[i * C::ni + r / P] : 0.0);
-                if constexpr (C::EXT) qd += Rc[R::RQ + e];
-                acc = Rc[R::RX + e] + qd * F.dx[r];
+                if constexpr (C::EXT) qd += Rl[R::RQ + e];
+                acc = Rl[R::RX + e] + qd * F.dx[r];
                 if (C::POS && r < C::PD * P) {
-                    for (int c = 0; c < C::PD * P; c++) acc += pairblock<C>(Rc + R::HH, i, r, c) * F.dx[c];
+                    for (int c = 0; c < C::PD * P; c++) acc += pairblock<C>(Rl + R::HH, i, r, c) * F.dx[c];
                 }
                 if (k < N - 2) { const double* dli = &F.dl[cur ^ 1][i * n]; acc += AT_vec<C>(coefn, dt, [&](int rr) { return dli[rr]; }, r); }
             }
@@ -1736,6 +1826,8 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         }
         __syncthreads();
     }
+    ALG_PROF(8)
+    ALG_PROF_FLUSH
     pl1 = wave_sum(pl1); bad = wave_or(bad);
     if constexpr (NWV > 1) {
         if (lane == 0) { L.red[wv] = pl1; L.red[4 + wv] = (double)bad; }
@@ -2506,6 +2598,9 @@ template <class C>
 __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
     const auto& o = pr.opt; const int lane = phase_lane();
     if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; } // reset!(prob.stats)
+#ifdef ALG_PHASE_PROF
+    if (lane < 12) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums
+#endif
 #ifndef ALG_TEST_NOINIT
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
     else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }

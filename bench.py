@@ -39,11 +39,16 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROAR
 F64_PEAK = 78.6e12         # FLOP/s, dense f64 vector = f64 MFMA peak (same guide)
 
 # configuration -> (scenario family of algames.jl_amd/scenarios.py, default scenarios per GPU)
-CONFIGS = {"C2": ("C2", 4096), "C3": ("C3", 1024), "C4": ("C2", 8192), "C5": ("C5", 64)}
+CONFIGS = {"C2": ("C2", 4096), "C3": ("C3", 1024), "C4": ("C2", 8192), "C5": ("C5", 64),
+           # not BASELINE configurations: the QuadrotorGame scenario of scenarios.quadrotor_crossing (dense Newton direction)
+           "Q2": ("Q", 4096), "Q4": ("Q", 1024)}
+CONFIG_KW = {"Q2": {"p": 2}, "Q4": {"p": 4}}
 WORKLOADS = {"C2": "C2: 3-player DoubleIntegrator (d=2), N=40, collision cost + collision avoidance, 4096 scenarios/GPU",
              "C3": "C3: 4-player Unicycle, N=50, collision avoidance + control bounds, 1024 scenarios/GPU",
              "C4": "C4: 3-player DoubleIntegrator (d=2), N=40, 65536 scenarios sharded over 8 GPUs (8192/GPU)",
-             "C5": "C5: 3-player Unicycle, N=30, collision avoidance + control bounds, receding-horizon seeds"}
+             "C5": "C5: 3-player Unicycle, N=30, collision avoidance + control bounds, receding-horizon seeds",
+             "Q2": "Q2 (not a BASELINE configuration): 2-player Quadrotor, N=20, planar collision avoidance + rotor bounds",
+             "Q4": "Q4 (not a BASELINE configuration): 4-player Quadrotor, N=20, planar collision avoidance + rotor bounds"}
 
 
 def survey_balg(N, n, m, p):
@@ -62,12 +67,12 @@ def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0):
     touch it: this is the floor for this algorithm, re-reads are not included."""
     S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
     it, K = S + n, N - 1
-    nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p}[family]                    # RK2 Jacobian coefficients per step
+    nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p, "Q": 204 * p}[family]      # RK2 Jacobian coefficients per step (quadrotor: dense blocks)
     npair = p * (p - 1)
     len_costate = nc + 3 * npair + 3 * p + p * n                         # [coef | Hh | Hd | rx]
     len_sweep = len_costate + 2 * m + n                                  # + [R^ | ru | rd]
     len_rec = len_sweep + 2 * p * p                                      # + pair-gradient table
-    con = K * npair + (2 * m * K if family in ("C3", "C5") else 0)       # constraint rows touched (lam, mu read)
+    con = K * npair + (2 * m * K if family in ("C3", "C5", "Q") else 0)  # constraint rows touched (lam, mu read)
     gains = K * m * (n + 1)
     trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec))   # axpy + assemble pass
     backward = K * len_sweep + gains
@@ -87,7 +92,7 @@ def make_shard(alg, config, games_per_rank, rank, world, backend=None, device=0,
     family = CONFIGS[config][0]
     lo, hi = alg.scenarios.shard_range(games_per_rank * world, rank, world)
     ids = np.arange(lo, hi)
-    prob = alg.scenarios.make_problem(family, ids, backend=backend, device=device, **kw)
+    prob = alg.scenarios.make_problem(family, ids, backend=backend, device=device, **{**CONFIG_KW.get(config, {}), **kw})
     return prob, ids
 
 
@@ -186,6 +191,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
 
     family, default_games = CONFIGS[args.config]
+    cfg_kw = CONFIG_KW.get(args.config, {})
     G = args.games_per_gpu or default_games
     prob, ids = make_shard(alg, args.config, G, rank, world, device=local_rank)
     b = prob.batch
@@ -282,7 +288,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(alg, family, G, args.mpc_steps)
+            out["cpu_baseline"] = cpu_baseline(alg, family, G, args.mpc_steps, cfg_kw)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -315,7 +321,7 @@ def usable_cpus():
     return n, (os.cpu_count() or 1), quota
 
 
-def cpu_baseline(alg, family, G, mpc_steps=0):
+def cpu_baseline(alg, family, G, mpc_steps=0, cfg_kw=None):
     """The oracle (literal CPU restatement of the reference algorithm: global KKT assembly + general partial-pivot
     LU per game, OpenMP over games) timed on a bounded sample of the same workload: all host cores, and one core
     (the closest analogue of the single-threaded Julia solver)."""
@@ -326,7 +332,7 @@ def cpu_baseline(alg, family, G, mpc_steps=0):
     prev = orc.set_threads(cores)
 
     def run(nsample):
-        prob = alg.scenarios.make_problem(family, np.arange(nsample), backend=orc.lib())
+        prob = alg.scenarios.make_problem(family, np.arange(nsample), backend=orc.lib(), **(cfg_kw or {}))
         t0 = time.perf_counter()
         if mpc_steps:
             steps = min(mpc_steps, 8)

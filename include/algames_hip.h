@@ -178,6 +178,9 @@ int alg_add_collision_avoidance(alg_handle* h, const double* radius /*p*/);
 /* add_control_bound!(game_con, u_max, u_min) (constraints_methods.jl:104-115); +-inf allowed */
 int alg_add_control_bound(alg_handle* h, const double* u_max /*m*/, const double* u_min /*m*/);
 
+/* Every adder of the extended set below (state bounds, walls, circles, and the 3-D set incl. spherical collision avoidance)
+ * re-creates the handle's multiplier storage: all lambda = 0, all mu = the current opts.rho_0 -- like freshly built ALConVals
+ * (it matters only when the first solve runs with dual_reset = false). */
 /* BicycleGame(p; lf, lr) parameters (bicycle.jl:15); only for ALG_MODEL_BICYCLE */
 int alg_set_bicycle(alg_handle* h, double lf, double lr);
 /* add_state_bound!(game_con, i, x_max, x_min) (constraints_methods.jl:86-98; state_bound_constraint.jl): bounds on the joint

@@ -1257,7 +1257,8 @@ int orc_add_spherical_collision_avoidance(alg_handle* h, const double* radius) {
     Shared& s = H->sh;
     if (!radius) { s.has_colavoid = false; s.D.ca_dim = 2; return ALG_OK; }
     if (int rc = need_3d(H, "orc_add_spherical_collision_avoidance")) return rc;
-    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; s.D.ca_dim = 3; return ALG_OK;
+    // (like every adder of the extended set: the multipliers are re-created, lambda = 0, mu = rho_0 -- include/algames_hip.h)
+    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; s.D.ca_dim = 3; orc_resize_con(H); return ALG_OK;
 }
 int orc_add_wall3d_constraint(alg_handle* h, int32_t nw, const double* p1, const double* p2, const double* p3, const double* v) {
     Shared& s = H->sh;

@@ -149,6 +149,22 @@ def test_fuzz_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
         assert hg["ls_j"][0] == ho["ls_j"][0] and hg["alpha"][0] == ho["alpha"][0], (tag, game)
 
 
+# The two of 700 cases of the long dense-family run (scratch/fuzz_long_dense.py) that ended outside the tolerances: quadrotor problems
+# whose iterates blow up (residual norms 1e2 .. 1e15 after failed line searches with ls_iter = 2 / 3, no regularisation in one).
+@pytest.mark.parametrize("seed", [400034, 400081])
+def test_fuzz_dense_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
+    rng = np.random.default_rng(seed)
+    fam = DENSE_FAMILIES[(seed - 400000) % len(DENSE_FAMILIES)]
+    g, o, tag = _random_pair(alg, orc, rng, ext=bool((seed - 400000) % 2), force=fam)
+    g.newton_solve(init=True, game_id0=7); o.newton_solve(init=True, game_id0=7)
+    for game in range(g.B):
+        hg, ho = g.get_history(game), o.get_history(game)
+        assert len(hg) >= 1 and len(ho) >= 1
+        for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+            assert abs(hg[f][0] - ho[f][0]) <= 1e-9 * abs(ho[f][0]) + 1e-12, (tag, game, f, hg[f][0], ho[f][0])
+        assert hg["ls_j"][0] == ho["ls_j"][0] and hg["alpha"][0] == ho["alpha"][0], (tag, game)
+
+
 @pytest.mark.parametrize("seed", [100005, 100031, 100063, 100122, 100136, 100154, 100170, 100178])
 def test_fuzz_team_kernel_regressions(alg, orc, seed):
     """Problems of the long run on which the first team kernels (several wavefronts per game) went wrong: a race between the dual

@@ -269,6 +269,28 @@ def test_quadrotor_dynamics(orc, p):
     assert np.abs(b.kat_dynamics(x, u)[0]).max() < 1e-14
 
 
+def test_quadrotor_game_end_to_end_on_the_oracle(alg, orc):
+    """No solver test of the reference uses the QuadrotorGame; what can be held against it is its own exit test
+    (solver_methods.jl:49-53): the crossing scenario of scenarios.quadrotor_crossing converges with every violation < 1e-3,
+    the quadrotors reach the far side, planar collision avoidance (px[i], quadrotor.jl:34) is active and respected."""
+    p = 2
+    prob = alg.scenarios.make_problem("Q", np.arange(3), p=p, backend=orc.lib())
+    assert isinstance(prob.model, alg.QuadrotorGame) and prob.probsize.n == 24 and prob.probsize.m == 8
+    alg.newton_solve(prob)
+    s = prob.stats.summary
+    assert np.all(s["status"] == 0) and np.all(s["converged"] == 1)
+    for f in ("opt_vio", "sta_vio", "dyn_vio", "con_vio"):
+        assert np.all(s["last"][f] < 1e-3), f
+    X, U, _ = prob.batch.split_traj(prob.batch.get_traj())
+    d = np.hypot(X[:, :, 0] - X[:, :, 1], X[:, :, 2] - X[:, :, 3])              # planar distance of the two vehicles per knot
+    assert d.min() > 0.2 - 2e-3 and d.min() < 0.25                               # pair radius 0.1 + 0.1: the constraint binds
+    assert prob.batch.get_con_duals()[0].max() > 1e-4
+    assert np.all(U > -1e-3) and np.all(U < 3.0 + 1e-3)                          # rotor commands inside their bounds
+    assert np.abs(X[:, -1, 4:6] - 0.5).max() < 0.15                              # height held
+    with pytest.raises(alg.AlgamesError):
+        alg.velocity_index(prob.model, 1)                                        # velocity_constraint.jl:30-43: no method for this model
+
+
 def test_quadrotor_rotation_is_orthogonal():
     # the restated MRP rotation (oracle: I + (4 (1 - s) [g x] + 8 [g x]^2) / (1 + s)^2) is a proper rotation and matches
     # Rodrigues for angle 4 atan(|g|) about g / |g|

@@ -55,6 +55,18 @@ def test_c3_all_1024_games_against_the_oracle(alg, orc):
     assert np.all(pg.stats.summary["converged"] == 1)
 
 
+@pytest.mark.parametrize("p,games", [(2, 4096), (3, 1024), (4, 1024)])
+def test_quadrotor_batches_against_the_oracle(alg, orc, p, games):
+    """bench.py's quadrotor workloads (scenarios.quadrotor_crossing, not BASELINE configurations) at their bench sizes (Q2: 4096 games, Q4: 1024 games)
+    dense banded LU with forward-mode AD finishes in seconds: every game, the automatic kernel shape."""
+    ids = np.arange(games)
+    pg = alg.scenarios.make_problem("Q", ids, p=p)
+    po = alg.scenarios.make_problem("Q", ids, p=p, backend=orc.lib())
+    alg.newton_solve(pg); alg.newton_solve(po)
+    _assert_full_parity(pg, po)
+    assert np.all(pg.stats.summary["converged"] == 1) and np.all(pg.stats.summary["status"] == 0)
+
+
 def test_c4_one_8192_game_shard_against_the_oracle(alg, orc):
     lo, hi = alg.scenarios.shard_range(65536, 3, 8)
     assert hi - lo == 8192

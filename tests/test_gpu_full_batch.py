@@ -57,8 +57,8 @@ def test_c3_all_1024_games_against_the_oracle(alg, orc):
 
 @pytest.mark.parametrize("p,games", [(2, 4096), (3, 1024), (4, 1024)])
 def test_quadrotor_batches_against_the_oracle(alg, orc, p, games):
-    """bench.py's quadrotor workloads (scenarios.quadrotor_crossing, not BASELINE configurations) at their bench sizes (Q2: 4096 games, Q4: 1024 games)
-    dense banded LU with forward-mode AD finishes in seconds: every game, the automatic kernel shape."""
+    """bench.py's quadrotor workloads (scenarios.quadrotor_crossing, not BASELINE configurations) at their bench sizes (Q2: 4096
+    games, Q4: 1024 games): every game against the oracle, the automatic kernel shape."""
     ids = np.arange(games)
     pg = alg.scenarios.make_problem("Q", ids, p=p)
     po = alg.scenarios.make_problem("Q", ids, p=p, backend=orc.lib())

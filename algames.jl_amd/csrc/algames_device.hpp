@@ -375,6 +375,7 @@ __device__ __forceinline__ void model_player(CPR pr, int i, const double* x, con
 // RK3 step of player i (rollout!, solver_methods.jl:17; RobotDynamics 0.3.1 RK3)
 template <class C>
 __device__ __forceinline__ void model_player_rk3(CPR pr, int i, const double* x, const double* u, double dt, double* xn) {
+    static_assert(!C::QUAD, "the quadrotor integrates through quad_rk3 (rollout)");
     double xi[C::ni], k1[C::ni], k2[C::ni], k3[C::ni], t[C::ni], ui[C::mi];
 #pragma unroll
     for (int j = 0; j < C::ni; j++) xi[j] = x[i + j * C::P];
@@ -698,9 +699,9 @@ struct DirLds<C, true> {
         double Wm[C::m * WC];                            // augmented control system, row-major
         double cf[2][CFL];                               // Jacobian coefficient blocks of steps k and k + 1 (slot = step & 1)
         double pcol[2][C::m];                            // pivot column of the Gauss-Jordan (double-buffered)
-        double rs[Rec<C>::LEN_SWEEP - C::NC];            // the step record behind the coefficient block ([Hh | Hd | RQ | rx | R^ | ru | rd])
+        double rs[2][Rec<C>::LEN_SWEEP - C::NC];         // the step record behind the coefficient block ([Hh | Hd | RQ | rx | R^ | ru | rd]), slot = step & 1
     };
-    struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n], cf[2][CFL], rs[Rec<C>::LEN_SWEEP - C::NC]; };
+    struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n], cf[2][CFL], rs[2][Rec<C>::LEN_SWEEP - C::NC], dxb[2][C::n]; };
     union { Bwd bw; Fwd fw; };
     double red[8];
 };
@@ -1328,6 +1329,46 @@ __device__ __forceinline__ double fast_rcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return fma(fma(-x, r, 1.0), r, r);
 }
+// Same elimination with XC columns per lane (lane t: columns t, t + 64, ...; the pivot columns c < M < 64 are first columns): the
+// control system of the dense direction (m + n + 1 up to 65 columns) solved by one wavefront without LDS traffic or barriers.
+template <int M, int XC>
+__device__ __forceinline__ int gj_solve_cols_x(double (&col)[XC][M]) {
+    int sing = 0;
+#pragma unroll
+    for (int c = 0; c < M; c++) {
+        double pc[M];
+#pragma unroll
+        for (int r = 0; r < M; r++) pc[r] = bcast_lane(col[0][r], c);
+        double best = fabs(pc[c]), oth = 0.0;
+        double rpiv = fast_rcp(pc[c]);
+#pragma unroll
+        for (int r = c + 1; r < M; r++) oth = fmax(oth, fabs(pc[r]));
+        if (__builtin_amdgcn_readfirstlane((int)(oth > best))) {
+            int piv = c;
+#pragma unroll
+            for (int r = c + 1; r < M; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
+            piv = __builtin_amdgcn_readfirstlane(piv);
+#pragma unroll
+            for (int r = c + 1; r < M; r++) {
+                if (piv == r) {
+                    double t = pc[c]; pc[c] = pc[r]; pc[r] = t;
+#pragma unroll
+                    for (int x = 0; x < XC; x++) { t = col[x][c]; col[x][c] = col[x][r]; col[x][r] = t; }
+                }
+            }
+            rpiv = fast_rcp(pc[c]);
+        }
+        if (!(best > 0.0) || !isfinite(best)) sing = 1;
+#pragma unroll
+        for (int x = 0; x < XC; x++) {
+            const double prow = col[x][c] * rpiv;
+#pragma unroll
+            for (int r = 0; r < M; r++) if (r != c) col[x][r] -= pc[r] * prow;
+            col[x][c] = prow;
+        }
+    }
+    return sing;
+}
 template <int M>
 __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
     int sing = 0;
@@ -1551,6 +1592,19 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
 #define ALG_PROF(j)
 #define ALG_PROF_FLUSH
 #endif
+// Flat parallel loop of the dense direction: entries e = tid, tid + BT, ... < total; U entries per thread and trip are evaluated
+// together (independent dependency chains in flight; out-of-range slots re-evaluate the trip's first entry) and stored afterwards.
+template <int U, class F, class S>
+__device__ __forceinline__ void flat_loop(int tid, int BT, int total, F&& f, S&& st) {
+    for (int e0 = tid; e0 < total; e0 += U * BT) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int e = e0 + u * BT; v[u] = f(e < total ? e : e0); }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int e = e0 + u * BT; if (e < total) st(e, v[u]); }
+    }
+}
+
 // ---- dense variant (Cfg::DENSE: QuadrotorGame, n = 12 p up to 48, dense 12 x 12 / 12 x 4 Jacobian blocks per player) ------------
 // The same structured elimination with everything of one backward step LDS-resident and all threads of the workgroup on every
 // phase: [P_i | s_i] [[F f],[0 1]] as ceil(n/16) x ceil((n+1)/16) tiles of v_mfma_f64_16x16x4_f64 chains (the tiles of a player are
@@ -1562,7 +1616,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     const Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, WC = DirLds<C>::WC, NK = m * (n + 1);
     constexpr int BT = C::NT, NWV = BT / WAVE;
-    constexpr int RSL = Rec<C>::LEN_SWEEP - C::NC;            // record fields behind the coefficient block
+    constexpr int FU = 2;                                     // entries per thread and trip of the flat loops
     constexpr int TR = (n + 15) / 16, TC = (n + 1 + 15) / 16, KBN = (n + 1 + 3) / 4;
     static_assert(NWV <= 4, "cross-wavefront reduction slots");
     using R = Rec<C>;
@@ -1575,16 +1629,31 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     for (int e = tid; e < (n + 1) * LDP; e += BT) B.Fx[e] = (e == n * LDP + n) ? 1.0 : 0.0;     // last row e_n: passes s_i through the product
     for (int e = tid; e < P * n * LDP; e += BT) B.Pm[e] = 0.0;
     int sing = 0;
+    // Step records travel HBM -> registers -> LDS one step ahead: requested at the top of step k for step k - 1, parked in LDS at the
+    // end of step k (coefficient block -> cf[(k - 1) & 1], the rest -> rs[(k - 1) & 1]), so the load latency hides behind a whole step
+    constexpr int RPT = (R::LEN_SWEEP + BT - 1) / BT;
+    double pre[RPT];
+    auto rec_load = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < RPT; q++) { const int e = tid + q * BT; pre[q] = recs[(size_t)kk * R::LEN + (e < R::LEN_SWEEP ? e : 0)]; }
+    };
+    auto rec_store = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            const int e = tid + q * BT;
+            if (e < C::NC) B.cf[kk & 1][e] = pre[q];
+            else if (e < R::LEN_SWEEP) B.rs[kk & 1][e - C::NC] = pre[q];
+        }
+    };
+    // (global-memory schedule of a step, as in the tile path: gfx9 counts loads and stores in one vmcnt, so the data requested one
+    // step ago is landed BEFORE this step's result stores are issued, and the next request follows them)
+    rec_load(N - 2); rec_store(N - 2);
+    if (N - 3 >= 0) rec_load(N - 3);
     __syncthreads();
     ALG_PROF_DECL
     // ------------------------------------------------------------------ backward sweep
     for (int k = N - 2; k >= 0; k--) {
-        const double* Rc = recs + (size_t)k * R::LEN;
-        // the step's Jacobian coefficient block -> LDS (slot k & 1; slot (k + 1) & 1 still holds step k + 1's, which the value
-        // recursion applies); first read after the barriers below
-        for (int e = tid; e < C::NC; e += BT) B.cf[k & 1][e] = Rc[R::COEF + e];
-        for (int e = tid; e < RSL; e += BT) B.rs[e] = Rc[C::NC + e];         // the rest of the record's sweep slice
-        const double* Rl = B.rs - C::NC;                                     // record offsets >= NC address the staged copy
+        const double* Rl = B.rs[k & 1] - C::NC;                              // record offsets >= NC address the staged copy
         const double* coefk = B.cf[k & 1];
         const double* coefn = B.cf[(k + 1) & 1];                           // A_{k+1} (only read while k < N - 2)
         const double w = (k + 1 < N - 1) ? dt : 1.0;
@@ -1638,16 +1707,15 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                         for (int r4 = 0; r4 < 3; r4++) { const int a = lq + 4 * r4; if (bok) Pi[(a * P + j) * LDP + bcol] = acc[r4]; }
                     }
                 } else {
-                    for (int e = tid; e < n * LDP; e += BT) {
+                    flat_loop<FU>(tid, BT, n * LDP, [&](int e) {
                         const int r = e / LDP, c = e % LDP;
-                        Pi[e] = AT_vec<C>(coefn, dt, [&](int rr) { return B.Tm[rr * LDP + c]; }, r);
-                    }
+                        return AT_vec<C>(coefn, dt, [&](int rr) { return B.Tm[rr * LDP + c]; }, r);
+                    }, [&](int e, double v) { Pi[e] = v; });
                 }
                 __syncthreads();
                 ALG_PROF(1)
             }
         }
-        if (k == N - 2) __syncthreads();                                    // (the recursion's barriers cover the staged record otherwise)
         // ---- + [Q^_i | rx_i]: diagonal, position block, column n
         for (int e = tid; e < P * n; e += BT) {
             const int i = e / n, r = e % n;
@@ -1664,100 +1732,82 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         __syncthreads();
         ALG_PROF(2)
         // ---- V[c][:] = B[:,c]' P_i(c),  y_i = P_i rd + s_i
-        for (int e = tid; e < m * n; e += BT) {
+        flat_loop<FU>(tid, BT, m * n, [&](int e) {
             const int c = e / n, col = e % n; const double* Pi = &B.Pm[(c % P) * n * LDP];
-            B.V[e] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
-        }
-        for (int e = tid; e < P * n; e += BT) {
+            return BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
+        }, [&](int e, double v) { B.V[e] = v; });
+        flat_loop<FU>(tid, BT, P * n, [&](int e) {
             const double* Pr = &B.Pm[e * LDP];
             double a = Pr[n];
             for (int c = 0; c < n; c++) a += Pr[c] * Rl[R::RD + c];
-            B.y[e] = a;
-        }
+            return a;
+        }, [&](int e, double v) { B.y[e] = v; });
         __syncthreads();
         ALG_PROF(3)
-        // ---- [ W | V A_k | g ],  W = diag(R^) + V B,  g_c = ru_c + B[:,c]' y_i(c)
-        for (int e = tid; e < m * WC; e += BT) {
-            const int c = e / WC, t = e % WC;
-            const double* Vc = &B.V[c * n];
-            double v;
-            if (t < m) v = BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rl[R::RHAT + c] : 0.0);
-            else if (t < m + n) v = (k >= 1) ? AT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t - m) : 0.0;     // dx_1 = 0: A_0 never acts
-            else { const double* yi = &B.y[(c % P) * n]; v = Rl[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c); }
+        // ---- [ W | V A_k | g ],  W = diag(R^) + V B,  g_c = ru_c + B[:,c]' y_i(c): three uniform loops (no divergent entry kinds)
+        auto ibr_mask = [&](int c, int t, double v) {
             if (IBR) {
                 if (c % P != ip) v = (t == c) ? 1.0 : 0.0;                   // unit row: du_c = 0
                 else if (t < m && t % P != ip) v = 0.0;                      // fixed controls of the other players
             }
-            B.Wm[e] = v;
-        }
+            return v;
+        };
+        flat_loop<FU>(tid, BT, m * m, [&](int e) {
+            const int c = e / m, t = e % m; const double* Vc = &B.V[c * n];
+            return ibr_mask(c, t, BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rl[R::RHAT + c] : 0.0));
+        }, [&](int e, double v) { B.Wm[(e / m) * WC + e % m] = v; });
+        flat_loop<FU>(tid, BT, m * n, [&](int e) {
+            const int c = e / n, col = e % n; const double* Vc = &B.V[c * n];
+            return ibr_mask(c, m + col, (k >= 1) ? AT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, col) : 0.0);    // dx_1 = 0: A_0 never acts
+        }, [&](int e, double v) { B.Wm[(e / n) * WC + m + e % n] = v; });
+        flat_loop<1>(tid, BT, m, [&](int c) {
+            const double* yi = &B.y[(c % P) * n];
+            return ibr_mask(c, m + n, Rl[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c));
+        }, [&](int c, double v) { B.Wm[c * WC + m + n] = v; });
         __syncthreads();
         ALG_PROF(4)
-        // ---- partially pivoted Gauss-Jordan (pivot rule and row operations of gj_solve_cols): thread t holds columns t, t + BT, ...
-        // in registers; per pivot only the pivot column travels through LDS (double-buffered: one barrier per pivot)
+        // ---- partially pivoted Gauss-Jordan (gj_solve_cols_x: pivot rule and row operations of the tile path): wavefront 0 alone, lane t
+        // holds columns t and t + 64 in registers, the pivot column travels by v_readlane -- no LDS traffic, no barrier per pivot
         {
-            constexpr int XC = (WC + BT - 1) / BT;
-            double col[XC][m];
-#pragma unroll
-            for (int x = 0; x < XC; x++) {
-                const int t = tid + x * BT;
-#pragma unroll
-                for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
-            }
-#pragma unroll
-            for (int c = 0; c < m; c++) {
-                if (tid == c) {
-#pragma unroll
-                    for (int r = 0; r < m; r++) B.pcol[c & 1][r] = col[0][r];
-                }
-                __syncthreads();
-                double pc[m];
-#pragma unroll
-                for (int r = 0; r < m; r++) pc[r] = B.pcol[c & 1][r];
-                double best = fabs(pc[c]); int piv = c;
-#pragma unroll
-                for (int r = c + 1; r < m; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
-                if (!(best > 0.0) || !isfinite(best)) sing = 1;
-                piv = __builtin_amdgcn_readfirstlane(piv);
-                if (piv != c) {
-#pragma unroll
-                    for (int r = c + 1; r < m; r++) {
-                        if (piv == r) {
-                            double t2 = pc[c]; pc[c] = pc[r]; pc[r] = t2;
-#pragma unroll
-                            for (int x = 0; x < XC; x++) { t2 = col[x][c]; col[x][c] = col[x][r]; col[x][r] = t2; }
-                        }
-                    }
-                }
-                const double rpiv = fast_rcp(pc[c]);
+            constexpr int XC = (WC + WAVE - 1) / WAVE;
+            static_assert(m < WAVE && XC <= 2, "control system of the dense direction: at most 128 columns");
+            int sg = 0;
+            if (wv == 0) {
+                double col[XC][m];
 #pragma unroll
                 for (int x = 0; x < XC; x++) {
-                    const double prow = col[x][c] * rpiv;
+                    const int t = lane + x * WAVE;
 #pragma unroll
-                    for (int r = 0; r < m; r++) if (r != c) col[x][r] -= pc[r] * prow;
-                    col[x][c] = prow;
+                    for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
                 }
-            }
-            // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
+                sg = gj_solve_cols_x<m, XC>(col);
+                // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
 #pragma unroll
-            for (int x = 0; x < XC; x++) {
-                const int t = tid + x * BT;
-                if (t >= m && t < WC) {
+                for (int x = 0; x < XC; x++) {
+                    const int t = lane + x * WAVE;
+                    if (t >= m && t < WC) {
 #pragma unroll
-                    for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                        for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                    }
                 }
+                if (lane == 0) B.pcol[0][0] = (double)sg;
             }
             __syncthreads();
+            if constexpr (NWV > 1) sg = (int)B.pcol[0][0];
+            sing |= __builtin_amdgcn_readfirstlane(sg);
         }
         ALG_PROF(5)
-        // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
-        for (int e = tid; e < NK; e += BT) { const int col = e / m, c = e % m; kg[(size_t)k * NK + e] = -B.Wm[c * WC + m + col]; }
+        // ---- [F | f] = [A_k | rd] + B [K | kappa] ; K = -Y -> HBM (column-major m x (n+1))
         if (k > 0) {
-            for (int e = tid; e < n * LDP; e += BT) {
+            flat_loop<FU>(tid, BT, n * LDP, [&](int e) {
                 const int r = e / LDP, col = e % LDP;
                 const double base = col < n ? A_entry<C>(coefk, dt, r, col) : Rl[R::RD + r];
-                B.Fx[e] = base + B_vec<C>(coefk, dt, [&](int c2) { return -B.Wm[c2 * WC + m + col]; }, r);
-            }
+                return base + B_vec<C>(coefk, dt, [&](int c2) { return -B.Wm[c2 * WC + m + col]; }, r);
+            }, [&](int e, double v) { B.Fx[e] = v; });
         }
+        if (k > 0) rec_store(k - 1);                                         // (1) land the record of step k - 1
+        for (int e = tid; e < NK; e += BT) { const int col = e / m, c = e % m; kg[(size_t)k * NK + e] = -B.Wm[c * WC + m + col]; }   // (2) gains out
+        if (k > 1) rec_load(k - 2);                                          // (3) request step k - 2
         __syncthreads();
         ALG_PROF(6)
     }
@@ -1766,64 +1816,123 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     double* __restrict__ dz = G.z(2);
     auto& F = L.fw;
     for (int e = tid; e < n; e += BT) { F.dx[e] = 0.0; dz[e] = 0.0; }
+    // forward sweep slice of a record: [coef | rd], one step ahead through registers like above
+    constexpr int FSL = C::NC + n, FPT = (FSL + BT - 1) / BT;
+    double fpre[FPT];
+    auto fw_load = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < FPT; q++) { const int e = tid + q * BT; fpre[q] = recs[(size_t)kk * R::LEN + (e < C::NC ? e : (e < FSL ? R::RD + (e - C::NC) : 0))]; }
+    };
+    auto fw_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < FPT; q++) {
+            const int e = tid + q * BT;
+            if (e < C::NC) F.cf[0][e] = fpre[q];
+            else if (e < FSL) F.rs[0][R::RD - C::NC + (e - C::NC)] = fpre[q];
+        }
+    };
+    fw_load(0); fw_store();
+    if (1 < N - 1) fw_load(1);
     __syncthreads();
     double pl1 = 0.0; int bad = 0;
     constexpr int XPT = (n + BT - 1) / BT;
     for (int k = 0; k < N - 1; k++) {
-        const double* Rc = recs + (size_t)k * R::LEN;
-        for (int e = tid; e < C::NC; e += BT) F.cf[0][e] = Rc[R::COEF + e];      // read after the barrier below
-        if (tid < n) F.rs[R::RD - C::NC + tid] = Rc[R::RD + tid];
         const double* coefk = F.cf[0];
         const double* Kg = kg + (size_t)k * NK;
-        for (int c = tid; c < m; c += BT) {
-            double a = Kg[n * m + c];
-            for (int q = 0; q < n; q++) a += Kg[q * m + c] * F.dx[q];
-            F.du[c] = a; dz[n + hu<C>(k, 0) + uoff<C>(c)] = a;
-            pl1 += fabs(a); bad |= !isfinite(a);
+        constexpr int UPT = (m + BT - 1) / BT;
+        double duv[UPT];
+#pragma unroll
+        for (int q0 = 0; q0 < UPT; q0++) {
+            const int c = tid + q0 * BT; duv[q0] = 0.0;
+            if (c < m) {
+                double a = Kg[n * m + c];
+                for (int q = 0; q < n; q++) a += Kg[q * m + c] * F.dx[q];
+                F.du[c] = a; duv[q0] = a;
+                pl1 += fabs(a); bad |= !isfinite(a);
+            }
         }
         __syncthreads();
         double nx[XPT];
 #pragma unroll
         for (int q = 0; q < XPT; q++) {
             const int r = tid + q * BT; nx[q] = 0.0;
-            if (r < n) nx[q] = (A_vec<C>(coefk, dt, [&](int rr) { return F.dx[rr]; }, r) + B_vec<C>(coefk, dt, [&](int cc) { return F.du[cc]; }, r)) + F.rs[R::RD - C::NC + r];
+            if (r < n) nx[q] = (A_vec<C>(coefk, dt, [&](int rr) { return F.dx[rr]; }, r) + B_vec<C>(coefk, dt, [&](int cc) { return F.du[cc]; }, r)) + F.rs[0][R::RD - C::NC + r];
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < XPT; q++) {
             const int r = tid + q * BT;
-            if (r < n) { F.dx[r] = nx[q]; dz[n + hx<C>(k) + r] = nx[q]; pl1 += fabs(nx[q]); bad |= !isfinite(nx[q]); }
+            if (r < n) { F.dx[r] = nx[q]; pl1 += fabs(nx[q]); bad |= !isfinite(nx[q]); }
         }
+        if (k + 1 < N - 1) fw_store();                                       // (1) land step k + 1's slice
+#pragma unroll
+        for (int q0 = 0; q0 < UPT; q0++) { const int c = tid + q0 * BT; if (c < m) dz[n + hu<C>(k, 0) + uoff<C>(c)] = duv[q0]; }   // (2) results out
+#pragma unroll
+        for (int q = 0; q < XPT; q++) { const int r = tid + q * BT; if (r < n) dz[n + hx<C>(k) + r] = nx[q]; }
+        if (k + 2 < N - 1) fw_load(k + 2);                                   // (3) request step k + 2
         __syncthreads();
     }
     ALG_PROF(7)
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    for (int k = N - 2; k >= 0; k--) {
-        const double* Rc = recs + (size_t)k * R::LEN;
-        const int cur = k & 1;
-        // this step's coefficients go to slot cur for the next (earlier) step; slot cur ^ 1 holds step k + 1's
-        for (int e = tid; e < C::NC; e += BT) F.cf[cur][e] = Rc[R::COEF + e];
-        for (int e = tid; e < R::LEN_COSTATE - C::NC; e += BT) F.rs[e] = Rc[C::NC + e];
-        const double* Rl = F.rs - C::NC;
-        const double* coefn = F.cf[cur ^ 1];
-        const double w = (k + 1 < N - 1) ? dt : 1.0;
-        for (int e = tid; e < n; e += BT) F.dx[e] = dz[n + hx<C>(k) + e];
-        __syncthreads();
-        for (int e = tid; e < P * n; e += BT) {
-            const int i = e / n, r = e % n;
-            double acc = 0.0;
-            if (!IBR || i == ip) {
-                double qd = reg + ((r % P == i) ? w * Qd[i * C::ni + r / P] : 0.0);
-                if constexpr (C::EXT) qd += Rl[R::RQ + e];
-                acc = Rl[R::RX + e] + qd * F.dx[r];
-                if (C::POS && r < C::PD * P) {
-                    for (int c = 0; c < C::PD * P; c++) acc += pairblock<C>(Rl + R::HH, i, r, c) * F.dx[c];
-                }
-                if (k < N - 2) { const double* dli = &F.dl[cur ^ 1][i * n]; acc += AT_vec<C>(coefn, dt, [&](int rr) { return dli[rr]; }, r); }
-            }
-            F.dl[cur][e] = acc; dz[n + hl<C>(k, 0) + e] = acc; bad |= !isfinite(acc);
+    // costate slice: this step's coefficient block (applied as A_{k+1}' one step later) and the NEXT (earlier) step's
+    // [Hh | Hd | RQ | rx], both requested at the top of a step and parked in LDS at its end
+    // plus dx_k (the direction's state block the step multiplies with): cs_load(kk) requests the coefficients of step kk + 1 and
+    // [Hh | Hd | RQ | rx], dx of step kk; cs_store(kk) parks them in the slots step kk reads
+    constexpr int CSL = R::LEN_COSTATE, CPT = (CSL + n + BT - 1) / BT;
+    double cpre[CPT];
+    auto cs_load = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < CPT; q++) {
+            const int e = tid + q * BT;
+            const double* src = e < C::NC ? recs + (size_t)(kk + 1 < N - 1 ? kk + 1 : kk) * R::LEN + e
+                              : e < CSL ? recs + (size_t)kk * R::LEN + e
+                              : dz + n + hx<C>(kk) + (e < CSL + n ? e - CSL : 0);
+            cpre[q] = *src;
         }
+    };
+    auto cs_store = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < CPT; q++) {
+            const int e = tid + q * BT;
+            if (e < C::NC) F.cf[(kk + 1) & 1][e] = cpre[q];
+            else if (e < CSL) F.rs[kk & 1][e - C::NC] = cpre[q];
+            else if (e < CSL + n) F.dxb[kk & 1][e - CSL] = cpre[q];
+        }
+    };
+    cs_load(N - 2); cs_store(N - 2);
+    if (N - 3 >= 0) cs_load(N - 3);
+    __syncthreads();
+    for (int k = N - 2; k >= 0; k--) {
+        const int cur = k & 1;
+        const double* Rl = F.rs[cur] - C::NC;
+        const double* coefn = F.cf[cur ^ 1];
+        const double* dxk = F.dxb[cur];
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
+        constexpr int LPT = (P * n + BT - 1) / BT;
+        double lv[LPT];
+#pragma unroll
+        for (int q0 = 0; q0 < LPT; q0++) {
+            const int e = tid + q0 * BT; lv[q0] = 0.0;
+            if (e < P * n) {
+                const int i = e / n, r = e % n;
+                double acc = 0.0;
+                if (!IBR || i == ip) {
+                    double qd = reg + ((r % P == i) ? w * Qd[i * C::ni + r / P] : 0.0);
+                    if constexpr (C::EXT) qd += Rl[R::RQ + e];
+                    acc = Rl[R::RX + e] + qd * dxk[r];
+                    if (C::POS && r < C::PD * P) {
+                        for (int c = 0; c < C::PD * P; c++) acc += pairblock<C>(Rl + R::HH, i, r, c) * dxk[c];
+                    }
+                    if (k < N - 2) { const double* dli = &F.dl[cur ^ 1][i * n]; acc += AT_vec<C>(coefn, dt, [&](int rr) { return dli[rr]; }, r); }
+                }
+                F.dl[cur][e] = acc; lv[q0] = acc; bad |= !isfinite(acc);
+            }
+        }
+        if (k > 0) cs_store(k - 1);                                          // (1) land step k - 1's slices (other slots than the ones read above)
+#pragma unroll
+        for (int q0 = 0; q0 < LPT; q0++) { const int e = tid + q0 * BT; if (e < P * n) dz[n + hl<C>(k, 0) + e] = lv[q0]; }   // (2) results out
+        if (k > 1) cs_load(k - 2);                                           // (3) request step k - 2
         __syncthreads();
     }
     ALG_PROF(8)
@@ -2522,9 +2631,7 @@ __device__ __forceinline__ void rollout(CPR pr, double* z) {
                 for (int j = 0; j < 12; j++) { xi[j] = xo[j]; z[n + hx<C>(k) + lane + j * P] = xo[j]; }
             }
         }
-        return;
-    }
-    if (lane < P) {
+    } else if (lane < P) {
         double x[n], u[m];     // only this player's entries are used
         for (int j = 0; j < C::ni; j++) x[lane + j * P] = z[lane + j * P];
         for (int k = 0; k < pr.N - 1; k++) {

@@ -57,6 +57,31 @@ def kernel_resources(lib_path):
     return out
 
 
+def scratch_load_counts(lib_path, only=None):
+    """{demangled kernel name: number of scratch_load* instructions in its ISA} (llvm-objdump -d over the gfx950 code objects).
+    A kernel whose metadata reports a private segment but whose ISA never loads from it only parks a by-reference argument
+    object there (stores without loads): no register spill is involved."""
+    objdump = os.path.join(os.path.dirname(READELF), "llvm-objdump")
+    out = {}
+    for img in code_objects(lib_path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(img)
+            f.flush()
+            txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True).stdout
+        cur = None
+        for line in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                out.setdefault(cur, 0)
+            elif cur is not None and "scratch_load" in line:
+                out[cur] += 1
+    names = [n for n in out if n.startswith("_Z")]
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n") if names else []
+    res = {re.sub(r"^void |alg::|\(.*$", "", d): out[n] for d, n in zip(dem, names)}
+    return res if only is None else {k: v for k, v in res.items() if k in only}
+
+
 if __name__ == "__main__":
     import sys
     here = os.path.dirname(os.path.abspath(__file__))

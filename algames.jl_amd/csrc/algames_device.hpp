@@ -1616,7 +1616,10 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     const Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, WC = DirLds<C>::WC, NK = m * (n + 1);
     constexpr int BT = C::NT, NWV = BT / WAVE;
-    constexpr int FU = 2;                                     // entries per thread and trip of the flat loops
+#ifndef ALG_DENSE_FU
+#define ALG_DENSE_FU 2
+#endif
+    constexpr int FU = ALG_DENSE_FU;                          // entries per thread and trip of the flat loops
     constexpr int TR = (n + 15) / 16, TC = (n + 1 + 15) / 16, KBN = (n + 1 + 3) / 4;
     static_assert(NWV <= 4, "cross-wavefront reduction slots");
     using R = Rec<C>;
@@ -1631,18 +1634,32 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     int sing = 0;
     // Step records travel HBM -> registers -> LDS one step ahead: requested at the top of step k for step k - 1, parked in LDS at the
     // end of step k (coefficient block -> cf[(k - 1) & 1], the rest -> rs[(k - 1) & 1]), so the load latency hides behind a whole step
+    // (PREF: only while a thread's share of a record is small -- the largest shapes, e.g. four quadrotors on one wavefront, would
+    // run out of registers; they copy the record at the landing point instead)
+#ifndef ALG_DENSE_PREF
+#define ALG_DENSE_PREF 12
+#endif
     constexpr int RPT = (R::LEN_SWEEP + BT - 1) / BT;
-    double pre[RPT];
+    constexpr bool PREF = RPT <= ALG_DENSE_PREF;
+    double pre[PREF ? RPT : 1];
     auto rec_load = [&](int kk) {
+        if constexpr (PREF) {
 #pragma unroll
-        for (int q = 0; q < RPT; q++) { const int e = tid + q * BT; pre[q] = recs[(size_t)kk * R::LEN + (e < R::LEN_SWEEP ? e : 0)]; }
+            for (int q = 0; q < RPT; q++) { const int e = tid + q * BT; pre[q] = recs[(size_t)kk * R::LEN + (e < R::LEN_SWEEP ? e : 0)]; }
+        }
     };
     auto rec_store = [&](int kk) {
+        if constexpr (PREF) {
 #pragma unroll
-        for (int q = 0; q < RPT; q++) {
-            const int e = tid + q * BT;
-            if (e < C::NC) B.cf[kk & 1][e] = pre[q];
-            else if (e < R::LEN_SWEEP) B.rs[kk & 1][e - C::NC] = pre[q];
+            for (int q = 0; q < RPT; q++) {
+                const int e = tid + q * BT;
+                if (e < C::NC) B.cf[kk & 1][e] = pre[q];
+                else if (e < R::LEN_SWEEP) B.rs[kk & 1][e - C::NC] = pre[q];
+            }
+        } else {
+            const double* Rk = recs + (size_t)kk * R::LEN;
+            for (int e = tid; e < C::NC; e += BT) B.cf[kk & 1][e] = Rk[e];
+            for (int e = tid; e < R::LEN_SWEEP - C::NC; e += BT) B.rs[kk & 1][e] = Rk[C::NC + e];
         }
     };
     // (global-memory schedule of a step, as in the tile path: gfx9 counts loads and stores in one vmcnt, so the data requested one
@@ -1766,35 +1783,93 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         }, [&](int c, double v) { B.Wm[c * WC + m + n] = v; });
         __syncthreads();
         ALG_PROF(4)
-        // ---- partially pivoted Gauss-Jordan (gj_solve_cols_x: pivot rule and row operations of the tile path): wavefront 0 alone, lane t
-        // holds columns t and t + 64 in registers, the pivot column travels by v_readlane -- no LDS traffic, no barrier per pivot
-        {
-            constexpr int XC = (WC + WAVE - 1) / WAVE;
-            static_assert(m < WAVE && XC <= 2, "control system of the dense direction: at most 128 columns");
-            int sg = 0;
-            if (wv == 0) {
-                double col[XC][m];
+        // ---- partially pivoted Gauss-Jordan (pivot rule and row operations of the tile path's gj_solve_cols).  m <= 8: wavefront 0
+        // alone, columns in registers, the pivot column by v_readlane (no LDS traffic, no barrier).  m > 8 (the 2 m scalar registers
+        // of a readlane broadcast inside the fully unrolled elimination push those kernels into scratch): all threads, columns in
+        // registers, the pivot column through LDS, one barrier per pivot.
+#ifndef ALG_DENSE_GJW
+#define ALG_DENSE_GJW 8
+#endif
+        if constexpr (m <= ALG_DENSE_GJW) {
+                constexpr int XC = (WC + WAVE - 1) / WAVE;
+                static_assert(m < WAVE && XC <= 2, "control system of the dense direction: at most 128 columns");
+                int sg = 0;
+                if (wv == 0) {
+                    double col[XC][m];
 #pragma unroll
-                for (int x = 0; x < XC; x++) {
-                    const int t = lane + x * WAVE;
+                    for (int x = 0; x < XC; x++) {
+                        const int t = lane + x * WAVE;
 #pragma unroll
-                    for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
+                        for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
+                    }
+                    sg = gj_solve_cols_x<m, XC>(col);
+                    // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
+#pragma unroll
+                    for (int x = 0; x < XC; x++) {
+                        const int t = lane + x * WAVE;
+                        if (t >= m && t < WC) {
+#pragma unroll
+                            for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                        }
+                    }
+                    if (lane == 0) L.red[7] = (double)sg;
                 }
-                sg = gj_solve_cols_x<m, XC>(col);
-                // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
+                __syncthreads();
+                if constexpr (NWV > 1) sg = (int)L.red[7];
+                sing |= __builtin_amdgcn_readfirstlane(sg);
+        } else {
+            constexpr int XC = (WC + BT - 1) / BT;
+            double col[XC][m];
 #pragma unroll
-                for (int x = 0; x < XC; x++) {
-                    const int t = lane + x * WAVE;
-                    if (t >= m && t < WC) {
+            for (int x = 0; x < XC; x++) {
+                const int t = tid + x * BT;
 #pragma unroll
-                        for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
+            }
+#pragma unroll
+            for (int c = 0; c < m; c++) {
+                if (tid == c) {
+#pragma unroll
+                    for (int r = 0; r < m; r++) B.pcol[c & 1][r] = col[0][r];
+                }
+                __syncthreads();
+                double pc[m];
+#pragma unroll
+                for (int r = 0; r < m; r++) pc[r] = B.pcol[c & 1][r];
+                double best = fabs(pc[c]); int piv = c;
+#pragma unroll
+                for (int r = c + 1; r < m; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
+                if (!(best > 0.0) || !isfinite(best)) sing = 1;
+                piv = __builtin_amdgcn_readfirstlane(piv);
+                if (piv != c) {
+#pragma unroll
+                    for (int r = c + 1; r < m; r++) {
+                        if (piv == r) {
+                            double t2 = pc[c]; pc[c] = pc[r]; pc[r] = t2;
+#pragma unroll
+                            for (int x = 0; x < XC; x++) { t2 = col[x][c]; col[x][c] = col[x][r]; col[x][r] = t2; }
+                        }
                     }
                 }
-                if (lane == 0) B.pcol[0][0] = (double)sg;
+                const double rpiv = fast_rcp(pc[c]);
+#pragma unroll
+                for (int x = 0; x < XC; x++) {
+                    const double prow = col[x][c] * rpiv;
+#pragma unroll
+                    for (int r = 0; r < m; r++) if (r != c) col[x][r] -= pc[r] * prow;
+                    col[x][c] = prow;
+                }
+            }
+            // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
+#pragma unroll
+            for (int x = 0; x < XC; x++) {
+                const int t = tid + x * BT;
+                if (t >= m && t < WC) {
+#pragma unroll
+                    for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                }
             }
             __syncthreads();
-            if constexpr (NWV > 1) sg = (int)B.pcol[0][0];
-            sing |= __builtin_amdgcn_readfirstlane(sg);
         }
         ALG_PROF(5)
         // ---- [F | f] = [A_k | rd] + B [K | kappa] ; K = -Y -> HBM (column-major m x (n+1))
@@ -1818,17 +1893,27 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     for (int e = tid; e < n; e += BT) { F.dx[e] = 0.0; dz[e] = 0.0; }
     // forward sweep slice of a record: [coef | rd], one step ahead through registers like above
     constexpr int FSL = C::NC + n, FPT = (FSL + BT - 1) / BT;
-    double fpre[FPT];
+    double fpre[PREF ? FPT : 1];
+    int fw_req = 0;                                          // step whose slice is in flight / due at the landing point
     auto fw_load = [&](int kk) {
+        fw_req = kk;
+        if constexpr (PREF) {
 #pragma unroll
-        for (int q = 0; q < FPT; q++) { const int e = tid + q * BT; fpre[q] = recs[(size_t)kk * R::LEN + (e < C::NC ? e : (e < FSL ? R::RD + (e - C::NC) : 0))]; }
+            for (int q = 0; q < FPT; q++) { const int e = tid + q * BT; fpre[q] = recs[(size_t)kk * R::LEN + (e < C::NC ? e : (e < FSL ? R::RD + (e - C::NC) : 0))]; }
+        }
     };
     auto fw_store = [&]() {
+        if constexpr (PREF) {
 #pragma unroll
-        for (int q = 0; q < FPT; q++) {
-            const int e = tid + q * BT;
-            if (e < C::NC) F.cf[0][e] = fpre[q];
-            else if (e < FSL) F.rs[0][R::RD - C::NC + (e - C::NC)] = fpre[q];
+            for (int q = 0; q < FPT; q++) {
+                const int e = tid + q * BT;
+                if (e < C::NC) F.cf[0][e] = fpre[q];
+                else if (e < FSL) F.rs[0][R::RD - C::NC + (e - C::NC)] = fpre[q];
+            }
+        } else {
+            const double* Rk = recs + (size_t)fw_req * R::LEN;
+            for (int e = tid; e < C::NC; e += BT) F.cf[0][e] = Rk[e];
+            for (int e = tid; e < n; e += BT) F.rs[0][R::RD - C::NC + e] = Rk[R::RD + e];
         }
     };
     fw_load(0); fw_store();
@@ -1880,24 +1965,33 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     // plus dx_k (the direction's state block the step multiplies with): cs_load(kk) requests the coefficients of step kk + 1 and
     // [Hh | Hd | RQ | rx], dx of step kk; cs_store(kk) parks them in the slots step kk reads
     constexpr int CSL = R::LEN_COSTATE, CPT = (CSL + n + BT - 1) / BT;
-    double cpre[CPT];
+    double cpre[PREF ? CPT : 1];
     auto cs_load = [&](int kk) {
+        if constexpr (PREF) {
 #pragma unroll
-        for (int q = 0; q < CPT; q++) {
-            const int e = tid + q * BT;
-            const double* src = e < C::NC ? recs + (size_t)(kk + 1 < N - 1 ? kk + 1 : kk) * R::LEN + e
-                              : e < CSL ? recs + (size_t)kk * R::LEN + e
-                              : dz + n + hx<C>(kk) + (e < CSL + n ? e - CSL : 0);
-            cpre[q] = *src;
+            for (int q = 0; q < CPT; q++) {
+                const int e = tid + q * BT;
+                const double* src = e < C::NC ? recs + (size_t)(kk + 1 < N - 1 ? kk + 1 : kk) * R::LEN + e
+                                  : e < CSL ? recs + (size_t)kk * R::LEN + e
+                                  : dz + n + hx<C>(kk) + (e < CSL + n ? e - CSL : 0);
+                cpre[q] = *src;
+            }
         }
     };
     auto cs_store = [&](int kk) {
+        if constexpr (PREF) {
 #pragma unroll
-        for (int q = 0; q < CPT; q++) {
-            const int e = tid + q * BT;
-            if (e < C::NC) F.cf[(kk + 1) & 1][e] = cpre[q];
-            else if (e < CSL) F.rs[kk & 1][e - C::NC] = cpre[q];
-            else if (e < CSL + n) F.dxb[kk & 1][e - CSL] = cpre[q];
+            for (int q = 0; q < CPT; q++) {
+                const int e = tid + q * BT;
+                if (e < C::NC) F.cf[(kk + 1) & 1][e] = cpre[q];
+                else if (e < CSL) F.rs[kk & 1][e - C::NC] = cpre[q];
+                else if (e < CSL + n) F.dxb[kk & 1][e - CSL] = cpre[q];
+            }
+        } else {
+            const double* Rn = recs + (size_t)(kk + 1 < N - 1 ? kk + 1 : kk) * R::LEN; const double* Rk = recs + (size_t)kk * R::LEN;
+            for (int e = tid; e < C::NC; e += BT) F.cf[(kk + 1) & 1][e] = Rn[e];
+            for (int e = tid; e < CSL - C::NC; e += BT) F.rs[kk & 1][e] = Rk[C::NC + e];
+            for (int e = tid; e < n; e += BT) F.dxb[kk & 1][e] = dz[n + hx<C>(kk) + e];
         }
     };
     cs_load(N - 2); cs_store(N - 2);

@@ -86,6 +86,8 @@ def test_solver_kernels_of_the_shipped_library_do_not_spill(alg):
     assert head["vgpr_spill"] == 0 and head["sgpr_spill"] == 0 and head["scratch"] == 0 and head["vgpr"] <= 128, head
     for k, v in solve.items():
         assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
+    # no solver kernel keeps a phase function as a real call (its per-game view would live in scratch): a kernel whose metadata
+    # shows no private segment cannot contain one; the dense-direction units get there with a raised inliner limit (__graft_entry__)
     allowed = {"k_mpc_loop<Cfg<2, 4, 2, 1, 1> >"}                  # 4-player bicycle loop kernel: 8 VGPRs at the 256-VGPR ceiling
     for k, v in res.items():
         if k.startswith(("k_mpc_loop<", "k_ibr<", "k_direction<", "k_newton_step<")) and k not in allowed:

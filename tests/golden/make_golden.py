@@ -21,6 +21,8 @@ CASES = {                      # name -> (scenario set, global scenario ids, mak
     "c2_n40": ("C2", np.arange(4090, 4094), {}),
     "c5": ("C5", np.arange(300, 304), {}),
     "c3_n20": ("C3", np.arange(8, 10), dict(N=20)),
+    "q2": ("Q", np.arange(16, 20), dict(p=2)),              # quadrotors (scenarios.quadrotor_crossing): dense Newton direction
+    "q3_n10": ("Q", np.arange(5, 7), dict(p=3, N=10)),
 }
 
 
@@ -53,5 +55,9 @@ if __name__ == "__main__":
     for name in list(CASES) + ["intro"]:
         for k, v in solve(name, alg, orc.lib()).items():
             out[f"{name}.{k}"] = v
-    np.savez_compressed(os.path.join(HERE, "oracle_solutions.npz"), **out)
+    path = os.path.join(HERE, "oracle_solutions.npz")
+    if os.path.exists(path):        # committed vectors stay as they are (a rebuilt oracle agrees with them to rounding); new cases are added
+        old = np.load(path)
+        out = {**out, **{k: old[k] for k in old.files}}
+    np.savez_compressed(path, **out)
     print("wrote", os.path.join(HERE, "oracle_solutions.npz"), {k: v.shape for k, v in out.items() if k.endswith(".z")})

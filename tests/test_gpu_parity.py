@@ -463,7 +463,7 @@ def test_golden_solutions_gpu(alg):
     sys.path.insert(0, gdir)
     import make_golden
     ref = np.load(os.path.join(gdir, "oracle_solutions.npz"))
-    for name in ("c2_n12", "c2_n40", "c5", "c3_n20", "intro"):
+    for name in ("c2_n12", "c2_n40", "c5", "c3_n20", "q2", "q3_n10", "intro"):
         got = make_golden.solve(name, alg, None)
         for k in ("newton_iters", "outer_iters", "status", "converged"):
             assert np.array_equal(got[k], ref[f"{name}.{k}"]), (name, k)

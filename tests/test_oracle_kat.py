@@ -960,7 +960,7 @@ def test_golden_solutions_oracle(alg, orc):
     sys.path.insert(0, gdir)
     import make_golden
     ref = np.load(os.path.join(gdir, "oracle_solutions.npz"))
-    for name in ("c2_n12", "c5", "intro"):
+    for name in ("c2_n12", "c5", "q2", "intro"):
         got = make_golden.solve(name, alg, orc.lib())
         for k, v in got.items():
             r = ref[f"{name}.{k}"]

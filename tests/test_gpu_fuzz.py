@@ -149,9 +149,10 @@ def test_fuzz_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
         assert hg["ls_j"][0] == ho["ls_j"][0] and hg["alpha"][0] == ho["alpha"][0], (tag, game)
 
 
-# The two of 700 cases of the long dense-family run (scratch/fuzz_long_dense.py) that ended outside the tolerances: quadrotor problems
-# whose iterates blow up (residual norms 1e2 .. 1e15 after failed line searches with ls_iter = 2 / 3, no regularisation in one).
-@pytest.mark.parametrize("seed", [400034, 400081])
+# Cases of the long dense-family runs (scratch/fuzz_long_dense.py: 700 and 1400 problems) that ended outside the tolerances: quadrotor
+# problems whose iterates blow up (dt = 0.2 over 8 steps from random attitudes and rates; residual norms 1e2 .. 1e15 after failed
+# line searches with ls_iter = 2 / 3).  Their discrete histories agree, both kernel shapes give the same numbers.
+@pytest.mark.parametrize("seed", [400034, 400081, 400795, 401042, 401091, 401322])
 def test_fuzz_dense_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
     rng = np.random.default_rng(seed)
     fam = DENSE_FAMILIES[(seed - 400000) % len(DENSE_FAMILIES)]

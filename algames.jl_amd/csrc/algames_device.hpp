@@ -692,14 +692,21 @@ struct DirLds<C, true> {
     static constexpr int CFL = C::NC > 0 ? C::NC : 1;
     struct Bwd {
         double Pm[C::P * C::n * LDP];                    // [P_i | s_i], row-major
-        double Tm[C::n * LDP];                           // [P_i F | P_i f + s_i] of the player being advanced
         double Fx[(C::n + 1) * LDP];                     // [[F f],[0 1]]
-        double V[C::m * C::n];                           // V[c][:] = B[:,c]' P_i(c)
-        double y[C::P * C::n];                           // y_i = P_i rd + s_i
-        double Wm[C::m * WC];                            // augmented control system, row-major
-        double cf[2][CFL];                               // Jacobian coefficient blocks of steps k and k + 1 (slot = step & 1)
-        double pcol[2][C::m];                            // pivot column of the Gauss-Jordan (double-buffered)
-        double rs[2][Rec<C>::LEN_SWEEP - C::NC];         // the step record behind the coefficient block ([Hh | Hd | RQ | rx | R^ | ru | rd]), slot = step & 1
+        struct Sys {
+            double V[C::m * C::n];                       // V[c][:] = B[:,c]' P_i(c)
+            double y[C::P * C::n];                       // y_i = P_i rd + s_i
+            double Wm[C::m * WC];                        // augmented control system, row-major
+            double pcol[2][C::m];                        // pivot column of the Gauss-Jordan (double-buffered)
+        };
+        union {                                          // the value recursion's product and the control system are never live together
+            double Tm[C::n * LDP];                       // [P_i F | P_i f + s_i] of the player being advanced
+            Sys sv;
+        };
+        // one step record: during the value recursion of step k the coefficient block still is step k + 1's (A_{k+1}'), then step
+        // k's record is landed from the registers that prefetched it
+        double cf[CFL];                                  // Jacobian coefficient block
+        double rs[Rec<C>::LEN_SWEEP - C::NC];            // the record behind it ([Hh | Hd | RQ | rx | R^ | ru | rd])
     };
     struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n], cf[2][CFL], rs[2][Rec<C>::LEN_SWEEP - C::NC], dxb[2][C::n]; };
     union { Bwd bw; Fwd fw; };
@@ -1632,8 +1639,9 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     for (int e = tid; e < (n + 1) * LDP; e += BT) B.Fx[e] = (e == n * LDP + n) ? 1.0 : 0.0;     // last row e_n: passes s_i through the product
     for (int e = tid; e < P * n * LDP; e += BT) B.Pm[e] = 0.0;
     int sing = 0;
-    // Step records travel HBM -> registers -> LDS one step ahead: requested at the top of step k for step k - 1, parked in LDS at the
-    // end of step k (coefficient block -> cf[(k - 1) & 1], the rest -> rs[(k - 1) & 1]), so the load latency hides behind a whole step
+    // Step records travel HBM -> registers -> LDS ahead of their use: step k - 1's record is requested at the tail of step k (after
+    // the gains went out) and landed in the single LDS copy right after the value recursion of step k - 1 -- the last reader of the
+    // previous coefficient block -- so the load latency hides behind the tail of one step and the recursion of the next
     // (PREF: only while a thread's share of a record is small -- the largest shapes, e.g. four quadrotors on one wavefront, would
     // run out of registers; they copy the record at the landing point instead)
 #ifndef ALG_DENSE_PREF
@@ -1653,26 +1661,23 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 const int e = tid + q * BT;
-                if (e < C::NC) B.cf[kk & 1][e] = pre[q];
-                else if (e < R::LEN_SWEEP) B.rs[kk & 1][e - C::NC] = pre[q];
+                if (e < C::NC) B.cf[e] = pre[q];
+                else if (e < R::LEN_SWEEP) B.rs[e - C::NC] = pre[q];
             }
         } else {
             const double* Rk = recs + (size_t)kk * R::LEN;
-            for (int e = tid; e < C::NC; e += BT) B.cf[kk & 1][e] = Rk[e];
-            for (int e = tid; e < R::LEN_SWEEP - C::NC; e += BT) B.rs[kk & 1][e] = Rk[C::NC + e];
+            for (int e = tid; e < C::NC; e += BT) B.cf[e] = Rk[e];
+            for (int e = tid; e < R::LEN_SWEEP - C::NC; e += BT) B.rs[e] = Rk[C::NC + e];
         }
     };
-    // (global-memory schedule of a step, as in the tile path: gfx9 counts loads and stores in one vmcnt, so the data requested one
-    // step ago is landed BEFORE this step's result stores are issued, and the next request follows them)
-    rec_load(N - 2); rec_store(N - 2);
-    if (N - 3 >= 0) rec_load(N - 3);
+    rec_load(N - 2);
     __syncthreads();
     ALG_PROF_DECL
     // ------------------------------------------------------------------ backward sweep
     for (int k = N - 2; k >= 0; k--) {
-        const double* Rl = B.rs[k & 1] - C::NC;                              // record offsets >= NC address the staged copy
-        const double* coefk = B.cf[k & 1];
-        const double* coefn = B.cf[(k + 1) & 1];                           // A_{k+1} (only read while k < N - 2)
+        const double* Rl = B.rs - C::NC;                                     // record offsets >= NC address the staged copy
+        const double* coefk = B.cf;                                        // step k's block -- after the landing point below
+        const double* coefn = B.cf;                                        // A_{k+1}: what the buffer holds during the value recursion
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         // ---- value recursion: [P_i | s_i] <- A_{k+1}' ([P_i | s_i] [[F f],[0 1]])
         if (k < N - 2) {
@@ -1733,6 +1738,10 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                 ALG_PROF(1)
             }
         }
+        // ---- landing point of step k's record (requested at the tail of step k + 1): the recursion above was the last reader of
+        // step k + 1's coefficients
+        rec_store(k);
+        __syncthreads();
         // ---- + [Q^_i | rx_i]: diagonal, position block, column n
         for (int e = tid; e < P * n; e += BT) {
             const int i = e / n, r = e % n;
@@ -1752,13 +1761,13 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         flat_loop<FU>(tid, BT, m * n, [&](int e) {
             const int c = e / n, col = e % n; const double* Pi = &B.Pm[(c % P) * n * LDP];
             return BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
-        }, [&](int e, double v) { B.V[e] = v; });
+        }, [&](int e, double v) { B.sv.V[e] = v; });
         flat_loop<FU>(tid, BT, P * n, [&](int e) {
             const double* Pr = &B.Pm[e * LDP];
             double a = Pr[n];
             for (int c = 0; c < n; c++) a += Pr[c] * Rl[R::RD + c];
             return a;
-        }, [&](int e, double v) { B.y[e] = v; });
+        }, [&](int e, double v) { B.sv.y[e] = v; });
         __syncthreads();
         ALG_PROF(3)
         // ---- [ W | V A_k | g ],  W = diag(R^) + V B,  g_c = ru_c + B[:,c]' y_i(c): three uniform loops (no divergent entry kinds)
@@ -1770,17 +1779,17 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             return v;
         };
         flat_loop<FU>(tid, BT, m * m, [&](int e) {
-            const int c = e / m, t = e % m; const double* Vc = &B.V[c * n];
+            const int c = e / m, t = e % m; const double* Vc = &B.sv.V[c * n];
             return ibr_mask(c, t, BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rl[R::RHAT + c] : 0.0));
-        }, [&](int e, double v) { B.Wm[(e / m) * WC + e % m] = v; });
+        }, [&](int e, double v) { B.sv.Wm[(e / m) * WC + e % m] = v; });
         flat_loop<FU>(tid, BT, m * n, [&](int e) {
-            const int c = e / n, col = e % n; const double* Vc = &B.V[c * n];
+            const int c = e / n, col = e % n; const double* Vc = &B.sv.V[c * n];
             return ibr_mask(c, m + col, (k >= 1) ? AT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, col) : 0.0);    // dx_1 = 0: A_0 never acts
-        }, [&](int e, double v) { B.Wm[(e / n) * WC + m + e % n] = v; });
+        }, [&](int e, double v) { B.sv.Wm[(e / n) * WC + m + e % n] = v; });
         flat_loop<1>(tid, BT, m, [&](int c) {
-            const double* yi = &B.y[(c % P) * n];
+            const double* yi = &B.sv.y[(c % P) * n];
             return ibr_mask(c, m + n, Rl[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c));
-        }, [&](int c, double v) { B.Wm[c * WC + m + n] = v; });
+        }, [&](int c, double v) { B.sv.Wm[c * WC + m + n] = v; });
         __syncthreads();
         ALG_PROF(4)
         // ---- partially pivoted Gauss-Jordan (pivot rule and row operations of the tile path's gj_solve_cols).  m <= 8: wavefront 0
@@ -1800,7 +1809,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                     for (int x = 0; x < XC; x++) {
                         const int t = lane + x * WAVE;
 #pragma unroll
-                        for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
+                        for (int r = 0; r < m; r++) col[x][r] = B.sv.Wm[r * WC + (t < WC ? t : 0)];
                     }
                     sg = gj_solve_cols_x<m, XC>(col);
                     // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
@@ -1809,7 +1818,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                         const int t = lane + x * WAVE;
                         if (t >= m && t < WC) {
 #pragma unroll
-                            for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                            for (int r = 0; r < m; r++) B.sv.Wm[r * WC + t] = col[x][r];
                         }
                     }
                     if (lane == 0) L.red[7] = (double)sg;
@@ -1824,18 +1833,18 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             for (int x = 0; x < XC; x++) {
                 const int t = tid + x * BT;
 #pragma unroll
-                for (int r = 0; r < m; r++) col[x][r] = B.Wm[r * WC + (t < WC ? t : 0)];
+                for (int r = 0; r < m; r++) col[x][r] = B.sv.Wm[r * WC + (t < WC ? t : 0)];
             }
 #pragma unroll
             for (int c = 0; c < m; c++) {
                 if (tid == c) {
 #pragma unroll
-                    for (int r = 0; r < m; r++) B.pcol[c & 1][r] = col[0][r];
+                    for (int r = 0; r < m; r++) B.sv.pcol[c & 1][r] = col[0][r];
                 }
                 __syncthreads();
                 double pc[m];
 #pragma unroll
-                for (int r = 0; r < m; r++) pc[r] = B.pcol[c & 1][r];
+                for (int r = 0; r < m; r++) pc[r] = B.sv.pcol[c & 1][r];
                 double best = fabs(pc[c]); int piv = c;
 #pragma unroll
                 for (int r = c + 1; r < m; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
@@ -1866,7 +1875,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                 const int t = tid + x * BT;
                 if (t >= m && t < WC) {
 #pragma unroll
-                    for (int r = 0; r < m; r++) B.Wm[r * WC + t] = col[x][r];
+                    for (int r = 0; r < m; r++) B.sv.Wm[r * WC + t] = col[x][r];
                 }
             }
             __syncthreads();
@@ -1877,12 +1886,11 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             flat_loop<FU>(tid, BT, n * LDP, [&](int e) {
                 const int r = e / LDP, col = e % LDP;
                 const double base = col < n ? A_entry<C>(coefk, dt, r, col) : Rl[R::RD + r];
-                return base + B_vec<C>(coefk, dt, [&](int c2) { return -B.Wm[c2 * WC + m + col]; }, r);
+                return base + B_vec<C>(coefk, dt, [&](int c2) { return -B.sv.Wm[c2 * WC + m + col]; }, r);
             }, [&](int e, double v) { B.Fx[e] = v; });
         }
-        if (k > 0) rec_store(k - 1);                                         // (1) land the record of step k - 1
-        for (int e = tid; e < NK; e += BT) { const int col = e / m, c = e % m; kg[(size_t)k * NK + e] = -B.Wm[c * WC + m + col]; }   // (2) gains out
-        if (k > 1) rec_load(k - 2);                                          // (3) request step k - 2
+        for (int e = tid; e < NK; e += BT) { const int col = e / m, c = e % m; kg[(size_t)k * NK + e] = -B.sv.Wm[c * WC + m + col]; }   // gains out
+        if (k > 0) rec_load(k - 1);                                          // then request step k - 1 (landed after its value recursion)
         __syncthreads();
         ALG_PROF(6)
     }

@@ -1629,6 +1629,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     constexpr int FU = ALG_DENSE_FU;                          // entries per thread and trip of the flat loops
     constexpr int TR = (n + 15) / 16, TC = (n + 1 + 15) / 16, KBN = (n + 1 + 3) / 4;
     static_assert(NWV <= 4, "cross-wavefront reduction slots");
+    static_assert(C::NW == 1 || C::NW >= 4, "every wavefront of the team runs this function (inner_iteration sends teams of two through wavefront 0 only)");
     using R = Rec<C>;
     const int N = phase_int(pr.N), tid = phase_lane(), lane = tid & 63, wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
     const double dt = phase_f64(pr.dt);

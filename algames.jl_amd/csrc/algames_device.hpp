@@ -1623,10 +1623,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     const Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, WC = DirLds<C>::WC, NK = m * (n + 1);
     constexpr int BT = C::NT, NWV = BT / WAVE;
-#ifndef ALG_DENSE_FU
-#define ALG_DENSE_FU 2
-#endif
-    constexpr int FU = ALG_DENSE_FU;                          // entries per thread and trip of the flat loops
+    constexpr int FU = 2;                                     // entries per thread and trip of the flat loops
     constexpr int TR = (n + 15) / 16, TC = (n + 1 + 15) / 16, KBN = (n + 1 + 3) / 4;
     static_assert(NWV <= 4, "cross-wavefront reduction slots");
     static_assert(C::NW == 1 || C::NW >= 4, "every wavefront of the team runs this function (inner_iteration sends teams of two through wavefront 0 only)");
@@ -1645,11 +1642,8 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     // previous coefficient block -- so the load latency hides behind the tail of one step and the recursion of the next
     // (PREF: only while a thread's share of a record is small -- the largest shapes, e.g. four quadrotors on one wavefront, would
     // run out of registers; they copy the record at the landing point instead)
-#ifndef ALG_DENSE_PREF
-#define ALG_DENSE_PREF 12
-#endif
     constexpr int RPT = (R::LEN_SWEEP + BT - 1) / BT;
-    constexpr bool PREF = RPT <= ALG_DENSE_PREF;
+    constexpr bool PREF = RPT <= 12;
     double pre[PREF ? RPT : 1];
     auto rec_load = [&](int kk) {
         if constexpr (PREF) {
@@ -1797,10 +1791,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         // alone, columns in registers, the pivot column by v_readlane (no LDS traffic, no barrier).  m > 8 (the 2 m scalar registers
         // of a readlane broadcast inside the fully unrolled elimination push those kernels into scratch): all threads, columns in
         // registers, the pivot column through LDS, one barrier per pivot.
-#ifndef ALG_DENSE_GJW
-#define ALG_DENSE_GJW 8
-#endif
-        if constexpr (m <= ALG_DENSE_GJW) {
+        if constexpr (m <= 8) {
                 constexpr int XC = (WC + WAVE - 1) / WAVE;
                 static_assert(m < WAVE && XC <= 2, "control system of the dense direction: at most 128 columns");
                 int sg = 0;

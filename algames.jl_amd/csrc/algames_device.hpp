@@ -1792,32 +1792,32 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         // of a readlane broadcast inside the fully unrolled elimination push those kernels into scratch): all threads, columns in
         // registers, the pivot column through LDS, one barrier per pivot.
         if constexpr (m <= 8) {
-                constexpr int XC = (WC + WAVE - 1) / WAVE;
-                static_assert(m < WAVE && XC <= 2, "control system of the dense direction: at most 128 columns");
-                int sg = 0;
-                if (wv == 0) {
-                    double col[XC][m];
+            constexpr int XC = (WC + WAVE - 1) / WAVE;
+            static_assert(m < WAVE && XC <= 2, "control system of the dense direction: at most 128 columns");
+            int sg = 0;
+            if (wv == 0) {
+                double col[XC][m];
 #pragma unroll
-                    for (int x = 0; x < XC; x++) {
-                        const int t = lane + x * WAVE;
+                for (int x = 0; x < XC; x++) {
+                    const int t = lane + x * WAVE;
 #pragma unroll
-                        for (int r = 0; r < m; r++) col[x][r] = B.sv.Wm[r * WC + (t < WC ? t : 0)];
-                    }
-                    sg = gj_solve_cols_x<m, XC>(col);
-                    // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
-#pragma unroll
-                    for (int x = 0; x < XC; x++) {
-                        const int t = lane + x * WAVE;
-                        if (t >= m && t < WC) {
-#pragma unroll
-                            for (int r = 0; r < m; r++) B.sv.Wm[r * WC + t] = col[x][r];
-                        }
-                    }
-                    if (lane == 0) L.red[7] = (double)sg;
+                    for (int r = 0; r < m; r++) col[x][r] = B.sv.Wm[r * WC + (t < WC ? t : 0)];
                 }
-                __syncthreads();
-                if constexpr (NWV > 1) sg = (int)L.red[7];
-                sing |= __builtin_amdgcn_readfirstlane(sg);
+                sg = gj_solve_cols_x<m, XC>(col);
+                // solved right-hand-side columns back to LDS (the gains and the closed-loop rows read them)
+#pragma unroll
+                for (int x = 0; x < XC; x++) {
+                    const int t = lane + x * WAVE;
+                    if (t >= m && t < WC) {
+#pragma unroll
+                        for (int r = 0; r < m; r++) B.sv.Wm[r * WC + t] = col[x][r];
+                    }
+                }
+                if (lane == 0) L.red[7] = (double)sg;
+            }
+            __syncthreads();
+            if constexpr (NWV > 1) sg = (int)L.red[7];
+            sing |= __builtin_amdgcn_readfirstlane(sg);
         } else {
             constexpr int XC = (WC + BT - 1) / BT;
             double col[XC][m];

@@ -86,6 +86,7 @@ SIGNATURES = {
     "add_collision_avoidance": (C.c_int, [_P, _D]),
     "add_control_bound": (C.c_int, [_P, _D, _D]),
     "set_bicycle": (C.c_int, [_P, C.c_double, C.c_double]),
+    "set_quadrotor": (C.c_int, [_P, C.c_double]),
     "add_state_bound": (C.c_int, [_P, C.c_int32, _D, _D]),
     "add_wall_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D, _D, _D]),
     "add_circle_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
@@ -272,6 +273,9 @@ class Batch:
 
     def set_bicycle(self, lf, lr):
         self.lib.check(self.lib.set_bicycle(self.h, float(lf), float(lr)))
+
+    def set_quadrotor(self, mass):
+        self.lib.check(self.lib.set_quadrotor(self.h, float(mass)))
 
     def add_state_bound(self, player, x_max, x_min):
         self.lib.check(self.lib.add_state_bound(self.h, int(player), _dptr(_f64(x_max, (self.n,))), _dptr(_f64(x_min, (self.n,)))))

@@ -58,6 +58,7 @@ struct Params {
     int ext, has_sb, nwall, ncirc, sb_len, wall_len, circ_len;
     int nwall3, ncyl, wall3_len, cyl_len, ca_dim;   // 3-D half (Cfg::PD == 3 only): Wall3D, Cylinder, spherical collision avoidance (ca_dim = 3)
     double lf, lr;          // BicycleGame(lf, lr), bicycle.jl:15
+    double qmass;           // QuadrotorGame(; mass), quadrotor.jl:20 (0.5 unless alg_set_quadrotor)
     // per-player wall / circle sets (add_wall_constraint!(game_con, i, walls), add_circle_constraint!(game_con, i, ...),
     // constraints_methods.jl:121-139, 161-187): bit w of wall_mask[i] = table entry w constrains player i.  A row whose bit is
     // clear evaluates to c = 0 with a zero Jacobian -- exactly inert in the AL terms, the violations and the dual update.
@@ -252,8 +253,8 @@ __device__ __forceinline__ Jet operator+(const Jet& a, double s) { return Jet{a.
 __device__ __forceinline__ Jet max0(const Jet& a) { return a.v > 0.0 ? a : Jet{0.0, 0.0}; }      // ForwardDiff: derivative of the selected branch
 __device__ __forceinline__ double max0(double a) { return a > 0.0 ? a : 0.0; }
 template <class T>
-__device__ __forceinline__ void quad_f(const T (&x)[12], const T (&u)[4], T (&xd)[12]) {
-    const double mass = 0.5, J0 = 0.0023, J1 = 0.0023, J2 = 0.004, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
+__device__ __forceinline__ void quad_f(const T (&x)[12], const T (&u)[4], double mass, T (&xd)[12]) {
+    const double J0 = 0.0023, J1 = 0.0023, J2 = 0.004, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
     const T g0 = x[3], g1 = x[4], g2 = x[5], w0 = x[9], w1 = x[10], w2 = x[11];
     const T F1 = max0(u[0] * kf), F2 = max0(u[1] * kf), F3 = max0(u[2] * kf), F4 = max0(u[3] * kf);
     const T Ft = F1 + F2 + F3 + F4;
@@ -278,26 +279,26 @@ __device__ __forceinline__ void quad_f(const T (&x)[12], const T (&u)[4], T (&xd
 }
 // RobotDynamics 0.3.1 RK2 (explicit midpoint) of one quadrotor
 template <class T>
-__device__ __forceinline__ void quad_rk2(const T (&x)[12], const T (&u)[4], double dt, T (&xn)[12]) {
+__device__ __forceinline__ void quad_rk2(const T (&x)[12], const T (&u)[4], double mass, double dt, T (&xn)[12]) {
     T k[12], xm[12];
-    quad_f(x, u, k);
+    quad_f(x, u, mass, k);
 #pragma unroll
     for (int j = 0; j < 12; j++) xm[j] = x[j] + k[j] * (dt * 0.5);
-    quad_f(xm, u, k);
+    quad_f(xm, u, mass, k);
 #pragma unroll
     for (int j = 0; j < 12; j++) xn[j] = x[j] + k[j] * dt;
 }
 
 // RobotDynamics 0.3.1 RK3 of one quadrotor (rollout!, solver_methods.jl:17)
-__device__ __forceinline__ void quad_rk3(const double (&x)[12], const double (&u)[4], double dt, double (&xn)[12]) {
+__device__ __forceinline__ void quad_rk3(const double (&x)[12], const double (&u)[4], double mass, double dt, double (&xn)[12]) {
     double k1[12], k2[12], k3[12], t[12];
-    quad_f(x, u, k1);
+    quad_f(x, u, mass, k1);
 #pragma unroll
     for (int j = 0; j < 12; j++) { k1[j] *= dt; t[j] = x[j] + k1[j] / 2; }
-    quad_f(t, u, k2);
+    quad_f(t, u, mass, k2);
 #pragma unroll
     for (int j = 0; j < 12; j++) { k2[j] *= dt; t[j] = x[j] - k1[j] + 2 * k2[j]; }
-    quad_f(t, u, k3);
+    quad_f(t, u, mass, k3);
 #pragma unroll
     for (int j = 0; j < 12; j++) { k3[j] *= dt; xn[j] = x[j] + (k1[j] + 4 * k2[j] + k3[j]) / 6; }
 }
@@ -334,7 +335,7 @@ __device__ __forceinline__ void model_player(CPR pr, int i, const double* x, con
         for (int j = 0; j < 12; j++) xi[j] = x[i + j * C::P];
 #pragma unroll
         for (int j = 0; j < 4; j++) ui[j] = u[i + j * C::P];
-        quad_rk2(xi, ui, dt, xo);
+        quad_rk2(xi, ui, pr.qmass, dt, xo);
 #pragma unroll
         for (int j = 0; j < 12; j++) xn[j] = xo[j];
         coef[0] = coef[1] = coef[2] = coef[3] = 0.0;
@@ -808,6 +809,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
         // quadrotor: work item = (knot k, player i, seed direction c of the player's 12 states + 4 rotor commands): column c of
         // [A_i | B_i] = d RK2 / d (x_i, u_i)[c] by forward-mode differentiation along e_c; the item with c = 0 also leaves the
         // RK2 value (the dyn rows of phase B read it)
+        const double qmass = phase_f64(pr.qmass);
         for (int e = lane; e < (N - 1) * P * 16; e += C::NT) {
             const int c = e & 15, i = (e >> 4) % P, k = (e >> 4) / P;
             const double* sk = zstate<C>(z, k);
@@ -816,7 +818,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             for (int j = 0; j < 12; j++) xj[j] = Jet{sk[i + j * P], c == j ? 1.0 : 0.0};
 #pragma unroll
             for (int j = 0; j < 4; j++) uj[j] = Jet{z[n + hu<C>(k, i) + j], c == 12 + j ? 1.0 : 0.0};
-            quad_rk2(xj, uj, dt, xo);
+            quad_rk2(xj, uj, qmass, dt, xo);
             double* __restrict__ rc = G.rec(pr) + (size_t)k * R::LEN + R::COEF + i * C::QS;
             const int o = c < 12 ? C::QA + c : C::QB + (c - 12), ld = c < 12 ? 12 : 4;
 #pragma unroll
@@ -2720,7 +2722,7 @@ __device__ __forceinline__ void rollout(CPR pr, double* z) {
             for (int k = 0; k < pr.N - 1; k++) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) ui[j] = z[n + hu<C>(k, lane) + j];
-                quad_rk3(xi, ui, pr.dt, xo);
+                quad_rk3(xi, ui, pr.qmass, pr.dt, xo);
 #pragma unroll
                 for (int j = 0; j < 12; j++) { xi[j] = xo[j]; z[n + hx<C>(k) + lane + j * P] = xo[j]; }
             }

@@ -47,6 +47,7 @@ bool fill_dims(const alg_desc& a, Params& p) {
     } else if (a.model == ALG_MODEL_QUADROTOR) {                          // quadrotor.jl:20-46
         if (a.p > 4) return false;
         p.d = 3; p.n = 12 * p.p; p.m = 4 * p.p; p.mi = 4; p.ni = 12;
+        p.qmass = 0.5;                                                   // QuadrotorGame default, quadrotor.jl:20
     } else return false;
     p.S = p.n * p.p * (p.N - 1) + p.m * (p.N - 1) + p.n * (p.N - 1);     // problem_size.jl:22
     p.b = p.n + p.m + p.p * p.n;
@@ -498,6 +499,12 @@ static int ext_commit(Handle* hd) {
     hipLaunchKernelGGL(k_reset_con, dim3(p.B), dim3(WAVE), 0, hd->stream, hd->pr);
     if ((rc = launch_check("k_reset_con"))) return rc;
     return sync(hd);
+}
+int alg_set_quadrotor(alg_handle* h, double mass) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_set_quadrotor: null handle");
+    if (H->pr.model != ALG_MODEL_QUADROTOR) return fail(ALG_ERR_ARG, "alg_set_quadrotor: not a quadrotor model");
+    if (!(mass > 0)) return fail(ALG_ERR_ARG, "alg_set_quadrotor: mass must be positive");
+    H->pr.qmass = mass; return ALG_OK;
 }
 int alg_set_bicycle(alg_handle* h, double lf, double lr) {
     if (!h) return fail(ALG_ERR_ARG, "alg_set_bicycle: null handle");

@@ -140,7 +140,7 @@ __device__ __forceinline__ void mpc_advance(CPR pr, const Game& G) {
             for (int j = 0; j < 12; j++) xi[j] = G.z(0)[lane + j * C::P];
 #pragma unroll
             for (int j = 0; j < 4; j++) ui[j] = G.z(0)[C::n + hu<C>(0, lane) + j];
-            quad_rk2(xi, ui, pr.dt, xo);
+            quad_rk2(xi, ui, pr.qmass, pr.dt, xo);
 #pragma unroll
             for (int j = 0; j < 12; j++) { const int a = lane + j * C::P; G.x0w(pr)[a] = xo[j]; G.z(0)[a] = xo[j]; G.z(1)[a] = xo[j]; }
         }

@@ -90,8 +90,8 @@ class QuadrotorGame(AbstractGameModel):
 
     def __init__(self, p=2, mass=0.5):
         assert p <= 4                      # quadrotor.jl:22
-        if mass != 0.5:
-            raise AlgamesError("QuadrotorGame: only the default mass = 0.5 is bound")
+        if not mass > 0:
+            raise AlgamesError("QuadrotorGame: mass must be positive")
         self.p, self.d, self.mass = p, 3, float(mass)
         self.n, self.m = 12 * p, 4 * p
         self.pu = [[i + (j - 1) * p for j in range(1, 5)] for i in range(1, p + 1)]
@@ -587,6 +587,8 @@ class GameProblem:
         self.batch = Batch(lib, model.model_id, model.p, N, dt, self.B, d=model.d, device=device)
         if isinstance(model, BicycleGame):
             self.batch.set_bicycle(model.lf, model.lr)
+        if isinstance(model, QuadrotorGame) and model.mass != 0.5:
+            self.batch.set_quadrotor(model.mass)
         self.batch.set_x0(self.x0)
         self.batch.set_lqr(game_obj.Qdiag, game_obj.Rdiag, game_obj.xf, game_obj.uf)
         if game_obj.collision_radius is not None:

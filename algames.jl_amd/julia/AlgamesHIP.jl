@@ -55,7 +55,7 @@ check(rc) = rc == 0 || error(unsafe_string(ccall((:alg_last_error, LIB), Cstring
 model_id(::DoubleIntegratorGame) = Int32(0)
 model_id(::UnicycleGame) = Int32(1)
 model_id(::BicycleGame) = Int32(2)
-model_id(::QuadrotorGame) = Int32(3)      # src/dynamics/quadrotor.jl (the constructor's constants; mass = 0.5 only)
+model_id(::QuadrotorGame) = Int32(3)      # src/dynamics/quadrotor.jl (the constructor's constants; mass through alg_set_quadrotor)
 
 function abi_options(o::Options)
     ax = ntuple(i -> i <= length(o.αx_dual) ? Float64(o.αx_dual[i]) : 1.0, 10)
@@ -141,6 +141,8 @@ function setup!(bp::BatchedGameProblem, device)
     end
     if prob.model isa BicycleGame
         check(ccall((:alg_set_bicycle, LIB), Cint, (Ptr{Cvoid}, Float64, Float64), bp.h, prob.model.lf, prob.model.lr))
+    elseif prob.model isa QuadrotorGame
+        check(ccall((:alg_set_quadrotor, LIB), Cint, (Ptr{Cvoid}, Float64), bp.h, prob.model.mass))
     end
     pts(a, b, c) = Vector{Float64}(vec(permutedims(hcat(Vector(a), Vector(b), Vector(c)))))      # n x 3, row-major
     for i in 1:p, cv in prob.game_con.state_conval[i]

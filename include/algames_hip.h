@@ -59,7 +59,7 @@ extern "C" {
 #define ALG_MODEL_UNICYCLE 1
 #define ALG_MODEL_BICYCLE 2             /* src/dynamics/bicycle.jl:2-41 (lf = lr = 0.05 unless alg_set_bicycle) */
 #define ALG_MODEL_QUADROTOR 3           /* src/dynamics/quadrotor.jl:3-206: n = 12 p, m = 4 p; per player [x(3) | MRP attitude (3) | v(3) | omega(3)],
-                                           rotor commands w1..w4; mass 0.5, J = diag(0.0023, 0.0023, 0.004), g = (0, 0, -9.81),
+                                           rotor commands w1..w4; mass 0.5 (alg_set_quadrotor), J = diag(0.0023, 0.0023, 0.004), g = (0, 0, -9.81),
                                            motor_dist 0.175, kf 1.245, km 1.0 (the constructor's values) */
 #define ALG_MAX_WALLS 8
 #define ALG_MAX_CIRCLES 8
@@ -183,6 +183,9 @@ int alg_add_control_bound(alg_handle* h, const double* u_max /*m*/, const double
  * (it matters only when the first solve runs with dual_reset = false). */
 /* BicycleGame(p; lf, lr) parameters (bicycle.jl:15); only for ALG_MODEL_BICYCLE */
 int alg_set_bicycle(alg_handle* h, double lf, double lr);
+/* QuadrotorGame(; p, mass) (quadrotor.jl:20-46): the constructor's one parameter (default 0.5 kg; inertia, gravity, motor_dist, kf, km are
+ * fixed there); only for ALG_MODEL_QUADROTOR */
+int alg_set_quadrotor(alg_handle* h, double mass);
 /* add_state_bound!(game_con, i, x_max, x_min) (constraints_methods.jl:86-98; state_bound_constraint.jl): bounds on the joint
  * state (n each, +-inf allowed) attached to player `player` (0-based), knots 2..N */
 int alg_add_state_bound(alg_handle* h, int32_t player, const double* x_max /*n*/, const double* x_min /*n*/);

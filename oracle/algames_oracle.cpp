@@ -54,6 +54,7 @@ struct Dims {
     int nwall = 0, ncirc = 0, has_sb = 0, sb_len = 0, wall_len = 0, circ_len = 0;      // extended constraints
     int nwall3 = 0, ncyl = 0, wall3_len = 0, cyl_len = 0, ca_dim = 2;                  // 3-D half: Wall3D, Cylinder, spherical collision avoidance
     double dt = 0, lf = 0.05, lr = 0.05;                                              // BicycleGame(lf, lr), bicycle.jl:15
+    double qmass = 0.5;                                                               // QuadrotorGame(; mass), quadrotor.jl:20
     // src/struct/problem_size.jl:18-35 ; src/dynamics/double_integrator.jl:13-25 ; unicycle.jl:14-25
     bool init(const alg_desc& a) {
         model = a.model; p = a.p; N = a.N; dt = a.dt;
@@ -156,7 +157,7 @@ void dynamics(const Dims& D, const T* x, const T* u, T* xd) {
         // Rotations.jl 1.0 MRP [restated from the published source; parity unpinned]: rotation matrix of g (via the unit quaternion
         // ((1 - |g|^2), 2 g) / (1 + |g|^2)), kinematics(g, w) = 1/4 ((1 - |g|^2) w + 2 g x w + 2 (g . w) g)
         const int P = D.p;
-        const double mass = 0.5, Jd[3] = {0.0023, 0.0023, 0.004}, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
+        const double mass = D.qmass, Jd[3] = {0.0023, 0.0023, 0.004}, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
         for (int i = 0; i < P; i++) {
             const T g0 = x[3 * P + i], g1 = x[4 * P + i], g2 = x[5 * P + i];
             const T w0 = x[9 * P + i], w1 = x[10 * P + i], w2 = x[11 * P + i];
@@ -1187,6 +1188,11 @@ static void orc_resize_con(Handle* hd) {
     hd->sh.D.recount();
     for (Game& g : hd->g) { g.lam.assign(hd->sh.D.con_len, 0.0); g.mu.assign(hd->sh.D.con_len, hd->sh.opt.rho_0); g.vals.assign(hd->sh.D.con_len, 0.0); }
 }
+int orc_set_quadrotor(alg_handle* h, double mass) {
+    if (H->sh.D.model != ALG_MODEL_QUADROTOR) return fail(ALG_ERR_ARG, "orc_set_quadrotor: not a quadrotor model");
+    if (!(mass > 0)) return fail(ALG_ERR_ARG, "orc_set_quadrotor: mass must be positive");
+    H->sh.D.qmass = mass; return ALG_OK;
+}
 int orc_set_bicycle(alg_handle* h, double lf, double lr) {
     if (H->sh.D.model != ALG_MODEL_BICYCLE) return fail(ALG_ERR_ARG, "orc_set_bicycle: not a bicycle model");
     if (!(lr > 0) || !(lf >= 0)) return fail(ALG_ERR_ARG, "orc_set_bicycle: bad lengths");
@@ -1455,6 +1461,15 @@ int orc_set_threads(int nthreads) {
 // ---- fine-grained pieces exposed for the known-answer tests (Appendix B) ----------------------
 int orc_kat_dynamics(const alg_desc* d, const double* x, const double* u, double* xdot, double* x_rk2, double* x_rk3, double* jac_rk2) {
     Dims D; if (!D.init(*d)) return fail(ALG_ERR_ARG, "bad descriptor");
+    if (xdot) dynamics(D, x, u, xdot);
+    if (x_rk2) rk2(D, x, u, x_rk2);
+    if (x_rk3) rk3(D, x, u, x_rk3);
+    if (jac_rk2) rk2_jacobian(D, x, u, jac_rk2);
+    return ALG_OK;
+}
+// the same on a handle's model (its parameters: bicycle lengths, quadrotor mass)
+int orc_kat_dynamics_h(alg_handle* h, const double* x, const double* u, double* xdot, double* x_rk2, double* x_rk3, double* jac_rk2) {
+    const Dims& D = H->sh.D;
     if (xdot) dynamics(D, x, u, xdot);
     if (x_rk2) rk2(D, x, u, x_rk2);
     if (x_rk3) rk3(D, x, u, x_rk3);

@@ -34,6 +34,8 @@ def lib():
         d = _lib.dll
         d.orc_kat_dynamics.restype = C.c_int
         d.orc_kat_dynamics.argtypes = [C.POINTER(alg_desc)] + [C.POINTER(C.c_double)] * 6
+        d.orc_kat_dynamics_h.restype = C.c_int
+        d.orc_kat_dynamics_h.argtypes = [_P] + [C.POINTER(C.c_double)] * 6
         d.orc_kat_cost.restype = C.c_int
         d.orc_kat_cost.argtypes = [_P, C.c_int32, C.c_int32, C.c_int32] + [C.POINTER(C.c_double)] * 5
         d.orc_kat_collision_cost.restype = C.c_double
@@ -60,7 +62,7 @@ class OracleBatch(Batch):
         x, u = _f64(x, (self.n,)), _f64(u, (self.m,))
         xd, x2, x3 = np.empty(self.n), np.empty(self.n), np.empty(self.n)
         J = np.empty((self.n, self.n + self.m))
-        self.lib.check(self.lib.dll.orc_kat_dynamics(C.byref(self.desc), _dptr(x), _dptr(u), _dptr(xd), _dptr(x2), _dptr(x3), _dptr(J)))
+        self.lib.check(self.lib.dll.orc_kat_dynamics_h(self.h, _dptr(x), _dptr(u), _dptr(xd), _dptr(x2), _dptr(x3), _dptr(J)))
         return xd, x2, x3, J
 
     def kat_cost(self, i, k, x, u, game=0):

@@ -195,6 +195,22 @@ def test_ibr_and_mpc_parity_quadrotor(alg, orc):
     assert np.array_equal(is_, ig) and np.abs(ss - sg).max() < 1e-9
 
 
+def test_quadrotor_mass_parameter_parity(alg, orc):
+    """alg_set_quadrotor (QuadrotorGame(; mass), quadrotor.jl:20): residual, Jacobian and direction with a non-default mass."""
+    g, o = _pair(alg, orc, 2, 6, B=2, seed=21)
+    g.set_quadrotor(0.8); o.set_quadrotor(0.8)
+    rg, _ = g.residual(0, 0.0); ro, _ = o.residual(0, 0.0)
+    assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max())
+    g2, o2 = _pair(alg, orc, 2, 6, B=2, seed=21)
+    assert np.abs(ro - o2.residual(0, 0.0)[0]).max() > 1e-3                     # the mass matters
+    Jg, Jo = g.residual_jacobian(1e-3), o.residual_jacobian(1e-3)
+    assert np.abs(Jg - Jo).max() <= 1e-12 * np.abs(Jo).max()
+    dg, sg = g.newton_direction(1e-3); do, so = o.newton_direction(1e-3)
+    assert np.all(sg == 0) and (np.abs(dg - do) / np.abs(do).max(axis=1, keepdims=True)).max() < 1e-9
+    ig, io = g.newton_step(1, 1), o.newton_step(1, 1)
+    assert np.array_equal(ig["ls_j"], io["ls_j"]) and np.abs(g.get_traj(0) - o.get_traj(0)).max() <= 1e-9 * max(1.0, np.abs(o.get_traj(0)).max())
+
+
 def test_quadrotor_rejections(alg):
     """quadrotor.jl:22: at most four players; anything else is refused with a message."""
     with pytest.raises(alg.AlgamesError):

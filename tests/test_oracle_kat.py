@@ -221,11 +221,11 @@ def test_quadrotor_index_literals(alg):
         alg.QuadrotorGame(p=5)                                   # quadrotor.jl:22
 
 
-def _quad_f(x, u, P):
+def _quad_f(x, u, P, mass=0.5):
     """src/dynamics/quadrotor.jl:49-121 restated independently: attitude through the unit quaternion of the MRP
     (Rotations.jl 1.0: q = ((1 - |g|^2), 2 g) / (1 + |g|^2)) and the generic quaternion rotation matrix, MRP rate through
     B(g) w / 4 with B = (1 - |g|^2) I + 2 [g x] + 2 g g'."""
-    mass, J, grav, L, kf, km = 0.5, np.array([0.0023, 0.0023, 0.004]), np.array([0, 0, -9.81]), 0.175, 1.245, 1.0
+    J, grav, L, kf, km = np.array([0.0023, 0.0023, 0.004]), np.array([0, 0, -9.81]), 0.175, 1.245, 1.0
     xd = np.zeros_like(x)
     for i in range(P):
         g = x[[3 * P + i, 4 * P + i, 5 * P + i]]; v = x[[6 * P + i, 7 * P + i, 8 * P + i]]; w = x[[9 * P + i, 10 * P + i, 11 * P + i]]
@@ -289,6 +289,25 @@ def test_quadrotor_game_end_to_end_on_the_oracle(alg, orc):
     assert np.abs(X[:, -1, 4:6] - 0.5).max() < 0.15                              # height held
     with pytest.raises(alg.AlgamesError):
         alg.velocity_index(prob.model, 1)                                        # velocity_constraint.jl:30-43: no method for this model
+
+
+def test_quadrotor_mass_parameter(alg, orc):
+    # QuadrotorGame(; p, mass) (quadrotor.jl:20): the mass enters vdot = g + R F / m only
+    rng = np.random.default_rng(77)
+    b = orc.OracleBatch(QUAD, 2, 6, 0.05, 1)
+    b.set_quadrotor(0.8)
+    x, u = rng.random(b.n) - 0.3, rng.random(b.m)
+    xd = b.kat_dynamics(x, u)[0]
+    assert np.allclose(xd, _quad_f(x, u, 2, mass=0.8), rtol=1e-13, atol=1e-13)
+    assert np.abs(xd - _quad_f(x, u, 2, mass=0.5))[12:18].max() > 1e-3          # the velocity rows really changed
+    with pytest.raises(alg.AlgamesError):
+        b.set_quadrotor(0.0)
+    with pytest.raises(alg.AlgamesError):
+        orc.OracleBatch(UNI, 2, 6, 0.05, 1).set_quadrotor(0.8)
+    model = alg.QuadrotorGame(p=2, mass=0.8)
+    assert model.mass == 0.8
+    with pytest.raises(alg.AlgamesError):
+        alg.QuadrotorGame(p=2, mass=-1.0)
 
 
 def test_quadrotor_rotation_is_orthogonal():

@@ -238,7 +238,21 @@ __global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(P
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 1)                  \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 1)                  \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 1)
-#define ALG_CFGS_DENSE(X) ALG_CFGS_QUAD(X) ALG_CFGS_QUAD_EXT(X) ALG_CFGS_DI3D(X)
+// Five and six players (n = 20 / 24: dense Newton direction; algames_p5.hip, algames_p6.hip).  The reference itself caps p at 10 (options.jl:68)
+#define ALG_CFGS_P5(X)                                      \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 5, 2, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 5, 2, 1)                  \
+    X(ALG_MODEL_UNICYCLE, 5, 2, 0)                           \
+    X(ALG_MODEL_UNICYCLE, 5, 2, 1)                           \
+    X(ALG_MODEL_BICYCLE, 5, 2, 1)
+#define ALG_CFGS_P6(X)                                      \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 6, 2, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 6, 2, 1)                  \
+    X(ALG_MODEL_UNICYCLE, 6, 2, 0)                           \
+    X(ALG_MODEL_UNICYCLE, 6, 2, 1)                           \
+    X(ALG_MODEL_BICYCLE, 6, 2, 1)
+#define ALG_CFGS_P56(X) ALG_CFGS_P5(X) ALG_CFGS_P6(X)
+#define ALG_CFGS_DENSE(X) ALG_CFGS_QUAD(X) ALG_CFGS_QUAD_EXT(X) ALG_CFGS_DI3D(X) ALG_CFGS_P56(X)
 #define ALG_CFGS_EXT(X) ALG_CFGS_EXT_DI(X) ALG_CFGS_EXT_UNI(X) ALG_CFGS_EXT_BIC(X) ALG_CFGS_EXT_DI3(X)
 
 // every kernel of one instantiation; PREFIX is `template` (definition) or `extern template` (declaration)

@@ -10,13 +10,13 @@ pytestmark = pytest.mark.gpu
 DI, UNI, BIC = 0, 1, 2
 
 
-def _random_pair(alg, orc, rng, ext, d3=False, force=None):
+def _random_pair(alg, orc, rng, ext, d3=False, force=None, force_d3=True):
     model = DI if d3 else int(rng.choice([DI, UNI, BIC] if ext else [DI, UNI]))
     p = 2 if d3 else int(rng.integers(1, 5))
     N = int(rng.integers(2, 16))
     if force is not None:                                      # (model, p) of a dense-direction family: three position dimensions
         model, p = force
-        d3 = True
+        d3 = force_d3
         N = min(N, 9)
     B = 3
     dt = float(rng.choice([0.05, 0.1, 0.2]))
@@ -103,6 +103,15 @@ def test_fuzz_extended_instantiations(alg, orc, seed):
 
 
 DENSE_FAMILIES = [(DI, 1), (DI, 3), (DI, 4), (3, 1), (3, 2), (3, 3), (3, 4)]      # DoubleIntegrator d = 3 / QuadrotorGame (model id 3)
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_fuzz_five_and_six_players(alg, orc, seed):
+    """DoubleIntegrator d = 2, Unicycle, Bicycle with five and six players (dense Newton direction), base or extended set."""
+    rng = np.random.default_rng(17000 + seed)
+    model, p = [(DI, 5), (DI, 6), (UNI, 5), (UNI, 6), (BIC, 5), (BIC, 6)][seed % 6]
+    g, o, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool(seed % 2)), force=(model, p), force_d3=False)
+    _compare_solve(g, o, tag)
 
 
 @pytest.mark.parametrize("seed", range(28))

@@ -15,6 +15,8 @@ DI, UNI = 0, 1
 CASES = [  # (model, p, d, N)
     (DI, 1, 2, 6), (DI, 2, 2, 20), (DI, 3, 2, 12), (DI, 4, 2, 7), (DI, 2, 3, 8),
     (UNI, 1, 2, 9), (UNI, 2, 2, 20), (UNI, 3, 2, 10), (UNI, 4, 2, 8),
+    # outside the 16 x 16 tile (dense Newton direction): five / six players, DoubleIntegrator d = 3 with p = 1, 3, 4
+    (DI, 5, 2, 6), (DI, 6, 2, 5), (UNI, 5, 2, 6), (UNI, 6, 2, 5), (DI, 1, 3, 7), (DI, 3, 3, 6), (DI, 4, 3, 5),
 ]
 
 

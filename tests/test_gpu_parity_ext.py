@@ -10,6 +10,8 @@ DI, UNI, BIC = 0, 1, 2
 CASES = [  # (model, p, N)
     (DI, 1, 6), (DI, 3, 10), (DI, 4, 6), (UNI, 1, 7), (UNI, 2, 12), (UNI, 3, 9), (UNI, 4, 6),
     (BIC, 1, 8), (BIC, 2, 12), (BIC, 3, 10), (BIC, 4, 6),
+    # five and six players (n = 20 / 24: dense Newton direction, algames_p5.hip / algames_p6.hip)
+    (DI, 5, 5), (DI, 6, 4), (UNI, 5, 5), (UNI, 6, 4), (BIC, 5, 5), (BIC, 6, 4),
 ]
 ALL = ("cost", "avoid", "ctl", "sb", "wall", "circ")
 
@@ -222,7 +224,7 @@ def test_reference_constrained_unicycle_with_circles_on_gpu(alg):
 
 def test_extended_constraints_unsupported_configuration_fails_loudly(alg):
     with pytest.raises(alg.AlgamesError):
-        alg.Batch(alg.hip_lib(), DI, 5, 6, 0.1, 1, d=2)         # five players: no kernel instantiation at all
+        alg.Batch(alg.hip_lib(), DI, 7, 6, 0.1, 1, d=2)         # seven players: no kernel instantiation at all
 
 
 def _guards_ok(batch):
@@ -236,7 +238,8 @@ def _guards_ok(batch):
 # every compiled kernel instantiation (ALG_CFGS_BASE / ALG_CFGS_EXT of algames_kernels.hpp): (model, p, N, extended constraints)
 ALL_INSTANTIATIONS = ([(DI, p, N, False) for p, N in ((1, 5), (2, 13), (3, 40), (4, 9))] + [(UNI, p, N, False) for p, N in ((1, 6), (2, 12), (3, 30), (4, 50))]
                       + [(DI, p, N, True) for p, N in ((1, 7), (2, 9), (3, 12), (4, 6))] + [(UNI, p, N, True) for p, N in ((1, 9), (2, 8), (3, 11), (4, 7))]
-                      + [(BIC, p, N, True) for p, N in ((1, 8), (2, 7), (3, 20), (4, 11))])
+                      + [(BIC, p, N, True) for p, N in ((1, 8), (2, 7), (3, 20), (4, 11))]
+                      + [(DI, 5, 7, False), (DI, 6, 5, True), (UNI, 5, 6, True), (UNI, 6, 5, False), (BIC, 5, 6, True), (BIC, 6, 5, True)])
 
 
 @pytest.mark.timeout(120)

@@ -103,13 +103,33 @@ def test_fuzz_extended_instantiations(alg, orc, seed):
 
 
 DENSE_FAMILIES = [(DI, 1), (DI, 3), (DI, 4), (3, 1), (3, 2), (3, 3), (3, 4)]      # DoubleIntegrator d = 3 / QuadrotorGame (model id 3)
+P56_FAMILIES = [(DI, 5), (DI, 6), (UNI, 5), (UNI, 6), (BIC, 5), (BIC, 6)]
+
+
+# Three of the 25 (of 480) cases of the long five- / six-player run (scratch/fuzz_long_p56.py) that ended outside the tolerances.  These
+# random many-player problems (thirty ordered pairs inside the collision-cost radius, control costs down to 1e-4) diverge; the oracle
+# ITSELF amplifies a 1e-13 relative change of x0 to 1e-3 .. 1e-7 in exactly the games that differ (scratch/fuzz_sensitivity.py) and
+# by ~1 on ordinary seeds.
+@pytest.mark.parametrize("seed", [500258, 500262, 500365])
+def test_fuzz_five_and_six_players_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
+    rng = np.random.default_rng(seed)
+    model, p = P56_FAMILIES[(seed - 500000) % 6]
+    g, o, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool((seed - 500000) % 2)), force=(model, p), force_d3=False)
+    sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
+    assert np.array_equal(sg["status"], so["status"]), tag
+    for game in range(g.B):
+        hg, ho = g.get_history(game), o.get_history(game)
+        for rec in range(min(3, len(hg), len(ho))):                  # the first records: rounding has not been amplified yet
+            for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+                assert abs(hg[f][rec] - ho[f][rec]) <= 1e-9 * abs(ho[f][rec]) + 1e-12, (tag, game, rec, f)
+            assert hg["ls_j"][rec] == ho["ls_j"][rec] and hg["alpha"][rec] == ho["alpha"][rec], (tag, game, rec)
 
 
 @pytest.mark.parametrize("seed", range(18))
 def test_fuzz_five_and_six_players(alg, orc, seed):
     """DoubleIntegrator d = 2, Unicycle, Bicycle with five and six players (dense Newton direction), base or extended set."""
     rng = np.random.default_rng(17000 + seed)
-    model, p = [(DI, 5), (DI, 6), (UNI, 5), (UNI, 6), (BIC, 5), (BIC, 6)][seed % 6]
+    model, p = P56_FAMILIES[seed % 6]
     g, o, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool(seed % 2)), force=(model, p), force_d3=False)
     _compare_solve(g, o, tag)
 

@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <cstddef>
 #include <type_traits>
+#include <utility>
 #include "../../include/algames_hip.h"
 
 // tunables (scratch/build_variant.sh builds A/B variants of the library with other values)
@@ -169,10 +170,22 @@ template <class C> __device__ __forceinline__ int con_ctl(CPR pr, int k, int row
 // state of knot k (0-based) inside a traj buffer
 template <class C> __device__ __forceinline__ const double* zstate(const double* z, int k) { return k == 0 ? z : z + C::n + hx<C>(k - 1); }
 
+// ---- thread index / synchronisation of ONE game -------------------------------------------------------------------------------
+// Every kernel runs one game per workgroup (one wavefront, or a team of Cfg::NW), so the game's thread index is the workgroup's
+// and its barrier is the workgroup barrier -- except in the quad-team translation unit (ALG_QT, algames_qt.hpp): there a
+// 256-thread workgroup carries FOUR games, one wavefront each, which meet only inside the collective Newton direction; the
+// per-game code sees its own 64 lanes and synchronises wave-locally (the fences of a barrier without the s_barrier).
+#ifdef ALG_QT
+__device__ __forceinline__ int game_tid() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ void game_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#else
+__device__ __forceinline__ int game_tid() { return (int)threadIdx.x; }
+__device__ __forceinline__ void game_sync() { __syncthreads(); }
+#endif
 // ---- wave reductions ---------------------------------------------------------------------------
 // Opaque copy of the lane id: keeps per-lane role / address computations of a phase from being hoisted out of the
 // solver's outer loops (where every phase's invariants would be live at once).
-__device__ __forceinline__ int phase_lane() { int l = threadIdx.x; asm volatile("" : "+v"(l)); return l; }
+__device__ __forceinline__ int phase_lane() { int l = game_tid(); asm volatile("" : "+v"(l)); return l; }
 // Opaque copies of wave-uniform loop invariants (problem sizes, dt, base pointers), taken at the start of a phase: whatever is
 // derived from them (row counts, address vectors, dt^2 / 2, (double)S ...) is recomputed inside the phase with a handful of
 // scalar instructions instead of being hoisted in front of the solver's outer loops and kept alive -- or spilled -- there.
@@ -198,12 +211,12 @@ __device__ __forceinline__ int wave_or(int v) {
 
 // ---- wavefront team of one game (Cfg::NW) ----------------------------------------------------------------------------------
 // Synchronisation inside the Newton-direction sweeps, which only wavefront 0 of a team executes: a wave-local fence (the same
-// fences __syncthreads() carries, without the workgroup barrier).  NW == 1: the workgroup is the wavefront, plain __syncthreads().
+// fences game_sync() carries, without the workgroup barrier).  NW == 1: the workgroup is the wavefront, plain game_sync().
 template <class C> __device__ __forceinline__ void dir_sync() {
-    if constexpr (C::NW == 1) __syncthreads();
+    if constexpr (C::NW == 1) game_sync();
     else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 }
-template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(game_tid() >> 6)); }
 
 // ---- counter RNG shared bit-for-bit with the oracle ------------------------------
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
@@ -774,16 +787,16 @@ struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; doub
 template <class C> __device__ __forceinline__ void team_combine(ResOut& o) {
     if constexpr (C::NW > 1) {
         __shared__ double red[C::NW][8];
-        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const int w = game_tid() >> 6, l = game_tid() & 63;
         if (l == 0) { red[w][0] = o.l1; red[w][1] = o.opt; red[w][2] = o.dyn; red[w][3] = o.con; red[w][4] = o.sta; red[w][5] = (double)o.nonfinite; red[w][6] = o.l1reg; red[w][7] = o.l1full; }
-        __syncthreads();
+        game_sync();
         ResOut r = {0.0, 0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < C::NW; q++) {
             r.l1 += red[q][0]; r.opt = fmax(r.opt, red[q][1]); r.dyn = fmax(r.dyn, red[q][2]); r.con = fmax(r.con, red[q][3]); r.sta = fmax(r.sta, red[q][4]);
             r.nonfinite |= (int)red[q][5]; r.l1reg += red[q][6]; r.l1full += red[q][7];
         }
-        __syncthreads();                         // red[] may be rewritten by the next pass
+        game_sync();                         // red[] may be rewritten by the next pass
         o = r;
     }
 }
@@ -959,7 +972,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             }
           }
           if constexpr (STAGED) {
-              __syncthreads();
+              game_sync();
               // write-out: contiguous [coef | Hh | Hd] and table segments of the staged steps
               const int nst = (N - 1 - kA) < SPP ? (N - 1 - kA) : SPP;
               for (int t = lane; t < nst * SL; t += C::NT) {
@@ -968,10 +981,10 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                   if (o >= HEAD) G.rec(pr)[base + R::GVT + (o - HEAD)] = L.stage[t];
                   else if (RECS || o < C::NC) G.rec(pr)[base + o] = L.stage[t];
               }
-              __syncthreads();
+              game_sync();
           }
         }
-        if constexpr (!AsmLds<C>::STAGED) __syncthreads();
+        if constexpr (!AsmLds<C>::STAGED) game_sync();
     }
     // ---------------- phase B ------------------------------------------------------------------------------
     // Every residual row of every step is independent once phase A has left the coefficients and the pair-gradient table:
@@ -1411,6 +1424,97 @@ __device__ __forceinline__ int gj_solve_cols(double (&col)[M]) {
     }
     return sing;
 }
+// ---- the same elimination with the pivot column broadcast by DPP -----------------------------------------------------------
+// gfx950 has v_fmac_f64_dpp / v_mov_b64_dpp with row_newbcast:L (lane L of every 16-lane row feeds the whole row): one
+// instruction does "broadcast lane L's register and FMA" where the v_readlane form needs two scalar reads per double plus the
+// FMA.  The broadcast stays inside a 16-lane row, so every row that holds right-hand-side columns carries its own replica of
+// the M columns of W in its lanes 0..M-1 (they are eliminated redundantly: free in SIMD terms).  Lane layout of a row:
+// [W col 0..M-1 | right-hand-side columns]; see GjLanes.
+// The elimination of one pivot is ONE asm statement (hipcc pads no hazards inside or around it, cdna_hip_programming.md 5.7:
+// a VALU write followed by a DPP read of the same VGPR needs two wait states -> s_nop 1 on both ends).
+template <int L>
+__device__ __forceinline__ double bcast16(double v) {           // lane L of the reader's 16-lane row (v_mov_b64_dpp row_newbcast)
+    long long x = __double_as_longlong(v);
+    x = __builtin_amdgcn_update_dpp(x, x, 0x150 + L, 0xf, 0xf, false);
+    return __longlong_as_double(x);
+}
+#define ALG_DPPF(d) "v_fmac_f64_dpp %" #d ", %" #d ", -%[np] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\t"
+template <int M> struct DppElim;
+// col[r] -= bcast_L(col[r]) * np for every r (the caller overwrites col[L] afterwards).  No trailing pad: the next DPP reader of
+// these registers is bcast16_asm / the next elimination, which open with their own s_nop 1.
+template <> struct DppElim<2> { template <int L> __device__ __forceinline__ static void run(double (&c)[2], double np) {
+    asm volatile("s_nop 1\n\t" ALG_DPPF(0) ALG_DPPF(1) "" : "+v"(c[0]), "+v"(c[1]) : [np] "v"(np), [l] "n"(L)); } };
+template <> struct DppElim<4> { template <int L> __device__ __forceinline__ static void run(double (&c)[4], double np) {
+    asm volatile("s_nop 1\n\t" ALG_DPPF(0) ALG_DPPF(1) ALG_DPPF(2) ALG_DPPF(3) ""
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : [np] "v"(np), [l] "n"(L)); } };
+template <> struct DppElim<6> { template <int L> __device__ __forceinline__ static void run(double (&c)[6], double np) {
+    asm volatile("s_nop 1\n\t" ALG_DPPF(0) ALG_DPPF(1) ALG_DPPF(2) ALG_DPPF(3) ALG_DPPF(4) ALG_DPPF(5) ""
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]) : [np] "v"(np), [l] "n"(L)); } };
+template <> struct DppElim<8> { template <int L> __device__ __forceinline__ static void run(double (&c)[8], double np) {
+    asm volatile("s_nop 1\n\t" ALG_DPPF(0) ALG_DPPF(1) ALG_DPPF(2) ALG_DPPF(3) ALG_DPPF(4) ALG_DPPF(5) ALG_DPPF(6) ALG_DPPF(7) ""
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) : [np] "v"(np), [l] "n"(L)); } };
+#undef ALG_DPPF
+// Lane roles of the DPP elimination inside one wavefront: row q = lane / 16 holds W's columns in its lanes 0..M-1 and the
+// right-hand-side columns q (16 - M) ... in the lanes behind them.
+template <int M, int NRHS> struct GjLanes {
+    static constexpr int RPR = 16 - M;                               // right-hand-side columns per 16-lane row
+    static_assert(RPR > 0 && (NRHS + RPR - 1) / RPR <= 4, "the control system does not fit the four rows of a wavefront");
+    __device__ __forceinline__ static bool wlane(int lane) { return (lane & 15) < M; }
+    __device__ __forceinline__ static int rhs_col(int lane) { return (lane >> 4) * RPR + (lane & 15) - M; }     // < 0 on W lanes
+    __device__ __forceinline__ static bool rhs(int lane) { const int c = rhs_col(lane); return !wlane(lane) && c < NRHS; }
+    // column of [W | right-hand sides] this lane builds (idle lanes duplicate the last right-hand side)
+    __device__ __forceinline__ static int column(int lane) { return wlane(lane) ? (lane & 15) : (rhs(lane) ? M + rhs_col(lane) : M + NRHS - 1); }
+};
+template <int M, int C>
+__device__ __forceinline__ void gj_dpp_pivot(double (&col)[M], int& sing) {
+    // lane C of the row owns W's column C: its entries below the diagonal decide the pivot (wave-uniform: every row holds the
+    // same replica; bit C of the ballot is row 0's lane C)
+    double best = fabs(col[C]);
+    unsigned long long need = 0;
+    if constexpr (C + 1 < M) {
+        // max |.| below the diagonal (v_max_f64 with |.| modifiers; through fmax() the compiler canonicalises every operand first)
+        // (one asm statement: the compiler pads every statement boundary with an s_nop)
+        double oth;
+        constexpr int NB = M - C - 1;                 // entries below the diagonal
+        const double* b = &col[C + 1];
+        if constexpr (NB == 1) oth = fabs(b[0]);
+        else if constexpr (NB == 2) asm("v_max_f64 %0, |%1|, |%2|" : "=v"(oth) : "v"(b[0]), "v"(b[1]));
+        else if constexpr (NB == 3) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|" : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]));
+        else if constexpr (NB == 4) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|" : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+        else if constexpr (NB == 5) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|"
+                                        : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]));
+        else if constexpr (NB == 6) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|\n\tv_max_f64 %0, %0, |%6|"
+                                        : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]));
+        else asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|\n\tv_max_f64 %0, %0, |%6|\n\tv_max_f64 %0, %0, |%7|"
+                 : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]));
+        static_assert(NB <= 7, "control system larger than the DPP elimination supports");
+        need = __builtin_amdgcn_ballot_w64(oth > best);
+    }
+    if ((need >> C) & 1ull) {
+        int piv = C;
+#pragma unroll
+        for (int r = C + 1; r < M; r++) { const double v = fabs(col[r]); if (v > best) { best = v; piv = r; } }
+        piv = __builtin_amdgcn_readlane(piv, C);
+#pragma unroll
+        for (int r = C + 1; r < M; r++) {
+            if (piv == r) { const double t = col[C]; col[C] = col[r]; col[r] = t; }
+        }
+    }
+    double pvt;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pvt) : "v"(col[C]), "n"(C));
+    if (!(fabs(pvt) > 0.0) || !isfinite(pvt)) sing = 1;
+    const double prow = col[C] * fast_rcp(pvt);
+    DppElim<M>::template run<C>(col, prow);
+    col[C] = prow;
+}
+template <int M, int... Cs>
+__device__ __forceinline__ void gj_dpp_all(double (&col)[M], int& sing, std::integer_sequence<int, Cs...>) { (gj_dpp_pivot<M, Cs>(col, sing), ...); }
+template <int M>
+__device__ __forceinline__ int gj_solve_cols_dpp(double (&col)[M]) {
+    int sing = 0;
+    gj_dpp_all<M>(col, sing, std::make_integer_sequence<int, M>{});
+    return sing;
+}
 // Sparse pattern (<= 3 entries) of column `idx` of the n x (m + n) matrix [B_k | A_k]  (idx < m: B column, else A column)
 template <class C>
 __device__ __forceinline__ void col_pattern(const double* coef, double dt, int idx, bool useA, int (&rows)[C::NPAT + 1], double (&vals)[C::NPAT + 1]) {
@@ -1595,7 +1699,12 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
 #ifdef ALG_PHASE_PROF
 #define ALG_PROF_DECL unsigned long long prof_t_ = __builtin_readcyclecounter(), prof_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define ALG_PROF(j) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc_[j] += t_ - prof_t_; prof_t_ = t_; }
-#define ALG_PROF_FLUSH if (threadIdx.x == 0) { for (int j_ = 0; j_ < 12; j_++) G.res(pr)[j_] += (double)prof_acc_[j_]; }
+#define ALG_PROF_FLUSH if (game_tid() == 0) { for (int j_ = 0; j_ < 12; j_++) G.res(pr)[j_] += (double)prof_acc_[j_]; }
+#elif defined(ALG_ISA_MARK)
+// static accounting (scratch/isa_phases.py): the phase boundaries show up as comments in the -S output
+#define ALG_PROF_DECL
+#define ALG_PROF(j) asm volatile("; ALGMARK " #j ::: "memory");
+#define ALG_PROF_FLUSH
 #else
 #define ALG_PROF_DECL
 #define ALG_PROF(j)
@@ -1668,7 +1777,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         }
     };
     rec_load(N - 2);
-    __syncthreads();
+    game_sync();
     ALG_PROF_DECL
     // ------------------------------------------------------------------ backward sweep
     for (int k = N - 2; k >= 0; k--) {
@@ -1706,7 +1815,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
 #pragma unroll
                         for (int r4 = 0; r4 < 4; r4++) { const int row = 16 * tr + lq + 4 * r4; if (row < n && bcol <= n) B.Tm[row * LDP + bcol] = acc[tr][r4]; }
                 }
-                __syncthreads();
+                game_sync();
                 ALG_PROF(0)
                 if constexpr (C::QUAD) {
                     // block-diagonal A' (dense 12 x 12 block per player j) as MFMA products too: rows (., j) of the result =
@@ -1731,14 +1840,14 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                         return AT_vec<C>(coefn, dt, [&](int rr) { return B.Tm[rr * LDP + c]; }, r);
                     }, [&](int e, double v) { Pi[e] = v; });
                 }
-                __syncthreads();
+                game_sync();
                 ALG_PROF(1)
             }
         }
         // ---- landing point of step k's record (requested at the tail of step k + 1): the recursion above was the last reader of
         // step k + 1's coefficients
         rec_store(k);
-        __syncthreads();
+        game_sync();
         // ---- + [Q^_i | rx_i]: diagonal, position block, column n
         for (int e = tid; e < P * n; e += BT) {
             const int i = e / n, r = e % n;
@@ -1752,7 +1861,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                 for (int c = 0; c < C::PD * P; c++) row[c] += pairblock<C>(Rl + R::HH, i, r, c);
             }
         }
-        __syncthreads();
+        game_sync();
         ALG_PROF(2)
         // ---- V[c][:] = B[:,c]' P_i(c),  y_i = P_i rd + s_i
         flat_loop<FU>(tid, BT, m * n, [&](int e) {
@@ -1765,7 +1874,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             for (int c = 0; c < n; c++) a += Pr[c] * Rl[R::RD + c];
             return a;
         }, [&](int e, double v) { B.sv.y[e] = v; });
-        __syncthreads();
+        game_sync();
         ALG_PROF(3)
         // ---- [ W | V A_k | g ],  W = diag(R^) + V B,  g_c = ru_c + B[:,c]' y_i(c): three uniform loops (no divergent entry kinds)
         auto ibr_mask = [&](int c, int t, double v) {
@@ -1787,7 +1896,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             const double* yi = &B.sv.y[(c % P) * n];
             return ibr_mask(c, m + n, Rl[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c));
         }, [&](int c, double v) { B.sv.Wm[c * WC + m + n] = v; });
-        __syncthreads();
+        game_sync();
         ALG_PROF(4)
         // ---- partially pivoted Gauss-Jordan (pivot rule and row operations of the tile path's gj_solve_cols).  m <= 8: wavefront 0
         // alone, columns in registers, the pivot column by v_readlane (no LDS traffic, no barrier).  m > 8 (the 2 m scalar registers
@@ -1817,7 +1926,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                 }
                 if (lane == 0) L.red[7] = (double)sg;
             }
-            __syncthreads();
+            game_sync();
             if constexpr (NWV > 1) sg = (int)L.red[7];
             sing |= __builtin_amdgcn_readfirstlane(sg);
         } else {
@@ -1835,7 +1944,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
 #pragma unroll
                     for (int r = 0; r < m; r++) B.sv.pcol[c & 1][r] = col[0][r];
                 }
-                __syncthreads();
+                game_sync();
                 double pc[m];
 #pragma unroll
                 for (int r = 0; r < m; r++) pc[r] = B.sv.pcol[c & 1][r];
@@ -1872,7 +1981,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                     for (int r = 0; r < m; r++) B.sv.Wm[r * WC + t] = col[x][r];
                 }
             }
-            __syncthreads();
+            game_sync();
         }
         ALG_PROF(5)
         // ---- [F | f] = [A_k | rd] + B [K | kappa] ; K = -Y -> HBM (column-major m x (n+1))
@@ -1885,7 +1994,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         }
         for (int e = tid; e < NK; e += BT) { const int col = e / m, c = e % m; kg[(size_t)k * NK + e] = -B.sv.Wm[c * WC + m + col]; }   // gains out
         if (k > 0) rec_load(k - 1);                                          // then request step k - 1 (landed after its value recursion)
-        __syncthreads();
+        game_sync();
         ALG_PROF(6)
     }
     if (sing) return ALG_STATUS_SINGULAR;                  // uniform: every thread saw the same pivots
@@ -1920,7 +2029,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     };
     fw_load(0); fw_store();
     if (1 < N - 1) fw_load(1);
-    __syncthreads();
+    game_sync();
     double pl1 = 0.0; int bad = 0;
     constexpr int XPT = (n + BT - 1) / BT;
     for (int k = 0; k < N - 1; k++) {
@@ -1938,14 +2047,14 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
                 pl1 += fabs(a); bad |= !isfinite(a);
             }
         }
-        __syncthreads();
+        game_sync();
         double nx[XPT];
 #pragma unroll
         for (int q = 0; q < XPT; q++) {
             const int r = tid + q * BT; nx[q] = 0.0;
             if (r < n) nx[q] = (A_vec<C>(coefk, dt, [&](int rr) { return F.dx[rr]; }, r) + B_vec<C>(coefk, dt, [&](int cc) { return F.du[cc]; }, r)) + F.rs[0][R::RD - C::NC + r];
         }
-        __syncthreads();
+        game_sync();
 #pragma unroll
         for (int q = 0; q < XPT; q++) {
             const int r = tid + q * BT;
@@ -1957,7 +2066,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
 #pragma unroll
         for (int q = 0; q < XPT; q++) { const int r = tid + q * BT; if (r < n) dz[n + hx<C>(k) + r] = nx[q]; }
         if (k + 2 < N - 1) fw_load(k + 2);                                   // (3) request step k + 2
-        __syncthreads();
+        game_sync();
     }
     ALG_PROF(7)
     // ------------------------------------------------------------------ costate sweep:
@@ -1998,7 +2107,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     };
     cs_load(N - 2); cs_store(N - 2);
     if (N - 3 >= 0) cs_load(N - 3);
-    __syncthreads();
+    game_sync();
     for (int k = N - 2; k >= 0; k--) {
         const int cur = k & 1;
         const double* Rl = F.rs[cur] - C::NC;
@@ -2029,14 +2138,14 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
 #pragma unroll
         for (int q0 = 0; q0 < LPT; q0++) { const int e = tid + q0 * BT; if (e < P * n) dz[n + hl<C>(k, 0) + e] = lv[q0]; }   // (2) results out
         if (k > 1) cs_load(k - 2);                                           // (3) request step k - 2
-        __syncthreads();
+        game_sync();
     }
     ALG_PROF(8)
     ALG_PROF_FLUSH
     pl1 = wave_sum(pl1); bad = wave_or(bad);
     if constexpr (NWV > 1) {
         if (lane == 0) { L.red[wv] = pl1; L.red[4 + wv] = (double)bad; }
-        __syncthreads();
+        game_sync();
         pl1 = 0.0; bad = 0;
 #pragma unroll
         for (int q = 0; q < NWV; q++) { pl1 += L.red[q]; bad |= (int)L.red[4 + q]; }
@@ -2069,7 +2178,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     const int N = phase_int(pr.N), tid = phase_lane();
     const int lane = TEAM ? (tid & 63) : tid;             // lane inside the wavefront
     const int tw = TEAM ? team_wave<C>() : 0;
-    auto bsync = [&]() { if constexpr (TEAM) __syncthreads(); else dir_sync<C>(); };
+    auto bsync = [&]() { if constexpr (TEAM) game_sync(); else dir_sync<C>(); };
     const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
     const double dt = phase_f64(pr.dt);
     constexpr int RPL = (R::LEN_SWEEP + BT - 1) / BT;          // record doubles per thread
@@ -2262,10 +2371,15 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         ALG_PROF(3)
         // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B: every lane forms its column as the same
         // short sparse combination of row c of the extended V (lane < m: B column + R^ slot; lane < m+n: A column; lane m+n: g slot)
+        // (lane layout of the DPP elimination: every 16-lane row carries W's columns in its lanes 0..m-1 and its share of the
+        // n + 1 right-hand-side columns behind them, GjLanes)
+        using GL = GjLanes<m, n + 1>;
+        const int cidx = GL::column(lane);                 // column of [W | V A_k | g] this lane builds
+        const bool rhsl = GL::rhs(lane);                   // ... and whether it is a right-hand side (its solution column is used)
         double col[m];
         {
             int rows[C::NPAT + 1]; double vals[C::NPAT + 1];
-            col_pattern<C>(coefk, dt, lane, k >= 1, rows, vals);
+            col_pattern<C>(coefk, dt, cidx, k >= 1, rows, vals);
 #pragma unroll
             for (int c = 0; c < m; c++) {
                 const double* Vc = &L.bw.V[c * VW];
@@ -2273,20 +2387,20 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
                 for (int t = 1; t < C::NPAT + 1; t++) v = fma(vals[t], Vc[rows[t]], v);
                 if (IBR) {
-                    if (c % P != ip) v = (lane == c) ? 1.0 : 0.0;               // unit row: du_c = 0
-                    else if (lane < m && lane % P != ip) v = 0.0;               // fixed controls of the other players
+                    if (c % P != ip) v = (cidx == c) ? 1.0 : 0.0;               // unit row: du_c = 0
+                    else if (cidx < m && cidx % P != ip) v = 0.0;               // fixed controls of the other players
                 }
                 col[c] = v;
             }
         }
         ALG_PROF(4)
 #ifndef ALG_NO_GJ
-        sing |= gj_solve_cols<m>(col);
+        sing |= gj_solve_cols_dpp<m>(col);
 #endif
         ALG_PROF(5)
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
-        if (lane >= m && lane <= m + n) {
-            const int cc = lane - m;
+        if (rhsl) {
+            const int cc = cidx - m;
 #pragma unroll
             for (int c = 0; c < m; c++) col[c] = -col[c];
             // column cc of [A_k | rd]: contiguous in LDS (T row cc, or the record's rd); A_0 is never used (dx_1 = 0)
@@ -2314,8 +2428,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // the gains go out last (gfx9 counts loads and stores in one vmcnt: the wait for the prefetched record above should not
         // meet stores that were just issued; measured neutral, the phase profile shows no exposed wait either way)
         asm volatile("" ::: "memory");
-        if (tw == 0 && lane >= m && lane <= m + n) {
-            double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (lane - m) * m;
+        if (tw == 0 && rhsl) {
+            double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (cidx - m) * m;
 #pragma unroll
             for (int c = 0; c < m; c++) Kg[c] = col[c];
         }
@@ -2463,9 +2577,9 @@ template <class C>
 __device__ void jacobian_dense(CPR pr, const Game& G, double reg, double* J) {
     constexpr int n = C::n, m = C::m, P = C::P;
     using R = Rec<C>;
-    const int N = pr.N, lane = threadIdx.x; const size_t S = pr.S; const double dt = pr.dt;
+    const int N = pr.N, lane = game_tid(); const size_t S = pr.S; const double dt = pr.dt;
     for (size_t e = lane; e < S * S; e += WAVE) J[e] = 0.0;
-    __syncthreads();
+    game_sync();
     auto at = [&](int r, int c) -> double& { return J[(size_t)c * S + r]; };
     for (int k = 0; k < N - 1; k++) {
         const double* Rc = G.rec(pr) + (size_t)k * R::LEN;
@@ -2544,7 +2658,7 @@ template <class C>
 __device__ __forceinline__ RecScalars make_record(CPR pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
     ResOut ro;
     assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, jreg, ro);
-    __syncthreads();
+    game_sync();
     return push_stats(pr, G, ro, delta, outer, out);
 }
 
@@ -2557,7 +2671,7 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
     while (j < pr.opt.ls_iter) {
         const auto& o = phase_params(pr).opt;
         update_traj<C>(pr, G, 1, 0, alpha);
-        __syncthreads();
+        game_sync();
         ResOut ro;
         bool done = false;
         if constexpr (C::TRIAL_REUSE) {
@@ -2597,28 +2711,28 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     else {
         // team: the serial sweeps run on wavefront 0; status and sum |d_primal| reach the other wavefronts through LDS
         __shared__ double dir_out[2];
-        __syncthreads();
+        game_sync();
         // teams of >= 4: backward sweep on the whole team, forward / costate on wavefront 0; team of 2: wavefront 0 does it all
         if (C::NW >= 4 || team_wave<C>() == 0) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);
-        if (threadIdx.x == 0) { dir_out[0] = (double)st; dir_out[1] = pl1; }
-        __syncthreads();
+        if (game_tid() == 0) { dir_out[0] = (double)st; dir_out[1] = pl1; }
+        game_sync();
         st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1 = uni(dir_out[1]);
     }
     if (st != ALG_STATUS_OK) return finish(st, 1);
-    __syncthreads();
+    game_sync();
     double alpha; int j;
     const double lf1 = (double)(l + 1);
     const bool reuse = C::TRIAL_REUSE && cache_valid && l < o.inner_iter && o.regularize;    // the next inner iteration may reuse the trial
     line_search<C>(pr, G, L, reg, rs.res, reuse ? o.reg_0 * (lf1 * lf1 * lf1 * lf1) : -1.0, &alpha, &j);   // :91
     const int failed = (j == o.ls_iter);                                   // :92
     if (failed) LS_count += 1; else LS_count = 0;                          // :93
-    __syncthreads();
+    game_sync();
     // :94 update_traj!(pdtraj, pdtraj, alpha, delta): the last trial already holds exactly these values unless the search ran
     // out of trials (alpha was halved once more after the last trial) -> exchange the roles of the two buffers
     if (!failed) { const int t = G.zo[0]; G.zo[0] = G.zo[1]; G.zo[1] = t; }
     else update_traj<C>(pr, G, 0, 0, alpha);
     { double sd = pl1; sd *= alpha; sd /= (double)((phase_int(pr.N) - 1) * (C::n + C::m)); Delta = uni(sd); }     // :95 Delta_step
-    __syncthreads();
+    game_sync();
     if (reuse && !failed) *cache_valid = 1;
     if (lane0) {
         const Game G = G_.fresh();
@@ -2705,7 +2819,7 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
     }
     // penalty_update! rewrites mu of EVERY row: in a team, another wavefront may still be in the dual-update loops above, which
     // read mu of rows this thread is about to scale (one wavefront alone runs the loops in program order)
-    if constexpr (C::NW > 1) __syncthreads();
+    if constexpr (C::NW > 1) game_sync();
     for (int e = tid; e < pr.con_len; e += C::NT) G.mu(pr)[e] = fmin(fmax(G.mu(pr)[e] * o.rho_increase, 0.0), o.rho_max);
 }
 
@@ -2713,7 +2827,7 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
 template <class C>
 __device__ __forceinline__ void rollout(CPR pr, double* z) {
     constexpr int n = C::n, m = C::m, P = C::P;
-    const int lane = threadIdx.x;
+    const int lane = game_tid();
     if constexpr (C::QUAD) {
         if (lane < P) {
             double xi[12], ui[4], xo[12];
@@ -2743,14 +2857,14 @@ __device__ __forceinline__ void rollout(CPR pr, double* z) {
 template <class C>
 __device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bool use_shift, int shift = -1) {
     constexpr int n = C::n, m = C::m, P = C::P;
-    const int N = pr.N, lane = threadIdx.x; const auto& o = pr.opt;
+    const int N = pr.N, lane = game_tid(); const auto& o = pr.opt;
     const int s = use_shift ? (shift >= 0 ? shift : o.shift) : (1 << 30);
     if (use_shift && s < N) {
         // in-place shift: element e of step k takes element e of step k+s; ascending k is safe within one wave only
         // with a barrier per step, so stage through the trial buffer
         double* tmp = G.z(1);
         for (int e = lane; e < pr.traj_len; e += C::NT) tmp[e] = z[e];
-        __syncthreads();
+        game_sync();
         z = z; // (same buffer)
         for (int e = lane; e < pr.S; e += C::NT) {
             const int k = e / C::b, a = e % C::b;
@@ -2779,7 +2893,7 @@ __device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bo
         }
     }
     if (lane < n) z[lane] = G.x0(pr)[lane];
-    __syncthreads();
+    game_sync();
 }
 
 // After an odd number of buffer exchanges pdtraj lives in the trial buffer: move it home (and leave the trial buffer with
@@ -2787,12 +2901,12 @@ __device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bo
 template <class C>
 __device__ __forceinline__ void settle_traj(CPR pr, Game& G) {
     if (G.zo[0] != 0) {
-        __syncthreads();
+        game_sync();
         const Game H = G.fresh();
         double* a = H.z(0); double* z_home = H.base;
         for (int e = phase_lane(); e < pr.traj_len; e += C::NT) { const double v = a[e]; a[e] = z_home[e]; z_home[e] = v; }
         G.zo[1] = G.zo[0]; G.zo[0] = 0;
-        __syncthreads();
+        game_sync();
     }
 }
 
@@ -2808,11 +2922,11 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
     else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
     if (lane < C::n) { G.z(1)[lane] = G.x0(pr)[lane]; G.z(2)[lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
-    __syncthreads();
+    game_sync();
     rollout<C>(pr, G.z(0));                                                // :17
 #endif
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con<C::NT>(pr, G);     // :25
-    __syncthreads();
+    game_sync();
     int out = 0, status = ALG_STATUS_OK, fresh = 0; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30
         out = k;
@@ -2825,7 +2939,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
             if (LS_count >= 1 || ((rcode >> 8) & 0xff) == 1) break;        // :43
         }
         if (status != ALG_STATUS_OK) break;
-        __syncthreads();
+        game_sync();
         // prob.stats.*_vio[end]: the record made at the top of the last inner iteration (lane 0 wrote it; same wave)
         alg_game_stats* const stk = G.fresh().st(phase_params(pr));
         const alg_record& last = stk->last;
@@ -2834,9 +2948,9 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
         if (convu && phase_lane() == 0) stk->converged = 1;          // written where it is decided (one loop-carried scalar less)
         if (k == o.outer_iter || convu) break;                             // :49-55
         dual_penalty_update<C>(pr, G);                                     // :57-61
-        __syncthreads();
+        game_sync();
     }
-    __syncthreads();
+    game_sync();
     // :63 record! at the final iterate.  When the solver left its loops at the optimality test of an inner iteration (the usual
     // exit) that iteration's record! was made at this very iterate with these very multipliers: the same numbers, so the
     // assemble pass is not repeated, the record is pushed again (with the Delta and outer index this call passes)
@@ -2866,7 +2980,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
 template <class C>
 __device__ __forceinline__ RecScalars ibr_push_stats(CPR pr, const Game& G, const ResOut& ro, double delta, int outer) {
     const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));            // length(verti_mask)
-    if (threadIdx.x == 0) {
+    if (game_tid() == 0) {
         alg_record rc;
         rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1full / (double)pr.S; rc.delta = delta;
         rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
@@ -2888,18 +3002,18 @@ __device__ int ibr_inner_iteration(CPR pr, const Game& G, Lds<C>& L, int& LS_cou
     const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));
     ResOut ro;
     assemble_pass<C, 1, true>(pr, G, L.a, 0, -1, 0.0, reg, ro, ip);        // :236-241
-    __syncthreads();
+    game_sync();
     const RecScalars rs = ibr_push_stats<C>(pr, G, ro, Delta, k);
     Delta = 0.0;
     if (rs.nonfinite) return ALG_STATUS_NAN | (1 << 8);
     if (rs.opt < o.eps_opt) return ALG_STATUS_OK | (1 << 8);                       // :245-247
     const int st = newton_direction<C, true>(pr, G, L.d, reg, ip);                  // :249-252
     if (st != ALG_STATUS_OK) return st | (1 << 8);
-    __syncthreads();
+    game_sync();
     int j = 1; double alpha = 1.0;                                                  // ibr_line_search (:270-289)
     while (j < o.ls_iter) {
         update_traj<C>(pr, G, 1, 0, alpha);
-        __syncthreads();
+        game_sync();
         ResOut rt;
         assemble_pass<C, 0, true>(pr, G, L.a, 1, o.regularize ? 0 : -1, reg, 0.0, rt, ip);
         if (uni(rt.l1 / sm) <= (1.0 - alpha * o.beta) * rs.res) break;
@@ -2907,11 +3021,11 @@ __device__ int ibr_inner_iteration(CPR pr, const Game& G, Lds<C>& L, int& LS_cou
     }
     const int failed = (j == o.ls_iter);
     if (failed) LS_count += 1; else LS_count = 0;
-    __syncthreads();
+    game_sync();
     update_traj<C>(pr, G, 0, 0, alpha);                              // :258
     Delta = uni(delta_step<C>(pr, G.z(2), alpha));                                  // :259
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    game_sync();
+    if (game_tid() == 0) {
         G.st(pr)->newton_iters += 1; if (failed) G.st(pr)->ls_failures += 1;
         const int idx = G.st(pr)->records - 1;
         if (idx < pr.hist_max) { G.hist(pr)[idx].alpha = alpha; G.hist(pr)[idx].ls_j = j; }
@@ -2922,7 +3036,7 @@ __device__ int ibr_inner_iteration(CPR pr, const Game& G, Lds<C>& L, int& LS_cou
 // ibr_newton_solve!(prob, i) (solver_methods.jl:171-228)
 template <class C>
 __device__ int ibr_solve_player(CPR pr, const Game& G, Lds<C>& L, int ip) {
-    const auto& o = pr.opt; const int lane = threadIdx.x;
+    const auto& o = pr.opt; const int lane = game_tid();
     if (o.dual_reset) {                                                            // :181-185
         reset_con(pr, G);
         for (int e = lane; e < (pr.N - 1) * C::P * C::n; e += WAVE) {              // reset_duals!(pdtraj), reset_duals!(pdtraj_trial)
@@ -2930,7 +3044,7 @@ __device__ int ibr_solve_player(CPR pr, const Game& G, Lds<C>& L, int ip) {
             G.z(0)[C::n + hl<C>(k, 0) + a] *= 0.0; G.z(1)[C::n + hl<C>(k, 0) + a] *= 0.0;
         }
     }
-    __syncthreads();
+    game_sync();
     int out = 0, status = ALG_STATUS_OK, converged = 0; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {
         out = k; int LS_count = 0;
@@ -2940,22 +3054,22 @@ __device__ int ibr_solve_player(CPR pr, const Game& G, Lds<C>& L, int ip) {
             if (LS_count >= 1 || (rcode >> 8) == 1) break;
         }
         if (status != ALG_STATUS_OK) break;
-        __syncthreads();
+        game_sync();
         const alg_record& last = G.st(pr)->last;
         const bool conv = last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
         const int convu = __builtin_amdgcn_readfirstlane((int)conv);
         converged = convu;
         if (k == o.outer_iter || convu) break;
         dual_penalty_update<C>(pr, G);
-        __syncthreads();
+        game_sync();
     }
-    __syncthreads();
+    game_sync();
     ResOut ro;
     assemble_pass<C, 1, true>(pr, G, L.a, 0, -1, 0.0, 0.0, ro, ip);          // :226
-    __syncthreads();
+    game_sync();
     ibr_push_stats<C>(pr, G, ro, Delta, out);
     if (lane == 0) { G.st(pr)->status = status; G.st(pr)->outer_iters = out; G.st(pr)->converged = converged; }
-    __syncthreads();
+    game_sync();
     return status;
 }
 struct IbrOrder { int v[MAXP]; };
@@ -2964,16 +3078,16 @@ struct IbrOrder { int v[MAXP]; };
 template <class C>
 __device__ void ibr_newton_solve(CPR pr, const Game& G, Lds<C>& L, bool single, int player, int init, uint64_t game_id,
                                  int ibr_iter, const IbrOrder& order, double delta_min) {
-    const int lane = threadIdx.x;
+    const int lane = game_tid();
     if (!single) {
         if (lane == 0) { alg_game_stats z{}; *G.st(pr) = z; G.tc(pr)[6] = 0.0; }             // reset!(prob.stats)
         if (init) init_traj<C>(pr, G, G.z(0), game_id, true);
         else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
-        __syncthreads();
+        game_sync();
         for (int e = lane; e < pr.traj_len; e += WAVE) { G.z(1)[e] = G.z(0)[e]; G.z(2)[e] = 0.0; }   // :142-143 (the trial's duals are reset below)
-        __syncthreads();
+        game_sync();
         rollout<C>(pr, G.z(0));
-        __syncthreads();
+        game_sync();
     }
     unsigned change = (1u << C::P) - 1u;                                             // Δ_change = trues(p)
     const int rounds = single ? 1 : ibr_iter, nplay = single ? 1 : C::P;

@@ -80,6 +80,8 @@ SIGNATURES = {
     "set_stream": (C.c_int, [_P, _P]),
     "set_waves_per_game": (C.c_int, [_P, C.c_int32]),
     "get_waves_per_game": (C.c_int, [_P, _I]),
+    "set_quad_team": (C.c_int, [_P, C.c_int32]),
+    "get_quad_team": (C.c_int, [_P, _I]),
     "set_x0": (C.c_int, [_P, _D]),
     "set_lqr": (C.c_int, [_P, _D, _D, _D, _D, C.c_int32]),
     "add_collision_cost": (C.c_int, [_P, _D, _D]),
@@ -236,6 +238,15 @@ class Batch:
     def get_waves_per_game(self):
         v = C.c_int32()
         self.lib.check(self.lib.get_waves_per_game(self.h, C.byref(v)))
+        return v.value
+
+    def set_quad_team(self, mode):
+        """-1 = automatic, 0 = one game per workgroup, 1 = four games per workgroup required (alg_set_quad_team)."""
+        self.lib.check(self.lib.set_quad_team(self.h, int(mode)))
+
+    def get_quad_team(self):
+        v = C.c_int32()
+        self.lib.check(self.lib.get_quad_team(self.h, C.byref(v)))
         return v.value
 
     def set_stream(self, stream_ptr):

@@ -112,10 +112,13 @@ __device__ __forceinline__ CPR phase_params(CPR pr) { return *(const ALG_AS4 Par
 // NW_ > 1: NW_ wavefronts work on one game (workgroup = NW_ x 64 threads; small batches that leave most SIMDs empty): the
 // streaming phases (assemble pass, trajectory updates, dual updates) are spread over all of them, the serial Newton-direction
 // sweeps run on wavefront 0.  NW_ = 1 is the one-game-per-wavefront kernel of the large batches.
-template <int MODEL_, int P_, int D_, int EXT_ = 0, int NW_ = 1>
+// GW_ = 4: quad-team kernels (algames_qt.hpp): four games per workgroup, one wavefront each; the Newton direction is a collective
+// of the four wavefronts.  Only meaningful in the ALG_QT translation unit.
+template <int MODEL_, int P_, int D_, int EXT_ = 0, int NW_ = 1, int GW_ = 1>
 struct Cfg {
     static constexpr int MODEL = MODEL_, P = P_, D = D_;
     static constexpr int NW = NW_, NT = NW_ * 64;          // wavefronts / threads per game
+    static constexpr int GW = GW_;                         // games per workgroup
     static constexpr bool EXT = EXT_ != 0;
     static constexpr bool POS = (P_ > 1) || EXT;     // position blocks (pair / wall / circle terms) present in Q^_i
     // QuadrotorGame (quadrotor.jl:20-46): dense 12 x 12 / 12 x 4 Jacobian blocks per player, n up to 48
@@ -215,6 +218,15 @@ __device__ __forceinline__ int wave_or(int v) {
 template <class C> __device__ __forceinline__ void dir_sync() {
     if constexpr (C::NW == 1) game_sync();
     else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+}
+// Synchronisation between the LDS phases of the tile-path sweeps when one wavefront runs them: orders LDS only.  game_sync() /
+// __syncthreads() also drain vmcnt, i.e. every phase boundary of a time step (eight in the backward sweep) waited for the record
+// prefetch and the gain stores that had just been issued -- the sweeps ran at global-memory latency.  What the sweeps exchange
+// through global memory (gains, dx) crosses a full game_sync() between the sweeps.
+template <class C> __device__ __forceinline__ void sweep_sync() {
+    if constexpr (C::NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    } else dir_sync<C>();
 }
 template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(game_tid() >> 6)); }
 
@@ -2178,7 +2190,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     const int N = phase_int(pr.N), tid = phase_lane();
     const int lane = TEAM ? (tid & 63) : tid;             // lane inside the wavefront
     const int tw = TEAM ? team_wave<C>() : 0;
-    auto bsync = [&]() { if constexpr (TEAM) game_sync(); else dir_sync<C>(); };
+    auto bsync = [&]() { if constexpr (TEAM) game_sync(); else sweep_sync<C>(); };
     const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
     const double dt = phase_f64(pr.dt);
     constexpr int RPL = (R::LEN_SWEEP + BT - 1) / BT;          // record doubles per thread
@@ -2272,7 +2284,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
                         for (int i = 0; i < P; i++) c2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[i][kb], c2[i], 0, 0, 0);
                 }
-                dir_sync<C>();
+                sweep_sync<C>();
 #pragma unroll
                 for (int i = 0; i < P; i++)
 #pragma unroll
@@ -2300,7 +2312,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
                         for (int kb = 0; kb < KB; kb++) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kb], c1[kb], c2, 0, 0, 0);
                     }
-                    dir_sync<C>();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
+                    sweep_sync<C>();            // this player's reads of P_i / s_i are done (single wave: a wait + compiler fence)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; r4++) {
                         const int row = lq + 4 * r4;
@@ -2442,6 +2454,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     return ALG_STATUS_OK;
 #endif
     // ------------------------------------------------------------------ forward sweep: dx, du
+    if constexpr (C::NW == 1) game_sync();            // the gains are in global memory (the sweeps' own syncs order LDS only)
     G = G0.fresh();
     double* __restrict__ dz = G.z(2);
     if (lane < n) dz[lane] = 0.0;
@@ -2466,7 +2479,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     };
     double pref, prek[KPL];
     fwd_load(1, pref, prek);
-    dir_sync<C>();
+    sweep_sync<C>();
     cur = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
     int bad = 0;                                    // non-finite direction entries (checked where they are produced)
@@ -2496,7 +2509,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         if (lane < n) dz[n + hx<C>(k) + lane] = dxn;
         // (3) request step k+2
         fwd_load(k + 2, pref, prek);
-        dir_sync<C>();
+        sweep_sync<C>();
     }
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
     return ALG_STATUS_OK;
@@ -2506,6 +2519,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     hxm.init(phase_lane());
+    if constexpr (C::NW == 1) game_sync();            // dx of every step is in global memory
     G = G0.fresh();
     dz = G.z(2);
     constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
@@ -2525,7 +2539,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     };
     double pre[RPLC], pdx = 0.0;
     if constexpr (PFD == 2) cs_load(N - 3, pdx, pre);
-    dir_sync<C>();
+    sweep_sync<C>();
     cur = 0;
     for (int k = N - 2; k >= 0; k--, cur ^= 1) {
         const double* Rc = L.rec[cur];
@@ -2535,7 +2549,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         else cs_load(k - 1, pdx, pre);
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         hxm.expand(lane, Rc, L.fw.hx);
-        dir_sync<C>();
+        sweep_sync<C>();
         double acc = 0.0;
         if (lane < P * n && (!IBR || ci_ == ip)) {
             double qd = reg + w * L.qdf[lane];
@@ -2549,7 +2563,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             }
             if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
-        dir_sync<C>();
+        sweep_sync<C>();
         if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; bad |= !isfinite(acc); }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         dxk = pdx;
@@ -2562,7 +2576,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
             for (int q = 0; q < RPLC; q++) pre[q] = nx[q];
         }
-        dir_sync<C>();
+        sweep_sync<C>();
     }
     ALG_PROF(8)
     ALG_PROF_FLUSH
@@ -2686,6 +2700,8 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
     *alpha_out = alpha; *j_out = j;
 }
 
+// quad-team Newton direction of one game (algames_qt.hpp; only instantiated for Cfg::GW > 1)
+template <class C> __device__ int qt_direction_call(CPR pr, Lds<C>& mine, int want, double reg, double* primal_l1);
 // inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
 // the history record / *info (lane 0).  `cache` (optional) carries an accepted trial's statistics to the next call.
 template <class C>
@@ -2707,7 +2723,8 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
     if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1) | (1 << 16);  // :80-82 (bit 16: pdtraj untouched since this record!)
     double pl1; int st;
-    if constexpr (C::NW == 1) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);         // :84-88
+    if constexpr (C::GW > 1) st = qt_direction_call<C>(pr, L, 1, reg, &pl1);               // collective of the workgroup's four games
+    else if constexpr (C::NW == 1) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);    // :84-88
     else {
         // team: the serial sweeps run on wavefront 0; status and sum |d_primal| reach the other wavefronts through LDS
         __shared__ double dir_out[2];
@@ -2916,7 +2933,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     const auto& o = pr.opt; const int lane = phase_lane();
     if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; } // reset!(prob.stats)
 #ifdef ALG_PHASE_PROF
-    if (lane < 12) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums
+    if (lane < 48) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums
 #endif
 #ifndef ALG_TEST_NOINIT
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13

@@ -1,10 +1,13 @@
 // algames_hip.hip -- kernels and the C ABI (include/algames_hip.h) of libalgames_hip.so.
 // gfx950 only.  One workgroup (= one wavefront) per game; see algames_device.hpp.
 #include "algames_kernels.hpp"
+#include "algames_qt_launch.h"
 
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -60,7 +63,7 @@ bool fill_dims(const alg_desc& a, Params& p) {
     for (int i = 0; i < MAXP; i++) p.wall_mask[i] = p.circ_mask[i] = 0xffffffffu;
     p.ca_dim = 2;
     p.hist_max = HIST_MAX;
-    p.kscratch_len = (p.N - 1) * p.m * (p.n + 1);
+    p.kscratch_len = (p.N - 1) * p.m * std::max(p.n + 1, 16);            // gains m x (n + 1) per step; the quad-team kernels store rows of 16
     {   // Rec<C>::LEN of the EXT instantiation (the base one is p n shorter; the buffer is sized for either)
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : (p.model == ALG_MODEL_QUADROTOR) ? 204 * p.p : 0;
         const int pd = (p.d == 3) ? 3 : 2, ns = pd * (pd + 1) / 2;   // Cfg::PD / NS of the EXT instantiation
@@ -118,6 +121,7 @@ struct Handle {
     double* d_extc = nullptr;
     std::vector<double> extc;     // host copy of pr.extc
     int waves_per_game = 0;       // 0 = automatic (alg_set_waves_per_game)
+    int quad_team = -1;           // -1 = automatic, 0 = off, 1 = required (alg_set_quad_team)
     long long solves_since_reset = 0;   // solves whose records share the Statistics history (best responses accumulate)
     void* d_scratch = nullptr;    // grow-only scratch of the inspection entry points (dense Jacobians, MPC state logs)
     size_t scratch_bytes = 0;
@@ -301,9 +305,17 @@ int team_width(const Handle* hd) {
 #undef X
     return hd->waves_per_game > 1 ? -1 : best;
 }
+// Quad-team shape (algames_qt.hip).  Measured 3-6 % slower than the one-wavefront kernels at 4096-16384 games (DESIGN.md section
+// 10), so "automatic" means off unless ALGAMES_QT=1; alg_set_quad_team(h, 1) selects it explicitly.
+bool quad_team_on(const Handle* hd) {
+    if (hd->quad_team == 0 || !alg_qt_supported(hd->pr) || team_width(hd) != 1) return false;
+    if (hd->quad_team < 0) { const char* e = getenv("ALGAMES_QT"); return e && e[0] == '1'; }
+    return true;
+}
 int launch_newton_solve(Handle* h, int init, uint64_t game_id0) {
     const int nw = team_width(h);
     if (nw < 0) return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration");
+    if (quad_team_on(h)) { alg_qt_launch_newton_solve(h->pr, h->stream, init, game_id0); return launch_check("k_newton_solve_qt"); }
     if (nw == 1) { LAUNCH(k_newton_solve, h->pr, init, game_id0); return ALG_OK; }
     const Params& pr = h->pr; bool done = false;
 #define X(M, P, D, E, W) if (!done && nw == (W) && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                   \
@@ -425,6 +437,18 @@ int alg_set_waves_per_game(alg_handle* h, int32_t nw) {
     H->waves_per_game = nw;
     if (team_width(H) < 0) { H->waves_per_game = prev; return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration"); }
     return ALG_OK;
+}
+int alg_set_quad_team(alg_handle* h, int32_t mode) {
+    NEED_HANDLE("alg_set_quad_team");
+    if (mode < -1 || mode > 1) return fail(ALG_ERR_ARG, "alg_set_quad_team: -1 (automatic), 0 (off) or 1 (required)");
+    const int prev = H->quad_team;
+    H->quad_team = mode;
+    if (mode == 1 && !quad_team_on(H)) { H->quad_team = prev; return fail(ALG_ERR_ARG, "alg_set_quad_team: the quad-team kernels need the 3-player planar double integrator without extended constraints, a batch that is a multiple of four and one wavefront per game"); }
+    return ALG_OK;
+}
+int alg_get_quad_team(alg_handle* h, int32_t* on) {
+    if (!h || !on) return fail(ALG_ERR_ARG, "alg_get_quad_team: null argument");
+    *on = quad_team_on(H) ? 1 : 0; return ALG_OK;
 }
 int alg_get_waves_per_game(alg_handle* h, int32_t* nw) {
     if (!h || !nw) return fail(ALG_ERR_ARG, "alg_get_waves_per_game: null argument");

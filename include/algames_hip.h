@@ -162,6 +162,15 @@ int  alg_get_options(alg_handle* h, alg_options* o);
  * summed in a different order).  alg_get_waves_per_game returns the width the next solve will use. */
 int  alg_set_waves_per_game(alg_handle* h, int32_t waves);
 int  alg_get_waves_per_game(alg_handle* h, int32_t* waves);
+/* Quad-team shape of alg_newton_solve* (3-player planar double integrator without extended constraints, batch a multiple of
+ * four, waves per game 0 / 1): four games share a 256-thread workgroup, every wavefront runs its own game, and the Newton
+ * direction (solver_methods.jl:87) is a collective of the four wavefronts over the four games (DPP row products, three players
+ * on three SIMDs).  mode -1 (default) = automatic (off: measured slower than one game per
+ * workgroup at every batch size so far; ALGAMES_QT=1 in the environment turns it on), 0 = off, 1 = required
+ * (ALG_ERR_ARG when unsupported).  Results agree with the one-wavefront kernel to rounding.
+ * alg_get_quad_team reports whether the next alg_newton_solve will use it. */
+int  alg_set_quad_team(alg_handle* h, int32_t mode);
+int  alg_get_quad_team(alg_handle* h, int32_t* on);
 /* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = library stream. */
 int  alg_set_stream(alg_handle* h, void* hip_stream);
 

@@ -1383,6 +1383,8 @@ int orc_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_sta
 }
 int orc_debug_check_guards(alg_handle*) { return 0; }
 int orc_set_waves_per_game(alg_handle*, int32_t nw) { return (nw == 0 || nw == 1 || nw == 2 || nw == 4) ? ALG_OK : fail(ALG_ERR_ARG, "bad width"); }   // kernel shape: no meaning on the CPU (ABI mirror)
+int orc_set_quad_team(alg_handle*, int32_t mode) { return (mode >= -1 && mode <= 0) ? ALG_OK : fail(ALG_ERR_ARG, "quad team: a kernel shape of the HIP library"); }   // (ABI mirror)
+int orc_get_quad_team(alg_handle*, int32_t* on) { if (on) *on = 0; return ALG_OK; }
 int orc_get_waves_per_game(alg_handle*, int32_t* nw) { if (nw) *nw = 1; return ALG_OK; }      // host vectors: nothing to check (ABI mirror)
 int orc_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) { return orc_newton_solve(h, init, game_id0, nullptr); }
 int orc_get_stats(alg_handle* h, alg_game_stats* stats) { for (size_t gi = 0; gi < H->g.size(); gi++) stats[gi] = H->g[gi].st; return ALG_OK; }

@@ -10,3 +10,5 @@ from .host import *  # noqa: F401,F403
 from .host import hip_lib, HIP_LIB_PATH  # noqa: F401
 from . import scenarios  # noqa: F401,E402
 from . import active_set  # noqa: F401,E402
+from . import sharding  # noqa: F401,E402
+from .sharding import ShardedGameProblem  # noqa: F401,E402

@@ -86,6 +86,8 @@ SIGNATURES = {
     "set_lqr": (C.c_int, [_P, _D, _D, _D, _D, C.c_int32]),
     "add_collision_cost": (C.c_int, [_P, _D, _D]),
     "add_collision_avoidance": (C.c_int, [_P, _D]),
+    "add_collision_avoidance_pair": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double]),
+    "add_spherical_collision_avoidance_pair": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double]),
     "add_control_bound": (C.c_int, [_P, _D, _D]),
     "set_bicycle": (C.c_int, [_P, C.c_double, C.c_double]),
     "set_quadrotor": (C.c_int, [_P, C.c_double]),
@@ -311,6 +313,13 @@ class Batch:
         arrs = [_f64(a) for a in (xc, yc, radius)]
         self.lib.check(self.lib.add_circle_constraint_player(self.h, int(player), len(arrs[0]), *[_dptr(a) for a in arrs]))
         self._refresh_con_len()
+
+    def add_collision_avoidance_pair(self, i, j, radius, spherical=False):
+        """One ordered pair (0-based players), own radius: add_collision_avoidance!(game_con, i, j, radius)."""
+        fn = self.lib.add_spherical_collision_avoidance_pair if spherical else self.lib.add_collision_avoidance_pair
+        self.lib.check(fn(self.h, int(i), int(j), float(radius)))
+        if spherical:
+            self._refresh_con_len()
 
     def add_spherical_collision_avoidance(self, radius):
         r = _f64(np.broadcast_to(np.asarray(radius, dtype=np.float64), (self.p,)))

@@ -49,7 +49,12 @@ struct Params {
     double dt;
     alg_options opt;
     int has_colcost, has_colavoid, has_ctl, lqr_per_game;
-    double cc_radius[MAXP], cc_mu[MAXP], ca_radius[MAXP];
+    double cc_radius[MAXP], cc_mu[MAXP];
+    // collision avoidance of the ordered pair (i, j): radius of its CollisionConstraint and presence (bit j of ca_mask[i]);
+    // add_collision_avoidance!(game_con, i, j, radius) adds single pairs, the vector form all of them with r_i + r_j
+    // (constraints_methods.jl:5-43).  A pair whose bit is clear evaluates to c = 0 with a zero Jacobian: inert everywhere.
+    double ca_pair_r[MAXP * MAXP];
+    unsigned ca_mask[MAXP];
     double umax[MAXM], umin[MAXM];
     int hist_max;
     int kscratch_len;       // per game doubles of gain scratch
@@ -917,13 +922,14 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                             }
                         }
                         if (pr.has_colavoid) {                                   // CollisionConstraint + AL expansion
-                            const double Rr = pr.ca_radius[i] + pr.ca_radius[j];
+                            const double Rr = pr.ca_pair_r[i * MAXP + j];
+                            const double on = (double)((pr.ca_mask[i] >> j) & 1u);                    // 0: this ordered pair carries no constraint
                             double s2c = s2;
                             if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c += dl[2] * dl[2]; }   // spherical: pz[i][1:3]
-                            const double c = Rr * Rr - s2c;
+                            const double c = on * (Rr * Rr - s2c);
                             const int ci = con_col<C>(N, pairq<C>(i, j), kn);
-                            const double lm = G.lam(pr)[ci], am = al_active_mu(c, lm, G.mu(pr)[ci]);
-                            const double wl = lm + am * c;
+                            const double lm = G.lam(pr)[ci], am = on * al_active_mu(c, lm, G.mu(pr)[ci]);
+                            const double wl = on * lm + am * c;
 #pragma unroll
                             for (int a = 0; a < PD; a++) {
                                 gv[a] += -2.0 * dl[a] * wl;
@@ -2781,10 +2787,10 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
             constexpr int PM1 = P > 1 ? P - 1 : 1;
             const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / PM1, jj = q % PM1, j = jj < i ? jj : jj + 1;
             const double* x = zstate<C>(z, k);
-            const double d0 = x[i] - x[j], d1 = x[P + i] - x[P + j], R = pr.ca_radius[i] + pr.ca_radius[j];
+            const double d0 = x[i] - x[j], d1 = x[P + i] - x[P + j], R = pr.ca_pair_r[i * MAXP + j];
             double s2 = d0 * d0 + d1 * d1;
             if constexpr (C::PD == 3) { const double d2 = pr.ca_dim == 3 ? x[2 * P + i] - x[2 * P + j] : 0.0; s2 += d2 * d2; }
-            const double c = R * R - s2;
+            const double c = (double)((pr.ca_mask[i] >> j) & 1u) * (R * R - s2);
             G.vals(pr)[e] = c;
             const double lb = G.lam(pr)[e] + o.alphax_dual[i] * G.mu(pr)[e] * c;
             G.lam(pr)[e] = fmin(fmax(lb, 0.0), o.lambda_max);

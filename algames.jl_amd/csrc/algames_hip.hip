@@ -483,6 +483,18 @@ int alg_set_lqr(alg_handle* h, const double* Qd, const double* Rd, const double*
     return ALG_OK;
 }
 
+// the vector form of the adders: every ordered pair (i, j), radius r_i + r_j (constraints_methods.jl:21-33)
+void set_all_pairs(Params& p, const double* radius) {
+    for (int i = 0; i < MAXP; i++) {
+        p.ca_mask[i] = 0u;
+        for (int j = 0; j < MAXP; j++) {
+            p.ca_pair_r[i * MAXP + j] = 0.0;
+            if (i < p.p && j < p.p && i != j) { p.ca_pair_r[i * MAXP + j] = radius[i] + radius[j]; p.ca_mask[i] |= 1u << j; }
+        }
+    }
+}
+static int need_3d(Handle* hd, const char* who);
+static int ext_commit(Handle* hd);
 int alg_add_collision_cost(alg_handle* h, const double* radius, const double* mu) {
     NEED_HANDLE("alg_add_collision_cost");
     Params& p = H->pr;
@@ -494,8 +506,30 @@ int alg_add_collision_avoidance(alg_handle* h, const double* radius) {
     NEED_HANDLE("alg_add_collision_avoidance");
     Params& p = H->pr;
     if (!radius) { p.has_colavoid = 0; return ALG_OK; }
-    for (int i = 0; i < p.p; i++) p.ca_radius[i] = radius[i];
+    set_all_pairs(p, radius);
     p.has_colavoid = 1; p.ca_dim = 2; return ALG_OK;
+}
+// add_collision_avoidance!(game_con, i, j, radius) (constraints_methods.jl:5-19): ONE ordered pair with its own radius
+int add_pair(Handle* hd, const char* who, int i, int j, double radius, int dim) {
+    Params& p = hd->pr;
+    if (i < 0 || j < 0 || i >= p.p || j >= p.p || i == j) return fail(ALG_ERR_ARG, std::string(who) + ": players i != j in 0..p-1");
+    if (!(radius > 0.0)) return fail(ALG_ERR_ARG, std::string(who) + ": radius must be positive");
+    if (p.has_colavoid && p.ca_dim != dim) return fail(ALG_ERR_ARG, std::string(who) + ": planar and spherical collision avoidance cannot be mixed on one handle");
+    if (!p.has_colavoid) for (int a = 0; a < MAXP; a++) p.ca_mask[a] = 0u;
+    if ((p.ca_mask[i] >> j) & 1u) return fail(ALG_ERR_ARG, std::string(who) + ": this ordered pair already carries a collision-avoidance constraint (one per pair)");
+    p.ca_mask[i] |= 1u << j; p.ca_pair_r[i * MAXP + j] = radius;
+    p.has_colavoid = 1; p.ca_dim = dim;
+    return ALG_OK;
+}
+int alg_add_collision_avoidance_pair(alg_handle* h, int32_t i, int32_t j, double radius) {
+    NEED_HANDLE("alg_add_collision_avoidance_pair");
+    return add_pair(H, "alg_add_collision_avoidance_pair", i, j, radius, 2);
+}
+int alg_add_spherical_collision_avoidance_pair(alg_handle* h, int32_t i, int32_t j, double radius) {
+    NEED_HANDLE("alg_add_spherical_collision_avoidance_pair");
+    if (int rc = need_3d(H, "alg_add_spherical_collision_avoidance_pair")) return rc;
+    if (int rc = add_pair(H, "alg_add_spherical_collision_avoidance_pair", i, j, radius, 3)) return rc;
+    return ext_commit(H);
 }
 int alg_add_control_bound(alg_handle* h, const double* umax, const double* umin) {
     NEED_HANDLE("alg_add_control_bound");
@@ -570,6 +604,29 @@ int alg_add_wall_constraint(alg_handle* h, int32_t nw, const double* x1, const d
 }
 // add_wall_constraint!(game_con, i, walls) (constraints_methods.jl:161-187): the walls join the table (an entry that is already
 // there is shared) and constrain player `player` only
+// Per-player wall / circle sets: the entries join the handle's table (identical entries are shared) and set the player's mask bit.
+// Nothing is touched unless every new entry fits (the table is extended on a copy first).  After an all-player set
+// (alg_add_wall_constraint / alg_add_circle_constraint: every mask = all ones) the masks are first made explicit, so that an entry
+// added for one player does not silently constrain the others.
+static int add_table_entries(int F, int MAXE, Handle* hd, const char* who, double* T, const double* const* src, int cnt, int player, int& ntab, unsigned* mask) {
+    std::vector<double> tmp(T, T + F * MAXE); unsigned m2[MAXP];
+    for (int i = 0; i < MAXP; i++) m2[i] = ntab == 0 ? 0u : (mask[i] == 0xffffffffu ? (ntab >= 32 ? 0xffffffffu : (1u << ntab) - 1u) : mask[i]);
+    int n2 = ntab;
+    for (int w = 0; w < cnt; w++) {
+        int at = -1;
+        for (int e = 0; e < n2 && at < 0; e++) { bool same = true; for (int f = 0; f < F; f++) same &= (tmp[f * MAXE + e] == src[f][w]); if (same) at = e; }
+        if (at < 0) {
+            if (n2 >= MAXE) return fail(ALG_ERR_ARG, std::string(who) + ": more distinct entries than the table holds (ALG_MAX_WALLS / ALG_MAX_CIRCLES)");
+            at = n2++;
+            for (int f = 0; f < F; f++) tmp[f * MAXE + at] = src[f][w];
+        }
+        m2[player] |= 1u << at;
+    }
+    for (int e = 0; e < F * MAXE; e++) T[e] = tmp[e];
+    for (int i = 0; i < MAXP; i++) mask[i] = m2[i];
+    ntab = n2;
+    return ext_commit(hd);
+}
 int alg_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t nw, const double* x1, const double* y1, const double* x2, const double* y2, const double* xv, const double* yv) {
     if (!h) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: null handle");
     Params& p = H->pr;
@@ -577,20 +634,7 @@ int alg_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t nw, co
     if (nw < 0 || (nw > 0 && (!x1 || !y1 || !x2 || !y2 || !xv || !yv))) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: bad argument");
     double* W = H->extc.data() + 2 * p.p * p.n;
     const double* src[6] = {x1, y1, x2, y2, xv, yv};
-    if (p.nwall == 0) for (int i = 0; i < MAXP; i++) p.wall_mask[i] = 0u;       // first per-player set: nothing applies yet
-    Params q = p;                                                               // commit only if every wall fits
-    for (int w = 0; w < nw; w++) {
-        int at = -1;
-        for (int e = 0; e < q.nwall && at < 0; e++) { bool same = true; for (int f = 0; f < 6; f++) same &= (W[f * ALG_MAX_WALLS + e] == src[f][w]); if (same) at = e; }
-        if (at < 0) {
-            if (q.nwall >= ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: more than ALG_MAX_WALLS distinct walls");
-            at = q.nwall++;
-            for (int f = 0; f < 6; f++) W[f * ALG_MAX_WALLS + at] = src[f][w];
-        }
-        q.wall_mask[player] |= 1u << at;
-    }
-    p.nwall = q.nwall; for (int i = 0; i < MAXP; i++) p.wall_mask[i] = q.wall_mask[i];
-    return ext_commit(H);
+    return add_table_entries(6, ALG_MAX_WALLS, H, "alg_add_wall_constraint_player", W, src, nw, player, p.nwall, p.wall_mask);
 }
 int alg_add_circle_constraint(alg_handle* h, int32_t nc, const double* xc, const double* yc, const double* rad) {
     if (!h) return fail(ALG_ERR_ARG, "alg_add_circle_constraint: null handle");
@@ -611,20 +655,7 @@ int alg_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t nc, 
     if (nc < 0 || (nc > 0 && (!xc || !yc || !rad))) return fail(ALG_ERR_ARG, "alg_add_circle_constraint_player: bad argument");
     double* Cc = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS;
     const double* src[3] = {xc, yc, rad};
-    if (p.ncirc == 0) for (int i = 0; i < MAXP; i++) p.circ_mask[i] = 0u;
-    Params q = p;
-    for (int c = 0; c < nc; c++) {
-        int at = -1;
-        for (int e = 0; e < q.ncirc && at < 0; e++) { bool same = true; for (int f = 0; f < 3; f++) same &= (Cc[f * ALG_MAX_CIRCLES + e] == src[f][c]); if (same) at = e; }
-        if (at < 0) {
-            if (q.ncirc >= ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "alg_add_circle_constraint_player: more than ALG_MAX_CIRCLES distinct circles");
-            at = q.ncirc++;
-            for (int f = 0; f < 3; f++) Cc[f * ALG_MAX_CIRCLES + at] = src[f][c];
-        }
-        q.circ_mask[player] |= 1u << at;
-    }
-    p.ncirc = q.ncirc; for (int i = 0; i < MAXP; i++) p.circ_mask[i] = q.circ_mask[i];
-    return ext_commit(H);
+    return add_table_entries(3, ALG_MAX_CIRCLES, H, "alg_add_circle_constraint_player", Cc, src, nc, player, p.ncirc, p.circ_mask);
 }
 // ---- 3-D half (pz[i][1:3] = positions of DoubleIntegrator d = 3) -------------------------------------------------------
 static int need_3d(Handle* hd, const char* who) {
@@ -638,7 +669,7 @@ int alg_add_spherical_collision_avoidance(alg_handle* h, const double* radius) {
     Params& p = H->pr;
     if (!radius) { p.has_colavoid = 0; p.ca_dim = 2; return ALG_OK; }
     if (int rc = need_3d(H, "alg_add_spherical_collision_avoidance")) return rc;
-    for (int i = 0; i < p.p; i++) p.ca_radius[i] = radius[i];
+    set_all_pairs(p, radius);
     p.has_colavoid = 1; p.ca_dim = 3;
     return ext_commit(H);                      // the 3-D pair blocks live in the EXT instantiation
 }

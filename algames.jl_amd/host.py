@@ -297,6 +297,7 @@ class GameConstraintValues:
         self.αx_dual = [1.0] * probsize.p
         self.active_set_tolerance = 0.0  # game_constraints.jl:23; set_constraint_params! copies opts.active_set_tolerance (:37)
         self.collision_radius = None     # per player, pair radius = r_i + r_j
+        self.collision_pairs = {}        # (i, j) 1-based ordered pair -> radius of its own CollisionConstraint (the per-pair adders)
         self.u_max = None
         self.u_min = None
         self.state_bounds = {}           # player (1-based) -> merged (x_max, x_min) on the joint state
@@ -310,22 +311,36 @@ class GameConstraintValues:
         self.cylinders = None
 
 
-def add_collision_avoidance(game_con, radius):
-    """add_collision_avoidance!(game_con, radius), constraints_methods.jl:21-39."""
+def add_collision_avoidance(game_con, *args):
+    """add_collision_avoidance!(game_con, radius) (constraints_methods.jl:21-39: every ordered pair, r_i + r_j) or
+    add_collision_avoidance!(game_con, i, j, radius) (:5-19: ONE CollisionConstraint of player i against player j, 1-based, with
+    its own radius)."""
     p = game_con.probsize.p
+    if len(args) == 3:
+        i, j, radius = int(args[0]), int(args[1]), float(args[2])
+        if not (1 <= i <= p and 1 <= j <= p and i != j):
+            raise AlgamesError("add_collision_avoidance!(game_con, i, j, radius): players i != j in 1..p")
+        if game_con.collision_radius is not None or (i, j) in game_con.collision_pairs:
+            raise AlgamesError("one collision-avoidance constraint per ordered pair is supported")
+        game_con.collision_pairs[(i, j)] = radius
+        return
+    (radius,) = args
     r = np.asarray(radius, dtype=np.float64)
     if r.ndim == 0:
         r = r * np.ones(p)
     assert p == len(r)
-    if game_con.collision_radius is not None:
+    if game_con.collision_radius is not None or game_con.collision_pairs:
         raise AlgamesError("only one collision-avoidance set per GameConstraintValues is supported")
     game_con.collision_radius = r
 
 
-def add_spherical_collision_avoidance(game_con, radius):
-    """add_spherical_collision_avoidance!(game_con, radius), constraints_methods.jl:63-81: CollisionConstraint on pz[i][1:3]
-    (the x, y, z positions of a DoubleIntegratorGame with d = 3; other models are rejected when the problem is built)."""
-    add_collision_avoidance(game_con, radius)
+def add_spherical_collision_avoidance(game_con, *args):
+    """add_spherical_collision_avoidance!(game_con, radius) / (game_con, i, j, radius), constraints_methods.jl:45-81:
+    CollisionConstraint on pz[i][1:3] (the x, y, z positions of a DoubleIntegratorGame with d = 3 or a Quadrotor; other models
+    are rejected when the problem is built)."""
+    if (game_con.collision_radius is not None or game_con.collision_pairs) and not game_con.spherical:
+        raise AlgamesError("planar and spherical collision avoidance cannot be mixed")
+    add_collision_avoidance(game_con, *args)
     game_con.spherical = True
 
 
@@ -598,6 +613,8 @@ class GameProblem:
                 self.batch.add_spherical_collision_avoidance(game_con.collision_radius)
             else:
                 self.batch.add_collision_avoidance(game_con.collision_radius)
+        for (i, j) in sorted(game_con.collision_pairs):
+            self.batch.add_collision_avoidance_pair(i - 1, j - 1, game_con.collision_pairs[(i, j)], spherical=game_con.spherical)
         if game_con.u_max is not None:
             self.batch.add_control_bound(game_con.u_max, game_con.u_min)
         for i in sorted(game_con.state_bounds):
@@ -657,7 +674,11 @@ class GameProblem:
 # --------------------------------------------------------------------------------------------------
 def newton_solve(prob, init=True):
     """newton_solve!(prob) for every game of the batch (solver_methods.jl:5-65).
-    init=False keeps the stored controls/duals as the initial guess (explicit warm start)."""
+    init=False keeps the stored controls/duals as the initial guess (explicit warm start).
+    A `sharding.ShardedGameProblem` (batch split over several devices) is solved on all of its devices concurrently."""
+    if hasattr(prob, "shards"):
+        from . import sharding
+        return sharding.newton_solve_sharded(prob, init=init)
     prob._sync_options()
     summary = prob.batch.newton_solve(init=init, game_id0=prob.game_id0)
     prob.stats = Statistics(summary, prob.batch.get_history)

@@ -10,6 +10,7 @@
 #   ibr_newton_solve!(bp; ibr_opts), ibr_newton_solve!(bp, i)     solver_methods.jl:133-228
 #   mpc_solve!(bp, steps)                             receding-horizon loop of BASELINE config 5 (opts.shift / opts.dual_reset)
 #   newton_solve!(probs::Vector{<:GameProblem})       convenience: build a handle, solve, release
+#   sp = ShardedGameProblem(probs; devices=0:7); newton_solve!(sp)     the batch split over several devices (one handle each)
 # After a solve every `prob.pdtraj`, the multipliers / penalties / values of every constraint (`conval.λ`, `.μ`, `.vals`,
 # constraints_methods.jl:329-379) and `prob.stats` (struct/statistics.jl:5-57) hold what the reference's solver would have left.
 module AlgamesHIP
@@ -76,8 +77,13 @@ mutable struct BatchedGameProblem{P<:GameProblem}
     con_len::Int
     function BatchedGameProblem(probs::Vector{P}; device::Integer=0) where {P<:GameProblem}
         bp = new{P}(probs, C_NULL, 0)
-        setup!(bp, device)
-        finalizer(close, bp)
+        finalizer(close, bp)                                        # registered first: a failing setup! must not leak the handle
+        try
+            setup!(bp, device)
+        catch
+            close(bp)
+            rethrow()
+        end
         return bp
     end
 end
@@ -125,19 +131,17 @@ function setup!(bp::BatchedGameProblem, device)
         check(ccall((:alg_add_collision_cost, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), bp.h, rad, mu))
     end
     # state constraints of player i, in the order they were added (constraints_methods.jl): dispatch on the type
-    colcons = [cv.con for cv in prob.game_con.state_conval[1] if cv.con isa TO.CollisionConstraint]
-    if p > 1 && !isempty(colcons)
-        # collision avoidance: con.radius = r_i + r_j (constraints_methods.jl:27-29) -> per-player radii
-        col2 = [cv.con for cv in prob.game_con.state_conval[2] if cv.con isa TO.CollisionConstraint]
-        R12 = colcons[1].radius                                     # r_1 + r_2
-        R1p = p > 2 ? colcons[2].radius : R12                       # r_1 + r_3
-        R2p = p > 2 ? col2[2].radius : R12                          # r_2 + r_3
-        r1 = p > 2 ? (R12 + R1p - R2p) / 2 : R12 / 2
-        radius = [i == 1 ? r1 : colcons[i-1].radius - r1 for i in 1:p]
-        # add_spherical_collision_avoidance! builds the constraint on pz[i][1:3] (three indices) instead of px[i] (two)
-        spherical = length(colcons[1].x1) == 3
-        check(spherical ? ccall((:alg_add_spherical_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), bp.h, radius) :
-                          ccall((:alg_add_collision_avoidance, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), bp.h, radius))
+    # collision avoidance: every CollisionConstraint of player i's state constraints is ONE ordered pair (i, j) with its own radius
+    # (add_collision_avoidance!(game_con, i, j, radius), constraints_methods.jl:5-19; the vector form adds all pairs with r_i + r_j,
+    # :21-33).  add_spherical_collision_avoidance! builds the constraint on pz[i][1:3] (three indices) instead of px[i] (two).
+    for i in 1:p, cv in prob.game_con.state_conval[i]
+        con = cv.con
+        con isa TO.CollisionConstraint || continue
+        j = partner_of(ps, con)
+        fn = length(con.x1) == 3 ? :alg_add_spherical_collision_avoidance_pair : :alg_add_collision_avoidance_pair
+        check(fn === :alg_add_collision_avoidance_pair ?
+              ccall((:alg_add_collision_avoidance_pair, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Float64), bp.h, i - 1, j - 1, con.radius) :
+              ccall((:alg_add_spherical_collision_avoidance_pair, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Float64), bp.h, i - 1, j - 1, con.radius))
     end
     if prob.model isa BicycleGame
         check(ccall((:alg_set_bicycle, LIB), Cint, (Ptr{Cvoid}, Float64, Float64), bp.h, prob.model.lf, prob.model.lr))
@@ -178,6 +182,28 @@ function setup!(bp::BatchedGameProblem, device)
     return bp
 end
 
+# player j whose position indices a CollisionConstraint of player i points at (x2 = px[j] or pz[j][1:3])
+partner_of(ps, con) = findfirst(q -> all(con.x2 .== ps.px[q][1:length(con.x2)]) || all(con.x2 .== ps.pz[q][1:length(con.x2)]), 1:ps.p)
+
+# The library keeps ONE table of distinct walls (circles) per handle; alg_add_wall_constraint_player appends the entries it has not
+# seen, in call order, and row w of the ABI's wall block is table entry w for every player (include/algames_hip.h).  The same
+# table is rebuilt here from the constraint objects, in the order setup! made the calls (players 1..p, their convals in order), so
+# that a conval's row r maps to its table index.
+wall_key(con, r) = (con.x1[r], con.y1[r], con.x2[r], con.y2[r], con.xv[r], con.yv[r])
+circ_key(con, r) = (con.x[r], con.y[r], con.radius[r])
+function constraint_tables(prob)
+    walls = Tuple[]; circs = Tuple[]
+    for i in 1:prob.probsize.p, cv in prob.game_con.state_conval[i]
+        con = cv.con
+        if con isa Algames.WallConstraint
+            for r in 1:length(con); k = wall_key(con, r); k in walls || push!(walls, k); end
+        elseif con isa TO.CircleConstraint
+            for r in 1:length(con); k = circ_key(con, r); k in circs || push!(circs, k); end
+        end
+    end
+    return walls, circs
+end
+
 # ---- layout of the ABI's constraint vectors (include/algames_hip.h "Layouts") -----------------------------------------------
 # Returns, for constraint value object `cv` of player i (0 = shared control constraint), a function (l, r) -> 1-based position in
 # the ABI vector of row r (1-based, in the conval's own row numbering) at the l-th knot index of the conval.
@@ -185,14 +211,14 @@ function abi_position(bp::BatchedGameProblem, cv, i::Int)
     prob = bp.probs[1]; ps = prob.probsize; N, n, m, p = ps.N, ps.n, ps.m, ps.p
     K = N - 1
     con = cv.con
-    col_len = p > 1 && any(c -> c.con isa TO.CollisionConstraint, prob.game_con.state_conval[1]) ? p * (p - 1) * K : 0
-    ctl_len = isempty(prob.game_con.control_conval) ? 0 : 2m * K
+    col_len = p * (p - 1) * K                                        # the ABI always carries the collision-avoidance and control-bound rows
+    ctl_len = 2m * K                                                # (include/algames_hip.h "Layouts"); rows that were never added are inert
     has_sb = any(c -> c.con isa Algames.StateBoundConstraint, vcat(prob.game_con.state_conval...))
     sb_len = has_sb ? p * 2n * K : 0
-    nwall = maximum([sum(Int[length(c.con) for c in prob.game_con.state_conval[q] if c.con isa Algames.WallConstraint]) for q in 1:p])
-    ncirc = maximum([sum(Int[length(c.con) for c in prob.game_con.state_conval[q] if c.con isa TO.CircleConstraint]) for q in 1:p])
+    walls, circs = constraint_tables(prob)                           # distinct entries in call order = the library's tables
+    nwall, ncirc = length(walls), length(circs)
     if con isa TO.CollisionConstraint                               # rows: pair q = (i, j), knot k = 2..N
-        j = findfirst(q -> all(con.x2 .== ps.px[q][1:length(con.x2)]) || all(con.x2 .== ps.pz[q][1:length(con.x2)]), 1:p)
+        j = partner_of(ps, con)
         q = (i - 1) * (p - 1) + (j < i ? j : j - 1) - 1
         return (l, r) -> q * K + (cv.inds[l] - 2) + 1
     elseif con isa Algames.ControlBoundConstraint                   # knot k = 1..N-1: (u - u_max)(m) then (u_min - u)(m); the reference keeps finite rows only
@@ -201,10 +227,12 @@ function abi_position(bp::BatchedGameProblem, cv, i::Int)
     elseif con isa Algames.StateBoundConstraint                     # player i, knot k = 2..N: (x - x_max)(n) then (x_min - x)(n), finite rows
         fin = con.inds
         return (l, r) -> col_len + ctl_len + ((i - 1) * K + (cv.inds[l] - 2)) * 2n + fin[r]
-    elseif con isa Algames.WallConstraint
-        return (l, r) -> col_len + ctl_len + sb_len + ((i - 1) * K + (cv.inds[l] - 2)) * nwall + r
+    elseif con isa Algames.WallConstraint                           # row r of the conval = table entry w(r)
+        tw = [findfirst(==(wall_key(con, r)), walls) for r in 1:length(con)]
+        return (l, r) -> col_len + ctl_len + sb_len + ((i - 1) * K + (cv.inds[l] - 2)) * nwall + tw[r]
     elseif con isa TO.CircleConstraint
-        return (l, r) -> col_len + ctl_len + sb_len + p * nwall * K + ((i - 1) * K + (cv.inds[l] - 2)) * ncirc + r
+        tc = [findfirst(==(circ_key(con, r)), circs) for r in 1:length(con)]
+        return (l, r) -> col_len + ctl_len + sb_len + p * nwall * K + ((i - 1) * K + (cv.inds[l] - 2)) * ncirc + tc[r]
     elseif con isa Algames.Wall3DConstraint || con isa Algames.CylinderConstraint
         nw3 = sum(Int[length(c.con) for c in prob.game_con.state_conval[1] if c.con isa Algames.Wall3DConstraint])
         ncy = sum(Int[length(c.con) for c in prob.game_con.state_conval[1] if c.con isa Algames.CylinderConstraint])
@@ -296,7 +324,7 @@ Batched drop-in for `newton_solve!(prob)` (src/problem/solver_methods.jl:5-65). 
 problems currently hold as the initial guess (`alg_set_traj`); with `opts.dual_reset == false` the constraint multipliers and
 penalties the problems hold are pushed first (warm start).  Returns the per-game `AlgGameStats`.
 """
-function newton_solve!(bp::BatchedGameProblem; game_id0::Integer=0, init::Bool=true)
+function newton_solve!(bp::BatchedGameProblem; game_id0::Integer=0, init::Bool=true, async::Bool=false)
     sync_options!(bp)
     B = length(bp.probs); ps = bp.probs[1].probsize
     bp.probs[1].opts.dual_reset || push_duals!(bp)
@@ -309,8 +337,48 @@ function newton_solve!(bp::BatchedGameProblem; game_id0::Integer=0, init::Bool=t
         check(ccall((:alg_set_traj, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), bp.h, 0, z))
     end
     stats = Vector{AlgGameStats}(undef, B)
+    if async                                                        # ShardedGameProblem: every device is launched before the first wait
+        check(ccall((:alg_newton_solve_async, LIB), Cint, (Ptr{Cvoid}, Int32, Int64), bp.h, init ? 1 : 0, game_id0))
+        return nothing
+    end
     check(ccall((:alg_newton_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Int64, Ptr{AlgGameStats}), bp.h, init ? 1 : 0, game_id0, stats))
     return pull_results!(bp, stats)
+end
+
+"Waits for an asynchronous solve of the handle and writes the results back into its problems."
+function finish!(bp::BatchedGameProblem)
+    check(ccall((:alg_synchronize, LIB), Cint, (Ptr{Cvoid},), bp.h))
+    stats = Vector{AlgGameStats}(undef, length(bp.probs))
+    check(ccall((:alg_get_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{AlgGameStats}), bp.h, stats))
+    return pull_results!(bp, stats)
+end
+
+"""
+    ShardedGameProblem(probs; devices=0:7)
+
+The batch split over several devices (BASELINE north_star: "the batch shards naturally across the 8 GPUs"; SURVEY.md 8(e)): shard r
+owns the contiguous problems `cuts[r]` and the global scenario ids `game_id0 + first(cuts[r]) - 1 ...`, one `BatchedGameProblem`
+(device handle + stream) per entry of `devices`.  `newton_solve!` launches every shard (`alg_newton_solve_async`) before it waits
+for the first one; there is no data-path collective.  Python twin: `algames.jl_amd/sharding.py` (`ShardedGameProblem`,
+tests/test_gpu_boundary.py::test_multi_device_solve_behind_the_boundary_two_handles_on_one_gpu).
+"""
+struct ShardedGameProblem{P<:GameProblem}
+    shards::Vector{BatchedGameProblem{P}}
+    cuts::Vector{UnitRange{Int}}
+end
+function ShardedGameProblem(probs::Vector{P}; devices=0:0) where {P<:GameProblem}
+    B, W = length(probs), length(devices)
+    per = cld(B, W)                                                 # scenarios.shard_range: ceil(B / W) games per shard, last ones shorter
+    cuts = [min((r - 1) * per, B)+1:min(r * per, B) for r in 1:W]
+    keep = [r for r in 1:W if !isempty(cuts[r])]
+    ShardedGameProblem{P}([BatchedGameProblem(probs[cuts[r]]; device=collect(devices)[r]) for r in keep], cuts[keep])
+end
+Base.close(sp::ShardedGameProblem) = foreach(close, sp.shards)
+function newton_solve!(sp::ShardedGameProblem; game_id0::Integer=0, init::Bool=true)
+    for (bp, r) in zip(sp.shards, sp.cuts)
+        newton_solve!(bp; game_id0=game_id0 + first(r) - 1, init=init, async=true)
+    end
+    return vcat([finish!(bp) for bp in sp.shards]...)
 end
 
 function newton_solve!(probs::Vector{<:GameProblem}; device::Integer=0, game_id0::Integer=0)

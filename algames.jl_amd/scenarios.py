@@ -146,9 +146,9 @@ def quadrotor_crossing(ids, N=20, seed=100, p=2):
     return model, N, dt, x0, game_obj, game_con, opts
 
 
-def make_problem(cfg, ids, backend=None, device=0, **kw):
+def make_problem(cfg, ids, backend=None, device=0, devices=None, **kw):
     """cfg in {'C2','C3','C4','C5'} (BASELINE configurations) or 'Q' (quadrotors) -> GameProblem over the scenarios `ids`
-    (global scenario ids)."""
+    (global scenario ids).  devices=[...]: a sharding.ShardedGameProblem, the batch split contiguously over those devices."""
     ids = np.asarray(ids, dtype=np.int64)
     if cfg in ("C2", "C4"):                      # C4 = the C2 problem, 65 536 scenarios sharded over 8 GPUs
         model, N, dt, x0, obj, con, opts = c2_double_integrator(ids, **kw)
@@ -163,4 +163,7 @@ def make_problem(cfg, ids, backend=None, device=0, **kw):
     contiguous = len(ids) > 0 and np.array_equal(ids, ids[0] + np.arange(len(ids)))
     if not contiguous:
         raise ValueError("scenario ids of one problem must be contiguous (the device RNG is keyed by game_id0 + g)")
+    if devices is not None:
+        from . import sharding
+        return sharding.ShardedGameProblem(N, dt, x0, model, opts, obj, con, devices=devices, backend=backend, game_id0=int(ids[0]))
     return host.GameProblem(N, dt, x0, model, opts, obj, con, backend=backend, device=device, game_id0=int(ids[0]))

@@ -82,30 +82,19 @@ def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0):
 
 
 # --------------------------------------------------------------------------------------------------
-# Sharding + reduction: the N > 1 path.  tests/test_sharding_gloo.py runs exactly these two functions with
-# world_size 2 on the gloo backend (the CPU oracle standing in for the device there).
+# Sharding + reduction: the N > 1 path lives in the package (algames.jl_amd/sharding.py); bench.py only maps its
+# configuration names.  tests/test_sharding_gloo.py runs the package functions with world_size 2 on gloo.
 # --------------------------------------------------------------------------------------------------
 def make_shard(alg, config, games_per_rank, rank, world, backend=None, device=0, **kw):
-    """Rank `rank` of `world` owns the contiguous global scenario ids [rank*G, (rank+1)*G): all
-    random inputs are keyed by global id, so the shard layout does not change them."""
-    import numpy as np
-    family = CONFIGS[config][0]
-    lo, hi = alg.scenarios.shard_range(games_per_rank * world, rank, world)
-    ids = np.arange(lo, hi)
-    prob = alg.scenarios.make_problem(family, ids, backend=backend, device=device, **{**CONFIG_KW.get(config, {}), **kw})
-    return prob, ids
+    """The rank's shard of a bench configuration: a thin caller of the package's `sharding.make_shard` (contiguous global
+    scenario ids)."""
+    return alg.sharding.make_shard(CONFIGS[config][0], games_per_rank, rank, world, backend=backend, device=device,
+                                   **{**CONFIG_KW.get(config, {}), **kw})
 
 
-def reduce_counters(counts, elapsed, world, device):
-    """Sum of the per-rank integer counters and max of the per-rank wall time (the only collectives of the run)."""
-    import torch
-    import torch.distributed as dist
-    tot = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device)
-    tmax = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    return [int(v) for v in tot.tolist()], float(tmax.item())
+def reduce_counters(alg, counts, elapsed, world, device):
+    """Sum of the per-rank counters, max of the per-rank wall time: the package's `sharding.reduce_counters` (the only collectives)."""
+    return alg.sharding.reduce_counters(counts, elapsed, world, device)
 
 
 def _free_port():
@@ -148,6 +137,73 @@ def committed_profile(config, games_per_gpu, mpc_steps):
     return best
 
 
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+               "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE"))
+
+
+def inrun_pmc(argv_tail, kernel, iters_per_launch, own_bytes, timeout_s=150):
+    """Hardware counters of THIS run's workload, measured now: after the timed region rank 0 starts one short child of this very
+    script per counter group under `rocprofv3 --pmc ... --kernel-trace` (counter passes on their own, as the MI355X guide
+    prescribes; FETCH_SIZE x 2 = the gfx950 correction calibrated with scratch/pmc_calib.hip, KB units) and averages the solver
+    kernel's launches.  Returns None when rocprofv3 is missing or a pass fails (the caller then falls back to the committed
+    profile and says so)."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    cnt, dur_ns, ncalls = {}, [], 0
+    work = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    try:
+        for i, group in enumerate(PMC_PASSES):
+            out = os.path.join(work, f"p{i}")
+            cmd = [exe, "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            acc, disp = {}, {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel not in row["Kernel_Name"]:
+                        continue
+                    acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    disp.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
+            if not acc:
+                return None
+            for k, v in acc.items():
+                cnt[k] = v / len(disp[k])
+            for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel in row["Kernel_Name"]:
+                        dur_ns.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F64")
+    if any(k not in cnt for k in need) or not dur_ns:
+        return None
+    t = sum(dur_ns) / len(dur_ns) * 1e-9
+    hbm = 1024.0 * (2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"])
+    simd_quads = cnt["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0      # 8 XCDs report their cycles; 1024 SIMDs; quad-cycle = 4 clocks
+    res = {"traffic": hbm, "traffic_over_model": hbm / (own_bytes * iters_per_launch),
+           "valu_issue_frac": cnt["SQ_ACTIVE_INST_VALU"] / simd_quads,
+           "mfma_frac": cnt["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / t / F64_PEAK,
+           "kernel_ms_profiled": 1e3 * t,
+           "pmc_source": "in-run: %d rocprofv3 --pmc passes of a 2-step child of this command, started after the timed region" % len(PMC_PASSES)}
+    if "SQ_WAVE_CYCLES" in cnt and cnt["SQ_WAVE_CYCLES"] > 0:
+        res["wave_issue_frac"] = cnt.get("SQ_ACTIVE_INST_ANY", 0.0) / cnt["SQ_WAVE_CYCLES"]
+        res["wave_wait_frac"] = cnt.get("SQ_WAIT_ANY", 0.0) / cnt["SQ_WAVE_CYCLES"]
+    if "SQ_INSTS_VALU" in cnt:
+        res["valu_insts_per_game_iter"] = cnt["SQ_INSTS_VALU"] / iters_per_launch
+        res["salu_insts_per_game_iter"] = cnt.get("SQ_INSTS_SALU", 0.0) / iters_per_launch
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +216,7 @@ def main():
     ap.add_argument("--waves-per-game", type=int, default=0, choices=[0, 1, 2, 4],
                     help="kernel shape of the fused solver: wavefronts per game (0 = the library's automatic choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (the children of a run use this)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -242,7 +299,7 @@ def main():
     # one launch lasts as long as its slowest game: mean / max of the per-game iteration counts (1.0 = homogeneous batch)
     balance = float(per_game.mean() / max(1, per_game.max()))
     bad_rank = int((st["status"] != 0).sum())
-    (iters_all, conv_all, bad_all), elapsed = reduce_counters([iters_rank, conv_rank, bad_rank], elapsed, world, "cuda")
+    (iters_all, conv_all, bad_all), elapsed = reduce_counters(alg, [iters_rank, conv_rank, bad_rank], elapsed, world, "cuda")
 
     if rank == 0:
         K = args.steps
@@ -264,14 +321,23 @@ def main():
             # context only (SURVEY.md 8(d) priced a dense block-LU with factor spill; this kernel never performs it)
             "survey_dense_lu_bytes_per_game_iter": survey_balg(N, n, m, p),
         }
-        prof = committed_profile(args.config, G, args.mpc_steps)
-        if prof is not None:
-            _, pf, pj = prof
-            roof["traffic"] = pj.get("hbm_bytes_per_launch")
-            for k in ("valu_issue_frac", "mfma_frac", "wave_issue_frac", "traffic_over_model"):
-                if k in pj:
-                    roof[k] = pj[k]
-            roof["pmc_source"] = os.path.relpath(pf, ROOT) + " (separate rocprofv3 --pmc passes of this command; not re-measured in this run)"
+        pmc = None
+        if world == 1 and not args.no_pmc:
+            tail = ["--config", args.config, "--games-per-gpu", str(G), "--waves-per-game", str(args.waves_per_game)]
+            if args.mpc_steps:
+                tail += ["--mpc-steps", str(args.mpc_steps)]
+            pmc = inrun_pmc(tail, kernel, iters_rank, own)
+        if pmc is not None:
+            roof.update(pmc)
+        elif not args.no_pmc:
+            prof = committed_profile(args.config, G, args.mpc_steps)
+            if prof is not None:
+                _, pf, pj = prof
+                roof["traffic"] = pj.get("hbm_bytes_per_launch")
+                for k in ("valu_issue_frac", "mfma_frac", "wave_issue_frac", "traffic_over_model"):
+                    if k in pj:
+                        roof[k] = pj[k]
+                roof["pmc_source"] = "committed: " + os.path.relpath(pf, ROOT) + " (the in-run rocprofv3 passes were not available; not re-measured in this run)"
         out = {
             "metric": "newton_iters_per_sec", "value": value, "unit": "game-Newton-iterations/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
@@ -346,9 +412,15 @@ def cpu_baseline(alg, family, G, mpc_steps=0, cfg_kw=None):
 
     nsample = int(max(8, 16 * cores))
     it, cv, dt, what = run(nsample)
-    if dt < 4.0:                                                    # aim at ~10 s of wall time on all cores, bounded
+    if dt < 4.0:                                                    # a bigger sample first (bounded: host memory)
         nsample = int(min(64 * cores, max(nsample, nsample * 10.0 / max(dt, 1e-3))))
         it, cv, dt, what = run(nsample)
+    reps = 1
+    while dt < 6.0 and reps < 64:                                   # ... then repeat it until >= 6 s of OpenMP work are timed
+        it2, cv2, dt2, _ = run(nsample)
+        it += it2; cv += cv2; dt += dt2; reps += 1
+    if reps > 1:
+        what += f", sample solved {reps} times"
     orc.set_threads(1)
     n1 = 24 if not mpc_steps else 8
     it1, cv1, dt1, _ = run(n1)

@@ -184,6 +184,14 @@ int alg_set_lqr(alg_handle* h, const double* Qdiag, const double* Rdiag, const d
 int alg_add_collision_cost(alg_handle* h, const double* radius /*p*/, const double* mu /*p*/);
 /* add_collision_avoidance!(game_con, radius::Vector) (constraints_methods.jl:21-33) */
 int alg_add_collision_avoidance(alg_handle* h, const double* radius /*p*/);
+/* add_collision_avoidance!(game_con, i, j, radius) (constraints_methods.jl:5-19) and
+ * add_spherical_collision_avoidance!(game_con, i, j, radius) (:45-64): ONE CollisionConstraint of player i against player j
+ * (0-based) with its own radius -- asymmetric radii or a subset of the ordered pairs.  The multiplier / value rows keep the
+ * all-pairs layout [pair q = i (p-1) + (j < i ? j : j-1)][knot]; a pair that was never added is inert (c = 0, zero Jacobian,
+ * multiplier stays 0).  The first pair call on a handle starts from "no pair"; the vector forms (alg_add_collision_avoidance,
+ * alg_add_spherical_collision_avoidance) set every ordered pair to r_i + r_j.  One constraint per ordered pair. */
+int alg_add_collision_avoidance_pair(alg_handle* h, int32_t i, int32_t j, double radius);
+int alg_add_spherical_collision_avoidance_pair(alg_handle* h, int32_t i, int32_t j, double radius);
 /* add_control_bound!(game_con, u_max, u_min) (constraints_methods.jl:104-115); +-inf allowed */
 int alg_add_control_bound(alg_handle* h, const double* u_max /*m*/, const double* u_min /*m*/);
 

@@ -254,7 +254,11 @@ struct Shared {
     alg_options opt;
     bool has_colcost = false, has_colavoid = false, has_ctl = false;
     std::vector<double> cc_radius, cc_mu;   // collision cost (objective.jl:84-100)
-    std::vector<double> ca_radius;          // collision avoidance radii per player
+    std::vector<double> ca_radius;          // collision avoidance radii per player (vector form of the adder)
+    // per ordered pair: radius of its CollisionConstraint, < 0 = this pair carries none (add_collision_avoidance!(game_con, i, j, radius),
+    // constraints_methods.jl:5-19; the vector form fills every pair with r_i + r_j, :21-33)
+    std::vector<double> pair_r;
+    bool pair_on(int i, int j) const { return pair_r[(size_t)i * D.p + j] >= 0.0; }
     std::vector<double> umax, umin;         // control bound
     std::vector<double> sbmax, sbmin;       // state bounds [p][n] (+-inf where absent)
     std::vector<double> wx1, wy1, wx2, wy2, wxv, wyv;   // walls
@@ -372,7 +376,7 @@ inline int con_ctl(const Dims& D, int k /*0..N-2*/, int row) { return D.col_len 
 // d c/d x2 = 2 d  [restated; parity unpinned].  Pair radius = r_i + r_j (constraints_methods.jl:27-29).
 inline double colavoid_val(const Shared& sh, int i, int j, const double* x, double* dl) {
     const Dims& D = sh.D;
-    double R = sh.ca_radius[i] + sh.ca_radius[j], s = 0;
+    double R = sh.pair_r[(size_t)i * D.p + j], s = 0;
     // add_collision_avoidance!: px[i] (2 positions, constraints_methods.jl:13); add_spherical_collision_avoidance!: pz[i][1:3] (:52-54)
     for (int a = 0; a < D.ca_dim; a++) { dl[a] = x[D.pz(i, a)] - x[D.pz(j, a)]; s += dl[a] * dl[a]; }
     return R * R - s;
@@ -458,7 +462,7 @@ void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
     const Dims& D = sh.D;
     std::vector<double> u(D.m);
     if (sh.has_colavoid)
-        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i)
+        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i && sh.pair_on(i, j))
             for (int k = 1; k < D.N; k++) { double dl[3]; g.vals[con_col(D, D.pair(i, j), k)] = colavoid_val(sh, i, j, state(D, z, k), dl); }
     if (sh.has_ctl)
         for (int k = 0; k < D.N - 1; k++) { get_control(D, z, k, u.data()); for (int r = 0; r < 2 * D.m; r++) g.vals[con_ctl(D, k, r)] = ctl_val(sh, u.data(), r); }
@@ -511,7 +515,7 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
     }
     // Constraints: constraint_residual! (constraint_derivatives.jl:39-74)
     if (sh.has_colavoid) {
-        for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i) {
+        for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i && sh.pair_on(i, j)) {
             const int qd = D.pair(i, j);
             for (int k = 1; k < N; k++) {
                 double dl[3];
@@ -588,7 +592,7 @@ void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double re
     }
     // Constraints: constraint_jacobian_residual! (constraint_derivatives.jl:1-36)
     if (sh.has_colavoid) {
-        for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i) {
+        for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i && sh.pair_on(i, j)) {
             const int qd = D.pair(i, j);
             for (int k = 1; k < N; k++) {
                 double dl[3];
@@ -824,7 +828,7 @@ void dual_penalty_update(const Shared& sh, Game& g) {
     const Dims& D = sh.D; const alg_options& o = sh.opt;
     evaluate_con(sh, g, g.z[0]);
     if (sh.has_colavoid)
-        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i) for (int k = 1; k < D.N; k++) {
+        for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i && sh.pair_on(i, j)) for (int k = 1; k < D.N; k++) {
             const int ci = con_col(D, D.pair(i, j), k);
             const double lb = g.lam[ci] + o.alphax_dual[i] * g.mu[ci] * g.vals[ci];
             g.lam[ci] = std::min(std::max(lb, 0.0), o.lambda_max);
@@ -985,7 +989,7 @@ alg_record ibr_record(const Shared& sh, Game& g, double delta, int outer, int i)
     }
     rc.con_vio = cv;
     double sv = 0;                                               // state_violation(game_con, pdtraj, i): player i's convals
-    if (sh.has_colavoid) for (int j = 0; j < D.p; j++) if (j != i) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, D.pair(i, j), k)]));
+    if (sh.has_colavoid) for (int j = 0; j < D.p; j++) if (j != i && sh.pair_on(i, j)) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, D.pair(i, j), k)]));
     for (int k = 1; k < D.N; k++) {
         if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { double v = g.vals[D.o_sb(i, k, r)]; if (std::isfinite(v)) sv = std::max(sv, std::max(0.0, v)); }
         for (int w = 0; w < D.nwall; w++) sv = std::max(sv, std::max(0.0, g.vals[D.o_wall(i, k, w)]));
@@ -1173,11 +1177,30 @@ int orc_add_collision_cost(alg_handle* h, const double* radius, const double* mu
     if (!radius || !mu) { s.has_colcost = false; return ALG_OK; }
     s.cc_radius.assign(radius, radius + s.D.p); s.cc_mu.assign(mu, mu + s.D.p); s.has_colcost = true; return ALG_OK;
 }
+// vector form: add_collision_avoidance!(game_con, radius::Vector) loops over i, j != i with r_i + r_j (constraints_methods.jl:21-33)
+static void set_all_pairs(Shared& s, const double* radius) {
+    const int p = s.D.p;
+    s.ca_radius.assign(radius, radius + p);
+    s.pair_r.assign((size_t)p * p, -1.0);
+    for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i) s.pair_r[(size_t)i * p + j] = radius[i] + radius[j];
+}
 int orc_add_collision_avoidance(alg_handle* h, const double* radius) {
     Shared& s = H->sh;
     if (!radius) { s.has_colavoid = false; return ALG_OK; }
-    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; s.D.ca_dim = 2; return ALG_OK;
+    set_all_pairs(s, radius); s.has_colavoid = true; s.D.ca_dim = 2; return ALG_OK;
 }
+// add_collision_avoidance!(game_con, i, j, radius) (constraints_methods.jl:5-19): one CollisionConstraint(n, px[i], px[j], radius)
+static int add_pair(Handle* hd, const char* who, int i, int j, double radius, int dim) {
+    Shared& s = hd->sh; const int p = s.D.p;
+    if (i < 0 || j < 0 || i >= p || j >= p || i == j) return fail(ALG_ERR_ARG, std::string(who) + ": players i != j in 0..p-1");
+    if (!(radius > 0.0)) return fail(ALG_ERR_ARG, std::string(who) + ": radius must be positive");
+    if (s.has_colavoid && s.D.ca_dim != dim) return fail(ALG_ERR_ARG, std::string(who) + ": planar and spherical collision avoidance cannot be mixed on one handle");
+    if (!s.has_colavoid) s.pair_r.assign((size_t)p * p, -1.0);
+    if (s.pair_on(i, j)) return fail(ALG_ERR_ARG, std::string(who) + ": this ordered pair already carries a collision-avoidance constraint (one per pair)");
+    s.pair_r[(size_t)i * p + j] = radius; s.has_colavoid = true; s.D.ca_dim = dim;
+    return ALG_OK;
+}
+int orc_add_collision_avoidance_pair(alg_handle* h, int32_t i, int32_t j, double radius) { return add_pair(H, "orc_add_collision_avoidance_pair", i, j, radius, 2); }
 int orc_add_control_bound(alg_handle* h, const double* umax, const double* umin) {
     Shared& s = H->sh;
     if (!umax || !umin) { s.has_ctl = false; return ALG_OK; }
@@ -1216,6 +1239,7 @@ int orc_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t nw, co
     Shared& s = H->sh;
     if (player < 0 || player >= s.D.p || nw < 0) return fail(ALG_ERR_ARG, "orc_add_wall_constraint_player: bad argument");
     if (s.D.nwall == 0) for (int i = 0; i < 10; i++) s.wall_mask[i] = 0u;
+    else for (int i = 0; i < 10; i++) if (s.wall_mask[i] == 0xffffffffu) s.wall_mask[i] = (1u << s.D.nwall) - 1u;   // after an all-player set: explicit bits (as the HIP library)
     std::vector<double>* tab[6] = {&s.wx1, &s.wy1, &s.wx2, &s.wy2, &s.wxv, &s.wyv}; const double* src[6] = {x1, y1, x2, y2, xv, yv};
     for (int f = 0; f < 6; f++) tab[f]->resize(s.D.nwall);
     for (int w = 0; w < nw; w++) {
@@ -1240,6 +1264,7 @@ int orc_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t nc, 
     Shared& s = H->sh;
     if (player < 0 || player >= s.D.p || nc < 0) return fail(ALG_ERR_ARG, "orc_add_circle_constraint_player: bad argument");
     if (s.D.ncirc == 0) for (int i = 0; i < 10; i++) s.circ_mask[i] = 0u;
+    else for (int i = 0; i < 10; i++) if (s.circ_mask[i] == 0xffffffffu) s.circ_mask[i] = (1u << s.D.ncirc) - 1u;
     std::vector<double>* tab[3] = {&s.cxc, &s.cyc, &s.crad}; const double* src[3] = {xc, yc, rad};
     for (int f = 0; f < 3; f++) tab[f]->resize(s.D.ncirc);
     for (int c = 0; c < nc; c++) {
@@ -1264,7 +1289,13 @@ int orc_add_spherical_collision_avoidance(alg_handle* h, const double* radius) {
     if (!radius) { s.has_colavoid = false; s.D.ca_dim = 2; return ALG_OK; }
     if (int rc = need_3d(H, "orc_add_spherical_collision_avoidance")) return rc;
     // (like every adder of the extended set: the multipliers are re-created, lambda = 0, mu = rho_0 -- include/algames_hip.h)
-    s.ca_radius.assign(radius, radius + s.D.p); s.has_colavoid = true; s.D.ca_dim = 3; orc_resize_con(H); return ALG_OK;
+    set_all_pairs(s, radius); s.has_colavoid = true; s.D.ca_dim = 3; orc_resize_con(H); return ALG_OK;
+}
+// add_spherical_collision_avoidance!(game_con, i, j, radius) (constraints_methods.jl:45-64): CollisionConstraint(n, pz[i][1:3], pz[j][1:3], radius)
+int orc_add_spherical_collision_avoidance_pair(alg_handle* h, int32_t i, int32_t j, double radius) {
+    if (int rc = need_3d(H, "orc_add_spherical_collision_avoidance_pair")) return rc;
+    if (int rc = add_pair(H, "orc_add_spherical_collision_avoidance_pair", i, j, radius, 3)) return rc;
+    orc_resize_con(H); return ALG_OK;
 }
 int orc_add_wall3d_constraint(alg_handle* h, int32_t nw, const double* p1, const double* p2, const double* p3, const double* v) {
     Shared& s = H->sh;

@@ -118,3 +118,22 @@ def test_shim_ibr_and_mpc_on_a_live_handle(alg, orc):
     ito, cvo, sto = alg.mpc_solve(po, 4, record_states=True)
     assert np.array_equal(itg, ito) and np.array_equal(cvg, cvo) and np.abs(stg - sto).max() < 1e-7
     assert np.array_equal(pg.batch.get_x0(), stg[-1])          # the handle's x0 moved with the loop
+
+
+@pytest.mark.gpu
+def test_multi_device_solve_behind_the_boundary_two_handles_on_one_gpu(alg):
+    """SURVEY.md 8(e) behind the boundary: `ShardedGameProblem` = contiguous shards, one handle (own stream) per device entry,
+    alg_newton_solve_async on all of them, then alg_synchronize.  One GPU here, so both handles sit on device 0 and their
+    launches run concurrently on two streams; the result must equal the single-handle batch bit for bit."""
+    ids = np.arange(100, 100 + 512)
+    one = alg.scenarios.make_problem("C2", ids); one.batch.set_waves_per_game(1)
+    alg.newton_solve(one)
+    two = alg.scenarios.make_problem("C2", ids, devices=[0, 0])
+    for s in two.shards:
+        s.batch.set_waves_per_game(1)
+    alg.newton_solve(two)
+    assert [s.B for s in two.shards] == [256, 256]
+    assert np.array_equal(two.get_traj(), one.batch.get_traj())
+    assert np.array_equal(two.stats.summary["newton_iters"], one.stats.summary["newton_iters"])
+    assert alg.sharding.local_counters(two) == alg.sharding.local_counters(one)
+    assert np.array_equal(two.stats.history(300)["res"], one.stats.history(300)["res"])

@@ -493,3 +493,56 @@ def test_shards_reproduce_the_whole_batch_bitwise(alg):
                 parts.append(shard.batch.get_traj()); iters += int(shard.stats.summary["newton_iters"].sum())
             assert np.array_equal(np.concatenate(parts), zw)
             assert iters == int(sw["newton_iters"].sum())
+
+
+PAIR_CASES = [  # (model, p, d, N, pairs (i, j, radius), spherical)
+    (DI, 3, 2, 12, ((0, 1, 0.9), (2, 0, 0.35), (1, 2, 0.5)), False),          # asymmetric subset, tile path (the BASELINE C2 shape)
+    (UNI, 3, 2, 10, ((1, 0, 0.7), (0, 2, 0.4)), False),
+    (UNI, 4, 2, 8, ((0, 3, 0.6), (3, 0, 0.2), (1, 2, 0.8), (2, 3, 0.45)), False),
+    (DI, 2, 3, 8, ((1, 0, 0.8),), True),                                       # spherical, one direction only
+    (DI, 5, 2, 6, ((0, 4, 0.7), (4, 2, 0.3), (1, 3, 0.5)), False),              # dense Newton direction
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_pair_collision_avoidance_parity(alg, orc, case):
+    """add_collision_avoidance!(game_con, i, j, radius) / add_spherical_collision_avoidance!(game_con, i, j, radius)
+    (constraints_methods.jl:5-19, 45-64): asymmetric radii on a subset of the ordered pairs -- residual, Jacobian, Newton
+    direction, dual update and the full solve against the oracle."""
+    model, p, d, N, pairs, sph = case
+    g, o = _pair(alg, orc, model, p, d, N, B=4, seed=3, ingredients=("cost", "ctl"))
+    z, (lam, mu) = g.get_traj(), g.get_con_duals()
+    for b in (g, o):
+        for (i, j, r) in pairs:
+            b.add_collision_avoidance_pair(i, j, r, spherical=sph)
+    rng = np.random.default_rng(11)
+    lam, mu = rng.random((g.B, g.con_len)), 1.0 + 2.0 * rng.random((g.B, g.con_len))
+    lam[rng.random((g.B, g.con_len)) < 0.3] = 0.0
+    for b in (g, o):
+        b.set_traj(z); b.set_con_duals(lam, mu)
+    assert g.con_len == o.con_len
+    rg, ng = g.residual(0, 1e-3); ro, no = o.residual(0, 1e-3)
+    assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max()) and np.allclose(ng, no, rtol=1e-13, atol=0)
+    Jg, Jo = g.residual_jacobian(1e-3), o.residual_jacobian(1e-3)
+    assert np.abs(Jg - Jo).max() <= 1e-12 * np.abs(Jo).max()
+    dg, sg = g.newton_direction(1e-3); do, so = o.newton_direction(1e-3)
+    assert np.array_equal(sg, so) and np.abs(dg - do).max() <= 1e-9 * (1 + np.abs(do).max())
+    vg, vo = g.dual_penalty_update(), o.dual_penalty_update()
+    assert np.abs(vg - vo).max() <= 1e-13 * (1 + np.abs(vo).max())
+    (lg, mg), (lo_, mo) = g.get_con_duals(), o.get_con_duals()
+    assert np.abs(lg - lo_).max() <= 1e-12 * (1 + np.abs(lo_).max()) and np.array_equal(mg, mo)
+    # pairs that were never added: value 0, multiplier untouched by the dual ascent
+    K = N - 1
+    on = {(i, j) for (i, j, _) in pairs}
+    for i in range(p):
+        for j in range(p):
+            if i != j and (i, j) not in on:
+                q = i * (p - 1) + (j if j < i else j - 1)
+                assert np.all(vg[:, q * K:(q + 1) * K] == 0.0) and np.array_equal(lg[:, q * K:(q + 1) * K], lam[:, q * K:(q + 1) * K])
+    # full solve from the seeded initial guess
+    for b in (g, o):
+        b.reset_con()
+    sg, so = g.newton_solve(init=True, game_id0=5), o.newton_solve(init=True, game_id0=5)
+    for f in ("status", "outer_iters", "newton_iters", "ls_failures", "converged"):
+        assert np.array_equal(sg[f], so[f]), f
+    assert np.abs(g.get_traj() - o.get_traj()).max() <= 1e-7

@@ -1237,3 +1237,74 @@ def test_per_player_wall_and_circle_sets(alg, orc):
     assert list(con.player_walls) == [2] and list(con.player_circles) == [3]
     with pytest.raises(alg.AlgamesError):
         alg.add_wall_constraint(con, [alg.Wall([0.0, 0.5], [1.0, 0.5], [0.0, 1.0])])
+
+
+def test_pair_collision_avoidance_adders(alg, orc):
+    """add_collision_avoidance!(game_con, i, j, radius) (constraints_methods.jl:5-19): one CollisionConstraint per ordered pair
+    with its own radius.  (1) every ordered pair added one by one with r_i + r_j is the vector form (:21-33), bit for bit;
+    (2) an asymmetric subset: c = radius^2 - |px_i - px_j|^2 on the pairs that were added, the others are inert (value 0, zero
+    residual / Jacobian contribution, multiplier never moves); (3) the ABI refuses a second constraint on a pair and a mix of
+    planar and spherical sets."""
+    import oracle as orcmod
+    p, N, B = 3, 8, 3
+    rng = np.random.default_rng(5)
+
+    def batch():
+        b = orcmod.OracleBatch(0, p, N, 0.1, B, d=2)
+        b.set_x0(rng0["x0"]); b.set_lqr(rng0["Q"], rng0["R"], rng0["xf"], rng0["uf"])
+        return b
+    ni = 4
+    rng0 = dict(x0=rng.random((B, 4 * p)), Q=1 + rng.random((B, p, ni)), R=0.5 + rng.random((B, p, 2)), xf=rng.random((B, p, ni)), uf=rng.random((B, p, 2)) - 0.5)
+    r = np.array([0.3, 0.4, 0.55])
+    a, b = batch(), batch()
+    a.add_collision_avoidance(r)
+    for i in range(p):
+        for j in range(p):
+            if i != j:
+                b.add_collision_avoidance_pair(i, j, r[i] + r[j])
+    z = rng.random((B, a.traj_len)); lam = rng.random((B, a.con_len)); mu = 1 + rng.random((B, a.con_len))
+    for t in (a, b):
+        t.set_traj(z); t.set_con_duals(lam, mu)
+    assert np.array_equal(a.residual(0, 0.0)[0], b.residual(0, 0.0)[0])
+    assert np.array_equal(a.residual_jacobian(1e-3), b.residual_jacobian(1e-3))
+    # asymmetric subset: (0 -> 1) with radius 0.9, (2 -> 0) with radius 0.2; nothing else
+    c = batch(); c.add_collision_avoidance_pair(0, 1, 0.9); c.add_collision_avoidance_pair(2, 0, 0.2)
+    c.set_traj(z); c.set_con_duals(lam, mu)
+    res, _ = c.residual(0, 0.0)
+    e = batch(); e.add_collision_avoidance_pair(0, 1, 0.9); e.add_collision_avoidance_pair(2, 0, 0.2)
+    e.set_traj(z); e.set_con_duals(lam, mu)
+    vals = e.dual_penalty_update()                                          # evaluate! at pdtraj: the constraint values
+    K = N - 1
+    def q(i, j): return i * (p - 1) + (j if j < i else j - 1)
+    X = z[:, 4 * p:].reshape(B, K, -1)[:, :, :4 * p]                     # x_2 .. x_N
+    for (i, j, R_) in ((0, 1, 0.9), (2, 0, 0.2)):
+        d2 = (X[:, :, i] - X[:, :, j]) ** 2 + (X[:, :, p + i] - X[:, :, p + j]) ** 2
+        if vals is not None:
+            assert np.allclose(vals[:, q(i, j) * K:(q(i, j) + 1) * K], R_ ** 2 - d2, rtol=1e-14, atol=1e-15)
+    if vals is not None:
+        for (i, j) in ((1, 0), (0, 2), (1, 2), (2, 1)):
+            assert np.all(vals[:, q(i, j) * K:(q(i, j) + 1) * K] == 0.0)
+    # the absent pairs contribute nothing: removing them from the vector form's residual = zeroing their multipliers AND penalties
+    # cannot be expressed through the ABI, so compare with a batch whose only pairs are the same two, radii as r_i + r_j
+    d = batch(); d.add_collision_avoidance_pair(0, 1, 0.9); d.add_collision_avoidance_pair(2, 0, 0.2)
+    lam2 = lam.copy(); mu2 = mu.copy()
+    for (i, j) in ((1, 0), (0, 2), (1, 2), (2, 1)):
+        lam2[:, q(i, j) * K:(q(i, j) + 1) * K] = 7.0; mu2[:, q(i, j) * K:(q(i, j) + 1) * K] = 123.0      # must not matter
+    d.set_traj(z); d.set_con_duals(lam2, mu2)
+    assert np.array_equal(d.residual(0, 0.0)[0], res)
+    assert np.array_equal(d.residual_jacobian(0.0), c.residual_jacobian(0.0))
+    d.dual_penalty_update()
+    lam_after = d.get_con_duals()[0]
+    for (i, j) in ((1, 0), (0, 2), (1, 2), (2, 1)):
+        assert np.all(lam_after[:, q(i, j) * K:(q(i, j) + 1) * K] == 7.0)           # inert rows: no dual ascent
+    with pytest.raises(alg.AlgamesError, match="already carries"):
+        c.add_collision_avoidance_pair(0, 1, 0.5)
+    with pytest.raises(alg.AlgamesError, match="i != j"):
+        c.add_collision_avoidance_pair(1, 1, 0.5)
+    # host mirror of the reference signature (1-based players)
+    model = alg.DoubleIntegratorGame(p=3)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    alg.add_collision_avoidance(con, 1, 2, 0.9); alg.add_collision_avoidance(con, 3, 1, 0.2)
+    assert con.collision_pairs == {(1, 2): 0.9, (3, 1): 0.2}
+    with pytest.raises(alg.AlgamesError):
+        alg.add_collision_avoidance(con, 0.3)

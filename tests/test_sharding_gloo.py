@@ -20,13 +20,16 @@ import algames_jl_amd as alg, oracle as orc
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 TOTAL = 10
-import bench                                   # the N > 1 path under test is bench.py's own sharding + reduction
-prob, ids = bench.make_shard(alg, "C4", TOTAL // world, rank, world, backend=orc.lib(), N=10)
+import bench                                   # the N > 1 path under test is the package's sharding module; bench.py is a thin caller of it
+prob, ids = alg.sharding.make_shard("C4", TOTAL // world, rank, world, backend=orc.lib(), N=10)
+p2, ids2 = bench.make_shard(alg, "C4", TOTAL // world, rank, world, backend=orc.lib(), N=10)
+assert np.array_equal(ids, ids2) and np.array_equal(prob.x0, p2.x0)
 lo, hi = int(ids[0]), int(ids[-1]) + 1
 assert (lo, hi) == alg.scenarios.shard_range(TOTAL, rank, world)
 alg.newton_solve(prob)
 s = prob.stats.summary
-cnt, tmax = bench.reduce_counters([int(s["newton_iters"].sum()), int(s["converged"].sum()), hi - lo], 1.0 + rank, world, "cpu")
+assert alg.sharding.local_counters(prob)[:2] == [int(s["newton_iters"].sum()), int(s["converged"].sum())]
+cnt, tmax = alg.sharding.reduce_counters([int(s["newton_iters"].sum()), int(s["converged"].sum()), hi - lo], 1.0 + rank, world, "cpu")
 assert tmax == float(world)                    # max over ranks of the per-rank time
 cnt = torch.tensor(cnt)
 z = torch.from_numpy(prob.batch.get_traj())
@@ -88,3 +91,21 @@ def test_world_size_2_gloo_sharded_solve(orc):
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "SHARDING_OK" in out.stdout
+
+
+def test_sharded_problem_in_one_process_equals_the_whole_batch(orc):
+    """`ShardedGameProblem` (one process, several handles): the same contiguous-shard rule, every launch before the first
+    synchronisation.  With the oracle standing in for the device the sharded solve must equal the single-handle solve bit for
+    bit (inputs depend only on global scenario ids) -- also with an uneven split and more devices than games."""
+    import algames_jl_amd as alg
+    full = alg.scenarios.make_problem("C2", np.arange(3, 13), N=10, backend=orc.lib())
+    alg.newton_solve(full)
+    for devs in ([0, 0], [0, 0, 0], [0] * 16):
+        sh = alg.scenarios.make_problem("C2", np.arange(3, 13), N=10, backend=orc.lib(), devices=devs)
+        assert isinstance(sh, alg.ShardedGameProblem) and sum(hi - lo for lo, hi in sh.cuts) == 10
+        alg.newton_solve(sh)
+        assert np.array_equal(sh.get_traj(), full.batch.get_traj())
+        assert np.array_equal(sh.stats.summary["newton_iters"], full.stats.summary["newton_iters"])
+        assert alg.sharding.local_counters(sh) == alg.sharding.local_counters(full)
+        assert np.array_equal(sh.stats.history(7)["res"], full.stats.history(7)["res"])
+        assert np.array_equal(sh.pdtraj.states, full.pdtraj.states)

@@ -36,7 +36,7 @@ class alg_options(C.Structure):
 class alg_record(C.Structure):
     _fields_ = [("outer", C.c_int32), ("ls_j", C.c_int32), ("alpha", C.c_double),
                 ("res", C.c_double), ("delta", C.c_double), ("dyn_vio", C.c_double),
-                ("con_vio", C.c_double), ("sta_vio", C.c_double), ("opt_vio", C.c_double)]
+                ("con_vio", C.c_double), ("sta_vio", C.c_double), ("opt_vio", C.c_double), ("t_elap", C.c_double)]
 
 
 class alg_game_stats(C.Structure):
@@ -53,7 +53,7 @@ class alg_step_info(C.Structure):
 
 record_dtype = np.dtype([("outer", "<i4"), ("ls_j", "<i4"), ("alpha", "<f8"), ("res", "<f8"),
                          ("delta", "<f8"), ("dyn_vio", "<f8"), ("con_vio", "<f8"),
-                         ("sta_vio", "<f8"), ("opt_vio", "<f8")])
+                         ("sta_vio", "<f8"), ("opt_vio", "<f8"), ("t_elap", "<f8")])
 game_stats_dtype = np.dtype([("status", "<i4"), ("outer_iters", "<i4"), ("newton_iters", "<i4"),
                              ("records", "<i4"), ("converged", "<i4"), ("ls_failures", "<i4"),
                              ("last", record_dtype)])
@@ -421,9 +421,18 @@ class Batch:
         self.lib.check(self.lib.get_stats(self.h, st.ctypes.data_as(_P)))
         return st
 
-    def get_history(self, game, max_records=512):
+    def get_history(self, game, max_records=None):
+        """Statistics history of one game.  max_records=None: everything the game recorded (alg_get_stats first); a history
+        the device buffer could not hold completely raises a warning (alg_get_history returns fewer records than were made)."""
+        made = None
+        if max_records is None:
+            made = int(self.get_stats()["records"][game])
+            max_records = max(made, 1)
         out = np.zeros(max_records, dtype=record_dtype); cnt = C.c_int32()
         self.lib.check(self.lib.get_history(self.h, game, max_records, out.ctypes.data_as(_P), C.byref(cnt)))
+        if made is not None and cnt.value < made:
+            import warnings
+            warnings.warn(f"alg_get_history: game {game} made {made} records, the device history holds {cnt.value} (truncated)")
         return out[:cnt.value]
 
     def synchronize(self):

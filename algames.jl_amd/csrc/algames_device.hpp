@@ -929,7 +929,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                             const double c = on * (Rr * Rr - s2c);
                             const int ci = con_col<C>(N, pairq<C>(i, j), kn);
                             const double lm = G.lam(pr)[ci], am = on * al_active_mu(c, lm, G.mu(pr)[ci]);
-                            const double wl = on * lm + am * c;
+                            const double wl = fma(am, c, on * lm);            // (the contraction the all-pairs form always had: lm + am c)
 #pragma unroll
                             for (int a = 0; a < PD; a++) {
                                 gv[a] += -2.0 * dl[a] * wl;
@@ -2647,6 +2647,18 @@ __device__ __forceinline__ double uni(double v) {
 struct RecScalars { double res, opt; int nonfinite; };
 // Statistics of an accepted line-search trial = what the next record! would recompute (same point, same arithmetic)
 // (kept in HBM, G.tc(pr), so that it costs no registers across the Newton direction)
+// t_elap of the reference's Statistics (statistics.jl:8,34; @elapsed around inner_iteration, solver_methods.jl:40-42): lane 0 stamps
+// the 100 MHz real-time counter into the game's scratch block at the top of an inner iteration and turns it into seconds at its
+// end -- through HBM, so that no register is live across the phases of the iteration; the next record! picks it up.
+constexpr int TC_TELAP = 8, TC_TSTART = 9;
+__device__ __forceinline__ void iter_clock_start(CPR pr0, const Game& G0) {
+    CPR pr = phase_params(pr0); const Game G = G0.fresh();
+    if (phase_lane() == 0) G.tc(pr)[TC_TSTART] = (double)__builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void iter_clock_stop(CPR pr0, const Game& G0) {
+    CPR pr = phase_params(pr0); const Game G = G0.fresh();
+    if (phase_lane() == 0) G.tc(pr)[TC_TELAP] = ((double)__builtin_amdgcn_s_memrealtime() - G.tc(pr)[TC_TSTART]) * 1e-8;
+}
 __device__ __forceinline__ void tcache_store(CPR pr0, const Game& G0, const ResOut& ro) {
     CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
@@ -2665,6 +2677,7 @@ __device__ __forceinline__ RecScalars push_stats(CPR pr0, const Game& G0, const 
         alg_record rc;
         rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1 / (double)pr.S; rc.delta = delta;
         rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
+        rc.t_elap = G.tc(pr)[TC_TELAP];               // the previous inner iteration's duration (iter_clock_stop)
         const int idx = G.st(pr)->records;
         if (idx < pr.hist_max) G.hist(pr)[idx] = rc;
         G.st(pr)->records = idx + 1;
@@ -2720,12 +2733,13 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
     if (info && lane0) { alg_step_info z{}; *info = z; }
+    iter_clock_start(pr, G_);                    // @elapsed begins (solver_methods.jl:40); record! below still reads the previous t_elap
     RecScalars rs;                                                         // :73-76 (regularisation term is zero at pdtraj)
     if (cache_valid && *cache_valid) { ResOut cro; tcache_load(pr, G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }
     else rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr);
     if (cache_valid) *cache_valid = 0;
     Delta = 0.0;                                                           // :79
-    auto finish = [&](int status, int flow) { if (info && lane0) { info->status = status; info->control_flow = flow; } return status | (flow << 8); };
+    auto finish = [&](int status, int flow) { if (info && lane0) { info->status = status; info->control_flow = flow; } iter_clock_stop(pr, G_); return status | (flow << 8); };
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
     if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1) | (1 << 16);  // :80-82 (bit 16: pdtraj untouched since this record!)
     double pl1; int st;
@@ -2937,7 +2951,7 @@ __device__ __forceinline__ void settle_traj(CPR pr, Game& G) {
 template <class C>
 __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
     const auto& o = pr.opt; const int lane = phase_lane();
-    if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; } // reset!(prob.stats)
+    if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; G.fresh().tc(phase_params(pr))[TC_TELAP] = 0.0; } // reset!(prob.stats); t_elap = 0
 #ifdef ALG_PHASE_PROF
     if (lane < 48) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums
 #endif
@@ -2981,12 +2995,12 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
         if (phase_lane() == 0) {
             CPR prs = phase_params(pr); const Game Gs = G.fresh();
             alg_game_stats* st = Gs.st(prs);
-            st->last.outer = out; st->last.delta = Delta; st->last.alpha = 0.0; st->last.ls_j = 0;
+            st->last.outer = out; st->last.delta = Delta; st->last.alpha = 0.0; st->last.ls_j = 0; st->last.t_elap = Gs.tc(prs)[TC_TELAP];
             const int idx = st->records;
             if (idx < prs.hist_max) {
                 alg_record* dst = Gs.hist(prs) + idx; const alg_record* src = &st->last;
                 dst->outer = src->outer; dst->ls_j = src->ls_j; dst->alpha = src->alpha; dst->res = src->res; dst->delta = src->delta;
-                dst->dyn_vio = src->dyn_vio; dst->con_vio = src->con_vio; dst->sta_vio = src->sta_vio; dst->opt_vio = src->opt_vio;
+                dst->dyn_vio = src->dyn_vio; dst->con_vio = src->con_vio; dst->sta_vio = src->sta_vio; dst->opt_vio = src->opt_vio; dst->t_elap = src->t_elap;
             }
             st->records = idx + 1;
         }
@@ -3007,6 +3021,7 @@ __device__ __forceinline__ RecScalars ibr_push_stats(CPR pr, const Game& G, cons
         alg_record rc;
         rc.outer = outer; rc.ls_j = 0; rc.alpha = 0.0; rc.res = ro.l1full / (double)pr.S; rc.delta = delta;
         rc.dyn_vio = ro.dyn; rc.con_vio = ro.con; rc.sta_vio = ro.sta; rc.opt_vio = ro.opt;
+        rc.t_elap = G.tc(pr)[TC_TELAP];
         const int idx = G.st(pr)->records;
         if (idx < pr.hist_max) G.hist(pr)[idx] = rc;
         G.st(pr)->records = idx + 1;
@@ -3024,14 +3039,15 @@ __device__ int ibr_inner_iteration(CPR pr, const Game& G, Lds<C>& L, int& LS_cou
     const double reg = o.reg_0 * (lf * lf * lf * lf);
     const double sm = (double)((pr.N - 1) * (2 * C::n + C::mi));
     ResOut ro;
+    iter_clock_start(pr, G);                                               // t_elap = @elapsed ibr_inner_iteration (:151-153)
     assemble_pass<C, 1, true>(pr, G, L.a, 0, -1, 0.0, reg, ro, ip);        // :236-241
     game_sync();
     const RecScalars rs = ibr_push_stats<C>(pr, G, ro, Delta, k);
     Delta = 0.0;
-    if (rs.nonfinite) return ALG_STATUS_NAN | (1 << 8);
-    if (rs.opt < o.eps_opt) return ALG_STATUS_OK | (1 << 8);                       // :245-247
+    if (rs.nonfinite) { iter_clock_stop(pr, G); return ALG_STATUS_NAN | (1 << 8); }
+    if (rs.opt < o.eps_opt) { iter_clock_stop(pr, G); return ALG_STATUS_OK | (1 << 8); }   // :245-247
     const int st = newton_direction<C, true>(pr, G, L.d, reg, ip);                  // :249-252
-    if (st != ALG_STATUS_OK) return st | (1 << 8);
+    if (st != ALG_STATUS_OK) { iter_clock_stop(pr, G); return st | (1 << 8); }
     game_sync();
     int j = 1; double alpha = 1.0;                                                  // ibr_line_search (:270-289)
     while (j < o.ls_iter) {
@@ -3054,6 +3070,7 @@ __device__ int ibr_inner_iteration(CPR pr, const Game& G, Lds<C>& L, int& LS_cou
         if (idx < pr.hist_max) { G.hist(pr)[idx].alpha = alpha; G.hist(pr)[idx].ls_j = j; }
         G.st(pr)->last.alpha = alpha; G.st(pr)->last.ls_j = j;
     }
+    iter_clock_stop(pr, G);
     return ALG_STATUS_OK | ((Delta < o.delta_min ? 1 : 0) << 8);
 }
 // ibr_newton_solve!(prob, i) (solver_methods.jl:171-228)

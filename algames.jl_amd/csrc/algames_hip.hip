@@ -122,7 +122,7 @@ struct Handle {
     std::vector<double> extc;     // host copy of pr.extc
     int waves_per_game = 0;       // 0 = automatic (alg_set_waves_per_game)
     int quad_team = -1;           // -1 = automatic, 0 = off, 1 = required (alg_set_quad_team)
-    long long solves_since_reset = 0;   // solves whose records share the Statistics history (best responses accumulate)
+    long long records_bound = 0;        // upper bound of the records the Statistics history holds since its last reset (one per record!)
     void* d_scratch = nullptr;    // grow-only scratch of the inspection entry points (dense Jacobians, MPC state logs)
     size_t scratch_bytes = 0;
 };
@@ -272,6 +272,15 @@ int ensure_hist(Handle* hd, long long need) {
     }
     p.hist = fresh; p.hist_max = (int)need;
     return ALG_OK;
+}
+// Room for `more` further records behind the ones the history may already hold.  The buffer grows geometrically (a host-driven
+// loop of alg_newton_step adds ONE record per call: sizing every call for a whole solve re-allocated and copied the history on
+// nearly every step) and never beyond ensure_hist's cap; records past the capacity are dropped by the kernels (idx < hist_max)
+// and alg_get_history reports the truncation.
+int reserve_records(Handle* hd, long long more) {
+    hd->records_bound += more;
+    if (hd->pr.hist && hd->records_bound <= hd->pr.hist_max) return ALG_OK;
+    return ensure_hist(hd, std::max<long long>(hd->records_bound, 2ll * hd->pr.hist_max));
 }
 int ensure_scratch(Handle* hd, size_t bytes) {
     if (bytes <= hd->scratch_bytes) return ALG_OK;
@@ -792,6 +801,7 @@ int alg_update_traj(alg_handle* h, int32_t target, int32_t source, const double*
 int alg_record_stats(alg_handle* h, alg_record* rec) {
     if (!h || !rec) return fail(ALG_ERR_ARG, "alg_record_stats: null argument");
     int rc = use_device(H); if (rc) return rc;
+    if ((rc = reserve_records(H, 1))) return rc;
     LAUNCH(k_record, H->pr, H->d_rec);
     return d2h(H, rec, H->d_rec, sizeof(alg_record) * H->pr.B);
 }
@@ -816,8 +826,7 @@ int alg_dual_penalty_update(alg_handle* h, double* vals) {
 int alg_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, const double* delta_in, alg_step_info* info) {
     NEED_HANDLE("alg_newton_step");
     int rc = use_device(H); if (rc) return rc;
-    H->solves_since_reset += 1;                   // one more record! in the shared Statistics history
-    if ((rc = ensure_hist(H, H->solves_since_reset * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
+    if ((rc = reserve_records(H, 1))) return rc;  // one more record! in the shared Statistics history
     const double* d_delta = nullptr;
     if (delta_in) { if ((rc = h2d(H, H->d_tmp, delta_in, sizeof(double) * H->pr.B))) return rc; d_delta = H->d_tmp; }
     LAUNCH(k_newton_step, H->pr, (int)k_outer, (int)l_inner, d_delta, H->d_info);
@@ -829,7 +838,8 @@ int alg_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) {
     NEED_HANDLE("alg_newton_solve");
     int rc = use_device(H); if (rc) return rc;
     if (!H->x0_set || !H->lqr_set) return fail(ALG_ERR_STATE, "alg_newton_solve: x0 / LQR data not set");
-    H->solves_since_reset = 1;                    // newton_solve! starts with reset!(prob.stats)
+    H->records_bound = 0;                         // newton_solve! starts with reset!(prob.stats)
+    if ((rc = reserve_records(H, (long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1))) return rc;
     return launch_newton_solve(H, (int)init, (uint64_t)game_id0);
 }
 int alg_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats) {
@@ -895,8 +905,7 @@ int alg_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats) {
     int rc = use_device(H); if (rc) return rc;
     if (player < 0 || player >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_solve_player: bad player index");
     // statistics accumulate over the players' solves (the reference does not reset them between players): room for one more
-    H->solves_since_reset += 1;
-    if ((rc = ensure_hist(H, (long long)(H->solves_since_reset + 1) * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
+    if ((rc = reserve_records(H, (long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1))) return rc;
     IbrOrder order{};
     LAUNCH(k_ibr, H->pr, 0, (int)player, 0, (uint64_t)0, 1, order, 0.0);
     if (stats) return alg_get_stats(h, stats);
@@ -909,9 +918,10 @@ int alg_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t 
     if (!ordering || ibr_iter < 1) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: bad arguments");
     IbrOrder order{};
     for (int i = 0; i < H->pr.p; i++) { if (ordering[i] < 0 || ordering[i] >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: ordering entries must be player ids"); order.v[i] = ordering[i]; }
-    // records accumulate over rounds and players: ibr_iter * p * (outer_iter * inner_iter + 1) at most
-    if ((rc = ensure_hist(H, (long long)ibr_iter * H->pr.p * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
-    H->solves_since_reset = (long long)ibr_iter * H->pr.p;
+    // records accumulate over rounds and players: ibr_iter * p * (outer_iter * inner_iter + 1) at most.  The loop usually ends after
+    // a few rounds (delta_min), so the history is sized for 16 rounds; later records are dropped (alg_get_history reports it)
+    H->records_bound = 0;
+    if ((rc = reserve_records(H, (long long)std::min<int>(ibr_iter, 16) * H->pr.p * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
     LAUNCH(k_ibr, H->pr, 1, 0, (int)init, (uint64_t)game_id0, (int)ibr_iter, order, delta_min);
     if (stats) return alg_get_stats(h, stats);
     return sync(H);

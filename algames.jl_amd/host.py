@@ -487,7 +487,8 @@ class PrimalDualTraj:
 class Statistics:
     """Per-game `Statistics` history (src/struct/statistics.jl:5-15) as numpy record arrays; the reference's field names
     (`outer_iter`, `res`, `Δ_traj`, `dyn_vio`, `con_vio`, `sta_vio`, `opt_vio`) are views of game 0's history, the `*_vio`
-    entries being the `.max` of the reference's violation objects.  `t_elap` is not recorded on the device (zeros)."""
+    entries being the `.max` of the reference's violation objects.  `t_elap[r]` is the duration (seconds) of the inner iteration
+    that preceded record r, measured on the device with the 100 MHz real-time counter (0 for the first record of a solve)."""
 
     def __init__(self, summary, history_fn):
         self.summary = summary
@@ -510,7 +511,7 @@ class Statistics:
     con_vio = property(lambda self: self._col("con_vio"))
     sta_vio = property(lambda self: self._col("sta_vio"))
     opt_vio = property(lambda self: self._col("opt_vio"))
-    t_elap = property(lambda self: np.zeros(len(self.history(0))))
+    t_elap = property(lambda self: self._col("t_elap"))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ struct AlgRecord
     outer::Int32; ls_j::Int32
     alpha::Float64; res::Float64; delta::Float64
     dyn_vio::Float64; con_vio::Float64; sta_vio::Float64; opt_vio::Float64
+    t_elap::Float64
 end
 
 struct AlgGameStats
@@ -304,7 +305,7 @@ function pull_results!(bp::BatchedGameProblem, stats::Vector{AlgGameStats})
             cvv = Algames.ControlViolation(N); cvv.max = r.con_vio
             sv = Algames.StateViolation(N); sv.max = r.sta_vio
             ov = Algames.OptimalityViolation(N); ov.max = r.opt_vio
-            Algames.record!(pr.stats, 0.0, r.res, r.delta, dv, cvv, sv, ov, Int(r.outer))
+            Algames.record!(pr.stats, r.t_elap, r.res, r.delta, dv, cvv, sv, ov, Int(r.outer))      # t_elap: device real-time counter
         end
         if cnt[] > 0                                                # final record (solver_methods.jl:63): full per-knot profiles
             Algames.residual!(pr, pr.pdtraj)

@@ -118,6 +118,9 @@ typedef struct alg_record {
     double  res;       /* ||res||_1 / S                */
     double  delta;     /* Δ_traj passed to record!     */
     double  dyn_vio, con_vio, sta_vio, opt_vio; /* the four .max scalars */
+    double  t_elap;    /* stats.t_elap[end] (statistics.jl:8,34): seconds the previous inner_iteration of this solve took
+                          (@elapsed at solver_methods.jl:40-42; 0 for the first record), measured on the device with the
+                          100 MHz real-time counter from the first to the last instruction of the game's iteration */
 } alg_record;
 
 /* Result of newton_solve! for one game (src/problem/solver_methods.jl:5-65). */

@@ -32,14 +32,46 @@
 #include <omp.h>
 #endif
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
 #include <string>
 #include <vector>
+#if defined(ORC_REAL_KIND) && ORC_REAL_KIND == 2
+#include <quadmath.h>
+#endif
 
 namespace {
+// Scalar type of the restated arithmetic.  `double` is the oracle proper (the reference's Float64).  The same source compiled with
+// -DORC_REAL_KIND=1 (long double, 64-bit mantissa: liboracle_x.so) or 2 (__float128: liboracle_q.so) is the ARBITER of the parity
+// tests: where the HIP path and the double oracle disagree beyond the tolerances (ill-conditioned, diverging problems), both are
+// compared with the extended-precision run of the very same algorithm on the very same double inputs.  The C ABI stays double.
+#if !defined(ORC_REAL_KIND) || ORC_REAL_KIND == 0
+typedef double real;
+#elif ORC_REAL_KIND == 1
+typedef long double real;
+#else
+typedef __float128 real;
+#endif
+#if defined(ORC_REAL_KIND) && ORC_REAL_KIND == 2
+inline real r_sqrt(real x) { return sqrtq(x); }
+inline real r_sin(real x) { return sinq(x); }
+inline real r_cos(real x) { return cosq(x); }
+inline real r_tan(real x) { return tanq(x); }
+inline real r_atan2(real y, real x) { return atan2q(y, x); }
+inline real r_fabs(real x) { return fabsq(x); }
+inline bool r_isfinite(real x) { return finiteq(x) != 0; }
+#else
+inline real r_sqrt(real x) { return std::sqrt(x); }
+inline real r_sin(real x) { return std::sin(x); }
+inline real r_cos(real x) { return std::cos(x); }
+inline real r_tan(real x) { return std::tan(x); }
+inline real r_atan2(real y, real x) { return std::atan2(y, x); }
+inline real r_fabs(real x) { return std::fabs(x); }
+inline bool r_isfinite(real x) { return std::isfinite(x); }
+#endif
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -53,8 +85,8 @@ struct Dims {
     int traj_len = 0, npair = 0, col_len = 0, ctl_len = 0, con_len = 0;
     int nwall = 0, ncirc = 0, has_sb = 0, sb_len = 0, wall_len = 0, circ_len = 0;      // extended constraints
     int nwall3 = 0, ncyl = 0, wall3_len = 0, cyl_len = 0, ca_dim = 2;                  // 3-D half: Wall3D, Cylinder, spherical collision avoidance
-    double dt = 0, lf = 0.05, lr = 0.05;                                              // BicycleGame(lf, lr), bicycle.jl:15
-    double qmass = 0.5;                                                               // QuadrotorGame(; mass), quadrotor.jl:20
+    real dt = 0, lf = 0.05, lr = 0.05;                                              // BicycleGame(lf, lr), bicycle.jl:15
+    real qmass = 0.5;                                                               // QuadrotorGame(; mass), quadrotor.jl:20
     // src/struct/problem_size.jl:18-35 ; src/dynamics/double_integrator.jl:13-25 ; unicycle.jl:14-25
     bool init(const alg_desc& a) {
         model = a.model; p = a.p; N = a.N; dt = a.dt;
@@ -114,30 +146,30 @@ constexpr int MAXD = 96;
     if (name##_tl.size() < (size_t)(count)) name##_tl.resize((size_t)(count)); \
     std::vector<T>& name = name##_tl
 struct Dual {
-    double v = 0;
-    std::array<double, MAXD> e;            // only e[0 .. nd) is ever written or read
+    real v = 0;
+    std::array<real, MAXD> e;            // only e[0 .. nd) is ever written or read
     int nd = 0;
 };
-inline Dual dconst(double v, int nd) { Dual r; r.v = v; r.nd = nd; for (int i = 0; i < nd; i++) r.e[i] = 0.0; return r; }
+inline Dual dconst(real v, int nd) { Dual r; r.v = v; r.nd = nd; for (int i = 0; i < nd; i++) r.e[i] = 0.0; return r; }
 inline Dual operator+(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v + b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] + b.e[i]; return r; }
 inline Dual operator*(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v * b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * b.v + a.v * b.e[i]; return r; }
 inline Dual operator-(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v - b.v; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] - b.e[i]; return r; }
-inline Dual operator+(const Dual& a, double s) { Dual r = a; r.v = a.v + s; return r; }
-inline Dual operator*(double s, const Dual& a);
-inline Dual operator/(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v / b.v; const double ib = 1.0 / b.v; for (int i = 0; i < a.nd; i++) r.e[i] = (a.e[i] - r.v * b.e[i]) * ib; return r; }
+inline Dual operator+(const Dual& a, real s) { Dual r = a; r.v = a.v + s; return r; }
+inline Dual operator*(real s, const Dual& a);
+inline Dual operator/(const Dual& a, const Dual& b) { Dual r; r.nd = a.nd; r.v = a.v / b.v; const real ib = 1.0 / b.v; for (int i = 0; i < a.nd; i++) r.e[i] = (a.e[i] - r.v * b.e[i]) * ib; return r; }
 // max(0, a) as ForwardDiff differentiates it (derivative of the selected branch)
 inline Dual dmax0(const Dual& a) { if (a.v > 0.0) return a; Dual r; r.nd = a.nd; r.v = 0.0; for (int i = 0; i < a.nd; i++) r.e[i] = 0.0; return r; }
-inline double dmax0(double a) { return a > 0.0 ? a : 0.0; }
-inline Dual operator*(const Dual& a, double s) { Dual r; r.nd = a.nd; r.v = a.v * s; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * s; return r; }
-inline Dual dcos(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::cos(a.v); double s = -std::sin(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
-inline Dual dsin(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::sin(a.v); double c = std::cos(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = c * a.e[i]; return r; }
-inline Dual dtan(const Dual& a) { Dual r; r.nd = a.nd; r.v = std::tan(a.v); double s = 1.0 + r.v * r.v; for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
-inline Dual datan2(const Dual& y, double x) { Dual r; r.nd = y.nd; r.v = std::atan2(y.v, x); double s = x / (x * x + y.v * y.v); for (int i = 0; i < y.nd; i++) r.e[i] = s * y.e[i]; return r; }
-inline Dual operator*(double s, const Dual& a) { return a * s; }
-inline double dtan(double a) { return std::tan(a); }
-inline double datan2(double y, double x) { return std::atan2(y, x); }
-inline double dcos(double a) { return std::cos(a); }
-inline double dsin(double a) { return std::sin(a); }
+inline real dmax0(real a) { return a > 0.0 ? a : 0.0; }
+inline Dual operator*(const Dual& a, real s) { Dual r; r.nd = a.nd; r.v = a.v * s; for (int i = 0; i < a.nd; i++) r.e[i] = a.e[i] * s; return r; }
+inline Dual dcos(const Dual& a) { Dual r; r.nd = a.nd; r.v = r_cos(a.v); real s = -r_sin(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
+inline Dual dsin(const Dual& a) { Dual r; r.nd = a.nd; r.v = r_sin(a.v); real c = r_cos(a.v); for (int i = 0; i < a.nd; i++) r.e[i] = c * a.e[i]; return r; }
+inline Dual dtan(const Dual& a) { Dual r; r.nd = a.nd; r.v = r_tan(a.v); real s = 1.0 + r.v * r.v; for (int i = 0; i < a.nd; i++) r.e[i] = s * a.e[i]; return r; }
+inline Dual datan2(const Dual& y, real x) { Dual r; r.nd = y.nd; r.v = r_atan2(y.v, x); real s = x / (x * x + y.v * y.v); for (int i = 0; i < y.nd; i++) r.e[i] = s * y.e[i]; return r; }
+inline Dual operator*(real s, const Dual& a) { return a * s; }
+inline real dtan(real a) { return r_tan(a); }
+inline real datan2(real y, real x) { return r_atan2(y, x); }
+inline real dcos(real a) { return r_cos(a); }
+inline real dsin(real a) { return r_sin(a); }
 
 // continuous dynamics.  DoubleIntegrator: xdot = [x[m+1:n]; u] (double_integrator.jl:27-31).
 // Unicycle: xdot_i = cos(th_i) v_i, ydot_i = sin(th_i) v_i, thdot = u[1:p], vdot = u[p+1:2p]
@@ -157,7 +189,7 @@ void dynamics(const Dims& D, const T* x, const T* u, T* xd) {
         // Rotations.jl 1.0 MRP [restated from the published source; parity unpinned]: rotation matrix of g (via the unit quaternion
         // ((1 - |g|^2), 2 g) / (1 + |g|^2)), kinematics(g, w) = 1/4 ((1 - |g|^2) w + 2 g x w + 2 (g . w) g)
         const int P = D.p;
-        const double mass = D.qmass, Jd[3] = {0.0023, 0.0023, 0.004}, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
+        const real mass = D.qmass, Jd[3] = {0.0023, 0.0023, 0.004}, grav = -9.81, L = 0.1750, kf = 1.245, km = 1.0;
         for (int i = 0; i < P; i++) {
             const T g0 = x[3 * P + i], g1 = x[4 * P + i], g2 = x[5 * P + i];
             const T w0 = x[9 * P + i], w1 = x[10 * P + i], w2 = x[11 * P + i];
@@ -191,7 +223,7 @@ void dynamics(const Dims& D, const T* x, const T* u, T* xd) {
     } else {
         // BicycleGame (bicycle.jl:28-41): X = [x, y, v, psi] (each block of P), U = [a, delta];
         // beta = atan(lr tan(delta), lr + lf); Xdot = [v cos(beta+psi), v sin(beta+psi), a, v sin(beta)/lr]
-        const int P = D.p; const double L = D.lr + D.lf;
+        const int P = D.p; const real L = D.lr + D.lf;
         for (int i = 0; i < P; i++) {
             const T beta = datan2(dtan(u[P + i]) * D.lr, L);
             xd[i] = x[2 * P + i] * dcos(beta + x[3 * P + i]);
@@ -213,8 +245,8 @@ void rk2(const Dims& D, const T* x, const T* u, T* xn) {
     for (int i = 0; i < D.n; i++) xn[i] = x[i] + k2[i] * D.dt;
 }
 // RobotDynamics 0.3.1 discrete_dynamics(RK3,...) used by rollout! (solver_methods.jl:17)
-void rk3(const Dims& D, const double* x, const double* u, double* xn) {
-    TL_VEC(double, k1, D.n); TL_VEC(double, k2, D.n); TL_VEC(double, k3, D.n); TL_VEC(double, t, D.n);
+void rk3(const Dims& D, const real* x, const real* u, real* xn) {
+    TL_VEC(real, k1, D.n); TL_VEC(real, k2, D.n); TL_VEC(real, k3, D.n); TL_VEC(real, t, D.n);
     dynamics(D, x, u, k1.data());
     for (int i = 0; i < D.n; i++) { k1[i] *= D.dt; t[i] = x[i] + k1[i] / 2; }
     dynamics(D, t.data(), u, k2.data());
@@ -223,7 +255,7 @@ void rk3(const Dims& D, const double* x, const double* u, double* xn) {
     for (int i = 0; i < D.n; i++) { k3[i] *= D.dt; xn[i] = x[i] + (k1[i] + 4 * k2[i] + k3[i]) / 6; }
 }
 // ∇dynamics! (local_quantities.jl:20-27): n x (n+m) Jacobian [A B] of the RK2 map, row-major J[r*(n+m)+c]
-void rk2_jacobian(const Dims& D, const double* x, const double* u, double* J) {
+void rk2_jacobian(const Dims& D, const real* x, const real* u, real* J) {
     const int nd = D.n + D.m;
     TL_VEC(Dual, xd, D.n); TL_VEC(Dual, ud, D.m); TL_VEC(Dual, xn, D.n);
     for (int i = 0; i < D.n; i++) { xd[i] = dconst(x[i], nd); xd[i].e[i] = 1.0; }
@@ -240,10 +272,10 @@ inline uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-inline double counter_uniform(uint64_t seed, uint64_t game, uint64_t counter) {
+inline real counter_uniform(uint64_t seed, uint64_t game, uint64_t counter) {
     uint64_t h = splitmix64(seed ^ splitmix64(game * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull));
     h = splitmix64(h + counter * 0x9E3779B97F4A7C15ull);
-    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    return (real)(h >> 11) * (1.0 / 9007199254740992.0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,37 +285,38 @@ struct Shared {
     Dims D;
     alg_options opt;
     bool has_colcost = false, has_colavoid = false, has_ctl = false;
-    std::vector<double> cc_radius, cc_mu;   // collision cost (objective.jl:84-100)
-    std::vector<double> ca_radius;          // collision avoidance radii per player (vector form of the adder)
+    std::vector<real> cc_radius, cc_mu;   // collision cost (objective.jl:84-100)
+    std::vector<real> ca_radius;          // collision avoidance radii per player (vector form of the adder)
     // per ordered pair: radius of its CollisionConstraint, < 0 = this pair carries none (add_collision_avoidance!(game_con, i, j, radius),
     // constraints_methods.jl:5-19; the vector form fills every pair with r_i + r_j, :21-33)
-    std::vector<double> pair_r;
+    std::vector<real> pair_r;
     bool pair_on(int i, int j) const { return pair_r[(size_t)i * D.p + j] >= 0.0; }
-    std::vector<double> umax, umin;         // control bound
-    std::vector<double> sbmax, sbmin;       // state bounds [p][n] (+-inf where absent)
-    std::vector<double> wx1, wy1, wx2, wy2, wxv, wyv;   // walls
-    std::vector<double> cxc, cyc, crad;     // circles
+    std::vector<real> umax, umin;         // control bound
+    std::vector<real> sbmax, sbmin;       // state bounds [p][n] (+-inf where absent)
+    std::vector<real> wx1, wy1, wx2, wy2, wxv, wyv;   // walls
+    std::vector<real> cxc, cyc, crad;     // circles
     // per-player sets (add_wall_constraint!(game_con, i, walls) / add_circle_constraint!(game_con, i, ...), constraints_methods.jl:121-187):
     // the reference pushes the constraint object to state_conval[i] only; here the table is shared and bit w of wall_mask[i] says
     // whether entry w constrains player i -- a row whose bit is clear evaluates to c = 0 with a zero Jacobian (inert)
     unsigned wall_mask[10], circ_mask[10];
     Shared() { for (int i = 0; i < 10; i++) wall_mask[i] = circ_mask[i] = 0xffffffffu; }
-    std::vector<double> w3p1, w3p2, w3p3, w3v;   // Wall3D(p1, p2, p3, v): nwall3 x 3 each (constraints_methods.jl:201-206)
-    std::vector<double> cyp, cyl, cyr; std::vector<int> cyax;   // CylinderWall(p, v, l, r): ncyl x 3, axis 0/1/2 = :x/:y/:z (:249-254)
+    std::vector<real> w3p1, w3p2, w3p3, w3v;   // Wall3D(p1, p2, p3, v): nwall3 x 3 each (constraints_methods.jl:201-206)
+    std::vector<real> cyp, cyl, cyr; std::vector<int> cyax;   // CylinderWall(p, v, l, r): ncyl x 3, axis 0/1/2 = :x/:y/:z (:249-254)
 };
 
 struct Game {
     // joint-dimension zero-padded LQR data per player (objective.jl:24-28)
-    std::vector<double> Q, R, xf, uf;     // p*n, p*m, p*n, p*m
-    std::vector<double> x0;
-    std::vector<double> z[3];             // pdtraj, trial, delta (traj_len each)
-    std::vector<double> lam, mu, vals;    // con_len
+    std::vector<real> Q, R, xf, uf;     // p*n, p*m, p*n, p*m
+    std::vector<real> x0;
+    std::vector<real> z[3];             // pdtraj, trial, delta (traj_len each)
+    std::vector<real> lam, mu, vals;    // con_len
     std::vector<alg_record> hist;
     alg_game_stats st{};
     int64_t mpc_iters = 0, mpc_conv = 0;
-    double max_delta = 0.0;       // maximum(prob.stats.Δ_traj) over the Statistics history
+    real max_delta = 0.0;       // maximum(prob.stats.Δ_traj) over the Statistics history
+    double t_elap = 0.0;        // @elapsed of the previous inner iteration (statistics.jl:8; 0 before the first)
     // scratch
-    std::vector<double> res, jac;
+    std::vector<real> res, jac;
 };
 
 struct Handle {
@@ -292,19 +325,19 @@ struct Handle {
     bool x0_set = false, lqr_set = false;
 };
 
-inline const double* state(const Dims& D, const std::vector<double>& z, int k) {  // knot k = 0..N-1
+inline const real* state(const Dims& D, const std::vector<real>& z, int k) {  // knot k = 0..N-1
     return k == 0 ? z.data() : z.data() + D.n + D.hx(k - 1);
 }
-inline double* state(const Dims& D, std::vector<double>& z, int k) {
+inline real* state(const Dims& D, std::vector<real>& z, int k) {
     return k == 0 ? z.data() : z.data() + D.n + D.hx(k - 1);
 }
-inline void get_control(const Dims& D, const std::vector<double>& z, int k, double* u) {  // joint order
+inline void get_control(const Dims& D, const std::vector<real>& z, int k, real* u) {  // joint order
     for (int i = 0; i < D.p; i++) for (int j = 0; j < D.mi; j++) u[D.pu(i, j)] = z[D.n + D.hu(k, i) + j];
 }
-inline void set_control(const Dims& D, std::vector<double>& z, int k, const double* u) {
+inline void set_control(const Dims& D, std::vector<real>& z, int k, const real* u) {
     for (int i = 0; i < D.p; i++) for (int j = 0; j < D.mi; j++) z[D.n + D.hu(k, i) + j] = u[D.pu(i, j)];
 }
-inline const double* dual(const Dims& D, const std::vector<double>& z, int i, int k) {
+inline const real* dual(const Dims& D, const std::vector<real>& z, int i, int k) {
     return z.data() + D.n + D.hl(k, i);
 }
 
@@ -314,21 +347,21 @@ inline const double* dual(const Dims& D, const std::vector<double>& z, int i, in
 // [PINNED test/objective/objective.jl:52-64].
 // q (n) of player i at knot k for all objectives j (LQR + collision costs), summed as in
 // global_quantities.jl:26-31.
-void cost_grad_x(const Shared& sh, const Game& g, int i, int k, const double* x, double* q) {
+void cost_grad_x(const Shared& sh, const Game& g, int i, int k, const real* x, real* q) {
     const Dims& D = sh.D;
-    const double w = (k < D.N - 1) ? D.dt : 1.0;
+    const real w = (k < D.N - 1) ? D.dt : 1.0;
     for (int r = 0; r < D.n; r++) q[r] = w * (g.Q[i * D.n + r] * (x[r] - g.xf[i * D.n + r]));   // LQRCost: Q(x-xf)
     if (sh.has_colcost) {
         // CollisionCost gradient (objective.jl:134-149)
-        const double eps = 1e-10, eps_norm = eps * std::sqrt((double)D.n);
+        const real eps = 1e-10, eps_norm = eps * r_sqrt((real)D.n);
         for (int j = 0; j < D.p; j++) if (j != i) {
-            double dl[2], nrm = 0;
+            real dl[2], nrm = 0;
             for (int a = 0; a < 2; a++) { dl[a] = x[D.px(i, a)] - x[D.px(j, a)]; nrm += dl[a] * dl[a]; }
-            nrm = std::sqrt(nrm);
-            const double mu = sh.cc_mu[i], rad = sh.cc_radius[i];
-            if (std::max(0.0, rad - nrm) > 0.0) {
+            nrm = r_sqrt(nrm);
+            const real mu = sh.cc_mu[i], rad = sh.cc_radius[i];
+            if (std::max<real>(0.0, rad - nrm) > 0.0) {
                 for (int a = 0; a < 2; a++) {
-                    double gg = mu * (rad * (eps + dl[a]) / (eps_norm + nrm) - dl[a]);
+                    real gg = mu * (rad * (eps + dl[a]) / (eps_norm + nrm) - dl[a]);
                     q[D.px(i, a)] += w * (-gg);
                     q[D.px(j, a)] += w * (gg);
                 }
@@ -337,26 +370,26 @@ void cost_grad_x(const Shared& sh, const Game& g, int i, int k, const double* x,
     }
 }
 // r[pu[i]] of player i at knot k < N-1 (global_quantities.jl:34-40); only the LQR term is non-zero
-void cost_grad_u(const Shared& sh, const Game& g, int i, const double* u, double* r /*mi*/) {
+void cost_grad_u(const Shared& sh, const Game& g, int i, const real* u, real* r /*mi*/) {
     const Dims& D = sh.D;
     for (int j = 0; j < D.mi; j++) { int c = D.pu(i, j); r[j] = D.dt * (g.R[i * D.m + c] * (u[c] - g.uf[i * D.m + c])); }
 }
 // cost_hessian!: Q (n x n, row-major) of player i at knot k, all objectives (global_quantities.jl:128-136)
-void cost_hess_x(const Shared& sh, const Game& g, int i, int k, const double* x, double* Qm) {
+void cost_hess_x(const Shared& sh, const Game& g, int i, int k, const real* x, real* Qm) {
     const Dims& D = sh.D;
-    const double w = (k < D.N - 1) ? D.dt : 1.0;
+    const real w = (k < D.N - 1) ? D.dt : 1.0;
     std::fill(Qm, Qm + D.n * D.n, 0.0);
     for (int r = 0; r < D.n; r++) Qm[r * D.n + r] += w * g.Q[i * D.n + r];
     if (sh.has_colcost) {
         // CollisionCost Hessian (objective.jl:157-173)
         for (int j = 0; j < D.p; j++) if (j != i) {
-            double dl[2], nrm = 0;
+            real dl[2], nrm = 0;
             for (int a = 0; a < 2; a++) { dl[a] = x[D.px(i, a)] - x[D.px(j, a)]; nrm += dl[a] * dl[a]; }
-            nrm = std::sqrt(nrm);
-            const double mu = sh.cc_mu[i], rad = sh.cc_radius[i];
-            if (std::max(0.0, rad - nrm) > 0.0) {
+            nrm = r_sqrt(nrm);
+            const real mu = sh.cc_mu[i], rad = sh.cc_radius[i];
+            if (std::max<real>(0.0, rad - nrm) > 0.0) {
                 for (int a = 0; a < 2; a++) for (int c = 0; c < 2; c++) {
-                    double h = mu * ((a == c ? 1.0 : 0.0) - (a == c ? rad / nrm : 0.0) + rad * (dl[a] * dl[c]) / (nrm * nrm * nrm));
+                    real h = mu * ((a == c ? 1.0 : 0.0) - (a == c ? rad / nrm : 0.0) + rad * (dl[a] * dl[c]) / (nrm * nrm * nrm));
                     Qm[D.px(i, a) * D.n + D.px(i, c)] += w * h;
                     Qm[D.px(i, a) * D.n + D.px(j, c)] += -w * h;
                     Qm[D.px(j, a) * D.n + D.px(i, c)] += -w * h;
@@ -374,105 +407,105 @@ inline int con_ctl(const Dims& D, int k /*0..N-2*/, int row) { return D.col_len 
 
 // TrajectoryOptimization 0.4.1 CollisionConstraint: c = radius^2 - |x[x1]-x[x2]|^2, d c/d x1 = -2 d,
 // d c/d x2 = 2 d  [restated; parity unpinned].  Pair radius = r_i + r_j (constraints_methods.jl:27-29).
-inline double colavoid_val(const Shared& sh, int i, int j, const double* x, double* dl) {
+inline real colavoid_val(const Shared& sh, int i, int j, const real* x, real* dl) {
     const Dims& D = sh.D;
-    double R = sh.pair_r[(size_t)i * D.p + j], s = 0;
+    real R = sh.pair_r[(size_t)i * D.p + j], s = 0;
     // add_collision_avoidance!: px[i] (2 positions, constraints_methods.jl:13); add_spherical_collision_avoidance!: pz[i][1:3] (:52-54)
     for (int a = 0; a < D.ca_dim; a++) { dl[a] = x[D.pz(i, a)] - x[D.pz(j, a)]; s += dl[a] * dl[a]; }
     return R * R - s;
 }
 // ControlBoundConstraint evaluate (control_bound_constraint.jl:94-96): [u - u_max; u_min - u]
-inline double ctl_val(const Shared& sh, const double* u, int row) {
+inline real ctl_val(const Shared& sh, const real* u, int row) {
     const int m = sh.D.m;
     return row < m ? u[row] - sh.umax[row] : sh.umin[row - m] - u[row - m];
 }
-inline double al_active_mu(double c, double lam, double mu);
+inline real al_active_mu(real c, real lam, real mu);
 // WallConstraint evaluate / jacobian (wall_constraint.jl:68-96): c = ((x-x1) xv + (y-y1) yv) left right, grad = [xv, yv] left right
-inline double wall_val(const Shared& sh, int w, double x, double y, double* gx, double* gy) {
-    const double x1 = sh.wx1[w], y1 = sh.wy1[w], x2 = sh.wx2[w], y2 = sh.wy2[w], xv = sh.wxv[w], yv = sh.wyv[w];
-    const double left = ((x - x1) * (x2 - x1) + (y - y1) * (y2 - y1) > 0) ? 1.0 : 0.0;
-    const double right = ((x - x2) * (x1 - x2) + (y - y2) * (y1 - y2) > 0) ? 1.0 : 0.0;
+inline real wall_val(const Shared& sh, int w, real x, real y, real* gx, real* gy) {
+    const real x1 = sh.wx1[w], y1 = sh.wy1[w], x2 = sh.wx2[w], y2 = sh.wy2[w], xv = sh.wxv[w], yv = sh.wyv[w];
+    const real left = ((x - x1) * (x2 - x1) + (y - y1) * (y2 - y1) > 0) ? 1.0 : 0.0;
+    const real right = ((x - x2) * (x1 - x2) + (y - y2) * (y1 - y2) > 0) ? 1.0 : 0.0;
     *gx = left * right * xv; *gy = left * right * yv;
     return ((x - x1) * xv + (y - y1) * yv) * left * right;
 }
 // TrajectoryOptimization 0.4.1 CircleConstraint: c = r^2 - (x-xc)^2 - (y-yc)^2, grad = [-2(x-xc), -2(y-yc)]  [restated; parity unpinned]
-inline double circ_val(const Shared& sh, int c, double x, double y, double* gx, double* gy) {
-    const double dx = x - sh.cxc[c], dy = y - sh.cyc[c];
+inline real circ_val(const Shared& sh, int c, real x, real y, real* gx, real* gy) {
+    const real dx = x - sh.cxc[c], dy = y - sh.cyc[c];
     *gx = -2.0 * dx; *gy = -2.0 * dy;
     return -(dx * dx) - (dy * dy) + sh.crad[c] * sh.crad[c];
 }
 // Wall3DConstraint evaluate / jacobian! (wall_constraint.jl:186-236): c = (x - p1).v inside the slab spanned by (p1,p2) and (p2,p3)
-inline double wall3_val(const Shared& sh, int w, const double* q /*x y z*/, double* gv /*3*/) {
-    const double* p1 = &sh.w3p1[3 * w]; const double* p2 = &sh.w3p2[3 * w]; const double* p3 = &sh.w3p3[3 * w]; const double* v = &sh.w3v[3 * w];
-    auto dot = [&](const double* a, const double* b2, const double* c) { return (q[0] - a[0]) * (b2[0] - c[0]) + (q[1] - a[1]) * (b2[1] - c[1]) + (q[2] - a[2]) * (b2[2] - c[2]); };
-    const double left = dot(p1, p2, p1) > 0 ? 1.0 : 0.0, right = dot(p2, p1, p2) > 0 ? 1.0 : 0.0;
-    const double bottom = dot(p3, p2, p3) > 0 ? 1.0 : 0.0, top = dot(p2, p3, p2) > 0 ? 1.0 : 0.0;
-    const double in = left * right * bottom * top;
+inline real wall3_val(const Shared& sh, int w, const real* q /*x y z*/, real* gv /*3*/) {
+    const real* p1 = &sh.w3p1[3 * w]; const real* p2 = &sh.w3p2[3 * w]; const real* p3 = &sh.w3p3[3 * w]; const real* v = &sh.w3v[3 * w];
+    auto dot = [&](const real* a, const real* b2, const real* c) { return (q[0] - a[0]) * (b2[0] - c[0]) + (q[1] - a[1]) * (b2[1] - c[1]) + (q[2] - a[2]) * (b2[2] - c[2]); };
+    const real left = dot(p1, p2, p1) > 0 ? 1.0 : 0.0, right = dot(p2, p1, p2) > 0 ? 1.0 : 0.0;
+    const real bottom = dot(p3, p2, p3) > 0 ? 1.0 : 0.0, top = dot(p2, p3, p2) > 0 ? 1.0 : 0.0;
+    const real in = left * right * bottom * top;
     for (int a = 0; a < 3; a++) gv[a] = in * v[a];
     return ((q[0] - p1[0]) * v[0] + (q[1] - p1[1]) * v[1] + (q[2] - p1[2]) * v[2]) * in;
 }
 // CylinderConstraint evaluate / jacobian! (cylinder_constraint.jl:68-127): axis-aligned cylinder of radius r starting at p,
 // length l along axis v; c = r^2 - (squared distance to the axis) while 0 < (q - p)[v] < l, else 0
-inline double cyl_val(const Shared& sh, int c, const double* q, double* gv /*3*/) {
-    const double* p = &sh.cyp[3 * c]; const int ax = sh.cyax[c]; const double l = sh.cyl[c], r = sh.cyr[c];
-    const double t0[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
-    const double valid = (t0[ax] > 0.0 && t0[ax] < l) ? 1.0 : 0.0;
-    double out = r * r - t0[0] * t0[0] - t0[1] * t0[1] - t0[2] * t0[2] + t0[ax] * t0[ax];
+inline real cyl_val(const Shared& sh, int c, const real* q, real* gv /*3*/) {
+    const real* p = &sh.cyp[3 * c]; const int ax = sh.cyax[c]; const real l = sh.cyl[c], r = sh.cyr[c];
+    const real t0[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+    const real valid = (t0[ax] > 0.0 && t0[ax] < l) ? 1.0 : 0.0;
+    real out = r * r - t0[0] * t0[0] - t0[1] * t0[1] - t0[2] * t0[2] + t0[ax] * t0[ax];
     for (int a = 0; a < 3; a++) gv[a] = (a == ax) ? 0.0 : -valid * 2 * t0[a];
     return out * valid;
 }
 // StateBoundConstraint evaluate (state_bound_constraint.jl:85-87): [x - x_max; x_min - x]
-inline double sb_val(const Shared& sh, int i, const double* x, int row) {
+inline real sb_val(const Shared& sh, int i, const real* x, int row) {
     const int n = sh.D.n;
     return row < n ? x[row] - sh.sbmax[i * n + row] : sh.sbmin[i * n + row - n] - x[row - n];
 }
 // Adds the AL gradient (into res rows of player i at knot k) and/or the AL Hessian (through add) of the extended
 // state constraints of player i at knot k (constraint_derivatives.jl:10-19,47-58): all are per-row scalar constraints.
 template <class Add>
-void ext_state_con(const Shared& sh, Game& g, const std::vector<double>& z, int i, int k, double* grad /*n or null*/, Add add) {
-    const Dims& D = sh.D; const double* x = state(D, z, k);
-    auto row = [&](int ci, double c, const int* idx, const double* gv, int cnt) {
+void ext_state_con(const Shared& sh, Game& g, const std::vector<real>& z, int i, int k, real* grad /*n or null*/, Add add) {
+    const Dims& D = sh.D; const real* x = state(D, z, k);
+    auto row = [&](int ci, real c, const int* idx, const real* gv, int cnt) {
         g.vals[ci] = c;
-        if (!std::isfinite(c)) return;
-        const double am = al_active_mu(c, g.lam[ci], g.mu[ci]);
-        const double w = g.lam[ci] + am * c;
+        if (!r_isfinite(c)) return;
+        const real am = al_active_mu(c, g.lam[ci], g.mu[ci]);
+        const real w = g.lam[ci] + am * c;
         for (int a = 0; a < cnt; a++) { if (grad) grad[idx[a]] += gv[a] * w; for (int b2 = 0; b2 < cnt; b2++) if (am != 0.0) add(idx[a], idx[b2], am * gv[a] * gv[b2]); }
     };
-    if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { int idx[1] = {r % D.n}; double gv[1] = {r < D.n ? 1.0 : -1.0}; row(D.o_sb(i, k, r), sb_val(sh, i, x, r), idx, gv, 1); }
+    if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { int idx[1] = {r % D.n}; real gv[1] = {r < D.n ? 1.0 : -1.0}; row(D.o_sb(i, k, r), sb_val(sh, i, x, r), idx, gv, 1); }
     const int idx2[2] = {D.px(i, 0), D.px(i, 1)};
     for (int w = 0; w < D.nwall; w++) {
-        double gv[2]; const double on = (double)((sh.wall_mask[i] >> w) & 1u);
-        const double c = on * wall_val(sh, w, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); gv[0] *= on; gv[1] *= on;
+        real gv[2]; const real on = (real)((sh.wall_mask[i] >> w) & 1u);
+        const real c = on * wall_val(sh, w, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); gv[0] *= on; gv[1] *= on;
         row(D.o_wall(i, k, w), c, idx2, gv, 2);
     }
     for (int c2 = 0; c2 < D.ncirc; c2++) {
-        double gv[2]; const double on = (double)((sh.circ_mask[i] >> c2) & 1u);
-        const double c = on * circ_val(sh, c2, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); gv[0] *= on; gv[1] *= on;
+        real gv[2]; const real on = (real)((sh.circ_mask[i] >> c2) & 1u);
+        const real c = on * circ_val(sh, c2, x[idx2[0]], x[idx2[1]], &gv[0], &gv[1]); gv[0] *= on; gv[1] *= on;
         row(D.o_circ(i, k, c2), c, idx2, gv, 2);
     }
     // Wall3D / Cylinder act on pz[i][1..3] (constraints_methods.jl:231-236,275)
     const int idx3[3] = {D.pz(i, 0), D.pz(i, 1), D.pz(i, 2)};
-    const double q3[3] = {x[idx3[0]], x[idx3[1]], x[idx3[2]]};
-    for (int w = 0; w < D.nwall3; w++) { double gv[3]; const double c = wall3_val(sh, w, q3, gv); row(D.o_wall3(i, k, w), c, idx3, gv, 3); }
-    for (int c2 = 0; c2 < D.ncyl; c2++) { double gv[3]; const double c = cyl_val(sh, c2, q3, gv); row(D.o_cyl(i, k, c2), c, idx3, gv, 3); }
+    const real q3[3] = {x[idx3[0]], x[idx3[1]], x[idx3[2]]};
+    for (int w = 0; w < D.nwall3; w++) { real gv[3]; const real c = wall3_val(sh, w, q3, gv); row(D.o_wall3(i, k, w), c, idx3, gv, 3); }
+    for (int c2 = 0; c2 < D.ncyl; c2++) { real gv[3]; const real c = cyl_val(sh, c2, q3, gv); row(D.o_cyl(i, k, c2), c, idx3, gv, 3); }
 }
 
 // evaluate!(game_con, traj) (constraints_methods.jl:367-379)
-void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
+void evaluate_con(const Shared& sh, Game& g, const std::vector<real>& z) {
     const Dims& D = sh.D;
-    std::vector<double> u(D.m);
+    std::vector<real> u(D.m);
     if (sh.has_colavoid)
         for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i && sh.pair_on(i, j))
-            for (int k = 1; k < D.N; k++) { double dl[3]; g.vals[con_col(D, D.pair(i, j), k)] = colavoid_val(sh, i, j, state(D, z, k), dl); }
+            for (int k = 1; k < D.N; k++) { real dl[3]; g.vals[con_col(D, D.pair(i, j), k)] = colavoid_val(sh, i, j, state(D, z, k), dl); }
     if (sh.has_ctl)
         for (int k = 0; k < D.N - 1; k++) { get_control(D, z, k, u.data()); for (int r = 0; r < 2 * D.m; r++) g.vals[con_ctl(D, k, r)] = ctl_val(sh, u.data(), r); }
     for (int i = 0; i < D.p; i++) for (int k = 1; k < D.N; k++) {
-        const double* x = state(D, z, k); double gx, gy;
+        const real* x = state(D, z, k); real gx, gy;
         if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) g.vals[D.o_sb(i, k, r)] = sb_val(sh, i, x, r);
-        for (int w = 0; w < D.nwall; w++) g.vals[D.o_wall(i, k, w)] = (double)((sh.wall_mask[i] >> w) & 1u) * wall_val(sh, w, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
-        for (int c = 0; c < D.ncirc; c++) g.vals[D.o_circ(i, k, c)] = (double)((sh.circ_mask[i] >> c) & 1u) * circ_val(sh, c, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
+        for (int w = 0; w < D.nwall; w++) g.vals[D.o_wall(i, k, w)] = (real)((sh.wall_mask[i] >> w) & 1u) * wall_val(sh, w, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
+        for (int c = 0; c < D.ncirc; c++) g.vals[D.o_circ(i, k, c)] = (real)((sh.circ_mask[i] >> c) & 1u) * circ_val(sh, c, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
         if (D.nwall3 + D.ncyl > 0) {
-            const double q3[3] = {x[D.pz(i, 0)], x[D.pz(i, 1)], x[D.pz(i, 2)]}; double gv[3];
+            const real q3[3] = {x[D.pz(i, 0)], x[D.pz(i, 1)], x[D.pz(i, 2)]}; real gv[3];
             for (int w = 0; w < D.nwall3; w++) g.vals[D.o_wall3(i, k, w)] = wall3_val(sh, w, q3, gv);
             for (int c = 0; c < D.ncyl; c++) g.vals[D.o_cyl(i, k, c)] = cyl_val(sh, c, q3, gv);
         }
@@ -480,15 +513,15 @@ void evaluate_con(const Shared& sh, Game& g, const std::vector<double>& z) {
 }
 // Altro 0.3.0 / TrajOpt cost_expansion!(conval): a = (c >= 0) | (lambda > 0); I_mu = diag(a*mu);
 // grad = C'(lambda + I_mu c); hess = C' I_mu C  [PINNED test/constraints/constraint_derivatives.jl:28-34]
-inline double al_active_mu(double c, double lam, double mu) { return ((c >= 0) || (lam > 0)) ? mu : 0.0; }
+inline real al_active_mu(real c, real lam, real mu) { return ((c >= 0) || (lam > 0)) ? mu : 0.0; }
 
 // ---- residual! (global_quantities.jl:9-65) + regularize_residual! (:67-86) -------------------
-void residual(const Shared& sh, Game& g, const std::vector<double>& z, double reg, const std::vector<double>* zref) {
+void residual(const Shared& sh, Game& g, const std::vector<real>& z, real reg, const std::vector<real>* zref) {
     const Dims& D = sh.D;
     const int n = D.n, m = D.m, p = D.p, N = D.N, nd = n + m;
-    std::vector<double>& res = g.res;
+    std::vector<real>& res = g.res;
     res.assign(D.S, 0.0);                                                            // :18
-    TL_VEC(double, q, n); TL_VEC(double, r, D.mi); TL_VEC(double, u, m); TL_VEC(double, J, n * nd); TL_VEC(double, xn, n); TL_VEC(double, uref, m);
+    TL_VEC(real, q, n); TL_VEC(real, r, D.mi); TL_VEC(real, u, m); TL_VEC(real, J, n * nd); TL_VEC(real, xn, n); TL_VEC(real, uref, m);
     // Cost (:23-41).  stamp (opt,i,x,k) is invalid for the first knot (stamp.jl:203).
     for (int i = 0; i < p; i++) {
         for (int k = 1; k < N; k++) {
@@ -506,10 +539,10 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
         get_control(D, z, k, u.data());
         rk2_jacobian(D, state(D, z, k), u.data(), J.data());
         for (int i = 0; i < p; i++) {
-            const double* lam = dual(D, z, i, k);
+            const real* lam = dual(D, z, i, k);
             if (k >= 1)                                                              // (opt,i,x,k) valid only for knots 2..N
-                for (int c = 0; c < n; c++) { double s = 0; for (int rr = 0; rr < n; rr++) s += J[rr * nd + c] * lam[rr]; res[D.vx(i, k - 1) + c] += s; }
-            for (int j = 0; j < D.mi; j++) { int c = n + D.pu(i, j); double s = 0; for (int rr = 0; rr < n; rr++) s += J[rr * nd + c] * lam[rr]; res[D.vu(i, k) + j] += s; }
+                for (int c = 0; c < n; c++) { real s = 0; for (int rr = 0; rr < n; rr++) s += J[rr * nd + c] * lam[rr]; res[D.vx(i, k - 1) + c] += s; }
+            for (int j = 0; j < D.mi; j++) { int c = n + D.pu(i, j); real s = 0; for (int rr = 0; rr < n; rr++) s += J[rr * nd + c] * lam[rr]; res[D.vu(i, k) + j] += s; }
             for (int c = 0; c < n; c++) res[D.vx(i, k) + c] += -lam[c];
         }
     }
@@ -518,11 +551,11 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
         for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i && sh.pair_on(i, j)) {
             const int qd = D.pair(i, j);
             for (int k = 1; k < N; k++) {
-                double dl[3];
-                const double c = colavoid_val(sh, i, j, state(D, z, k), dl);
+                real dl[3];
+                const real c = colavoid_val(sh, i, j, state(D, z, k), dl);
                 const int ci = con_col(D, qd, k);
                 g.vals[ci] = c;
-                const double w = g.lam[ci] + al_active_mu(c, g.lam[ci], g.mu[ci]) * c;
+                const real w = g.lam[ci] + al_active_mu(c, g.lam[ci], g.mu[ci]) * c;
                 for (int a = 0; a < D.ca_dim; a++) {                                 // grad = C' w, C = [-2d' at px[i], +2d' at px[j]]
                     res[D.vx(i, k - 1) + D.pz(i, a)] += -2 * dl[a] * w;
                     res[D.vx(i, k - 1) + D.pz(j, a)] += 2 * dl[a] * w;
@@ -531,19 +564,19 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
         }
     }
     if (D.con_len > D.col_len + D.ctl_len)
-        for (int i = 0; i < p; i++) for (int k = 1; k < N; k++) ext_state_con(sh, g, z, i, k, &res[D.vx(i, k - 1)], [](int, int, double) {});
+        for (int i = 0; i < p; i++) for (int k = 1; k < N; k++) ext_state_con(sh, g, z, i, k, &res[D.vx(i, k - 1)], [](int, int, real) {});
     if (sh.has_ctl) {
         for (int k = 0; k < N - 1; k++) {
             get_control(D, z, k, u.data());
             for (int i = 0; i < p; i++) for (int j = 0; j < D.mi; j++) {
                 const int c = D.pu(i, j);
-                double gsum = 0;
+                real gsum = 0;
                 for (int half = 0; half < 2; half++) {
                     const int row = half * m + c, ci = con_ctl(D, k, row);
-                    const double cv = ctl_val(sh, u.data(), row);
+                    const real cv = ctl_val(sh, u.data(), row);
                     g.vals[ci] = cv;
-                    if (!std::isfinite(cv)) continue;                                // infinite bound: row absent in the reference
-                    const double w = g.lam[ci] + al_active_mu(cv, g.lam[ci], g.mu[ci]) * cv;
+                    if (!r_isfinite(cv)) continue;                                // infinite bound: row absent in the reference
+                    const real w = g.lam[ci] + al_active_mu(cv, g.lam[ci], g.mu[ci]) * cv;
                     gsum += (half == 0 ? 1.0 : -1.0) * w;
                 }
                 res[D.vu(i, k) + j] += gsum;
@@ -554,13 +587,13 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
     for (int k = 0; k < N - 1; k++) {
         get_control(D, z, k, u.data());
         rk2(D, state(D, z, k), u.data(), xn.data());
-        const double* x1 = state(D, z, k + 1);
+        const real* x1 = state(D, z, k + 1);
         for (int a = 0; a < n; a++) res[D.vd(k) + a] += xn[a] - x1[a];
     }
     // regularize_residual! (:67-86)
     if (zref && reg != 0.0) {
         for (int k = 0; k < N - 1; k++) {
-            const double* x = state(D, z, k + 1); const double* xr = state(D, *zref, k + 1);
+            const real* x = state(D, z, k + 1); const real* xr = state(D, *zref, k + 1);
             get_control(D, z, k, u.data()); get_control(D, *zref, k, uref.data());
             for (int i = 0; i < p; i++) {
                 for (int a = 0; a < n; a++) res[D.vx(i, k) + a] += reg * (x[a] - xr[a]);
@@ -570,17 +603,17 @@ void residual(const Shared& sh, Game& g, const std::vector<double>& z, double re
     }
 }
 
-double res_norm(const Shared& sh, const Game& g) {   // norm(core.res,1)/length(core.res)  (solver_methods.jl:76)
-    double s = 0; for (double v : g.res) s += std::fabs(v); return s / sh.D.S;
+real res_norm(const Shared& sh, const Game& g) {   // norm(core.res,1)/length(core.res)  (solver_methods.jl:76)
+    real s = 0; for (real v : g.res) s += r_fabs(v); return s / sh.D.S;
 }
 
 // ---- residual_jacobian! (:109-174) + regularize_residual_jacobian! (:176-193) ----------------
 // add(row_vertical, col_horizontal, value)
 template <class Add>
-void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double reg, Add add) {
+void jacobian(const Shared& sh, Game& g, const std::vector<real>& z, real reg, Add add) {
     const Dims& D = sh.D;
     const int n = D.n, m = D.m, p = D.p, N = D.N, nd = n + m;
-    TL_VEC(double, Qm, n * n); TL_VEC(double, u, m); TL_VEC(double, J, n * nd);
+    TL_VEC(real, Qm, n * n); TL_VEC(real, u, m); TL_VEC(real, J, n * nd);
     // Cost (:128-145)
     for (int i = 0; i < p; i++) {
         for (int k = 1; k < N; k++) {
@@ -595,14 +628,14 @@ void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double re
         for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) if (j != i && sh.pair_on(i, j)) {
             const int qd = D.pair(i, j);
             for (int k = 1; k < N; k++) {
-                double dl[3];
-                const double c = colavoid_val(sh, i, j, state(D, z, k), dl);
+                real dl[3];
+                const real c = colavoid_val(sh, i, j, state(D, z, k), dl);
                 const int ci = con_col(D, qd, k);
-                const double am = al_active_mu(c, g.lam[ci], g.mu[ci]);
+                const real am = al_active_mu(c, g.lam[ci], g.mu[ci]);
                 if (am == 0.0) continue;
                 // hess = C' I_mu C with C = [-2d at px[i], 2d at px[j]]
                 const int cd = D.ca_dim;
-                int idx[6]; double cv[6];
+                int idx[6]; real cv[6];
                 for (int a = 0; a < cd; a++) { idx[a] = D.pz(i, a); idx[cd + a] = D.pz(j, a); cv[a] = -2 * dl[a]; cv[cd + a] = 2 * dl[a]; }
                 for (int a = 0; a < 2 * cd; a++) for (int c2 = 0; c2 < 2 * cd; c2++)
                     add(D.vx(i, k - 1) + idx[a], D.hx(k - 1) + idx[c2], am * cv[a] * cv[c2]);
@@ -611,17 +644,17 @@ void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double re
     }
     if (D.con_len > D.col_len + D.ctl_len)
         for (int i = 0; i < p; i++) for (int k = 1; k < N; k++)
-            ext_state_con(sh, g, z, i, k, nullptr, [&](int a, int c, double v) { add(D.vx(i, k - 1) + a, D.hx(k - 1) + c, v); });
+            ext_state_con(sh, g, z, i, k, nullptr, [&](int a, int c, real v) { add(D.vx(i, k - 1) + a, D.hx(k - 1) + c, v); });
     if (sh.has_ctl) {
         for (int k = 0; k < N - 1; k++) {
             get_control(D, z, k, u.data());
             for (int i = 0; i < p; i++) for (int j = 0; j < D.mi; j++) {
                 const int c = D.pu(i, j);
-                double h = 0;
+                real h = 0;
                 for (int half = 0; half < 2; half++) {
                     const int row = half * m + c, ci = con_ctl(D, k, row);
-                    const double cv = ctl_val(sh, u.data(), row);
-                    if (!std::isfinite(cv)) continue;
+                    const real cv = ctl_val(sh, u.data(), row);
+                    if (!r_isfinite(cv)) continue;
                     h += al_active_mu(cv, g.lam[ci], g.mu[ci]);
                 }
                 if (h != 0.0) add(D.vu(i, k) + j, D.hu(k, i) + j, h);
@@ -634,12 +667,12 @@ void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double re
         rk2_jacobian(D, state(D, z, k), u.data(), J.data());
         if (k >= 1) for (int a = 0; a < n; a++) for (int c = 0; c < n; c++) if (J[a * nd + c] != 0.0) add(D.vd(k) + a, D.hx(k - 1) + c, J[a * nd + c]);
         for (int i = 0; i < p; i++) for (int j = 0; j < D.mi; j++) for (int a = 0; a < n; a++) {
-            double v = J[a * nd + n + D.pu(i, j)]; if (v != 0.0) add(D.vd(k) + a, D.hu(k, i) + j, v);
+            real v = J[a * nd + n + D.pu(i, j)]; if (v != 0.0) add(D.vd(k) + a, D.hu(k, i) + j, v);
         }
         for (int a = 0; a < n; a++) add(D.vd(k) + a, D.hx(k) + a, -1.0);
         for (int i = 0; i < p; i++) {
             if (k >= 1) for (int a = 0; a < n; a++) for (int c = 0; c < n; c++) if (J[a * nd + c] != 0.0) add(D.vx(i, k - 1) + c, D.hl(k, i) + a, J[a * nd + c]);
-            for (int j = 0; j < D.mi; j++) for (int a = 0; a < n; a++) { double v = J[a * nd + n + D.pu(i, j)]; if (v != 0.0) add(D.vu(i, k) + j, D.hl(k, i) + a, v); }
+            for (int j = 0; j < D.mi; j++) for (int a = 0; a < n; a++) { real v = J[a * nd + n + D.pu(i, j)]; if (v != 0.0) add(D.vu(i, k) + j, D.hl(k, i) + a, v); }
             for (int a = 0; a < n; a++) add(D.vx(i, k) + a, D.hl(k, i) + a, -1.0);
         }
     }
@@ -657,39 +690,39 @@ void jacobian(const Shared& sh, Game& g, const std::vector<double>& z, double re
 // dense partial-pivot LU of the row-permuted matrix would take.
 struct Banded {
     int S = 0, kl = 0, ku = 0, ld = 0;
-    std::vector<double> ab;    // (2kl+ku+1) x S, column-major, LAPACK band storage
+    std::vector<real> ab;    // (2kl+ku+1) x S, column-major, LAPACK band storage
     std::vector<int> ipiv;
     void init(int S_, int kl_, int ku_) { S = S_; kl = kl_; ku = ku_; ld = 2 * kl + ku + 1; ab.assign((size_t)ld * S, 0.0); ipiv.assign(S, 0); }
-    double& at(int r, int c) { return ab[(size_t)c * ld + (kl + ku + r - c)]; }
+    real& at(int r, int c) { return ab[(size_t)c * ld + (kl + ku + r - c)]; }
     // returns 0 ok, >0 singular at column
     int factor() {
         for (int j = 0; j < S; j++) {
             const int km = std::min(kl, S - 1 - j);
-            int jp = 0; double best = std::fabs(at(j, j));
-            for (int i = 1; i <= km; i++) { double v = std::fabs(at(j + i, j)); if (v > best) { best = v; jp = i; } }
+            int jp = 0; real best = r_fabs(at(j, j));
+            for (int i = 1; i <= km; i++) { real v = r_fabs(at(j + i, j)); if (v > best) { best = v; jp = i; } }
             ipiv[j] = j + jp;
-            if (best == 0.0 || !std::isfinite(best)) return j + 1;
+            if (best == 0.0 || !r_isfinite(best)) return j + 1;
             const int ju = std::min(j + ku + kl, S - 1);   // last column affected (U fill-in bound)
             if (jp != 0) for (int c = j; c <= ju; c++) std::swap(at(j, c), at(j + jp, c));
-            const double inv = 1.0 / at(j, j);
+            const real inv = 1.0 / at(j, j);
             for (int i = 1; i <= km; i++) at(j + i, j) *= inv;
             for (int c = j + 1; c <= ju; c++) {
-                const double v = at(j, c);
+                const real v = at(j, c);
                 if (v != 0.0) for (int i = 1; i <= km; i++) at(j + i, c) -= at(j + i, j) * v;
             }
         }
         return 0;
     }
-    void solve(std::vector<double>& x) {
+    void solve(std::vector<real>& x) {
         for (int j = 0; j < S; j++) {
             const int km = std::min(kl, S - 1 - j);
             if (ipiv[j] != j) std::swap(x[j], x[ipiv[j]]);
-            const double v = x[j];
+            const real v = x[j];
             if (v != 0.0) for (int i = 1; i <= km; i++) x[j + i] -= at(j + i, j) * v;
         }
         for (int j = S - 1; j >= 0; j--) {
             x[j] /= at(j, j);
-            const double v = x[j];
+            const real v = x[j];
             const int i0 = std::max(0, j - ku - kl);
             if (v != 0.0) for (int i = i0; i < j; i++) x[i] -= at(i, j) * v;
         }
@@ -716,73 +749,75 @@ void build_perms(const Dims& D, std::vector<int>& rpos, std::vector<int>& cpos) 
 }
 
 // Δtraj = - lu(jac) \ res ; set_traj!(core, Δpdtraj, Δtraj)  (solver_methods.jl:87-88)
-int newton_direction(const Shared& sh, Game& g, double reg) {
+int newton_direction(const Shared& sh, Game& g, real reg) {
     const Dims& D = sh.D;
     thread_local std::vector<int> rpos, cpos; build_perms(D, rpos, cpos);
     int kl = 0, ku = 0;
-    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double) { int dlt = rpos[r] - cpos[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); });
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, real) { int dlt = rpos[r] - cpos[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); });
     thread_local Banded B; B.init(D.S, kl, ku);           // per-thread storage, zero-filled by init (no allocation after the first call)
-    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double v) { B.at(rpos[r], cpos[c]) += v; });
-    TL_VEC(double, rhs, D.S);
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, real v) { B.at(rpos[r], cpos[c]) += v; });
+    TL_VEC(real, rhs, D.S);
     for (int r = 0; r < D.S; r++) rhs[rpos[r]] = g.res[r];
     if (B.factor() != 0) return ALG_STATUS_SINGULAR;
     B.solve(rhs);
-    std::vector<double>& dz = g.z[2];
+    std::vector<real>& dz = g.z[2];
     for (int a = 0; a < D.n; a++) dz[a] = 0.0;
     for (int c = 0; c < D.S; c++) dz[D.n + c] = -rhs[cpos[c]];
-    for (int c = 0; c < D.S; c++) if (!std::isfinite(dz[D.n + c])) return ALG_STATUS_SINGULAR;
+    for (int c = 0; c < D.S; c++) if (!r_isfinite(dz[D.n + c])) return ALG_STATUS_SINGULAR;
     return ALG_STATUS_OK;
 }
 
 // update_traj!(target, source, alpha, Δ) (primal_dual_traj.jl:109-128): x_{2..N}, u_{1..N-1}, duals; x_1 untouched
-void update_traj(const Shared& sh, std::vector<double>& tgt, const std::vector<double>& src, double alpha, const std::vector<double>& dz) {
+void update_traj(const Shared& sh, std::vector<real>& tgt, const std::vector<real>& src, real alpha, const std::vector<real>& dz) {
     const Dims& D = sh.D;
     for (int c = 0; c < D.S; c++) tgt[D.n + c] = src[D.n + c] + alpha * dz[D.n + c];
 }
 // Δ_step (primal_dual_traj.jl:130-147)
-double delta_step(const Shared& sh, const std::vector<double>& dz, double alpha) {
+real delta_step(const Shared& sh, const std::vector<real>& dz, real alpha) {
     const Dims& D = sh.D;
-    double s = 0;
+    real s = 0;
     for (int k = 0; k < D.N - 1; k++) {
-        for (int a = 0; a < D.n; a++) s += std::fabs(dz[D.n + D.hx(k) + a]);
-        for (int a = 0; a < D.m; a++) s += std::fabs(dz[D.n + D.hu(k, 0) + a]);
+        for (int a = 0; a < D.n; a++) s += r_fabs(dz[D.n + D.hx(k) + a]);
+        for (int a = 0; a < D.m; a++) s += r_fabs(dz[D.n + D.hu(k, 0) + a]);
     }
     s *= alpha;
-    s /= (double)((D.N - 1) * (D.n + D.m));
+    s /= (real)((D.N - 1) * (D.n + D.m));
     return s;
 }
 
 // record! (statistics.jl:44-57): residual_norm (recomputes residual!, unregularised) + four violations
-alg_record record(const Shared& sh, Game& g, double delta, int outer) {
+// @elapsed of the reference (solver_methods.jl:40-42, :151-153): wall time of the previous (ibr_)inner_iteration of this game
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+alg_record record(const Shared& sh, Game& g, real delta, int outer) {
     const Dims& D = sh.D;
     alg_record rc{};
-    rc.outer = outer; rc.delta = delta;
+    rc.outer = outer; rc.delta = delta; rc.t_elap = g.t_elap;
     residual(sh, g, g.z[0], 0.0, nullptr);                       // residual_norm(prob, pdtraj) (global_quantities.jl:92-97)
     rc.res = res_norm(sh, g);
     // dynamics_violation (violations.jl:18-26): max_k max|dyn_k|
-    double dv = 0; for (int k = 0; k < D.N - 1; k++) for (int a = 0; a < D.n; a++) dv = std::max(dv, std::fabs(g.res[D.vd(k) + a]));
+    real dv = 0; for (int k = 0; k < D.N - 1; k++) for (int a = 0; a < D.n; a++) dv = std::max<real>(dv, r_fabs(g.res[D.vd(k) + a]));
     rc.dyn_vio = dv;
     // control_violation / state_violation (violations.jl:57-67,101-114): max(0, max c) [PINNED test/struct/violations.jl:27-49]
-    double cv = 0, sv = 0;
-    if (sh.has_ctl) for (int k = 0; k < D.N - 1; k++) for (int r = 0; r < 2 * D.m; r++) cv = std::max(cv, std::max(0.0, g.vals[con_ctl(D, k, r)]));
-    if (sh.has_colavoid) for (int q = 0; q < D.npair; q++) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, q, k)]));
-    for (int e = D.col_len + D.ctl_len; e < D.con_len; e++) if (std::isfinite(g.vals[e])) sv = std::max(sv, std::max(0.0, g.vals[e]));
+    real cv = 0, sv = 0;
+    if (sh.has_ctl) for (int k = 0; k < D.N - 1; k++) for (int r = 0; r < 2 * D.m; r++) cv = std::max<real>(cv, std::max<real>(0.0, g.vals[con_ctl(D, k, r)]));
+    if (sh.has_colavoid) for (int q = 0; q < D.npair; q++) for (int k = 1; k < D.N; k++) sv = std::max<real>(sv, std::max<real>(0.0, g.vals[con_col(D, q, k)]));
+    for (int e = D.col_len + D.ctl_len; e < D.con_len; e++) if (r_isfinite(g.vals[e])) sv = std::max<real>(sv, std::max<real>(0.0, g.vals[e]));
     rc.con_vio = cv; rc.sta_vio = sv;
     // optimality_violation (violations.jl:153-168): max |res| over opt rows
-    double ov = 0; const int nopt = D.p * (D.N - 1) * (D.n + D.mi);
-    for (int r = 0; r < nopt; r++) ov = std::max(ov, std::fabs(g.res[r]));
+    real ov = 0; const int nopt = D.p * (D.N - 1) * (D.n + D.mi);
+    for (int r = 0; r < nopt; r++) ov = std::max<real>(ov, r_fabs(g.res[r]));
     rc.opt_vio = ov;
     return rc;
 }
 
 // line_search (solver_methods.jl:105-125)
-void line_search(const Shared& sh, Game& g, double reg, double res_norm0, double* alpha_out, int* j_out) {
+void line_search(const Shared& sh, Game& g, real reg, real res_norm0, real* alpha_out, int* j_out) {
     const alg_options& o = sh.opt;
-    int j = 1; double alpha = 1.0;
+    int j = 1; real alpha = 1.0;
     while (j < o.ls_iter) {
         update_traj(sh, g.z[1], g.z[0], alpha, g.z[2]);
         residual(sh, g, g.z[1], o.regularize ? reg : 0.0, &g.z[0]);
-        const double rt = res_norm(sh, g);
+        const real rt = res_norm(sh, g);
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
     }
@@ -790,21 +825,21 @@ void line_search(const Shared& sh, Game& g, double reg, double res_norm0, double
 }
 
 // inner_iteration (solver_methods.jl:67-103)
-alg_step_info inner_iteration(const Shared& sh, Game& g, int& LS_count, double& Delta, int k, int l) {
+alg_step_info inner_iteration(const Shared& sh, Game& g, int& LS_count, real& Delta, int k, int l) {
     const alg_options& o = sh.opt;
     alg_step_info info{};
-    const double reg = o.reg_0 * std::pow((double)l, 4);                  // solver_methods.jl:39
+    const real reg = o.reg_0 * ((real)l * (real)l * (real)l * (real)l);                  // solver_methods.jl:39
     residual(sh, g, g.z[0], o.regularize ? reg : 0.0, &g.z[0]);           // :73-74 (adds zero)
     alg_record rc = record(sh, g, Delta, k);                              // :75
-    const double rn = res_norm(sh, g);                                    // :76
+    const real rn = res_norm(sh, g);                                    // :76
     info.rec = rc;
     Delta = 0.0;                                                          // :79
-    if (!std::isfinite(rn)) { info.status = ALG_STATUS_NAN; info.control_flow = 1; g.hist.push_back(rc); g.st.records++; return info; }
+    if (!r_isfinite(rn)) { info.status = ALG_STATUS_NAN; info.control_flow = 1; g.hist.push_back(rc); g.st.records++; return info; }
     if (rc.opt_vio < o.eps_opt) { info.control_flow = 1; g.hist.push_back(rc); g.st.records++; return info; }   // :80-82
     int st = newton_direction(sh, g, reg);                                // :84-88
     if (st != ALG_STATUS_OK) { info.status = st; info.control_flow = 1; g.hist.push_back(rc); g.st.records++; return info; }
     g.st.newton_iters++;
-    double alpha; int j;
+    real alpha; int j;
     line_search(sh, g, reg, rn, &alpha, &j);                              // :91
     const bool failed = (j == o.ls_iter);                                 // :92
     if (failed) { LS_count += 1; g.st.ls_failures++; } else LS_count = 0; // :93
@@ -830,18 +865,18 @@ void dual_penalty_update(const Shared& sh, Game& g) {
     if (sh.has_colavoid)
         for (int i = 0; i < D.p; i++) for (int j = 0; j < D.p; j++) if (j != i && sh.pair_on(i, j)) for (int k = 1; k < D.N; k++) {
             const int ci = con_col(D, D.pair(i, j), k);
-            const double lb = g.lam[ci] + o.alphax_dual[i] * g.mu[ci] * g.vals[ci];
-            g.lam[ci] = std::min(std::max(lb, 0.0), o.lambda_max);
+            const real lb = g.lam[ci] + o.alphax_dual[i] * g.mu[ci] * g.vals[ci];
+            g.lam[ci] = std::min<real>(std::max<real>(lb, 0.0), o.lambda_max);
         }
     if (sh.has_ctl)
         for (int k = 0; k < D.N - 1; k++) for (int r = 0; r < 2 * D.m; r++) {
             const int ci = con_ctl(D, k, r);
-            if (!std::isfinite(g.vals[ci])) continue;
-            const double lb = g.lam[ci] + o.alpha_dual * g.mu[ci] * g.vals[ci];
-            g.lam[ci] = std::min(std::max(lb, 0.0), o.lambda_max);
+            if (!r_isfinite(g.vals[ci])) continue;
+            const real lb = g.lam[ci] + o.alpha_dual * g.mu[ci] * g.vals[ci];
+            g.lam[ci] = std::min<real>(std::max<real>(lb, 0.0), o.lambda_max);
         }
     for (int e = D.col_len + D.ctl_len; e < D.con_len; e++) {
-        if (!std::isfinite(g.vals[e])) continue;
+        if (!r_isfinite(g.vals[e])) continue;
         const int e2 = e - D.col_len - D.ctl_len;
         int i, e3 = e2;
         if (e3 < D.sb_len) i = e3 / ((D.N - 1) * 2 * D.n);
@@ -849,16 +884,16 @@ void dual_penalty_update(const Shared& sh, Game& g) {
         else if ((e3 -= D.wall_len) < D.circ_len) i = e3 / ((D.N - 1) * D.ncirc);
         else if ((e3 -= D.circ_len) < D.wall3_len) i = e3 / ((D.N - 1) * D.nwall3);
         else i = (e3 - D.wall3_len) / ((D.N - 1) * D.ncyl);
-        const double lb = g.lam[e] + o.alphax_dual[i] * g.mu[e] * g.vals[e];
-        g.lam[e] = std::min(std::max(lb, 0.0), o.lambda_max);
+        const real lb = g.lam[e] + o.alphax_dual[i] * g.mu[e] * g.vals[e];
+        g.lam[e] = std::min<real>(std::max<real>(lb, 0.0), o.lambda_max);
     }
-    for (double& v : g.mu) v = std::min(std::max(v * o.rho_increase, 0.0), o.rho_max);
+    for (real& v : g.mu) v = std::min<real>(std::max<real>(v * o.rho_increase, 0.0), o.rho_max);
 }
 
 // rollout!(RK3, model, traj) (solver_methods.jl:17)
-void rollout(const Shared& sh, std::vector<double>& z) {
+void rollout(const Shared& sh, std::vector<real>& z) {
     const Dims& D = sh.D;
-    std::vector<double> u(D.m), xn(D.n);
+    std::vector<real> u(D.m), xn(D.n);
     for (int k = 0; k < D.N - 1; k++) {
         get_control(D, z, k, u.data());
         rk3(D, state(D, z, k), u.data(), xn.data());
@@ -869,10 +904,10 @@ void rollout(const Shared& sh, std::vector<double>& z) {
 // init_traj! (primal_dual_traj.jl:29-44) with f = counter RNG.  Element counters: knot k (0-based),
 // entry e of z_k=[x_k;u_k] (joint order) -> k*(n+m)+e ; dual (i,k,r) -> N*(n+m) + (i*(N-1)+k)*n + r.
 // The terminal knot's control is drawn by the reference but never used.
-void init_traj(const Shared& sh, Game& g, std::vector<double>& z, uint64_t game_id, bool use_shift, bool zero) {
+void init_traj(const Shared& sh, Game& g, std::vector<real>& z, uint64_t game_id, bool use_shift, bool zero) {
     const Dims& D = sh.D; const alg_options& o = sh.opt;
     const int s = use_shift ? o.shift : (1 << 30);
-    std::vector<double> old = z, u(D.m);
+    std::vector<real> old = z, u(D.m);
     for (int k = 0; k < D.N; k++) {
         const bool sh_ok = (k + s <= D.N - 1);
         // states are overwritten by the rollout for k >= 1, kept here for literalness
@@ -893,21 +928,23 @@ void init_traj(const Shared& sh, Game& g, std::vector<double>& z, uint64_t game_
 // newton_solve! (solver_methods.jl:5-65)
 void newton_solve(const Shared& sh, Game& g, bool init, uint64_t game_id) {
     const alg_options& o = sh.opt;
-    g.st = alg_game_stats{}; g.hist.clear();                               // reset!(prob.stats)
+    g.st = alg_game_stats{}; g.hist.clear(); g.t_elap = 0.0;                // reset!(prob.stats)
     if (init) init_traj(sh, g, g.z[0], game_id, true, false);             // :13
     else for (int a = 0; a < sh.D.n; a++) g.z[0][a] = g.x0[a];
     g.z[1] = g.z[0];                                                       // :14 (trial is overwritten before use; x_1 = x0 matters)
     std::fill(g.z[2].begin(), g.z[2].end(), 0.0);                          // :15
     rollout(sh, g.z[0]);                                                   // :17
     if (o.dual_reset) reset_con(sh, g);                                    // :25
-    int out = 0; double Delta = 0.0;
+    int out = 0; real Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30
         out = k;
         int LS_count = 0;                                                  // :35
         alg_record last{};
         bool any = false;
         for (int l = 1; l <= o.inner_iter; l++) {                          // :38
+            const double t0 = now_s();
             alg_step_info info = inner_iteration(sh, g, LS_count, Delta, k, l);
+            g.t_elap = now_s() - t0;
             last = info.rec; any = true;
             if (info.status != ALG_STATUS_OK) { g.st.status = info.status; break; }
             if (LS_count >= 1 || info.control_flow == 1) break;            // :43
@@ -946,22 +983,22 @@ void ibr_masks(const Dims& D, int i, std::vector<int>& rmask, std::vector<int>& 
     }
 }
 // norm(core.res[verti_mask], 1) / length(verti_mask)  (solver_methods.jl:241)
-double ibr_res_norm(const Shared& sh, const Game& g, int i) {
-    const Dims& D = sh.D; double s = 0;
+real ibr_res_norm(const Shared& sh, const Game& g, int i) {
+    const Dims& D = sh.D; real s = 0;
     for (int k = 0; k < D.N - 1; k++) {
-        for (int a = 0; a < D.n; a++) s += std::fabs(g.res[D.vx(i, k) + a]) + std::fabs(g.res[D.vd(k) + a]);
-        for (int j = 0; j < D.mi; j++) s += std::fabs(g.res[D.vu(i, k) + j]);
+        for (int a = 0; a < D.n; a++) s += r_fabs(g.res[D.vx(i, k) + a]) + r_fabs(g.res[D.vd(k) + a]);
+        for (int j = 0; j < D.mi; j++) s += r_fabs(g.res[D.vu(i, k) + j]);
     }
-    return s / (double)((D.N - 1) * (2 * D.n + D.mi));
+    return s / (real)((D.N - 1) * (2 * D.n + D.mi));
 }
 // ibr_residual! + regularize_ibr_residual! restricted to the mask == the full residual! on the player's rows; the
 // proximal term only touches the player's rows (global_quantities.jl:262-280).  Rows outside the mask are not used.
-void ibr_residual(const Shared& sh, Game& g, const std::vector<double>& z, int i, double reg, const std::vector<double>* zref) {
+void ibr_residual(const Shared& sh, Game& g, const std::vector<real>& z, int i, real reg, const std::vector<real>* zref) {
     residual(sh, g, z, 0.0, nullptr);
     if (zref && reg != 0.0) {
-        const Dims& D = sh.D; std::vector<double> u(D.m), ur(D.m);
+        const Dims& D = sh.D; std::vector<real> u(D.m), ur(D.m);
         for (int k = 0; k < D.N - 1; k++) {
-            const double* x = state(D, z, k + 1); const double* xr = state(D, *zref, k + 1);
+            const real* x = state(D, z, k + 1); const real* xr = state(D, *zref, k + 1);
             get_control(D, z, k, u.data()); get_control(D, *zref, k, ur.data());
             for (int a = 0; a < D.n; a++) g.res[D.vx(i, k) + a] += reg * (x[a] - xr[a]);
             for (int j = 0; j < D.mi; j++) { int c = D.pu(i, j); g.res[D.vu(i, k) + j] += reg * (u[c] - ur[c]); }
@@ -969,61 +1006,61 @@ void ibr_residual(const Shared& sh, Game& g, const std::vector<double>& z, int i
     }
 }
 // record!(stats, prob, model, game_con, pdtraj, t_elap, Δ, k, i) (statistics.jl:59-73): full residual norm, player-specific violations
-alg_record ibr_record(const Shared& sh, Game& g, double delta, int outer, int i) {
+alg_record ibr_record(const Shared& sh, Game& g, real delta, int outer, int i) {
     const Dims& D = sh.D;
-    alg_record rc{}; rc.outer = outer; rc.delta = delta;
+    alg_record rc{}; rc.outer = outer; rc.delta = delta; rc.t_elap = g.t_elap;
     residual(sh, g, g.z[0], 0.0, nullptr);
     rc.res = res_norm(sh, g);
-    double dv = 0;                                               // dynamics_violation(model, pdtraj, i): entries pz[i]
-    for (int k = 0; k < D.N - 1; k++) for (int j = 0; j < D.ni; j++) dv = std::max(dv, std::fabs(g.res[D.vd(k) + D.pz(i, j)]));
+    real dv = 0;                                               // dynamics_violation(model, pdtraj, i): entries pz[i]
+    for (int k = 0; k < D.N - 1; k++) for (int j = 0; j < D.ni; j++) dv = std::max<real>(dv, r_fabs(g.res[D.vd(k) + D.pz(i, j)]));
     rc.dyn_vio = dv;
     // control_violation(game_con, pdtraj, i) (violations.jl:69-82): c_max = max(0, maximum(v[pu[i]])) -- v is the vector of
     // FINITE bound rows [u - u_max; u_min - u][inds] and is indexed by the control indices pu[i] (literal restatement)
-    double cv = 0;
+    real cv = 0;
     if (sh.has_ctl) for (int k = 0; k < D.N - 1; k++) {
-        std::vector<double> fin;
-        for (int r = 0; r < 2 * D.m; r++) if (std::isfinite(g.vals[con_ctl(D, k, r)])) fin.push_back(g.vals[con_ctl(D, k, r)]);
-        double mx = -std::numeric_limits<double>::infinity();
-        for (int j = 0; j < D.mi; j++) { int pos = D.pu(i, j); if (pos < (int)fin.size()) mx = std::max(mx, fin[pos]); }
-        cv = std::max(cv, std::max(0.0, mx));
+        std::vector<real> fin;
+        for (int r = 0; r < 2 * D.m; r++) if (r_isfinite(g.vals[con_ctl(D, k, r)])) fin.push_back(g.vals[con_ctl(D, k, r)]);
+        real mx = -std::numeric_limits<double>::infinity();
+        for (int j = 0; j < D.mi; j++) { int pos = D.pu(i, j); if (pos < (int)fin.size()) mx = std::max<real>(mx, fin[pos]); }
+        cv = std::max<real>(cv, std::max<real>(0.0, mx));
     }
     rc.con_vio = cv;
-    double sv = 0;                                               // state_violation(game_con, pdtraj, i): player i's convals
-    if (sh.has_colavoid) for (int j = 0; j < D.p; j++) if (j != i && sh.pair_on(i, j)) for (int k = 1; k < D.N; k++) sv = std::max(sv, std::max(0.0, g.vals[con_col(D, D.pair(i, j), k)]));
+    real sv = 0;                                               // state_violation(game_con, pdtraj, i): player i's convals
+    if (sh.has_colavoid) for (int j = 0; j < D.p; j++) if (j != i && sh.pair_on(i, j)) for (int k = 1; k < D.N; k++) sv = std::max<real>(sv, std::max<real>(0.0, g.vals[con_col(D, D.pair(i, j), k)]));
     for (int k = 1; k < D.N; k++) {
-        if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { double v = g.vals[D.o_sb(i, k, r)]; if (std::isfinite(v)) sv = std::max(sv, std::max(0.0, v)); }
-        for (int w = 0; w < D.nwall; w++) sv = std::max(sv, std::max(0.0, g.vals[D.o_wall(i, k, w)]));
-        for (int c = 0; c < D.ncirc; c++) sv = std::max(sv, std::max(0.0, g.vals[D.o_circ(i, k, c)]));
-        for (int w = 0; w < D.nwall3; w++) sv = std::max(sv, std::max(0.0, g.vals[D.o_wall3(i, k, w)]));
-        for (int c = 0; c < D.ncyl; c++) sv = std::max(sv, std::max(0.0, g.vals[D.o_cyl(i, k, c)]));
+        if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) { real v = g.vals[D.o_sb(i, k, r)]; if (r_isfinite(v)) sv = std::max<real>(sv, std::max<real>(0.0, v)); }
+        for (int w = 0; w < D.nwall; w++) sv = std::max<real>(sv, std::max<real>(0.0, g.vals[D.o_wall(i, k, w)]));
+        for (int c = 0; c < D.ncirc; c++) sv = std::max<real>(sv, std::max<real>(0.0, g.vals[D.o_circ(i, k, c)]));
+        for (int w = 0; w < D.nwall3; w++) sv = std::max<real>(sv, std::max<real>(0.0, g.vals[D.o_wall3(i, k, w)]));
+        for (int c = 0; c < D.ncyl; c++) sv = std::max<real>(sv, std::max<real>(0.0, g.vals[D.o_cyl(i, k, c)]));
     }
     rc.sta_vio = sv;
-    double ov = 0;                                               // optimality_violation(core, i)
-    for (int k = 0; k < D.N - 1; k++) { for (int a = 0; a < D.n; a++) ov = std::max(ov, std::fabs(g.res[D.vx(i, k) + a])); for (int j = 0; j < D.mi; j++) ov = std::max(ov, std::fabs(g.res[D.vu(i, k) + j])); }
+    real ov = 0;                                               // optimality_violation(core, i)
+    for (int k = 0; k < D.N - 1; k++) { for (int a = 0; a < D.n; a++) ov = std::max<real>(ov, r_fabs(g.res[D.vx(i, k) + a])); for (int j = 0; j < D.mi; j++) ov = std::max<real>(ov, r_fabs(g.res[D.vu(i, k) + j])); }
     rc.opt_vio = ov;
-    g.max_delta = std::max(g.max_delta, delta);
+    g.max_delta = std::max<real>(g.max_delta, delta);
     return rc;
 }
 // Δtraj[horiz_mask] = - lu(jac[verti_mask, horiz_mask]) \ res[verti_mask]  (solver_methods.jl:249-251)
-int ibr_direction(const Shared& sh, Game& g, int i, double reg) {
+int ibr_direction(const Shared& sh, Game& g, int i, real reg) {
     const Dims& D = sh.D;
     thread_local std::vector<int> rm, cm; int Sm; ibr_masks(D, i, rm, cm, Sm);
     int kl = 0, ku = 0;
-    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double) { if (rm[r] >= 0 && cm[c] >= 0) { int dlt = rm[r] - cm[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); } });
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, real) { if (rm[r] >= 0 && cm[c] >= 0) { int dlt = rm[r] - cm[c]; kl = std::max(kl, dlt); ku = std::max(ku, -dlt); } });
     thread_local Banded B; B.init(Sm, kl, ku);
-    jacobian(sh, g, g.z[0], reg, [&](int r, int c, double v) { if (rm[r] >= 0 && cm[c] >= 0) B.at(rm[r], cm[c]) += v; });
-    TL_VEC(double, rhs, Sm);
+    jacobian(sh, g, g.z[0], reg, [&](int r, int c, real v) { if (rm[r] >= 0 && cm[c] >= 0) B.at(rm[r], cm[c]) += v; });
+    TL_VEC(real, rhs, Sm);
     for (int r = 0; r < D.S; r++) if (rm[r] >= 0) rhs[rm[r]] = g.res[r];
     if (B.factor() != 0) return ALG_STATUS_SINGULAR;
     B.solve(rhs);
-    std::vector<double>& dz = g.z[2];
+    std::vector<real>& dz = g.z[2];
     std::fill(dz.begin(), dz.end(), 0.0);
-    for (int c = 0; c < D.S; c++) if (cm[c] >= 0) { dz[D.n + c] = -rhs[cm[c]]; if (!std::isfinite(dz[D.n + c])) return ALG_STATUS_SINGULAR; }
+    for (int c = 0; c < D.S; c++) if (cm[c] >= 0) { dz[D.n + c] = -rhs[cm[c]]; if (!r_isfinite(dz[D.n + c])) return ALG_STATUS_SINGULAR; }
     return ALG_STATUS_OK;
 }
 // ibr_line_search (solver_methods.jl:270-289)
-void ibr_line_search(const Shared& sh, Game& g, int i, double reg, double res_norm0, double* alpha_out, int* j_out) {
-    const alg_options& o = sh.opt; int j = 1; double alpha = 1.0;
+void ibr_line_search(const Shared& sh, Game& g, int i, real reg, real res_norm0, real* alpha_out, int* j_out) {
+    const alg_options& o = sh.opt; int j = 1; real alpha = 1.0;
     while (j < o.ls_iter) {
         update_traj(sh, g.z[1], g.z[0], alpha, g.z[2]);
         ibr_residual(sh, g, g.z[1], i, o.regularize ? reg : 0.0, &g.z[0]);
@@ -1033,19 +1070,19 @@ void ibr_line_search(const Shared& sh, Game& g, int i, double reg, double res_no
     *alpha_out = alpha; *j_out = j;
 }
 // ibr_inner_iteration (solver_methods.jl:230-268)
-alg_step_info ibr_inner_iteration(const Shared& sh, Game& g, int& LS_count, double& Delta, int k, int l, int i) {
+alg_step_info ibr_inner_iteration(const Shared& sh, Game& g, int& LS_count, real& Delta, int k, int l, int i) {
     const alg_options& o = sh.opt; alg_step_info info{};
-    const double reg = o.reg_0 * std::pow((double)l, 4);
+    const real reg = o.reg_0 * ((real)l * (real)l * (real)l * (real)l);
     alg_record rc = ibr_record(sh, g, Delta, k, i);                        // :238-240 (leaves the full residual in core.res)
-    const double rn = ibr_res_norm(sh, g, i);                              // :241
+    const real rn = ibr_res_norm(sh, g, i);                              // :241
     info.rec = rc; Delta = 0.0;
     auto done = [&](int status, int flow) { info.status = status; info.control_flow = flow; g.hist.push_back(info.rec); g.st.records++; return info; };
-    if (!std::isfinite(rn)) return done(ALG_STATUS_NAN, 1);
+    if (!r_isfinite(rn)) return done(ALG_STATUS_NAN, 1);
     if (rc.opt_vio < o.eps_opt) return done(ALG_STATUS_OK, 1);            // :245-247
     int st = ibr_direction(sh, g, i, reg);                                 // :249-252
     if (st != ALG_STATUS_OK) return done(st, 1);
     g.st.newton_iters++;
-    double alpha; int j; ibr_line_search(sh, g, i, reg, rn, &alpha, &j);   // :255
+    real alpha; int j; ibr_line_search(sh, g, i, reg, rn, &alpha, &j);   // :255
     const bool failed = (j == o.ls_iter);
     if (failed) { LS_count += 1; g.st.ls_failures++; } else LS_count = 0;
     update_traj(sh, g.z[0], g.z[0], alpha, g.z[2]);                        // :258
@@ -1054,18 +1091,20 @@ alg_step_info ibr_inner_iteration(const Shared& sh, Game& g, int& LS_count, doub
     return done(ALG_STATUS_OK, Delta < o.delta_min ? 1 : 0);
 }
 // reset_duals!(pdtraj) (primal_dual_traj.jl:149-158)
-void reset_traj_duals(const Dims& D, std::vector<double>& z) {
+void reset_traj_duals(const Dims& D, std::vector<real>& z) {
     for (int k = 0; k < D.N - 1; k++) for (int i = 0; i < D.p; i++) for (int a = 0; a < D.n; a++) z[D.n + D.hl(k, i) + a] *= 0.0;
 }
 // ibr_newton_solve!(prob, i) (solver_methods.jl:171-228)
 void ibr_solve_player(const Shared& sh, Game& g, int i) {
     const alg_options& o = sh.opt;
     if (o.dual_reset) { reset_con(sh, g); reset_traj_duals(sh.D, g.z[0]); reset_traj_duals(sh.D, g.z[1]); }   // :181-185
-    int out = 0; double Delta = 0.0; g.st.status = ALG_STATUS_OK; g.st.converged = 0;
+    int out = 0; real Delta = 0.0; g.st.status = ALG_STATUS_OK; g.st.converged = 0;
     for (int k = 1; k <= o.outer_iter; k++) {
         out = k; int LS_count = 0; alg_record last{}; bool any = false;
         for (int l = 1; l <= o.inner_iter; l++) {
+            const double t0 = now_s();
             alg_step_info info = ibr_inner_iteration(sh, g, LS_count, Delta, k, l, i);
+            g.t_elap = now_s() - t0;
             last = info.rec; any = true;
             if (info.status != ALG_STATUS_OK) { g.st.status = info.status; break; }
             if (LS_count >= 1 || info.control_flow == 1) break;
@@ -1080,9 +1119,9 @@ void ibr_solve_player(const Shared& sh, Game& g, int i) {
     g.hist.push_back(fin); g.st.records++; g.st.outer_iters = out; g.st.last = fin;
 }
 // ibr_newton_solve!(prob; ibr_opts) (solver_methods.jl:133-169)
-void ibr_newton_solve(const Shared& sh, Game& g, bool init, uint64_t game_id, int ibr_iter, const int* ordering, double delta_min) {
+void ibr_newton_solve(const Shared& sh, Game& g, bool init, uint64_t game_id, int ibr_iter, const int* ordering, real delta_min) {
     const Dims& D = sh.D;
-    g.st = alg_game_stats{}; g.hist.clear(); g.max_delta = 0.0;             // reset!(prob.stats)
+    g.st = alg_game_stats{}; g.hist.clear(); g.max_delta = 0.0; g.t_elap = 0.0;   // reset!(prob.stats)
     if (init) init_traj(sh, g, g.z[0], game_id, true, false); else for (int a = 0; a < D.n; a++) g.z[0][a] = g.x0[a];
     g.z[1] = g.z[0]; std::fill(g.z[2].begin(), g.z[2].end(), 0.0);
     rollout(sh, g.z[0]);
@@ -1105,6 +1144,14 @@ void ibr_newton_solve(const Shared& sh, Game& g, bool init, uint64_t game_id, in
 // C ABI (same signatures as include/algames_hip.h with the orc_ prefix)
 // ------------------------------------------------------------------------------------------
 #define H ((Handle*)h)
+// double <-> real at the ABI (the known-answer hooks pass plain double arrays)
+static std::vector<real> rin(const double* p, size_t n) { return p ? std::vector<real>(p, p + n) : std::vector<real>(n, 0); }
+struct ROut {
+    double* dst; std::vector<real> v;
+    ROut(double* d, size_t n) : dst(d), v(n, 0) {}
+    real* ptr() { return dst ? v.data() : nullptr; }
+    ~ROut() { if (dst) for (size_t i = 0; i < v.size(); i++) dst[i] = (double)v[i]; }
+};
 extern "C" {
 
 const char* orc_last_error(void) { return g_err.c_str(); }
@@ -1240,7 +1287,7 @@ int orc_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t nw, co
     if (player < 0 || player >= s.D.p || nw < 0) return fail(ALG_ERR_ARG, "orc_add_wall_constraint_player: bad argument");
     if (s.D.nwall == 0) for (int i = 0; i < 10; i++) s.wall_mask[i] = 0u;
     else for (int i = 0; i < 10; i++) if (s.wall_mask[i] == 0xffffffffu) s.wall_mask[i] = (1u << s.D.nwall) - 1u;   // after an all-player set: explicit bits (as the HIP library)
-    std::vector<double>* tab[6] = {&s.wx1, &s.wy1, &s.wx2, &s.wy2, &s.wxv, &s.wyv}; const double* src[6] = {x1, y1, x2, y2, xv, yv};
+    std::vector<real>* tab[6] = {&s.wx1, &s.wy1, &s.wx2, &s.wy2, &s.wxv, &s.wyv}; const double* src[6] = {x1, y1, x2, y2, xv, yv};
     for (int f = 0; f < 6; f++) tab[f]->resize(s.D.nwall);
     for (int w = 0; w < nw; w++) {
         int at = -1;
@@ -1265,7 +1312,7 @@ int orc_add_circle_constraint_player(alg_handle* h, int32_t player, int32_t nc, 
     if (player < 0 || player >= s.D.p || nc < 0) return fail(ALG_ERR_ARG, "orc_add_circle_constraint_player: bad argument");
     if (s.D.ncirc == 0) for (int i = 0; i < 10; i++) s.circ_mask[i] = 0u;
     else for (int i = 0; i < 10; i++) if (s.circ_mask[i] == 0xffffffffu) s.circ_mask[i] = (1u << s.D.ncirc) - 1u;
-    std::vector<double>* tab[3] = {&s.cxc, &s.cyc, &s.crad}; const double* src[3] = {xc, yc, rad};
+    std::vector<real>* tab[3] = {&s.cxc, &s.cyc, &s.crad}; const double* src[3] = {xc, yc, rad};
     for (int f = 0; f < 3; f++) tab[f]->resize(s.D.ncirc);
     for (int c = 0; c < nc; c++) {
         int at = -1;
@@ -1381,7 +1428,7 @@ int orc_newton_direction(alg_handle* h, double reg, double* delta, int32_t* stat
 int orc_line_search(alg_handle* h, double reg, const double* rn, double* alpha, int32_t* j) {
     const int B = (int)H->g.size();
 #pragma omp parallel for schedule(dynamic)
-    for (int gi = 0; gi < B; gi++) { int jj; double a; line_search(H->sh, H->g[gi], reg, rn[gi], &a, &jj); alpha[gi] = a; j[gi] = jj; }
+    for (int gi = 0; gi < B; gi++) { int jj; real a; line_search(H->sh, H->g[gi], reg, rn[gi], &a, &jj); alpha[gi] = (double)a; j[gi] = jj; }
     return ALG_OK;
 }
 int orc_update_traj(alg_handle* h, int32_t target, int32_t source, const double* alpha) {
@@ -1402,7 +1449,7 @@ int orc_dual_penalty_update(alg_handle* h, double* vals) {
 int orc_newton_step(alg_handle* h, int32_t k_outer, int32_t l_inner, const double* delta_in, alg_step_info* info) {
     const int B = (int)H->g.size();
 #pragma omp parallel for schedule(dynamic)
-    for (int gi = 0; gi < B; gi++) { int ls = 0; double dl = delta_in ? delta_in[gi] : 0.0; alg_step_info si = inner_iteration(H->sh, H->g[gi], ls, dl, k_outer, l_inner); if (info) info[gi] = si; }
+    for (int gi = 0; gi < B; gi++) { int ls = 0; real dl = delta_in ? delta_in[gi] : 0.0; alg_step_info si = inner_iteration(H->sh, H->g[gi], ls, dl, k_outer, l_inner); if (info) info[gi] = si; }
     return ALG_OK;
 }
 int orc_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_stats* stats) {
@@ -1445,7 +1492,7 @@ int orc_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t 
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1); totals += finished solve
 int orc_mpc_advance(alg_handle* h) {
     const Dims& D = H->sh.D;
-    std::vector<double> u(D.m), xn(D.n);
+    std::vector<real> u(D.m), xn(D.n);
     for (Game& g : H->g) {
         get_control(D, g.z[0], 0, u.data());
         rk2(D, state(D, g.z[0], 0), u.data(), xn.data());
@@ -1494,27 +1541,33 @@ int orc_set_threads(int nthreads) {
 // ---- fine-grained pieces exposed for the known-answer tests (Appendix B) ----------------------
 int orc_kat_dynamics(const alg_desc* d, const double* x, const double* u, double* xdot, double* x_rk2, double* x_rk3, double* jac_rk2) {
     Dims D; if (!D.init(*d)) return fail(ALG_ERR_ARG, "bad descriptor");
-    if (xdot) dynamics(D, x, u, xdot);
-    if (x_rk2) rk2(D, x, u, x_rk2);
-    if (x_rk3) rk3(D, x, u, x_rk3);
-    if (jac_rk2) rk2_jacobian(D, x, u, jac_rk2);
+    const std::vector<real> xr = rin(x, D.n), ur = rin(u, D.m);
+    ROut o1(xdot, D.n), o2(x_rk2, D.n), o3(x_rk3, D.n), o4(jac_rk2, (size_t)D.n * (D.n + D.m));
+    if (xdot) dynamics(D, xr.data(), ur.data(), o1.ptr());
+    if (x_rk2) rk2(D, xr.data(), ur.data(), o2.ptr());
+    if (x_rk3) rk3(D, xr.data(), ur.data(), o3.ptr());
+    if (jac_rk2) rk2_jacobian(D, xr.data(), ur.data(), o4.ptr());
     return ALG_OK;
 }
 // the same on a handle's model (its parameters: bicycle lengths, quadrotor mass)
 int orc_kat_dynamics_h(alg_handle* h, const double* x, const double* u, double* xdot, double* x_rk2, double* x_rk3, double* jac_rk2) {
     const Dims& D = H->sh.D;
-    if (xdot) dynamics(D, x, u, xdot);
-    if (x_rk2) rk2(D, x, u, x_rk2);
-    if (x_rk3) rk3(D, x, u, x_rk3);
-    if (jac_rk2) rk2_jacobian(D, x, u, jac_rk2);
+    const std::vector<real> xr = rin(x, D.n), ur = rin(u, D.m);
+    ROut o1(xdot, D.n), o2(x_rk2, D.n), o3(x_rk3, D.n), o4(jac_rk2, (size_t)D.n * (D.n + D.m));
+    if (xdot) dynamics(D, xr.data(), ur.data(), o1.ptr());
+    if (x_rk2) rk2(D, xr.data(), ur.data(), o2.ptr());
+    if (x_rk3) rk3(D, xr.data(), ur.data(), o3.ptr());
+    if (jac_rk2) rk2_jacobian(D, xr.data(), ur.data(), o4.ptr());
     return ALG_OK;
 }
 // cost gradient/Hessian of player i at knot k (0-based) for state x / control u: q (n), r (mi), Q (n x n row-major)
 int orc_kat_cost(alg_handle* h, int32_t game, int32_t i, int32_t k, const double* x, const double* u, double* q, double* r, double* Qm) {
-    Game& g = H->g[game];
-    if (q) cost_grad_x(H->sh, g, i, k, x, q);
-    if (r) cost_grad_u(H->sh, g, i, u, r);
-    if (Qm) cost_hess_x(H->sh, g, i, k, x, Qm);
+    Game& g = H->g[game]; const Dims& D = H->sh.D;
+    const std::vector<real> xr = rin(x, D.n), ur = rin(u, D.m);
+    ROut oq(q, D.n), orr(r, D.mi), oQ(Qm, (size_t)D.n * D.n);
+    if (q) cost_grad_x(H->sh, g, i, k, xr.data(), oq.ptr());
+    if (r) cost_grad_u(H->sh, g, i, u ? ur.data() : nullptr, orr.ptr());
+    if (Qm) cost_hess_x(H->sh, g, i, k, xr.data(), oQ.ptr());
     return ALG_OK;
 }
 // stage_cost of CollisionCost (objective.jl:122-126), for the 0.05 KAT

@@ -13,20 +13,39 @@ import algames_jl_amd  # noqa: E402
 from algames_jl_amd._abi import CLib, Batch, alg_desc, _dptr, _f64, _P  # noqa: E402
 
 LIB_PATH = os.path.join(_here, "lib", "liboracle.so")
+# arbiter builds: the same source with the scalar type swapped (oracle/Makefile): long double / __float128
+LIB_X_PATH = os.path.join(_here, "lib", "liboracle_x.so")
+LIB_Q_PATH = os.path.join(_here, "lib", "liboracle_q.so")
 
 
 def build(force=False):
     src = os.path.join(_here, "algames_oracle.cpp")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    stale = any((not os.path.exists(q)) or os.path.getmtime(q) < os.path.getmtime(src) for q in (LIB_PATH, LIB_X_PATH, LIB_Q_PATH))
+    if force or stale:
         subprocess.check_call(["make", "-C", _here, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
 
 _lib = None
+_arb = {}
 
 
-def lib():
+def _declare(d):
+    pass
+
+
+def lib(kind=""):
+    """kind "": the oracle (double).  "x" / "q": the arbiter builds (long double / __float128 arithmetic behind the same ABI)."""
     global _lib
+    if kind:
+        if kind not in _arb:
+            path = {"x": LIB_X_PATH, "q": LIB_Q_PATH}[kind]
+            if not os.path.exists(path):
+                build()
+            _arb[kind] = CLib(path, "orc_")
+            _arb[kind].dll.orc_set_threads.restype = C.c_int
+            _arb[kind].dll.orc_set_threads.argtypes = [C.c_int]
+        return _arb[kind]
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
@@ -54,8 +73,8 @@ def lib():
 
 
 class OracleBatch(Batch):
-    def __init__(self, model, p, N, dt, batch, d=2):
-        super().__init__(lib(), model, p, N, dt, batch, d=d, device=0)
+    def __init__(self, model, p, N, dt, batch, d=2, kind=""):
+        super().__init__(lib(kind), model, p, N, dt, batch, d=d, device=0)
 
     # fine-grained known-answer hooks ------------------------------------------------------------
     def kat_dynamics(self, x, u):

@@ -137,3 +137,38 @@ def test_multi_device_solve_behind_the_boundary_two_handles_on_one_gpu(alg):
     assert np.array_equal(two.stats.summary["newton_iters"], one.stats.summary["newton_iters"])
     assert alg.sharding.local_counters(two) == alg.sharding.local_counters(one)
     assert np.array_equal(two.stats.history(300)["res"], one.stats.history(300)["res"])
+
+
+@pytest.mark.gpu
+def test_statistics_t_elap_is_measured_on_the_device(alg):
+    """Statistics.t_elap (statistics.jl:8,34; @elapsed at solver_methods.jl:40-42): record r carries the duration of the inner
+    iteration that preceded it -- 0 for the first record of a solve, positive afterwards, and the sum over a game's records is
+    bounded by the wall time of the launch that produced them."""
+    import time
+    prob = alg.scenarios.make_problem("C2", np.arange(64))
+    alg.newton_solve(prob)                                     # warm-up (module load)
+    prob = alg.scenarios.make_problem("C2", np.arange(64))
+    t0 = time.perf_counter(); alg.newton_solve(prob); wall = time.perf_counter() - t0
+    for game in (0, 17, 63):
+        h = prob.stats.history(game)
+        assert len(h) == prob.stats.summary["records"][game] >= 3
+        assert h["t_elap"][0] == 0.0 and np.all(h["t_elap"][1:] > 0.0)
+        assert 1e-6 < h["t_elap"][1:].max() < wall and h["t_elap"].sum() < wall
+    assert np.array_equal(prob.stats.t_elap, prob.stats.history(0)["t_elap"])
+
+
+@pytest.mark.gpu
+def test_step_wise_history_grows_by_records(alg):
+    """A host-driven loop of alg_newton_step adds one record per call: the device history grows geometrically by RECORDS (it used
+    to be re-sized for a whole solve on every call) and keeps every record."""
+    prob = alg.scenarios.make_problem("C2", np.arange(8), N=10)
+    prob.batch.set_waves_per_game(1)
+    prob.batch.init_traj(game_id0=0)
+    prob.batch.rollout(0)
+    n = 0
+    for k in range(1, 4):
+        for l in range(1, 60):
+            info = prob.batch.newton_step(k, l)
+            n += 1
+    h = prob.batch.get_history(3)
+    assert len(h) == n == 177 and np.all(h["res"] > 0)

@@ -82,7 +82,9 @@ def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
     ids = np.arange(128, 192)
     pg = alg.scenarios.make_problem("C5", ids)
     po = alg.scenarios.make_problem("C5", ids, backend=orc.lib())
-    bg, bo = pg.batch, po.batch
+    px = alg.scenarios.make_problem("C5", ids, backend=orc.lib("x"))       # the arbiter: the oracle's source in long double arithmetic
+    bg, bo, bx = pg.batch, po.batch, px.batch
+    hip_far = orc_far = hip_right = orc_right = neither = 0
     bg.set_waves_per_game(waves_per_game)
     bg.mpc_totals(reset=True)
     states = [bg.get_x0()]
@@ -90,15 +92,17 @@ def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
     worst_short = worst_all = worst_first = 0.0
     for t in range(T):
         if t == 1:                                              # later solves: shift = 1, dual_reset = false
-            for p_ in (pg, po):
+            for p_ in (pg, po, px):
                 p_.opts.shift, p_.opts.dual_reset = 1, False
                 p_._sync_options()
         z = bg.get_traj(0)
         lam, mu = bg.get_con_duals()
-        bo.set_x0(z[:, :bg.n].copy()); bo.set_traj(z, 0); bo.set_con_duals(lam, mu)
+        for b_ in (bo, bx):
+            b_.set_x0(z[:, :bg.n].copy()); b_.set_traj(z, 0); b_.set_con_duals(lam, mu)
         gid = pg.game_id0 + t * 1000003
         sg = bg.newton_solve(init=True, game_id0=gid)
         so = bo.newton_solve(init=True, game_id0=gid)
+        sx = bx.newton_solve(init=True, game_id0=gid)
         same = np.ones(len(ids), dtype=bool)
         for f in ("status", "outer_iters", "newton_iters", "ls_failures", "converged", "records"):
             same &= sg[f] == so[f]
@@ -109,6 +113,14 @@ def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
         short = same & (sg["newton_iters"] <= 10) & (sg["ls_failures"] == 0) & (sg["converged"] == 1)
         worst_short = max(worst_short, float(err[short].max(initial=0.0)))
         worst_all = max(worst_all, float(err[same & (sg["converged"] == 1)].max(initial=0.0)))
+        # against the arbiter: which of the two double programs is closer to the extended-precision run of the same solve
+        CNT = ("status", "outer_iters", "newton_iters", "ls_failures", "converged", "records")
+        gx = np.all([sg[f] == sx[f] for f in CNT], axis=0); ox = np.all([so[f] == sx[f] for f in CNT], axis=0)
+        zx = bx.get_traj(0)
+        eg, eo = np.abs(bg.get_traj(0) - zx).max(axis=1), np.abs(bo.get_traj(0) - zx).max(axis=1)
+        all3 = gx & ox & (sx["converged"] == 1)
+        hip_far += int((all3 & (eg > 1e-8 + 100.0 * eo)).sum()); orc_far += int((all3 & (eo > 1e-8 + 100.0 * eg)).sum())
+        hip_right += int((gx & ~ox).sum()); orc_right += int((ox & ~gx).sum()); neither += int((~gx & ~ox).sum())
         for g in range(len(ids)):
             hg, ho = bg.get_history(g, 1), bo.get_history(g, 1)
             for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
@@ -117,7 +129,10 @@ def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
         bg.mpc_advance()
         states.append(bg.get_x0())
     it_step, cv_step = bg.mpc_totals()
+    print("C5 lock-step vs arbiter:", dict(hip_far=hip_far, orc_far=orc_far, hip_right=hip_right, orc_right=orc_right, neither=neither,
+                                           n_diff=n_diff, worst_all=worst_all, worst_short=worst_short))
     return dict(n_solves=n_solves, n_diff=n_diff, worst_short=worst_short, worst_all=worst_all, worst_first=worst_first,
+                hip_far=hip_far, orc_far=orc_far, hip_right=hip_right, orc_right=orc_right, neither=neither,
                 it=it_step, cv=cv_step, states=np.stack(states), ids=ids, n=pg.model.n)
 
 

@@ -1308,3 +1308,28 @@ def test_pair_collision_avoidance_adders(alg, orc):
     assert con.collision_pairs == {(1, 2): 0.9, (3, 1): 0.2}
     with pytest.raises(alg.AlgamesError):
         alg.add_collision_avoidance(con, 0.3)
+
+
+def test_arbiter_builds(alg, orc):
+    """The arbiter of the parity tests is the oracle's own source with the scalar type swapped (oracle/Makefile): long double
+    (liboracle_x.so) and __float128 (liboracle_q.so) behind the same double ABI.  On a well-conditioned problem the three agree to
+    the double oracle's rounding, the two extended builds to long-double rounding; the discrete history is identical."""
+    import oracle as orcmod
+    ids = np.arange(40, 43)
+    probs = {k: alg.scenarios.make_problem("C2", ids, N=8, backend=orcmod.lib(k)) for k in ("", "x", "q")}
+    for p_ in probs.values():
+        alg.newton_solve(p_)
+    z = {k: p_.batch.get_traj() for k, p_ in probs.items()}
+    s = {k: p_.stats.summary for k, p_ in probs.items()}
+    for k in ("x", "q"):
+        for f in ("status", "outer_iters", "newton_iters", "ls_failures", "converged"):
+            assert np.array_equal(s[k][f], s[""][f]), (k, f)
+    assert np.abs(z[""] - z["q"]).max() <= 1e-10 and np.abs(z["x"] - z["q"]).max() <= 1e-13
+    # residual of one fixed iterate: double rounding vs extended (the ABI rounds the result to double)
+    rng = np.random.default_rng(2)
+    zz = rng.random(z[""].shape); zz[:, :12] = probs[""].x0
+    r = {}
+    for k, p_ in probs.items():
+        p_.batch.set_traj(zz); r[k] = p_.batch.residual(0, 1e-3)[0]
+    assert np.abs(r["x"] - r["q"]).max() <= 4e-16 * (1 + np.abs(r["q"]).max())
+    assert 0 < np.abs(r[""] - r["q"]).max() <= 1e-12 * (1 + np.abs(r["q"]).max())

@@ -85,6 +85,7 @@ def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
     px = alg.scenarios.make_problem("C5", ids, backend=orc.lib("x"))       # the arbiter: the oracle's source in long double arithmetic
     bg, bo, bx = pg.batch, po.batch, px.batch
     hip_far = orc_far = hip_right = orc_right = neither = 0
+    worst_eg = worst_eo = 0.0
     bg.set_waves_per_game(waves_per_game)
     bg.mpc_totals(reset=True)
     states = [bg.get_x0()]
@@ -120,6 +121,7 @@ def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
         eg, eo = np.abs(bg.get_traj(0) - zx).max(axis=1), np.abs(bo.get_traj(0) - zx).max(axis=1)
         all3 = gx & ox & (sx["converged"] == 1)
         hip_far += int((all3 & (eg > 1e-8 + 100.0 * eo)).sum()); orc_far += int((all3 & (eo > 1e-8 + 100.0 * eg)).sum())
+        worst_eg = max(worst_eg, float(eg[all3].max(initial=0.0))); worst_eo = max(worst_eo, float(eo[all3].max(initial=0.0)))
         hip_right += int((gx & ~ox).sum()); orc_right += int((ox & ~gx).sum()); neither += int((~gx & ~ox).sum())
         for g in range(len(ids)):
             hg, ho = bg.get_history(g, 1), bo.get_history(g, 1)
@@ -130,9 +132,9 @@ def _c5_lockstep(alg, orc, T, waves_per_game, hard_iters):
         states.append(bg.get_x0())
     it_step, cv_step = bg.mpc_totals()
     print("C5 lock-step vs arbiter:", dict(hip_far=hip_far, orc_far=orc_far, hip_right=hip_right, orc_right=orc_right, neither=neither,
-                                           n_diff=n_diff, worst_all=worst_all, worst_short=worst_short))
+                                           n_diff=n_diff, worst_all=worst_all, worst_short=worst_short, worst_eg=worst_eg, worst_eo=worst_eo))
     return dict(n_solves=n_solves, n_diff=n_diff, worst_short=worst_short, worst_all=worst_all, worst_first=worst_first,
-                hip_far=hip_far, orc_far=orc_far, hip_right=hip_right, orc_right=orc_right, neither=neither,
+                hip_far=hip_far, orc_far=orc_far, hip_right=hip_right, orc_right=orc_right, neither=neither, worst_eg=worst_eg, worst_eo=worst_eo,
                 it=it_step, cv=cv_step, states=np.stack(states), ids=ids, n=pg.model.n)
 
 
@@ -150,12 +152,24 @@ def test_c5_receding_horizon_64_seeds_x_200_steps_against_the_oracle(alg, orc):
         >= 10 Newton iterations;
       * converged solves with identical counts, <= 10 Newton iterations and no failed line search agree to 1e-8 in the
         trajectory, all other converged solves with identical counts to 1e-4 (measured 1.3e-5 on a 33-iteration solve);
-    and the fused loop kernel (one launch, alg_mpc_solve) reproduces the step-wise launches."""
+    and the fused loop kernel (one launch, alg_mpc_solve) reproduces the step-wise launches.
+
+    The arbiter (round 3): every one of the 12 800 solves is also run by the oracle's source in long double arithmetic on the same
+    inputs.  Measured: in the 7 solves whose counts differ the arbiter's counts are the double oracle's 7 times and the HIP path's 0
+    times; among the solves where all three agree on the counts and converge, the HIP trajectory is the far one (more than
+    1e-8 + 100 x the oracle's distance from the arbiter) in 21 solves, the oracle's in none; the worst distances are 1.35e-5 (HIP)
+    and 2.3e-8 (oracle).  I.e. the 1e-4 bound on long solves is the HIP path's own error on ill-conditioned solves (penalties
+    grown over tens of iterations make the pivot blocks of the structured elimination ill-conditioned; the pivoted banded LU is
+    backward stable regardless), not a shared amplification.  The bounds below pin that finding: rare (<= 0.25 % of the solves),
+    small (<= 1e-4), and never the other way round by more than the oracle's own 1e-6."""
     T = 200
     r = _c5_lockstep(alg, orc, T, waves_per_game=1, hard_iters=10)
     assert r["worst_first"] <= 1.0, r["worst_first"]
     assert r["n_diff"] <= 0.002 * r["n_solves"], (r["n_diff"], r["n_solves"])
     assert r["worst_short"] <= 1e-8 and r["worst_all"] <= 1e-4, (r["worst_short"], r["worst_all"])
+    assert r["hip_far"] <= 0.0025 * r["n_solves"] and r["worst_eg"] <= 1e-4, (r["hip_far"], r["worst_eg"])
+    assert r["orc_far"] <= 0.0025 * r["n_solves"] and r["worst_eo"] <= 1e-6, (r["orc_far"], r["worst_eo"])
+    assert r["hip_right"] + r["orc_right"] + r["neither"] <= 3 * r["n_diff"] + 8, r      # the arbiter disagrees with BOTH only on hard solves
     states = r["states"]
     assert np.abs(states[-1] - states[0]).max() > 0.5          # the vehicles really travel
     assert r["it"].sum() > 64 * T                              # at least one Newton iteration per solve
@@ -165,8 +179,9 @@ def test_c5_receding_horizon_64_seeds_x_200_steps_against_the_oracle(alg, orc):
     it_f, cv_f, st_f = alg.mpc_solve(pf, T, record_states=True)
     assert st_f.shape == states.shape == (T + 1, 64, r["n"])
     same_f = it_f == r["it"]
-    assert same_f.mean() >= 0.9, (np.nonzero(~same_f)[0], it_f[~same_f], r["it"][~same_f])
-    assert np.abs(st_f - states)[:, same_f].max() < 1e-6
+    print("fused loop vs step-wise: seeds with the same iteration total", same_f.mean(), "max state diff on those", np.abs(st_f - states)[:, same_f].max())
+    assert same_f.mean() >= 0.98, (np.nonzero(~same_f)[0], it_f[~same_f], r["it"][~same_f])      # measured: all 64 seeds, states bit-identical
+    assert np.abs(st_f - states)[:, same_f].max() < 1e-9
     assert np.array_equal(cv_f[same_f], r["cv"][same_f])
 
 
@@ -174,7 +189,8 @@ def test_c5_receding_horizon_team_kernel_lock_step(alg, orc):
     """The same lock-step comparison with the kernel shape the library picks for 64 seeds (a team of 4 wavefronts per game), 100
     MPC steps.  The team sums the residual norms in a different order, so its closed loop visits slightly different states than
     the one-wavefront loop and meets other hard solves (non-converging 100-iteration solves at steps 4-6 of this run); measured:
-    22 of 12 800 solves with different counts, every one of them a solve of >= 13 iterations on one side."""
+    22 of 12 800 solves with different counts in round 2; since round 3 (DPP reductions in both shapes) the team's 100 steps give the
+    one-wavefront kernel's tallies (7 differing solves, all at steps 10-13)."""
     r = _c5_lockstep(alg, orc, 100, waves_per_game=0, hard_iters=10)
     assert r["worst_first"] <= 1.0, r["worst_first"]
     assert r["n_diff"] <= 0.005 * r["n_solves"], (r["n_diff"], r["n_solves"])

@@ -27,7 +27,7 @@
 #include <utility>
 #include "../../include/algames_hip.h"
 
-// tunables (scratch/build_variant.sh builds A/B variants of the library with other values)
+// tunables (tests/probes/build_variant.sh builds A/B variants of the library with other values)
 #ifndef ALG_ASM_UNROLL
 #define ALG_ASM_UNROLL 2
 #endif
@@ -160,7 +160,7 @@ struct Cfg {
 // newton_solve / rollout are __forceinline__: they have two callers per instantiation (k_newton_solve, k_mpc_loop) and the
 // inliner would outline the largest instantiations -- a kernel whose callee is outlined gets its by-value Params copied to
 // scratch (1.3 KB per lane) and loses a third of its speed.  (Forcing the other solver-level functions changes the inlining
-// order and costs registers: they are left to the inliner, scratch/isa_stats.py + `grep s_swappc` guard against outlining.)
+// order and costs registers: they are left to the inliner, tests/probes/isa_stats.py + `grep s_swappc` guard against outlining.)
 
 // ---- index maps (newton_core.jl:40-89), 0-based --------------------------------------------------
 template <class C> __device__ __forceinline__ int hx(int k) { return k * C::b; }
@@ -1712,14 +1712,14 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
     }
 }
 
-// Scratch instrumentation (-DALG_PHASE_PROF, scratch/phase_prof.sh): shader-clock cycles per phase of the sweeps, accumulated
+// Scratch instrumentation (-DALG_PHASE_PROF, tests/probes/phase_prof.sh): shader-clock cycles per phase of the sweeps, accumulated
 // into G.res(pr)[0..] (unused by the fused solver).  Never defined in the product build.
 #ifdef ALG_PHASE_PROF
 #define ALG_PROF_DECL unsigned long long prof_t_ = __builtin_readcyclecounter(), prof_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define ALG_PROF(j) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc_[j] += t_ - prof_t_; prof_t_ = t_; }
 #define ALG_PROF_FLUSH if (game_tid() == 0) { for (int j_ = 0; j_ < 12; j_++) G.res(pr)[j_] += (double)prof_acc_[j_]; }
 #elif defined(ALG_ISA_MARK)
-// static accounting (scratch/isa_phases.py): the phase boundaries show up as comments in the -S output
+// static accounting (tests/probes/isa_phases.py): the phase boundaries show up as comments in the -S output
 #define ALG_PROF_DECL
 #define ALG_PROF(j) asm volatile("; ALGMARK " #j ::: "memory");
 #define ALG_PROF_FLUSH

@@ -44,7 +44,7 @@ __device__ __forceinline__ double dpp64(double v) {
 }
 constexpr int DPP_ROR8 = 0x128, DPP_ROR4 = 0x124, DPP_ROR2 = 0x122, DPP_ROR1 = 0x121;
 // lane ^ 8 inside the 16-lane row: ds_swizzle SWAP,8 -- on the LDS crossbar, not on the VALU (every VALU instruction, 32-bit DPP
-// moves included, costs the SIMD 4.4 cycles: scratch/valu_rate.hip; the vector pipe is what the collective is bound by)
+// moves included, costs the SIMD 4.4 cycles: tests/probes/valu_rate.hip; the vector pipe is what the collective is bound by)
 __device__ __forceinline__ double partner8(double v) {
     const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x201f), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x201f);
     return __hiloint2double(hi, lo);
@@ -124,7 +124,7 @@ __device__ __forceinline__ void qt_elim6(double (&cw)[6], double (&cr)[6], doubl
                  : [pw] "v"(pw), [pr] "v"(pr), [l] "n"(L));
 }
 
-// Scratch instrumentation (-DALG_PHASE_PROF, scratch/qt_prof.sh): shader-clock cycles per phase and role, accumulated into the
+// Scratch instrumentation (-DALG_PHASE_PROF, tests/probes/qt_prof.sh): shader-clock cycles per phase and role, accumulated into the
 // res buffer of the row's game (slots 16 + 8 wavefront + j).  Never defined in the product build.
 #ifdef ALG_PHASE_PROF
 #define QT_PROF_DECL unsigned qp_t_ = (unsigned)__builtin_readcyclecounter(), qp_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};

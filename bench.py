@@ -145,7 +145,7 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
 def inrun_pmc(argv_tail, kernel, iters_per_launch, own_bytes, timeout_s=150):
     """Hardware counters of THIS run's workload, measured now: after the timed region rank 0 starts one short child of this very
     script per counter group under `rocprofv3 --pmc ... --kernel-trace` (counter passes on their own, as the MI355X guide
-    prescribes; FETCH_SIZE x 2 = the gfx950 correction calibrated with scratch/pmc_calib.hip, KB units) and averages the solver
+    prescribes; FETCH_SIZE x 2 = the gfx950 correction calibrated with tests/probes/pmc_calib.hip, KB units) and averages the solver
     kernel's launches.  Returns None when rocprofv3 is missing or a pass fails (the caller then falls back to the committed
     profile and says so)."""
     import csv

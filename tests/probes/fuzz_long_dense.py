@@ -1,4 +1,4 @@
-"""One-off long differential fuzz run of the dense-direction families (GPU box): python scratch/fuzz_long_dense.py [n_seeds] --
+"""One-off long differential fuzz run of the dense-direction families (GPU box): python tests/probes/fuzz_long_dense.py [n_seeds] --
 generator and comparison of tests/test_gpu_fuzz.py::test_fuzz_dense_direction_instantiations, seeds 400000 + i."""
 import sys, os, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,7 @@
 """How much does the CPU oracle itself amplify a 1e-13 relative perturbation of x0 on a fuzz problem?  (CPU only.)  On the seeds where
 the HIP path and the oracle end outside the comparison tolerances the answer is 1e6 .. 1e10 in exactly the games that differ; on
 ordinary seeds it is ~1: those mismatches are conditioning of the (diverging) problem, not an arithmetic difference that matters.
-usage: python scratch/fuzz_sensitivity.py [seed ...]   (five- / six-player family, seeds 500000 + i)"""
+usage: python tests/probes/fuzz_sensitivity.py [seed ...]   (five- / six-player family, seeds 500000 + i)"""
 import sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))

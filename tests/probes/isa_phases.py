@@ -1,5 +1,5 @@
 """Static per-phase instruction counts of the Newton direction (tile path): compiles k_direction with -DALG_ISA_MARK and counts
-the instructions between the ALGMARK comments.  usage: python scratch/isa_phases.py [model p d ext] [extra flags]"""
+the instructions between the ALGMARK comments.  usage: python tests/probes/isa_phases.py [model p d ext] [extra flags]"""
 import re, subprocess, sys, os, collections
 cfg = sys.argv[1:5] if len(sys.argv) > 4 else ["ALG_MODEL_DOUBLE_INTEGRATOR", "3", "2", "0"]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """Static ISA accounting of one kernel instantiation (default: k_newton_solve of C2).
-usage: python scratch/isa_stats.py [kernel] [model p d ext]  -> registers / scratch and per-loop instruction mix."""
+usage: python tests/probes/isa_stats.py [kernel] [model p d ext]  -> registers / scratch and per-loop instruction mix."""
 import re, subprocess, sys, os, collections
 kern = sys.argv[1] if len(sys.argv) > 1 else "k_newton_solve"
 cfg = sys.argv[2:6] if len(sys.argv) > 5 else ["ALG_MODEL_DOUBLE_INTEGRATOR", "3", "2", "0"]

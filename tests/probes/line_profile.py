@@ -1,5 +1,5 @@
 """Static instruction counts per source line of algames_device.hpp for one kernel instantiation (needs -gline-tables-only):
-python scratch/line_profile.py [kernel] [model p d ext] -> instructions attributed to each source line inside the hottest loops."""
+python tests/probes/line_profile.py [kernel] [model p d ext] -> instructions attributed to each source line inside the hottest loops."""
 import re, subprocess, sys, os, collections
 kern = sys.argv[1] if len(sys.argv) > 1 else "k_direction"
 cfg = sys.argv[2:6] if len(sys.argv) > 5 else ["ALG_MODEL_DOUBLE_INTEGRATOR", "3", "2", "0"]

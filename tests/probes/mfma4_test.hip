@@ -1,5 +1,5 @@
 // Layout and issue rate of v_mfma_f64_4x4x4_4b_f64 on gfx950 (4 blocks of 4x4x4 per wave: block = 16-lane row).
-// build: hipcc --offload-arch=gfx950 -O2 -o /tmp/mfma4 scratch/mfma4_test.hip ; run on the GPU box.
+// build: hipcc --offload-arch=gfx950 -O2 -o /tmp/mfma4 tests/probes/mfma4_test.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>

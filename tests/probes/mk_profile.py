@@ -1,4 +1,4 @@
-"""Turn a gpurun_out/<tag>/ directory produced by scratch/prof_run.sh into the committed evidence under profiles/:
+"""Turn a gpurun_out/<tag>/ directory produced by tests/probes/prof_run.sh into the committed evidence under profiles/:
    profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats) and profiles/<tag>_pmc_traffic.json."""
 import csv, glob, json, os, shutil, sys, collections
 tag = sys.argv[1]
@@ -21,7 +21,7 @@ out = {
     "kernel": kname, "launches_averaged": nf,
     "fetch_size_kb": fetch["FETCH_SIZE"], "write_size_kb": write["WRITE_SIZE"],
     "hbm_bytes_per_launch": 1024.0 * (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]),
-    "note": "separate --pmc passes (scratch/prof_run.sh); KB units; FETCH_SIZE is doubled (gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE taken as is: calibrated on this box with scratch/pmc_calib.hip (2 GiB streams: FETCH_SIZE = 0.500 x bytes for 8 B/lane and 16 B/lane loads, WRITE_SIZE = 1.000 x bytes for 8 B/lane and 16 B/lane stores); these are L2-fabric-side bytes, Infinity-Cache hits included",
+    "note": "separate --pmc passes (tests/probes/prof_run.sh); KB units; FETCH_SIZE is doubled (gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE taken as is: calibrated on this box with tests/probes/pmc_calib.hip (2 GiB streams: FETCH_SIZE = 0.500 x bytes for 8 B/lane and 16 B/lane loads, WRITE_SIZE = 1.000 x bytes for 8 B/lane and 16 B/lane stores); these are L2-fabric-side bytes, Infinity-Cache hits included",
     "sq_per_launch": sq, "bench": bench,
 }
 json.dump(out, open(os.path.join(root, "profiles", tag + "_pmc_traffic.json"), "w"), indent=1)

@@ -1,4 +1,4 @@
-"""gpurun_out/<tag>/ (scratch/prof_r02.sh) -> profiles/<tag>_kernel_stats.csv + profiles/<tag>_pmc.json (read by bench.py)."""
+"""gpurun_out/<tag>/ (tests/probes/prof_r02.sh) -> profiles/<tag>_kernel_stats.csv + profiles/<tag>_pmc.json (read by bench.py)."""
 import csv, glob, json, os, shutil, sys, collections
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,8 +32,8 @@ out = {
     "mfma_frac": cnt["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / (kavg_ns * 1e-9) / 78.6e12,
     "own_hbm_frac": own * it / (kavg_ns * 1e-9) / 8.0e12,
     "insts_per_game_iter": {k[9:].lower(): cnt[k] / it for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_MFMA")},
-    "note": "separate rocprofv3 --pmc passes (scratch/prof_r02.sh), per-launch averages for the named kernel; FETCH_SIZE doubled (gfx950 correction, "
-            "calibrated with scratch/pmc_calib.hip), WRITE_SIZE as is, KB units; valu_issue_frac = SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs / 4 x 1024 SIMDs): "
+    "note": "separate rocprofv3 --pmc passes (tests/probes/prof_r02.sh), per-launch averages for the named kernel; FETCH_SIZE doubled (gfx950 correction, "
+            "calibrated with tests/probes/pmc_calib.hip), WRITE_SIZE as is, KB units; valu_issue_frac = SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs / 4 x 1024 SIMDs): "
             "share of all SIMD issue quad-cycles of the launch that issued a VALU / MFMA instruction; mfma_frac = f64 MFMA flops / time / 78.6 TF; "
             "own_hbm_frac = bench.py structured_bytes() x game-iterations / rocprof kernel time / 8 TB/s",
     "counters_per_launch": cnt, "bench": bench,

@@ -1,9 +1,9 @@
 #!/bin/bash
-# per-kernel dynamic instruction counts of the stepwise API (run on the GPU box): scratch/phase_pmc.sh C2 4096
+# per-kernel dynamic instruction counts of the stepwise API (run on the GPU box): tests/probes/phase_pmc.sh C2 4096
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o t -- python $R/scratch/phase_times.py $1 $2 > /tmp/pt.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d /tmp/pp -o p -- python $R/scratch/phase_times.py $1 $2 > /tmp/pp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o t -- python $R/tests/probes/phase_times.py $1 $2 > /tmp/pt.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d /tmp/pp -o p -- python $R/tests/probes/phase_times.py $1 $2 > /tmp/pp.log 2>&1
 python - <<PY
 import csv, glob, collections
 f=[x for x in glob.glob("/tmp/pt/**/*.csv",recursive=True) if "kernel_stats" in x][0]

@@ -1,5 +1,5 @@
-"""Per-phase cycle profile of newton_direction_dense (library built with -DALG_PHASE_PROF: scratch/phase_prof.sh build).
-usage: python scratch/phase_prof_dense.py P GAMES [NW]"""
+"""Per-phase cycle profile of newton_direction_dense (library built with -DALG_PHASE_PROF: tests/probes/phase_prof.sh build).
+usage: python tests/probes/phase_prof_dense.py P GAMES [NW]"""
 import sys, os, ctypes
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, root)
 import numpy as np

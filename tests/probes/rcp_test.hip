@@ -1,4 +1,4 @@
-// accuracy of v_rcp_f64 and of one / two Newton refinements on gfx950: hipcc --offload-arch=gfx950 -O3 scratch/rcp_test.hip -o /tmp/rcp_test && /tmp/rcp_test
+// accuracy of v_rcp_f64 and of one / two Newton refinements on gfx950: hipcc --offload-arch=gfx950 -O3 tests/probes/rcp_test.hip -o /tmp/rcp_test && /tmp/rcp_test
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>

@@ -1,4 +1,4 @@
-"""Summarise -Rpass-analysis=kernel-resource-usage logs: python scratch/resusage.py LOG... [regex]"""
+"""Summarise -Rpass-analysis=kernel-resource-usage logs: python tests/probes/resusage.py LOG... [regex]"""
 import re, subprocess, sys
 pat = r"k_newton_solve|k_ibr|k_direction"
 files = [a for a in sys.argv[1:] if a.endswith(".log")]

@@ -1,5 +1,5 @@
 // Issue cost of the f64 / DPP instructions the quad-team kernels are built from (gfx950): cycles per instruction for one wavefront
-// alone on its SIMD and for four wavefronts per SIMD.  hipcc --offload-arch=gfx950 -O2 -o scratch/valu_rate scratch/valu_rate.hip
+// alone on its SIMD and for four wavefronts per SIMD.  hipcc --offload-arch=gfx950 -O2 -o tests/probes/valu_rate tests/probes/valu_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)

@@ -144,7 +144,7 @@ def test_c5_receding_horizon_64_seeds_x_200_steps_against_the_oracle(alg, orc):
     The closed loop feeds every solve's output into the next one and the scenario contains hard solves (vehicles crossing:
     20-140 Newton iterations, failed line searches), where a 1e-10 difference is amplified until a discrete decision flips;
     free-running loops of the two implementations therefore separate after a few dozen steps for a third of the seeds
-    (scratch/c5_loop_probe.py).  SURVEY.md 8(d) defines C5 parity per individual solve, so the comparison is lock-step
+    (tests/probes/c5_loop_probe.py).  SURVEY.md 8(d) defines C5 parity per individual solve, so the comparison is lock-step
     (_c5_lockstep).  Bounds for the one-wavefront kernel (measured: 7 of 12 800 solves differ in their counts, all of them
     >= 14-iteration solves at steps 10-13):
       * the first record! of every solve (same inputs, pure arithmetic) agrees to 1e-9 relative / 1e-12 absolute;

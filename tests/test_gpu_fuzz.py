@@ -109,9 +109,9 @@ DENSE_FAMILIES = [(DI, 1), (DI, 3), (DI, 4), (3, 1), (3, 2), (3, 3), (3, 4)]    
 P56_FAMILIES = [(DI, 5), (DI, 6), (UNI, 5), (UNI, 6), (BIC, 5), (BIC, 6)]
 
 
-# Three of the 25 (of 480) cases of the long five- / six-player run (scratch/fuzz_long_p56.py) that ended outside the tolerances.  These
+# Three of the 25 (of 480) cases of the long five- / six-player run (tests/probes/fuzz_long_p56.py) that ended outside the tolerances.  These
 # random many-player problems (thirty ordered pairs inside the collision-cost radius, control costs down to 1e-4) diverge; the oracle
-# ITSELF amplifies a 1e-13 relative change of x0 to 1e-3 .. 1e-7 in exactly the games that differ (scratch/fuzz_sensitivity.py) and
+# ITSELF amplifies a 1e-13 relative change of x0 to 1e-3 .. 1e-7 in exactly the games that differ (tests/probes/fuzz_sensitivity.py) and
 # by ~1 on ordinary seeds.
 @pytest.mark.parametrize("seed", [500258, 500262, 500365])
 def test_fuzz_five_and_six_players_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
@@ -157,7 +157,7 @@ def test_fuzz_3d_instantiation(alg, orc, seed):
     _compare_solve(g, o, tag)
 
 
-# Seeds of the long run of this generator (scratch/fuzz_long.py, 1800 cases on the round-2 binary) that ended outside the
+# Seeds of the long run of this generator (tests/probes/fuzz_long.py, 1800 cases on the round-2 binary) that ended outside the
 # tolerances of _compare_solve: 15 bicycle problems and one extended unicycle problem, all ill-conditioned and not converging
 # (residual norms growing to 5-60, multipliers up to 1e3, control costs down to 1e-4); their discrete histories are identical and
 # their trajectories differ by more than 1e-7 at the end.
@@ -181,7 +181,7 @@ def test_fuzz_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
         assert hg["ls_j"][0] == ho["ls_j"][0] and hg["alpha"][0] == ho["alpha"][0], (tag, game)
 
 
-# Cases of the long dense-family runs (scratch/fuzz_long_dense.py: 700 and 1400 problems) that ended outside the tolerances: quadrotor
+# Cases of the long dense-family runs (tests/probes/fuzz_long_dense.py: 700 and 1400 problems) that ended outside the tolerances: quadrotor
 # problems whose iterates blow up (dt = 0.2 over 8 steps from random attitudes and rates; residual norms 1e2 .. 1e15 after failed
 # line searches with ls_iter = 2 / 3).  Their discrete histories agree, both kernel shapes give the same numbers.
 @pytest.mark.parametrize("seed", [400034, 400081, 400795, 401042, 401091, 401322])
@@ -222,7 +222,7 @@ def test_fuzz_team_kernel_regressions(alg, orc, seed):
 # at a record where the decisions split, the arbiter's decision is taken by the HIP path or by the oracle (never by neither), and
 # over the whole seed list the HIP path sides with the arbiter at least as often as the double oracle does, give or take two.
 #
-# What the arbiter found (scratch/arbiter_probe.py, scratch/arbiter_dir_probe.py): for DoubleIntegrator, Unicycle
+# What the arbiter found (tests/probes/arbiter_probe.py, tests/probes/arbiter_dir_probe.py): for DoubleIntegrator, Unicycle
 # and Bicycle games the structured elimination and the oracle's pivoted banded LU are equally accurate -- Newton directions with the
 # same backward error (1e-17 .. 1e-18 in the arbiter's Jacobian), records that drift from the arbiter at the same rate.  For the
 # QuadrotorGame the elimination is only CONDITIONALLY stable: its pivot blocks R + B' P B (controls acting through two integrators,

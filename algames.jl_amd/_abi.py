@@ -108,6 +108,8 @@ SIGNATURES = {
     "rollout": (C.c_int, [_P, C.c_int32]),
     "residual": (C.c_int, [_P, C.c_int32, C.c_double, _D, _D]),
     "residual_jacobian": (C.c_int, [_P, C.c_double, _D]),
+    "residual_jacobian_games": (C.c_int, [_P, C.c_double, C.c_int32, C.c_int32, _D]),
+    "release_scratch": (C.c_int, [_P]),
     "newton_direction": (C.c_int, [_P, C.c_double, _D, _I]),
     "line_search": (C.c_int, [_P, C.c_double, _D, _D, _I]),
     "update_traj": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
@@ -369,10 +371,15 @@ class Batch:
         self.lib.check(self.lib.residual(self.h, which, reg, _dptr(res), _dptr(rn)))
         return res, rn
 
-    def residual_jacobian(self, reg=0.0):
-        jac = np.empty((self.B, self.S, self.S))
-        self.lib.check(self.lib.residual_jacobian(self.h, reg, _dptr(jac)))
+    def residual_jacobian(self, reg=0.0, games=None):
+        """Dense KKT Jacobians [g, row, col]; games = (first, count) restricts the work and the memory to that range."""
+        first, cnt = (0, self.B) if games is None else (int(games[0]), int(games[1]))
+        jac = np.empty((cnt, self.S, self.S))
+        self.lib.check(self.lib.residual_jacobian_games(self.h, reg, first, cnt, _dptr(jac)))
         return jac.transpose(0, 2, 1)     # column-major S x S per game -> [g, row, col]
+
+    def release_scratch(self):
+        self.lib.check(self.lib.release_scratch(self.h))
 
     def newton_direction(self, reg=0.0):
         delta = np.empty((self.B, self.S)); st = np.empty(self.B, dtype=np.int32)

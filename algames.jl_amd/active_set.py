@@ -239,7 +239,8 @@ def residual_jacobian(ascore, prob, game=0, constraint_rows=False):
     ps = ascore.probsize
     N, p = ps.N, ps.p
     ascore.jac[:] = 0.0
-    ascore.jac[:ps.S, :ps.S] = host.residual_jacobian(prob, 0.0)[game]
+    ascore.jac[:ps.S, :ps.S] = host.residual_jacobian(prob, 0.0, games=(game, 1))[0]      # this game only, and give the device copy back
+    prob.batch.release_scratch()
     X = _game_state(prob, game)
     evaluate(prob.game_con, X)
     for (i, j), cv in collision_convals(prob.game_con).items():
@@ -259,7 +260,13 @@ def nullspace(A, atol=1e-20):
     the first r, r = number of singular values > atol.  The reference's atol = 1e-20 is below what LAPACK leaves in the singular
     values of identically-zero rows (~1e-17 sigma_max), so in the reference those count as non-zero; NumPy may return them as
     exact zeros.  To give the same answer on every platform, singular values that belong to identically-zero rows of A are
-    counted as non-zero whenever atol is below eps * sigma_max."""
+    counted as non-zero whenever atol is below eps * sigma_max.
+
+    This is an APPROXIMATION of the reference's call, exact in the case the reference meets (rank deficiency from identically-zero
+    rows: inactive constraint rows of the active-set Jacobian): the rank used is (numerical rank at eps * sigma_max * max(m, n))
+    + (number of zero rows).  A matrix that is rank deficient for another reason (dependent non-zero rows) has singular values of
+    ~1e-17 sigma_max there, which LinearAlgebra.nullspace(atol = 1e-20) counts as non-zero and this function does not: its null
+    space is then larger than the reference's.  Pass atol >= eps * sigma_max to get the plain `s > atol` count."""
     A = np.asarray(A, dtype=np.float64)
     m, n = A.shape
     if m == 0 or n == 0:

@@ -44,6 +44,7 @@ constexpr int MAXM = 32;
 constexpr int HIST_MAX = ALG_HIST_MAX;
 
 // Everything that is shared by the games of a handle; passed to kernels by value.
+constexpr int TC_LEN = 16;       // per-game control slots (G.tc): solver scalars 0..7, t_elap accumulator and start stamp 8, 9
 struct Params {
     int model, p, d, N, n, m, mi, ni, S, b, traj_len, npair, col_len, ctl_len, con_len, B;
     double dt;
@@ -73,7 +74,7 @@ struct Params {
     // main arena: B x stride doubles; one contiguous, 128-byte aligned chunk per game holding every per-game array at the
     // offsets below (doubles, multiples of 16): [pdtraj | trial | delta | x0 | res | rec | kgain | tcache | stats | mpc totals]
     double* arena;
-    int stride, o_z1, o_z2, o_x0, o_res, o_rec, o_kgain, o_tc, o_st, o_mpc;
+    int stride, o_z1, o_z2, o_x0, o_res, o_rec, o_kgain, o_tc, o_st, o_mpc;      // o_tc: TC_LEN control slots per game
     // constraint arena: B x con_stride doubles, per game [lam | mu | vals] (con_pad doubles each; re-created when extended
     // constraints are added)
     double* con;
@@ -2651,6 +2652,7 @@ struct RecScalars { double res, opt; int nonfinite; };
 // the 100 MHz real-time counter into the game's scratch block at the top of an inner iteration and turns it into seconds at its
 // end -- through HBM, so that no register is live across the phases of the iteration; the next record! picks it up.
 constexpr int TC_TELAP = 8, TC_TSTART = 9;
+static_assert(TC_TSTART < TC_LEN, "per-game control slots");
 __device__ __forceinline__ void iter_clock_start(CPR pr0, const Game& G0) {
     CPR pr = phase_params(pr0); const Game G = G0.fresh();
     if (phase_lane() == 0) G.tc(pr)[TC_TSTART] = (double)__builtin_amdgcn_s_memrealtime();

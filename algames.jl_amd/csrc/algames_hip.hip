@@ -99,7 +99,7 @@ void layout_arena(Params& p) {
     auto seg = [&](int len) { const int at = o; o += pad16(std::max(len, 1)); return at; };
     seg(p.traj_len); p.o_z1 = seg(p.traj_len); p.o_z2 = seg(p.traj_len);
     p.o_x0 = seg(p.n); p.o_res = seg(p.S); p.o_rec = seg(p.rec_len); p.o_kgain = seg(p.kscratch_len);
-    p.o_tc = seg(8); p.o_st = seg((int)((sizeof(alg_game_stats) + 7) / 8)); p.o_mpc = seg(2);
+    p.o_tc = seg(TC_LEN); p.o_st = seg((int)((sizeof(alg_game_stats) + 7) / 8)); p.o_mpc = seg(2);
     p.stride = o;
 }
 int lqr_block(const Params& p) { return 2 * p.p * p.ni + 2 * p.p * p.mi; }
@@ -160,9 +160,11 @@ int launch_check(const char* what) {
 }
 
 #define H ((Handle*)h)
-#define LAUNCH(kernel, ...)                                                                     \
+#define LAUNCH(kernel, ...) LAUNCH_GRID(H->pr.B, kernel, __VA_ARGS__)
+#define LAUNCH_GRID(nblocks, kernel, ...)                                                       \
     do {                                                                                        \
         const Params& pr_ = H->pr;                                                              \
+        const int grid_ = (nblocks);                                                            \
         bool done_ = false;                                                                     \
         LAUNCH_CASES_(kernel, __VA_ARGS__)                                                      \
         if (!done_) return fail(ALG_ERR_ARG, "unsupported (model, p, d) configuration");        \
@@ -172,7 +174,7 @@ int launch_check(const char* what) {
 
 #define LAUNCH_ONE_(M, P, D, E, kernel, ...)                                                    \
     if (!done_ && pr_.model == (M) && pr_.p == (P) && pr_.d == (D) && pr_.ext == (E)) {         \
-        hipLaunchKernelGGL((kernel<Cfg<M, P, D, E>>), dim3(pr_.B), dim3(WAVE), 0, H->stream, __VA_ARGS__); \
+        hipLaunchKernelGGL((kernel<Cfg<M, P, D, E>>), dim3(grid_), dim3(WAVE), 0, H->stream, __VA_ARGS__); \
         done_ = true;                                                                           \
     }
 #define LAUNCH_CASES_(kernel, ...)                                                  \
@@ -759,14 +761,27 @@ int alg_residual(alg_handle* h, int32_t which, double reg, double* res, double* 
     return sync(H);
 }
 
-int alg_residual_jacobian(alg_handle* h, double reg, double* jac) {
+int alg_residual_jacobian_games(alg_handle* h, double reg, int32_t first_game, int32_t n_games, double* jac) {
     if (!h || !jac) return fail(ALG_ERR_ARG, "alg_residual_jacobian: null argument");
     int rc = use_device(H); if (rc) return rc;
     const Params& p = H->pr;
-    const size_t bytes = sizeof(double) * (size_t)p.B * p.S * p.S;
+    if (first_game < 0 || n_games < 1 || (long long)first_game + n_games > p.B) return fail(ALG_ERR_ARG, "alg_residual_jacobian_games: game range outside the batch");
+    const size_t bytes = sizeof(double) * (size_t)n_games * p.S * p.S;
     if ((rc = ensure_scratch(H, bytes))) return rc;
-    LAUNCH(k_jacobian, H->pr, reg, (double*)H->d_scratch);
+    LAUNCH_GRID(n_games, k_jacobian, H->pr, reg, (double*)H->d_scratch, (int)first_game);
     return d2h(H, jac, H->d_scratch, bytes);
+}
+int alg_residual_jacobian(alg_handle* h, double reg, double* jac) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_residual_jacobian: null argument");
+    return alg_residual_jacobian_games(h, reg, 0, H->pr.B, jac);
+}
+int alg_release_scratch(alg_handle* h) {
+    NEED_HANDLE("alg_release_scratch");
+    if (!H->d_scratch) return ALG_OK;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    dfree(H, H->d_scratch);
+    H->d_scratch = nullptr; H->scratch_bytes = 0;
+    return ALG_OK;
 }
 
 int alg_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status) {
@@ -881,7 +896,7 @@ int alg_debug_check_guards(alg_handle* h) {
     std::vector<double> chunk((size_t)ng * p.stride);
     if (hipMemcpy(chunk.data(), p.arena, sizeof(double) * chunk.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     const int segs[][2] = {{0, p.traj_len}, {p.o_z1, p.traj_len}, {p.o_z2, p.traj_len}, {p.o_x0, p.n}, {p.o_res, p.S}, {p.o_rec, p.rec_len},
-                           {p.o_kgain, p.kscratch_len}, {p.o_tc, 8}, {p.o_st, (int)((sizeof(alg_game_stats) + 7) / 8)}, {p.o_mpc, 2}};
+                           {p.o_kgain, p.kscratch_len}, {p.o_tc, TC_LEN}, {p.o_st, (int)((sizeof(alg_game_stats) + 7) / 8)}, {p.o_mpc, 2}};
     for (int gi = 0; gi < ng; gi++)
         for (auto& sg : segs)
             for (int e = sg[0] + sg[1]; e < sg[0] + pad16(std::max(sg[1], 1)); e++) {

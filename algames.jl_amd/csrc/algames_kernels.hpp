@@ -43,15 +43,15 @@ __global__ void __launch_bounds__(WAVE) k_residual(Params pr_arg, int which, dou
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr_arg, double reg, double* J) {
+__global__ void __launch_bounds__(WAVE) k_jacobian(Params pr_arg, double reg, double* J, int g0) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
-    const int g = blockIdx.x;
+    const int g = blockIdx.x + g0;        // games g0 .. g0 + gridDim.x - 1; J holds gridDim.x blocks
     Game G = game_view(pr, g);
     ResOut ro;
     assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, reg, ro);
     __syncthreads();
-    jacobian_dense<C>(pr, G, reg, J + (size_t)g * pr.S * pr.S);
+    jacobian_dense<C>(pr, G, reg, J + (size_t)blockIdx.x * pr.S * pr.S);
 }
 
 template <class C>
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(P
     PREFIX __global__ void k_newton_solve<Cfg<M, P, D, E>>(Params, int, uint64_t);                                \
     PREFIX __global__ void k_newton_step<Cfg<M, P, D, E>>(Params, int, int, const double*, alg_step_info*);                      \
     PREFIX __global__ void k_residual<Cfg<M, P, D, E>>(Params, int, double, double*);                    \
-    PREFIX __global__ void k_jacobian<Cfg<M, P, D, E>>(Params, double, double*);                                  \
+    PREFIX __global__ void k_jacobian<Cfg<M, P, D, E>>(Params, double, double*, int);                             \
     PREFIX __global__ void k_direction<Cfg<M, P, D, E>>(Params, double, int*);                                    \
     PREFIX __global__ void k_line_search<Cfg<M, P, D, E>>(Params, double, const double*, double*, int*);          \
     PREFIX __global__ void k_update<Cfg<M, P, D, E>>(Params, int, int, const double*);                            \

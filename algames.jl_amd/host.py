@@ -700,10 +700,11 @@ def residual_norm(prob, which=ALG_TRAJ_PD):
     return prob.batch.residual(which, 0.0, want_res=False)[1]
 
 
-def residual_jacobian(prob, reg=0.0):
-    """residual_jacobian! + regularize_residual_jacobian!: dense (B, S, S), [row vertical, col horizontal]."""
+def residual_jacobian(prob, reg=0.0, games=None):
+    """residual_jacobian! + regularize_residual_jacobian!: dense (B, S, S), [row vertical, col horizontal]; games = (first, count)
+    builds only that range of the batch ((count, S, S))."""
     prob._sync_options()
-    return prob.batch.residual_jacobian(reg)
+    return prob.batch.residual_jacobian(reg, games)
 
 
 def inner_iteration(prob, LS_count, t_elap, Δ, k, l):

@@ -443,11 +443,14 @@ function residual(bp::BatchedGameProblem; reg::Float64=0.0)
     return res, rn
 end
 "residual_jacobian! + regularisation (global_quantities.jl:109-193): S x S x B dense, rows vertical order, columns horizontal order."
-function residual_jacobian(bp::BatchedGameProblem; reg::Float64=0.0)
-    S = bp.probs[1].probsize.S; B = length(bp.probs)
-    jac = zeros(S, S, B)
-    check(ccall((:alg_residual_jacobian, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}), bp.h, reg, jac))
+function residual_jacobian(bp::BatchedGameProblem; reg::Float64=0.0, games::UnitRange{Int}=1:length(bp.probs))
+    S = bp.probs[1].probsize.S
+    jac = zeros(S, S, length(games))      # only the requested games are built on the device and copied
+    check(ccall((:alg_residual_jacobian_games, LIB), Cint, (Ptr{Cvoid}, Float64, Int32, Int32, Ptr{Float64}),
+                bp.h, reg, Int32(first(games) - 1), Int32(length(games)), jac))
     return jac
 end
+"Give the inspection entry points' device scratch (dense Jacobians, MPC state logs) back to the allocator."
+release_scratch!(bp::BatchedGameProblem) = check(ccall((:alg_release_scratch, LIB), Cint, (Ptr{Cvoid},), bp.h))
 
 end # module

@@ -262,6 +262,13 @@ int alg_residual(alg_handle* h, int32_t which, double reg, double* res, double* 
  * jac is B x S x S dense column-major (parity / inspection entry point; the solver itself never
  * materialises it). */
 int alg_residual_jacobian(alg_handle* h, double reg, double* jac);
+/* The same for games first_game .. first_game + n_games - 1 only: jac is n_games x S x S.  The active-set inspection
+ * (active_set_methods.jl:127-170 works on ONE problem) uses this so that looking at one game of a large batch does not
+ * materialise B dense Jacobians. */
+int alg_residual_jacobian_games(alg_handle* h, double reg, int32_t first_game, int32_t n_games, double* jac);
+/* Frees the device scratch the inspection entry points (dense Jacobians, MPC state logs) grow on demand.  The solver never
+ * uses that buffer; the next inspection call allocates it again. */
+int alg_release_scratch(alg_handle* h);
 /* Δtraj = -lu(jac) \ res ; set_traj!(Δpdtraj, Δtraj) (solver_methods.jl:87-88).  delta: B x S or NULL. */
 int alg_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status /*B or NULL*/);
 /* line_search (solver_methods.jl:105-125) on the stored Δpdtraj. */

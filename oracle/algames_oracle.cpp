@@ -1405,14 +1405,17 @@ int orc_residual(alg_handle* h, int32_t which, double reg, double* res, double* 
     }
     return ALG_OK;
 }
-int orc_residual_jacobian(alg_handle* h, double reg, double* jac) {
+int orc_residual_jacobian_games(alg_handle* h, double reg, int32_t first_game, int32_t n_games, double* jac) {
     const int B = (int)H->g.size(); const size_t S = H->sh.D.S;
-    for (int gi = 0; gi < B; gi++) {
-        double* Jm = jac + (size_t)gi * S * S; std::fill(Jm, Jm + S * S, 0.0);
+    if (first_game < 0 || n_games < 1 || (long long)first_game + n_games > B) return fail(ALG_ERR_ARG, "orc_residual_jacobian_games: game range outside the batch");
+    for (int gi = first_game; gi < first_game + n_games; gi++) {
+        double* Jm = jac + (size_t)(gi - first_game) * S * S; std::fill(Jm, Jm + S * S, 0.0);
         jacobian(H->sh, H->g[gi], H->g[gi].z[0], reg, [&](int r, int c, double v) { Jm[(size_t)c * S + r] += v; });
     }
     return ALG_OK;
 }
+int orc_residual_jacobian(alg_handle* h, double reg, double* jac) { return orc_residual_jacobian_games(h, reg, 0, (int)H->g.size(), jac); }
+int orc_release_scratch(alg_handle*) { return ALG_OK; }
 int orc_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status) {
     const int B = (int)H->g.size(), S = H->sh.D.S, n = H->sh.D.n;
 #pragma omp parallel for schedule(dynamic)

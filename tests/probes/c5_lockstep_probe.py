@@ -1,7 +1,7 @@
 """C5 closed loop, lock-step: the HIP path drives the loop; before every MPC step the oracle receives the HIP path's complete
 solver state (x0, warm-start trajectory, multipliers, penalties) and both run that one newton_solve!."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import algames_jl_amd as alg, oracle as orc

@@ -1,6 +1,6 @@
 """Where does the C5 closed loop of the HIP path leave the oracle's?  Step-wise loops of both, per-step iteration counts."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import algames_jl_amd as alg, oracle as orc

@@ -1,7 +1,7 @@
 """Work accounting of the C5 receding-horizon loop at 64 seeds: Newton directions, record! passes and line-search trial passes per
 game (step-wise loop, statistics read back per MPC step), against the fused loop's wall time."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import algames_jl_amd as alg

@@ -1,6 +1,6 @@
 """One-off long differential fuzz run (GPU box): python tests/probes/fuzz_long.py [n_seeds] -- same generator as tests/test_gpu_fuzz.py."""
 import sys, os, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import algames_jl_amd as alg, oracle as orc

@@ -1,7 +1,7 @@
 """One-off long differential fuzz run of the dense-direction families (GPU box): python tests/probes/fuzz_long_dense.py [n_seeds] --
 generator and comparison of tests/test_gpu_fuzz.py::test_fuzz_dense_direction_instantiations, seeds 400000 + i."""
 import sys, os, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import algames_jl_amd as alg, oracle as orc

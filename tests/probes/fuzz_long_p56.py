@@ -1,7 +1,7 @@
 """One-off long differential fuzz run of the five- / six-player families (GPU box): python tests/probes/fuzz_long_p56.py [n] -- generator and
 comparison of tests/test_gpu_fuzz.py::test_fuzz_five_and_six_players, seeds 500000 + i."""
 import sys, os, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import algames_jl_amd as alg, oracle as orc

@@ -1,6 +1,6 @@
 """One fuzz case (generator of tests/test_gpu_fuzz.py) under both kernel shapes: python tests/probes/fuzz_nw.py SEED [ext] [d3]"""
 import sys, os
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import algames_jl_amd as alg, oracle as orc

@@ -3,7 +3,7 @@ the HIP path and the oracle end outside the comparison tolerances the answer is 
 ordinary seeds it is ~1: those mismatches are conditioning of the (diverging) problem, not an arithmetic difference that matters.
 usage: python tests/probes/fuzz_sensitivity.py [seed ...]   (five- / six-player family, seeds 500000 + i)"""
 import sys, os
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import algames_jl_amd as alg, oracle as orc

@@ -2,7 +2,7 @@
 of Newton iterations.  C5 problems (3-player Unicycle, N=30) at 4096 games: iteration counts spread; compare the measured rate with
 the rate the same kernel reaches on a homogeneous batch (every game = a copy of one median game)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import algames_jl_amd as alg

@@ -2,7 +2,7 @@
 the instructions between the ALGMARK comments.  usage: python tests/probes/isa_phases.py [model p d ext] [extra flags]"""
 import re, subprocess, sys, os, collections
 cfg = sys.argv[1:5] if len(sys.argv) > 4 else ["ALG_MODEL_DOUBLE_INTEGRATOR", "3", "2", "0"]
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.makedirs("/tmp/isa", exist_ok=True)
 src = "/tmp/isa/ph.hip"
 open(src, "w").write('#include "%s/algames.jl_amd/csrc/algames_kernels.hpp"\ntemplate __global__ void k_direction<Cfg<%s>>(Params, double, int*);\n' % (root, ", ".join(cfg)))

@@ -9,7 +9,7 @@ sigs = {
  "k_newton_step": "(Params, int, int, alg_step_info*)",
  "k_ibr": "(Params, int, int, int, uint64_t, int, IbrOrder, double)",
 }
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.makedirs("/tmp/isa", exist_ok=True)
 src = "/tmp/isa/one_%s.hip" % kern
 open(src, "w").write('#include "%s/algames.jl_amd/csrc/algames_kernels.hpp"\ntemplate __global__ void %s<Cfg<%s>>%s;\n' % (root, kern, ", ".join(cfg), sigs[kern]))

@@ -4,7 +4,7 @@ import re, subprocess, sys, os, collections
 kern = sys.argv[1] if len(sys.argv) > 1 else "k_direction"
 cfg = sys.argv[2:6] if len(sys.argv) > 5 else ["ALG_MODEL_DOUBLE_INTEGRATOR", "3", "2", "0"]
 sigs = {"k_newton_solve": "(Params, int, uint64_t)", "k_direction": "(Params, double, int*)"}
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = "/tmp/isa/lp_%s.hip" % kern
 os.makedirs("/tmp/isa", exist_ok=True)
 open(src, "w").write('#include "%s/algames.jl_amd/csrc/algames_kernels.hpp"\ntemplate __global__ void %s<Cfg<%s>>%s;\n' % (root, kern, ", ".join(cfg), sigs[kern]))

@@ -4,7 +4,7 @@ import csv, glob, json, os, shutil, sys, collections
 tag = sys.argv[1]
 cfg = sys.argv[2] if len(sys.argv) > 2 else "C2"
 kname = {"C2": "k_newton_solve<Cfg<DI,3,2,0>>", "C3": "k_newton_solve<Cfg<UNI,4,2,0>>", "C5": "k_newton_solve<Cfg<UNI,3,2,0>>"}[cfg]
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = os.path.join(root, "gpurun_out", tag)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 def counters(sub):

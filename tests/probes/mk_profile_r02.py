@@ -1,7 +1,7 @@
 """gpurun_out/<tag>/ (tests/probes/prof_r02.sh) -> profiles/<tag>_kernel_stats.csv + profiles/<tag>_pmc.json (read by bench.py)."""
 import csv, glob, json, os, shutil, sys, collections
 tag = sys.argv[1]
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = os.path.join(root, "gpurun_out", tag)
 shutil.copy(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().split("\n")[-1])

@@ -1,7 +1,7 @@
 """Per-phase cycle profile of the Newton-direction sweeps (library built with -DALG_PHASE_PROF: tests/probes/phase_prof.sh).
 usage: python tests/probes/phase_prof.py CONFIG GAMES"""
 import sys, os, ctypes
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, root)
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, root)
 import numpy as np
 import algames_jl_amd as alg
 cfg, G = sys.argv[1], int(sys.argv[2])

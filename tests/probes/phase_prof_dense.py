@@ -1,7 +1,7 @@
 """Per-phase cycle profile of newton_direction_dense (library built with -DALG_PHASE_PROF: tests/probes/phase_prof.sh build).
 usage: python tests/probes/phase_prof_dense.py P GAMES [NW]"""
 import sys, os, ctypes
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, root)
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, root)
 import numpy as np
 import algames_jl_amd as alg
 P, G = int(sys.argv[1]), int(sys.argv[2]); nw = int(sys.argv[3]) if len(sys.argv) > 3 else 1

@@ -1,6 +1,6 @@
 """Per-phase kernel timing of the stepwise API at a BASELINE config (run under rocprofv3 --kernel-trace --stats)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import algames_jl_amd as alg
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"

@@ -1,6 +1,6 @@
 """Cycle profile of the quad-team direction per role (library built with tests/probes/qt_prof.sh build). usage: qt_prof.py [games]"""
 import sys, os, ctypes
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, root)
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, root)
 import numpy as np
 import torch
 import algames_jl_amd as alg

@@ -2,7 +2,7 @@
 # Per-phase / per-role cycle profile of the quad-team Newton direction.  build (CPU container): bash tests/probes/qt_prof.sh build ;
 # on the GPU box: bash tests/probes/qt_prof.sh run [games]
 set -e
-R=$(cd $(dirname $0)/.. && pwd); D=$R/algames.jl_amd/lib/obj
+R=$(cd $(dirname $0)/../.. && pwd); D=$R/algames.jl_amd/lib/obj
 if [ "$1" = build ]; then
   FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-invalid-offsetof -mllvm -disable-machine-licm -DALG_PHASE_PROF"
   for f in algames_hip algames_qt; do /opt/rocm/bin/hipcc $FL -c $R/algames.jl_amd/csrc/$f.hip -o /tmp/qtprof_$f.o & done; wait

@@ -1,6 +1,6 @@
 """Step-wise timing of the quadrotor configurations: assemble pass (record!), assemble + Newton direction, one line-search call."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import algames_jl_amd as alg

@@ -172,3 +172,23 @@ def test_step_wise_history_grows_by_records(alg):
             n += 1
     h = prob.batch.get_history(3)
     assert len(h) == n == 177 and np.all(h["res"] > 0)
+
+
+@pytest.mark.gpu
+def test_jacobian_of_a_game_range_and_scratch_release(alg):
+    """alg_residual_jacobian_games builds the dense KKT Jacobians of a sub-range only (what the active-set inspection of ONE game of a
+    large batch needs); alg_release_scratch frees the inspection buffer and the next call allocates it again."""
+    prob = alg.scenarios.make_problem("C2", np.arange(12), N=8)
+    prob.batch.init_traj(game_id0=0); prob.batch.rollout(0)
+    full = alg.residual_jacobian(prob, 1e-4)
+    part = alg.residual_jacobian(prob, 1e-4, games=(5, 3))
+    assert part.shape == (3,) + full.shape[1:] and np.array_equal(part, full[5:8])
+    prob.batch.release_scratch(); prob.batch.release_scratch()
+    assert np.array_equal(alg.residual_jacobian(prob, 1e-4, games=(11, 1))[0], full[11])
+    with pytest.raises(alg.AlgamesError):
+        alg.residual_jacobian(prob, 1e-4, games=(11, 2))
+    from algames_jl_amd import active_set as A
+    core = A.ActiveSetCore(prob.probsize)
+    A.residual_jacobian(core, prob, game=7)
+    S = prob.probsize.S
+    assert np.array_equal(core.jac[:S, :S], alg.residual_jacobian(prob, 0.0, games=(7, 1))[0])

@@ -1716,8 +1716,9 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
 // Scratch instrumentation (-DALG_PHASE_PROF, tests/probes/phase_prof.sh): shader-clock cycles per phase of the sweeps, accumulated
 // into G.res(pr)[0..] (unused by the fused solver).  Never defined in the product build.
 #ifdef ALG_PHASE_PROF
-#define ALG_PROF_DECL unsigned long long prof_t_ = __builtin_readcyclecounter(), prof_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define ALG_PROF(j) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc_[j] += t_ - prof_t_; prof_t_ = t_; }
+// (32-bit differences: the upper half of the 64-bit counter read is not dependable across s_memtime reads on this part)
+#define ALG_PROF_DECL unsigned prof_t_ = (unsigned)__builtin_readcyclecounter(), prof_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ALG_PROF(j) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); const unsigned d_ = t_ - prof_t_; prof_acc_[j] += d_ < (1u << 28) ? d_ : 0u; prof_t_ = t_; }
 #define ALG_PROF_FLUSH if (game_tid() == 0) { for (int j_ = 0; j_ < 12; j_++) G.res(pr)[j_] += (double)prof_acc_[j_]; }
 #elif defined(ALG_ISA_MARK)
 // static accounting (tests/probes/isa_phases.py): the phase boundaries show up as comments in the -S output

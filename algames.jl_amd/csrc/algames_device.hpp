@@ -154,6 +154,12 @@ struct Cfg {
     static constexpr int WPE = (DENSE && n >= 24) ? 1 : (DENSE || n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3)) ? 2 : 4;
     // reuse the accepted line-search trial as the next record! (one assemble pass less per Newton iteration)
     static constexpr bool TRIAL_REUSE = true;
+    // forward / costate sweeps of the tile path: time steps whose record slice / gains / dx are in flight (register ring, loop unrolled by it)
+#ifndef ALG_SWEEP_DEPTH
+#define ALG_SWEEP_DEPTH 4
+#endif
+    // (measured, depth 1 / 2 / 4 / 8: C2 10.22 / 10.28 / 10.37 / 10.33 M/s, C3 2.38 / 2.43 / 2.43 / 2.44 M/s, C5 loop 154 / 158 / 157 / 156 K/s)
+    static constexpr int SWEEP_DEPTH = WPE == 4 ? ALG_SWEEP_DEPTH : (ALG_SWEEP_DEPTH < 2 ? ALG_SWEEP_DEPTH : 2);
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
     static constexpr int ASM_UNROLL = ALG_ASM_UNROLL;
 };
@@ -786,6 +792,23 @@ struct AsmLds {
 };
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 
+// Pass-level instrumentation of the solver (same build flag): shader-clock cycles of the axpy / assemble phases / Newton direction as
+// seen by thread 0 of the game, accumulated in LDS and flushed into G.res(pr)[16..] at the end of every newton_solve (slots:
+// 16 axpy + barrier, 17 trial assemble, 18 #trials, 20 phase A, 21 rows x, 22 rows u, 23 rows d, 24 reductions, 25 #passes,
+// 26 direction, 27 record pass, 28 #directions, 29 #record passes)
+#ifdef ALG_PHASE_PROF
+__device__ __forceinline__ unsigned* lsp_slots() { __shared__ unsigned slots[32]; return slots; }
+__device__ __forceinline__ unsigned lsp_now() { return (unsigned)__builtin_readcyclecounter(); }
+__device__ __forceinline__ void lsp_add(int slot, unsigned t0) { if (game_tid() == 0) { const unsigned d = lsp_now() - t0; lsp_slots()[slot] += d < (1u << 28) ? d : 0u; } }
+__device__ __forceinline__ void lsp_count(int slot) { if (game_tid() == 0) lsp_slots()[slot] += 1u; }
+#define LSP_T0 unsigned lsp_t0_ = lsp_now();
+#define LSP(slot) { lsp_add(slot, lsp_t0_); lsp_t0_ = lsp_now(); }
+#define LSP_COUNT(slot) lsp_count(slot);
+#else
+#define LSP_T0
+#define LSP(slot)
+#define LSP_COUNT(slot)
+#endif
 // ================================================================================================
 // Assemble pass: residual! + regularize_residual! + the scalars of record! (+ step records)
 //   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl.
@@ -835,6 +858,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
     const double dt = phase_f64(pr.dt);
     double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
+    LSP_T0 LSP_COUNT(25)
     // ---------------- phase A ------------------------------------------------------------------------------
     if constexpr (C::QUAD) {
         // quadrotor: work item = (knot k, player i, seed direction c of the player's 12 states + 4 rotor commands): column c of
@@ -1005,6 +1029,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
         }
         if constexpr (!AsmLds<C>::STAGED) game_sync();
     }
+    LSP(20)
     // ---------------- phase B ------------------------------------------------------------------------------
     // Every residual row of every step is independent once phase A has left the coefficients and the pair-gradient table:
     // three flat row loops (opt_x | opt_u | dyn), work item = one row, operands read straight from the trajectory (the
@@ -1102,6 +1127,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
         };
         run_rows(row_x, RXN, false);
     }
+    LSP(21)
     // ---- rows opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
     {
         auto row_u = [&](int k, int c, bool ok) -> Row {
@@ -1138,6 +1164,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
         };
         run_rows(row_u, m, false);
     }
+    LSP(22)
     // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint, RobotDynamics 0.3.1)
     {
         auto row_d = [&](int k, int a, bool ok) -> Row {
@@ -1176,11 +1203,13 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
         };
         run_rows(row_d, n, true);
     }
+    LSP(23)
     out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
     out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
     out.l1reg = (MODE == 3) ? wave_sum(l1r) : out.l1;
     out.l1full = IBR ? wave_sum(l1f) : out.l1;
     team_combine<C>(out);
+    LSP(24)
 }
 
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
@@ -2485,8 +2514,15 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
         for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = G.kgain(pr)[(size_t)kc * NK + (e < NK ? e : NK - 1)]; }
     };
-    double pref, prek[KPL];
-    fwd_load(1, pref, prek);
+    // Prefetch ring: the slices of steps k + 1 .. k + SD are in flight in registers while step k computes.  With four games per
+    // SIMD all streaming, a fetch takes about two microseconds -- longer than a step of this sweep -- so with one step in flight
+    // (rounds 1-2) the sweep ran at memory latency: 4.7 K cycles per step at 4096 games against 1.0 K for a lone wavefront
+    // (tests/probes/phase_prof.py).  The loop is unrolled by SD so that every ring slot is a fixed register (a rotating copy
+    // would read the newest load and wait for it).
+    constexpr int SD = C::SWEEP_DEPTH;
+    double pref[SD], prek[SD][KPL];
+#pragma unroll
+    for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
     sweep_sync<C>();
     cur = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
@@ -2494,7 +2530,12 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     // dx_k lives one entry per lane (lanes 0..n-1) and is broadcast with v_readlane; du and dx_{k+1} never pass through LDS:
     // one LDS round trip (gain rows, record slice) per step instead of three.
     double dxr = 0.0;
-    for (int k = 0; k < N - 1; k++, cur ^= 1) {
+    for (int k0 = 0; k0 < N - 1; k0 += SD) {
+#pragma unroll
+      for (int u = 0; u < SD; u++) {
+        const int k = k0 + u;
+        if (k >= N - 1) break;
+        constexpr int 	slot_dummy = 0; (void)slot_dummy;
         const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
         const int cl = lane < m ? lane : 0;
         double acc = Kl[n * m + cl];
@@ -2507,23 +2548,24 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         if (lane < m) { pl1 += fabs(duv); bad |= !isfinite(duv); }
         if (lane < n) { pl1 += fabs(dxn); bad |= !isfinite(dxn); }
         dxr = dxn;
-        // (1) data of step k+1 -> LDS (clamped duplicates at the last step are never read)
-        L.rec[cur ^ 1][froc] = pref;
+        // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
+        L.rec[cur ^ 1][froc] = pref[(u + 1) % SD];
 #pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[q]; }
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
         asm volatile("" ::: "memory");
         // (2) results out
         if (lane < m) dz[n + hu<C>(k, 0) + uoff<C>(lane)] = duv;
         if (lane < n) dz[n + hx<C>(k) + lane] = dxn;
-        // (3) request step k+2
-        fwd_load(k + 2, pref, prek);
+        // (3) request step k+1+SD into the slot that was just emptied
+        fwd_load(k + 1 + SD, pref[(u + 1) % SD], prek[(u + 1) % SD]);
         sweep_sync<C>();
+        cur ^= 1;
+      }
     }
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
     return ALG_STATUS_OK;
 #endif
     ALG_PROF(7)
-    constexpr int PFD = (C::WPE == 2 && C::MODEL != ALG_MODEL_BICYCLE) ? 2 : 1;
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
     hxm.init(phase_lane());
@@ -2535,26 +2577,27 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
     const bool cpos = C::POS && cr_ < C::PD * P;
     double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
+    // unconditional loads from clamped addresses (a conditional load into a zeroed register costs a vmcnt drain, see the forward sweep)
+    const int cdxo = lane < n ? lane : 0;
     auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
-        rdx = 0.0;
+        const int kc = kk > 0 ? kk : 0;
 #pragma unroll
-        for (int q = 0; q < RPLC; q++) rr[q] = 0.0;
-        if (kk >= 0) {
-#pragma unroll
-            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) rr[q] = G.rec(pr)[(size_t)kk * R::LEN + e]; }
-            if (lane < n) rdx = dz[n + hx<C>(kk) + lane];
-        }
+        for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; rr[q] = G.rec(pr)[(size_t)kc * R::LEN + (e < R::LEN_COSTATE ? e : R::LEN_COSTATE - 1)]; }
+        rdx = dz[n + hx<C>(kc) + cdxo];
     };
-    double pre[RPLC], pdx = 0.0;
-    if constexpr (PFD == 2) cs_load(N - 3, pdx, pre);
+    // register ring like the forward sweep's: [record slice | dx] of steps k - 1 .. k - SD are in flight while step k computes
+    double pre[SD][RPLC], pdx[SD];
+#pragma unroll
+    for (int u = 0; u < SD; u++) cs_load(N - 3 - u, pdx[(1 + u) % SD], pre[(1 + u) % SD]);
     sweep_sync<C>();
     cur = 0;
-    for (int k = N - 2; k >= 0; k--, cur ^= 1) {
+    for (int k0 = N - 2; k0 >= 0; k0 -= SD) {
+#pragma unroll
+      for (int u = 0; u < SD; u++) {
+        const int k = k0 - u;
+        if (k < 0) break;
         const double* Rc = L.rec[cur];
         if (lane < n) L.fw.dx[lane] = dxk;
-        double nx[RPLC], ndx = 0.0;
-        if constexpr (PFD == 2) cs_load(k - 2, ndx, nx);
-        else cs_load(k - 1, pdx, pre);
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         hxm.expand(lane, Rc, L.fw.hx);
         sweep_sync<C>();
@@ -2574,17 +2617,16 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         sweep_sync<C>();
         if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; bad |= !isfinite(acc); }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
-        dxk = pdx;
+        // land step k - 1 (requested SD steps ago), then request step k - 1 - SD into the emptied slot
+        dxk = lane < n ? pdx[(u + 1) % SD] : 0.0;
         if (k > 0) {
 #pragma unroll
-            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) L.rec[cur ^ 1][e] = pre[q]; }
+            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) L.rec[cur ^ 1][e] = pre[(u + 1) % SD][q]; }
         }
-        if constexpr (PFD == 2) {
-            pdx = ndx;
-#pragma unroll
-            for (int q = 0; q < RPLC; q++) pre[q] = nx[q];
-        }
+        cs_load(k - 1 - SD, pdx[(u + 1) % SD], pre[(u + 1) % SD]);
         sweep_sync<C>();
+        cur ^= 1;
+      }
     }
     ALG_PROF(8)
     ALG_PROF_FLUSH
@@ -2693,8 +2735,10 @@ __device__ __forceinline__ RecScalars push_stats(CPR pr0, const Game& G0, const 
 template <class C>
 __device__ __forceinline__ RecScalars make_record(CPR pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
     ResOut ro;
+    LSP_T0 LSP_COUNT(29)
     assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, jreg, ro);
     game_sync();
+    LSP(27)
     return push_stats(pr, G, ro, delta, outer, out);
 }
 
@@ -2706,14 +2750,17 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
     int j = 1; double alpha = 1.0;
     while (j < pr.opt.ls_iter) {
         const auto& o = phase_params(pr).opt;
+        LSP_T0 LSP_COUNT(18)
         update_traj<C>(pr, G, 1, 0, alpha);
         game_sync();
+        LSP(16)
         ResOut ro;
         bool done = false;
         if constexpr (C::TRIAL_REUSE) {
             if (jreg_next >= 0.0 && o.regularize) { assemble_pass<C, 3>(pr, G, L.a, 1, 0, reg, jreg_next, ro); done = true; }
         }
         if (!done) assemble_pass<C, 0>(pr, G, L.a, 1, o.regularize ? 0 : -1, reg, 0.0, ro);
+        LSP(17)
         if (jreg_next >= 0.0) tcache_store(pr, G, ro);
         const double rt = uni(ro.l1reg / (double)phase_int(phase_params(pr).S));
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
@@ -2746,6 +2793,7 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     if (rs.nonfinite) return finish(ALG_STATUS_NAN, 1);
     if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1) | (1 << 16);  // :80-82 (bit 16: pdtraj untouched since this record!)
     double pl1; int st;
+    LSP_T0 LSP_COUNT(28)
     if constexpr (C::GW > 1) st = qt_direction_call<C>(pr, L, 1, reg, &pl1);               // collective of the workgroup's four games
     else if constexpr (C::NW == 1) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);    // :84-88
     else {
@@ -2758,6 +2806,7 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
         game_sync();
         st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1 = uni(dir_out[1]);
     }
+    LSP(26)
     if (st != ALG_STATUS_OK) return finish(st, 1);
     game_sync();
     double alpha; int j;
@@ -2956,7 +3005,8 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     const auto& o = pr.opt; const int lane = phase_lane();
     if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; G.fresh().tc(phase_params(pr))[TC_TELAP] = 0.0; } // reset!(prob.stats); t_elap = 0
 #ifdef ALG_PHASE_PROF
-    if (lane < 48) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums
+    if (lane < 16) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums (16..: pass-level sums over the handle's lifetime)
+    if (game_tid() < 32) lsp_slots()[game_tid()] = 0u;
 #endif
 #ifndef ALG_TEST_NOINIT
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
@@ -3010,6 +3060,11 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     } else make_record<C>(pr, G, L, Delta, out, 0.0, nullptr);
     settle_traj<C>(pr, G);
     if (phase_lane() == 0) { alg_game_stats* st = G.fresh().st(phase_params(pr)); st->status = status; st->outer_iters = out; }
+#ifdef ALG_PHASE_PROF
+    game_sync();
+    if (game_tid() >= 16 && game_tid() < 32) G.fresh().res(phase_params(pr))[game_tid()] += (double)lsp_slots()[game_tid()];
+    game_sync();
+#endif
 }
 
 // ================================================================================================

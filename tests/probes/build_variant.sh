@@ -11,5 +11,5 @@ for f in algames_hip algames_ext_di algames_ext_uni algames_ext_bic algames_ext_
   /opt/rocm/bin/hipcc $FL -c $C/$f.hip -o $O/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/algames.jl_amd/lib/variants/$NAME.so $O/*.o $D/algames_quad.hip.o $D/algames_quad_ext.hip.o $D/algames_di3.hip.o $D/algames_mw_dense.hip.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/algames.jl_amd/lib/variants/$NAME.so $O/*.o $D/algames_quad.hip.o $D/algames_quad_ext.hip.o $D/algames_di3.hip.o $D/algames_mw_dense.hip.o $D/algames_p5.hip.o $D/algames_p6.hip.o
 echo built $R/algames.jl_amd/lib/variants/$NAME.so

@@ -29,3 +29,23 @@ for cfg, B, spread in (("C2", 4096, 0.0), ("C2", 4096, 0.3), ("C2", 4096, 0.6), 
           % (cfg, B, it.min(), np.median(it), it.mean(), it.max(), dt * 1e3, it.sum() / dt, it.mean() / it.max()))
     hist = np.bincount(it)
     print("   histogram (iters:count)", {int(k): int(v) for k, v in enumerate(hist) if v})
+# ---- what removes the tail: more games than resident slots (the dispatcher backfills), or a second batch in flight on another stream
+print("batch-size sweep, C2 +-0.3:")
+def spread_problem(B, seed0=0):
+    prob = alg.scenarios.make_problem("C2", np.arange(seed0, seed0 + B)); prob.batch.set_waves_per_game(1)
+    rng = np.random.default_rng(5 + seed0); x0 = prob.x0.copy(); npos = 2 * prob.model.p
+    x0[:, :npos] += rng.uniform(-0.3, 0.3, (B, npos)); prob.batch.set_x0(x0)
+    return prob
+for B in (4096, 8192, 16384, 32768):
+    prob = spread_problem(B); it, dt = rate(prob, reps=3)
+    print("  %6d games in one launch: mean %.1f max %d iterations | %.2f ms | %.3g game-iterations/s" % (B, it.mean(), it.max(), dt * 1e3, it.sum() / dt))
+for K in (2, 4):
+    probs = [spread_problem(4096, seed0=4096 * q) for q in range(K)]
+    for p_ in probs: p_._sync_options()
+    def go():
+        for p_ in probs: p_.batch.newton_solve_async(init=True, game_id0=p_.game_id0)
+        for p_ in probs: p_.batch.synchronize()
+    go(); go()
+    t0 = time.perf_counter(); go(); go(); go(); dt = (time.perf_counter() - t0) / 3
+    its = sum(int(p_.batch.get_stats()["newton_iters"].sum()) for p_ in probs)
+    print("  %d handles x 4096 games on their own streams, launched together: %.2f ms | %.3g game-iterations/s" % (K, dt * 1e3, its / dt))

@@ -110,6 +110,7 @@ SIGNATURES = {
     "residual_jacobian": (C.c_int, [_P, C.c_double, _D]),
     "residual_jacobian_games": (C.c_int, [_P, C.c_double, C.c_int32, C.c_int32, _D]),
     "release_scratch": (C.c_int, [_P]),
+    "get_violation_profile": (C.c_int, [_P, _D, _D, _D, _D]),
     "newton_direction": (C.c_int, [_P, C.c_double, _D, _I]),
     "line_search": (C.c_int, [_P, C.c_double, _D, _D, _I]),
     "update_traj": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
@@ -380,6 +381,12 @@ class Batch:
 
     def release_scratch(self):
         self.lib.check(self.lib.release_scratch(self.h))
+
+    def violation_profile(self):
+        """Per-knot .vio vectors at pdtraj: dict(dyn (B, N-1), con (B, N-1), sta (B, N), opt (B, N))."""
+        out = dict(dyn=np.empty((self.B, self.N - 1)), con=np.empty((self.B, self.N - 1)), sta=np.empty((self.B, self.N)), opt=np.empty((self.B, self.N)))
+        self.lib.check(self.lib.get_violation_profile(self.h, _dptr(out["dyn"]), _dptr(out["con"]), _dptr(out["sta"]), _dptr(out["opt"])))
+        return out
 
     def newton_direction(self, reg=0.0):
         delta = np.empty((self.B, self.S)); st = np.empty(self.B, dtype=np.int32)

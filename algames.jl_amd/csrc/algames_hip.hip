@@ -373,6 +373,45 @@ int sync(Handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); return ALG_OK; }
 
 } // namespace
 
+// Per-knot violation profiles at pdtraj (violations.jl:5-26, 41-67, 86-110, 140-170): the .vio vectors of dynamics_violation,
+// control_violation, state_violation, optimality_violation, from the residual vector (vertical order) and the constraint values a
+// MODE-2 assemble pass (k_residual) has just left in the game's arena.  One wavefront per game, lane = knot; out: [dyn (N-1) | con (N-1) |
+// sta (N) | opt (N)] per game.  Model-independent: only the problem sizes enter.
+__global__ void __launch_bounds__(WAVE) k_vio_profile(Params pr_arg, double* out) {
+    CPR pr = kernel_params();
+    const int g = blockIdx.x, N = pr.N, n = pr.n, m = pr.m, P = pr.p, mi = pr.mi, K = N - 1;
+    Game G = game_view(pr, g);
+    const double* res = G.res(pr); const double* vals = G.vals(pr);
+    double* o = out + (size_t)g * (4 * N - 2);
+    auto pos = [](double c) { return (isfinite(c) && c > 0.0) ? c : 0.0; };
+    for (int j = threadIdx.x; j < N; j += WAVE) {
+        double vopt = 0.0, vsta = 0.0;
+        if (j < K) {
+            double vdyn = 0.0, vcon = 0.0;
+            for (int a = 0; a < n; a++) vdyn = fmax(vdyn, fabs(res[P * K * (n + mi) + j * n + a]));
+            if (pr.has_ctl) for (int r = 0; r < 2 * m; r++) vcon = fmax(vcon, pos(vals[pr.col_len + j * 2 * m + r]));
+            o[j] = vdyn; o[K + j] = vcon;
+            for (int i = 0; i < P; i++) for (int c = 0; c < mi; c++) vopt = fmax(vopt, fabs(res[i * K * (n + mi) + j * (n + mi) + n + c]));      // opt_i,u_{i,k}, knot j + 1
+        }
+        if (j >= 1) {
+            const int k = j - 1;                                                                                                             // step whose x_{k+1} is knot j + 1
+            for (int i = 0; i < P; i++) for (int a = 0; a < n; a++) vopt = fmax(vopt, fabs(res[i * K * (n + mi) + k * (n + mi) + a]));     // opt_i,x, knot j + 1
+            if (pr.has_colavoid) for (int q = 0; q < P * (P - 1); q++) vsta = fmax(vsta, pos(vals[q * K + k]));
+            int e0 = pr.col_len + pr.ctl_len;
+            if (pr.sb_len)   { for (int i = 0; i < P; i++) for (int r = 0; r < 2 * n; r++) vsta = fmax(vsta, pos(vals[e0 + (i * K + k) * 2 * n + r])); }
+            e0 += pr.sb_len;
+            if (pr.wall_len) { for (int i = 0; i < P; i++) for (int w = 0; w < pr.nwall; w++) vsta = fmax(vsta, pos(vals[e0 + (i * K + k) * pr.nwall + w])); }
+            e0 += pr.wall_len;
+            if (pr.circ_len) { for (int i = 0; i < P; i++) for (int w = 0; w < pr.ncirc; w++) vsta = fmax(vsta, pos(vals[e0 + (i * K + k) * pr.ncirc + w])); }
+            e0 += pr.circ_len;
+            if (pr.wall3_len) { for (int i = 0; i < P; i++) for (int w = 0; w < pr.nwall3; w++) vsta = fmax(vsta, pos(vals[e0 + (i * K + k) * pr.nwall3 + w])); }
+            e0 += pr.wall3_len;
+            if (pr.cyl_len)  { for (int i = 0; i < P; i++) for (int w = 0; w < pr.ncyl; w++) vsta = fmax(vsta, pos(vals[e0 + (i * K + k) * pr.ncyl + w])); }
+        }
+        o[2 * K + j] = vsta; o[2 * K + N + j] = vopt;
+    }
+}
+
 #define NEED_HANDLE(name) do { if (!h) return fail(ALG_ERR_ARG, name ": null handle"); } while (0)
 
 extern "C" {
@@ -782,6 +821,22 @@ int alg_release_scratch(alg_handle* h) {
     dfree(H, H->d_scratch);
     H->d_scratch = nullptr; H->scratch_bytes = 0;
     return ALG_OK;
+}
+int alg_get_violation_profile(alg_handle* h, double* dyn, double* con, double* sta, double* opt) {
+    NEED_HANDLE("alg_get_violation_profile");
+    int rc = use_device(H); if (rc) return rc;
+    const Params& p = H->pr;
+    const size_t per = (size_t)(4 * p.N - 2), bytes = sizeof(double) * per * p.B;
+    if ((rc = ensure_scratch(H, bytes))) return rc;
+    LAUNCH(k_residual, H->pr, 0, 0.0, H->d_tmp);                 // residual vector + constraint values at pdtraj into the arena
+    hipLaunchKernelGGL(k_vio_profile, dim3(p.B), dim3(WAVE), 0, H->stream, H->pr, (double*)H->d_scratch);
+    if ((rc = launch_check("k_vio_profile"))) return rc;
+    const double* d = (const double*)H->d_scratch; const int K = p.N - 1;
+    if (dyn && (rc = d2h_seg(H, dyn, d, per, sizeof(double) * K))) return rc;
+    if (con && (rc = d2h_seg(H, con, d + K, per, sizeof(double) * K))) return rc;
+    if (sta && (rc = d2h_seg(H, sta, d + 2 * K, per, sizeof(double) * p.N))) return rc;
+    if (opt && (rc = d2h_seg(H, opt, d + 2 * K + p.N, per, sizeof(double) * p.N))) return rc;
+    return sync(H);
 }
 
 int alg_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status) {

@@ -724,6 +724,14 @@ def line_search(prob, res_norm, reg=0.0):
     return prob.batch.line_search(res_norm, reg)
 
 
+def violation_profile(prob):
+    """The `.vio` vectors of dynamics_violation / control_violation / state_violation / optimality_violation at pdtraj
+    (violations.jl:5-26, 41-67, 86-114, 140-168): dict(dyn (B, N-1), con (B, N-1), sta (B, N), opt (B, N)); their maxima over the knots
+    are the `*_vio` entries record! stores."""
+    prob._sync_options()
+    return prob.batch.violation_profile()
+
+
 def dynamics_violation(prob):
     return prob.batch.record()["dyn_vio"]
 

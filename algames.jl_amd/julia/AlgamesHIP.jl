@@ -292,9 +292,12 @@ function pull_results!(bp::BatchedGameProblem, stats::Vector{AlgGameStats})
         end
     end
     # prob.stats: one record! per stored record (statistics.jl:30-57); the violation objects carry the recorded maxima (what the
-    # solver's exit test and the plot recipes read, solver_plots.jl:83-125); per-knot profiles are recomputed for the final record
+    # solver's exit test and the plot recipes read, solver_plots.jl:83-125); the final record also gets its per-knot profiles
     cap = max(Int(maximum(s.records for s in stats)), 1)
     rec = Vector{AlgRecord}(undef, cap); cnt = Ref{Int32}(0)
+    # the .vio vectors of the four violation objects at the final iterate (violations.jl), all games in one call
+    vdyn = zeros(N - 1, B); vcon = zeros(N - 1, B); vsta = zeros(N, B); vopt = zeros(N, B)
+    check(ccall((:alg_get_violation_profile, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), bp.h, vdyn, vcon, vsta, vopt))
     for (g, pr) in enumerate(bp.probs)
         check(ccall((:alg_get_history, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{AlgRecord}, Ref{Int32}), bp.h, g - 1, cap, rec, cnt))
         cnt[] < stats[g].records && @warn "AlgamesHIP: Statistics history truncated" game = g kept = cnt[] records = stats[g].records
@@ -307,12 +310,9 @@ function pull_results!(bp::BatchedGameProblem, stats::Vector{AlgGameStats})
             ov = Algames.OptimalityViolation(N); ov.max = r.opt_vio
             Algames.record!(pr.stats, r.t_elap, r.res, r.delta, dv, cvv, sv, ov, Int(r.outer))      # t_elap: device real-time counter
         end
-        if cnt[] > 0                                                # final record (solver_methods.jl:63): full per-knot profiles
-            Algames.residual!(pr, pr.pdtraj)
-            pr.stats.dyn_vio[end] = Algames.dynamics_violation(pr.model, pr.pdtraj)
-            pr.stats.con_vio[end] = Algames.control_violation(pr.game_con, pr.pdtraj)
-            pr.stats.sta_vio[end] = Algames.state_violation(pr.game_con, pr.pdtraj)
-            pr.stats.opt_vio[end] = Algames.optimality_violation(pr.core)
+        if cnt[] > 0                                                # final record (solver_methods.jl:63): per-knot profiles from the device
+            pr.stats.dyn_vio[end].vio .= view(vdyn, :, g); pr.stats.con_vio[end].vio .= view(vcon, :, g)
+            pr.stats.sta_vio[end].vio .= view(vsta, :, g); pr.stats.opt_vio[end].vio .= view(vopt, :, g)
         end
     end
     return stats

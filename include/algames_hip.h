@@ -269,6 +269,11 @@ int alg_residual_jacobian_games(alg_handle* h, double reg, int32_t first_game, i
 /* Frees the device scratch the inspection entry points (dense Jacobians, MPC state logs) grow on demand.  The solver never
  * uses that buffer; the next inspection call allocates it again. */
 int alg_release_scratch(alg_handle* h);
+/* Per-knot violation profiles at pdtraj: the .vio vectors the reference's violation objects carry next to .max
+ * (violations.jl:5-26 dynamics, :41-67 control, :86-114 state, :140-168 optimality).  dyn, con: B x (N-1) (steps 1..N-1);
+ * sta, opt: B x N (knots 1..N; sta[0] is 0: no state constraint acts on x_1).  Any pointer may be NULL.  Evaluated on the device
+ * from the residual and the constraint values at the current pdtraj (one assemble pass + one reduction kernel). */
+int alg_get_violation_profile(alg_handle* h, double* dyn, double* con, double* sta, double* opt);
 /* Δtraj = -lu(jac) \ res ; set_traj!(Δpdtraj, Δtraj) (solver_methods.jl:87-88).  delta: B x S or NULL. */
 int alg_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status /*B or NULL*/);
 /* line_search (solver_methods.jl:105-125) on the stored Δpdtraj. */

@@ -1416,6 +1416,42 @@ int orc_residual_jacobian_games(alg_handle* h, double reg, int32_t first_game, i
 }
 int orc_residual_jacobian(alg_handle* h, double reg, double* jac) { return orc_residual_jacobian_games(h, reg, 0, (int)H->g.size(), jac); }
 int orc_release_scratch(alg_handle*) { return ALG_OK; }
+// Per-knot violation profiles at pdtraj: the .vio vectors of dynamics_violation (violations.jl:18-26), control_violation (:57-67),
+// state_violation (:101-114) and optimality_violation (:153-168).  dyn, con: B x (N-1); sta, opt: B x N (knot 1 first).
+int orc_get_violation_profile(alg_handle* h, double* dyn, double* con, double* sta, double* opt) {
+    const Shared& sh = H->sh; const Dims& D = sh.D; const int N = D.N, K = N - 1;
+    for (size_t gi = 0; gi < H->g.size(); gi++) {
+        Game& g = H->g[gi];
+        residual(sh, g, g.z[0], 0.0, nullptr);
+        auto pos = [](real c) { return (r_isfinite(c) && c > 0.0) ? c : (real)0.0; };
+        for (int j = 0; j < N; j++) {
+            real vo = 0, vs = 0;
+            if (j < K) {
+                real vd = 0, vc = 0;
+                for (int a = 0; a < D.n; a++) vd = std::max<real>(vd, r_fabs(g.res[D.vd(j) + a]));
+                if (sh.has_ctl) for (int r = 0; r < 2 * D.m; r++) vc = std::max<real>(vc, pos(g.vals[con_ctl(D, j, r)]));
+                if (dyn) dyn[gi * K + j] = (double)vd;
+                if (con) con[gi * K + j] = (double)vc;
+                for (int i = 0; i < D.p; i++) for (int c = 0; c < D.mi; c++) vo = std::max<real>(vo, r_fabs(g.res[D.vu(i, j) + c]));
+            }
+            if (j >= 1) {
+                const int k = j - 1;
+                for (int i = 0; i < D.p; i++) for (int a = 0; a < D.n; a++) vo = std::max<real>(vo, r_fabs(g.res[D.vx(i, k) + a]));
+                if (sh.has_colavoid) for (int q = 0; q < D.npair; q++) vs = std::max<real>(vs, pos(g.vals[con_col(D, q, k + 1)]));
+                for (int i = 0; i < D.p; i++) {
+                    if (D.has_sb) for (int r = 0; r < 2 * D.n; r++) vs = std::max<real>(vs, pos(g.vals[D.o_sb(i, k + 1, r)]));
+                    for (int w = 0; w < D.nwall; w++) vs = std::max<real>(vs, pos(g.vals[D.o_wall(i, k + 1, w)]));
+                    for (int c = 0; c < D.ncirc; c++) vs = std::max<real>(vs, pos(g.vals[D.o_circ(i, k + 1, c)]));
+                    for (int w = 0; w < D.nwall3; w++) vs = std::max<real>(vs, pos(g.vals[D.o_wall3(i, k + 1, w)]));
+                    for (int c = 0; c < D.ncyl; c++) vs = std::max<real>(vs, pos(g.vals[D.o_cyl(i, k + 1, c)]));
+                }
+            }
+            if (sta) sta[gi * N + j] = (double)vs;
+            if (opt) opt[gi * N + j] = (double)vo;
+        }
+    }
+    return ALG_OK;
+}
 int orc_newton_direction(alg_handle* h, double reg, double* delta, int32_t* status) {
     const int B = (int)H->g.size(), S = H->sh.D.S, n = H->sh.D.n;
 #pragma omp parallel for schedule(dynamic)

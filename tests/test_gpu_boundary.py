@@ -69,6 +69,12 @@ def test_shim_call_sequence_and_write_back(alg, orc):
     lam2, mu2 = bg.get_con_duals()
     assert np.array_equal(mu2, np.minimum(10.0 * mu, 1e7))     # penalty_update!: mu <- min(phi mu, mu_max)
     assert np.allclose(lam2, np.clip(lam + mu * vals, 0.0, 1e7), rtol=1e-13, atol=0)    # dual_update! with alpha = 1
+    # the final record's per-knot profiles (read_back!: alg_get_violation_profile, before the histories): their maxima are that record's
+    vg, vo = bg.violation_profile(), bo.violation_profile()
+    for f in ("dyn", "con", "sta"):                              # (the HIP handle's multipliers moved in the dual update above: its optimality rows are no longer the record's)
+        assert np.abs(vg[f] - vo[f]).max() <= 1e-9 * (1 + np.abs(vo[f]).max()), f
+        assert np.allclose(vg[f].max(axis=1), sg["last"][f + "_vio"], rtol=1e-12, atol=0), f
+    assert vg["opt"].shape == vo["opt"].shape == (B, bg.N)
     # prob.stats from alg_get_history (record! per stored record, statistics.jl:30-57)
     for g in range(B):
         hg, ho = bg.get_history(g, int(sg["records"][g])), bo.get_history(g, int(so["records"][g]))

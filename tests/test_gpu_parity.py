@@ -547,3 +547,33 @@ def test_pair_collision_avoidance_parity(alg, orc, case):
     for f in ("status", "outer_iters", "newton_iters", "ls_failures", "converged"):
         assert np.array_equal(sg[f], so[f]), f
     assert np.abs(g.get_traj() - o.get_traj()).max() <= 1e-7
+
+
+@pytest.mark.parametrize("model,p,N,ext", [(0, 3, 12, False), (1, 4, 9, False), (1, 3, 8, True), (2, 2, 7, True)])
+def test_violation_profile_parity(alg, orc, model, p, N, ext):
+    """alg_get_violation_profile (the .vio vectors of violations.jl) after a short solve: HIP path vs oracle, and the maxima over the
+    knots equal the record's *_vio on the same backend."""
+    B = 3
+    g = alg.Batch(alg.hip_lib(), model, p, N, 0.1, B); o = orc.OracleBatch(model, p, N, 0.1, B)
+    rng = np.random.default_rng(31)
+    ni = g.n // p
+    Q, R = 1 + rng.random((B, p, ni)), 0.5 + rng.random((B, p, g.mi)); xf, uf = rng.random((B, p, ni)), rng.random((B, p, g.mi)) - 0.5
+    x0 = rng.random((B, g.n))
+    for b in (g, o):
+        b.set_x0(x0); b.set_lqr(Q, R, xf, uf); b.set_options(outer_iter=2, inner_iter=3)
+        if p > 1:
+            b.add_collision_avoidance(0.3 + 0.1 * np.arange(p))
+        umax = np.full(b.m, 0.3); umax[0] = np.inf
+        b.add_control_bound(umax, np.full(b.m, -0.2))
+        if ext:
+            xmax = np.full(b.n, np.inf); xmin = np.full(b.n, -np.inf); xmax[::3] = 0.6
+            b.add_state_bound(0, xmax, xmin)
+            b.add_wall_constraint([0.0], [0.5], [1.0], [0.5], [0.0], [1.0]); b.add_circle_constraint([0.5], [0.5], [0.3])
+        b.newton_solve(init=True, game_id0=5)
+    vg, vo = g.violation_profile(), o.violation_profile()
+    rg = g.record()
+    for f in ("dyn", "con", "sta", "opt"):
+        assert vg[f].shape == vo[f].shape
+        assert np.abs(vg[f] - vo[f]).max() <= 1e-9 * (1 + np.abs(vo[f]).max()), f
+        assert np.array_equal(vg[f].max(axis=1), rg[f + "_vio"]), f
+    assert np.all(vg["sta"][:, 0] == 0.0)

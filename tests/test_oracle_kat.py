@@ -1333,3 +1333,31 @@ def test_arbiter_builds(alg, orc):
         p_.batch.set_traj(zz); r[k] = p_.batch.residual(0, 1e-3)[0]
     assert np.abs(r["x"] - r["q"]).max() <= 4e-16 * (1 + np.abs(r["q"]).max())
     assert 0 < np.abs(r[""] - r["q"]).max() <= 1e-12 * (1 + np.abs(r["q"]).max())
+
+
+def test_violation_profiles(alg, orc):
+    """The .vio vectors of the four violation objects (violations.jl:5-26, 41-67, 86-114, 140-168) through orc_get_violation_profile:
+    shapes (N-1, N-1, N, N), no state violation at knot 1, the maxima over the knots are what record! stores as *_vio, the
+    dynamics profile of a rolled-out trajectory is zero, and a knot moved by hand shows up in exactly the two dynamics steps
+    around it and in the state profile of its own knot."""
+    import oracle as orcmod
+    p, N, B = 3, 9, 2
+    rng = np.random.default_rng(9)
+    b = orcmod.OracleBatch(1, p, N, 0.1, B)                       # Unicycle
+    b.set_x0(rng.random((B, 4 * p))); b.set_lqr(1 + rng.random((B, p, 4)), 0.5 + rng.random((B, p, 2)), rng.random((B, p, 4)), np.zeros((B, p, 2)))
+    b.add_collision_avoidance(np.full(p, 0.8)); b.add_control_bound(np.full(2 * p, -0.01), np.full(2 * p, -0.5))       # upper bound below the initial controls: violated
+    b.init_traj(game_id0=3); b.rollout()
+    v = b.violation_profile()
+    assert v["dyn"].shape == (B, N - 1) and v["con"].shape == (B, N - 1) and v["sta"].shape == (B, N) and v["opt"].shape == (B, N)
+    assert np.abs(v["dyn"]).max() <= 1e-14 and np.all(v["sta"][:, 0] == 0.0)
+    rec = b.record()
+    for f in ("dyn", "con", "sta", "opt"):
+        assert np.array_equal(v[f].max(axis=1), rec[f + "_vio"]), f
+    assert v["con"].max() > 0 and v["sta"].max() > 0 and v["opt"].max() > 0
+    # move the state of knot 5 (1-based) of game 0: dynamics steps 4 and 5 (1-based) see it, the others do not
+    z = b.get_traj(); X, U, L = b.split_traj(z); X = X.copy(); X[0, 4, :] += 0.25
+    b.set_traj(b.join_traj(X, U, L))
+    w = b.violation_profile()
+    changed = np.nonzero(w["dyn"][0] > 1e-12)[0]
+    assert list(changed) == [3, 4] and np.abs(w["dyn"][1]).max() <= 1e-14
+    assert np.array_equal(w["sta"][0, np.arange(N) != 4], v["sta"][0, np.arange(N) != 4])

@@ -240,6 +240,7 @@ template <class C> __device__ __forceinline__ void sweep_sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     } else dir_sync<C>();
 }
+template <class C> __device__ __forceinline__ void rotate_priority(int it);
 template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(game_tid() >> 6)); }
 
 // ---- counter RNG shared bit-for-bit with the oracle ------------------------------
@@ -2769,6 +2770,19 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
     *alpha_out = alpha; *j_out = j;
 }
 
+// Issue priority of a one-wavefront game.  The SIMD's arbiter serves its wavefronts oldest first: of the four games that share a SIMD at
+// the BASELINE batch the first-dispatched one finishes after 3.7 ms and the last after 4.7 ms (tests/probes/finish_times.py), and the
+// SIMD runs its last millisecond with three, two, one wavefront.  s_setprio overrides the age order completely (a static priority
+// by dispatch round reverses the finishing order exactly), so every inner iteration rotates the priority by one: each game spends
+// a quarter of its iterations at each level and the four finish together (mean / max of the per-game durations 0.87 -> 0.96; C2
+// 10.2 -> 10.7 M/s, C4 10.6 -> 11.1 M/s in A/B runs; rotating every second iteration, every time step of the backward sweep, or twice per
+// iteration all measured worse than once per inner iteration).  Dispatch round = blockIdx / (number of SIMDs: 256 CUs x 4).
+template <class C> __device__ __forceinline__ void rotate_priority(int it) {
+    if constexpr (C::NW == 1 && C::GW == 1) {
+        const int q = ((int)(blockIdx.x >> 10) + it) & 3;
+        if (q == 0) __builtin_amdgcn_s_setprio(0); else if (q == 1) __builtin_amdgcn_s_setprio(1); else if (q == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+    }
+}
 // quad-team Newton direction of one game (algames_qt.hpp; only instantiated for Cfg::GW > 1)
 template <class C> __device__ int qt_direction_call(CPR pr, Lds<C>& mine, int want, double reg, double* primal_l1);
 // inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
@@ -2783,6 +2797,7 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     const double lf = (double)l;
     const double reg = o.reg_0 * (lf * lf * lf * lf);                      // :39  reg_0 * l^4
     if (info && lane0) { alg_step_info z{}; *info = z; }
+    rotate_priority<C>(k + l);
     iter_clock_start(pr, G_);                    // @elapsed begins (solver_methods.jl:40); record! below still reads the previous t_elap
     RecScalars rs;                                                         // :73-76 (regularisation term is zero at pdtraj)
     if (cache_valid && *cache_valid) { ResOut cro; tcache_load(pr, G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }

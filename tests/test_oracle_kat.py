@@ -1361,3 +1361,27 @@ def test_violation_profiles(alg, orc):
     changed = np.nonzero(w["dyn"][0] > 1e-12)[0]
     assert list(changed) == [3, 4] and np.abs(w["dyn"][1]).max() <= 1e-14
     assert np.array_equal(w["sta"][0, np.arange(N) != 4], v["sta"][0, np.arange(N) != 4])
+
+
+def test_violation_profiles_extended_constraints(alg, orc):
+    """The same with state bounds, a wall and a circle (the per-player constraint blocks behind the collision / control rows): the
+    state profile's maximum is the record's sta_vio, and a knot pushed through the wall by hand changes the state profile at that
+    knot only."""
+    import oracle as orcmod
+    p, N, B = 2, 7, 2
+    rng = np.random.default_rng(4)
+    b = orcmod.OracleBatch(2, p, N, 0.1, B)                       # Bicycle (extended instantiations)
+    b.set_x0(0.2 * rng.random((B, 4 * p))); b.set_lqr(1 + rng.random((B, p, 4)), 0.5 + rng.random((B, p, 2)), rng.random((B, p, 4)), np.zeros((B, p, 2)))
+    xmax = np.full(b.n, np.inf); xmin = np.full(b.n, -np.inf); xmax[0] = 0.05
+    b.add_state_bound(0, xmax, xmin)
+    b.add_wall_constraint([0.0], [0.5], [1.0], [0.5], [0.0], [1.0]); b.add_circle_constraint([0.5], [0.5], [0.1])
+    b.init_traj(game_id0=1); b.rollout()
+    v = b.violation_profile(); rec = b.record()
+    assert np.array_equal(v["sta"].max(axis=1), rec["sta_vio"]) and np.all(v["sta"][:, 0] == 0.0)
+    z = b.get_traj(); X, U, L = b.split_traj(z); X = X.copy()
+    X[1, 3, 0] = 0.5; X[1, 3, p] = 0.9                              # player 0 of game 1 at knot 4: x = 0.5, y = 0.9, above the wall y = 0.5
+    b.set_traj(b.join_traj(X, U, L))
+    w = b.violation_profile()
+    assert np.array_equal(w["sta"][0], v["sta"][0])
+    assert np.array_equal(w["sta"][1, np.arange(N) != 3], v["sta"][1, np.arange(N) != 3])
+    assert abs(w["sta"][1, 3] - max(0.5 - 0.05, 0.9 - 0.5)) < 1e-12  # the larger of the state-bound and the wall violation

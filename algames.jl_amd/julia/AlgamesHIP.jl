@@ -372,7 +372,14 @@ function ShardedGameProblem(probs::Vector{P}; devices=0:0) where {P<:GameProblem
     per = cld(B, W)                                                 # scenarios.shard_range: ceil(B / W) games per shard, last ones shorter
     cuts = [min((r - 1) * per, B)+1:min(r * per, B) for r in 1:W]
     keep = [r for r in 1:W if !isempty(cuts[r])]
-    ShardedGameProblem{P}([BatchedGameProblem(probs[cuts[r]]; device=collect(devices)[r]) for r in keep], cuts[keep])
+    shards = [BatchedGameProblem(probs[cuts[r]]; device=collect(devices)[r]) for r in keep]
+    # one kernel shape for all shards (the automatic choice depends on a handle's batch size; the shapes differ at rounding level)
+    w = Ref{Int32}(0)
+    check(ccall((:alg_get_waves_per_game, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), shards[1].h, w))
+    for bp in shards
+        check(ccall((:alg_set_waves_per_game, LIB), Cint, (Ptr{Cvoid}, Int32), bp.h, w[]))
+    end
+    ShardedGameProblem{P}(shards, cuts[keep])
 end
 Base.close(sp::ShardedGameProblem) = foreach(close, sp.shards)
 function newton_solve!(sp::ShardedGameProblem; game_id0::Integer=0, init::Bool=true)

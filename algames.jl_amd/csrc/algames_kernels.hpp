@@ -19,7 +19,9 @@ __global__ void __launch_bounds__(C::NT, C::WPE) k_newton_solve(Params pr_arg, i
 }
 
 template <class C>
-__global__ void __launch_bounds__(WAVE, C::WPE) k_newton_step(Params pr_arg, int k, int l, const double* delta_in, alg_step_info* out) {
+// (no occupancy bound: the host-driven stepping entry point is not throughput code, and inner_iteration's live ranges at the four-waves-per-SIMD
+// budget are sized for the fused kernel, where the surrounding loops are in the same function)
+__global__ void __launch_bounds__(WAVE) k_newton_step(Params pr_arg, int k, int l, const double* delta_in, alg_step_info* out) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
     const int g = blockIdx.x;

@@ -31,6 +31,9 @@
 #ifndef ALG_ASM_UNROLL
 #define ALG_ASM_UNROLL 2
 #endif
+#ifndef ALG_DIROW
+#define ALG_DIROW 1
+#endif
 #ifndef ALG_AXPY_U
 #define ALG_AXPY_U 4
 #endif
@@ -1722,6 +1725,14 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
     const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// v_mov_b32_dpp on both halves of a double: CTRL = 0x100 + k: lane i takes lane i + k of its 16-lane row (row_shl:k), 0x110 + k: lane i - k
+// (row_shr:k); lanes whose source falls outside the row read 0.
+template <int CTRL>
+__device__ __forceinline__ double row_shift(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 // Row `lane` of A_k dx + B_k du with dx / du held one entry per lane (dx: lanes 0..n-1, du: lanes 0..m-1, joint control order):
 // the forward sweep's state update without a trip through LDS.  Branch-free (the shuffles need all lanes); the entries are
 // those of A_vec / B_vec.
@@ -1730,8 +1741,14 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
     constexpr int n = C::n, m = C::m, P = C::P;
     const int r = lane < n ? lane : 0;
     if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        // position row r takes the velocity dx[r + m] and its control du[r]; velocity row r takes du[r - m]: two shifts inside the 16-lane
+        // row that holds dx and du (v_mov_b32_dpp row_shl / row_shr on the two halves of the double; the ds_bpermute form went through
+        // the LDS crossbar: four LDS operations per step)
+        static_assert(n <= 16 && m < 16, "dx and du live in one 16-lane row");
         const bool lo = r < m;
-        const double other = shfl_d(dxr, lo ? r + m : r), uu = shfl_d(duv, lo ? r : r - m);
+        // (both shifts are executed by every lane before the selects: a DPP read of a lane that a divergent branch has switched off returns 0)
+        const double sx = row_shift<0x100 + m>(dxr), su = row_shift<0x110 + m>(duv);
+        const double other = lo ? sx : dxr, uu = lo ? duv : su;
         const double a = lo ? dxr + dt * other : dxr;
         const double b = lo ? 0.5 * dt * dt * uu : dt * uu;
         return a + b;
@@ -2589,7 +2606,13 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     ALG_PROF(7)
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    hxm.init(phase_lane());
+    // Double integrator: lane 16 i + r = (player i, row r), one 16-lane row per player.  dx_{k+1} is replicated in every row and reaches
+    // the position-block products through the DPP row broadcast, A' dlambda is a shift inside the row (velocity row r takes dt times
+    // position row r - m), the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table
+    // round trips through LDS and one fence per step instead of three.  Same products in the same order as the general form below.
+    constexpr bool DIROW = ALG_DIROW && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && P * 16 <= WAVE;
+    constexpr int NPOS = C::POS ? C::PD * P : 1;
+    if constexpr (!DIROW) hxm.init(phase_lane());
     if constexpr (C::NW == 1) game_sync();            // dx of every step is in global memory
     G = G0.fresh();
     dz = G.z(2);
@@ -2599,7 +2622,30 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     const bool cpos = C::POS && cr_ < C::PD * P;
     double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
     // unconditional loads from clamped addresses (a conditional load into a zeroed register costs a vmcnt drain, see the forward sweep)
-    const int cdxo = lane < n ? lane : 0;
+    const int cdxo = DIROW ? ((lane & 15) < n ? (lane & 15) : 0) : (lane < n ? lane : 0);
+    const int ri_ = lane >> 4, rr_ = lane & 15;
+    const bool rok = DIROW && ri_ < P && rr_ < n;
+    const int re_ = rok ? ri_ * n + rr_ : 0;                           // entry of rx / qdf / dlambda this lane owns
+    const double qdfv = DIROW ? L.qdf[re_] : 0.0;
+    int hso[NPOS]; float hsg[NPOS];                                     // record offset and sign of Q^_i's position-block entry (row rr_, column c)
+    if constexpr (DIROW && C::POS) {
+        constexpr int NS = C::NS;
+        const int i = ri_ < P ? ri_ : 0, jr = rr_ % P, ar = rr_ / P;
+#pragma unroll
+        for (int c = 0; c < NPOS; c++) {
+            const int jc = c % P, h = C::sym(ar < C::PD ? ar : 0, c / P);
+            int so = R::HH; float sg = 0.f;
+            if (rr_ < C::PD * P) {
+                if (jr == i && jc == i) { so = R::HD + NS * i + h; sg = 1.f; }
+                else if (jr == i) { so = R::HH + NS * pairq<C>(i, jc) + h; sg = -1.f; }
+                else if (jc == i) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = -1.f; }
+                else if (jr == jc) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = 1.f; }
+            }
+            hso[c] = so; hsg[c] = sg;
+        }
+    }
+    double lamp = 0.0;                                                  // dlambda of the previous (later) step, entry re_
+    if constexpr (DIROW) dxk = dz[n + hx<C>(N - 2) + cdxo];
     auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
         const int kc = kk > 0 ? kk : 0;
 #pragma unroll
@@ -2618,8 +2664,25 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         const int k = k0 - u;
         if (k < 0) break;
         const double* Rc = L.rec[cur];
-        if (lane < n) L.fw.dx[lane] = dxk;
         const double w = (k + 1 < N - 1) ? dt : 1.0;
+        if constexpr (DIROW) {
+            double qd = reg + w * qdfv;
+            if constexpr (C::EXT) qd += Rc[R::RQ + re_];
+            double acc = Rc[R::RX + re_] + qd * dxk;
+            if constexpr (C::POS) {
+                double hv[NPOS];
+#pragma unroll
+                for (int c = 0; c < NPOS; c++) hv[c] = (double)hsg[c] * Rc[hso[c]];
+                double t = acc;
+                rowdot_dpp<NPOS>(t, dxk, hv);
+                acc = rr_ < C::PD * P ? t : acc;
+            }
+            if (k < N - 2) { const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp); }
+            acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
+            lamp = acc;
+            if (rok) { dz[n + hl<C>(k, 0) + re_] = acc; bad |= !isfinite(acc); }
+        } else {
+        if (lane < n) L.fw.dx[lane] = dxk;
         hxm.expand(lane, Rc, L.fw.hx);
         sweep_sync<C>();
         double acc = 0.0;
@@ -2638,8 +2701,9 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         sweep_sync<C>();
         if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; bad |= !isfinite(acc); }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
+        }
         // land step k - 1 (requested SD steps ago), then request step k - 1 - SD into the emptied slot
-        dxk = lane < n ? pdx[(u + 1) % SD] : 0.0;
+        dxk = (DIROW || lane < n) ? pdx[(u + 1) % SD] : 0.0;
         if (k > 0) {
 #pragma unroll
             for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) L.rec[cur ^ 1][e] = pre[(u + 1) % SD][q]; }

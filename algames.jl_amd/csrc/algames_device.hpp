@@ -32,7 +32,7 @@
 #define ALG_ASM_UNROLL 2
 #endif
 #ifndef ALG_DIROW
-#define ALG_DIROW 1
+#define ALG_DIROW 2
 #endif
 #ifndef ALG_AXPY_U
 #define ALG_AXPY_U 4
@@ -2606,11 +2606,12 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     ALG_PROF(7)
     // ------------------------------------------------------------------ costate sweep:
     //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    // Double integrator: lane 16 i + r = (player i, row r), one 16-lane row per player.  dx_{k+1} is replicated in every row and reaches
-    // the position-block products through the DPP row broadcast, A' dlambda is a shift inside the row (velocity row r takes dt times
-    // position row r - m), the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table
-    // round trips through LDS and one fence per step instead of three.  Same products in the same order as the general form below.
-    constexpr bool DIROW = ALG_DIROW && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && P * 16 <= WAVE;
+    // Lane 16 i + r = (player i, row r), one 16-lane row per player.  dx_{k+1} is replicated in every row and reaches the position-block
+    // products through the DPP row broadcast, A' dlambda is a few shifts inside the row (double integrator: velocity row r takes dt
+    // times position row r - m; unicycle / bicycle: the heading / speed rows take the coefficient-weighted position rows r - P .. r - 3P),
+    // the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table round trips through
+    // LDS and one fence per step instead of three.  Same products in the same order as the general form below.
+    constexpr bool DIROW = ALG_DIROW && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || ALG_DIROW >= 2) && P * 16 <= WAVE;
     constexpr int NPOS = C::POS ? C::PD * P : 1;
     if constexpr (!DIROW) hxm.init(phase_lane());
     if constexpr (C::NW == 1) game_sync();            // dx of every step is in global memory
@@ -2645,6 +2646,11 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         }
     }
     double lamp = 0.0;                                                  // dlambda of the previous (later) step, entry re_
+    // state-dependent models: this lane's entries of A_{k+1}' (AT_vec), taken from step k + 1's record one iteration earlier
+    const int cblk = rr_ / P, cpi = rr_ % P;
+    const bool c_hi = C::MODEL == ALG_MODEL_BICYCLE ? cblk == 2 : cblk == 3, c_on = cblk >= 2 && rr_ < n;
+    const int cia = (c_hi ? 1 : 0) * P + cpi, cib = (c_hi ? 3 : 2) * P + cpi, cic = 4 * P + cpi;
+    double can = 0.0, cbn = 0.0, ccn = 0.0;
     if constexpr (DIROW) dxk = dz[n + hx<C>(N - 2) + cdxo];
     auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
         const int kc = kk > 0 ? kk : 0;
@@ -2677,7 +2683,21 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 rowdot_dpp<NPOS>(t, dxk, hv);
                 acc = rr_ < C::PD * P ? t : acc;
             }
-            if (k < N - 2) { const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp); }
+            if (k < N - 2) {
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                    const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp);
+                } else {
+                    // AT_vec: v(r) + ca v(i) + cb v(P + i) (+ cc v(3P + i), bicycle heading rows), i = r % P: rows 2P + i take lanes r - 2P, r - P
+                    // (, r + P), rows 3P + i take lanes r - 3P, r - 2P
+                    const double s1 = row_shift<0x110 + P>(lamp), s2 = row_shift<0x110 + 2 * P>(lamp), s3 = row_shift<0x110 + 3 * P>(lamp);
+                    const double vi = cblk == 3 ? s3 : s2, vpi = cblk == 3 ? s2 : s1;
+                    if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                        const double u1 = row_shift<0x100 + P>(lamp);
+                        acc += lamp + (c_on ? can : 0.0) * (c_on ? vi : lamp) + (c_on ? cbn : 0.0) * (c_on ? vpi : lamp) + (cblk == 2 ? ccn : 0.0) * (cblk == 2 ? u1 : lamp);
+                    } else acc += lamp + (c_on ? can : 0.0) * (c_on ? vi : lamp) + (c_on ? cbn : 0.0) * (c_on ? vpi : lamp);
+                }
+            }
+            if constexpr (C::NC > 0) { can = Rc[R::COEF + cia]; cbn = Rc[R::COEF + cib]; if constexpr (C::MODEL == ALG_MODEL_BICYCLE) ccn = Rc[R::COEF + cic]; }
             acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
             lamp = acc;
             if (rok) { dz[n + hl<C>(k, 0) + re_] = acc; bad |= !isfinite(acc); }

@@ -1763,7 +1763,14 @@ __device__ __forceinline__ double fwd_next(const double* coef, double dt, double
         return a + (b0 * w0 + b1 * w1);
     } else {
         const int blk = r / P, i = r % P;
-        const double th = shfl_d(dxr, 2 * P + i), vv = shfl_d(dxr, 3 * P + i), w0 = shfl_d(duv, i), w1 = shfl_d(duv, P + i);
+        // heading / speed of the row's player and its two controls, by shifts inside the 16-lane row that holds dx and du (executed by
+        // every lane, selected afterwards): rows i and P + i read dx[2P + i], dx[3P + i], du[i], du[P + i]; rows 2P + i / 3P + i read du[i] / du[P + i]
+        static_assert(n <= 16, "dx and du live in one 16-lane row");
+        const double x1 = row_shift<0x100 + P>(dxr), x2 = row_shift<0x100 + 2 * P>(dxr), x3 = row_shift<0x100 + 3 * P>(dxr);
+        const double u1 = row_shift<0x100 + P>(duv), d1 = row_shift<0x110 + P>(duv), d2 = row_shift<0x110 + 2 * P>(duv);
+        const bool b0 = blk == 0;
+        const double th = b0 ? x2 : x1, vv = b0 ? x3 : x2;
+        const double w0 = blk >= 2 ? d2 : (b0 ? duv : d1), w1 = blk >= 2 ? d2 : (b0 ? u1 : duv);
         const bool pos = blk < 2;
         const double ca = coef[(pos ? 2 * blk : 0) * P + i], cb = coef[(pos ? 2 * blk + 1 : 1) * P + i];
         const double a = pos ? dxr + ca * th + cb * vv : dxr;

@@ -210,20 +210,35 @@ __device__ __forceinline__ int phase_lane() { int l = game_tid(); asm volatile("
 __device__ __forceinline__ int phase_int(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ double phase_f64(double v) { return __longlong_as_double((long long)uniform_u64((unsigned long long)__double_as_longlong(v))); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+// Butterfly over the 64 lanes without the LDS crossbar (the __shfl_xor form costs two ds_bpermute per level and double, ~100 cycles of
+// latency each).  Levels 32 and 16: v_permlane32_swap / v_permlane16_swap return (own | partner's) and (partner's | own) in their two
+// results, so result0 (op) result1 is own (op) partner in every lane, without a lane select.  Levels 8, 4, 2, 1: row rotations
+// (v_mov_b32_dpp row_ror): after level 8 the row holds every value twice 8 lanes apart, so lane i + 4 carries what lane i ^ 4 does, and
+// so on down -- the same operands meet at every level as in the xor butterfly: bit-identical results for commutative ops.
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) { return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v))); }
+template <class Op>
+__device__ __forceinline__ double wave_butterfly(double v, Op op) {
+    {
+        const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = op(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    {
+        const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = op(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    v = op(v, dpp_f64<0x128>(v)); v = op(v, dpp_f64<0x124>(v)); v = op(v, dpp_f64<0x122>(v)); v = op(v, dpp_f64<0x121>(v));
     return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_butterfly(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double wave_max(double v) { return wave_butterfly(v, [](double a, double b) { return fmax(a, b); }); }
 // fmax drops NaNs; carry a separate finite flag where NaN detection matters
 __device__ __forceinline__ int wave_or(int v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o);
+    { const auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = a[0] | a[1]; }
+    { const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = a[0] | a[1]; }
+    v |= dpp_i32<0x128>(v); v |= dpp_i32<0x124>(v); v |= dpp_i32<0x122>(v); v |= dpp_i32<0x121>(v);
     return v;
 }
 

@@ -5,7 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 import numpy as np
 import algames_jl_amd as alg
 cfg, G = sys.argv[1], int(sys.argv[2])
-prob = alg.scenarios.make_problem(cfg, np.arange(G)); prob.batch.set_waves_per_game(1)
+prob = alg.scenarios.make_problem(cfg, np.arange(G)); prob.batch.set_waves_per_game(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
 alg.newton_solve(prob)
 b = prob.batch
 fn = b.lib.dll.alg_debug_read_res; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]

@@ -198,3 +198,24 @@ def test_jacobian_of_a_game_range_and_scratch_release(alg):
     A.residual_jacobian(core, prob, game=7)
     S = prob.probsize.S
     assert np.array_equal(core.jac[:S, :S], alg.residual_jacobian(prob, 0.0, games=(7, 1))[0])
+
+
+@pytest.mark.gpu
+def test_per_record_violation_profiles_through_the_step_wise_entry_points(alg):
+    """The fused solver keeps the violation maxima per record; the .vio vectors of every record (violations.jl) are available to a
+    caller that drives the inner iterations itself: the profile read after step t is the profile of record t + 1 (record! is made at
+    the iterate the previous step left), so its maxima must be that record's *_vio."""
+    prob = alg.scenarios.make_problem("C5", np.arange(6), N=12)
+    b = prob.batch
+    b.set_waves_per_game(1)
+    b.init_traj(game_id0=0); b.rollout(0)
+    profs = []
+    for l in range(1, 6):
+        b.newton_step(1, l)
+        profs.append(b.violation_profile())
+    for g in range(6):
+        h = b.get_history(g)
+        assert len(h) == 5
+        for t in range(4):
+            for f in ("dyn", "con", "sta", "opt"):
+                assert np.isclose(profs[t][f][g].max(), h[f + "_vio"][t + 1], rtol=1e-12, atol=1e-300), (g, t, f)

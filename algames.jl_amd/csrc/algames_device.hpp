@@ -2286,6 +2286,10 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     constexpr int KPL = (NK + WAVE - 1) / WAVE;
     constexpr bool AUGS = DirLds<C>::AUGS;               // s_i rides through the first MFMA product (n < 16)
     constexpr int KB1 = DirLds<C>::KB1, VW = DirLds<C>::VW;
+#ifndef ALG_GFUSE
+#define ALG_GFUSE 1
+#endif
+    constexpr bool GFUSE = ALG_GFUSE && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
     HxMap<C> hxm;
     QaddMap<C, BT> qam; qam.init(tid);
     struct NoGather { __device__ void init(int, int) {} };
@@ -2454,7 +2458,23 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
             for (int c = 0; c < n; c++) pr_[c] = Pr[c];
             rowdot_dpp<n>(a, rdl, pr_);
-            if ((tid & 15) < n) L.bw.t[yp * n + yr] = a;
+            if (!GFUSE && (tid & 15) < n) L.bw.t[yp * n + yr] = a;
+            // g_c = ru_c + B[:,c]' y_i for the controls c of this row's player (c % P == i): the rows of y_i that column c of B touches are
+            // shifts away inside the row, so lane 16 i + c finishes g_c here -- no second phase, no trip of y through LDS (BT_vec's expression)
+            if constexpr (GFUSE) {
+                const int rl = tid & 15;
+                double gb;
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                    const double up = row_shift<0x100 + m>(a);
+                    gb = 0.5 * dt * dt * a + dt * up;
+                } else {
+                    const double dn = row_shift<0x110 + P>(a), up = row_shift<0x100 + P>(a), up2 = row_shift<0x100 + 2 * P>(a);
+                    const int kind = rl < m ? rl / P : 0;
+                    const double vi = kind ? dn : a, vpi = kind ? a : up;
+                    gb = 0.5 * dt * (coefk[kind * P + yp] * vi + coefk[(2 + kind) * P + yp] * vpi) + dt * up2;
+                }
+                if (rl < m && rl % P == yp) L.bw.V[rl * VW + n] = Rc[R::RU + rl] + gb;
+            }
         }
         // coefficient entries of A_k' (state-dependent models)
         if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
@@ -2469,12 +2489,14 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         if (tid < m) L.bw.V[tid * VW + n + 1 + tid] = Rc[R::RHAT + tid];
         bsync();
         ALG_PROF(2)
-        // ---- V[c][n] = g_c = ru_c + B[:,c]' (P rd + s)
-        if (tid < m) {
-            const double* yi = &L.bw.t[(tid % P) * n];
-            L.bw.V[tid * VW + n] = Rc[R::RU + tid] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, tid);
+        // ---- V[c][n] = g_c = ru_c + B[:,c]' (P rd + s)   (double integrator / unicycle: done in the y_i lanes above)
+        if constexpr (!GFUSE) {
+            if (tid < m) {
+                const double* yi = &L.bw.t[(tid % P) * n];
+                L.bw.V[tid * VW + n] = Rc[R::RU + tid] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, tid);
+            }
+            bsync();
         }
-        bsync();
         ALG_PROF(3)
         // ---- column-per-lane augmented system [ W | V A_k | g ],  W = diag(R^) + V B: every lane forms its column as the same
         // short sparse combination of row c of the extended V (lane < m: B column + R^ slot; lane < m+n: A column; lane m+n: g slot)

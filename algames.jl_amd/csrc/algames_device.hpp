@@ -2290,6 +2290,10 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #define ALG_GFUSE 1
 #endif
     constexpr bool GFUSE = ALG_GFUSE && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
+#ifndef ALG_SYSROW
+#define ALG_SYSROW 1
+#endif
+    constexpr bool SYSROW = ALG_SYSROW && GFUSE && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR;      // the V phase forms the system's rows (needs g from the y lanes)
     HxMap<C> hxm;
     QaddMap<C, BT> qam; qam.init(tid);
     struct NoGather { __device__ void init(int, int) {} };
@@ -2441,7 +2445,22 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
         for (int q = 0; q < (m + CPP - 1) / CPP; q++) {
             const int c = CPP * q + (tid >> 4), col = tid & 15;
-            if (c < m && col < n) {
+            if constexpr (SYSROW) {
+                // Double integrator: row c of the augmented system [W | V A_k | g] is a combination of row c of V with itself shifted by m
+                // ((V A)[c][j] = V[c][j] + dt V[c][j - m], W[c][j] = dt^2/2 V[c][j] + dt V[c][j + m] + R^ slot), and a 16-lane row of this
+                // phase IS row c of V: the lanes form the system's entries from their own V entry and two row shifts, so the column
+                // build reads its m entries instead of 3 m entries of V (same FMA sequences as the pattern form: bit-identical)
+                const bool cok = c < m; const int cq = cok ? c : 0, colr = col < n ? col : n - 1;
+                const double* Pi = &L.bw.Pm[(cq % P) * n * LDP];
+                const double vcol = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + colr]; }, cq);
+                const double below = row_shift<0x110 + m>(vcol), above = row_shift<0x100 + m>(vcol);
+                const double ea = (k >= 1) ? (col >= m ? fma(dt, below, vcol) : vcol) : 0.0;
+                double eb = (0.5 * dt * dt) * vcol; eb = fma(dt, above, eb);
+                const double rh = (col == cq) ? Rc[R::RHAT + cq] : 0.0;
+                eb = fma(1.0, rh, eb);
+                if (cok && col < n) L.bw.V[c * VW + m + col] = ea;
+                if (cok && col < m) L.bw.V[c * VW + col] = eb;
+            } else if (c < m && col < n) {
                 const double* Pi = &L.bw.Pm[(c % P) * n * LDP];
                 L.bw.V[c * VW + col] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
             }
@@ -2473,7 +2492,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                     const double vi = kind ? dn : a, vpi = kind ? a : up;
                     gb = 0.5 * dt * (coefk[kind * P + yp] * vi + coefk[(2 + kind) * P + yp] * vpi) + dt * up2;
                 }
-                if (rl < m && rl % P == yp) L.bw.V[rl * VW + n] = Rc[R::RU + rl] + gb;
+                if (rl < m && rl % P == yp) L.bw.V[rl * VW + (SYSROW ? m + n : n)] = Rc[R::RU + rl] + gb;
             }
         }
         // coefficient entries of A_k' (state-dependent models)
@@ -2486,7 +2505,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 L.bw.T[(colb * P + i) * n + row] = coefk[tid];
             }
         }
-        if (tid < m) L.bw.V[tid * VW + n + 1 + tid] = Rc[R::RHAT + tid];
+        if (!SYSROW && tid < m) L.bw.V[tid * VW + n + 1 + tid] = Rc[R::RHAT + tid];
         bsync();
         ALG_PROF(2)
         // ---- V[c][n] = g_c = ru_c + B[:,c]' (P rd + s)   (double integrator / unicycle: done in the y_i lanes above)
@@ -2508,13 +2527,17 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         double col[m];
         {
             int rows[C::NPAT + 1]; double vals[C::NPAT + 1];
-            col_pattern<C>(coefk, dt, cidx, k >= 1, rows, vals);
+            if constexpr (!SYSROW) col_pattern<C>(coefk, dt, cidx, k >= 1, rows, vals);
 #pragma unroll
             for (int c = 0; c < m; c++) {
                 const double* Vc = &L.bw.V[c * VW];
-                double v = vals[0] * Vc[rows[0]];
+                double v;
+                if constexpr (SYSROW) v = Vc[cidx];
+                else {
+                    v = vals[0] * Vc[rows[0]];
 #pragma unroll
-                for (int t = 1; t < C::NPAT + 1; t++) v = fma(vals[t], Vc[rows[t]], v);
+                    for (int t = 1; t < C::NPAT + 1; t++) v = fma(vals[t], Vc[rows[t]], v);
+                }
                 if (IBR) {
                     if (c % P != ip) v = (cidx == c) ? 1.0 : 0.0;               // unit row: du_c = 0
                     else if (cidx < m && cidx % P != ip) v = 0.0;               // fixed controls of the other players

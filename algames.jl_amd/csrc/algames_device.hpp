@@ -2293,7 +2293,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #ifndef ALG_SYSROW
 #define ALG_SYSROW 1
 #endif
-    constexpr bool SYSROW = ALG_SYSROW && GFUSE && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR;      // the V phase forms the system's rows (needs g from the y lanes)
+    constexpr bool SYSROW = ALG_SYSROW && GFUSE;      // the V phase forms the system's rows (needs g from the y lanes)
     HxMap<C> hxm;
     QaddMap<C, BT> qam; qam.init(tid);
     struct NoGather { __device__ void init(int, int) {} };
@@ -2446,17 +2446,33 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         for (int q = 0; q < (m + CPP - 1) / CPP; q++) {
             const int c = CPP * q + (tid >> 4), col = tid & 15;
             if constexpr (SYSROW) {
-                // Double integrator: row c of the augmented system [W | V A_k | g] is a combination of row c of V with itself shifted by m
+                // Row c of the augmented system (double integrator shown; unicycle: coefficient-weighted shifts by P, 2P, 3P) [W | V A_k | g] is a combination of row c of V with itself shifted by m
                 // ((V A)[c][j] = V[c][j] + dt V[c][j - m], W[c][j] = dt^2/2 V[c][j] + dt V[c][j + m] + R^ slot), and a 16-lane row of this
                 // phase IS row c of V: the lanes form the system's entries from their own V entry and two row shifts, so the column
                 // build reads its m entries instead of 3 m entries of V (same FMA sequences as the pattern form: bit-identical)
                 const bool cok = c < m; const int cq = cok ? c : 0, colr = col < n ? col : n - 1;
                 const double* Pi = &L.bw.Pm[(cq % P) * n * LDP];
                 const double vcol = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + colr]; }, cq);
-                const double below = row_shift<0x110 + m>(vcol), above = row_shift<0x100 + m>(vcol);
-                const double ea = (k >= 1) ? (col >= m ? fma(dt, below, vcol) : vcol) : 0.0;
-                double eb = (0.5 * dt * dt) * vcol; eb = fma(dt, above, eb);
                 const double rh = (col == cq) ? Rc[R::RHAT + cq] : 0.0;
+                double ea, eb;
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                    const double below = row_shift<0x110 + m>(vcol), above = row_shift<0x100 + m>(vcol);
+                    ea = (k >= 1) ? (col >= m ? fma(dt, below, vcol) : vcol) : 0.0;
+                    eb = (0.5 * dt * dt) * vcol; eb = fma(dt, above, eb);
+                } else {
+                    // unicycle (col_pattern): column idx = kind P + i of B touches rows i, P + i (coefficients) and (2 + kind) P + i (dt); column
+                    // (2 + kind') P + i of A touches rows i, P + i besides its own
+                    const double d1 = row_shift<0x110 + P>(vcol), d2 = row_shift<0x110 + 2 * P>(vcol), d3 = row_shift<0x110 + 3 * P>(vcol);
+                    const double u1 = row_shift<0x100 + P>(vcol), u2 = row_shift<0x100 + 2 * P>(vcol);
+                    const int blk = colr / P, pi = colr % P;
+                    const double ca = coefk[(blk >= 2 ? blk - 2 : 0) * P + pi], cb = coefk[(blk >= 2 ? blk : 2) * P + pi];
+                    double va = vcol;
+                    if (blk >= 2) { va = fma(ca, blk == 3 ? d3 : d2, va); va = fma(cb, blk == 3 ? d2 : d1, va); }
+                    ea = (k >= 1) ? va : 0.0;
+                    const int kind = blk & 1;                                  // col < m: blk = kind
+                    const double wa = 0.5 * dt * coefk[kind * P + pi], wb = 0.5 * dt * coefk[(2 + kind) * P + pi];
+                    eb = wa * (kind ? d1 : vcol); eb = fma(wb, kind ? vcol : u1, eb); eb = fma(dt, u2, eb);
+                }
                 eb = fma(1.0, rh, eb);
                 if (cok && col < n) L.bw.V[c * VW + m + col] = ea;
                 if (cok && col < m) L.bw.V[c * VW + col] = eb;

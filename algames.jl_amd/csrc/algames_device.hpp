@@ -31,6 +31,9 @@
 #ifndef ALG_ASM_UNROLL
 #define ALG_ASM_UNROLL 2
 #endif
+// round-3 A/B switches of the tile path's sparse phases (all on; 0 restores the round-2 form of the phase, results are bit-identical either way):
+//   ALG_DIROW  costate sweep with one 16-lane row per player (1: double integrator only, 2: all tile models)
+//   ALG_GFUSE  g_c finished in the y_i lanes        ALG_SYSROW  rows of the augmented control system formed in the V phase
 #ifndef ALG_DIROW
 #define ALG_DIROW 2
 #endif

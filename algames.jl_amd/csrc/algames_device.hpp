@@ -2617,97 +2617,18 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     G = G0.fresh();
     double* __restrict__ dz = G.z(2);
     if (lane < n) dz[lane] = 0.0;
-    // the forward sweep reads only [coef | rd] of a record: one load per lane
-    static_assert(C::NC + n <= WAVE, "forward sweep record slice");
-    const int fro = lane < C::NC ? R::COEF + lane : R::RD + (lane - C::NC);      // record offset of this lane's slice entry
-    const bool frok = lane < C::NC + n;
-    if (frok) L.rec[0][fro] = G.rec(pr)[fro];
-    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain(pr)[e];
-    // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
-    // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
-    // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
-    // addresses, and everything at the tail of the step in the order (1) land the data of step k+1 (requested one step ago) in
-    // LDS, (2) issue this step's result stores, (3) request the data of step k+2 -- the single wait of a step meets loads and
-    // stores that have been in flight for a whole step.
-    const int froc = frok ? fro : R::RD;                                       // lanes without a slice entry duplicate rd[0]
-    auto fwd_load = [&](int kk, double& rf, double (&rk)[KPL]) {
-        const int kc = kk < N - 1 ? kk : N - 2;
-        rf = G.rec(pr)[(size_t)kc * R::LEN + froc];
-#pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = G.kgain(pr)[(size_t)kc * NK + (e < NK ? e : NK - 1)]; }
-    };
-    // Prefetch ring: the slices of steps k + 1 .. k + SD are in flight in registers while step k computes.  With four games per
-    // SIMD all streaming, a fetch takes about two microseconds -- longer than a step of this sweep -- so with one step in flight
-    // (rounds 1-2) the sweep ran at memory latency: 4.7 K cycles per step at 4096 games against 1.0 K for a lone wavefront
-    // (tests/probes/phase_prof.py).  The loop is unrolled by SD so that every ring slot is a fixed register (a rotating copy
-    // would read the newest load and wait for it).
-    constexpr int SD = C::SWEEP_DEPTH;
-    double pref[SD], prek[SD][KPL];
-#pragma unroll
-    for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
-    sweep_sync<C>();
-    cur = 0;
-    double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
-    int bad = 0;                                    // non-finite direction entries (checked where they are produced)
-    // dx_k lives one entry per lane (lanes 0..n-1) and is broadcast with v_readlane; du and dx_{k+1} never pass through LDS:
-    // one LDS round trip (gain rows, record slice) per step instead of three.
-    double dxr = 0.0;
-    for (int k0 = 0; k0 < N - 1; k0 += SD) {
-#pragma unroll
-      for (int u = 0; u < SD; u++) {
-        const int k = k0 + u;
-        if (k >= N - 1) break;
-        constexpr int 	slot_dummy = 0; (void)slot_dummy;
-        const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
-        const int cl = lane < m ? lane : 0;
-        double acc = Kl[n * m + cl];
-        double kv[n];
-#pragma unroll
-        for (int q = 0; q < n; q++) kv[q] = Kl[q * m + cl];
-        rowdot_dpp<n>(acc, dxr, kv);                  // dx_k sits in lanes 0..n-1 of row 0, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
-        const double duv = lane < m ? acc : 0.0;
-        const double rdv = Rc[R::RD + (lane < n ? lane : 0)];
-        double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, lane) + rdv;
-        dxn = lane < n ? dxn : 0.0;
-        if (lane < m) { pl1 += fabs(duv); bad |= !isfinite(duv); }
-        if (lane < n) { pl1 += fabs(dxn); bad |= !isfinite(dxn); }
-        dxr = dxn;
-        // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
-        L.rec[cur ^ 1][froc] = pref[(u + 1) % SD];
-#pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
-        asm volatile("" ::: "memory");
-        // (2) results out
-        if (lane < m) dz[n + hu<C>(k, 0) + uoff<C>(lane)] = duv;
-        if (lane < n) dz[n + hx<C>(k) + lane] = dxn;
-        // (3) request step k+1+SD into the slot that was just emptied
-        fwd_load(k + 1 + SD, pref[(u + 1) % SD], prek[(u + 1) % SD]);
-        sweep_sync<C>();
-        cur ^= 1;
-      }
-    }
-#if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
-    return ALG_STATUS_OK;
-#endif
-    ALG_PROF(7)
-    // ------------------------------------------------------------------ costate sweep:
-    //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    // Lane 16 i + r = (player i, row r), one 16-lane row per player.  dx_{k+1} is replicated in every row and reaches the position-block
-    // products through the DPP row broadcast, A' dlambda is a few shifts inside the row (double integrator: velocity row r takes dt
-    // times position row r - m; unicycle / bicycle: the heading / speed rows take the coefficient-weighted position rows r - P .. r - 3P),
-    // the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table round trips through
-    // LDS and one fence per step instead of three.  Same products in the same order as the general form below.
     constexpr bool DIROW = ALG_DIROW && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || ALG_DIROW >= 2) && P * 16 <= WAVE;
     constexpr int NPOS = C::POS ? C::PD * P : 1;
-    if constexpr (!DIROW) hxm.init(phase_lane());
-    if constexpr (C::NW == 1) game_sync();            // dx of every step is in global memory
-    G = G0.fresh();
-    dz = G.z(2);
-    constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
-    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
-    const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
-    const bool cpos = C::POS && cr_ < C::PD * P;
-    double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
+#ifndef ALG_FWDW
+#define ALG_FWDW 1
+#endif
+    // FWDW: the forward sweep also forms the part of dlambda_k that does not depend on dlambda_{k+1} -- w_k = rx + Q^ dx_{k+1} -- right after
+    // dx_{k+1} exists, in the bubbles of its own dependency chain (every 16-lane row runs the forward recursion redundantly, so row i has
+    // dx for player i's products), and parks it in dlambda's slot; the costate sweep is left with dlambda_k = w_k + A' dlambda_{k+1}: one
+    // load, a few shifts, no LDS, no fence.  Bit-identical: w_k is exactly the intermediate value the one-sweep form holds in a register.
+    // (double integrator only: measured +1.1 % at C2; for the unicycle the recursion's coefficient loads cost more than the shorter chain
+    // saves: C3 -0.8 %, C5 loop -0.6 %)
+    constexpr bool FWDW = ALG_FWDW && DIROW && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR;
     // unconditional loads from clamped addresses (a conditional load into a zeroed register costs a vmcnt drain, see the forward sweep)
     const int cdxo = DIROW ? ((lane & 15) < n ? (lane & 15) : 0) : (lane < n ? lane : 0);
     const int ri_ = lane >> 4, rr_ = lane & 15;
@@ -2737,6 +2658,166 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     const bool c_hi = C::MODEL == ALG_MODEL_BICYCLE ? cblk == 2 : cblk == 3, c_on = cblk >= 2 && rr_ < n;
     const int cia = (c_hi ? 1 : 0) * P + cpi, cib = (c_hi ? 3 : 2) * P + cpi, cic = 4 * P + cpi;
     double can = 0.0, cbn = 0.0, ccn = 0.0;
+    // the forward sweep reads only [coef | rd] of a record: one load per lane
+    static_assert(C::NC + n <= WAVE, "forward sweep record slice");
+    const int fro = lane < C::NC ? R::COEF + lane : R::RD + (lane - C::NC);      // record offset of this lane's slice entry
+    const bool frok = lane < C::NC + n;
+    // FWDW: the slice is [coef | Hh | Hd | RQ | rx] (the costate's) followed by rd, FPL entries per lane (entries past the end duplicate rd[0])
+    constexpr int FSL2 = R::LEN_COSTATE + n, FPL = FWDW ? (FSL2 + WAVE - 1) / WAVE : 1;
+    int fso[FPL];
+#pragma unroll
+    for (int q = 0; q < FPL; q++) { const int e = lane + q * WAVE; fso[q] = FWDW ? (e < R::LEN_COSTATE ? e : (e < FSL2 ? R::RD + (e - R::LEN_COSTATE) : R::RD)) : (frok ? fro : R::RD); }
+    if constexpr (FWDW) {
+#pragma unroll
+        for (int q = 0; q < FPL; q++) L.rec[0][fso[q]] = G.rec(pr)[fso[q]];
+    } else if (frok) L.rec[0][fro] = G.rec(pr)[fro];
+    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain(pr)[e];
+    // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
+    // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
+    // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
+    // addresses, and everything at the tail of the step in the order (1) land the data of step k+1 (requested one step ago) in
+    // LDS, (2) issue this step's result stores, (3) request the data of step k+2 -- the single wait of a step meets loads and
+    // stores that have been in flight for a whole step.
+    auto fwd_load = [&](int kk, double (&rf)[FPL], double (&rk)[KPL]) {
+        const int kc = kk < N - 1 ? kk : N - 2;
+#pragma unroll
+        for (int q = 0; q < FPL; q++) rf[q] = G.rec(pr)[(size_t)kc * R::LEN + fso[q]];
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = G.kgain(pr)[(size_t)kc * NK + (e < NK ? e : NK - 1)]; }
+    };
+    // Prefetch ring: the slices of steps k + 1 .. k + SD are in flight in registers while step k computes.  With four games per
+    // SIMD all streaming, a fetch takes about two microseconds -- longer than a step of this sweep -- so with one step in flight
+    // (rounds 1-2) the sweep ran at memory latency: 4.7 K cycles per step at 4096 games against 1.0 K for a lone wavefront
+    // (tests/probes/phase_prof.py).  The loop is unrolled by SD so that every ring slot is a fixed register (a rotating copy
+    // would read the newest load and wait for it).
+    constexpr int SD = C::SWEEP_DEPTH;
+    double pref[SD][FPL], prek[SD][KPL];
+#pragma unroll
+    for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
+    sweep_sync<C>();
+    cur = 0;
+    double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
+    int bad = 0;                                    // non-finite direction entries (checked where they are produced)
+    // dx_k lives one entry per lane (lanes 0..n-1) and is broadcast with v_readlane; du and dx_{k+1} never pass through LDS:
+    // one LDS round trip (gain rows, record slice) per step instead of three.
+    double dxr = 0.0;
+    for (int k0 = 0; k0 < N - 1; k0 += SD) {
+#pragma unroll
+      for (int u = 0; u < SD; u++) {
+        const int k = k0 + u;
+        if (k >= N - 1) break;
+        const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
+        const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
+        const int cl = fl < m ? fl : 0;
+        double acc = Kl[n * m + cl];
+        double kv[n];
+#pragma unroll
+        for (int q = 0; q < n; q++) kv[q] = Kl[q * m + cl];
+        rowdot_dpp<n>(acc, dxr, kv);                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
+        const double duv = fl < m ? acc : 0.0;
+        const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
+        double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
+        dxn = fl < n ? dxn : 0.0;
+        if (lane < m) { pl1 += fabs(duv); bad |= !isfinite(duv); }
+        if (lane < n) { pl1 += fabs(dxn); bad |= !isfinite(dxn); }
+        dxr = dxn;
+        if constexpr (FWDW) {
+            // w_k = rx_{i,k+1} + Q^_{i,k+1} dx_{k+1} for (player, row) = (ri_, rr_): the head of the costate sweep's FMA sequence
+            const double wq = (k + 1 < N - 1) ? dt : 1.0;
+            double qd = reg + wq * qdfv;
+            if constexpr (C::EXT) qd += Rc[R::RQ + re_];
+            double wk = Rc[R::RX + re_] + qd * dxn;
+            if constexpr (C::POS) {
+                double hv[NPOS];
+#pragma unroll
+                for (int c = 0; c < NPOS; c++) hv[c] = (double)hsg[c] * Rc[hso[c]];
+                double t = wk;
+                rowdot_dpp<NPOS>(t, dxn, hv);
+                wk = rr_ < C::PD * P ? t : wk;
+            }
+            if (rok) dz[n + hl<C>(k, 0) + re_] = wk;
+        }
+        // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
+#pragma unroll
+        for (int q = 0; q < FPL; q++) L.rec[cur ^ 1][fso[q]] = pref[(u + 1) % SD][q];
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
+        asm volatile("" ::: "memory");
+        // (2) results out
+        if (lane < m) dz[n + hu<C>(k, 0) + uoff<C>(lane)] = duv;
+        if (lane < n) dz[n + hx<C>(k) + lane] = dxn;
+        // (3) request step k+1+SD into the slot that was just emptied
+        fwd_load(k + 1 + SD, pref[(u + 1) % SD], prek[(u + 1) % SD]);
+        sweep_sync<C>();
+        cur ^= 1;
+      }
+    }
+#if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
+    return ALG_STATUS_OK;
+#endif
+    ALG_PROF(7)
+    // ------------------------------------------------------------------ costate sweep:
+    //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
+    // Lane 16 i + r = (player i, row r), one 16-lane row per player.  dx_{k+1} is replicated in every row and reaches the position-block
+    // products through the DPP row broadcast, A' dlambda is a few shifts inside the row (double integrator: velocity row r takes dt
+    // times position row r - m; unicycle / bicycle: the heading / speed rows take the coefficient-weighted position rows r - P .. r - 3P),
+    // the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table round trips through
+    // LDS and one fence per step instead of three.  Same products in the same order as the general form below.
+    if constexpr (!DIROW) hxm.init(phase_lane());
+    if constexpr (C::NW == 1) game_sync();            // dx of every step is in global memory
+    G = G0.fresh();
+    dz = G.z(2);
+    if constexpr (FWDW) {
+        // dlambda_k = w_k + A_{k+1}' dlambda_{k+1}: w_k comes back from dlambda's own slot (this lane wrote it in the forward sweep), the
+        // coefficients of A_{k+1} (state-dependent models) from step k + 1's record; SD steps in flight, no LDS, no fence
+        constexpr int NCF = C::NC > 0 ? (C::MODEL == ALG_MODEL_BICYCLE ? 3 : 2) : 0;
+#ifndef ALG_FWDW_DEPTH
+#define ALG_FWDW_DEPTH 8
+#endif
+        constexpr int CD = ALG_FWDW_DEPTH;           // steps in flight: three doubles per slot, and nothing but these loads feeds the recursion
+        double wkr[CD], cfr[CD][NCF > 0 ? NCF : 1];
+        auto cw_load = [&](int kk, double& wv, double (&cf)[NCF > 0 ? NCF : 1]) {
+            const int kc = kk > 0 ? kk : 0, kn = kc + 1 < N - 1 ? kc + 1 : N - 2;
+            wv = dz[n + hl<C>(kc, 0) + re_];
+            if constexpr (NCF > 0) {
+                const double* Rn = G.rec(pr) + (size_t)kn * R::LEN + R::COEF;
+                cf[0] = Rn[cia]; cf[1] = Rn[cib];
+                if constexpr (NCF > 2) cf[2] = Rn[cic];
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < CD; u++) cw_load(N - 2 - u, wkr[u], cfr[u]);
+        for (int k0 = N - 2; k0 >= 0; k0 -= CD) {
+#pragma unroll
+          for (int u = 0; u < CD; u++) {
+            const int k = k0 - u;
+            if (k < 0) break;
+            double acc = wkr[u];
+            if (k < N - 2) {
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                    const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp);
+                } else {
+                    const double ca_ = cfr[u][0], cb_ = cfr[u][1];
+                    const double s1 = row_shift<0x110 + P>(lamp), s2 = row_shift<0x110 + 2 * P>(lamp), s3 = row_shift<0x110 + 3 * P>(lamp);
+                    const double vi = cblk == 3 ? s3 : s2, vpi = cblk == 3 ? s2 : s1;
+                    if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                        const double u1 = row_shift<0x100 + P>(lamp), cc_ = cfr[u][NCF > 2 ? 2 : 0];
+                        acc += lamp + (c_on ? ca_ : 0.0) * (c_on ? vi : lamp) + (c_on ? cb_ : 0.0) * (c_on ? vpi : lamp) + (cblk == 2 ? cc_ : 0.0) * (cblk == 2 ? u1 : lamp);
+                    } else acc += lamp + (c_on ? ca_ : 0.0) * (c_on ? vi : lamp) + (c_on ? cb_ : 0.0) * (c_on ? vpi : lamp);
+                }
+            }
+            acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
+            lamp = acc;
+            if (rok) { dz[n + hl<C>(k, 0) + re_] = acc; bad |= !isfinite(acc); }
+            cw_load(k - CD, wkr[u], cfr[u]);
+          }
+        }
+    } else {
+    constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
+    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
+    const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
+    const bool cpos = C::POS && cr_ < C::PD * P;
+    double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
     if constexpr (DIROW) dxk = dz[n + hx<C>(N - 2) + cdxo];
     auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
         const int kc = kk > 0 ? kk : 0;
@@ -2818,6 +2899,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         sweep_sync<C>();
         cur ^= 1;
       }
+    }
     }
     ALG_PROF(8)
     ALG_PROF_FLUSH

@@ -1532,10 +1532,12 @@ __device__ __forceinline__ void fmac_rowbcast(double& acc, double v, double p) {
     else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(p), "n"(L));
 }
 // acc + sum_c p[c] * (lane c of the row of v), c = 0 .. NC-1, in that order (the FMA chain `a += p[c] * x[c]` with x spread over a row)
-template <int NC, int C0 = 0>
-__device__ __forceinline__ void rowdot_dpp(double& acc, double v, const double* p) {
-    if constexpr (C0 < NC) { fmac_rowbcast<C0, C0 == 0>(acc, v, p[C0]); rowdot_dpp<NC, C0 + 1>(acc, v, p); }
+template <int NC, int C0 = 0, class PF>
+__device__ __forceinline__ void rowdot_dpp_f(double& acc, double v, PF&& p) {          // p(c): the c-th coefficient, fetched where it is used
+    if constexpr (C0 < NC) { fmac_rowbcast<C0, C0 == 0>(acc, v, p(C0)); rowdot_dpp_f<NC, C0 + 1>(acc, v, p); }
 }
+template <int NC>
+__device__ __forceinline__ void rowdot_dpp(double& acc, double v, const double* p) { rowdot_dpp_f<NC>(acc, v, [&](int c) { return p[c]; }); }
 // Lane roles of the DPP elimination inside one wavefront: row q = lane / 16 holds W's columns in its lanes 0..M-1 and the
 // right-hand-side columns q (16 - M) ... in the lanes behind them.
 template <int M, int NRHS> struct GjLanes {
@@ -1546,6 +1548,14 @@ template <int M, int NRHS> struct GjLanes {
     __device__ __forceinline__ static bool rhs(int lane) { const int c = rhs_col(lane); return !wlane(lane) && c < NRHS; }
     // column of [W | right-hand sides] this lane builds (idle lanes duplicate the last right-hand side)
     __device__ __forceinline__ static int column(int lane) { return wlane(lane) ? (lane & 15) : (rhs(lane) ? M + rhs_col(lane) : M + NRHS - 1); }
+};
+// One column per lane across the whole wavefront (lane c < M: column c of W, lane M + c': right-hand side c'): the layout of the
+// v_readlane elimination gj_solve_cols, kept for the one configuration whose register budget the DPP form (replicated W columns in
+// every row, two extra asm operand sets) does not fit: the 4-player extended bicycle, 8 controls x 17 right-hand sides at 256 VGPRs
+template <int M, int NRHS> struct GjFlat {
+    static_assert(M + NRHS <= WAVE, "one column per lane");
+    __device__ __forceinline__ static bool rhs(int lane) { return lane >= M && lane < M + NRHS; }
+    __device__ __forceinline__ static int column(int lane) { return lane < M + NRHS ? lane : M + NRHS - 1; }
 };
 template <int M, int C>
 __device__ __forceinline__ void gj_dpp_pivot(double (&col)[M], int& sing) {
@@ -2492,10 +2502,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
             const double rdl = Rc[R::RD + yr];
             double a = Pr[n];
-            double pr_[n];
-#pragma unroll
-            for (int c = 0; c < n; c++) pr_[c] = Pr[c];
-            rowdot_dpp<n>(a, rdl, pr_);
+            rowdot_dpp_f<n>(a, rdl, [&](int c) { return Pr[c]; });
             if (!GFUSE && (tid & 15) < n) L.bw.t[yp * n + yr] = a;
             // g_c = ru_c + B[:,c]' y_i for the controls c of this row's player (c % P == i): the rows of y_i that column c of B touches are
             // shifts away inside the row, so lane 16 i + c finishes g_c here -- no second phase, no trip of y through LDS (BT_vec's expression)
@@ -2540,7 +2547,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // short sparse combination of row c of the extended V (lane < m: B column + R^ slot; lane < m+n: A column; lane m+n: g slot)
         // (lane layout of the DPP elimination: every 16-lane row carries W's columns in its lanes 0..m-1 and its share of the
         // n + 1 right-hand-side columns behind them, GjLanes)
-        using GL = GjLanes<m, n + 1>;
+        constexpr bool FLATGJ = C::MODEL == ALG_MODEL_BICYCLE && P == 4 && C::EXT;
+        using GL = typename std::conditional<FLATGJ, GjFlat<m, n + 1>, GjLanes<m, n + 1>>::type;
         const int cidx = GL::column(lane);                 // column of [W | V A_k | g] this lane builds
         const bool rhsl = GL::rhs(lane);                   // ... and whether it is a right-hand side (its solution column is used)
         double col[m];
@@ -2566,7 +2574,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         }
         ALG_PROF(4)
 #ifndef ALG_NO_GJ
-        sing |= gj_solve_cols_dpp<m>(col);
+        if constexpr (FLATGJ) sing |= gj_solve_cols<m>(col); else sing |= gj_solve_cols_dpp<m>(col);
 #endif
         ALG_PROF(5)
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
@@ -2710,10 +2718,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
         const int cl = fl < m ? fl : 0;
         double acc = Kl[n * m + cl];
-        double kv[n];
-#pragma unroll
-        for (int q = 0; q < n; q++) kv[q] = Kl[q * m + cl];
-        rowdot_dpp<n>(acc, dxr, kv);                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
+        rowdot_dpp_f<n>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
         const double duv = fl < m ? acc : 0.0;
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;

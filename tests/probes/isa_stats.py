@@ -8,6 +8,7 @@ sigs = {
  "k_record": "(Params, alg_record*)", "k_line_search": "(Params, double, const double*, double*, int*)",
  "k_newton_step": "(Params, int, int, alg_step_info*)",
  "k_ibr": "(Params, int, int, int, uint64_t, int, IbrOrder, double)",
+ "k_mpc_loop": "(Params, int, uint64_t, double*)",
 }
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.makedirs("/tmp/isa", exist_ok=True)

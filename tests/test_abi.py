@@ -102,3 +102,5 @@ def test_solver_kernels_of_the_shipped_library_do_not_spill(alg):
     for k, v in res.items():
         if k.startswith(("k_mpc_loop<", "k_ibr<", "k_direction<", "k_newton_step<")) and k not in allowed:
             assert v["vgpr_spill"] == 0, (k, v)
+    for k in allowed:                                               # ... and stays there (the DPP elimination once took it to 900 unnoticed)
+        assert res[k]["vgpr_spill"] <= 16, (k, res[k])

@@ -42,7 +42,7 @@ class alg_record(C.Structure):
 class alg_game_stats(C.Structure):
     _fields_ = [("status", C.c_int32), ("outer_iters", C.c_int32), ("newton_iters", C.c_int32),
                 ("records", C.c_int32), ("converged", C.c_int32), ("ls_failures", C.c_int32),
-                ("last", alg_record)]
+                ("refinements", C.c_int32), ("reserved", C.c_int32), ("last", alg_record)]
 
 
 class alg_step_info(C.Structure):
@@ -56,7 +56,7 @@ record_dtype = np.dtype([("outer", "<i4"), ("ls_j", "<i4"), ("alpha", "<f8"), ("
                          ("sta_vio", "<f8"), ("opt_vio", "<f8"), ("t_elap", "<f8")])
 game_stats_dtype = np.dtype([("status", "<i4"), ("outer_iters", "<i4"), ("newton_iters", "<i4"),
                              ("records", "<i4"), ("converged", "<i4"), ("ls_failures", "<i4"),
-                             ("last", record_dtype)])
+                             ("refinements", "<i4"), ("reserved", "<i4"), ("last", record_dtype)])
 step_info_dtype = np.dtype([("status", "<i4"), ("control_flow", "<i4"), ("ls_j", "<i4"),
                             ("ls_failed", "<i4"), ("alpha", "<f8"), ("delta", "<f8"),
                             ("rec", record_dtype)])
@@ -80,8 +80,9 @@ SIGNATURES = {
     "set_stream": (C.c_int, [_P, _P]),
     "set_waves_per_game": (C.c_int, [_P, C.c_int32]),
     "get_waves_per_game": (C.c_int, [_P, _I]),
-    "set_quad_team": (C.c_int, [_P, C.c_int32]),
-    "get_quad_team": (C.c_int, [_P, _I]),
+    "set_refinement": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double]),
+    "get_refinement": (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "get_direction_gate": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "set_x0": (C.c_int, [_P, _D]),
     "set_lqr": (C.c_int, [_P, _D, _D, _D, _D, C.c_int32]),
     "add_collision_cost": (C.c_int, [_P, _D, _D]),
@@ -99,6 +100,8 @@ SIGNATURES = {
     "add_spherical_collision_avoidance": (C.c_int, [_P, _D]),
     "add_wall3d_constraint": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D]),
     "add_cylinder_constraint": (C.c_int, [_P, C.c_int32, _D, _I, _D, _D]),
+    "add_wall3d_constraint_player": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D, _D, _D]),
+    "add_cylinder_constraint_player": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _I, _D, _D]),
     "get_con_len": (C.c_int, [_P, _I]),
     "set_traj": (C.c_int, [_P, C.c_int32, _D]),
     "get_traj": (C.c_int, [_P, C.c_int32, _D]),
@@ -245,14 +248,25 @@ class Batch:
         self.lib.check(self.lib.get_waves_per_game(self.h, C.byref(v)))
         return v.value
 
-    def set_quad_team(self, mode):
-        """-1 = automatic, 0 = one game per workgroup, 1 = four games per workgroup required (alg_set_quad_team)."""
-        self.lib.check(self.lib.set_quad_team(self.h, int(mode)))
+    def set_refinement(self, max_steps=None, tol=None, mu_tight=None):
+        """Iterative refinement of the Newton direction (alg_set_refinement): the opt-u rows of every direction are evaluated and the
+        direction is corrected (at most `max_steps` correction solves) while their row-wise backward error exceeds `tol` (relaxed up to
+        16 x while the game's largest penalty is below `mu_tight`); max_steps = 0 switches gate and refinement off.  None keeps a value."""
+        ms0, tol0, mu0 = self.get_refinement()
+        self.lib.check(self.lib.set_refinement(self.h, int(ms0 if max_steps is None else max_steps), float(tol0 if tol is None else tol),
+                                               float(mu0 if mu_tight is None else mu_tight)))
 
-    def get_quad_team(self):
-        v = C.c_int32()
-        self.lib.check(self.lib.get_quad_team(self.h, C.byref(v)))
-        return v.value
+    def get_refinement(self):
+        ms = C.c_int32(); tol = C.c_double(); mu = C.c_double()
+        self.lib.check(self.lib.get_refinement(self.h, C.byref(ms), C.byref(tol), C.byref(mu)))
+        return ms.value, tol.value, mu.value
+
+    def get_direction_gate(self):
+        """(B, 3): [max |rho|, row-wise backward error omega, largest row scale] of the opt-u rows of the last Newton direction
+        (alg_get_direction_gate)."""
+        out = np.zeros((self.B, 3))
+        self.lib.check(self.lib.get_direction_gate(self.h, _dptr(out)))
+        return out
 
     def set_stream(self, stream_ptr):
         self.lib.check(self.lib.set_stream(self.h, _P(stream_ptr)))
@@ -337,6 +351,19 @@ class Batch:
         p = _f64(np.asarray(p, dtype=np.float64).reshape(-1, 3))
         ax = np.ascontiguousarray(axis, dtype=np.int32)
         self.lib.check(self.lib.add_cylinder_constraint(self.h, len(p), _dptr(p), ax.ctypes.data_as(_I), _dptr(_f64(l, (len(p),))), _dptr(_f64(r, (len(p),)))))
+        self._refresh_con_len()
+
+    def add_wall3d_constraint_player(self, player, p1, p2, p3, v):
+        """add_wall_constraint!(game_con, i, walls::Vector{Wall3D}): player i (0-based) only."""
+        arrs = [_f64(np.asarray(a, dtype=np.float64).reshape(-1, 3)) for a in (p1, p2, p3, v)]
+        self.lib.check(self.lib.add_wall3d_constraint_player(self.h, int(player), len(arrs[0]), *[_dptr(a) for a in arrs]))
+        self._refresh_con_len()
+
+    def add_cylinder_constraint_player(self, player, p, axis, l, r):
+        """add_wall_constraint!(game_con, i, walls::Vector{CylinderWall}): player i (0-based) only."""
+        p = _f64(np.asarray(p, dtype=np.float64).reshape(-1, 3))
+        ax = np.ascontiguousarray(axis, dtype=np.int32)
+        self.lib.check(self.lib.add_cylinder_constraint_player(self.h, int(player), len(p), _dptr(p), ax.ctypes.data_as(_I), _dptr(_f64(l, (len(p),))), _dptr(_f64(r, (len(p),)))))
         self._refresh_con_len()
 
     # ---- data movement -----------------------------------------------------------------------

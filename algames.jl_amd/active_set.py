@@ -132,24 +132,34 @@ def collision_convals(game_con):
     if getattr(game_con, "_col_conval", None) is None:
         ps = game_con.probsize
         cv = {}
+        K = ps.N - 1
+        mk = lambda radius: types.SimpleNamespace(inds=list(range(2, ps.N + 1)), vals=np.zeros(K), λ=np.zeros(K),
+                                                  active=np.zeros(K, dtype=bool), jac=np.zeros((K, ps.n)), radius=float(radius))
         if game_con.collision_radius is not None:
             for i in range(1, ps.p + 1):
                 for j in range(1, ps.p + 1):
                     if j != i:
-                        K = ps.N - 1
-                        cv[(i, j)] = types.SimpleNamespace(inds=list(range(2, ps.N + 1)), vals=np.zeros(K), λ=np.zeros(K),
-                                                           active=np.zeros(K, dtype=bool), jac=np.zeros((K, ps.n)),
-                                                           radius=float(game_con.collision_radius[i - 1] + game_con.collision_radius[j - 1]))
+                        cv[(i, j)] = mk(game_con.collision_radius[i - 1] + game_con.collision_radius[j - 1])
+        # add_collision_avoidance!(game_con, i, j, radius) (constraints_methods.jl:5-19): single ordered pairs with their own radius
+        for (i, j), radius in sorted(getattr(game_con, "collision_pairs", {}).items()):
+            cv[(i, j)] = mk(radius)
         game_con._col_conval = cv
     return game_con._col_conval
+
+
+def _col_inds(game_con, i):
+    """State entries a CollisionConstraint of player i reads: px[i] (x, y), or pz[i][1:3] (x, y, z) for the spherical form
+    (constraints_methods.jl:13, 52)."""
+    ps = game_con.probsize
+    idx = ps.pz[i - 1][:3] if getattr(game_con, "spherical", False) else ps.px[i - 1]
+    return [a - 1 for a in idx]
 
 
 def evaluate(game_con, states):
     """evaluate!(game_con, traj) + jacobian! for the collision constraints (constraints_methods.jl:367-393):
     c = R^2 - |x[px_i] - x[px_j]|^2 at knots 2..N, d c / d x = -2 Δ on px_i, +2 Δ on px_j.  states: (N, n)."""
-    ps = game_con.probsize
     for (i, j), cv in collision_convals(game_con).items():
-        pi, pj = [a - 1 for a in ps.px[i - 1]], [a - 1 for a in ps.px[j - 1]]
+        pi, pj = _col_inds(game_con, i), _col_inds(game_con, j)
         d = states[1:, pi] - states[1:, pj]
         cv.vals[:] = cv.radius ** 2 - (d * d).sum(axis=1)
         cv.jac[:] = 0.0

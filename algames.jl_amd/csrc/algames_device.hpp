@@ -50,7 +50,7 @@ constexpr int MAXM = 32;
 constexpr int HIST_MAX = ALG_HIST_MAX;
 
 // Everything that is shared by the games of a handle; passed to kernels by value.
-constexpr int TC_LEN = 16;       // per-game control slots (G.tc): solver scalars 0..7, t_elap accumulator and start stamp 8, 9
+constexpr int TC_LEN = 32;       // per-game control slots (G.tc): solver scalars 0..7, t_elap accumulator and start stamp 8, 9, refinement gate 10..17
 struct Params {
     int model, p, d, N, n, m, mi, ni, S, b, traj_len, npair, col_len, ctl_len, con_len, B;
     double dt;
@@ -64,6 +64,9 @@ struct Params {
     unsigned ca_mask[MAXP];
     double umax[MAXM], umin[MAXM];
     int hist_max;
+    int refine_max;         // iterative refinement of the Newton direction: correction solves allowed per direction (0 = off)
+    double refine_tol;      // ... taken while the row-wise backward error of the opt-u rows exceeds this (alg_set_refinement)
+    double refine_mu;       // ... relaxed up to 16 x in proportion while the game's largest penalty stays below this
     int kscratch_len;       // per game doubles of gain scratch
     int rec_len;            // per game doubles of step records
     unsigned long long ibr_ctl_rows[MAXP];   // control-bound rows counted by control_violation(game_con, pdtraj, i) (violations.jl:69-82)
@@ -76,6 +79,8 @@ struct Params {
     // constraints_methods.jl:121-139, 161-187): bit w of wall_mask[i] = table entry w constrains player i.  A row whose bit is
     // clear evaluates to c = 0 with a zero Jacobian -- exactly inert in the AL terms, the violations and the dual update.
     unsigned wall_mask[MAXP], circ_mask[MAXP];
+    // the same for the 3-D sets: add_wall_constraint!(game_con, i, walls::Vector{Wall3D}) / (..., i, ::Vector{CylinderWall}) (constraints_methods.jl:208-247, 256-299)
+    unsigned wall3_mask[MAXP], cyl_mask[MAXP];
     // ---- device memory of the handle (filled in by the host; see the "Per-game data view" section) ----------------------
     // main arena: B x stride doubles; one contiguous, 128-byte aligned chunk per game holding every per-game array at the
     // offsets below (doubles, multiples of 16): [pdtraj | trial | delta | x0 | res | rec | kgain | tcache | stats | mpc totals]
@@ -124,13 +129,10 @@ __device__ __forceinline__ CPR phase_params(CPR pr) { return *(const ALG_AS4 Par
 // NW_ > 1: NW_ wavefronts work on one game (workgroup = NW_ x 64 threads; small batches that leave most SIMDs empty): the
 // streaming phases (assemble pass, trajectory updates, dual updates) are spread over all of them, the serial Newton-direction
 // sweeps run on wavefront 0.  NW_ = 1 is the one-game-per-wavefront kernel of the large batches.
-// GW_ = 4: quad-team kernels (algames_qt.hpp): four games per workgroup, one wavefront each; the Newton direction is a collective
-// of the four wavefronts.  Only meaningful in the ALG_QT translation unit.
-template <int MODEL_, int P_, int D_, int EXT_ = 0, int NW_ = 1, int GW_ = 1>
+template <int MODEL_, int P_, int D_, int EXT_ = 0, int NW_ = 1>
 struct Cfg {
     static constexpr int MODEL = MODEL_, P = P_, D = D_;
     static constexpr int NW = NW_, NT = NW_ * 64;          // wavefronts / threads per game
-    static constexpr int GW = GW_;                         // games per workgroup
     static constexpr bool EXT = EXT_ != 0;
     static constexpr bool POS = (P_ > 1) || EXT;     // position blocks (pair / wall / circle terms) present in Q^_i
     // QuadrotorGame (quadrotor.jl:20-46): dense 12 x 12 / 12 x 4 Jacobian blocks per player, n up to 48
@@ -193,16 +195,9 @@ template <class C> __device__ __forceinline__ const double* zstate(const double*
 
 // ---- thread index / synchronisation of ONE game -------------------------------------------------------------------------------
 // Every kernel runs one game per workgroup (one wavefront, or a team of Cfg::NW), so the game's thread index is the workgroup's
-// and its barrier is the workgroup barrier -- except in the quad-team translation unit (ALG_QT, algames_qt.hpp): there a
-// 256-thread workgroup carries FOUR games, one wavefront each, which meet only inside the collective Newton direction; the
-// per-game code sees its own 64 lanes and synchronises wave-locally (the fences of a barrier without the s_barrier).
-#ifdef ALG_QT
-__device__ __forceinline__ int game_tid() { return (int)(threadIdx.x & 63u); }
-__device__ __forceinline__ void game_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-#else
+// and its barrier is the workgroup barrier.
 __device__ __forceinline__ int game_tid() { return (int)threadIdx.x; }
 __device__ __forceinline__ void game_sync() { __syncthreads(); }
-#endif
 // ---- wave reductions ---------------------------------------------------------------------------
 // Opaque copy of the lane id: keeps per-lane role / address computations of a phase from being hoisted out of the
 // solver's outer loops (where every phase's invariants would be live at once).
@@ -243,6 +238,13 @@ __device__ __forceinline__ int wave_or(int v) {
     { const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = a[0] | a[1]; }
     v |= dpp_i32<0x128>(v); v |= dpp_i32<0x124>(v); v |= dpp_i32<0x122>(v); v |= dpp_i32<0x121>(v);
     return v;
+}
+
+// wave-uniform scalars live in SGPRs
+__device__ __forceinline__ double uni(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
 }
 
 // ---- wavefront team of one game (Cfg::NW) ----------------------------------------------------------------------------------
@@ -1024,8 +1026,17 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                     }
                     if constexpr (PD == 3) {
                         const double* W3 = ext_walls3(pr, pr.extc); const double* Yc = ext_cyls(pr, pr.extc);
-                        for (int wq = 0; wq < pr.nwall3; wq++) { double g[3]; const double c = wall3_val(W3, wq, xi, g); al_row(ext_wall3_row(pr, i, k, wq), c, g); }
-                        for (int cq = 0; cq < pr.ncyl; cq++) { double g[3]; const double c = cyl_val(Yc, cq, xi, g); al_row(ext_cyl_row(pr, i, k, cq), c, g); }
+                        const unsigned w3mask = pr.wall3_mask[i], cymask = pr.cyl_mask[i];
+                        for (int wq = 0; wq < pr.nwall3; wq++) {
+                            double g[3]; const double on = (double)((w3mask >> wq) & 1u);
+                            const double c = on * wall3_val(W3, wq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
+                            al_row(ext_wall3_row(pr, i, k, wq), c, g);
+                        }
+                        for (int cq = 0; cq < pr.ncyl; cq++) {
+                            double g[3]; const double on = (double)((cymask >> cq) & 1u);
+                            const double c = on * cyl_val(Yc, cq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
+                            al_row(ext_cyl_row(pr, i, k, cq), c, g);
+                        }
                     }
                 }
 #pragma unroll
@@ -2913,6 +2924,193 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     return __builtin_amdgcn_readfirstlane(wave_or(bad)) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;     // scalar: the solver's control flow stays on the SALU
 }
 
+// ================================================================================================
+// Iterative refinement of the Newton direction (round 4; replaces the backward stability of `lu(core.jac)`, solver_methods.jl:87).
+//
+// The structured elimination is a block LU without pivoting across blocks: stable only up to the conditioning of its pivot blocks
+// R^ + B' P B (controls acting through two integrators, penalties at their ceiling), where UMFPACK's partial pivoting is backward
+// stable regardless.  Which rows of J d = -res can carry a residual is known, though: the forward sweep evaluates the dynamics rows
+// (dx_{k+1} = A dx_k + B du_k + rd) and the costate sweep the opt-x rows (dlambda_k = Q^ dx_{k+1} + A' dlambda_{k+1} + rx) on the final
+// numbers, so both hold to rounding whatever happened to the gains; every error of the elimination surfaces in the opt-u rows
+//     rho_{c,k} = R^_c du_{c,k} + B_k[:,c]' dlambda_{i(c),k} + ru_{c,k}.
+// dir_urow_residual evaluates them (one flat pass over (step, control)) together with lower bounds of |J|_inf and |d|_inf; when the
+// normwise backward error  max |rho| / (|J| |d|)  exceeds Params::refine_tol the direction is corrected by e from  J e = -(0, rho, 0)
+// -- the same elimination on the step records with ru <- rho, rx <- 0, rd <- 0 -- written to the (dead) trial buffer and added.  One
+// step of this fixed-precision refinement makes the solve backward stable (Skeel) as long as the elimination has any accuracy at
+// all; at most Params::refine_max steps are taken.  Well-conditioned solves pay the gate (one pass over du, part of dlambda and
+// 2 m + a few record entries per step), nothing else.
+// ================================================================================================
+struct DirGate { double rho, omega, smax; };      // max |rho|, row-wise max |rho_c| / (|J_c| |d| + |ru_c|), max row scale
+template <class C, int K> __device__ __forceinline__ void team_max(double (&v)[K]) {
+#pragma unroll
+    for (int q = 0; q < K; q++) v[q] = wave_max(v[q]);
+    if constexpr (C::NW > 1) {
+        __shared__ double tmx[C::NW][K];
+        const int w = game_tid() >> 6, l = game_tid() & 63;
+        if (l == 0) {
+#pragma unroll
+            for (int q = 0; q < K; q++) tmx[w][q] = v[q];
+        }
+        game_sync();
+#pragma unroll
+        for (int q = 0; q < K; q++) { double r = tmx[0][q]; for (int x = 1; x < C::NW; x++) r = fmax(r, tmx[x][q]); v[q] = r; }
+        game_sync();
+    }
+#pragma unroll
+    for (int q = 0; q < K; q++) v[q] = uni(v[q]);
+}
+// WRITE = false: the gate statistics of the direction in G.z(2) against the step records: one flat pass over the (step, control) pairs,
+// five loads each.  WRITE = true: also turns the records into the right-hand side of the correction system (ru <- rho, rx <- 0, rd <- 0).
+template <class C, bool IBR, bool WRITE>
+__device__ DirGate dir_urow_residual(CPR pr0, const Game& G0, int ip) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    constexpr int n = C::n, m = C::m, P = C::P;
+    using R = Rec<C>;
+    const int N = phase_int(pr.N), tid = phase_lane();
+    const double dt = phase_f64(pr.dt);
+    const double* __restrict__ dz = G.z(2);
+    double* __restrict__ recs = G.rec(pr);
+    // the pair with the largest ratio |rho| / scale is tracked by cross-multiplication: one division per lane at the end
+    double rho_m = 0.0, s_m = 0.0, wr = 0.0, ws = 1.0;
+    for (int e = tid; e < (N - 1) * m; e += C::NT) {
+        const int k = e / m, c = e % m, i = c % P;
+        double* Rk = recs + (size_t)k * R::LEN;
+        const double* dl = dz + n + hl<C>(k, i);
+        const double du = dz[n + hu<C>(k, 0) + uoff<C>(c)];
+        const double rh = Rk[R::RHAT + c], ru = Rk[R::RU + c];
+        const double bl = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return dl[rr]; }, c);
+        // |B[:,c]|' |dlambda| from below: the coefficients keep their signs (exact for the double integrator, whose B is non-negative)
+        const double bla = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return fabs(dl[rr]); }, c);
+        double rho = fma(rh, du, ru) + bl;
+        if (IBR && i != ip) rho = 0.0;                                  // unit rows of the other players (du_c = 0)
+        const double sc = fabs(rh * du) + fabs(ru) + fabs(bla);         // row scale |J_c| |d| + |ru_c|
+        const double ar = fabs(rho);
+        if (ar * ws > wr * sc) { wr = ar; ws = sc; }
+        rho_m = fmax(rho_m, ar); s_m = fmax(s_m, sc);
+        if constexpr (WRITE) Rk[R::RU + c] = rho;
+    }
+    if constexpr (WRITE) {
+        for (int e = tid; e < (N - 1) * P * n; e += C::NT) recs[(size_t)(e / (P * n)) * R::LEN + R::RX + e % (P * n)] = 0.0;
+        for (int e = tid; e < (N - 1) * n; e += C::NT) recs[(size_t)(e / n) * R::LEN + R::RD + e % n] = 0.0;
+    }
+    double v[3] = {rho_m, wr / fmax(ws, 1e-300), s_m};
+    team_max<C, 3>(v);
+    return DirGate{v[0], v[1], v[2]};
+}
+// d <- d + e (e in the trial buffer); returns sum |d_primal| (Delta_step), max |d| and the non-finite flag of the corrected direction;
+// restores x_1 of the trial buffer, which the correction's forward sweep zeroed.
+template <class C>
+__device__ void dir_add_correction(CPR pr0, const Game& G0, double& pl1, double& dn, int& bad) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    constexpr int n = C::n, m = C::m;
+    const int S = phase_int(pr.S), tid = phase_lane();
+    double* __restrict__ dz = G.z(2); double* __restrict__ ez = G.z(1); const double* __restrict__ z0 = G.z(0);
+    double s = 0.0, mx = 0.0; int nf = 0;
+    for (int e = tid; e < S; e += C::NT) {
+        const double v = dz[n + e] + ez[n + e];
+        dz[n + e] = v;
+        if (e % C::b < n + m) s += fabs(v);
+        mx = fmax(mx, fabs(v)); nf |= !isfinite(v);
+    }
+    if (tid < n) ez[tid] = z0[tid];
+    s = wave_sum(s); nf = wave_or(nf);
+    if constexpr (C::NW > 1) {
+        __shared__ double tad[C::NW][2];
+        const int w = game_tid() >> 6, l = game_tid() & 63;
+        if (l == 0) { tad[w][0] = s; tad[w][1] = (double)nf; }
+        game_sync();
+        s = 0.0; nf = 0;
+        for (int x = 0; x < C::NW; x++) { s += tad[x][0]; nf |= (int)tad[x][1]; }
+        game_sync();
+    }
+    double v[1] = {mx};
+    team_max<C, 1>(v);
+    pl1 = uni(s); dn = v[0]; bad = __builtin_amdgcn_readfirstlane(nf);
+}
+// Largest penalty of the game's constraint rows (ALConVal mu): the scale by which the augmented-Lagrangian terms can worsen the
+// conditioning of the KKT system.  Only evaluated for directions whose backward error falls between the two tolerances.
+template <class C>
+__device__ double con_mu_max(CPR pr0, const Game& G0) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    const double* __restrict__ mu = G.mu(pr);
+    double mx = 0.0;
+    for (int e = phase_lane(); e < pr.con_len; e += C::NT) mx = fmax(mx, mu[e]);
+    double v[1] = {mx};
+    team_max<C, 1>(v);
+    return v[0];
+}
+// Newton direction with the refinement gate: what the solver calls.  Every thread of the game's workgroup calls it (team kernels
+// included) and leaves with the same status / sum |d_primal|.
+template <class C, bool IBR = false>
+__device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>& L, double reg, int ip, double* primal_l1) {
+    // Nothing but the pass counter is live across the sweeps: sum |d_primal| and the two norms of the gate wait in the game's control
+    // slots (HBM), the output view is rebuilt from the pass counter.
+    constexpr int TC_PL1 = 10, TC_RHO = 13, TC_OMEGA = 14, TC_SMAX = 15;       // 13 .. 15: alg_get_direction_gate
+    constexpr int TC_OMCUR = 16, TC_RHOCUR = 17;                                                      // gate state between correction solves
+    static_assert(TC_RHOCUR < TC_LEN, "per-game control slots");
+    int st = ALG_STATUS_OK;
+    for (int pass = 0;; pass++) {
+        CPR pr = phase_params(pr0);
+        Game Gd = G0.fresh();                          // view whose delta slot is the sweeps' output buffer:
+        if (pass > 0) Gd.zo[2] = Gd.zo[1];             // a correction goes to the trial buffer (dead until the line search rewrites it)
+        double pl1s = 0.0;
+        if constexpr (C::NW == 1) st = newton_direction<C, IBR>(pr, Gd, L.d, reg, ip, &pl1s);          // solver_methods.jl:84-88
+        else {
+            // team: the serial sweeps run on wavefront 0; status and sum |d_primal| reach the other wavefronts through LDS
+            __shared__ double dir_out[2];
+            game_sync();
+            // teams of >= 4: backward sweep on the whole team, forward / costate on wavefront 0; team of 2: wavefront 0 does it all
+            if (C::NW >= 4 || team_wave<C>() == 0) st = newton_direction<C, IBR>(pr, Gd, L.d, reg, ip, &pl1s);
+            if (game_tid() == 0) { dir_out[0] = (double)st; dir_out[1] = pl1s; }
+            game_sync();
+            st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1s = uni(dir_out[1]);
+        }
+        const int rmax = phase_int(pr.refine_max);
+        if (pass == 0 && rmax <= 0) { if (primal_l1) *primal_l1 = pl1s; return st; }      // gate and refinement off
+        double* tc = G0.fresh().tc(pr);
+        if (pass == 0 && phase_lane() == 0) tc[TC_PL1] = pl1s;
+        if (st != ALG_STATUS_OK) break;
+        game_sync();                                   // the direction is in global memory
+        const DirGate gt = dir_urow_residual<C, IBR, false>(pr, Gd, ip);
+        // backward error of the whole direction: the row-wise omega of the first solve; after a correction, the residual of the correction
+        // system IS the new residual of the whole system, so omega contracts like max |rho| did
+        double omega;
+        if (pass == 0) {
+            omega = gt.omega;
+            if (phase_lane() == 0) { tc[TC_RHO] = gt.rho; tc[TC_OMEGA] = gt.omega; tc[TC_SMAX] = gt.smax; tc[TC_OMCUR] = gt.omega; tc[TC_RHOCUR] = gt.rho; }
+        } else {
+            int bad = 0; double pl1, dn;
+            dir_add_correction<C>(pr, G0, pl1, dn, bad);
+            const double rho_prev = tc[TC_RHOCUR];
+            omega = tc[TC_OMCUR] * (gt.rho / fmax(rho_prev, 1e-300));
+            game_sync();                               // every lane has read the slots
+            if (phase_lane() == 0) { tc[TC_PL1] = pl1; tc[TC_OMCUR] = omega; tc[TC_RHOCUR] = gt.rho; }
+            game_sync();
+            if (bad) { st = ALG_STATUS_SINGULAR; break; }
+        }
+        // The tolerance follows the conditioning the penalties bring: a forward error target delta needs a backward error of delta / cond(J), and
+        // cond(J) grows with the largest penalty.  tol applies from mu_max >= refine_mu on; below, it is relaxed in proportion, at most 16 x.
+        // (Most directions are far below tol: the penalties are only looked at inside the band.)
+        const double tol = phase_f64(pr.refine_tol);
+        if (!(uni(omega) > tol) || pass >= rmax) break;
+        if (!(uni(omega) > 16.0 * tol)) {
+            const double mumax = con_mu_max<C>(pr, G0);
+            const double relax = fmin(fmax(phase_f64(pr.refine_mu) / fmax(mumax, 1e-300), 1.0), 16.0);
+            if (!(uni(omega) > relax * tol)) break;
+        }
+        // rhs of the correction system from the buffer that holds the latest solve (d itself, or the previous correction)
+        dir_urow_residual<C, IBR, true>(pr, Gd, ip);
+        if (phase_lane() == 0) G0.fresh().st(pr)->refinements += 1;
+        game_sync();
+    }
+    game_sync();
+    if (primal_l1) *primal_l1 = uni(G0.fresh().tc(phase_params(pr0))[TC_PL1]);
+    return st;
+}
+
 // residual_jacobian! + regularize_residual_jacobian! into a dense S x S column-major matrix (global_quantities.jl:109-193).
 // Parity / inspection entry point; built from the same step records and block functions the solver uses.
 template <class C>
@@ -2956,12 +3154,6 @@ __device__ void jacobian_dense(CPR pr, const Game& G, double reg, double* J) {
 // ================================================================================================
 // Solver control flow (solver_methods.jl:5-125), per game
 // ================================================================================================
-// wave-uniform scalars live in SGPRs
-__device__ __forceinline__ double uni(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
-    return __hiloint2double(hi, lo);
-}
 
 // record! (statistics.jl:44-57): unregularised residual at pdtraj; also leaves the step records (with the Jacobian
 // regularisation jreg folded into R^) for the Newton direction and refreshes G.vals(pr).  The record is pushed to the
@@ -3055,13 +3247,11 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
 // 10.2 -> 10.7 M/s, C4 10.6 -> 11.1 M/s in A/B runs; rotating every second iteration, every time step of the backward sweep, or twice per
 // iteration all measured worse than once per inner iteration).  Dispatch round = blockIdx / (number of SIMDs: 256 CUs x 4).
 template <class C> __device__ __forceinline__ void rotate_priority(int it) {
-    if constexpr (C::NW == 1 && C::GW == 1) {
+    if constexpr (C::NW == 1) {
         const int q = ((int)(blockIdx.x >> 10) + it) & 3;
         if (q == 0) __builtin_amdgcn_s_setprio(0); else if (q == 1) __builtin_amdgcn_s_setprio(1); else if (q == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     }
 }
-// quad-team Newton direction of one game (algames_qt.hpp; only instantiated for Cfg::GW > 1)
-template <class C> __device__ int qt_direction_call(CPR pr, Lds<C>& mine, int want, double reg, double* primal_l1);
 // inner_iteration (solver_methods.jl:67-103).  Returns status (bits 0-7) | control_flow << 8; step details go to
 // the history record / *info (lane 0).  `cache` (optional) carries an accepted trial's statistics to the next call.
 template <class C>
@@ -3086,18 +3276,7 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     if (rs.opt < o.eps_opt) return finish(ALG_STATUS_OK, 1) | (1 << 16);  // :80-82 (bit 16: pdtraj untouched since this record!)
     double pl1; int st;
     LSP_T0 LSP_COUNT(28)
-    if constexpr (C::GW > 1) st = qt_direction_call<C>(pr, L, 1, reg, &pl1);               // collective of the workgroup's four games
-    else if constexpr (C::NW == 1) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);    // :84-88
-    else {
-        // team: the serial sweeps run on wavefront 0; status and sum |d_primal| reach the other wavefronts through LDS
-        __shared__ double dir_out[2];
-        game_sync();
-        // teams of >= 4: backward sweep on the whole team, forward / costate on wavefront 0; team of 2: wavefront 0 does it all
-        if (C::NW >= 4 || team_wave<C>() == 0) st = newton_direction<C>(pr, G, L.d, reg, -1, &pl1);
-        if (game_tid() == 0) { dir_out[0] = (double)st; dir_out[1] = pl1; }
-        game_sync();
-        st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1 = uni(dir_out[1]);
-    }
+    st = refined_direction<C>(pr, G, L, reg, -1, &pl1);                                    // :84-88
     LSP(26)
     if (st != ALG_STATUS_OK) return finish(st, 1);
     game_sync();
@@ -3190,7 +3369,8 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
                     const int cnt = w3 ? pr.nwall3 : pr.ncyl, q = e2 % cnt; k = (e2 / cnt) % K; i = e2 / (cnt * K);
                     const double* x = zstate<C>(z, k + 1);
                     const double pos[3] = {x[i], x[P + i], x[2 * P + i]}; double g[3];
-                    c = w3 ? wall3_val(ext_walls3(pr, pr.extc), q, pos, g) : cyl_val(ext_cyls(pr, pr.extc), q, pos, g);
+                    const double on = (double)(((w3 ? pr.wall3_mask[i] : pr.cyl_mask[i]) >> q) & 1u);
+                    c = on * (w3 ? wall3_val(ext_walls3(pr, pr.extc), q, pos, g) : cyl_val(ext_cyls(pr, pr.extc), q, pos, g));
                 }
             }
             const int ci = e0 + e;
@@ -3396,7 +3576,7 @@ __device__ int ibr_inner_iteration(CPR pr, const Game& G, Lds<C>& L, int& LS_cou
     Delta = 0.0;
     if (rs.nonfinite) { iter_clock_stop(pr, G); return ALG_STATUS_NAN | (1 << 8); }
     if (rs.opt < o.eps_opt) { iter_clock_stop(pr, G); return ALG_STATUS_OK | (1 << 8); }   // :245-247
-    const int st = newton_direction<C, true>(pr, G, L.d, reg, ip);                  // :249-252
+    const int st = refined_direction<C, true>(pr, G, L, reg, ip, nullptr);          // :249-252
     if (st != ALG_STATUS_OK) { iter_clock_stop(pr, G); return st | (1 << 8); }
     game_sync();
     int j = 1; double alpha = 1.0;                                                  // ibr_line_search (:270-289)
@@ -3470,7 +3650,7 @@ __device__ void ibr_newton_solve(CPR pr, const Game& G, Lds<C>& L, bool single, 
                                  int ibr_iter, const IbrOrder& order, double delta_min) {
     const int lane = game_tid();
     if (!single) {
-        if (lane == 0) { alg_game_stats z{}; *G.st(pr) = z; G.tc(pr)[6] = 0.0; }             // reset!(prob.stats)
+        if (lane == 0) { alg_game_stats z{}; *G.st(pr) = z; G.tc(pr)[6] = 0.0; G.tc(pr)[TC_TELAP] = 0.0; }             // reset!(prob.stats); the first record carries t_elap = 0
         if (init) init_traj<C>(pr, G, G.z(0), game_id, true);
         else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
         game_sync();

@@ -1,7 +1,6 @@
 // algames_hip.hip -- kernels and the C ABI (include/algames_hip.h) of libalgames_hip.so.
 // gfx950 only.  One workgroup (= one wavefront) per game; see algames_device.hpp.
 #include "algames_kernels.hpp"
-#include "algames_qt_launch.h"
 
 #include <cmath>
 #include <cstdio>
@@ -60,9 +59,11 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.ctl_len = 2 * p.m * (p.N - 1);
     p.con_len = p.col_len + p.ctl_len;
     p.ext = (a.model == ALG_MODEL_BICYCLE) ? 1 : 0;                      // the bicycle kernels are EXT instantiations
-    for (int i = 0; i < MAXP; i++) p.wall_mask[i] = p.circ_mask[i] = 0xffffffffu;
+    for (int i = 0; i < MAXP; i++) p.wall_mask[i] = p.circ_mask[i] = p.wall3_mask[i] = p.cyl_mask[i] = 0xffffffffu;
     p.ca_dim = 2;
     p.hist_max = HIST_MAX;
+    p.refine_max = 2; p.refine_tol = 0x1p-34; p.refine_mu = 1.6e5;
+    if (const char* e = getenv("ALGAMES_REFINE_STEPS")) p.refine_max = std::max(0, std::min(8, atoi(e)));      // A/B runs of whole test suites (alg_set_refinement otherwise)                             // alg_set_refinement
     p.kscratch_len = (p.N - 1) * p.m * std::max(p.n + 1, 16);            // gains m x (n + 1) per step; the quad-team kernels store rows of 16
     {   // Rec<C>::LEN of the EXT instantiation (the base one is p n shorter; the buffer is sized for either)
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : (p.model == ALG_MODEL_QUADROTOR) ? 204 * p.p : 0;
@@ -121,7 +122,6 @@ struct Handle {
     double* d_extc = nullptr;
     std::vector<double> extc;     // host copy of pr.extc
     int waves_per_game = 0;       // 0 = automatic (alg_set_waves_per_game)
-    int quad_team = -1;           // -1 = automatic, 0 = off, 1 = required (alg_set_quad_team)
     long long records_bound = 0;        // upper bound of the records the Statistics history holds since its last reset (one per record!)
     void* d_scratch = nullptr;    // grow-only scratch of the inspection entry points (dense Jacobians, MPC state logs)
     size_t scratch_bytes = 0;
@@ -316,17 +316,9 @@ int team_width(const Handle* hd) {
 #undef X
     return hd->waves_per_game > 1 ? -1 : best;
 }
-// Quad-team shape (algames_qt.hip).  Measured 3-6 % slower than the one-wavefront kernels at 4096-16384 games (DESIGN.md section
-// 10), so "automatic" means off unless ALGAMES_QT=1; alg_set_quad_team(h, 1) selects it explicitly.
-bool quad_team_on(const Handle* hd) {
-    if (hd->quad_team == 0 || !alg_qt_supported(hd->pr) || team_width(hd) != 1) return false;
-    if (hd->quad_team < 0) { const char* e = getenv("ALGAMES_QT"); return e && e[0] == '1'; }
-    return true;
-}
 int launch_newton_solve(Handle* h, int init, uint64_t game_id0) {
     const int nw = team_width(h);
     if (nw < 0) return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration");
-    if (quad_team_on(h)) { alg_qt_launch_newton_solve(h->pr, h->stream, init, game_id0); return launch_check("k_newton_solve_qt"); }
     if (nw == 1) { LAUNCH(k_newton_solve, h->pr, init, game_id0); return ALG_OK; }
     const Params& pr = h->pr; bool done = false;
 #define X(M, P, D, E, W) if (!done && nw == (W) && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                   \
@@ -488,17 +480,15 @@ int alg_set_waves_per_game(alg_handle* h, int32_t nw) {
     if (team_width(H) < 0) { H->waves_per_game = prev; return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration"); }
     return ALG_OK;
 }
-int alg_set_quad_team(alg_handle* h, int32_t mode) {
-    NEED_HANDLE("alg_set_quad_team");
-    if (mode < -1 || mode > 1) return fail(ALG_ERR_ARG, "alg_set_quad_team: -1 (automatic), 0 (off) or 1 (required)");
-    const int prev = H->quad_team;
-    H->quad_team = mode;
-    if (mode == 1 && !quad_team_on(H)) { H->quad_team = prev; return fail(ALG_ERR_ARG, "alg_set_quad_team: the quad-team kernels need the 3-player planar double integrator without extended constraints, a batch that is a multiple of four and one wavefront per game"); }
+int alg_set_refinement(alg_handle* h, int32_t max_steps, double tol, double mu_tight) {
+    NEED_HANDLE("alg_set_refinement");
+    if (max_steps < 0 || max_steps > 8 || !(tol >= 0.0) || !(mu_tight >= 0.0)) return fail(ALG_ERR_ARG, "alg_set_refinement: 0 <= max_steps <= 8, tol >= 0, mu_tight >= 0");
+    H->pr.refine_max = max_steps; H->pr.refine_tol = tol; H->pr.refine_mu = mu_tight;
     return ALG_OK;
 }
-int alg_get_quad_team(alg_handle* h, int32_t* on) {
-    if (!h || !on) return fail(ALG_ERR_ARG, "alg_get_quad_team: null argument");
-    *on = quad_team_on(H) ? 1 : 0; return ALG_OK;
+int alg_get_refinement(alg_handle* h, int32_t* max_steps, double* tol, double* mu_tight) {
+    if (!h || !max_steps || !tol || !mu_tight) return fail(ALG_ERR_ARG, "alg_get_refinement: null argument");
+    *max_steps = H->pr.refine_max; *tol = H->pr.refine_tol; *mu_tight = H->pr.refine_mu; return ALG_OK;
 }
 int alg_get_waves_per_game(alg_handle* h, int32_t* nw) {
     if (!h || !nw) return fail(ALG_ERR_ARG, "alg_get_waves_per_game: null argument");
@@ -677,6 +667,27 @@ static int add_table_entries(int F, int MAXE, Handle* hd, const char* who, doubl
     ntab = n2;
     return ext_commit(hd);
 }
+// the same for tables that keep an entry's ES doubles together (3-D walls: 12 per wall, cylinders: 6 per cylinder); `rows` = the new
+// entries in that layout
+static int add_table_rows(int ES, int MAXE, Handle* hd, const char* who, double* T, const double* rows, int cnt, int player, int& ntab, unsigned* mask) {
+    std::vector<double> tmp(T, T + ES * MAXE); unsigned m2[MAXP];
+    for (int i = 0; i < MAXP; i++) m2[i] = ntab == 0 ? 0u : (mask[i] == 0xffffffffu ? (ntab >= 32 ? 0xffffffffu : (1u << ntab) - 1u) : mask[i]);
+    int n2 = ntab;
+    for (int w = 0; w < cnt; w++) {
+        int at = -1;
+        for (int e = 0; e < n2 && at < 0; e++) { bool same = true; for (int f = 0; f < ES; f++) same &= (tmp[ES * e + f] == rows[ES * w + f]); if (same) at = e; }
+        if (at < 0) {
+            if (n2 >= MAXE) return fail(ALG_ERR_ARG, std::string(who) + ": more distinct entries than the table holds (ALG_MAX_WALLS / ALG_MAX_CIRCLES)");
+            at = n2++;
+            for (int f = 0; f < ES; f++) tmp[ES * at + f] = rows[ES * w + f];
+        }
+        m2[player] |= 1u << at;
+    }
+    for (int e = 0; e < ES * MAXE; e++) T[e] = tmp[e];
+    for (int i = 0; i < MAXP; i++) mask[i] = m2[i];
+    ntab = n2;
+    return ext_commit(hd);
+}
 int alg_add_wall_constraint_player(alg_handle* h, int32_t player, int32_t nw, const double* x1, const double* y1, const double* x2, const double* y2, const double* xv, const double* yv) {
     if (!h) return fail(ALG_ERR_ARG, "alg_add_wall_constraint_player: null handle");
     Params& p = H->pr;
@@ -731,7 +742,20 @@ int alg_add_wall3d_constraint(alg_handle* h, int32_t nw, const double* p1, const
     double* W = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES;
     for (int w = 0; w < nw; w++) for (int a = 0; a < 3; a++) { W[12 * w + a] = p1[3 * w + a]; W[12 * w + 3 + a] = p2[3 * w + a]; W[12 * w + 6 + a] = p3[3 * w + a]; W[12 * w + 9 + a] = v[3 * w + a]; }
     p.nwall3 = nw;
+    for (int i = 0; i < MAXP; i++) p.wall3_mask[i] = 0xffffffffu;     // one set, every player
     return ext_commit(H);
+}
+// add_wall_constraint!(game_con, i, walls::Vector{Wall3D}) (constraints_methods.jl:208-247): table + per-player mask like the 2-D form
+int alg_add_wall3d_constraint_player(alg_handle* h, int32_t player, int32_t nw, const double* p1, const double* p2, const double* p3, const double* v) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_wall3d_constraint_player: null handle");
+    Params& p = H->pr;
+    if (player < 0 || player >= p.p) return fail(ALG_ERR_ARG, "alg_add_wall3d_constraint_player: bad player index");
+    if (nw < 0 || (nw > 0 && (!p1 || !p2 || !p3 || !v))) return fail(ALG_ERR_ARG, "alg_add_wall3d_constraint_player: bad argument");
+    if (int rc = need_3d(H, "alg_add_wall3d_constraint_player")) return rc;
+    std::vector<double> rows(12 * (size_t)nw);
+    for (int w = 0; w < nw; w++) for (int a = 0; a < 3; a++) { rows[12 * w + a] = p1[3 * w + a]; rows[12 * w + 3 + a] = p2[3 * w + a]; rows[12 * w + 6 + a] = p3[3 * w + a]; rows[12 * w + 9 + a] = v[3 * w + a]; }
+    double* W = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES;
+    return add_table_rows(12, ALG_MAX_WALLS, H, "alg_add_wall3d_constraint_player", W, rows.data(), nw, player, p.nwall3, p.wall3_mask);
 }
 int alg_add_cylinder_constraint(alg_handle* h, int32_t nc, const double* pp, const int32_t* axis, const double* l, const double* r) {
     if (!h) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint: null handle");
@@ -742,7 +766,21 @@ int alg_add_cylinder_constraint(alg_handle* h, int32_t nc, const double* pp, con
     double* Y = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES + 12 * ALG_MAX_WALLS;
     for (int c = 0; c < nc; c++) { for (int a = 0; a < 3; a++) Y[6 * c + a] = pp[3 * c + a]; Y[6 * c + 3] = (double)axis[c]; Y[6 * c + 4] = l[c]; Y[6 * c + 5] = r[c]; }
     p.ncyl = nc;
+    for (int i = 0; i < MAXP; i++) p.cyl_mask[i] = 0xffffffffu;       // one set, every player
     return ext_commit(H);
+}
+// add_wall_constraint!(game_con, i, walls::Vector{CylinderWall}) (constraints_methods.jl:256-299)
+int alg_add_cylinder_constraint_player(alg_handle* h, int32_t player, int32_t nc, const double* pp, const int32_t* axis, const double* l, const double* r) {
+    if (!h) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint_player: null handle");
+    Params& p = H->pr;
+    if (player < 0 || player >= p.p) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint_player: bad player index");
+    if (nc < 0 || (nc > 0 && (!pp || !axis || !l || !r))) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint_player: bad argument");
+    if (int rc = need_3d(H, "alg_add_cylinder_constraint_player")) return rc;
+    for (int c = 0; c < nc; c++) if (axis[c] < 0 || axis[c] > 2) return fail(ALG_ERR_ARG, "alg_add_cylinder_constraint_player: axis must be 0 (:x), 1 (:y) or 2 (:z)");
+    std::vector<double> rows(6 * (size_t)nc);
+    for (int c = 0; c < nc; c++) { for (int a = 0; a < 3; a++) rows[6 * c + a] = pp[3 * c + a]; rows[6 * c + 3] = (double)axis[c]; rows[6 * c + 4] = l[c]; rows[6 * c + 5] = r[c]; }
+    double* Y = H->extc.data() + 2 * p.p * p.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES + 12 * ALG_MAX_WALLS;
+    return add_table_rows(6, ALG_MAX_CIRCLES, H, "alg_add_cylinder_constraint_player", Y, rows.data(), nc, player, p.ncyl, p.cyl_mask);
 }
 int alg_get_con_len(alg_handle* h, int32_t* n) {
     if (!h || !n) return fail(ALG_ERR_ARG, "alg_get_con_len: null argument");
@@ -968,6 +1006,13 @@ extern "C" int alg_debug_read_res(alg_handle* h, double* out, int cnt) {
     return d2h_seg(H, out, H->pr.arena + H->pr.o_res, H->pr.stride, sizeof(double) * cnt);
 }
 #endif
+int alg_get_direction_gate(alg_handle* h, double* out) {
+    NEED_HANDLE("alg_get_direction_gate");
+    if (!out) return fail(ALG_ERR_ARG, "alg_get_direction_gate: null argument");
+    int rc = use_device(H); if (rc) return rc;
+    if ((rc = sync(H))) return rc;
+    return d2h_seg(H, out, H->pr.arena + H->pr.o_tc + 13, H->pr.stride, sizeof(double) * 3);
+}
 int alg_synchronize(alg_handle* h) { NEED_HANDLE("alg_synchronize"); int rc = use_device(H); if (rc) return rc; return sync(H); }
 
 int alg_ibr_solve_player(alg_handle* h, int32_t player, alg_game_stats* stats) {
@@ -988,10 +1033,10 @@ int alg_ibr_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, int32_t 
     if (!ordering || ibr_iter < 1) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: bad arguments");
     IbrOrder order{};
     for (int i = 0; i < H->pr.p; i++) { if (ordering[i] < 0 || ordering[i] >= H->pr.p) return fail(ALG_ERR_ARG, "alg_ibr_newton_solve: ordering entries must be player ids"); order.v[i] = ordering[i]; }
-    // records accumulate over rounds and players: ibr_iter * p * (outer_iter * inner_iter + 1) at most.  The loop usually ends after
-    // a few rounds (delta_min), so the history is sized for 16 rounds; later records are dropped (alg_get_history reports it)
+    // records accumulate over rounds and players: ibr_iter * p * (outer_iter * inner_iter + 1) at most -- every record! is kept
+    // (reserve_records caps the buffer at ensure_hist's limit; a history beyond it is reported by alg_get_history)
     H->records_bound = 0;
-    if ((rc = reserve_records(H, (long long)std::min<int>(ibr_iter, 16) * H->pr.p * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
+    if ((rc = reserve_records(H, (long long)ibr_iter * H->pr.p * ((long long)H->pr.opt.outer_iter * H->pr.opt.inner_iter + 1)))) return rc;
     LAUNCH(k_ibr, H->pr, 1, 0, (int)init, (uint64_t)game_id0, (int)ibr_iter, order, delta_min);
     if (stats) return alg_get_stats(h, stats);
     return sync(H);

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr_arg, doubl
     ResOut ro;
     assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, reg, ro);
     __syncthreads();
-    const int st = newton_direction<C>(pr, G, L.d, reg);
+    const int st = refined_direction<C>(pr, G, L, reg, -1, nullptr);
     if (status && threadIdx.x == 0) status[g] = st;
 }
 

@@ -309,6 +309,8 @@ class GameConstraintValues:
         self.spherical = False           # collision_radius applies to the 3-D distance (add_spherical_collision_avoidance!)
         self.walls3d = None
         self.cylinders = None
+        self.player_walls3d = {}         # player (1-based) -> list of Wall3D (add_wall_constraint!(game_con, i, walls::Vector{Wall3D}))
+        self.player_cylinders = {}       # player (1-based) -> list of CylinderWall
 
 
 def add_collision_avoidance(game_con, *args):
@@ -434,11 +436,14 @@ def add_wall_constraint(game_con, *args):
         i, walls = int(args[0]), list(args[1])
         if not 1 <= i <= game_con.probsize.p:
             raise ValueError("add_wall_constraint: player index out of range")
-        if not all(isinstance(w, Wall) for w in walls):
-            raise TypeError("add_wall_constraint(game_con, i, walls): planar Wall objects only (the reference defines this method for Vector{Wall})")
-        if game_con.walls is not None:
+        kinds = {type(w) for w in walls}
+        if len(kinds) != 1 or not kinds <= {Wall, Wall3D, CylinderWall}:
+            raise TypeError("add_wall_constraint(game_con, i, walls): walls must all be Wall, all Wall3D or all CylinderWall")
+        kind = kinds.pop()                         # the reference's three methods: Vector{Wall} (:161), Vector{Wall3D} (:208), Vector{CylinderWall} (:256)
+        shared, own = {Wall: ("walls", "player_walls"), Wall3D: ("walls3d", "player_walls3d"), CylinderWall: ("cylinders", "player_cylinders")}[kind]
+        if getattr(game_con, shared) is not None:
             raise AlgamesError("per-player walls cannot be combined with an all-player wall set")
-        game_con.player_walls.setdefault(i, []).extend(walls)
+        getattr(game_con, own).setdefault(i, []).extend(walls)
         return
     (walls,) = args
     walls = list(walls)
@@ -446,7 +451,7 @@ def add_wall_constraint(game_con, *args):
     if len(kinds) != 1:
         raise TypeError("add_wall_constraint: walls must all be Wall, all Wall3D or all CylinderWall")
     slot = {Wall: "walls", Wall3D: "walls3d", CylinderWall: "cylinders"}[kinds.pop()]
-    if getattr(game_con, slot) is not None or (slot == "walls" and game_con.player_walls):
+    if getattr(game_con, slot) is not None or getattr(game_con, {"walls": "player_walls", "walls3d": "player_walls3d", "cylinders": "player_cylinders"}[slot]):
         raise AlgamesError("only one wall set of each kind per GameConstraintValues is supported")
     setattr(game_con, slot, walls)
 
@@ -638,6 +643,12 @@ class GameProblem:
         if game_con.cylinders:
             c = game_con.cylinders
             self.batch.add_cylinder_constraint([a.p for a in c], [a.v for a in c], [a.l for a in c], [a.r for a in c])
+        for i in sorted(game_con.player_walls3d):
+            w = game_con.player_walls3d[i]
+            self.batch.add_wall3d_constraint_player(i - 1, [a.p1 for a in w], [a.p2 for a in w], [a.p3 for a in w], [a.v for a in w])
+        for i in sorted(game_con.player_cylinders):
+            c = game_con.player_cylinders[i]
+            self.batch.add_cylinder_constraint_player(i - 1, [a.p for a in c], [a.v for a in c], [a.l for a in c], [a.r for a in c])
         self.stats = None
         game_con.active_set_tolerance = opts.active_set_tolerance      # set_constraint_params!, game_constraints.jl:37
         self._sync_options()       # set_constraint_params!(game_con, opts), problem.jl:49

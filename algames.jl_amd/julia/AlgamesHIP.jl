@@ -49,6 +49,7 @@ end
 
 struct AlgGameStats
     status::Int32; outer_iters::Int32; newton_iters::Int32; records::Int32; converged::Int32; ls_failures::Int32
+    refinements::Int32; reserved::Int32
     last::AlgRecord
 end
 
@@ -163,12 +164,12 @@ function setup!(bp::BatchedGameProblem, device)
         elseif con isa TO.CircleConstraint                           # add_circle_constraint!(game_con, xc, yc, radius) / (game_con, i, ...)
             check(ccall((:alg_add_circle_constraint_player, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), bp.h, i - 1, length(con),
                         Vector{Float64}(con.x), Vector{Float64}(con.y), Vector{Float64}(con.radius)))
-        elseif i == 1 && con isa Algames.Wall3DConstraint            # add_wall_constraint!(game_con, walls::Vector{Wall3D})
-            check(ccall((:alg_add_wall3d_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), bp.h, length(con),
+        elseif con isa Algames.Wall3DConstraint                      # add_wall_constraint!(game_con, walls::Vector{Wall3D}) / (game_con, i, walls) (constraints_methods.jl:208-247)
+            check(ccall((:alg_add_wall3d_constraint_player, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), bp.h, i - 1, length(con),
                         pts(con.x1, con.y1, con.z1), pts(con.x2, con.y2, con.z2), pts(con.x3, con.y3, con.z3), pts(con.xv, con.yv, con.zv)))
-        elseif i == 1 && con isa Algames.CylinderConstraint          # add_wall_constraint!(game_con, walls::Vector{CylinderWall})
+        elseif con isa Algames.CylinderConstraint                    # add_wall_constraint!(game_con, walls::Vector{CylinderWall}) / (game_con, i, walls) (:256-299)
             axis = Int32[s == :x ? 0 : s == :y ? 1 : 2 for s in con.v]
-            check(ccall((:alg_add_cylinder_constraint, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), bp.h, length(con),
+            check(ccall((:alg_add_cylinder_constraint_player, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), bp.h, i - 1, length(con),
                         pts(con.p1, con.p2, con.p3), axis, Vector{Float64}(con.l), Vector{Float64}(con.r)))
         end
     end
@@ -192,17 +193,23 @@ partner_of(ps, con) = findfirst(q -> all(con.x2 .== ps.px[q][1:length(con.x2)]) 
 # that a conval's row r maps to its table index.
 wall_key(con, r) = (con.x1[r], con.y1[r], con.x2[r], con.y2[r], con.xv[r], con.yv[r])
 circ_key(con, r) = (con.x[r], con.y[r], con.radius[r])
+wall3_key(con, r) = (con.x1[r], con.y1[r], con.z1[r], con.x2[r], con.y2[r], con.z2[r], con.x3[r], con.y3[r], con.z3[r], con.xv[r], con.yv[r], con.zv[r])
+cyl_key(con, r) = (con.p1[r], con.p2[r], con.p3[r], con.v[r], con.l[r], con.r[r])
 function constraint_tables(prob)
-    walls = Tuple[]; circs = Tuple[]
+    walls = Tuple[]; circs = Tuple[]; walls3 = Tuple[]; cyls = Tuple[]
     for i in 1:prob.probsize.p, cv in prob.game_con.state_conval[i]
         con = cv.con
         if con isa Algames.WallConstraint
             for r in 1:length(con); k = wall_key(con, r); k in walls || push!(walls, k); end
         elseif con isa TO.CircleConstraint
             for r in 1:length(con); k = circ_key(con, r); k in circs || push!(circs, k); end
+        elseif con isa Algames.Wall3DConstraint
+            for r in 1:length(con); k = wall3_key(con, r); k in walls3 || push!(walls3, k); end
+        elseif con isa Algames.CylinderConstraint
+            for r in 1:length(con); k = cyl_key(con, r); k in cyls || push!(cyls, k); end
         end
     end
-    return walls, circs
+    return walls, circs, walls3, cyls
 end
 
 # ---- layout of the ABI's constraint vectors (include/algames_hip.h "Layouts") -----------------------------------------------
@@ -216,7 +223,7 @@ function abi_position(bp::BatchedGameProblem, cv, i::Int)
     ctl_len = 2m * K                                                # (include/algames_hip.h "Layouts"); rows that were never added are inert
     has_sb = any(c -> c.con isa Algames.StateBoundConstraint, vcat(prob.game_con.state_conval...))
     sb_len = has_sb ? p * 2n * K : 0
-    walls, circs = constraint_tables(prob)                           # distinct entries in call order = the library's tables
+    walls, circs, walls3, cyls = constraint_tables(prob)             # distinct entries in call order = the library's tables
     nwall, ncirc = length(walls), length(circs)
     if con isa TO.CollisionConstraint                               # rows: pair q = (i, j), knot k = 2..N
         j = partner_of(ps, con)
@@ -235,11 +242,14 @@ function abi_position(bp::BatchedGameProblem, cv, i::Int)
         tc = [findfirst(==(circ_key(con, r)), circs) for r in 1:length(con)]
         return (l, r) -> col_len + ctl_len + sb_len + p * nwall * K + ((i - 1) * K + (cv.inds[l] - 2)) * ncirc + tc[r]
     elseif con isa Algames.Wall3DConstraint || con isa Algames.CylinderConstraint
-        nw3 = sum(Int[length(c.con) for c in prob.game_con.state_conval[1] if c.con isa Algames.Wall3DConstraint])
-        ncy = sum(Int[length(c.con) for c in prob.game_con.state_conval[1] if c.con isa Algames.CylinderConstraint])
+        nw3, ncy = length(walls3), length(cyls)                      # row r of the conval = table entry t(r), as for the planar walls
         base = col_len + ctl_len + sb_len + p * nwall * K + p * ncirc * K
-        con isa Algames.Wall3DConstraint && return (l, r) -> base + ((i - 1) * K + (cv.inds[l] - 2)) * nw3 + r
-        return (l, r) -> base + p * nw3 * K + ((i - 1) * K + (cv.inds[l] - 2)) * ncy + r
+        if con isa Algames.Wall3DConstraint
+            t3 = [findfirst(==(wall3_key(con, r)), walls3) for r in 1:length(con)]
+            return (l, r) -> base + ((i - 1) * K + (cv.inds[l] - 2)) * nw3 + t3[r]
+        end
+        ty = [findfirst(==(cyl_key(con, r)), cyls) for r in 1:length(con)]
+        return (l, r) -> base + p * nw3 * K + ((i - 1) * K + (cv.inds[l] - 2)) * ncy + ty[r]
     end
     error("AlgamesHIP: constraint type $(typeof(con)) is not bound")
 end
@@ -457,6 +467,24 @@ function residual_jacobian(bp::BatchedGameProblem; reg::Float64=0.0, games::Unit
                 bp.h, reg, Int32(first(games) - 1), Int32(length(games)), jac))
     return jac
 end
+"""
+    set_refinement!(bp; max_steps = 2, tol = 2.0^-34, mu_tight = 1.6e5)
+
+Iterative refinement of the Newton direction (alg_set_refinement): the stand-in for the backward stability of `lu(core.jac) \\ core.res`
+(solver_methods.jl:87).  After every structured solve the opt-u rows of `J d = -res` are evaluated; while their row-wise backward error exceeds `tol`
+the direction is corrected by one more elimination on the residual (at most `max_steps` times); below `mu_tight` (largest penalty of the game)
+the tolerance is relaxed in proportion, at most 16 x.  `max_steps = 0` switches both off.
+"""
+set_refinement!(bp::BatchedGameProblem; max_steps::Integer=2, tol::Float64=2.0^-34, mu_tight::Float64=1.6e5) =
+    check(ccall((:alg_set_refinement, LIB), Cint, (Ptr{Cvoid}, Int32, Float64, Float64), bp.h, max_steps, tol, mu_tight))
+
+"3 x B: [max |rho|, row-wise backward error, largest row scale] of the opt-u rows of every game's last Newton direction (alg_get_direction_gate)."
+function direction_gate(bp::BatchedGameProblem)
+    out = zeros(3, length(bp.probs))
+    check(ccall((:alg_get_direction_gate, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), bp.h, out))
+    return out
+end
+
 "Give the inspection entry points' device scratch (dense Jacobians, MPC state logs) back to the allocator."
 release_scratch!(bp::BatchedGameProblem) = check(ccall((:alg_release_scratch, LIB), Cint, (Ptr{Cvoid},), bp.h))
 

@@ -211,10 +211,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--games-per-gpu", type=int, default=0, help="scenarios per GPU (default: the config's BASELINE batch)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU gets the config's per-GPU batch (C4 = 8192 x 8 = north_star's 65 536); "
+                         "strong: the config's ONE-GPU batch (or --games-total) is split over the GPUs (C2: 4096 -> 4096 / N per GPU)")
+    ap.add_argument("--games-total", type=int, default=0, help="strong scaling: total scenarios of the job (default: the config's one-GPU batch)")
     ap.add_argument("--mpc-steps", type=int, default=0,
                     help="C5 receding-horizon mode: one bench step = this many warm-started MPC solves per game")
     ap.add_argument("--waves-per-game", type=int, default=0, choices=[0, 1, 2, 4],
                     help="kernel shape of the fused solver: wavefronts per game (0 = the library's automatic choice)")
+    ap.add_argument("--refine-steps", type=int, default=-1, help="alg_set_refinement max_steps (default: the library's; 0 = gate and refinement off)")
+    ap.add_argument("--refine-tol", type=float, default=-1.0, help="alg_set_refinement tol (default: the library's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (the children of a run use this)")
     args = ap.parse_args()
@@ -249,7 +255,13 @@ def main():
 
     family, default_games = CONFIGS[args.config]
     cfg_kw = CONFIG_KW.get(args.config, {})
-    G = args.games_per_gpu or default_games
+    if args.scaling == "strong":
+        total = args.games_total or default_games
+        if total % world:
+            raise SystemExit(f"bench.py: --scaling strong needs a total ({total}) divisible by --gpus ({world})")
+        G = total // world                                           # equal shards: every rank picks the same kernel shape
+    else:
+        G = args.games_per_gpu or default_games
     prob, ids = make_shard(alg, args.config, G, rank, world, device=local_rank)
     b = prob.batch
     stream = torch.cuda.Stream()                                    # a real (non-NULL) HIP stream owned by torch
@@ -257,6 +269,9 @@ def main():
     b.set_stream(stream.cuda_stream)                                # the library launches on this stream
     b.set_waves_per_game(args.waves_per_game)
     waves_per_game = b.get_waves_per_game()
+    if args.refine_steps >= 0 or args.refine_tol >= 0:
+        b.set_refinement(args.refine_steps if args.refine_steps >= 0 else None, args.refine_tol if args.refine_tol >= 0 else None)
+    refine_steps, refine_tol, refine_mu = b.get_refinement()
     prob._sync_options()
 
     def barrier():
@@ -299,6 +314,7 @@ def main():
     # one launch lasts as long as its slowest game: mean / max of the per-game iteration counts (1.0 = homogeneous batch)
     balance = float(per_game.mean() / max(1, per_game.max()))
     bad_rank = int((st["status"] != 0).sum())
+    refinements_rank = int(st["refinements"].sum())          # correction solves of the last launch (mpc mode: of every game's last solve)
     (iters_all, conv_all, bad_all), elapsed = reduce_counters(alg, [iters_rank, conv_rank, bad_rank], elapsed, world, "cuda")
 
     if rank == 0:
@@ -323,7 +339,8 @@ def main():
         }
         pmc = None
         if world == 1 and not args.no_pmc:
-            tail = ["--config", args.config, "--games-per-gpu", str(G), "--waves-per-game", str(args.waves_per_game)]
+            tail = ["--config", args.config, "--games-per-gpu", str(G), "--waves-per-game", str(args.waves_per_game),     # (a 1-GPU child: weak)
+                    "--refine-steps", str(refine_steps), "--refine-tol", repr(refine_tol)]
             if args.mpc_steps:
                 tail += ["--mpc-steps", str(args.mpc_steps)]
             pmc = inrun_pmc(tail, kernel, iters_rank, own)
@@ -341,12 +358,14 @@ def main():
         out = {
             "metric": "newton_iters_per_sec", "value": value, "unit": "game-Newton-iterations/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.config], "name": args.config,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.config] + f" [{args.scaling} scaling: {G} scenarios/GPU x {world} GPU = {G * world} scenarios]",
+                       "name": args.config,
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
                        "parallelism": f"scenario-sharded x{world}", "wavefronts_per_game": waves_per_game,
                        "iters_per_game_mean_over_max_rank0": balance,
+                       "direction_refinement": {"max_steps": refine_steps, "tol": refine_tol, "mu_tight": refine_mu, "correction_solves_rank0": refinements_rank},
                        "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve)" if args.mpc_steps
                                   else "fused per-game newton_solve! kernel")},
             "games_to_convergence_per_sec": conv_all * K / elapsed,

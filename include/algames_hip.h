@@ -131,6 +131,8 @@ typedef struct alg_game_stats {
     int32_t records;       /* stats.iter                                                */
     int32_t converged;     /* exit test solver_methods.jl:49-53 met (not the k==outer_iter arm) */
     int32_t ls_failures;   /* failed line searches                                      */
+    int32_t refinements;   /* correction solves of the Newton direction's iterative refinement (alg_set_refinement; 0 for the CPU oracle, whose pivoted LU needs none) */
+    int32_t reserved;
     alg_record last;       /* final record! (solver_methods.jl:63)                      */
 } alg_game_stats;
 
@@ -165,15 +167,22 @@ int  alg_get_options(alg_handle* h, alg_options* o);
  * summed in a different order).  alg_get_waves_per_game returns the width the next solve will use. */
 int  alg_set_waves_per_game(alg_handle* h, int32_t waves);
 int  alg_get_waves_per_game(alg_handle* h, int32_t* waves);
-/* Quad-team shape of alg_newton_solve* (3-player planar double integrator without extended constraints, batch a multiple of
- * four, waves per game 0 / 1): four games share a 256-thread workgroup, every wavefront runs its own game, and the Newton
- * direction (solver_methods.jl:87) is a collective of the four wavefronts over the four games (DPP row products, three players
- * on three SIMDs).  mode -1 (default) = automatic (off: measured slower than one game per
- * workgroup at every batch size so far; ALGAMES_QT=1 in the environment turns it on), 0 = off, 1 = required
- * (ALG_ERR_ARG when unsupported).  Results agree with the one-wavefront kernel to rounding.
- * alg_get_quad_team reports whether the next alg_newton_solve will use it. */
-int  alg_set_quad_team(alg_handle* h, int32_t mode);
-int  alg_get_quad_team(alg_handle* h, int32_t* on);
+/* Iterative refinement of the Newton direction (replaces the backward stability of `lu(core.jac) \\ core.res`, solver_methods.jl:87).
+ * The structured elimination behind alg_newton_direction / alg_newton_step / alg_newton_solve* is a block LU without pivoting across
+ * blocks; the forward and costate sweeps satisfy the dynamics and opt-x rows of J d = -res by construction, so all of the elimination's
+ * error surfaces in the opt-u rows, which are evaluated after every solve (the gate).  While their row-wise backward error
+ * max_c |rho_c| / (|J_c| |d| + |res_c|) exceeds `tol`, the direction is corrected by one more elimination on the residual (at most
+ * `max_steps` correction solves per direction).  `tol` is the tolerance for games whose largest constraint penalty (ALConVal mu) has
+ * reached `mu_tight`; below that it is relaxed in proportion mu_tight / mu_max, at most 16 x (a forward-error target needs a backward
+ * error of target / cond(J), and cond(J) grows with the penalties).  Defaults: max_steps = 2, tol = 2^-34, mu_tight = 1.6e5;
+ * max_steps = 0 switches gate and refinement off (the round-3 arithmetic).  alg_game_stats.refinements counts the correction
+ * solves of a newton_solve!. */
+int  alg_set_refinement(alg_handle* h, int32_t max_steps, double tol, double mu_tight);
+int  alg_get_refinement(alg_handle* h, int32_t* max_steps, double* tol, double* mu_tight);
+/* Inspection: the gate statistics of the most recent Newton direction of every game, before any correction; out is B x 3:
+ * [ max |rho| over the opt-u rows, row-wise backward error max |rho_c| / (|J_c| |d| + |ru_c|), largest row scale ].
+ * Not refreshed while the gate is off (max_steps = 0); zeros for the CPU oracle. */
+int  alg_get_direction_gate(alg_handle* h, double* out);
 /* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = library stream. */
 int  alg_set_stream(alg_handle* h, void* hip_stream);
 
@@ -236,6 +245,14 @@ int alg_add_wall3d_constraint(alg_handle* h, int32_t n_wall, const double* p1, c
 /* add_wall_constraint!(game_con, walls::Vector{CylinderWall}) (constraints_methods.jl:249-284; cylinder_constraint.jl:35-127):
  * axis-aligned cylinders, origin p (n_cyl x 3), axis 0/1/2 = :x/:y/:z, length l, radius r; every player, knots 2..N */
 int alg_add_cylinder_constraint(alg_handle* h, int32_t n_cyl, const double* p, const int32_t* axis, const double* l, const double* r);
+/* add_wall_constraint!(game_con, i, walls::Vector{Wall3D}) (constraints_methods.jl:208-247) and
+ * add_wall_constraint!(game_con, i, walls::Vector{CylinderWall}) (:256-299): the constraint joins state_conlist[i] of ONE player
+ * (0-based here).  Same mechanism as the planar *_player adders: the entries join the handle's table of distinct 3-D walls /
+ * cylinders (at most ALG_MAX_WALLS / ALG_MAX_CIRCLES; an identical entry is shared, row w of the ABI's block is table entry w for
+ * every player) and a per-player mask says whom an entry constrains; a row whose bit is clear is inert (value 0, zero Jacobian,
+ * multiplier untouched).  Can be called repeatedly; after an all-player set the masks become explicit first. */
+int alg_add_wall3d_constraint_player(alg_handle* h, int32_t player, int32_t n_wall, const double* p1, const double* p2, const double* p3, const double* v);
+int alg_add_cylinder_constraint_player(alg_handle* h, int32_t player, int32_t n_cyl, const double* p, const int32_t* axis, const double* l, const double* r);
 /* current length of the constraint dual / penalty / value vectors of one game */
 int alg_get_con_len(alg_handle* h, int32_t* con_len);
 

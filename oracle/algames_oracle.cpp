@@ -299,7 +299,9 @@ struct Shared {
     // the reference pushes the constraint object to state_conval[i] only; here the table is shared and bit w of wall_mask[i] says
     // whether entry w constrains player i -- a row whose bit is clear evaluates to c = 0 with a zero Jacobian (inert)
     unsigned wall_mask[10], circ_mask[10];
-    Shared() { for (int i = 0; i < 10; i++) wall_mask[i] = circ_mask[i] = 0xffffffffu; }
+    // the same for add_wall_constraint!(game_con, i, walls::Vector{Wall3D}) / (game_con, i, walls::Vector{CylinderWall}) (constraints_methods.jl:208-247, 256-299)
+    unsigned wall3_mask[10], cyl_mask[10];
+    Shared() { for (int i = 0; i < 10; i++) wall_mask[i] = circ_mask[i] = wall3_mask[i] = cyl_mask[i] = 0xffffffffu; }
     std::vector<real> w3p1, w3p2, w3p3, w3v;   // Wall3D(p1, p2, p3, v): nwall3 x 3 each (constraints_methods.jl:201-206)
     std::vector<real> cyp, cyl, cyr; std::vector<int> cyax;   // CylinderWall(p, v, l, r): ncyl x 3, axis 0/1/2 = :x/:y/:z (:249-254)
 };
@@ -486,8 +488,16 @@ void ext_state_con(const Shared& sh, Game& g, const std::vector<real>& z, int i,
     // Wall3D / Cylinder act on pz[i][1..3] (constraints_methods.jl:231-236,275)
     const int idx3[3] = {D.pz(i, 0), D.pz(i, 1), D.pz(i, 2)};
     const real q3[3] = {x[idx3[0]], x[idx3[1]], x[idx3[2]]};
-    for (int w = 0; w < D.nwall3; w++) { real gv[3]; const real c = wall3_val(sh, w, q3, gv); row(D.o_wall3(i, k, w), c, idx3, gv, 3); }
-    for (int c2 = 0; c2 < D.ncyl; c2++) { real gv[3]; const real c = cyl_val(sh, c2, q3, gv); row(D.o_cyl(i, k, c2), c, idx3, gv, 3); }
+    for (int w = 0; w < D.nwall3; w++) {
+        real gv[3]; const real on = (real)((sh.wall3_mask[i] >> w) & 1u);
+        const real c = on * wall3_val(sh, w, q3, gv); for (int a = 0; a < 3; a++) gv[a] *= on;
+        row(D.o_wall3(i, k, w), c, idx3, gv, 3);
+    }
+    for (int c2 = 0; c2 < D.ncyl; c2++) {
+        real gv[3]; const real on = (real)((sh.cyl_mask[i] >> c2) & 1u);
+        const real c = on * cyl_val(sh, c2, q3, gv); for (int a = 0; a < 3; a++) gv[a] *= on;
+        row(D.o_cyl(i, k, c2), c, idx3, gv, 3);
+    }
 }
 
 // evaluate!(game_con, traj) (constraints_methods.jl:367-379)
@@ -506,8 +516,8 @@ void evaluate_con(const Shared& sh, Game& g, const std::vector<real>& z) {
         for (int c = 0; c < D.ncirc; c++) g.vals[D.o_circ(i, k, c)] = (real)((sh.circ_mask[i] >> c) & 1u) * circ_val(sh, c, x[D.px(i, 0)], x[D.px(i, 1)], &gx, &gy);
         if (D.nwall3 + D.ncyl > 0) {
             const real q3[3] = {x[D.pz(i, 0)], x[D.pz(i, 1)], x[D.pz(i, 2)]}; real gv[3];
-            for (int w = 0; w < D.nwall3; w++) g.vals[D.o_wall3(i, k, w)] = wall3_val(sh, w, q3, gv);
-            for (int c = 0; c < D.ncyl; c++) g.vals[D.o_cyl(i, k, c)] = cyl_val(sh, c, q3, gv);
+            for (int w = 0; w < D.nwall3; w++) g.vals[D.o_wall3(i, k, w)] = (real)((sh.wall3_mask[i] >> w) & 1u) * wall3_val(sh, w, q3, gv);
+            for (int c = 0; c < D.ncyl; c++) g.vals[D.o_cyl(i, k, c)] = (real)((sh.cyl_mask[i] >> c) & 1u) * cyl_val(sh, c, q3, gv);
         }
     }
 }
@@ -1349,7 +1359,28 @@ int orc_add_wall3d_constraint(alg_handle* h, int32_t nw, const double* p1, const
     if (nw < 0 || nw > ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "orc_add_wall3d_constraint: too many walls");
     if (int rc = need_3d(H, "orc_add_wall3d_constraint")) return rc;
     s.w3p1.assign(p1, p1 + 3 * nw); s.w3p2.assign(p2, p2 + 3 * nw); s.w3p3.assign(p3, p3 + 3 * nw); s.w3v.assign(v, v + 3 * nw);
-    s.D.nwall3 = nw; orc_resize_con(H); return ALG_OK;
+    s.D.nwall3 = nw; for (int i = 0; i < 10; i++) s.wall3_mask[i] = 0xffffffffu; orc_resize_con(H); return ALG_OK;
+}
+// add_wall_constraint!(game_con, i, walls::Vector{Wall3D}) (constraints_methods.jl:208-247): the Wall3DConstraint joins state_conlist[i] only
+int orc_add_wall3d_constraint_player(alg_handle* h, int32_t player, int32_t nw, const double* p1, const double* p2, const double* p3, const double* v) {
+    Shared& s = H->sh;
+    if (player < 0 || player >= s.D.p || nw < 0) return fail(ALG_ERR_ARG, "orc_add_wall3d_constraint_player: bad argument");
+    if (int rc = need_3d(H, "orc_add_wall3d_constraint_player")) return rc;
+    if (s.D.nwall3 == 0) for (int i = 0; i < 10; i++) s.wall3_mask[i] = 0u;
+    else for (int i = 0; i < 10; i++) if (s.wall3_mask[i] == 0xffffffffu) s.wall3_mask[i] = (1u << s.D.nwall3) - 1u;
+    std::vector<real>* tab[4] = {&s.w3p1, &s.w3p2, &s.w3p3, &s.w3v}; const double* src[4] = {p1, p2, p3, v};
+    for (int f = 0; f < 4; f++) tab[f]->resize(3 * s.D.nwall3);
+    for (int w = 0; w < nw; w++) {
+        int at = -1;
+        for (int e = 0; e < s.D.nwall3 && at < 0; e++) { bool same = true; for (int f = 0; f < 4; f++) for (int a = 0; a < 3; a++) same &= ((*tab[f])[3 * e + a] == src[f][3 * w + a]); if (same) at = e; }
+        if (at < 0) {
+            if (s.D.nwall3 >= ALG_MAX_WALLS) return fail(ALG_ERR_ARG, "orc_add_wall3d_constraint_player: too many walls");
+            at = s.D.nwall3++;
+            for (int f = 0; f < 4; f++) for (int a = 0; a < 3; a++) tab[f]->push_back(src[f][3 * w + a]);
+        }
+        s.wall3_mask[player] |= 1u << at;
+    }
+    orc_resize_con(H); return ALG_OK;
 }
 int orc_add_cylinder_constraint(alg_handle* h, int32_t nc, const double* p, const int32_t* axis, const double* l, const double* r) {
     Shared& s = H->sh;
@@ -1357,7 +1388,33 @@ int orc_add_cylinder_constraint(alg_handle* h, int32_t nc, const double* p, cons
     if (int rc = need_3d(H, "orc_add_cylinder_constraint")) return rc;
     for (int c = 0; c < nc; c++) if (axis[c] < 0 || axis[c] > 2) return fail(ALG_ERR_ARG, "orc_add_cylinder_constraint: axis must be 0 (:x), 1 (:y) or 2 (:z)");
     s.cyp.assign(p, p + 3 * nc); s.cyax.assign(axis, axis + nc); s.cyl.assign(l, l + nc); s.cyr.assign(r, r + nc);
-    s.D.ncyl = nc; orc_resize_con(H); return ALG_OK;
+    s.D.ncyl = nc; for (int i = 0; i < 10; i++) s.cyl_mask[i] = 0xffffffffu; orc_resize_con(H); return ALG_OK;
+}
+// add_wall_constraint!(game_con, i, walls::Vector{CylinderWall}) (constraints_methods.jl:256-299): the CylinderConstraint joins state_conlist[i] only
+int orc_add_cylinder_constraint_player(alg_handle* h, int32_t player, int32_t nc, const double* p, const int32_t* axis, const double* l, const double* r) {
+    Shared& s = H->sh;
+    if (player < 0 || player >= s.D.p || nc < 0) return fail(ALG_ERR_ARG, "orc_add_cylinder_constraint_player: bad argument");
+    if (int rc = need_3d(H, "orc_add_cylinder_constraint_player")) return rc;
+    for (int c = 0; c < nc; c++) if (axis[c] < 0 || axis[c] > 2) return fail(ALG_ERR_ARG, "orc_add_cylinder_constraint_player: axis must be 0 (:x), 1 (:y) or 2 (:z)");
+    if (s.D.ncyl == 0) for (int i = 0; i < 10; i++) s.cyl_mask[i] = 0u;
+    else for (int i = 0; i < 10; i++) if (s.cyl_mask[i] == 0xffffffffu) s.cyl_mask[i] = (1u << s.D.ncyl) - 1u;
+    s.cyp.resize(3 * s.D.ncyl); s.cyax.resize(s.D.ncyl); s.cyl.resize(s.D.ncyl); s.cyr.resize(s.D.ncyl);
+    for (int c = 0; c < nc; c++) {
+        int at = -1;
+        for (int e = 0; e < s.D.ncyl && at < 0; e++) {
+            bool same = s.cyax[e] == axis[c] && s.cyl[e] == l[c] && s.cyr[e] == r[c];
+            for (int a = 0; a < 3; a++) same &= (s.cyp[3 * e + a] == p[3 * c + a]);
+            if (same) at = e;
+        }
+        if (at < 0) {
+            if (s.D.ncyl >= ALG_MAX_CIRCLES) return fail(ALG_ERR_ARG, "orc_add_cylinder_constraint_player: too many cylinders");
+            at = s.D.ncyl++;
+            for (int a = 0; a < 3; a++) s.cyp.push_back(p[3 * c + a]);
+            s.cyax.push_back(axis[c]); s.cyl.push_back(l[c]); s.cyr.push_back(r[c]);
+        }
+        s.cyl_mask[player] |= 1u << at;
+    }
+    orc_resize_con(H); return ALG_OK;
 }
 int orc_get_con_len(alg_handle* h, int32_t* n) { *n = H->sh.D.con_len; return ALG_OK; }
 int orc_set_traj(alg_handle* h, int32_t which, const double* z) {
@@ -1500,8 +1557,9 @@ int orc_newton_solve(alg_handle* h, int32_t init, int64_t game_id0, alg_game_sta
 }
 int orc_debug_check_guards(alg_handle*) { return 0; }
 int orc_set_waves_per_game(alg_handle*, int32_t nw) { return (nw == 0 || nw == 1 || nw == 2 || nw == 4) ? ALG_OK : fail(ALG_ERR_ARG, "bad width"); }   // kernel shape: no meaning on the CPU (ABI mirror)
-int orc_set_quad_team(alg_handle*, int32_t mode) { return (mode >= -1 && mode <= 0) ? ALG_OK : fail(ALG_ERR_ARG, "quad team: a kernel shape of the HIP library"); }   // (ABI mirror)
-int orc_get_quad_team(alg_handle*, int32_t* on) { if (on) *on = 0; return ALG_OK; }
+int orc_set_refinement(alg_handle*, int32_t max_steps, double tol, double mu_tight) { return (max_steps >= 0 && max_steps <= 8 && tol >= 0.0 && mu_tight >= 0.0) ? ALG_OK : fail(ALG_ERR_ARG, "bad refinement setting"); }   // the pivoted LU needs none (ABI mirror)
+int orc_get_direction_gate(alg_handle* h, double* out) { if (out) for (size_t e = 0; e < 3 * H->g.size(); e++) out[e] = 0.0; return ALG_OK; }
+int orc_get_refinement(alg_handle*, int32_t* max_steps, double* tol, double* mu_tight) { if (max_steps) *max_steps = 0; if (tol) *tol = 0.0; if (mu_tight) *mu_tight = 0.0; return ALG_OK; }
 int orc_get_waves_per_game(alg_handle*, int32_t* nw) { if (nw) *nw = 1; return ALG_OK; }      // host vectors: nothing to check (ABI mirror)
 int orc_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) { return orc_newton_solve(h, init, game_id0, nullptr); }
 int orc_get_stats(alg_handle* h, alg_game_stats* stats) { for (size_t gi = 0; gi < H->g.size(); gi++) stats[gi] = H->g[gi].st; return ALG_OK; }

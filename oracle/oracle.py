@@ -19,19 +19,24 @@ LIB_Q_PATH = os.path.join(_here, "lib", "liboracle_q.so")
 
 
 def build(force=False):
+    """Builds the oracle and the long-double arbiter (`make`).  The __float128 arbiter (libquadmath) is built on demand by lib("q")."""
     src = os.path.join(_here, "algames_oracle.cpp")
-    stale = any((not os.path.exists(q)) or os.path.getmtime(q) < os.path.getmtime(src) for q in (LIB_PATH, LIB_X_PATH, LIB_Q_PATH))
+    hdr = os.path.join(os.path.dirname(_here), "include", "algames_hip.h")
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+    stale = any((not os.path.exists(q)) or os.path.getmtime(q) < newest for q in (LIB_PATH, LIB_X_PATH))
     if force or stale:
         subprocess.check_call(["make", "-C", _here, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
 
+def _build_q():
+    src = os.path.join(_here, "algames_oracle.cpp")
+    if (not os.path.exists(LIB_Q_PATH)) or os.path.getmtime(LIB_Q_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _here, "-s", "lib/liboracle_q.so"])
+
+
 _lib = None
 _arb = {}
-
-
-def _declare(d):
-    pass
 
 
 def lib(kind=""):
@@ -40,7 +45,9 @@ def lib(kind=""):
     if kind:
         if kind not in _arb:
             path = {"x": LIB_X_PATH, "q": LIB_Q_PATH}[kind]
-            if not os.path.exists(path):
+            if kind == "q":
+                _build_q()
+            elif not os.path.exists(path):
                 build()
             _arb[kind] = CLib(path, "orc_")
             _arb[kind].dll.orc_set_threads.restype = C.c_int

@@ -7,7 +7,7 @@ NAME=$1; shift
 R=$(cd "$(dirname "$0")/../.." && pwd); C=$R/algames.jl_amd/csrc; O=$R/algames.jl_amd/lib/variants/obj_$NAME; D=$R/algames.jl_amd/lib/obj
 mkdir -p $O
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-invalid-offsetof -mllvm -disable-machine-licm $*"
-for f in algames_hip algames_ext_di algames_ext_uni algames_ext_bic algames_ext_di3 algames_mw algames_qt; do
+for f in algames_hip algames_ext_di algames_ext_uni algames_ext_bic algames_ext_di3 algames_mw; do
   /opt/rocm/bin/hipcc $FL -c $C/$f.hip -o $O/$f.o &
 done
 wait

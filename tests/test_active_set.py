@@ -111,3 +111,40 @@ def test_masks_and_nullspace_on_the_hip_path(alg, orc):
         A.update_nullspace(core, prob, constraint_rows=True)
     assert cg.vmask == co.vmask and cg.hmask == co.hmask
     assert cg.null.mat.shape == co.null.mat.shape
+
+
+def test_active_set_on_a_pair_only_problem(alg, orc):
+    """constraints added with add_collision_avoidance!(game_con, i, j, radius) (constraints_methods.jl:5-19) must reach the
+    active-set analysis too -- own radius per ordered pair, absent pairs inert; the spherical form measures the 3-D distance."""
+    A = alg.active_set
+    N, p = 6, 3
+    model = alg.UnicycleGame(p=p)
+    con = alg.GameConstraintValues(alg.ProblemSize(N, model))
+    alg.add_collision_avoidance(con, 1, 2, 0.5)
+    alg.add_collision_avoidance(con, 3, 1, 2.0)
+    cvs = A.collision_convals(con)
+    assert sorted(cvs) == [(1, 2), (3, 1)] and cvs[(1, 2)].radius == 0.5 and cvs[(3, 1)].radius == 2.0
+    X = np.zeros((N, model.n)); X[:, 0] = 1.0                  # player 1 at (1, 0), players 2 and 3 at the origin
+    A.update_active_set(con, X, tol=0.0)
+    assert np.allclose(cvs[(1, 2)].vals, 0.25 - 1.0) and np.allclose(cvs[(3, 1)].vals, 4.0 - 1.0)
+    assert A.active(con, A.stampify_c("v", "col", 1, 2, 3)) == [0] and A.active(con, A.stampify_c("h", "col", 3, 1, 3)) == [1]
+    assert A.active(con, A.stampify_c("h", "col", 2, 1, 3)) == [0]           # no such constraint
+    assert np.allclose(cvs[(3, 1)].jac[0, [2, 2 + p]], [2.0, 0.0]) and np.allclose(cvs[(3, 1)].jac[0, [0, p]], [-2.0, 0.0])
+    # the augmented system of a pair-only problem carries the pair's multiplier columns
+    obj = alg.GameObjective([np.ones(4)] * p, [np.ones(2)] * p, [np.zeros(4)] * p, [np.zeros(2)] * p, N, model)
+    prob = alg.GameProblem(N, 0.1, np.array([1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]), model, alg.Options(inner_print=False, outer_print=False), obj, con, backend=orc.lib())
+    prob.batch.init_traj(0)
+    core = A.ActiveSetCore(prob.probsize)
+    A.update_active_set(con, np.tile(prob.x0 if prob.x0.ndim == 1 else prob.x0[0], (N, 1)), tol=0.0)
+    A.active_vertical_mask(core, con); A.active_horizontal_mask(core, con)
+    S = prob.probsize.S
+    assert len(core.hmask) == S + (N - 1)                       # only (3, 1) is inside its radius: one multiplier column per knot
+    A.residual_jacobian(core, prob)
+    assert np.abs(core.jac[:S, S:]).max() > 0.0
+    # spherical: the third position coordinate counts
+    m3 = alg.DoubleIntegratorGame(p=2, d=3)
+    c3 = alg.GameConstraintValues(alg.ProblemSize(N, m3))
+    alg.add_spherical_collision_avoidance(c3, 1, 2, 1.0)
+    X3 = np.zeros((N, m3.n)); X3[:, 2 * 2] = 3.0               # z of player 1 (pz[1][3] = 1 + 2 p)
+    A.update_active_set(c3, X3, tol=0.0)
+    assert np.allclose(A.collision_convals(c3)[(1, 2)].vals, 1.0 - 9.0)

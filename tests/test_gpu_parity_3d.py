@@ -227,3 +227,67 @@ def test_3d_receding_horizon_and_ibr_solve_parity(alg, orc):
         assert np.array_equal(sg[f], so[f]), (f, sg[f], so[f])
     zg, zo = pg.batch.get_traj(), po.batch.get_traj()
     assert np.abs(zg - zo).max() <= 1e-7 * max(1.0, np.abs(zo).max())
+
+
+@pytest.mark.parametrize("model,p,N", [(DI, 2, 7), (3, 2, 5)])
+def test_per_player_wall3d_and_cylinder_parity(alg, orc, model, p, N):
+    """add_wall_constraint!(game_con, i, walls::Vector{Wall3D}) / (game_con, i, walls::Vector{CylinderWall})
+    (constraints_methods.jl:208-247, 256-299): DIFFERENT 3-D wall / cylinder sets per player with one shared entry each, HIP path vs
+    oracle on a DoubleIntegrator (d = 3) and a Quadrotor game: residual, Jacobian, direction, an inner iteration, the dual / penalty
+    update and a short full solve; the rows of a player an entry does not constrain stay inert."""
+    B = 3
+    g = alg.Batch(alg.hip_lib(), model, p, N, 0.1, B, d=3)
+    o = orc.OracleBatch(model, p, N, 0.1, B, d=3)
+    rng = np.random.default_rng(33)
+    ni = g.n // p
+    Q, R = 1 + rng.random((B, p, ni)), 0.5 + rng.random((B, p, g.mi))
+    xf, uf = rng.random((B, p, ni)), rng.random((B, p, g.mi)) - 0.5
+    x0 = rng.random((B, g.n))
+    if model == 3:
+        x0[:, 3 * p:] *= 0.1                                   # small attitudes / velocities: a flyable start
+        uf = 1.2 + 0.1 * uf
+    wa = ([[0.0, 0.0, 0.5]], [[1.0, 0.0, 0.5]], [[1.0, 1.0, 0.5]], [[0.0, 0.6, 0.8]])
+    wb = ([[0.0, 0.0, 0.1]], [[1.0, 0.2, 0.3]], [[0.8, 1.0, 0.9]], [[S2, 0.0, -S2]])
+    both = tuple(a + b_ for a, b_ in zip(wa, wb))
+    for b in (g, o):
+        b.set_x0(x0); b.set_lqr(Q, R, xf, uf)
+        b.add_spherical_collision_avoidance(0.3 + 0.1 * np.arange(p))
+        b.add_wall3d_constraint_player(0, *both)                                       # player 0: both panels
+        b.add_wall3d_constraint_player(p - 1, *wb)                                     # last player: the slanted one only (shared entry)
+        b.add_cylinder_constraint_player(p - 1, [[0.5, 0.5, 0.0], [0.0, 0.4, 0.6]], [2, 0], [1.5, 2.0], [0.45, 0.5])
+        b.add_cylinder_constraint_player(0, [[0.0, 0.4, 0.6], [0.3, -0.2, 0.3]], [0, 1], [2.0, 0.9], [0.5, 0.35])   # shares the x-axis cylinder
+    assert g.con_len == o.con_len
+    z = rng.random((B, g.traj_len)); z[:, :g.n] = x0
+    if model == 3:
+        X, U, L = g.split_traj(z); X[:, :, 3 * p:] *= 0.1; U[:] = 1.2 + 0.1 * U; z = g.join_traj(X, U, L)
+    lam, mu = rng.random((B, g.con_len)), 1.0 + 2.0 * rng.random((B, g.con_len))
+    lam[rng.random((B, g.con_len)) < 0.3] = 0.0
+    for b in (g, o):
+        b.set_traj(z); b.set_con_duals(lam, mu)
+    rg, ng = g.residual(0, 0.0); ro, no = o.residual(0, 0.0)
+    assert np.abs(rg - ro).max() <= 1e-12 * (1 + np.abs(ro).max()) and np.allclose(ng, no, rtol=1e-13, atol=0)
+    Jg, Jo = g.residual_jacobian(1e-3), o.residual_jacobian(1e-3)
+    assert np.abs(Jg - Jo).max() <= 1e-12 * np.abs(Jo).max()
+    dg, sg = g.newton_direction(1e-3); do, so = o.newton_direction(1e-3)
+    assert np.all(sg == 0) and np.all(so == 0)
+    assert (np.abs(dg - do) / np.abs(do).max(axis=1, keepdims=True)).max() < 1e-9
+    ig, io = g.newton_step(1, 1), o.newton_step(1, 1)
+    assert np.array_equal(ig["ls_j"], io["ls_j"]) and np.array_equal(ig["alpha"], io["alpha"])
+    for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+        assert np.allclose(ig["rec"][f], io["rec"][f], rtol=1e-9, atol=1e-14), f
+    vg, vo = g.dual_penalty_update(), o.dual_penalty_update()
+    assert np.abs(vg - vo).max() <= 1e-9 * max(1.0, np.abs(vo).max())
+    # inert rows: 3-D wall 0 (the floor panel) does not constrain the last player, cylinder 0 (z axis) not player 0
+    K = N - 1
+    nw3, ncy = 2, 3
+    base = g.con_len - p * K * (nw3 + ncy)
+    w3 = vg[:, base:base + p * K * nw3].reshape(B, p, K, nw3); cy = vg[:, base + p * K * nw3:].reshape(B, p, K, ncy)
+    assert np.all(w3[:, p - 1, :, 0] == 0.0) and np.all(cy[:, 0, :, 0] == 0.0) and np.all(cy[:, p - 1, :, 2] == 0.0)
+    (lg, mg), (lo, mo) = g.get_con_duals(), o.get_con_duals()
+    assert np.array_equal(mg, mo) and np.abs(lg - lo).max() <= 1e-9 * max(1.0, np.abs(lo).max())
+    for b in (g, o):
+        b.set_options(outer_iter=3, inner_iter=5)
+    sg, so = g.newton_solve(init=True, game_id0=5), o.newton_solve(init=True, game_id0=5)
+    for f in ("status", "outer_iters", "newton_iters", "records", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]), f
+    assert np.abs(g.get_traj() - o.get_traj()).max() <= 1e-7 * max(1.0, np.abs(o.get_traj()).max())

@@ -1046,6 +1046,44 @@ def test_cylinder_evaluate_literal(orc):
         b.add_cylinder_constraint(p, [0, 1, 2, 3, 0], l, r)
 
 
+def test_per_player_wall3d_and_cylinder_sets(orc):
+    """add_wall_constraint!(game_con, i, walls::Vector{Wall3D}) / (game_con, i, walls::Vector{CylinderWall}) (constraints_methods.jl:208-247,
+    256-299) attach the constraint to state_conlist[i] of ONE player.  The literal values of test/constraints/wall_constraint.jl:34-64 and
+    cylinder_constraint.jl:3-22 for the player that carries a set, exact zeros (inert rows) for the other one; an identical entry is shared."""
+    s2 = np.sqrt(2.0)
+    b = orc.OracleBatch(DI, 2, 3, 0.1, 1, d=3)
+    b.set_lqr(np.zeros((2, 6)), np.zeros((2, 3)), np.zeros((2, 6)), np.zeros((2, 3)))
+    p1 = np.zeros((2, 3)); p2 = np.array([[1.0, 0, 0], [1, 0, 0]]); p3 = np.array([[1.0, 1, 0], [1, 1, 1]]); v = np.array([[0.0, 0, 1], [0, -1 / s2, 1 / s2]])
+    off0 = b.con_len
+    b.add_wall3d_constraint_player(1, p1, p2, p3, v)                       # player 2 (1-based): both walls
+    b.add_wall3d_constraint_player(0, p1[1:], p2[1:], p3[1:], v[1:])       # player 1: the second wall only -- shared table entry
+    assert b.con_len == off0 + 2 * 2 * (b.N - 1)                           # two table entries, p = 2 players, knots 2..N
+    b.add_cylinder_constraint_player(0, [[1.0, 0, 1]], [2], [5.0], [3.0])
+    assert b.con_len == off0 + (2 * 2 + 2 * 1) * (b.N - 1)
+    X, U, L = b.split_traj(b.get_traj())
+    X[0, 1:, 0:2] = 0.10; X[0, 1:, 2:4] = 0.10; X[0, 1:, 4:6] = 0.0        # both players at (x, y, z) = (0.10, 0.10, 0): wall_constraint.jl:49-53
+    b.set_traj(b.join_traj(X, U, np.zeros_like(L)))
+    vals = b.kat_evaluate_con()[0][off0:]
+    K = b.N - 1
+    w = vals[:2 * 2 * K].reshape(2, K, 2); c = vals[2 * 2 * K:].reshape(2, K, 1)
+    assert np.all(w[0, :, 0] == 0.0)                                       # wall 0 does not constrain player 1
+    assert np.abs(w[0, :, 1] + 0.1 / s2).max() < 1e-12 and np.abs(w[1, :, 1] + 0.1 / s2).max() < 1e-12 and np.abs(w[1, :, 0]).max() < 1e-12
+    assert np.all(c[1] == 0.0)                                             # the cylinder belongs to player 1 only
+    X[0, 1:, 0:2] = 1.0; X[0, 1:, 2:4] = 1.0; X[0, 1:, 4:6] = 2.0           # (1, 1, 2): cylinder_constraint.jl:9-14 -> 8
+    b.set_traj(b.join_traj(X, U, np.zeros_like(L)))
+    c = b.kat_evaluate_con()[0][off0 + 2 * 2 * K:].reshape(2, K, 1)
+    assert np.abs(c[0] - 8.0).max() < 1e-12 and np.all(c[1] == 0.0)
+    # the inert rows stay out of the residual: player 2's opt rows see no cylinder term
+    lam = np.zeros((1, b.con_len)); lam[0, off0 + 2 * 2 * K:] = 1.0
+    b.set_con_duals(lam, np.full((1, b.con_len), 2.0))
+    r = b.residual()[0][0]
+    n, mi = b.n, b.mi
+    rows2 = r[(b.N - 1) * (n + mi):2 * (b.N - 1) * (n + mi)]
+    assert np.all(rows2 == 0.0) and np.abs(r[:(b.N - 1) * (n + mi)]).max() > 0.0
+    with pytest.raises(Exception):
+        orc.OracleBatch(DI, 2, 3, 0.1, 1).add_wall3d_constraint_player(0, p1, p2, p3, v)   # no third position dimension
+
+
 def test_3d_constraints_gradient_and_gauss_newton_block(orc):
     # jacobian! of both constraints equals ForwardDiff of evaluate (wall_constraint.jl test :67-70, cylinder test :25-34):
     # opt_x rows = d/dx of the AL penalty with the active set frozen; jacobian = C' I_mu C; spherical collision avoidance on
@@ -1315,6 +1353,11 @@ def test_arbiter_builds(alg, orc):
     (liboracle_x.so) and __float128 (liboracle_q.so) behind the same double ABI.  On a well-conditioned problem the three agree to
     the double oracle's rounding, the two extended builds to long-double rounding; the discrete history is identical."""
     import oracle as orcmod
+    import subprocess
+    try:
+        orcmod.lib("q")
+    except (subprocess.CalledProcessError, OSError) as e:      # a toolchain without libquadmath: only this test needs the __float128 build
+        pytest.skip(f"__float128 arbiter not buildable here: {e}")
     ids = np.arange(40, 43)
     probs = {k: alg.scenarios.make_problem("C2", ids, N=8, backend=orcmod.lib(k)) for k in ("", "x", "q")}
     for p_ in probs.values():

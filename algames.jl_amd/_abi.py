@@ -251,7 +251,7 @@ class Batch:
     def set_refinement(self, max_steps=None, tol=None, mu_tight=None):
         """Iterative refinement of the Newton direction (alg_set_refinement): the opt-u rows of every direction are evaluated and the
         direction is corrected (at most `max_steps` correction solves) while their row-wise backward error exceeds `tol` (relaxed up to
-        16 x while the game's largest penalty is below `mu_tight`); max_steps = 0 switches gate and refinement off.  None keeps a value."""
+        256 x while the game's largest penalty is below `mu_tight`); max_steps = 0 switches gate and refinement off.  None keeps a value."""
         ms0, tol0, mu0 = self.get_refinement()
         self.lib.check(self.lib.set_refinement(self.h, int(ms0 if max_steps is None else max_steps), float(tol0 if tol is None else tol),
                                                float(mu0 if mu_tight is None else mu_tight)))

@@ -66,7 +66,7 @@ struct Params {
     int hist_max;
     int refine_max;         // iterative refinement of the Newton direction: correction solves allowed per direction (0 = off)
     double refine_tol;      // ... taken while the row-wise backward error of the opt-u rows exceeds this (alg_set_refinement)
-    double refine_mu;       // ... relaxed up to 16 x in proportion while the game's largest penalty stays below this
+    double refine_mu;       // ... relaxed up to 256 x in proportion while the game's largest penalty stays below this
     int kscratch_len;       // per game doubles of gain scratch
     int rec_len;            // per game doubles of step records
     unsigned long long ibr_ctl_rows[MAXP];   // control-bound rows counted by control_violation(game_con, pdtraj, i) (violations.jl:69-82)
@@ -812,7 +812,17 @@ struct AsmLds {
     // batch sizes and write directly)
     static constexpr bool STAGED = (C::WPE == 4 && C::NW == 1);
     static constexpr int HEAD = Rec<C>::RQ, SL = HEAD + C::PD * C::P * C::P, SPP = C::NT / C::P;
-    double stage[STAGED ? SPP * SL : 1];
+    // Fused trial pass (assemble_fused; double integrator, one wavefront per game): the rows of FT time steps are evaluated out of LDS.
+    // A chunk holds x_k of its first step, the FT + 1 blocks [x_{k+1} | u_k | lambda_k] the rows touch (the last one only for
+    // A_{k+1}' lambda_{k+1}), the [x | u] parts of the proximal reference, the pair-gradient tables and the LQR constants.
+    static constexpr bool FUSED = C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && !C::EXT && C::NW == 1 && !C::DENSE;
+    static constexpr int FT = 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi);
+    struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], lqr[NLQR]; };
+    struct NoChunk {};
+    union {
+        double stage[STAGED ? SPP * SL : 1];
+        typename std::conditional<FUSED, Chunk, NoChunk>::type ch;
+    };
 };
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
 
@@ -866,48 +876,15 @@ template <class C> __device__ __forceinline__ void team_combine(ResOut& o) {
     }
 }
 
-// IBR = true: best-response statistics of player ip (solver_methods.jl:230-289): norms over the rows of the vertical mask
-// (player ip's opt rows + all dyn rows, newton_core.jl:205-246), player-specific violations (statistics.jl:59-73), the
-// proximal term only on player ip's rows (global_quantities.jl:262-280); out.l1full is the full ||res||_1 for record!.
-template <class C, int MODE, bool IBR = false>
-__device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, int zrefsel, double reg, double jreg,
-                              ResOut& out, int ip = -1) {
-    CPR pr = phase_params(pr0);
-    const Game G = G0.fresh();
-    const double* __restrict__ z = G.z(zsel);
-    const double* __restrict__ zref = zrefsel >= 0 ? G.z(zrefsel) : nullptr;
-    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b;
+struct AsmAcc { double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0; };
+// Phase A of the assemble pass (see assemble_pass): RK2 Jacobian coefficients and the pair / wall / circle terms of every (knot, player).
+// dzp != nullptr: the positions are those of the trial iterate z + alpha dz, formed on the fly (fused trial pass of the double integrator).
+template <class C, int MODE, bool IBR>
+__device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C>& L, const double* __restrict__ z, const double* __restrict__ dzp, double alpha,
+                                                 int N, int lane, double dt, int ip, AsmAcc& acc) {
+    constexpr int n = C::n, P = C::P;
     using R = Rec<C>;
-    const int N = phase_int(pr.N), lane = phase_lane();
-    const double dt = phase_f64(pr.dt);
-    double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0;
-    constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
-    LSP_T0 LSP_COUNT(25)
-    // ---------------- phase A ------------------------------------------------------------------------------
-    if constexpr (C::QUAD) {
-        // quadrotor: work item = (knot k, player i, seed direction c of the player's 12 states + 4 rotor commands): column c of
-        // [A_i | B_i] = d RK2 / d (x_i, u_i)[c] by forward-mode differentiation along e_c; the item with c = 0 also leaves the
-        // RK2 value (the dyn rows of phase B read it)
-        const double qmass = phase_f64(pr.qmass);
-        for (int e = lane; e < (N - 1) * P * 16; e += C::NT) {
-            const int c = e & 15, i = (e >> 4) % P, k = (e >> 4) / P;
-            const double* sk = zstate<C>(z, k);
-            Jet xj[12], uj[4], xo[12];
-#pragma unroll
-            for (int j = 0; j < 12; j++) xj[j] = Jet{sk[i + j * P], c == j ? 1.0 : 0.0};
-#pragma unroll
-            for (int j = 0; j < 4; j++) uj[j] = Jet{z[n + hu<C>(k, i) + j], c == 12 + j ? 1.0 : 0.0};
-            quad_rk2(xj, uj, qmass, dt, xo);
-            double* __restrict__ rc = G.rec(pr) + (size_t)k * R::LEN + R::COEF + i * C::QS;
-            const int o = c < 12 ? C::QA + c : C::QB + (c - 12), ld = c < 12 ? 12 : 4;
-#pragma unroll
-            for (int j = 0; j < 12; j++) rc[o + j * ld] = xo[j].d;
-            if (c == 0) {
-#pragma unroll
-                for (int j = 0; j < 12; j++) rc[C::QX + j] = xo[j].v;
-            }
-        }
-    }
+    constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);
     if (C::NC > 0 || C::POS) {
         const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
         constexpr int HEAD = AsmLds<C>::HEAD, SL = AsmLds<C>::SL, SPP = AsmLds<C>::SPP, SGVT = HEAD - R::GVT;   // stage offset of the table
@@ -937,10 +914,11 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             if constexpr (C::POS) {
                 constexpr int PD = C::PD, NS = C::NS;
                 const double w = (kn < N - 1) ? dt : 1.0;
-                const double* x1 = z + n + hx<C>(k);
+                const double* x1 = z + n + hx<C>(k); const double* d1 = dzp ? dzp + n + hx<C>(k) : nullptr;
+                auto xp = [&](int idx) { const double v = x1[idx]; return d1 ? v + alpha * d1[idx] : v; };    // position of the (trial) iterate
                 double xi[PD], ga[PD], dd[NS];
 #pragma unroll
-                for (int a = 0; a < PD; a++) { xi[a] = x1[a * P + i]; ga[a] = 0.0; }
+                for (int a = 0; a < PD; a++) { xi[a] = xp(a * P + i); ga[a] = 0.0; }
 #pragma unroll
                 for (int t = 0; t < NS; t++) dd[t] = 0.0;
 #pragma unroll
@@ -954,7 +932,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                     if (pairs_on) {
                         double dl[PD];
 #pragma unroll
-                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - x1[a * P + j];
+                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - xp(a * P + j);
                         const double dl0 = dl[0], dl1 = dl[1];
                         const double s2 = dl0 * dl0 + dl1 * dl1;
                         if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173 (planar: px[i])
@@ -985,7 +963,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
 #pragma unroll
                                 for (int a2 = 0; a2 <= a; a2++) H[C::sym(a, a2)] += am * 4.0 * dl[a2] * dl[a];
                             }
-                            if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
+                            if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
                         }
                     }
 #pragma unroll
@@ -1010,7 +988,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
 #pragma unroll
                             for (int a2 = 0; a2 <= a; a2++) dd[C::sym(a, a2)] += am * g[a2] * g[a];
                         }
-                        if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, c));
+                        if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
                     };
                     const double* Wc = ext_walls(pr, pr.extc); const double* Cc = ext_circs(pr, pr.extc);
                     const unsigned wmask = pr.wall_mask[i], cmask = pr.circ_mask[i];
@@ -1062,6 +1040,52 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
         }
         if constexpr (!AsmLds<C>::STAGED) game_sync();
     }
+}
+
+// IBR = true: best-response statistics of player ip (solver_methods.jl:230-289): norms over the rows of the vertical mask
+// (player ip's opt rows + all dyn rows, newton_core.jl:205-246), player-specific violations (statistics.jl:59-73), the
+// proximal term only on player ip's rows (global_quantities.jl:262-280); out.l1full is the full ||res||_1 for record!.
+template <class C, int MODE, bool IBR = false>
+__device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, int zrefsel, double reg, double jreg,
+                              ResOut& out, int ip = -1) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    const double* __restrict__ z = G.z(zsel);
+    const double* __restrict__ zref = zrefsel >= 0 ? G.z(zrefsel) : nullptr;
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b;
+    using R = Rec<C>;
+    const int N = phase_int(pr.N), lane = phase_lane();
+    const double dt = phase_f64(pr.dt);
+    AsmAcc acc;
+    double& l1 = acc.l1; double& l1r = acc.l1r; double& l1f = acc.l1f; double& vopt = acc.vopt; double& vdyn = acc.vdyn; double& vcon = acc.vcon; double& vsta = acc.vsta; int& bad = acc.bad;
+    constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
+    LSP_T0 LSP_COUNT(25)
+    // ---------------- phase A ------------------------------------------------------------------------------
+    if constexpr (C::QUAD) {
+        // quadrotor: work item = (knot k, player i, seed direction c of the player's 12 states + 4 rotor commands): column c of
+        // [A_i | B_i] = d RK2 / d (x_i, u_i)[c] by forward-mode differentiation along e_c; the item with c = 0 also leaves the
+        // RK2 value (the dyn rows of phase B read it)
+        const double qmass = phase_f64(pr.qmass);
+        for (int e = lane; e < (N - 1) * P * 16; e += C::NT) {
+            const int c = e & 15, i = (e >> 4) % P, k = (e >> 4) / P;
+            const double* sk = zstate<C>(z, k);
+            Jet xj[12], uj[4], xo[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) xj[j] = Jet{sk[i + j * P], c == j ? 1.0 : 0.0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) uj[j] = Jet{z[n + hu<C>(k, i) + j], c == 12 + j ? 1.0 : 0.0};
+            quad_rk2(xj, uj, qmass, dt, xo);
+            double* __restrict__ rc = G.rec(pr) + (size_t)k * R::LEN + R::COEF + i * C::QS;
+            const int o = c < 12 ? C::QA + c : C::QB + (c - 12), ld = c < 12 ? 12 : 4;
+#pragma unroll
+            for (int j = 0; j < 12; j++) rc[o + j * ld] = xo[j].d;
+            if (c == 0) {
+#pragma unroll
+                for (int j = 0; j < 12; j++) rc[C::QX + j] = xo[j].v;
+            }
+        }
+    }
+    assemble_phase_a<C, MODE, IBR>(pr, G, L, z, nullptr, 0.0, N, lane, dt, ip, acc);
     LSP(20)
     // ---------------- phase B ------------------------------------------------------------------------------
     // Every residual row of every step is independent once phase A has left the coefficients and the pair-gradient table:
@@ -1242,6 +1266,150 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
     out.l1reg = (MODE == 3) ? wave_sum(l1r) : out.l1;
     out.l1full = IBR ? wave_sum(l1f) : out.l1;
     team_combine<C>(out);
+    LSP(24)
+}
+
+// ================================================================================================
+// Fused trial pass (round 4; double integrator, one wavefront per game: the C2 / C4 kernel).  One pass does what update_traj! +
+// assemble_pass did in two: the trial iterate z + alpha dz is formed where the source iterate is read, written out once, and every
+// residual row is evaluated out of LDS, FT time steps at a time -- the trajectory, the direction and the proximal reference (= the
+// source iterate) cross the memory system once instead of the four to five times of the three flat row loops (per-pass counters:
+// tests/probes/phase_bytes.sh; r03: 112 KB read per trial against 17 + 17 KB of trajectory and direction).
+//   AXPY = false: the rows of the source iterate itself (record!: MODE 1, no proximal term, nothing written but the records)
+//   MODE 0 / 3 as in assemble_pass (3 = statistics and records of the unregularised rows + the regularised norm l1reg)
+// Same row arithmetic as assemble_pass (same expressions in the same order); the norms are summed in another order.
+// ================================================================================================
+template <class C, int MODE, bool AXPY>
+__device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alpha, bool prox, double reg, double jreg, ResOut& out) {
+    static_assert(AsmLds<C>::FUSED && (MODE == 0 || MODE == 1 || MODE == 3), "fused trial pass: double integrator, statistics / record modes");
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b, FT = AsmLds<C>::FT, TAB = AsmLds<C>::TAB, NXU = n + m;
+    using R = Rec<C>;
+    constexpr bool RECS = (MODE == 1 || MODE == 3);
+    const int N = phase_int(pr.N), lane = phase_lane();
+    const double dt = phase_f64(pr.dt);
+    const double* __restrict__ zs = G.z(0);                    // source iterate = proximal reference
+    const double* __restrict__ dz = G.z(2);
+    double* __restrict__ zo = G.z(1);                          // the trial iterate goes here
+    AsmAcc acc;
+    LSP_T0 LSP_COUNT(25)
+    // ---- phase A over all steps (positions of the trial iterate formed on the fly), heads and tables to the records as in assemble_pass
+    assemble_phase_a<C, MODE, false>(pr, G, L, zs, AXPY ? dz : nullptr, alpha, N, lane, dt, -1, acc);
+    LSP(20)
+    auto& Ch = L.ch;
+    for (int e = lane; e < AsmLds<C>::NLQR; e += WAVE) Ch.lqr[e] = G.Qd(pr)[e];          // [Qd | xf | Rd | uf]
+    const double* lQd = Ch.lqr; const double* lxf = lQd + P * ni; const double* lRd = lQd + 2 * P * ni; const double* luf = lRd + P * mi;
+    double* __restrict__ recg = G.rec(pr);
+    auto finish = [&](double r, double dprox, bool dynrow, unsigned rec_off) {
+        const double rr = prox ? r + reg * dprox : r;                // regularize_residual! (global_quantities.jl:67-86)
+        if (MODE == 3) acc.l1r += fabs(rr); else r = rr;
+        acc.bad |= !isfinite(r);
+        acc.l1 += fabs(r);
+        if (dynrow) acc.vdyn = fmax(acc.vdyn, fabs(r)); else acc.vopt = fmax(acc.vopt, fabs(r));
+        if (RECS) recg[rec_off] = r;
+    };
+    for (int k0 = 0; k0 < N - 1; k0 += FT) {
+        const int nst = (N - 1 - k0) < FT ? (N - 1 - k0) : FT;            // steps of this chunk
+        const int nblk = (k0 + nst < N - 1) ? nst + 1 : nst;             // blocks staged: the chunk's and the next one (A' lambda_{k+1})
+        // ---- stage: x_k of the first step, then blocks k0 .. k0 + nblk - 1; the trial blocks of the chunk's own steps go out here
+        if (lane < n) {
+            const int src = k0 == 0 ? lane : n + (k0 - 1) * b + lane;
+            double v = zs[src];
+            if (AXPY && k0 > 0) v = v + alpha * dz[src];                  // (x_1 does not move)
+            Ch.xprev[lane] = v;
+        }
+        {
+            const int base = n + k0 * b, cnt = nblk * b, own = nst * b;
+            for (int e0 = lane; e0 < cnt; e0 += 4 * WAVE) {
+                double a[4], d[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const int e = e0 + t * WAVE, ec = e < cnt ? e : e0; a[t] = zs[base + ec]; d[t] = AXPY ? dz[base + ec] : 0.0; }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int e = e0 + t * WAVE;
+                    if (e < cnt) {
+                        const double v = AXPY ? a[t] + alpha * d[t] : a[t];
+                        Ch.zt[e] = v;
+                        if (AXPY && e < own) zo[base + e] = v;
+                        const int j = e / b, o = e % b;
+                        if (o < NXU && j < nst) Ch.zxu[j * NXU + o] = a[t];
+                    }
+                }
+            }
+            if constexpr (C::POS) {
+                const int tcnt = nst * TAB;
+                for (int e = lane; e < tcnt; e += WAVE) Ch.gvt[e] = recg[(size_t)(k0 + e / TAB) * R::LEN + R::GVT + e % TAB];
+            }
+        }
+        sweep_sync<C>();
+        // ---- rows opt_i,x_{k+1}[a]
+        for (int e = lane; e < nst * P * n; e += WAVE) {
+            const int ks = e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n, k = k0 + ks;
+            const double* blk = Ch.zt + ks * b;
+            const bool has_next = (k + 1 <= N - 2);
+            const double w = (k + 1 < N - 1) ? dt : 1.0;
+            double r = -blk[n + m + ei];
+            {
+                const double* ln = blk + (has_next ? b : 0) + n + m + i * n;
+                const double t = AT_vec<C>(nullptr, dt, [&](int rr) { return ln[rr]; }, a);
+                r += has_next ? t : 0.0;
+            }
+            const bool own = (a % P == i);
+            const double tqv = lQd[i * ni + a / P], txv = lxf[i * ni + a / P];
+            const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
+            const double xa = blk[a];
+            r += w * (tq * (xa - tx));
+            if (C::POS) { const double gv = Ch.gvt[ks * TAB + (i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0)]; r += (a < C::PD * P) ? gv : 0.0; }
+            const double dprox = prox ? xa - Ch.zxu[ks * NXU + a] : 0.0;
+            finish(r, dprox, false, (unsigned)(k * R::LEN + R::RX + ei));
+        }
+        LSP(21)
+        // ---- rows opt_i,u_{i,k}[c]
+        for (int e = lane; e < nst * m; e += WAVE) {
+            const int ks = e / m, c = e % m, i = c % P, k = k0 + ks;
+            const double* blk = Ch.zt + ks * b;
+            const double u = blk[n + uoff<C>(c)];
+            const double* lo = blk + n + m + i * n;
+            const double tr = lRd[(c % P) * mi + c / P], tu = luf[(c % P) * mi + c / P];
+            double g = 0.0, rhat = dt * tr + jreg;
+            if (pr.has_ctl) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int ci = con_ctl<C>(pr, k, half * m + c);
+                    const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                    if (isfinite(cv)) {
+                        const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
+                        const double wl = lm + am * cv;
+                        g += (half == 0 ? wl : -wl); rhat += am;
+                        acc.vcon = fmax(acc.vcon, fmax(0.0, cv));
+                    }
+                }
+            }
+            const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(nullptr, dt, [&](int rr) { return lo[rr]; }, c);
+            const double dprox = prox ? u - Ch.zxu[ks * NXU + n + uoff<C>(c)] : 0.0;
+            if (RECS) recg[(size_t)k * R::LEN + R::RHAT + c] = rhat;
+            finish(r, dprox, false, (unsigned)(k * R::LEN + R::RU + c));
+        }
+        LSP(22)
+        // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]: position rows x + (v + dt/2 u) dt, velocity rows v + u dt
+        for (int e = lane; e < nst * n; e += WAVE) {
+            const int ks = e / n, a = e % n, k = k0 + ks;
+            const double* blk = Ch.zt + ks * b;
+            const double* xk = ks == 0 ? Ch.xprev : blk - b;
+            const int j = a < m ? a : a - m;
+            const double uj = blk[n + uoff<C>(j)], base = xk[a], vel = xk[j + m];
+            const double vm = vel + (uj * dt) * 0.5;
+            const double xn = base + (a < m ? vm : uj) * dt;
+            finish(xn - blk[a], 0.0, true, (unsigned)(k * R::LEN + R::RD + a));
+        }
+        LSP(23)
+        sweep_sync<C>();                                   // the next chunk overwrites the buffers
+    }
+    out.l1 = wave_sum(acc.l1); out.opt = wave_max(acc.vopt); out.dyn = wave_max(acc.vdyn);
+    out.con = wave_max(acc.vcon); out.sta = wave_max(acc.vsta); out.nonfinite = wave_or(acc.bad);
+    out.l1reg = (MODE == 3) ? wave_sum(acc.l1r) : out.l1;
+    out.l1full = out.l1;
     LSP(24)
 }
 
@@ -3092,13 +3260,14 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
             if (bad) { st = ALG_STATUS_SINGULAR; break; }
         }
         // The tolerance follows the conditioning the penalties bring: a forward error target delta needs a backward error of delta / cond(J), and
-        // cond(J) grows with the largest penalty.  tol applies from mu_max >= refine_mu on; below, it is relaxed in proportion, at most 16 x.
-        // (Most directions are far below tol: the penalties are only looked at inside the band.)
+        // cond(J) grows with the largest penalty.  tol applies from mu_max >= refine_mu on; below, it is relaxed in proportion, at most 256 x.
+        // (Most directions are far below tol: the penalties are only looked at inside the band.  In a homogeneous batch a correction
+        // solve delays its game by a whole direction and the launch with it: 68 corrections in 45 056 directions of C2 cost 3 %.)
         const double tol = phase_f64(pr.refine_tol);
         if (!(uni(omega) > tol) || pass >= rmax) break;
-        if (!(uni(omega) > 16.0 * tol)) {
+        if (!(uni(omega) > 256.0 * tol)) {
             const double mumax = con_mu_max<C>(pr, G0);
-            const double relax = fmin(fmax(phase_f64(pr.refine_mu) / fmax(mumax, 1e-300), 1.0), 16.0);
+            const double relax = fmin(fmax(phase_f64(pr.refine_mu) / fmax(mumax, 1e-300), 1.0), 256.0);
             if (!(uni(omega) > relax * tol)) break;
         }
         // rhs of the correction system from the buffer that holds the latest solve (d itself, or the previous correction)
@@ -3206,7 +3375,8 @@ template <class C>
 __device__ __forceinline__ RecScalars make_record(CPR pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
     ResOut ro;
     LSP_T0 LSP_COUNT(29)
-    assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, jreg, ro);
+    if constexpr (AsmLds<C>::FUSED) assemble_fused<C, 1, false>(pr, G, L.a, 0.0, false, 0.0, jreg, ro);
+    else assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, jreg, ro);
     game_sync();
     LSP(27)
     return push_stats(pr, G, ro, delta, outer, out);
@@ -3221,15 +3391,21 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
     while (j < pr.opt.ls_iter) {
         const auto& o = phase_params(pr).opt;
         LSP_T0 LSP_COUNT(18)
+        ResOut ro;
+        if constexpr (AsmLds<C>::FUSED) {
+            // update_traj! and the residual of the trial in one pass over the trajectory (assemble_fused)
+            if (C::TRIAL_REUSE && jreg_next >= 0.0 && o.regularize) assemble_fused<C, 3, true>(pr, G, L.a, alpha, true, reg, jreg_next, ro);
+            else assemble_fused<C, 0, true>(pr, G, L.a, alpha, o.regularize != 0, reg, 0.0, ro);
+        } else {
         update_traj<C>(pr, G, 1, 0, alpha);
         game_sync();
         LSP(16)
-        ResOut ro;
         bool done = false;
         if constexpr (C::TRIAL_REUSE) {
             if (jreg_next >= 0.0 && o.regularize) { assemble_pass<C, 3>(pr, G, L.a, 1, 0, reg, jreg_next, ro); done = true; }
         }
         if (!done) assemble_pass<C, 0>(pr, G, L.a, 1, o.regularize ? 0 : -1, reg, 0.0, ro);
+        }
         LSP(17)
         if (jreg_next >= 0.0) tcache_store(pr, G, ro);
         const double rt = uni(ro.l1reg / (double)phase_int(phase_params(pr).S));

@@ -473,7 +473,7 @@ end
 Iterative refinement of the Newton direction (alg_set_refinement): the stand-in for the backward stability of `lu(core.jac) \\ core.res`
 (solver_methods.jl:87).  After every structured solve the opt-u rows of `J d = -res` are evaluated; while their row-wise backward error exceeds `tol`
 the direction is corrected by one more elimination on the residual (at most `max_steps` times); below `mu_tight` (largest penalty of the game)
-the tolerance is relaxed in proportion, at most 16 x.  `max_steps = 0` switches both off.
+the tolerance is relaxed in proportion, at most 256 x.  `max_steps = 0` switches both off.
 """
 set_refinement!(bp::BatchedGameProblem; max_steps::Integer=2, tol::Float64=2.0^-34, mu_tight::Float64=1.6e5) =
     check(ccall((:alg_set_refinement, LIB), Cint, (Ptr{Cvoid}, Int32, Float64, Float64), bp.h, max_steps, tol, mu_tight))

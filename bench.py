@@ -59,12 +59,18 @@ def survey_balg(N, n, m, p):
     return 8 * (2 * (S + n) + 2 * (N - 1) * (b * b + b * p * n))
 
 
-def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0):
-    """Algorithmic HBM bytes per game-Newton-iteration of THIS implementation ("Roofline
-    accounting"): one line-search trial (axpy), one assemble pass (the accepted trial doubles as the next record!),
-    the three sweeps of the Newton direction with their step-record slices and the spilled gains.  The accepted
-    trial becomes pdtraj by exchanging buffers (no traffic).  Every array is counted once per pass that has to
-    touch it: this is the floor for this algorithm, re-reads are not included."""
+def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0, gate=True):
+    """Algorithmic HBM bytes per game-Newton-iteration of THIS implementation (DESIGN.md "Roofline accounting"): what the passes of
+    one iteration have to move when every array crosses the memory system once per pass that needs it -- the floor of this
+    algorithm; re-reads, partial lines and the per-outer-iteration record pass are not included.
+      trial pass   double integrator (C2 / C4): the FUSED pass of round 4 -- read z and dz, write the trial, read the multipliers, write the
+                   step records; other models: update_traj! (read z, dz, write the trial) + assemble pass (read trial and proximal
+                   reference, multipliers, write the records incl. the pair-gradient table)
+      backward     read the record slice [.. rd], write the gains
+      forward      read gains and record slice, write dx, du (double integrator: also reads [.. rx] and parks w = rx + Q dx for the costate)
+      costate      read [.. rx] and dx (double integrator: w only), write dlambda
+      gate         the opt-u rows of the refinement gate: du, two dlambda entries per control, R^, ru
+    The accepted trial becomes pdtraj by exchanging buffers (no traffic)."""
     S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
     it, K = S + n, N - 1
     nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p, "Q": 204 * p}[family]      # RK2 Jacobian coefficients per step (quadrotor: dense blocks)
@@ -74,11 +80,18 @@ def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0):
     len_rec = len_sweep + 2 * p * p                                      # + pair-gradient table
     con = K * npair + (2 * m * K if family in ("C3", "C5", "Q") else 0)  # constraint rows touched (lam, mu read)
     gains = K * m * (n + 1)
-    trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec))   # axpy + assemble pass
+    fused = family == "C2"                                               # double integrator, one wavefront per game
+    if fused:
+        trial = ls_trials_per_iter * (it + S + S + 2 * con + K * len_sweep)
+        forward = gains + K * (len_costate + n) + K * (n + m) + K * p * n
+        costate = 2 * K * p * n
+    else:
+        trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec))   # axpy + assemble pass
+        forward = gains + K * (nc + n) + K * (n + m)
+        costate = K * len_costate + K * n + K * p * n
     backward = K * len_sweep + gains
-    forward = gains + K * (nc + n) + K * (n + m)
-    costate = K * len_costate + K * n + K * p * n
-    return 8 * (trial + backward + forward + costate)
+    gate_b = K * 5 * m if gate else 0
+    return 8 * (trial + backward + forward + costate + gate_b)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -322,7 +335,7 @@ def main():
         value = iters_all * K / elapsed
         kern_s = float(np.mean(kernel_ms)) * 1e-3
         p, n, m, N = b.p, b.n, b.m, b.N
-        own = structured_bytes(family, N, n, m, p)
+        own = structured_bytes(family, N, n, m, p, gate=refine_steps > 0)
         kernel = "k_mpc_loop" if args.mpc_steps else "k_newton_solve"
         achieved = own * iters_rank / kern_s                         # B/s of this rank's launch
         roof = {

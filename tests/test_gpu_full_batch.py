@@ -155,19 +155,24 @@ def test_c5_receding_horizon_64_seeds_x_200_steps_against_the_oracle(alg, orc):
     and the fused loop kernel (one launch, alg_mpc_solve) reproduces the step-wise launches.
 
     The arbiter (round 3): every one of the 12 800 solves is also run by the oracle's source in long double arithmetic on the same
-    inputs.  Measured: in the 7 solves whose counts differ the arbiter's counts are the double oracle's 7 times and the HIP path's 0
-    times; among the solves where all three agree on the counts and converge, the HIP trajectory is the far one (more than
-    1e-8 + 100 x the oracle's distance from the arbiter) in 21 solves, the oracle's in none; the worst distances are 1.35e-5 (HIP)
-    and 2.3e-8 (oracle).  I.e. the 1e-4 bound on long solves is the HIP path's own error on ill-conditioned solves (penalties
-    grown over tens of iterations make the pivot blocks of the structured elimination ill-conditioned; the pivoted banded LU is
-    backward stable regardless), not a shared amplification.  The bounds below pin that finding: rare (<= 0.25 % of the solves),
-    small (<= 1e-4), and never the other way round by more than the oracle's own 1e-6."""
+    inputs.  Round 3 measured, WITHOUT refinement of the Newton direction: in the 7 solves whose counts differ the arbiter's counts are
+    the double oracle's 7 times and the HIP path's 0 times; among the solves where all three agree on the counts and converge, the HIP
+    trajectory is the far one (more than 1e-8 + 100 x the oracle's distance from the arbiter) in 21 solves, the oracle's in none; worst
+    distances 1.35e-5 (HIP) and 2.3e-8 (oracle) -- the structured elimination loses digits where the penalties sit at their ceiling
+    (warm-started multipliers, mu = 1e7, first Newton iterations of a solve: direction errors of 1e-8 .. 1e-7 against the LU's 1e-12,
+    tests/probes/c5_far_probe.py).  Round 4: the opt-u rows of every direction are evaluated and the direction is refined when their
+    backward error says so (alg_set_refinement; ~15 000 correction solves over the 12 800 solves).  Measured with the gate: counts
+    identical in ALL solves, the HIP trajectory far in 0 solves (the oracle's in 1), worst distances from the arbiter 1.87e-8 (HIP) and
+    2.44e-8 (oracle).  The bounds below pin that: no count mismatch beyond one arbiter split either way, the HIP path never the far
+    one more often than the oracle + 1, and never further from the arbiter than 1e-8 + 1.5 x the double oracle itself."""
     T = 200
     r = _c5_lockstep(alg, orc, T, waves_per_game=1, hard_iters=10)
     assert r["worst_first"] <= 1.0, r["worst_first"]
-    assert r["n_diff"] <= 0.002 * r["n_solves"], (r["n_diff"], r["n_solves"])
-    assert r["worst_short"] <= 1e-8 and r["worst_all"] <= 1e-4, (r["worst_short"], r["worst_all"])
-    assert r["hip_far"] <= 0.0025 * r["n_solves"] and r["worst_eg"] <= 1e-4, (r["hip_far"], r["worst_eg"])
+    assert r["n_diff"] <= 1, (r["n_diff"], r["n_solves"])                                       # round 3: 7
+    assert r["worst_short"] <= 1e-8, r["worst_short"]
+    assert r["hip_far"] <= r["orc_far"] + 1, (r["hip_far"], r["orc_far"])                       # round 3: 21 against 0
+    assert r["worst_eg"] <= 1e-8 + 1.5 * r["worst_eo"], (r["worst_eg"], r["worst_eo"])          # round 3: 1.35e-5 against 2.3e-8
+    assert r["worst_all"] <= 1e-8 + r["worst_eg"] + r["worst_eo"], (r["worst_all"], r["worst_eg"], r["worst_eo"])   # the two double programs meet within their distances from the arbiter
     assert r["orc_far"] <= 0.0025 * r["n_solves"] and r["worst_eo"] <= 1e-6, (r["orc_far"], r["worst_eo"])
     assert r["hip_right"] + r["orc_right"] + r["neither"] <= 3 * r["n_diff"] + 8, r      # the arbiter disagrees with BOTH only on hard solves
     states = r["states"]
@@ -190,11 +195,12 @@ def test_c5_receding_horizon_team_kernel_lock_step(alg, orc):
     MPC steps.  The team sums the residual norms in a different order, so its closed loop visits slightly different states than
     the one-wavefront loop and meets other hard solves (non-converging 100-iteration solves at steps 4-6 of this run); measured:
     22 of 12 800 solves with different counts in round 2; since round 3 (DPP reductions in both shapes) the team's 100 steps give the
-    one-wavefront kernel's tallies (7 differing solves, all at steps 10-13)."""
+    one-wavefront kernel's tallies (7 differing solves, all at steps 10-13); round 4 (refined directions): see the test above."""
     r = _c5_lockstep(alg, orc, 100, waves_per_game=0, hard_iters=10)
     assert r["worst_first"] <= 1.0, r["worst_first"]
-    assert r["n_diff"] <= 0.005 * r["n_solves"], (r["n_diff"], r["n_solves"])
+    assert r["n_diff"] <= 2, (r["n_diff"], r["n_solves"])
     assert r["worst_short"] <= 1e-8, r["worst_short"]
+    assert r["hip_far"] <= r["orc_far"] + 1 and r["worst_eg"] <= 1e-8 + 2.0 * r["worst_eo"], (r["hip_far"], r["orc_far"], r["worst_eg"], r["worst_eo"])
 
 
 @pytest.mark.parametrize("cfg,nw,ids", [("C5", 4, np.arange(128, 192)), ("C3", 2, np.arange(0, 64)), ("C3", 4, np.arange(64, 96)),

@@ -77,13 +77,19 @@ def rng_flag(rng, first, store, name):
 
 
 # Trajectory tolerance of the random-problem parity: SURVEY.md 8(d)'s 1e-8 (relative to the largest entry).  Round 2 ran all families at
-# 1e-7; with the arbiter (below) the two cases out of 164 that need it are named: an extended-constraint Bicycle problem and a
-# three-quadrotor problem (the dense elimination's conditional stability); at 1e-9 one more quadrotor seed joins them.
+# 1e-7; round 3 named the two cases out of 164 that still needed it (an extended-constraint Bicycle problem and a three-quadrotor problem:
+# the elimination's conditional stability).  Round 4: the Newton direction is refined when its opt-u rows say so (alg_set_refinement) and
+# the cases that still miss 1e-8 are settled by the arbiter inside _compare_solve (the HIP path no further from the extended-precision
+# run than the double oracle) instead of a looser tolerance -- the exception list is empty and stays as the place to name one.
 FUZZ_TOL = float(__import__("os").environ.get("ALGAMES_FUZZ_TOL", 1e-8))
-FUZZ_TOL_LOOSE = {("extended", 2): 1e-7, ("dense", 19): 1e-7}
+FUZZ_TOL_LOOSE = {}
 
 
-def _compare_solve(g, o, tag, tol=None):
+def _compare_solve(g, o, tag, tol=None, x=None):
+    """Discrete history identical, statistics within rounding, trajectories within FUZZ_TOL of each other -- or, where a problem amplifies
+    rounding differences beyond that (x = the long-double arbiter of the same problem), the HIP path no further from the arbiter than
+    the double oracle is: |hip - x| <= 4 |oracle - x| + FUZZ_TOL (both double programs miss the extended-precision run by the same
+    amount; round 3 kept a list of such cases at 1e-7, tests/probes/fuzz_case_probe.py shows who is far)."""
     tol = FUZZ_TOL if tol is None else tol
     sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
     for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
@@ -92,7 +98,16 @@ def _compare_solve(g, o, tag, tol=None):
     zg, zo = g.get_traj(0), o.get_traj(0)
     if ok.any():
         scale = max(1.0, np.abs(zo[ok]).max())
-        assert np.abs(zg[ok] - zo[ok]).max() <= tol * scale, (tag, np.abs(zg[ok] - zo[ok]).max(), scale)
+        err = np.abs(zg[ok] - zo[ok]).max()
+        if err > tol * scale and x is not None:
+            sx = x.newton_solve(init=True, game_id0=7)
+            same = np.all([sx[f] == so[f] for f in ("status", "outer_iters", "newton_iters", "ls_failures")], axis=0) & ok
+            zx = x.get_traj(0)
+            eg, eo = np.abs(zg[same] - zx[same]).max(initial=0.0), np.abs(zo[same] - zx[same]).max(initial=0.0)
+            print("arbiter consulted:", tag[:4], "|hip-orc| %.2e |hip-x| %.2e |orc-x| %.2e scale %.1f" % (err, eg, eo, scale))
+            assert same.all() and eg <= 4.0 * eo + tol * scale, (tag, err, eg, eo, scale)
+        else:
+            assert err <= tol * scale, (tag, err, scale)
         for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
             assert np.allclose(sg["last"][f][ok], so["last"][f][ok], rtol=1e-6, atol=1e-9), (tag, f)
     hg, ho = g.get_history(0), o.get_history(0)
@@ -102,15 +117,15 @@ def _compare_solve(g, o, tag, tol=None):
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_base_instantiations(alg, orc, seed):
     rng = np.random.default_rng(1000 + seed)
-    g, o, tag = _random_pair(alg, orc, rng, ext=False)
-    _compare_solve(g, o, tag)
+    g, o, x, tag = _random_pair(alg, orc, rng, ext=False, arb="x")
+    _compare_solve(g, o, tag, x=x)
 
 
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_extended_instantiations(alg, orc, seed):
     rng = np.random.default_rng(5000 + seed)
-    g, o, tag = _random_pair(alg, orc, rng, ext=True)
-    _compare_solve(g, o, tag, FUZZ_TOL_LOOSE.get(("extended", seed)))
+    g, o, x, tag = _random_pair(alg, orc, rng, ext=True, arb="x")
+    _compare_solve(g, o, tag, FUZZ_TOL_LOOSE.get(("extended", seed)), x=x)
 
 
 DENSE_FAMILIES = [(DI, 1), (DI, 3), (DI, 4), (3, 1), (3, 2), (3, 3), (3, 4)]      # DoubleIntegrator d = 3 / QuadrotorGame (model id 3)
@@ -141,8 +156,8 @@ def test_fuzz_five_and_six_players(alg, orc, seed):
     """DoubleIntegrator d = 2, Unicycle, Bicycle with five and six players (dense Newton direction), base or extended set."""
     rng = np.random.default_rng(17000 + seed)
     model, p = P56_FAMILIES[seed % 6]
-    g, o, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool(seed % 2)), force=(model, p), force_d3=False)
-    _compare_solve(g, o, tag)
+    g, o, x, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool(seed % 2)), force=(model, p), force_d3=False, arb="x")
+    _compare_solve(g, o, tag, x=x)
 
 
 @pytest.mark.parametrize("seed", range(28))
@@ -151,10 +166,10 @@ def test_fuzz_dense_direction_instantiations(alg, orc, seed):
     QuadrotorGame with p = 1..4, base or extended set, random subsets of every ingredient, both kernel shapes."""
     rng = np.random.default_rng(13000 + seed)
     fam = DENSE_FAMILIES[seed % len(DENSE_FAMILIES)]
-    g, o, tag = _random_pair(alg, orc, rng, ext=bool(seed % 2), force=fam)
+    g, o, x, tag = _random_pair(alg, orc, rng, ext=bool(seed % 2), force=fam, arb="x")
     if seed % 3 == 0:
         g.set_waves_per_game(1)
-    _compare_solve(g, o, tag, FUZZ_TOL_LOOSE.get(("dense", seed)))
+    _compare_solve(g, o, tag, FUZZ_TOL_LOOSE.get(("dense", seed)), x=x)
 
 
 @pytest.mark.parametrize("seed", range(16))
@@ -238,7 +253,7 @@ def test_fuzz_team_kernel_regressions(alg, orc, seed):
 # records lose two to four digits more per accepted step than the oracle's.  The Jacobians agree to 1e-16 in every family.  So the
 # record-by-record bound is asserted for the sparse families only; the quadrotor seeds are held to the decision tally and to
 # test_direction_backward_error_against_the_arbiter below.
-ARB_C = 1024.0
+ARB_C = 16.0
 ARB_FIELDS = ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio")
 
 
@@ -289,7 +304,8 @@ def test_direction_backward_error_against_the_arbiter(alg, orc, seed, fam):
     arbiter's iterate after a half step), measured in the ARBITER's Jacobian and residual:
         bwd(d) = |J_x d + r_x|_inf / (|J_x|_inf |d|_inf + |r_x|_inf).
     DoubleIntegrator / Unicycle / Bicycle: the structured elimination is as backward stable as the pivoted banded LU (same bwd within a
-    factor 64).  QuadrotorGame: conditionally stable, bwd <= 1e-12 (measured 1e-16 .. 6e-14; LU 1e-18) -- the comment block above."""
+    factor 64).  QuadrotorGame: the bare elimination is only conditionally stable (round 3: 1e-16 .. 6e-14 where LU holds 1e-18); with the
+    refinement gate (alg_set_refinement, round 4) the same bound as the other families holds, and bwd <= 1e-15 in absolute terms."""
     kw = dict(ext=False) if fam is None else dict(ext=bool(seed % 2), force=fam)
     g, o, x, tag = _random_pair(alg, orc, np.random.default_rng(seed), arb="x", **kw)
     reg = 1e-6
@@ -305,7 +321,7 @@ def test_direction_backward_error_against_the_arbiter(alg, orc, seed, fam):
             bwd = lambda d: np.abs(J @ d + r).max() / (np.abs(J).sum(1).max() * np.abs(d).max() + np.abs(r).max())
             bg, bo, bx = bwd(dg[game]), bwd(do[game]), bwd(dx[game])
             if tag[0] == 3:
-                assert bg <= 1e-12, (tag, it, game, bg, bo, bx)
+                assert bg <= 1e-15, (tag, it, game, bg, bo, bx)             # round 3 (no refinement): 1e-16 .. 6e-14
             else:
                 assert bg <= 64.0 * max(bo, bx) + 1e-17, (tag, it, game, bg, bo, bx)
         for b in (g, o, x):

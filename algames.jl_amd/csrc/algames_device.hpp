@@ -725,7 +725,7 @@ __device__ __forceinline__ double cyl_val(const double* Y, int c, const double (
 //   (EXT only: [RQ (P n): diagonal state-bound Hessian of player i at knot k+1])
 //   [rx (P n): rows opt_i,x_{k+1}]                                                                  <- LEN_COSTATE
 //   [Rhat (m): R^ of knot k incl. reg] [ru (m): rows opt_i,u_{i,k}, joint order] [rd (n): dyn_k]      <- LEN_SWEEP
-//   [gvt (PD P^2): pair gradient table, only used inside the assemble pass]
+//   the pair gradient tables (PD P^2 per step, only used inside the assemble pass) follow the N - 1 records (Rec::gvt)
 // ================================================================================================
 template <class C> struct Rec {
     static constexpr int COEF = 0;
@@ -738,8 +738,10 @@ template <class C> struct Rec {
     static constexpr int RU = RHAT + C::m;
     static constexpr int RD = RU + C::m;
     static constexpr int LEN_SWEEP = RD + C::n;
-    static constexpr int GVT = LEN_SWEEP;
-    static constexpr int LEN = GVT + C::PD * C::P * C::P;
+    static constexpr int LEN = LEN_SWEEP;                         // record stride: the sweeps stream whole records
+    // pair-gradient tables (only used inside the assemble pass): behind the N - 1 records, TAB doubles per step
+    static constexpr int TAB = C::PD * C::P * C::P;
+    __device__ static constexpr int gvt(int N, int k) { return (N - 1) * LEN + k * TAB; }
 };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -812,12 +814,13 @@ struct AsmLds {
     // batch sizes and write directly)
     static constexpr bool STAGED = (C::WPE == 4 && C::NW == 1);
     static constexpr int HEAD = Rec<C>::RQ, SL = HEAD + C::PD * C::P * C::P, SPP = C::NT / C::P;
-    // Fused trial pass (assemble_fused; double integrator, one wavefront per game): the rows of FT time steps are evaluated out of LDS.
+    // Fused trial pass (assemble_fused; double integrator and unicycle, base constraint set): the rows of FT time steps are evaluated out of LDS.
     // A chunk holds x_k of its first step, the FT + 1 blocks [x_{k+1} | u_k | lambda_k] the rows touch (the last one only for
     // A_{k+1}' lambda_{k+1}), the [x | u] parts of the proximal reference, the pair-gradient tables and the LQR constants.
-    static constexpr bool FUSED = C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && !C::EXT && C::NW == 1 && !C::DENSE;
-    static constexpr int FT = 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi);
-    struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], lqr[NLQR]; };
+    // (one wavefront per game only: on a team the chunks' workgroup barriers cost more than the pass saves -- C5 loop, team of four: 105 vs 152 K/s)
+    static constexpr bool FUSED = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE) && !C::EXT && !C::DENSE && C::NW == 1;
+    static constexpr int FT = 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
+    struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[(FT + 1) * NCF], lqr[NLQR]; };
     struct NoChunk {};
     union {
         double stage[STAGED ? SPP * SL : 1];
@@ -887,14 +890,14 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);
     if (C::NC > 0 || C::POS) {
         const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
-        constexpr int HEAD = AsmLds<C>::HEAD, SL = AsmLds<C>::SL, SPP = AsmLds<C>::SPP, SGVT = HEAD - R::GVT;   // stage offset of the table
+        constexpr int HEAD = AsmLds<C>::HEAD, SL = AsmLds<C>::SL, SPP = AsmLds<C>::SPP;
         for (int kA = 0; kA < N - 1; kA += SPP) {
           const int ks = lane / P, i = lane % P, k = kA + ks, kn = k + 1;
           constexpr bool STAGED = AsmLds<C>::STAGED;
-          constexpr int SGV = STAGED ? SGVT : 0;
           if (lane < SPP * P && k < N - 1) {
             // staged: record head (offsets as in the record) + table at HEAD of this step's LDS slot; else the record itself
             double* __restrict__ rec = STAGED ? L.stage + ks * SL : G.rec(pr) + (size_t)k * R::LEN;
+            double* __restrict__ tab = STAGED ? L.stage + ks * SL + HEAD : G.rec(pr) + R::gvt(N, k);       // pair-gradient table of the step
             if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
                 const double* sk = zstate<C>(z, k);
                 double cf[10];
@@ -902,10 +905,13 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
 #pragma unroll
                 for (int t = 0; t < 10; t++) rec[R::COEF + t * P + i] = cf[t];
             } else if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
-                // Jacobian coefficients of knot k (A_k, B_k): see the model section
-                const double* sk = zstate<C>(z, k);
-                const double th = sk[2 * P + i], v = sk[3 * P + i];
-                const double om = z[n + hu<C>(k, i)], ac = z[n + hu<C>(k, i) + 1];
+                // Jacobian coefficients of knot k (A_k, B_k): see the model section (of the trial iterate when dzp is given)
+                const double* sk = zstate<C>(z, k); const double* dk = (dzp && k > 0) ? zstate<C>(dzp, k) : nullptr;      // (x_1 does not move)
+                const int uo_ = n + hu<C>(k, i);
+                auto sv = [&](int idx) { const double q = sk[idx]; return dk ? q + alpha * dk[idx] : q; };
+                auto uv = [&](int j) { const double q = z[uo_ + j]; return dzp ? q + alpha * dzp[uo_ + j] : q; };
+                const double th = sv(2 * P + i), v = sv(3 * P + i);
+                const double om = uv(0), ac = uv(1);
                 const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
                 double sn, cs; sincos(thm, &sn, &cs);
                 rec[R::COEF + 0 * P + i] = -dt * vm * sn; rec[R::COEF + 1 * P + i] = dt * cs;
@@ -967,7 +973,7 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                         }
                     }
 #pragma unroll
-                    for (int a = 0; a < PD; a++) { ga[a] += gv[a]; rec[SGV + R::GVT + (i * P + j) * PD + a] = -gv[a]; }   // row opt_i at px(j,.)
+                    for (int a = 0; a < PD; a++) { ga[a] += gv[a]; tab[(i * P + j) * PD + a] = -gv[a]; }   // row opt_i at px(j,.)
 #pragma unroll
                     for (int t = 0; t < NS; t++) dd[t] += H[t];
                     if (RECS) {
@@ -1018,7 +1024,7 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                     }
                 }
 #pragma unroll
-                for (int a = 0; a < PD; a++) rec[SGV + R::GVT + (i * P + i) * PD + a] = ga[a];           // row opt_i at px(i,.)
+                for (int a = 0; a < PD; a++) tab[(i * P + i) * PD + a] = ga[a];           // row opt_i at px(i,.)
                 if (RECS) {
 #pragma unroll
                     for (int t = 0; t < NS; t++) rec[R::HD + NS * i + t] = dd[t];
@@ -1032,7 +1038,7 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
               for (int t = lane; t < nst * SL; t += C::NT) {
                   const int ks2 = t / SL, o = t % SL;
                   const size_t base = (size_t)(kA + ks2) * R::LEN;
-                  if (o >= HEAD) G.rec(pr)[base + R::GVT + (o - HEAD)] = L.stage[t];
+                  if (o >= HEAD) G.rec(pr)[R::gvt(N, kA + ks2) + (o - HEAD)] = L.stage[t];
                   else if (RECS || o < C::NC) G.rec(pr)[base + o] = L.stage[t];
               }
               game_sync();
@@ -1156,7 +1162,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
             const double xa = z[zo + (uidx)a];
             r += w * (tq * (xa - tx));
-            if (C::POS) { const double gv = recg[ro + (uidx)(R::GVT + (i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0))]; r += (a < C::PD * P) ? gv : 0.0; }
+            if (C::POS) { const double gv = recg[(uidx)R::gvt(N, k) + (uidx)((i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0))]; r += (a < C::PD * P) ? gv : 0.0; }
             if constexpr (C::EXT) {
                 // StateBoundConstraint of player i (state_bound_constraint.jl:85-97): rows (x - x_max)[a], (x_min - x)[a]
                 double qsb = 0.0;
@@ -1281,10 +1287,11 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
 // ================================================================================================
 template <class C, int MODE, bool AXPY>
 __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alpha, bool prox, double reg, double jreg, ResOut& out) {
-    static_assert(AsmLds<C>::FUSED && (MODE == 0 || MODE == 1 || MODE == 3), "fused trial pass: double integrator, statistics / record modes");
+    static_assert(AsmLds<C>::FUSED && (MODE == 0 || MODE == 1 || MODE == 3), "fused trial pass: double integrator / unicycle, statistics / record modes");
     CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
-    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b, FT = AsmLds<C>::FT, TAB = AsmLds<C>::TAB, NXU = n + m;
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b, FT = AsmLds<C>::FT, TAB = AsmLds<C>::TAB, NXU = n + m, NT = C::NT, NC = C::NC;
+    auto fsync = [&]() { if constexpr (C::NW == 1) sweep_sync<C>(); else game_sync(); };       // the chunk buffers are shared by the whole team
     using R = Rec<C>;
     constexpr bool RECS = (MODE == 1 || MODE == 3);
     const int N = phase_int(pr.N), lane = phase_lane();
@@ -1298,7 +1305,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
     assemble_phase_a<C, MODE, false>(pr, G, L, zs, AXPY ? dz : nullptr, alpha, N, lane, dt, -1, acc);
     LSP(20)
     auto& Ch = L.ch;
-    for (int e = lane; e < AsmLds<C>::NLQR; e += WAVE) Ch.lqr[e] = G.Qd(pr)[e];          // [Qd | xf | Rd | uf]
+    for (int e = lane; e < AsmLds<C>::NLQR; e += NT) Ch.lqr[e] = G.Qd(pr)[e];          // [Qd | xf | Rd | uf]
     const double* lQd = Ch.lqr; const double* lxf = lQd + P * ni; const double* lRd = lQd + 2 * P * ni; const double* luf = lRd + P * mi;
     double* __restrict__ recg = G.rec(pr);
     auto finish = [&](double r, double dprox, bool dynrow, unsigned rec_off) {
@@ -1321,13 +1328,13 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
         }
         {
             const int base = n + k0 * b, cnt = nblk * b, own = nst * b;
-            for (int e0 = lane; e0 < cnt; e0 += 4 * WAVE) {
+            for (int e0 = lane; e0 < cnt; e0 += 4 * NT) {
                 double a[4], d[4];
 #pragma unroll
-                for (int t = 0; t < 4; t++) { const int e = e0 + t * WAVE, ec = e < cnt ? e : e0; a[t] = zs[base + ec]; d[t] = AXPY ? dz[base + ec] : 0.0; }
+                for (int t = 0; t < 4; t++) { const int e = e0 + t * NT, ec = e < cnt ? e : e0; a[t] = zs[base + ec]; d[t] = AXPY ? dz[base + ec] : 0.0; }
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const int e = e0 + t * WAVE;
+                    const int e = e0 + t * NT;
                     if (e < cnt) {
                         const double v = AXPY ? a[t] + alpha * d[t] : a[t];
                         Ch.zt[e] = v;
@@ -1339,12 +1346,16 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             }
             if constexpr (C::POS) {
                 const int tcnt = nst * TAB;
-                for (int e = lane; e < tcnt; e += WAVE) Ch.gvt[e] = recg[(size_t)(k0 + e / TAB) * R::LEN + R::GVT + e % TAB];
+                for (int e = lane; e < tcnt; e += NT) Ch.gvt[e] = recg[R::gvt(N, k0) + e];            // contiguous behind the records
+            }
+            if constexpr (NC > 0) {                                        // Jacobian coefficients of the staged steps (phase A left them in the records)
+                const int ccnt = nblk * NC;
+                for (int e = lane; e < ccnt; e += NT) Ch.coef[e] = recg[(size_t)(k0 + e / NC) * R::LEN + R::COEF + e % NC];
             }
         }
-        sweep_sync<C>();
+        fsync();
         // ---- rows opt_i,x_{k+1}[a]
-        for (int e = lane; e < nst * P * n; e += WAVE) {
+        for (int e = lane; e < nst * P * n; e += NT) {
             const int ks = e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n, k = k0 + ks;
             const double* blk = Ch.zt + ks * b;
             const bool has_next = (k + 1 <= N - 2);
@@ -1352,7 +1363,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             double r = -blk[n + m + ei];
             {
                 const double* ln = blk + (has_next ? b : 0) + n + m + i * n;
-                const double t = AT_vec<C>(nullptr, dt, [&](int rr) { return ln[rr]; }, a);
+                const double t = AT_vec<C>(Ch.coef + (ks + (has_next ? 1 : 0)) * NC, dt, [&](int rr) { return ln[rr]; }, a);
                 r += has_next ? t : 0.0;
             }
             const bool own = (a % P == i);
@@ -1366,7 +1377,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
         }
         LSP(21)
         // ---- rows opt_i,u_{i,k}[c]
-        for (int e = lane; e < nst * m; e += WAVE) {
+        for (int e = lane; e < nst * m; e += NT) {
             const int ks = e / m, c = e % m, i = c % P, k = k0 + ks;
             const double* blk = Ch.zt + ks * b;
             const double u = blk[n + uoff<C>(c)];
@@ -1386,30 +1397,43 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                     }
                 }
             }
-            const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(nullptr, dt, [&](int rr) { return lo[rr]; }, c);
+            const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(Ch.coef + ks * NC, dt, [&](int rr) { return lo[rr]; }, c);
             const double dprox = prox ? u - Ch.zxu[ks * NXU + n + uoff<C>(c)] : 0.0;
             if (RECS) recg[(size_t)k * R::LEN + R::RHAT + c] = rhat;
             finish(r, dprox, false, (unsigned)(k * R::LEN + R::RU + c));
         }
         LSP(22)
-        // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]: position rows x + (v + dt/2 u) dt, velocity rows v + u dt
-        for (int e = lane; e < nst * n; e += WAVE) {
+        // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint; the expressions of assemble_pass)
+        for (int e = lane; e < nst * n; e += NT) {
             const int ks = e / n, a = e % n, k = k0 + ks;
             const double* blk = Ch.zt + ks * b;
             const double* xk = ks == 0 ? Ch.xprev : blk - b;
-            const int j = a < m ? a : a - m;
-            const double uj = blk[n + uoff<C>(j)], base = xk[a], vel = xk[j + m];
-            const double vm = vel + (uj * dt) * 0.5;
-            const double xn = base + (a < m ? vm : uj) * dt;
+            double xn;
+            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                // position rows: x + (v + dt/2 u) dt ; velocity rows: v + u dt
+                const int j = a < m ? a : a - m;
+                const double uj = blk[n + uoff<C>(j)], base = xk[a], vel = xk[j + m];
+                const double vm = vel + (uj * dt) * 0.5;
+                xn = base + (a < m ? vm : uj) * dt;
+            } else {
+                const double* Ck = Ch.coef + ks * NC;
+                const int blkk = a / P, i = a % P;
+                const double ua = blk[n + uoff<C>(P + i)], base = xk[a], vel = xk[3 * P + i];
+                const double uo = blk[n + uoff<C>((blkk >= 2 ? blkk - 2 : 0) * P + i)];
+                const double vm = vel + (ua * dt) * 0.5;
+                const double cf = Ck[(blkk == 0 ? 1 : 3) * P + i];                      // dt cos(thm) / dt sin(thm)
+                xn = (blkk <= 1) ? base + vm * cf : base + uo * dt;
+            }
             finish(xn - blk[a], 0.0, true, (unsigned)(k * R::LEN + R::RD + a));
         }
         LSP(23)
-        sweep_sync<C>();                                   // the next chunk overwrites the buffers
+        fsync();                                           // the next chunk overwrites the buffers
     }
     out.l1 = wave_sum(acc.l1); out.opt = wave_max(acc.vopt); out.dyn = wave_max(acc.vdyn);
     out.con = wave_max(acc.vcon); out.sta = wave_max(acc.vsta); out.nonfinite = wave_or(acc.bad);
     out.l1reg = (MODE == 3) ? wave_sum(acc.l1r) : out.l1;
     out.l1full = out.l1;
+    team_combine<C>(out);
     LSP(24)
 }
 
@@ -3216,6 +3240,19 @@ template <class C, bool IBR = false>
 __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>& L, double reg, int ip, double* primal_l1) {
     // Nothing but the pass counter is live across the sweeps: sum |d_primal| and the two norms of the gate wait in the game's control
     // slots (HBM), the output view is rebuilt from the pass counter.
+#ifdef ALG_NO_REFINE          // A/B builds (tests/probes/build_variant.sh): the bare elimination, gate compiled out
+    if constexpr (C::NW == 1) return newton_direction<C, IBR>(pr0, G0, L.d, reg, ip, primal_l1);
+    else {
+        __shared__ double dir_out0[2];
+        int st0 = ALG_STATUS_OK; double pl0 = 0.0;
+        game_sync();
+        if (C::NW >= 4 || team_wave<C>() == 0) st0 = newton_direction<C, IBR>(pr0, G0, L.d, reg, ip, &pl0);
+        if (game_tid() == 0) { dir_out0[0] = (double)st0; dir_out0[1] = pl0; }
+        game_sync();
+        if (primal_l1) *primal_l1 = uni(dir_out0[1]);
+        return __builtin_amdgcn_readfirstlane((int)dir_out0[0]);
+    }
+#endif
     constexpr int TC_PL1 = 10, TC_RHO = 13, TC_OMEGA = 14, TC_SMAX = 15;       // 13 .. 15: alg_get_direction_gate
     constexpr int TC_OMCUR = 16, TC_RHOCUR = 17;                                                      // gate state between correction solves
     static_assert(TC_RHOCUR < TC_LEN, "per-game control slots");
@@ -3263,9 +3300,12 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         // cond(J) grows with the largest penalty.  tol applies from mu_max >= refine_mu on; below, it is relaxed in proportion, at most 256 x.
         // (Most directions are far below tol: the penalties are only looked at inside the band.  In a homogeneous batch a correction
         // solve delays its game by a whole direction and the launch with it: 68 corrections in 45 056 directions of C2 cost 3 %.)
-        const double tol = phase_f64(pr.refine_tol);
+        // The dense elimination (quadrotor: dense 12 x 12 blocks per player, controls acting through two integrators, rotor costs down to 1e-4;
+        // n up to 48) needs a tighter gate and no relaxation: its directions miss the LU's backward error (1e-18) by four orders at row-wise
+        // errors of 1e-11 already (tests/test_gpu_fuzz.py::test_direction_backward_error_against_the_arbiter passes from tol / 64 on).
+        const double tol = phase_f64(pr.refine_tol) * (C::DENSE ? 0x1p-6 : 1.0);
         if (!(uni(omega) > tol) || pass >= rmax) break;
-        if (!(uni(omega) > 256.0 * tol)) {
+        if (!C::DENSE && !(uni(omega) > 256.0 * tol)) {
             const double mumax = con_mu_max<C>(pr, G0);
             const double relax = fmin(fmax(phase_f64(pr.refine_mu) / fmax(mumax, 1e-300), 1.0), 256.0);
             if (!(uni(omega) > relax * tol)) break;

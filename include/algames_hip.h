@@ -174,7 +174,8 @@ int  alg_get_waves_per_game(alg_handle* h, int32_t* waves);
  * max_c |rho_c| / (|J_c| |d| + |res_c|) exceeds `tol`, the direction is corrected by one more elimination on the residual (at most
  * `max_steps` correction solves per direction).  `tol` is the tolerance for games whose largest constraint penalty (ALConVal mu) has
  * reached `mu_tight`; below that it is relaxed in proportion mu_tight / mu_max, at most 256 x (a forward-error target needs a backward
- * error of target / cond(J), and cond(J) grows with the penalties).  Defaults: max_steps = 2, tol = 2^-34, mu_tight = 1.6e5;
+ * error of target / cond(J), and cond(J) grows with the penalties).  The dense-direction configurations (Quadrotor, n > 16) use
+ * tol / 64 without relaxation.  Defaults: max_steps = 2, tol = 2^-34, mu_tight = 1.6e5;
  * max_steps = 0 switches gate and refinement off (the round-3 arithmetic).  alg_game_stats.refinements counts the correction
  * solves of a newton_solve!. */
 int  alg_set_refinement(alg_handle* h, int32_t max_steps, double tol, double mu_tight);

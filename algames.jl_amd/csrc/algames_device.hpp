@@ -159,7 +159,8 @@ struct Cfg {
     // register budget of the solver kernels: waves per SIMD the compiler must leave room for (512 / WPE VGPRs per lane)
     // (the 3-D EXT instantiation carries 3 x 3 position blocks and does not fit 128 VGPRs without scratch)
     // (the LDS-resident dense direction of the larger configurations leaves room for less than one wavefront per SIMD)
-    static constexpr int WPE = (DENSE && n >= 24) ? 1 : (DENSE || n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3)) ? 2 : 4;
+    // (team kernels run small batches -- at most two wavefronts per SIMD are resident -- so they take the 256-register budget as well)
+    static constexpr int WPE = (DENSE && n >= 24) ? 1 : (DENSE || n >= 16 || MODEL_ != ALG_MODEL_DOUBLE_INTEGRATOR || (EXT_ != 0 && D_ == 3) || NW_ > 1) ? 2 : 4;
     // reuse the accepted line-search trial as the next record! (one assemble pass less per Newton iteration)
     static constexpr bool TRIAL_REUSE = true;
     // forward / costate sweeps of the tile path: time steps whose record slice / gains / dx are in flight (register ring, loop unrolled by it)

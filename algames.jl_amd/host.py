@@ -205,7 +205,7 @@ def _ones10():
 @dataclasses.dataclass
 class Options:
     θ: float = 1e-2
-    f_init: object = "rand"          # replaced by a counter-based generator, see alg_init_traj
+    f_init: object = "rand"          # "rand": counter-based generator on the device (alg_init_traj); a callable f(size): init_traj_host
     amplitude_init: float = 1e-8
     shift: int = 2 ** 10
     regularize: bool = True
@@ -684,14 +684,53 @@ class GameProblem:
 # --------------------------------------------------------------------------------------------------
 # Solver methods (src/problem/solver_methods.jl:5-125, src/problem/global_quantities.jl:1-193)
 # --------------------------------------------------------------------------------------------------
+def init_traj_host(prob):
+    """init_traj!(prob.pdtraj; x0, f = opts.f_init, amplitude = opts.amplitude_init, s = opts.shift) (primal_dual_traj.jl:29-44,
+    called at solver_methods.jl:13) for a CALLER-SUPPLIED generator: `opts.f_init` is a callable `f(size) -> array of that size`
+    (the reference calls `f(SVector{n+m,T})` per knot and `f(SVector{n,T})` per player and step; `zeros`, `ones`, `randn` are the
+    usual choices).  Calls are made game by game in the reference's order: knots k = 1..N (those with k + s > N), then players i,
+    steps k = 1..N-1 (those with k + s > N-1).  The default `"rand"` never comes here: the device generates it (alg_init_traj).
+    The result is stored as the handle's pdtraj; the solve then runs with init = 0, which still rolls the states out
+    (solver_methods.jl:17), so only x_1 = x0, the controls and the duals of this guess matter.  The layout keeps no control at knot
+    N (the reference's `pr[N]` carries one that nothing reads): when the shift copies knot N, its control is a fresh draw."""
+    b, o = prob.batch, prob.opts
+    f, a, s = o.f_init, float(o.amplitude_init), int(min(o.shift, 2 ** 30))
+    X, U, L = b.split_traj(b.get_traj(0))
+    B, N, n, m, p = X.shape[0], b.N, b.n, b.m, b.p
+    draw = lambda size: a * np.asarray(f(size), dtype=np.float64).reshape(size)
+    for g in range(B):
+        for k in range(1, N + 1):                                   # 1-based like the reference
+            if k + s <= N:
+                X[g, k - 1] = X[g, k + s - 1]
+                if k <= N - 1:
+                    U[g, k - 1] = U[g, k + s - 1] if k + s <= N - 1 else draw(n + m)[n:]
+            else:
+                z = draw(n + m)
+                X[g, k - 1] = z[:n]
+                if k <= N - 1:
+                    U[g, k - 1] = z[n:]
+        for i in range(p):
+            for k in range(1, N):
+                L[g, i, k - 1] = L[g, i, k + s - 1] if k + s <= N - 1 else draw(n)
+    X[:, 0] = b.get_x0()
+    b.set_traj(b.join_traj(X, U, L))
+
+
 def newton_solve(prob, init=True):
     """newton_solve!(prob) for every game of the batch (solver_methods.jl:5-65).
     init=False keeps the stored controls/duals as the initial guess (explicit warm start).
     A `sharding.ShardedGameProblem` (batch split over several devices) is solved on all of its devices concurrently."""
     if hasattr(prob, "shards"):
         from . import sharding
+        if init and any(callable(q.opts.f_init) for q in prob.shards):
+            for q in prob.shards:
+                init_traj_host(q)
+            init = False
         return sharding.newton_solve_sharded(prob, init=init)
     prob._sync_options()
+    if init and callable(prob.opts.f_init):
+        init_traj_host(prob)
+        init = False
     summary = prob.batch.newton_solve(init=init, game_id0=prob.game_id0)
     prob.stats = Statistics(summary, prob.batch.get_history)
     if prob.opts.inner_print:
@@ -779,6 +818,9 @@ def ibr_newton_solve(prob, i=None, ibr_opts=None, init=True):
     else:
         o = ibr_opts if ibr_opts is not None else IBROptions()
         order = [j - 1 for j in list(o.ordering)[:prob.probsize.p]]
+        if init and callable(prob.opts.f_init):
+            init_traj_host(prob)
+            init = False
         summary = prob.batch.ibr_newton_solve(o.ibr_iter, order, o.Δ_min, init=init, game_id0=prob.game_id0)
     prob.stats = Statistics(summary, prob.batch.get_history)
     return None

@@ -333,12 +333,21 @@ end
 
 Batched drop-in for `newton_solve!(prob)` (src/problem/solver_methods.jl:5-65).  `init=false` keeps the controls / duals the
 problems currently hold as the initial guess (`alg_set_traj`); with `opts.dual_reset == false` the constraint multipliers and
-penalties the problems hold are pushed first (warm start).  Returns the per-game `AlgGameStats`.
+penalties the problems hold are pushed first (warm start).  An `opts.f_init` other than `rand` is honoured through the reference's
+own `init_traj!` on the host followed by a solve with `init = 0`.  Returns the per-game `AlgGameStats`.
 """
 function newton_solve!(bp::BatchedGameProblem; game_id0::Integer=0, init::Bool=true, async::Bool=false)
     sync_options!(bp)
     B = length(bp.probs); ps = bp.probs[1].probsize
     bp.probs[1].opts.dual_reset || push_duals!(bp)
+    if init && bp.probs[1].opts.f_init !== rand                     # caller-supplied generator (options.jl:11): the reference's own
+        for pr in bp.probs                                          # init_traj! makes the guess (solver_methods.jl:12-13), the device
+            o = pr.opts                                             # generates only the default `rand`
+            Algames.Random.seed!(o.seed)
+            Algames.init_traj!(pr.pdtraj; x0=pr.x0, f=o.f_init, amplitude=o.amplitude_init, s=o.shift)
+        end
+        init = false
+    end
     if !init || bp.probs[1].opts.shift < ps.N                       # explicit initial guess / shifted warm start: upload pdtraj
         z = zeros(ps.n + ps.S, B)
         for (g, pr) in enumerate(bp.probs)

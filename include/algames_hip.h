@@ -267,7 +267,10 @@ int alg_get_con_duals(alg_handle* h, double* lambda, double* mu);
 /* init_traj! + rollout!(RK3) (solver_methods.jl:12-18, primal_dual_traj.jl:29-44).
  * f_init = rand is replaced by a counter-based generator (SplitMix64 keyed by seed, global game id
  * game_id0+g, element counter) because Julia's MersenneTwister stream cannot be reproduced
- * (SURVEY.md section 7 "hard parts").  use_shift!=0 applies the `shift` warm start to the stored pdtraj. */
+ * (SURVEY.md section 7 "hard parts").  use_shift!=0 applies the `shift` warm start to the stored pdtraj.
+ * Any other `opts.f_init` (options.jl:11: zeros, randn, a closure) is a host-side matter: the caller makes the
+ * guess (Julia shim: the reference's own init_traj!; Python: host.init_traj_host), stores it with alg_set_traj and
+ * solves with init = 0 -- the states are rolled out either way (solver_methods.jl:17). */
 int alg_init_traj(alg_handle* h, int64_t game_id0, int32_t use_shift);
 /* rollout!(RK3, model, pdtraj.pr) only (keeps controls/duals as set by alg_set_traj). */
 int alg_rollout(alg_handle* h, int32_t which);

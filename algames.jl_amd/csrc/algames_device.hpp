@@ -3275,7 +3275,11 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
             st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1s = uni(dir_out[1]);
         }
         const int rmax = phase_int(pr.refine_max);
-        if (pass == 0 && rmax <= 0) { if (primal_l1) *primal_l1 = pl1s; return st; }      // gate and refinement off
+        if (pass == 0 && rmax <= 0) {                                                     // gate and refinement off: nothing to report
+            if (phase_lane() == 0) { double* t0 = G0.fresh().tc(pr); t0[TC_RHO] = 0.0; t0[TC_OMEGA] = 0.0; t0[TC_SMAX] = 0.0; }
+            if (primal_l1) *primal_l1 = pl1s;
+            return st;
+        }
         double* tc = G0.fresh().tc(pr);
         if (pass == 0 && phase_lane() == 0) tc[TC_PL1] = pl1s;
         if (st != ALG_STATUS_OK) break;

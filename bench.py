@@ -118,12 +118,18 @@ def _free_port():
     return port
 
 
+# Test hook (tests/test_gpu_bench_ranks.py): ALGAMES_BENCH_SHARED_DEVICE=1 lets the ranks of an N > 1 run share device 0 with gloo
+# carrying the barrier and the counter reduction, so that the multi-process path of this script (shards, barrier, max over ranks,
+# reduction, the one JSON line) runs on a one-GPU box.  The line it prints is labelled and is not a multi-GPU measurement.
+SHARED_DEVICE = os.environ.get("ALGAMES_BENCH_SHARED_DEVICE") == "1"
+
+
 def launch_ranks(ngpu):
     """Re-executes this script as `ngpu` ranks (one per GPU) under torch.distributed.run.  Fails when the node cannot
     supply `ngpu` devices."""
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < ngpu:
+    if have < ngpu and not (SHARED_DEVICE and have >= 1):
         raise SystemExit(f"bench.py: --gpus {ngpu} requested but this node exposes {have} GPU(s); refusing to run a "
                          f"smaller job under the same label")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -259,12 +265,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if SHARED_DEVICE:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} (node exposes {torch.cuda.device_count()})")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if SHARED_DEVICE:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
 
     family, default_games = CONFIGS[args.config]
     cfg_kw = CONFIG_KW.get(args.config, {})
@@ -376,7 +387,7 @@ def main():
                        "name": args.config,
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
-                       "parallelism": f"scenario-sharded x{world}", "wavefronts_per_game": waves_per_game,
+                       "parallelism": f"scenario-sharded x{world}" + (" (TEST HOOK: the ranks share device 0, gloo; not a multi-GPU measurement)" if SHARED_DEVICE and world > 1 else ""), "wavefronts_per_game": waves_per_game,
                        "iters_per_game_mean_over_max_rank0": balance,
                        "direction_refinement": {"max_steps": refine_steps, "tol": refine_tol, "mu_tight": refine_mu, "correction_solves_rank0": refinements_rank},
                        "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve)" if args.mpc_steps

@@ -1,0 +1,51 @@
+"""bench.py's N > 1 path on a one-GPU box: two ranks started by bench.py itself (torch.distributed.run on 127.0.0.1), sharing
+device 0 through the script's test hook, gloo carrying the barrier and the counter reduction.  Checks what the driver's multi-GPU
+runs rely on -- contiguous global scenario ids per rank, whole-job totals, one JSON line from rank 0, weak and strong splits -- with
+the HIP path doing the solves in both processes.  RCCL itself needs a second device and is not exercised here."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, shared=False):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    if shared:
+        env["ALGAMES_BENCH_SHARED_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", *args],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints the one line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_ranks_weak_and_strong_split_equal_the_single_rank_job():
+    one = _bench("--games-per-gpu", "512")
+    weak = _bench("--gpus", "2", "--games-per-gpu", "256", shared=True)
+    strong = _bench("--gpus", "2", "--scaling", "strong", "--games-total", "512", shared=True)
+    assert one["n_gpus"] == 1 and weak["n_gpus"] == 2 and strong["n_gpus"] == 2
+    assert weak["scaling"] == "weak" and strong["scaling"] == "strong"
+    for d in (weak, strong):
+        c = d["config"]
+        assert c["games_total"] == 512 and c["games_per_gpu"] == 256 and "TEST HOOK" in c["parallelism"]
+        # scenario ids are global: two 256-game shards do the work of the 512-game batch, game for game
+        assert c["newton_iters_per_solve_total"] == one["config"]["newton_iters_per_solve_total"]
+        assert d["games_converged"] == one["games_converged"] == 512 and d["games_failed"] == 0
+        assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 - c["newton_iters_per_solve_total"]) <= 1e-6 * c["newton_iters_per_solve_total"]
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_devices_is_refused_without_the_hook():
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("ALGAMES_BENCH_SHARED_DEVICE", None)
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

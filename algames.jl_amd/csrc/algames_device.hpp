@@ -3281,8 +3281,8 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
             return st;
         }
         double* tc = G0.fresh().tc(pr);
-        if (pass == 0 && phase_lane() == 0) tc[TC_PL1] = pl1s;
-        if (st != ALG_STATUS_OK) break;
+        if (pass == 0 && phase_lane() == 0) tc[TC_PL1] = pl1s;       // read back only after a correction (below)
+        if (st != ALG_STATUS_OK) { if (pass == 0) { if (primal_l1) *primal_l1 = pl1s; return st; } break; }
         game_sync();                                   // the direction is in global memory
         const DirGate gt = dir_urow_residual<C, IBR, false>(pr, Gd, ip);
         // backward error of the whole direction: the row-wise omega of the first solve; after a correction, the residual of the correction
@@ -3309,11 +3309,19 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         // n up to 48) needs a tighter gate and no relaxation: its directions miss the LU's backward error (1e-18) by four orders at row-wise
         // errors of 1e-11 already (tests/test_gpu_fuzz.py::test_direction_backward_error_against_the_arbiter passes from tol / 64 on).
         const double tol = phase_f64(pr.refine_tol) * (C::DENSE ? 0x1p-6 : 1.0);
-        if (!(uni(omega) > tol) || pass >= rmax) break;
-        if (!C::DENSE && !(uni(omega) > 256.0 * tol)) {
+        bool done = !(uni(omega) > tol) || pass >= rmax;
+        if (!done && !C::DENSE && !(uni(omega) > 256.0 * tol)) {
             const double mumax = con_mu_max<C>(pr, G0);
             const double relax = fmin(fmax(phase_f64(pr.refine_mu) / fmax(mumax, 1e-300), 1.0), 256.0);
-            if (!(uni(omega) > relax * tol)) break;
+            done = !(uni(omega) > relax * tol);
+        }
+        if (done) {
+            // the common case leaves from the first pass with sum |d_primal| still in a register: no round trip through the control
+            // slots (the slot stores above are not waited for; every wavefront of a team has passed the gate's barriers)
+#ifndef ALG_GATE_NO_EARLY     // A/B builds (tests/probes/build_variant.sh)
+            if (pass == 0) { if (primal_l1) *primal_l1 = pl1s; return st; }
+#endif
+            break;
         }
         // rhs of the correction system from the buffer that holds the latest solve (d itself, or the previous correction)
         dir_urow_residual<C, IBR, true>(pr, Gd, ip);

@@ -177,7 +177,9 @@ int  alg_get_waves_per_game(alg_handle* h, int32_t* waves);
  * error of target / cond(J), and cond(J) grows with the penalties).  The dense-direction configurations (Quadrotor, n > 16) use
  * tol / 64 without relaxation.  Defaults: max_steps = 2, tol = 2^-34, mu_tight = 1.6e5;
  * max_steps = 0 switches gate and refinement off (the round-3 arithmetic).  alg_game_stats.refinements counts the correction
- * solves of a newton_solve!. */
+ * solves of a newton_solve!.  A correction solve uses the trial trajectory (ALG_TRAJ_TRIAL) as its output buffer: after
+ * alg_newton_direction that buffer holds the last correction (x_1 restored), until the next line search rewrites it -- as in
+ * the reference, pdtraj_trial is only meaningful between a line search and the update that follows it. */
 int  alg_set_refinement(alg_handle* h, int32_t max_steps, double tol, double mu_tight);
 int  alg_get_refinement(alg_handle* h, int32_t* max_steps, double* tol, double* mu_tight);
 /* Inspection: the gate statistics of the most recent Newton direction of every game, before any correction; out is B x 3:

@@ -2481,6 +2481,9 @@ __device__ __forceinline__ int newton_direction(CPR pr0, const Game& G0, DirLds<
 }
 template <class C, bool IBR>
 __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip, double* primal_l1) {
+#if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 0       // per-sweep byte / time accounts (tests/probes/dir_split.sh): nothing at all
+    return ALG_STATUS_OK;
+#endif
     CPR pr = phase_params(pr0);
     Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KB = DirLds<C>::KB, NK = m * (n + 1);

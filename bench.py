@@ -94,6 +94,24 @@ def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0, gate=True):
     return 8 * (trial + backward + forward + costate + gate_b)
 
 
+def outer_pass_bytes(family, N, n, m, p):
+    """Algorithmic bytes of the two passes newton_solve! makes once per OUTER iteration, which structured_bytes() (per Newton iteration)
+    leaves out: (record pass, dual / penalty update pass).
+      record pass   the first inner iteration after a dual update cannot reuse the accepted trial's records (the multipliers moved):
+                    read the iterate and the multipliers / penalties, write the step records and the pair-gradient tables
+      dual update   dual_update! / penalty_update! (constraints_methods.jl:295-445): read the iterate (positions and controls touch every
+                    line of it), lambda and mu, write the constraint values, lambda and mu
+    Per-sweep counters (tests/probes/phase_bytes.sh with the ALG_DIR_STOP builds) put the three sweeps and the gate
+    within 7 % of structured_bytes(); what the fabric moves beyond that model is these passes and re-reads inside the trial pass."""
+    S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
+    it, K = S + n, N - 1
+    nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p, "Q": 204 * p}[family]
+    npair = p * (p - 1)
+    len_rec = nc + 3 * npair + 3 * p + p * n + 2 * m + n + 2 * p * p
+    con = K * npair + (2 * m * K if family in ("C3", "C5", "Q") else 0)
+    return 8 * (it + 2 * con + K * len_rec), 8 * (it + 2 * con + 3 * con)
+
+
 # --------------------------------------------------------------------------------------------------
 # Sharding + reduction: the N > 1 path lives in the package (algames.jl_amd/sharding.py); bench.py only maps its
 # configuration names.  tests/test_sharding_gloo.py runs the package functions with world_size 2 on gloo.
@@ -361,6 +379,13 @@ def main():
             # context only (SURVEY.md 8(d) priced a dense block-LU with factor spill; this kernel never performs it)
             "survey_dense_lu_bytes_per_game_iter": survey_balg(N, n, m, p),
         }
+        if not args.mpc_steps:
+            # passes made once per outer iteration, amortised over the Newton iterations with this launch's own counts: every outer
+            # iteration starts with a record pass, every one but the last ends with the dual / penalty update
+            rec_b, dual_b = outer_pass_bytes(family, N, n, m, p)
+            n_out = int(st["outer_iters"].sum()); n_dual = int(np.maximum(st["outer_iters"] - 1, 0).sum())
+            roof["outer_passes_per_launch"] = {"record": n_out, "dual_update": n_dual}
+            roof["bytes_per_game_iter_outer_passes"] = (n_out * rec_b + n_dual * dual_b) / max(1, iters_rank)
         pmc = None
         if world == 1 and not args.no_pmc:
             tail = ["--config", args.config, "--games-per-gpu", str(G), "--waves-per-game", str(args.waves_per_game),     # (a 1-GPU child: weak)
@@ -370,6 +395,8 @@ def main():
             pmc = inrun_pmc(tail, kernel, iters_rank, own)
         if pmc is not None:
             roof.update(pmc)
+            if "bytes_per_game_iter_outer_passes" in roof:
+                roof["traffic_over_model_incl_outer_passes"] = roof["traffic"] / ((own + roof["bytes_per_game_iter_outer_passes"]) * iters_rank)
         elif not args.no_pmc:
             prof = committed_profile(args.config, G, args.mpc_steps)
             if prof is not None:

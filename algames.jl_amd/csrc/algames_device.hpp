@@ -259,10 +259,16 @@ template <class C> __device__ __forceinline__ void dir_sync() {
 // __syncthreads() also drain vmcnt, i.e. every phase boundary of a time step (eight in the backward sweep) waited for the record
 // prefetch and the gain stores that had just been issued -- the sweeps ran at global-memory latency.  What the sweeps exchange
 // through global memory (gains, dx) crosses a full game_sync() between the sweeps.
+// (team kernels: the serial sweeps run on wavefront 0 alone, so the same holds; until round 4 they used the full fence of dir_sync())
 template <class C> __device__ __forceinline__ void sweep_sync() {
-    if constexpr (C::NW == 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    } else dir_sync<C>();
+#ifdef ALG_TEAM_FULL_FENCE        // A/B builds
+    if constexpr (C::NW > 1) { dir_sync<C>(); return; }
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// Workgroup barrier that orders LDS only (no vmcnt drain: the record prefetch and the gain stores of a sweep step stay in flight)
+__device__ __forceinline__ void team_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 template <class C> __device__ __forceinline__ void rotate_priority(int it);
 template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(game_tid() >> 6)); }
@@ -1881,12 +1887,13 @@ struct HxMap {
 // Non-zeros of [Q^_i | rx_i] (rx_i only when s_i rides in tile column n, n < 16): after the MFMA products wrote A'(P F) back, every lane adds its entries
 //   (r, r): reg + w q_i,r (+ state-bound Hessian) (+ position-block diagonal)   (r, c) r != c < 2P: position block   (r, n): rx_i,r
 // into row block i of Pm.  Per lane and pass: packed (dst | src << 11 | qi << 19), sign of the record source, diagonal flag.
-template <class C, int NTQ = WAVE>
+// PS > 1 (team of two): the map of the players first, first + PS, ... only.
+template <class C, int NTQ = WAVE, int PS = 1>
 struct QaddMap {
     static constexpr int NP = C::PD * C::P;                // rows / columns of the position block
     static constexpr int OFF = C::POS ? NP * NP - NP : 0;
     static constexpr bool RXCOL = C::n < 16;             // s_i lives in tile column n (else it is updated on the VALU)
-    static constexpr int QE = C::n + OFF + (RXCOL ? C::n : 0), QTOT = C::P * QE, PASSES = (QTOT + NTQ - 1) / NTQ;
+    static constexpr int QE = C::n + OFF + (RXCOL ? C::n : 0), QTOT = (C::P / PS) * QE, PASSES = (QTOT + NTQ - 1) / NTQ;
     unsigned code[PASSES]; float sgn[PASSES], dfl[PASSES];
     __device__ __forceinline__ static void hxsrc(int i, int jr, int jc, int h, int& so, float& sg) {
         using R = Rec<C>;
@@ -1897,7 +1904,7 @@ struct QaddMap {
         else if (jc == i) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = -1.f; }
         else if (jr == jc) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = 1.f; }
     }
-    __device__ __forceinline__ void init(int lane) {
+    __device__ __forceinline__ void init(int lane, int first = 0) {
         constexpr int n = C::n, P = C::P, LDP = n + 1;
         using R = Rec<C>;
         static_assert(C::P * n * LDP < 2048 && R::LEN_SWEEP < 256 && P * n <= 64, "QaddMap packing");
@@ -1906,7 +1913,7 @@ struct QaddMap {
             const int e = lane + q * NTQ;
             int dst = 0, so = 0, qi = 0; float sg = 0.f, df = 0.f;
             if (e < QTOT) {
-                const int i = e / QE, t = e % QE;
+                const int i = (e / QE) * PS + first, t = e % QE;
                 if (t < n) {
                     dst = i * n * LDP + t * LDP + t; qi = i * n + t; df = 1.f;
                     if (C::POS && t < NP) hxsrc(i, t % P, t % P, C::sym(t / P, t / P), so, sg);
@@ -2479,6 +2486,57 @@ __device__ __forceinline__ int newton_direction(CPR pr0, const Game& G0, DirLds<
     if constexpr (C::DENSE) return newton_direction_dense<C, IBR>(pr0, G0, L, reg, ip, primal_l1);
     else return newton_direction_tile<C, IBR>(pr0, G0, L, reg, ip, primal_l1);
 }
+// Team of two (round 4): splitting the whole backward step over the two wavefronts costs more in barriers than it gains (measured on C3
+// at 1024 games: 2.30 against 2.35 M/s), but the value recursion alone -- a quarter of a step, independent per player, LDS in / LDS out
+// -- is worth two LDS-only barriers: wavefront 1 takes the odd players' MFMA chains of every step and does nothing else in the direction.
+#ifndef ALG_HELP2
+#define ALG_HELP2 1
+#endif
+template <class C, bool IBR>
+inline constexpr bool help2_v = ALG_HELP2 && C::NW == 2 && !IBR && !C::DENSE && C::WPE == 2 && C::P % 2 == 0 &&
+                                (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4));
+// [P_i | s_i] <- A' ([P_i | s_i] [[F f],[0 1]]) for the players first, first + 2, ...: operands of all of them read first, their MFMA
+// chains interleaved, results written back to the players' own LDS row blocks (nobody else touches those between the two barriers).
+template <class C>
+__device__ __forceinline__ void value_recursion_half(DirLds<C>& L, int first, int lrow, int lq, double dt) {
+    constexpr int n = C::n, P = C::P, PH = P / 2, LDP = DirLds<C>::LDP, KB1 = DirLds<C>::KB1;
+    constexpr bool AUGS = DirLds<C>::AUGS;
+    constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
+    double* const bwb = reinterpret_cast<double*>(&L.bw);
+    const bool colP = lrow < n;
+    double bF[KB1], pv[PH][KB1];
+#pragma unroll
+    for (int kb = 0; kb < KB1; kb++) bF[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];
+#pragma unroll
+    for (int ii = 0; ii < PH; ii++)
+#pragma unroll
+        for (int kb = 0; kb < KB1; kb++) {
+            const double v = L.bw.Pm[(first + 2 * ii) * n * LDP + (colP ? lrow : 0) * LDP + 4 * kb + lq];
+            pv[ii][kb] = colP ? v : 0.0;
+        }
+    double4_t c1[PH], c2[PH];
+#pragma unroll
+    for (int ii = 0; ii < PH; ii++) c1[ii] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < KB1; kb++)
+#pragma unroll
+        for (int ii = 0; ii < PH; ii++) c1[ii] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[ii][kb], bF[kb], c1[ii], 0, 0, 0);
+#pragma unroll
+    for (int ii = 0; ii < PH; ii++) {
+        if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) c2[ii] = di_AT_tile<C>(c1[ii], dt, lq);
+        else c2[ii] = p4_AT_tile<C>(c1[ii], L.coefn, lq);
+    }
+    sweep_sync<C>();
+#pragma unroll
+    for (int ii = 0; ii < PH; ii++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const int row = lq + 4 * r4;
+            const int slot = (row < n && lrow < n + (AUGS ? 1 : 0)) ? oPm + (first + 2 * ii) * n * LDP + row * LDP + lrow : oPad;
+            bwb[slot] = c2[ii][r4];
+        }
+}
+
 template <class C, bool IBR>
 __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip, double* primal_l1) {
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 0       // per-sweep byte / time accounts (tests/probes/dir_split.sh): nothing at all
@@ -2495,11 +2553,20 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     // (a team of two gains less from the split than its barriers cost -- measured on C3 at 1024 games: 2.35 M/s with the whole
     // direction on wavefront 0, 2.30 M/s with the split -- so only teams of four or more split the backward sweep)
     constexpr bool TEAM = C::NW >= 4 && !IBR;
+    constexpr bool HELP2 = help2_v<C, IBR>;              // team of two: wavefront 1 runs the odd players' value recursion (above)
     constexpr int BT = TEAM ? C::NT : WAVE;               // threads of the backward sweep
-    const int N = phase_int(pr.N), tid = phase_lane();
+    const int N = phase_int(pr.N);
+    const int hw = HELP2 ? team_wave<C>() : 0;            // 1: the helper wavefront of a team of two
+    const int tid = HELP2 ? (phase_lane() & 63) : phase_lane();
     const int lane = TEAM ? (tid & 63) : tid;             // lane inside the wavefront
     const int tw = TEAM ? team_wave<C>() : 0;
+    // (team: the wavefronts exchange LDS only inside the backward sweep -- a barrier that also drained vmcnt made every phase boundary wait
+    // for the record prefetch and the gain stores in flight, like the single-wavefront sweeps before round 3)
+#ifdef ALG_TEAM_FULL_FENCE
     auto bsync = [&]() { if constexpr (TEAM) game_sync(); else sweep_sync<C>(); };
+#else
+    auto bsync = [&]() { if constexpr (TEAM) team_lds_barrier(); else sweep_sync<C>(); };
+#endif
     const int lrow = lane & 15, lq = lane >> 4;          // MFMA lane coordinates
     const double dt = phase_f64(pr.dt);
     constexpr int RPL = (R::LEN_SWEEP + BT - 1) / BT;          // record doubles per thread
@@ -2514,8 +2581,23 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #define ALG_SYSROW 1
 #endif
     constexpr bool SYSROW = ALG_SYSROW && GFUSE;      // the V phase forms the system's rows (needs g from the y lanes)
+    QaddMap<C, BT, (HELP2 ? 2 : 1)> qam; qam.init(tid, hw);
+    if constexpr (HELP2) {
+        if (hw == 1) {
+            // the helper wavefront: value recursion and Q-add of the odd players, step by step between wavefront 0's two barriers
+            double* const bwh = reinterpret_cast<double*>(&L.bw) + (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8);
+            int curh = 0;
+            for (int k = N - 2; k >= 0; k--, curh ^= 1) {
+                team_lds_barrier();
+                if (k < N - 2) value_recursion_half<C>(L, 1, lrow, lq, dt);
+                sweep_sync<C>();
+                qam.apply(tid, L.rec[curh], L.qdf, bwh, reg, (k + 1 < N - 1) ? dt : 1.0, -1);
+                team_lds_barrier();
+            }
+            return ALG_STATUS_OK;
+        }
+    }
     HxMap<C> hxm;
-    QaddMap<C, BT> qam; qam.init(tid);
     struct NoGather { __device__ void init(int, int) {} };
     typename std::conditional<(C::P == 3 && C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR), P3Gather<C>, NoGather>::type p3g;
     p3g.init(lq, lrow);
@@ -2569,7 +2651,9 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) aA[kb] = colP ? A_entry<C>(L.coefn, dt, 4 * kb + lq, lrow) : 0.0;    // (A')[lrow][k] = A[k][lrow]
             // (measured for the 128-VGPR configurations as well in round 3: 126 VGPRs, no spills, C2 10.64 vs 10.67 M/s -- neutral, not enabled)
-            if constexpr (C::WPE == 2 && !IBR && !TEAM && C::MODEL != ALG_MODEL_BICYCLE) {
+            if constexpr (HELP2) {
+                // (below, outside this branch: the first step has no recursion but the same two barriers)
+            } else if constexpr (C::WPE == 2 && !IBR && !TEAM && C::MODEL != ALG_MODEL_BICYCLE) {
                 // 256-VGPR configurations (one game per SIMD at their batch sizes): all players' operands are read first,
                 // the P independent MFMA chains overlap in the matrix pipeline, then all results are written back
                 double pv[P][KB1];
@@ -2643,6 +2727,13 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         }
         ALG_PROF(0)
         // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
+        if constexpr (HELP2) {
+            team_lds_barrier();                           // [F f], the coefficients, the record and every P_i of the step before are in LDS for both wavefronts
+            if (k < N - 2) value_recursion_half<C>(L, 0, lrow, lq, dt);     // even players here, odd players on wavefront 1
+            sweep_sync<C>();
+            qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, -1);               // Q-add of the even players
+            team_lds_barrier();                           // all players' [P_i | s_i] are back
+        } else
         qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
         if constexpr (!AUGS) {
             for (int e = tid; e < P * n; e += BT) {                         // s_i <- rx_i + A_{k+1}' t_i
@@ -2828,7 +2919,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     return ALG_STATUS_OK;
 #endif
     // ------------------------------------------------------------------ forward sweep: dx, du
-    if constexpr (C::NW == 1) game_sync();            // the gains are in global memory (the sweeps' own syncs order LDS only)
+    if constexpr (C::NW == 1) game_sync(); else dir_sync<C>();   // the gains are in global memory (the sweeps' own syncs order LDS only)
     G = G0.fresh();
     double* __restrict__ dz = G.z(2);
     if (lane < n) dz[lane] = 0.0;
@@ -2976,7 +3067,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     // the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table round trips through
     // LDS and one fence per step instead of three.  Same products in the same order as the general form below.
     if constexpr (!DIROW) hxm.init(phase_lane());
-    if constexpr (C::NW == 1) game_sync();            // dx of every step is in global memory
+    if constexpr (C::NW == 1) game_sync(); else dir_sync<C>();   // dx of every step is in global memory
     G = G0.fresh();
     dz = G.z(2);
     if constexpr (FWDW) {
@@ -3250,7 +3341,7 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         __shared__ double dir_out0[2];
         int st0 = ALG_STATUS_OK; double pl0 = 0.0;
         game_sync();
-        if (C::NW >= 4 || team_wave<C>() == 0) st0 = newton_direction<C, IBR>(pr0, G0, L.d, reg, ip, &pl0);
+        if (C::NW >= 4 || help2_v<C, IBR> || team_wave<C>() == 0) st0 = newton_direction<C, IBR>(pr0, G0, L.d, reg, ip, &pl0);
         if (game_tid() == 0) { dir_out0[0] = (double)st0; dir_out0[1] = pl0; }
         game_sync();
         if (primal_l1) *primal_l1 = uni(dir_out0[1]);
@@ -3272,7 +3363,8 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
             __shared__ double dir_out[2];
             game_sync();
             // teams of >= 4: backward sweep on the whole team, forward / costate on wavefront 0; team of 2: wavefront 0 does it all
-            if (C::NW >= 4 || team_wave<C>() == 0) st = newton_direction<C, IBR>(pr, Gd, L.d, reg, ip, &pl1s);
+            // (team of two: wavefront 1 enters as the helper of the value recursion and returns with the backward sweep)
+            if (C::NW >= 4 || help2_v<C, IBR> || team_wave<C>() == 0) st = newton_direction<C, IBR>(pr, Gd, L.d, reg, ip, &pl1s);
             if (game_tid() == 0) { dir_out[0] = (double)st; dir_out[1] = pl1s; }
             game_sync();
             st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1s = uni(dir_out[1]);

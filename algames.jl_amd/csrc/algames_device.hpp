@@ -2486,6 +2486,41 @@ __device__ __forceinline__ int newton_direction(CPR pr0, const Game& G0, DirLds<
     if constexpr (C::DENSE) return newton_direction_dense<C, IBR>(pr0, G0, L, reg, ip, primal_l1);
     else return newton_direction_tile<C, IBR>(pr0, G0, L, reg, ip, primal_l1);
 }
+// Row c of the augmented control system [W | V A_k] from row c of V = B[:,c]' P_{i(c)} (one 16-lane row of lanes per control, col = the
+// lane's column): the SYSROW form of the backward sweep's V phase (described there).  Reads P_{c % P} and the step record, writes row c of L.bw.V.
+template <class C>
+__device__ __forceinline__ void v_sysrow(DirLds<C>& L, const double* Rc, int k, double dt, int c, int col) {
+    constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, VW = DirLds<C>::VW;
+    using R = Rec<C>;
+    const double* coefk = Rc + R::COEF;
+    const bool cok = c < m; const int cq = cok ? c : 0, colr = col < n ? col : n - 1;
+    const double* Pi = &L.bw.Pm[(cq % P) * n * LDP];
+    const double vcol = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + colr]; }, cq);
+    const double rh = (col == cq) ? Rc[R::RHAT + cq] : 0.0;
+    double ea, eb;
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        const double below = row_shift<0x110 + m>(vcol), above = row_shift<0x100 + m>(vcol);
+        ea = (k >= 1) ? (col >= m ? fma(dt, below, vcol) : vcol) : 0.0;
+        eb = (0.5 * dt * dt) * vcol; eb = fma(dt, above, eb);
+    } else {
+        // unicycle (col_pattern): column idx = kind P + i of B touches rows i, P + i (coefficients) and (2 + kind) P + i (dt); column
+        // (2 + kind') P + i of A touches rows i, P + i besides its own
+        const double d1 = row_shift<0x110 + P>(vcol), d2 = row_shift<0x110 + 2 * P>(vcol), d3 = row_shift<0x110 + 3 * P>(vcol);
+        const double u1 = row_shift<0x100 + P>(vcol), u2 = row_shift<0x100 + 2 * P>(vcol);
+        const int blk = colr / P, pi = colr % P;
+        const double ca = coefk[(blk >= 2 ? blk - 2 : 0) * P + pi], cb = coefk[(blk >= 2 ? blk : 2) * P + pi];
+        double va = vcol;
+        if (blk >= 2) { va = fma(ca, blk == 3 ? d3 : d2, va); va = fma(cb, blk == 3 ? d2 : d1, va); }
+        ea = (k >= 1) ? va : 0.0;
+        const int kind = blk & 1;                                  // col < m: blk = kind
+        const double wa = 0.5 * dt * coefk[kind * P + pi], wb = 0.5 * dt * coefk[(2 + kind) * P + pi];
+        eb = wa * (kind ? d1 : vcol); eb = fma(wb, kind ? vcol : u1, eb); eb = fma(dt, u2, eb);
+    }
+    eb = fma(1.0, rh, eb);
+    if (cok && col < n) L.bw.V[c * VW + m + col] = ea;
+    if (cok && col < m) L.bw.V[c * VW + col] = eb;
+}
+
 // Team of two (round 4): splitting the whole backward step over the two wavefronts costs more in barriers than it gains (measured on C3
 // at 1024 games: 2.30 against 2.35 M/s), but the value recursion alone -- a quarter of a step, independent per player, LDS in / LDS out
 // -- is worth two LDS-only barriers: wavefront 1 takes the odd players' MFMA chains of every step and does nothing else in the direction.
@@ -2592,7 +2627,18 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 if (k < N - 2) value_recursion_half<C>(L, 1, lrow, lq, dt);
                 sweep_sync<C>();
                 qam.apply(tid, L.rec[curh], L.qdf, bwh, reg, (k + 1 < N - 1) ? dt : 1.0, -1);
+                sweep_sync<C>();
+                v_sysrow<C>(L, L.rec[curh], k, dt, 2 * (tid >> 4) + 1, tid & 15);       // V rows of the odd players' controls
                 team_lds_barrier();
+                // while wavefront 0 runs the serial tail of step k: the record of step k - 1 from global memory into the other LDS slot
+                // (wavefront 0 never waits for a load inside the sweep)
+                if (k > 0) {
+                    double nx[RPL];
+#pragma unroll
+                    for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; nx[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+#pragma unroll
+                    for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; if (e < R::LEN_SWEEP) L.rec[curh ^ 1][e] = nx[q]; }
+                }
             }
             return ALG_STATUS_OK;
         }
@@ -2732,7 +2778,10 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             if (k < N - 2) value_recursion_half<C>(L, 0, lrow, lq, dt);     // even players here, odd players on wavefront 1
             sweep_sync<C>();
             qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, -1);               // Q-add of the even players
-            team_lds_barrier();                           // all players' [P_i | s_i] are back
+            sweep_sync<C>();
+            static_assert(!HELP2 || (SYSROW && m == 2 * P && m / 2 <= WAVE / 16), "V rows of one wavefront's players in one pass");
+            v_sysrow<C>(L, Rc, k, dt, 2 * (tid >> 4) + 0, tid & 15);       // V rows of the even players' controls (c % P = player)
+            team_lds_barrier();                           // all players' P_i and V rows are back
         } else
         qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
         if constexpr (!AUGS) {
@@ -2747,46 +2796,21 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         ALG_PROF(1)
         // prefetch of the next step's record: issued after the register-hungry MFMA phase, landed by the end of the step
         double pre[RPL];
-        if (k > 0) {
+        if (!HELP2 && k > 0) {                                       // (team of two: the helper wavefront fetches the record)
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; pre[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
         }
         // ---- V[c][0..n) = B[:,c]' P_{i(c)},  V[c][n+1+c] = R^_c,  y_i = P_i rd + s_i   (lane = 16 c + col: shifts, no divisions)
         constexpr int CPP = BT / 16;                                   // control rows of V per pass
 #pragma unroll
-        for (int q = 0; q < (m + CPP - 1) / CPP; q++) {
+        for (int q = 0; q < (HELP2 ? 0 : (m + CPP - 1) / CPP); q++) {       // (team of two: done per player between the two barriers above)
             const int c = CPP * q + (tid >> 4), col = tid & 15;
             if constexpr (SYSROW) {
                 // Row c of the augmented system (double integrator shown; unicycle: coefficient-weighted shifts by P, 2P, 3P) [W | V A_k | g] is a combination of row c of V with itself shifted by m
                 // ((V A)[c][j] = V[c][j] + dt V[c][j - m], W[c][j] = dt^2/2 V[c][j] + dt V[c][j + m] + R^ slot), and a 16-lane row of this
                 // phase IS row c of V: the lanes form the system's entries from their own V entry and two row shifts, so the column
                 // build reads its m entries instead of 3 m entries of V (same FMA sequences as the pattern form: bit-identical)
-                const bool cok = c < m; const int cq = cok ? c : 0, colr = col < n ? col : n - 1;
-                const double* Pi = &L.bw.Pm[(cq % P) * n * LDP];
-                const double vcol = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + colr]; }, cq);
-                const double rh = (col == cq) ? Rc[R::RHAT + cq] : 0.0;
-                double ea, eb;
-                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-                    const double below = row_shift<0x110 + m>(vcol), above = row_shift<0x100 + m>(vcol);
-                    ea = (k >= 1) ? (col >= m ? fma(dt, below, vcol) : vcol) : 0.0;
-                    eb = (0.5 * dt * dt) * vcol; eb = fma(dt, above, eb);
-                } else {
-                    // unicycle (col_pattern): column idx = kind P + i of B touches rows i, P + i (coefficients) and (2 + kind) P + i (dt); column
-                    // (2 + kind') P + i of A touches rows i, P + i besides its own
-                    const double d1 = row_shift<0x110 + P>(vcol), d2 = row_shift<0x110 + 2 * P>(vcol), d3 = row_shift<0x110 + 3 * P>(vcol);
-                    const double u1 = row_shift<0x100 + P>(vcol), u2 = row_shift<0x100 + 2 * P>(vcol);
-                    const int blk = colr / P, pi = colr % P;
-                    const double ca = coefk[(blk >= 2 ? blk - 2 : 0) * P + pi], cb = coefk[(blk >= 2 ? blk : 2) * P + pi];
-                    double va = vcol;
-                    if (blk >= 2) { va = fma(ca, blk == 3 ? d3 : d2, va); va = fma(cb, blk == 3 ? d2 : d1, va); }
-                    ea = (k >= 1) ? va : 0.0;
-                    const int kind = blk & 1;                                  // col < m: blk = kind
-                    const double wa = 0.5 * dt * coefk[kind * P + pi], wb = 0.5 * dt * coefk[(2 + kind) * P + pi];
-                    eb = wa * (kind ? d1 : vcol); eb = fma(wb, kind ? vcol : u1, eb); eb = fma(dt, u2, eb);
-                }
-                eb = fma(1.0, rh, eb);
-                if (cok && col < n) L.bw.V[c * VW + m + col] = ea;
-                if (cok && col < m) L.bw.V[c * VW + col] = eb;
+                v_sysrow<C>(L, Rc, k, dt, c, col);
             } else if (c < m && col < n) {
                 const double* Pi = &L.bw.Pm[(c % P) * n * LDP];
                 L.bw.V[c * VW + col] = BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
@@ -2897,7 +2921,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         }
         ALG_PROF(9)
         if (C::NC > 0 && tid < C::NC) L.coefn[tid] = coefk[tid];
-        if (k > 0) {
+        if (!HELP2 && k > 0) {
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; if (e < R::LEN_SWEEP) L.rec[cur ^ 1][e] = pre[q]; }
         }

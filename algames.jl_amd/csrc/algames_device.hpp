@@ -2521,15 +2521,64 @@ __device__ __forceinline__ void v_sysrow(DirLds<C>& L, const double* Rc, int k, 
     if (cok && col < m) L.bw.V[c * VW + col] = eb;
 }
 
+// Team of two, per-player part of a backward step that follows the Q-add, for the players first and first + 2:
+//   s_i <- rx_i + A_{k+1}' t_i                     (n == 16: s_i does not ride in the MFMA tile)
+//   y_i = P_i rd + s_i, g_c = ru_c + B[:,c]' y_i   with TWO lanes per row of P_i (lanes 0..31: columns 0..7, lanes 32..63: columns 8..15; the
+//   halves meet through v_permlane32_swap), i.e. FMA chains of eight instead of sixteen -- the sums associate differently from the
+//   one-wavefront kernel's (rounding-level differences, like the team's norms).
+template <class C>
+__device__ __forceinline__ void player_tail_half(DirLds<C>& L, const double* Rc, double dt, int k, int N, int first, int lane) {
+    constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, VW = DirLds<C>::VW;
+    static_assert(n == 16 && P == 4 && C::MODEL == ALG_MODEL_UNICYCLE, "lane layout of the team-of-two tail (4-player unicycle)");
+    using R = Rec<C>;
+    const double* coefk = Rc + R::COEF;
+    if constexpr (!DirLds<C>::AUGS) {
+        if (lane < 2 * n) {
+            const int i = first + 2 * (lane / n), r = lane % n; const double* ti = &L.bw.t[i * n];
+            double v = Rc[R::RX + i * n + r];
+            if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
+            L.bw.Pm[i * n * LDP + r * LDP + n] = v;
+        }
+        sweep_sync<C>();
+    }
+    const int h = lane >> 5, yp = first + 2 * ((lane >> 4) & 1), yr = lane & 15;
+    const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
+    const double rdl = Rc[R::RD + ((yr + 8 * h) & 15)];          // lane j of an upper-half row holds rd[j + 8]
+    const double* Ph = Pr + 8 * h;
+    double a = h ? 0.0 : Pr[n];
+    rowdot_dpp_f<8>(a, rdl, [&](int c) { return Ph[c]; });
+    a += xchg32(a, lane < 32);
+    const double dn = row_shift<0x110 + P>(a), up = row_shift<0x100 + P>(a), up2 = row_shift<0x100 + 2 * P>(a);
+    const int kind = yr < m ? yr / P : 0;
+    const double vi = kind ? dn : a, vpi = kind ? a : up;
+    const double gb = 0.5 * dt * (coefk[kind * P + yp] * vi + coefk[(2 + kind) * P + yp] * vpi) + dt * up2;
+    if (h == 0 && yr < m && yr % P == yp) L.bw.V[yr * VW + m + n] = Rc[R::RU + yr] + gb;
+}
+
+// Team of two: t_i = P_i f + s_i (n == 16) for the players first and first + 2 from the value functions of the step before, two lanes per
+// row like player_tail_half; runs before the same wavefront's value recursion overwrites those P_i.
+template <class C>
+__device__ __forceinline__ void t_half(DirLds<C>& L, int first, int lane) {
+    constexpr int n = C::n, LDP = DirLds<C>::LDP;
+    if constexpr (!DirLds<C>::AUGS) {
+        const int h = lane >> 5, i = first + 2 * ((lane >> 4) & 1), r = lane & 15;
+        const double* Pr = &L.bw.Pm[i * n * LDP + r * LDP];
+        double a = h ? 0.0 : Pr[n];
+#pragma unroll
+        for (int c = 0; c < 8; c++) a += Pr[c + 8 * h] * L.bw.fv[c + 8 * h];
+        a += xchg32(a, lane < 32);
+        if (h == 0) L.bw.t[i * n + r] = a;
+    }
+}
+
 // Team of two (round 4): splitting the whole backward step over the two wavefronts costs more in barriers than it gains (measured on C3
 // at 1024 games: 2.30 against 2.35 M/s), but the value recursion alone -- a quarter of a step, independent per player, LDS in / LDS out
 // -- is worth two LDS-only barriers: wavefront 1 takes the odd players' MFMA chains of every step and does nothing else in the direction.
 #ifndef ALG_HELP2
-#define ALG_HELP2 1
+#define ALG_HELP2 2            // 0: off; 1: value recursion, Q-add, V rows, record fetch (bit-identical to the unsplit direction); 2: + s_i, y_i, g_c
 #endif
 template <class C, bool IBR>
-inline constexpr bool help2_v = ALG_HELP2 && C::NW == 2 && !IBR && !C::DENSE && C::WPE == 2 && C::P % 2 == 0 &&
-                                (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4));
+inline constexpr bool help2_v = ALG_HELP2 && C::NW == 2 && !IBR && !C::DENSE && C::WPE == 2 && C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4;
 // [P_i | s_i] <- A' ([P_i | s_i] [[F f],[0 1]]) for the players first, first + 2, ...: operands of all of them read first, their MFMA
 // chains interleaved, results written back to the players' own LDS row blocks (nobody else touches those between the two barriers).
 template <class C>
@@ -2624,11 +2673,19 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             int curh = 0;
             for (int k = N - 2; k >= 0; k--, curh ^= 1) {
                 team_lds_barrier();
-                if (k < N - 2) value_recursion_half<C>(L, 1, lrow, lq, dt);
+                if (k < N - 2) {
+#if ALG_HELP2 >= 2
+                    t_half<C>(L, 1, tid);
+#endif
+                    value_recursion_half<C>(L, 1, lrow, lq, dt);
+                }
                 sweep_sync<C>();
                 qam.apply(tid, L.rec[curh], L.qdf, bwh, reg, (k + 1 < N - 1) ? dt : 1.0, -1);
                 sweep_sync<C>();
                 v_sysrow<C>(L, L.rec[curh], k, dt, 2 * (tid >> 4) + 1, tid & 15);       // V rows of the odd players' controls
+#if ALG_HELP2 >= 2
+                player_tail_half<C>(L, L.rec[curh], dt, k, N, 1, tid);                 // their s_i, y_i, g_c
+#endif
                 team_lds_barrier();
                 // while wavefront 0 runs the serial tail of step k: the record of step k - 1 from global memory into the other LDS slot
                 // (wavefront 0 never waits for a load inside the sweep)
@@ -2683,7 +2740,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // afterwards (Q-add phase).  Player i's chain reads only row block i of Pm, so its result is written back before the
         // next player starts: one accumulator tile live.
         if (k < N - 2) {
-            if constexpr (!AUGS) {
+            if constexpr (!AUGS && !(HELP2 && ALG_HELP2 >= 2)) {            // (team of two: per player, between the barriers below)
                 for (int e = tid; e < P * n; e += BT) {                     // t_i = P_i f + s_i (one (i,r) per thread)
                     const int i = e / n, r = e % n; double a = L.bw.Pm[i * n * LDP + r * LDP + n];
                     for (int c = 0; c < n; c++) a += L.bw.Pm[i * n * LDP + r * LDP + c] * L.bw.fv[c];
@@ -2775,16 +2832,25 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
         if constexpr (HELP2) {
             team_lds_barrier();                           // [F f], the coefficients, the record and every P_i of the step before are in LDS for both wavefronts
-            if (k < N - 2) value_recursion_half<C>(L, 0, lrow, lq, dt);     // even players here, odd players on wavefront 1
+            if (k < N - 2) {
+#if ALG_HELP2 >= 2
+                t_half<C>(L, 0, tid);
+#endif
+                value_recursion_half<C>(L, 0, lrow, lq, dt);                // even players here, odd players on wavefront 1
+            }
             sweep_sync<C>();
             qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, -1);               // Q-add of the even players
             sweep_sync<C>();
             static_assert(!HELP2 || (SYSROW && m == 2 * P && m / 2 <= WAVE / 16), "V rows of one wavefront's players in one pass");
             v_sysrow<C>(L, Rc, k, dt, 2 * (tid >> 4) + 0, tid & 15);       // V rows of the even players' controls (c % P = player)
-            team_lds_barrier();                           // all players' P_i and V rows are back
+#if ALG_HELP2 >= 2
+            player_tail_half<C>(L, Rc, dt, k, N, 0, tid);                   // their s_i, y_i, g_c
+#endif
+            team_lds_barrier();                           // all players' P_i, V rows and g_c are back
         } else
         qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
-        if constexpr (!AUGS) {
+        constexpr bool TAIL2 = HELP2 && ALG_HELP2 >= 2;                      // team of two: s_i, y_i, g_c were formed per player above
+        if constexpr (!AUGS && !TAIL2) {
             for (int e = tid; e < P * n; e += BT) {                         // s_i <- rx_i + A_{k+1}' t_i
                 const int i = e / n, r = e % n; const double* ti = &L.bw.t[i * n];
                 double v = Rc[R::RX + e];
@@ -2817,7 +2883,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             }
         }
         static_assert(P * 16 <= WAVE, "one (player, row) per lane");
-        if ((tid >> 4) < P) {
+        if (!TAIL2 && (tid >> 4) < P) {
             // rd sits one entry per lane in every 16-lane row and reaches the FMA chain through the DPP row broadcast: one LDS read of
             // rd per lane instead of n (same products, same order: bit-identical to `a += Pr[c] * rd[c]`)
             const int yp = tid >> 4, yr = (tid & 15) < n ? (tid & 15) : n - 1;

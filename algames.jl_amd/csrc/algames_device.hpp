@@ -825,7 +825,10 @@ struct AsmLds {
     // A chunk holds x_k of its first step, the FT + 1 blocks [x_{k+1} | u_k | lambda_k] the rows touch (the last one only for
     // A_{k+1}' lambda_{k+1}), the [x | u] parts of the proximal reference, the pair-gradient tables and the LQR constants.
     // (one wavefront per game only: on a team the chunks' workgroup barriers cost more than the pass saves -- C5 loop, team of four: 105 vs 152 K/s)
-    static constexpr bool FUSED = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE) && !C::EXT && !C::DENSE && C::NW == 1;
+#ifndef ALG_FUSED_TEAMS
+#define ALG_FUSED_TEAMS 0     // 1 (A/B builds): the fused pass on teams as well -- loses with LDS-only barriers too: C3 2.72 vs 2.79 M/s, C5 loop 122 vs 152 K/s
+#endif
+    static constexpr bool FUSED = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE) && !C::EXT && !C::DENSE && (C::NW == 1 || ALG_FUSED_TEAMS);
     static constexpr int FT = 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
     struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[(FT + 1) * NCF], lqr[NLQR]; };
     struct NoChunk {};
@@ -1298,7 +1301,9 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
     CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b, FT = AsmLds<C>::FT, TAB = AsmLds<C>::TAB, NXU = n + m, NT = C::NT, NC = C::NC;
-    auto fsync = [&]() { if constexpr (C::NW == 1) sweep_sync<C>(); else game_sync(); };       // the chunk buffers are shared by the whole team
+    // the chunk buffers are shared by the whole team; inside the chunk loop only LDS is exchanged (phase A ends with a full barrier), so the
+    // team's barrier orders LDS only -- with barriers that drained vmcnt the fused pass lost to the two passes on teams (C5 loop: 105 vs 152 K/s)
+    auto fsync = [&]() { if constexpr (C::NW == 1) sweep_sync<C>(); else team_lds_barrier(); };
     using R = Rec<C>;
     constexpr bool RECS = (MODE == 1 || MODE == 3);
     const int N = phase_int(pr.N), lane = phase_lane();

@@ -1772,29 +1772,59 @@ template <int M, int NRHS> struct GjFlat {
     __device__ __forceinline__ static bool rhs(int lane) { return lane >= M && lane < M + NRHS; }
     __device__ __forceinline__ static int column(int lane) { return lane < M + NRHS ? lane : M + NRHS - 1; }
 };
+#ifndef ALG_GJSPEC
+#define ALG_GJSPEC 1          // 1: reciprocal of the diagonal candidate started before the pivot test, pivot search as a max tree (bit-identical)
+#endif
+// max |b[0..NB-1]|: v_max_f64 with |.| modifiers (through fmax() the compiler canonicalises every operand first), ONE asm statement
+// (the compiler pads every statement boundary with an s_nop).  ALG_GJSPEC: a tree of depth <= 3 instead of a chain of depth NB - 1 --
+// max is exact and NaN-dropping either way, so the result is the same number; a lone wavefront waits for every link of the chain.
+template <int NB>
+__device__ __forceinline__ double absmax_below(const double* b) {
+    static_assert(NB >= 1 && NB <= 7, "control system larger than the DPP elimination supports");
+    double oth;
+    if constexpr (NB == 1) oth = fabs(b[0]);
+    else if constexpr (NB == 2) asm("v_max_f64 %0, |%1|, |%2|" : "=v"(oth) : "v"(b[0]), "v"(b[1]));
+    else if constexpr (NB == 3) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|" : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]));
+#if ALG_GJSPEC
+    else if constexpr (NB == 4) { double t1;
+        asm("v_max_f64 %0, |%2|, |%3|\n\tv_max_f64 %1, |%4|, |%5|\n\tv_max_f64 %0, %0, %1"
+            : "=&v"(oth), "=&v"(t1) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3])); }
+    else if constexpr (NB == 5) { double t1;
+        asm("v_max_f64 %0, |%2|, |%3|\n\tv_max_f64 %1, |%4|, |%5|\n\tv_max_f64 %0, %0, |%6|\n\tv_max_f64 %0, %0, %1"
+            : "=&v"(oth), "=&v"(t1) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4])); }
+    else if constexpr (NB == 6) { double t1, t2;
+        asm("v_max_f64 %0, |%3|, |%4|\n\tv_max_f64 %1, |%5|, |%6|\n\tv_max_f64 %2, |%7|, |%8|\n\tv_max_f64 %0, %0, %1\n\tv_max_f64 %0, %0, %2"
+            : "=&v"(oth), "=&v"(t1), "=&v"(t2) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5])); }
+    else { double t1, t2;
+        asm("v_max_f64 %0, |%3|, |%4|\n\tv_max_f64 %1, |%5|, |%6|\n\tv_max_f64 %2, |%7|, |%8|\n\tv_max_f64 %0, %0, %1\n\tv_max_f64 %2, %2, |%9|\n\tv_max_f64 %0, %0, %2"
+            : "=&v"(oth), "=&v"(t1), "=&v"(t2) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6])); }
+#else
+    else if constexpr (NB == 4) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|" : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    else if constexpr (NB == 5) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|"
+                                    : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]));
+    else if constexpr (NB == 6) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|\n\tv_max_f64 %0, %0, |%6|"
+                                    : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]));
+    else asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|\n\tv_max_f64 %0, %0, |%6|\n\tv_max_f64 %0, %0, |%7|"
+             : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]));
+#endif
+    return oth;
+}
 template <int M, int C>
 __device__ __forceinline__ void gj_dpp_pivot(double (&col)[M], int& sing) {
     // lane C of the row owns W's column C: its entries below the diagonal decide the pivot (wave-uniform: every row holds the
     // same replica; bit C of the ballot is row 0's lane C)
     double best = fabs(col[C]);
+    // ALG_GJSPEC: the diagonal entry is the pivot unless the test below says otherwise (it almost never does: W = R^ + V B is
+    // dominated by its diagonal), so its broadcast and reciprocal -- rcp + four dependent FMAs -- start BEFORE the pivot search and
+    // the two dependency chains overlap; a row exchange repeats them on the exchanged entry.  Same operations on the same numbers.
+    double pvt, rpv = 0.0;
+#if ALG_GJSPEC
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pvt) : "v"(col[C]), "n"(C));
+    rpv = fast_rcp(pvt);
+#endif
     unsigned long long need = 0;
     if constexpr (C + 1 < M) {
-        // max |.| below the diagonal (v_max_f64 with |.| modifiers; through fmax() the compiler canonicalises every operand first)
-        // (one asm statement: the compiler pads every statement boundary with an s_nop)
-        double oth;
-        constexpr int NB = M - C - 1;                 // entries below the diagonal
-        const double* b = &col[C + 1];
-        if constexpr (NB == 1) oth = fabs(b[0]);
-        else if constexpr (NB == 2) asm("v_max_f64 %0, |%1|, |%2|" : "=v"(oth) : "v"(b[0]), "v"(b[1]));
-        else if constexpr (NB == 3) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|" : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]));
-        else if constexpr (NB == 4) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|" : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
-        else if constexpr (NB == 5) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|"
-                                        : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]));
-        else if constexpr (NB == 6) asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|\n\tv_max_f64 %0, %0, |%6|"
-                                        : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]));
-        else asm("v_max_f64 %0, |%1|, |%2|\n\tv_max_f64 %0, %0, |%3|\n\tv_max_f64 %0, %0, |%4|\n\tv_max_f64 %0, %0, |%5|\n\tv_max_f64 %0, %0, |%6|\n\tv_max_f64 %0, %0, |%7|"
-                 : "=&v"(oth) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]));
-        static_assert(NB <= 7, "control system larger than the DPP elimination supports");
+        const double oth = absmax_below<M - C - 1>(&col[C + 1]);
         need = __builtin_amdgcn_ballot_w64(oth > best);
     }
     if ((need >> C) & 1ull) {
@@ -1806,11 +1836,17 @@ __device__ __forceinline__ void gj_dpp_pivot(double (&col)[M], int& sing) {
         for (int r = C + 1; r < M; r++) {
             if (piv == r) { const double t = col[C]; col[C] = col[r]; col[r] = t; }
         }
+#if ALG_GJSPEC
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pvt) : "v"(col[C]), "n"(C));
+        rpv = fast_rcp(pvt);
+#endif
     }
-    double pvt;
+#if !ALG_GJSPEC
     asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pvt) : "v"(col[C]), "n"(C));
+    rpv = fast_rcp(pvt);
+#endif
     if (!(fabs(pvt) > 0.0) || !isfinite(pvt)) sing = 1;
-    const double prow = col[C] * fast_rcp(pvt);
+    const double prow = col[C] * rpv;
     DppElim<M>::template run<C>(col, prow);
     col[C] = prow;
 }
@@ -2580,8 +2616,8 @@ __device__ __forceinline__ void t_half(DirLds<C>& L, int first, int lane) {
 // at 1024 games: 2.30 against 2.35 M/s), but the value recursion alone -- a quarter of a step, independent per player, LDS in / LDS out
 // -- is worth two LDS-only barriers: wavefront 1 takes the odd players' MFMA chains of every step and does nothing else in the direction.
 #ifndef ALG_HELP2
-#define ALG_HELP2 2            // 0: off; 1: value recursion, Q-add, V rows, record fetch (bit-identical to the unsplit direction); 2: + s_i, y_i, g_c
-#endif
+#define ALG_HELP2 4            // 0: off; 1: value recursion, Q-add, V rows, record fetch (bit-identical to the unsplit direction); 2: + s_i, y_i, g_c;
+#endif                         // 3: + the helper solves the control system as well and forms the odd rows of [F | f]; 4: + it writes the gains (3, 4: bit-identical to 2)
 template <class C, bool IBR>
 inline constexpr bool help2_v = ALG_HELP2 && C::NW == 2 && !IBR && !C::DENSE && C::WPE == 2 && C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4;
 // [P_i | s_i] <- A' ([P_i | s_i] [[F f],[0 1]]) for the players first, first + 2, ...: operands of all of them read first, their MFMA
@@ -2694,14 +2730,60 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 team_lds_barrier();
                 // while wavefront 0 runs the serial tail of step k: the record of step k - 1 from global memory into the other LDS slot
                 // (wavefront 0 never waits for a load inside the sweep)
+                double nx[RPL];
                 if (k > 0) {
-                    double nx[RPL];
 #pragma unroll
                     for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; nx[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+                }
+#if ALG_HELP2 >= 3
+                // ... and its share of that tail, with the record's loads in flight: the same columns of [W | V A_k | g], the same pivoted
+                // solve (every wavefront needs the solved columns for its rows), the odd rows of [F | f] = [A_k | rd] + B [K | kappa],
+                // and (ALG_HELP2 >= 4) the gain stores -- wavefront 0 forms the even rows and issues no store at all in the sweep
+                {
+                    using GLh = GjLanes<m, n + 1>;
+                    const double* Rh = L.rec[curh]; const double* coefh = Rh + R::COEF;
+                    const int cidx = GLh::column(tid); const bool rhsl = GLh::rhs(tid);
+                    double col[m];
+#pragma unroll
+                    for (int c = 0; c < m; c++) col[c] = L.bw.V[c * VW + cidx];
+                    gj_solve_cols_dpp<m>(col);
+                    if (rhsl) {
+                        const int cc = cidx - m;
+#pragma unroll
+                        for (int c = 0; c < m; c++) col[c] = -col[c];
+                        const double* acol = (cc < n) ? &L.bw.T[cc * n] : Rh + R::RD;
+                        double fxv[n];
+#pragma unroll
+                        for (int r = 1; r < n; r += 2) fxv[r] = B_vec<C>(coefh, dt, [&](int c2) { return col[c2]; }, r) + acol[r];
+#pragma unroll
+                        for (int r = 1; r < n; r += 2) {
+                            if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];
+                            else { double* dst = cc < n ? &L.bw.Fx[r * 16 + cc] : &L.bw.fv[r]; *dst = fxv[r]; }
+                        }
+                    }
+                    if (k > 0) {
+#pragma unroll
+                        for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; if (e < R::LEN_SWEEP) L.rec[curh ^ 1][e] = nx[q]; }
+                    }
+#if ALG_HELP2 >= 4
+                    asm volatile("" ::: "memory");
+                    if (rhsl) {
+                        double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (cidx - m) * m;
+#pragma unroll
+                        for (int c = 0; c < m; c++) Kg[c] = col[c];
+                    }
+#endif
+                }
+#else
+                if (k > 0) {
 #pragma unroll
                     for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; if (e < R::LEN_SWEEP) L.rec[curh ^ 1][e] = nx[q]; }
                 }
+#endif
             }
+#if ALG_HELP2 >= 4
+            game_sync();                 // the gains are this wavefront's stores: wavefront 0's forward sweep reads them behind a full barrier
+#endif
             return ALG_STATUS_OK;
         }
     }
@@ -2851,6 +2933,10 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #if ALG_HELP2 >= 2
             player_tail_half<C>(L, Rc, dt, k, N, 0, tid);                   // their s_i, y_i, g_c
 #endif
+#if ALG_HELP2 >= 3
+            // coefficient entries of A_k' for both wavefronts' closed-loop rows (the table's last readers finished before the first barrier)
+            if (tid < 4 * P) { const int kind = tid / P, i = tid % P; L.bw.T[(((kind & 1) ? 3 : 2) * P + i) * n + ((kind >> 1) ? P + i : i)] = coefk[tid]; }
+#endif
             team_lds_barrier();                           // all players' P_i, V rows and g_c are back
         } else
         qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, IBR ? ip : -1);
@@ -2888,19 +2974,27 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             }
         }
         static_assert(P * 16 <= WAVE, "one (player, row) per lane");
-        if (!TAIL2 && (tid >> 4) < P) {
+        // Team of four: the V rows above occupy wavefront 0 (and one or two rows of wavefront 1); y_i / g_c below and the A' table are
+        // independent of them inside this phase, so they run on wavefronts 2 and 3 at the same time instead of behind the V rows on
+        // wavefront 0 (same lanes of a 16-lane row, same instructions: bit-identical)
+#ifndef ALG_TEAM_YSPLIT
+#define ALG_TEAM_YSPLIT 1
+#endif
+        constexpr int YOFF = (TEAM && ALG_TEAM_YSPLIT && C::NT >= 256) ? 128 : 0, TOFF = (TEAM && ALG_TEAM_YSPLIT && C::NT >= 256) ? 192 : 0;
+        const int ty = tid - YOFF, tT = tid - TOFF;
+        if (!TAIL2 && ty >= 0 && (ty >> 4) < P) {
             // rd sits one entry per lane in every 16-lane row and reaches the FMA chain through the DPP row broadcast: one LDS read of
             // rd per lane instead of n (same products, same order: bit-identical to `a += Pr[c] * rd[c]`)
-            const int yp = tid >> 4, yr = (tid & 15) < n ? (tid & 15) : n - 1;
+            const int yp = ty >> 4, yr = (ty & 15) < n ? (ty & 15) : n - 1;
             const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
             const double rdl = Rc[R::RD + yr];
             double a = Pr[n];
             rowdot_dpp_f<n>(a, rdl, [&](int c) { return Pr[c]; });
-            if (!GFUSE && (tid & 15) < n) L.bw.t[yp * n + yr] = a;
+            if (!GFUSE && (ty & 15) < n) L.bw.t[yp * n + yr] = a;
             // g_c = ru_c + B[:,c]' y_i for the controls c of this row's player (c % P == i): the rows of y_i that column c of B touches are
             // shifts away inside the row, so lane 16 i + c finishes g_c here -- no second phase, no trip of y through LDS (BT_vec's expression)
             if constexpr (GFUSE) {
-                const int rl = tid & 15;
+                const int rl = ty & 15;
                 double gb;
                 if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
                     const double up = row_shift<0x100 + m>(a);
@@ -2916,12 +3010,12 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         }
         // coefficient entries of A_k' (state-dependent models)
         if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
-            if (tid < 4 * P) { const int kind = tid / P, i = tid % P; L.bw.T[(((kind & 1) ? 3 : 2) * P + i) * n + ((kind >> 1) ? P + i : i)] = coefk[tid]; }
+            if (!(HELP2 && ALG_HELP2 >= 3) && tT >= 0 && tT < 4 * P) { const int kind = tT / P, i = tT % P; L.bw.T[(((kind & 1) ? 3 : 2) * P + i) * n + ((kind >> 1) ? P + i : i)] = coefk[tT]; }
         } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
-            if (tid < 5 * P) {
-                const int kind = tid / P, i = tid % P;          // (x,psi) (x,v) (y,psi) (y,v) (psi,v)
+            if (tT >= 0 && tT < 5 * P) {
+                const int kind = tT / P, i = tT % P;          // (x,psi) (x,v) (y,psi) (y,v) (psi,v)
                 const int colb = (kind == 0 || kind == 2) ? 3 : 2, row = kind < 2 ? i : (kind < 4 ? P + i : 3 * P + i);
-                L.bw.T[(colb * P + i) * n + row] = coefk[tid];
+                L.bw.T[(colb * P + i) * n + row] = coefk[tT];
             }
         }
         if (!SYSROW && tid < m) L.bw.V[tid * VW + n + 1 + tid] = Rc[R::RHAT + tid];
@@ -2980,12 +3074,14 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             // all LDS reads first, then all writes: the compiler cannot prove that the Fx stores do not alias the T / record
             // loads and would otherwise serialise one LDS round trip per row
             // (team: wavefront tw forms the rows r = tw (mod NW); every wavefront holds the solved columns)
+            // (team of two, ALG_HELP2 >= 3: the helper wavefront forms the odd rows)
+            constexpr int RS = TEAM ? C::NW : ((HELP2 && ALG_HELP2 >= 3) ? 2 : 1);
             double fxv[n];
 #pragma unroll
-            for (int r = 0; r < n; r++) { if (!TEAM || (r % C::NW) == tw) fxv[r] = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r) + acol[r]; }
+            for (int r = 0; r < n; r++) { if (RS == 1 || (r % RS) == tw) fxv[r] = B_vec<C>(coefk, dt, [&](int c2) { return col[c2]; }, r) + acol[r]; }
 #pragma unroll
             for (int r = 0; r < n; r++) {
-                if (TEAM && (r % C::NW) != tw) continue;
+                if (RS != 1 && (r % RS) != tw) continue;
                 if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];         // f rides in tile column n
                 else { double* dst = cc < n ? &L.bw.Fx[r * 16 + cc] : &L.bw.fv[r]; *dst = fxv[r]; }   // one store, selected address (no exec-mask flip per row)
             }
@@ -3000,7 +3096,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // the gains go out last (gfx9 counts loads and stores in one vmcnt: the wait for the prefetched record above should not
         // meet stores that were just issued; measured neutral, the phase profile shows no exposed wait either way)
         asm volatile("" ::: "memory");
-        if (tw == 0 && rhsl) {
+        if (!(HELP2 && ALG_HELP2 >= 4) && tw == 0 && rhsl) {
             double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (cidx - m) * m;
 #pragma unroll
             for (int c = 0; c < m; c++) Kg[c] = col[c];
@@ -3008,6 +3104,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         bsync();
         ALG_PROF(6)
     }
+    if constexpr (HELP2 && ALG_HELP2 >= 4) game_sync();                        // the helper wavefront's gain stores
     if (__builtin_amdgcn_readfirstlane(sing)) return ALG_STATUS_SINGULAR;      // wave-uniform (every lane factors the same matrix)
     if (TEAM && tw != 0) return ALG_STATUS_OK;         // the serial sweeps below belong to wavefront 0 (the caller holds a barrier)
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 1

@@ -2567,19 +2567,26 @@ __device__ __forceinline__ void v_sysrow(DirLds<C>& L, const double* Rc, int k, 
 //   y_i = P_i rd + s_i, g_c = ru_c + B[:,c]' y_i   with TWO lanes per row of P_i (lanes 0..31: columns 0..7, lanes 32..63: columns 8..15; the
 //   halves meet through v_permlane32_swap), i.e. FMA chains of eight instead of sixteen -- the sums associate differently from the
 //   one-wavefront kernel's (rounding-level differences, like the team's norms).
+// s_i <- rx_i + A_{k+1}' t_i for the players first and first + 2 (n == 16: s_i lives in column n of the players' LDS rows, outside the MFMA tiles)
 template <class C>
+__device__ __forceinline__ void s_half(DirLds<C>& L, const double* Rc, double dt, bool rec, int first, int lane) {
+    constexpr int n = C::n, LDP = DirLds<C>::LDP;
+    using R = Rec<C>;
+    if (lane < 2 * n) {
+        const int i = first + 2 * (lane / n), r = lane % n; const double* ti = &L.bw.t[i * n];
+        double v = Rc[R::RX + i * n + r];
+        if (rec) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
+        L.bw.Pm[i * n * LDP + r * LDP + n] = v;
+    }
+}
+template <class C, bool SKIP_S = false>
 __device__ __forceinline__ void player_tail_half(DirLds<C>& L, const double* Rc, double dt, int k, int N, int first, int lane) {
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, VW = DirLds<C>::VW;
     static_assert(n == 16 && P == 4 && C::MODEL == ALG_MODEL_UNICYCLE, "lane layout of the team-of-two tail (4-player unicycle)");
     using R = Rec<C>;
     const double* coefk = Rc + R::COEF;
-    if constexpr (!DirLds<C>::AUGS) {
-        if (lane < 2 * n) {
-            const int i = first + 2 * (lane / n), r = lane % n; const double* ti = &L.bw.t[i * n];
-            double v = Rc[R::RX + i * n + r];
-            if (k < N - 2) v += AT_vec<C>(L.coefn, dt, [&](int rr) { return ti[rr]; }, r);
-            L.bw.Pm[i * n * LDP + r * LDP + n] = v;
-        }
+    if constexpr (!DirLds<C>::AUGS && !SKIP_S) {
+        s_half<C>(L, Rc, dt, k < N - 2, first, lane);
         sweep_sync<C>();
     }
     const int h = lane >> 5, yp = first + 2 * ((lane >> 4) & 1), yr = lane & 15;
@@ -2617,13 +2624,16 @@ __device__ __forceinline__ void t_half(DirLds<C>& L, int first, int lane) {
 // -- is worth two LDS-only barriers: wavefront 1 takes the odd players' MFMA chains of every step and does nothing else in the direction.
 #ifndef ALG_HELP2
 #define ALG_HELP2 4            // 0: off; 1: value recursion, Q-add, V rows, record fetch (bit-identical to the unsplit direction); 2: + s_i, y_i, g_c;
-#endif                         // 3: + the helper solves the control system as well and forms the odd rows of [F | f]; 4: + it writes the gains (3, 4: bit-identical to 2)
+#endif                         // 3: + the helper solves the control system as well and forms the odd rows of [F | f]; 4: + it writes the gains; 5: t_i and s_i behind the MFMA chains (3 - 5: bit-identical to 2)
 template <class C, bool IBR>
 inline constexpr bool help2_v = ALG_HELP2 && C::NW == 2 && !IBR && !C::DENSE && C::WPE == 2 && C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4;
 // [P_i | s_i] <- A' ([P_i | s_i] [[F f],[0 1]]) for the players first, first + 2, ...: operands of all of them read first, their MFMA
 // chains interleaved, results written back to the players' own LDS row blocks (nobody else touches those between the two barriers).
-template <class C>
-__device__ __forceinline__ void value_recursion_half(DirLds<C>& L, int first, int lrow, int lq, double dt) {
+// SHADOW (ALG_HELP2 >= 5, n == 16): t_i = P_i f + s_i and s_i <- rx_i + A' t_i of the same players -- VALU / LDS work that needs the OLD
+// P_i only -- are issued behind the MFMA chains and run while the matrix pipeline works (the wavefront would otherwise wait for
+// the accumulators); same instructions on the same numbers as in their own phases.
+template <class C, bool SHADOW = false>
+__device__ __forceinline__ void value_recursion_half(DirLds<C>& L, int first, int lrow, int lq, double dt, const double* Rc = nullptr, int lane = 0) {
     constexpr int n = C::n, P = C::P, PH = P / 2, LDP = DirLds<C>::LDP, KB1 = DirLds<C>::KB1;
     constexpr bool AUGS = DirLds<C>::AUGS;
     constexpr int oPm = (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8), oPad = (int)(offsetof(typename DirLds<C>::Bwd, pad) / 8);
@@ -2646,6 +2656,13 @@ __device__ __forceinline__ void value_recursion_half(DirLds<C>& L, int first, in
     for (int kb = 0; kb < KB1; kb++)
 #pragma unroll
         for (int ii = 0; ii < PH; ii++) c1[ii] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[ii][kb], bF[kb], c1[ii], 0, 0, 0);
+    if constexpr (SHADOW) {
+        __builtin_amdgcn_sched_barrier(0);
+        t_half<C>(L, first, lane);
+        sweep_sync<C>();
+        s_half<C>(L, Rc, dt, true, first, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int ii = 0; ii < PH; ii++) {
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) c2[ii] = di_AT_tile<C>(c1[ii], dt, lq);
@@ -2714,18 +2731,23 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             int curh = 0;
             for (int k = N - 2; k >= 0; k--, curh ^= 1) {
                 team_lds_barrier();
+#if ALG_HELP2 >= 5
+                if (k < N - 2) value_recursion_half<C, true>(L, 1, lrow, lq, dt, L.rec[curh], tid);
+                else s_half<C>(L, L.rec[curh], dt, false, 1, tid);
+#else
                 if (k < N - 2) {
 #if ALG_HELP2 >= 2
                     t_half<C>(L, 1, tid);
 #endif
                     value_recursion_half<C>(L, 1, lrow, lq, dt);
                 }
+#endif
                 sweep_sync<C>();
                 qam.apply(tid, L.rec[curh], L.qdf, bwh, reg, (k + 1 < N - 1) ? dt : 1.0, -1);
                 sweep_sync<C>();
                 v_sysrow<C>(L, L.rec[curh], k, dt, 2 * (tid >> 4) + 1, tid & 15);       // V rows of the odd players' controls
 #if ALG_HELP2 >= 2
-                player_tail_half<C>(L, L.rec[curh], dt, k, N, 1, tid);                 // their s_i, y_i, g_c
+                player_tail_half<C, (ALG_HELP2 >= 5)>(L, L.rec[curh], dt, k, N, 1, tid);                 // their s_i, y_i, g_c
 #endif
                 team_lds_barrier();
                 // while wavefront 0 runs the serial tail of step k: the record of step k - 1 from global memory into the other LDS slot
@@ -2919,19 +2941,24 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
         if constexpr (HELP2) {
             team_lds_barrier();                           // [F f], the coefficients, the record and every P_i of the step before are in LDS for both wavefronts
+#if ALG_HELP2 >= 5
+            if (k < N - 2) value_recursion_half<C, true>(L, 0, lrow, lq, dt, Rc, tid);     // even players here, odd players on wavefront 1
+            else s_half<C>(L, Rc, dt, false, 0, tid);
+#else
             if (k < N - 2) {
 #if ALG_HELP2 >= 2
                 t_half<C>(L, 0, tid);
 #endif
                 value_recursion_half<C>(L, 0, lrow, lq, dt);                // even players here, odd players on wavefront 1
             }
+#endif
             sweep_sync<C>();
             qam.apply(tid, Rc, L.qdf, bwb + oPm, reg, w, -1);               // Q-add of the even players
             sweep_sync<C>();
             static_assert(!HELP2 || (SYSROW && m == 2 * P && m / 2 <= WAVE / 16), "V rows of one wavefront's players in one pass");
             v_sysrow<C>(L, Rc, k, dt, 2 * (tid >> 4) + 0, tid & 15);       // V rows of the even players' controls (c % P = player)
 #if ALG_HELP2 >= 2
-            player_tail_half<C>(L, Rc, dt, k, N, 0, tid);                   // their s_i, y_i, g_c
+            player_tail_half<C, (ALG_HELP2 >= 5)>(L, Rc, dt, k, N, 0, tid);                   // their s_i, y_i, g_c
 #endif
 #if ALG_HELP2 >= 3
             // coefficient entries of A_k' for both wavefronts' closed-loop rows (the table's last readers finished before the first barrier)

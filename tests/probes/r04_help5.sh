@@ -1,0 +1,7 @@
+#!/bin/bash
+# GPU box: team of two, t_i / s_i behind the MFMA chains (default, ALG_HELP2 = 5) against level 4
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+V=${1:-help4}
+timeout 300 python tests/probes/bitwise_ab.py algames.jl_amd/lib/libalgames_hip.so algames.jl_amd/lib/variants/$V.so > $O/r04_help5_bitwise.txt 2>&1
+timeout 600 bash tests/probes/ab.sh "--steps 20 --warmup 3 --config C3" $V > $O/r04_ab_help5_c3.txt 2>&1
+cat $O/r04_help5_bitwise.txt $O/r04_ab_help5_c3.txt

@@ -1753,6 +1753,40 @@ __device__ __forceinline__ void rowdot_dpp_f(double& acc, double v, PF&& p) {   
 }
 template <int NC>
 __device__ __forceinline__ void rowdot_dpp(double& acc, double v, const double* p) { rowdot_dpp_f<NC>(acc, v, [&](int c) { return p[c]; }); }
+// The same chain with its coefficients requested G at a time, one group ahead of the FMAs that use them.  The FMAs are volatile asm
+// statements, which the compiler does not move loads across: in rowdot_dpp_f every coefficient's LDS read sits between two FMAs of the
+// chain and is waited for on the spot -- NC exposed LDS round trips (a lone wavefront: ~100 cycles each, 1.6 K cycles for the sixteen
+// gain columns of a forward-sweep step of the 4-player unicycle).  Here: ceil(NC / G) groups, the first two requested before the first
+// FMA.  Same products in the same order (bit-identical); costs 2 G live doubles, so the 128-register kernels take small groups.
+template <int C0, int G, int NC, int I = 0, class PF>
+__device__ __forceinline__ void rowdot_group_load(double (&buf)[G], PF&& p) {
+    if constexpr (I < G && C0 + I < NC) { buf[I] = p(C0 + I); rowdot_group_load<C0, G, NC, I + 1>(buf, p); }
+}
+template <int C0, int G, int NC, int I = 0>
+__device__ __forceinline__ void rowdot_group_fmac(double& acc, double v, const double (&buf)[G]) {
+    if constexpr (I < G && C0 + I < NC) { fmac_rowbcast<C0 + I, C0 + I == 0>(acc, v, buf[I]); rowdot_group_fmac<C0, G, NC, I + 1>(acc, v, buf); }
+}
+template <int NC, int G, int C0, class PF>
+__device__ __forceinline__ void rowdot_pipe(double& acc, double v, PF&& p, const double (&cur)[G]) {
+    if constexpr (C0 + G < NC) {
+        double nxt[G];
+        rowdot_group_load<C0 + G, G, NC>(nxt, p);
+        rowdot_group_fmac<C0, G, NC>(acc, v, cur);
+        rowdot_pipe<NC, G, C0 + G>(acc, v, p, nxt);
+    } else rowdot_group_fmac<C0, G, NC>(acc, v, cur);
+}
+template <int NC, int G, class PF>
+__device__ __forceinline__ void rowdot_dpp_g(double& acc, double v, PF&& p) {
+    if constexpr (G <= 0) rowdot_dpp_f<NC>(acc, v, p);
+    else { double cur[G]; rowdot_group_load<0, G, NC>(cur, p); rowdot_pipe<NC, G, 0>(acc, v, p, cur); }
+}
+#ifndef ALG_RDG_W2
+#define ALG_RDG_W2 16         // coefficient group of the row-broadcast chains, 256-register kernels (0: fetch where used)
+#endif
+#ifndef ALG_RDG_W4
+#define ALG_RDG_W4 4          // ... 128-register kernels
+#endif
+template <class C> inline constexpr int rowdot_group_v = C::WPE == 2 ? ALG_RDG_W2 : (C::WPE == 4 ? ALG_RDG_W4 : 0);
 // Lane roles of the DPP elimination inside one wavefront: row q = lane / 16 holds W's columns in its lanes 0..M-1 and the
 // right-hand-side columns q (16 - M) ... in the lanes behind them.
 template <int M, int NRHS> struct GjLanes {
@@ -2594,7 +2628,7 @@ __device__ __forceinline__ void player_tail_half(DirLds<C>& L, const double* Rc,
     const double rdl = Rc[R::RD + ((yr + 8 * h) & 15)];          // lane j of an upper-half row holds rd[j + 8]
     const double* Ph = Pr + 8 * h;
     double a = h ? 0.0 : Pr[n];
-    rowdot_dpp_f<8>(a, rdl, [&](int c) { return Ph[c]; });
+    rowdot_dpp_g<8, (rowdot_group_v<C> < 8 ? rowdot_group_v<C> : 8)>(a, rdl, [&](int c) { return Ph[c]; });
     a += xchg32(a, lane < 32);
     const double dn = row_shift<0x110 + P>(a), up = row_shift<0x100 + P>(a), up2 = row_shift<0x100 + 2 * P>(a);
     const int kind = yr < m ? yr / P : 0;
@@ -3016,7 +3050,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
             const double rdl = Rc[R::RD + yr];
             double a = Pr[n];
-            rowdot_dpp_f<n>(a, rdl, [&](int c) { return Pr[c]; });
+            rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
             if (!GFUSE && (ty & 15) < n) L.bw.t[yp * n + yr] = a;
             // g_c = ru_c + B[:,c]' y_i for the controls c of this row's player (c % P == i): the rows of y_i that column c of B touches are
             // shifts away inside the row, so lane 16 i + c finishes g_c here -- no second phase, no trip of y through LDS (BT_vec's expression)
@@ -3235,7 +3269,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
         const int cl = fl < m ? fl : 0;
         double acc = Kl[n * m + cl];
-        rowdot_dpp_f<n>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
+        rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
         const double duv = fl < m ? acc : 0.0;
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;

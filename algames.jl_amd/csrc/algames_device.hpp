@@ -1762,9 +1762,22 @@ template <int C0, int G, int NC, int I = 0, class PF>
 __device__ __forceinline__ void rowdot_group_load(double (&buf)[G], PF&& p) {
     if constexpr (I < G && C0 + I < NC) { buf[I] = p(C0 + I); rowdot_group_load<C0, G, NC, I + 1>(buf, p); }
 }
+#ifndef ALG_RDG_ASM4
+#define ALG_RDG_ASM4 0        // (measured neutral on C2 / C3 / C5, profiles/r04_ab_asm4_*.txt: off) four terms of a chain per asm statement (the compiler pads every statement boundary of inline asm with an s_nop)
+#endif
+template <int L0, bool FIRST>
+__device__ __forceinline__ void fmac_rowbcast4(double& acc, double v, double p0, double p1, double p2, double p3) {
+#define ALG_F4 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %0, %1, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t" \
+               "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %0, %1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+    if constexpr (FIRST) asm volatile("s_nop 1\n\t" ALG_F4 : "+v"(acc) : "v"(v), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "n"(L0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3));
+    else asm volatile(ALG_F4 : "+v"(acc) : "v"(v), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "n"(L0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3));
+#undef ALG_F4
+}
 template <int C0, int G, int NC, int I = 0>
 __device__ __forceinline__ void rowdot_group_fmac(double& acc, double v, const double (&buf)[G]) {
-    if constexpr (I < G && C0 + I < NC) { fmac_rowbcast<C0 + I, C0 + I == 0>(acc, v, buf[I]); rowdot_group_fmac<C0, G, NC, I + 1>(acc, v, buf); }
+    if constexpr (ALG_RDG_ASM4 && I + 3 < G && C0 + I + 3 < NC) {
+        fmac_rowbcast4<C0 + I, C0 + I == 0>(acc, v, buf[I], buf[I + 1], buf[I + 2], buf[I + 3]); rowdot_group_fmac<C0, G, NC, I + 4>(acc, v, buf);
+    } else if constexpr (I < G && C0 + I < NC) { fmac_rowbcast<C0 + I, C0 + I == 0>(acc, v, buf[I]); rowdot_group_fmac<C0, G, NC, I + 1>(acc, v, buf); }
 }
 template <int NC, int G, int C0, class PF>
 __device__ __forceinline__ void rowdot_pipe(double& acc, double v, PF&& p, const double (&cur)[G]) {

@@ -2626,8 +2626,8 @@ __device__ __forceinline__ void s_half(DirLds<C>& L, const double* Rc, double dt
         L.bw.Pm[i * n * LDP + r * LDP + n] = v;
     }
 }
-template <class C, bool SKIP_S = false>
-__device__ __forceinline__ void player_tail_half(DirLds<C>& L, const double* Rc, double dt, int k, int N, int first, int lane) {
+template <class C, bool SKIP_S = false, bool SREG = false>
+__device__ __forceinline__ void player_tail_half(DirLds<C>& L, const double* Rc, double dt, int k, int N, int first, int lane, double sreg = 0.0) {
     constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, VW = DirLds<C>::VW;
     static_assert(n == 16 && P == 4 && C::MODEL == ALG_MODEL_UNICYCLE, "lane layout of the team-of-two tail (4-player unicycle)");
     using R = Rec<C>;
@@ -2640,7 +2640,7 @@ __device__ __forceinline__ void player_tail_half(DirLds<C>& L, const double* Rc,
     const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
     const double rdl = Rc[R::RD + ((yr + 8 * h) & 15)];          // lane j of an upper-half row holds rd[j + 8]
     const double* Ph = Pr + 8 * h;
-    double a = h ? 0.0 : Pr[n];
+    double a = h ? 0.0 : (SREG ? sreg : Pr[n]);          // (SREG: s_i[yr] is still in this lane's register, ts_half)
     rowdot_dpp_g<8, (rowdot_group_v<C> < 8 ? rowdot_group_v<C> : 8)>(a, rdl, [&](int c) { return Ph[c]; });
     a += xchg32(a, lane < 32);
     const double dn = row_shift<0x110 + P>(a), up = row_shift<0x100 + P>(a), up2 = row_shift<0x100 + 2 * P>(a);
@@ -2666,12 +2666,40 @@ __device__ __forceinline__ void t_half(DirLds<C>& L, int first, int lane) {
     }
 }
 
+// t_i and s_i of the players first and first + 2 in one go (ALG_HELP2 >= 6): t_i stays in registers -- lane (row = player slot, r) of either
+// half holds t_i[r] after the exchange -- and the rows of t_i that A_{k+1}' t_i needs are shifts away inside the 16-lane row (the costate
+// sweep's form of AT_vec), so t_i makes no trip through LDS; s_i goes to its LDS column for the next step AND stays in the lane that
+// starts y_i = P_i rd + s_i from it (player_tail_half<.., SREG>): two LDS round trips and a fence less per step.  Same operations on the
+// same numbers as t_half + s_half (the lambda hands AT_vec exactly the entries it would have read).
+template <class C>
+__device__ __forceinline__ double ts_half(DirLds<C>& L, const double* Rc, double dt, bool rec, int first, int lane) {
+    constexpr int n = C::n, P = C::P, LDP = DirLds<C>::LDP;
+    static_assert(n == 16 && P == 4 && C::MODEL == ALG_MODEL_UNICYCLE && !DirLds<C>::AUGS, "lane layout of the team-of-two tail (4-player unicycle)");
+    using R = Rec<C>;
+    const int h = lane >> 5, i = first + 2 * ((lane >> 4) & 1), r = lane & 15;
+    double v = Rc[R::RX + i * n + r];
+    if (rec) {
+        const double* Pr = &L.bw.Pm[i * n * LDP + r * LDP];
+        double a = h ? 0.0 : Pr[n];
+#pragma unroll
+        for (int c = 0; c < 8; c++) a += Pr[c + 8 * h] * L.bw.fv[c + 8 * h];
+        a += xchg32(a, lane < 32);
+        const double tr = a;
+        const double s1 = row_shift<0x110 + P>(tr), s2 = row_shift<0x110 + 2 * P>(tr), s3 = row_shift<0x110 + 3 * P>(tr), u1 = row_shift<0x100 + P>(tr);
+        const int blk = r / P, ii = r % P;
+        const double vi = blk == 0 ? tr : (blk == 1 ? s1 : (blk == 2 ? s2 : s3)), vpi = blk == 0 ? u1 : (blk == 1 ? tr : (blk == 2 ? s1 : s2));
+        v += AT_vec<C>(L.coefn, dt, [&](int rr) { return rr == r ? tr : (rr == ii ? vi : vpi); }, r);
+    }
+    if (lane < 2 * n) L.bw.Pm[i * n * LDP + r * LDP + n] = v;
+    return v;
+}
+
 // Team of two (round 4): splitting the whole backward step over the two wavefronts costs more in barriers than it gains (measured on C3
 // at 1024 games: 2.30 against 2.35 M/s), but the value recursion alone -- a quarter of a step, independent per player, LDS in / LDS out
 // -- is worth two LDS-only barriers: wavefront 1 takes the odd players' MFMA chains of every step and does nothing else in the direction.
 #ifndef ALG_HELP2
 #define ALG_HELP2 4            // 0: off; 1: value recursion, Q-add, V rows, record fetch (bit-identical to the unsplit direction); 2: + s_i, y_i, g_c;
-#endif                         // 3: + the helper solves the control system as well and forms the odd rows of [F | f]; 4: + it writes the gains; 5: t_i and s_i behind the MFMA chains (3 - 5: bit-identical to 2)
+#endif                         // 3: + the helper solves the control system as well and forms the odd rows of [F | f]; 4: + it writes the gains; 5: t_i and s_i behind the MFMA chains (measured: loses); 6: t_i, s_i in registers (ts_half; measured +0.3 %, not shipped) (3 - 6: bit-identical to 2)
 template <class C, bool IBR>
 inline constexpr bool help2_v = ALG_HELP2 && C::NW == 2 && !IBR && !C::DENSE && C::WPE == 2 && C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4;
 // [P_i | s_i] <- A' ([P_i | s_i] [[F f],[0 1]]) for the players first, first + 2, ...: operands of all of them read first, their MFMA
@@ -2778,7 +2806,10 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             int curh = 0;
             for (int k = N - 2; k >= 0; k--, curh ^= 1) {
                 team_lds_barrier();
-#if ALG_HELP2 >= 5
+#if ALG_HELP2 >= 6
+                const double sregh = ts_half<C>(L, L.rec[curh], dt, k < N - 2, 1, tid);
+                if (k < N - 2) value_recursion_half<C>(L, 1, lrow, lq, dt);
+#elif ALG_HELP2 >= 5
                 if (k < N - 2) value_recursion_half<C, true>(L, 1, lrow, lq, dt, L.rec[curh], tid);
                 else s_half<C>(L, L.rec[curh], dt, false, 1, tid);
 #else
@@ -2794,7 +2825,11 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 sweep_sync<C>();
                 v_sysrow<C>(L, L.rec[curh], k, dt, 2 * (tid >> 4) + 1, tid & 15);       // V rows of the odd players' controls
 #if ALG_HELP2 >= 2
+#if ALG_HELP2 >= 6
+                player_tail_half<C, true, true>(L, L.rec[curh], dt, k, N, 1, tid, sregh);              // their y_i, g_c
+#else
                 player_tail_half<C, (ALG_HELP2 >= 5)>(L, L.rec[curh], dt, k, N, 1, tid);                 // their s_i, y_i, g_c
+#endif
 #endif
                 team_lds_barrier();
                 // while wavefront 0 runs the serial tail of step k: the record of step k - 1 from global memory into the other LDS slot
@@ -2988,7 +3023,10 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // ---- Q-add: the non-zeros of [Q^_i | rx_i] (diagonal, position block, column n), one entry per lane and pass
         if constexpr (HELP2) {
             team_lds_barrier();                           // [F f], the coefficients, the record and every P_i of the step before are in LDS for both wavefronts
-#if ALG_HELP2 >= 5
+#if ALG_HELP2 >= 6
+            const double sreg0 = ts_half<C>(L, Rc, dt, k < N - 2, 0, tid);
+            if (k < N - 2) value_recursion_half<C>(L, 0, lrow, lq, dt);                // even players here, odd players on wavefront 1
+#elif ALG_HELP2 >= 5
             if (k < N - 2) value_recursion_half<C, true>(L, 0, lrow, lq, dt, Rc, tid);     // even players here, odd players on wavefront 1
             else s_half<C>(L, Rc, dt, false, 0, tid);
 #else
@@ -3005,7 +3043,11 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             static_assert(!HELP2 || (SYSROW && m == 2 * P && m / 2 <= WAVE / 16), "V rows of one wavefront's players in one pass");
             v_sysrow<C>(L, Rc, k, dt, 2 * (tid >> 4) + 0, tid & 15);       // V rows of the even players' controls (c % P = player)
 #if ALG_HELP2 >= 2
+#if ALG_HELP2 >= 6
+            player_tail_half<C, true, true>(L, Rc, dt, k, N, 0, tid, sreg0);                // their y_i, g_c
+#else
             player_tail_half<C, (ALG_HELP2 >= 5)>(L, Rc, dt, k, N, 0, tid);                   // their s_i, y_i, g_c
+#endif
 #endif
 #if ALG_HELP2 >= 3
             // coefficient entries of A_k' for both wavefronts' closed-loop rows (the table's last readers finished before the first barrier)

@@ -3568,6 +3568,12 @@ __device__ DirGate dir_urow_residual(CPR pr0, const Game& G0, int ip) {
     double* __restrict__ recs = G.rec(pr);
     // the pair with the largest ratio |rho| / scale is tracked by cross-multiplication: one division per lane at the end
     double rho_m = 0.0, s_m = 0.0, wr = 0.0, ws = 1.0;
+#ifndef ALG_GATE_UNROLL
+#define ALG_GATE_UNROLL 0      // > 1: trips of the gate's flat loop whose loads are in flight together (a trip is one exposed memory round trip)
+#endif
+#if ALG_GATE_UNROLL > 1
+#pragma unroll ALG_GATE_UNROLL
+#endif
     for (int e = tid; e < (N - 1) * m; e += C::NT) {
         const int k = e / m, c = e % m, i = c % P;
         double* Rk = recs + (size_t)k * R::LEN;

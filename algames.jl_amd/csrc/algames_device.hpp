@@ -168,7 +168,10 @@ struct Cfg {
 #define ALG_SWEEP_DEPTH 4
 #endif
     // (measured, depth 1 / 2 / 4 / 8: C2 10.22 / 10.28 / 10.37 / 10.33 M/s, C3 2.38 / 2.43 / 2.43 / 2.44 M/s, C5 loop 154 / 158 / 157 / 156 K/s)
-    static constexpr int SWEEP_DEPTH = WPE == 4 ? ALG_SWEEP_DEPTH : (ALG_SWEEP_DEPTH < 2 ? ALG_SWEEP_DEPTH : 2);
+#ifndef ALG_SWEEP_DEPTH_W2
+#define ALG_SWEEP_DEPTH_W2 2       // 256-register kernels
+#endif
+    static constexpr int SWEEP_DEPTH = WPE == 4 ? ALG_SWEEP_DEPTH : (ALG_SWEEP_DEPTH < ALG_SWEEP_DEPTH_W2 ? ALG_SWEEP_DEPTH : ALG_SWEEP_DEPTH_W2);
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
     static constexpr int ASM_UNROLL = ALG_ASM_UNROLL;
 };

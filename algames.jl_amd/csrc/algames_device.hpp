@@ -2801,6 +2801,19 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #define ALG_SYSROW 1
 #endif
     constexpr bool SYSROW = ALG_SYSROW && GFUSE;      // the V phase forms the system's rows (needs g from the y lanes)
+    // Split value recursion (round 5; double integrator): with F = A_k + B K and f = rd + B kappa,
+    //   [P_i | s_i] [[F f],[0 1]] = [P_i A_k | y_i] + (P_i B) [K | kappa],      y_i = P_i rd + s_i  (already formed for g_c),
+    // and for the double integrator both P_i A_k (P + dt x its columns shifted by m) and P_i B (dt^2/2 x columns 0..m-1 + dt x columns
+    // m..n-1) are two-term combinations of entries of P_i.  The accumulator tile starts at [P_i A_k | y_i] and the product has inner
+    // dimension m instead of n + 1: ceil(m / 4) f64 MFMAs per player instead of (n + 4) / 4 (C2: 6 per step instead of 12 -- the matrix
+    // pipe of a SIMD is shared by its four resident games and was busy 3 250 of the ~10 500 cycles of a backward step), and the
+    // closed-loop phase ([F | f] = [A_k | rd] + B [K | kappa] -> LDS) disappears: the solved columns [K | kappa] go to LDS as they are
+    // (the B operand of the product) and y_i replaces s_i in column n of the player's rows.
+#ifndef ALG_SPLITF
+#define ALG_SPLITF 1
+#endif
+    constexpr bool SPLITF = ALG_SPLITF && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && AUGS && !IBR && (C::NW == 1 || TEAM);
+    constexpr int KBS = (m + 3) / 4;                    // k-blocks of the split product (inner dimension m)
     QaddMap<C, BT, (HELP2 ? 2 : 1)> qam; qam.init(tid, hw);
     if constexpr (HELP2) {
         if (hw == 1) {
@@ -2899,10 +2912,11 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     typename std::conditional<(C::P == 3 && C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR), P3Gather<C>, NoGather>::type p3g;
     p3g.init(lq, lrow);
     for (int e = tid; e < P * n; e += BT) { const int i = e / n, r = e % n; L.qdf[e] = (r % P == i) ? G.Qd(pr)[i * C::ni + r / P] : 0.0; }
-    for (int e = tid; e < 16 * 16; e += BT) L.bw.Fx[e] = (AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
+    // (split recursion: rows 0..m-1 of Fx hold [K | kappa] of the step before, rows m.. and columns n+1.. stay zero)
+    for (int e = tid; e < 16 * 16; e += BT) L.bw.Fx[e] = (!SPLITF && AUGS && e == n * 16 + n) ? 1.0 : 0.0;   // row n = e_n: passes s_i through
     for (int e = tid; e < P * n * LDP; e += BT) L.bw.Pm[e] = 0.0;
     for (int e = tid; e < m * VW; e += BT) L.bw.V[e] = 0.0;
-    for (int e = tid; e < n * n; e += BT) {                     // constant part of A' (the coefficient entries follow per step)
+    for (int e = tid; e < (SPLITF ? 0 : n * n); e += BT) {      // constant part of A' (the coefficient entries follow per step)
         const int c = e / n, r = e % n;
         double v = (r == c) ? 1.0 : 0.0;
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) { if (r < m && c == r + m) v = dt; }
@@ -2933,6 +2947,81 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // s_i <- rx_i + A'(P_i f + s_i) runs on the VALU.  Accumulators start at zero; the sparse Q^_i (and rx_i) are added
         // afterwards (Q-add phase).  Player i's chain reads only row block i of Pm, so its result is written back before the
         // next player starts: one accumulator tile live.
+        if constexpr (SPLITF) {
+          if (k < N - 2) {
+            double kt[KBS];
+#pragma unroll
+            for (int kb = 0; kb < KBS; kb++) kt[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];       // [K | kappa] of step k + 1, rows >= m zero
+            // Row placement in the MFMA tile: the product's row at tile position (lane group l, register r4) is whatever row of P_i the
+            // A operand's lane 4 r4 + l feeds, so the rows are PLACED such that A' costs no lane exchange afterwards: A' X adds dt x row
+            // r to row r + m, and the pair (r, r + m) sits in ONE lane group, r = 4 j + l in register 2 j and r + m in register 2 j + 1
+            // (the natural order r = l + 4 r4 has row r - m in lane ^ 32 when m = 2 mod 4: four v_permlane32_swap + selects per tile).
+            // Lane roles: the tile entry (row, column lrow) of P_i A takes dt x column lrow - m of the same row (columns m..n-1); the
+            // operand entry (row, k = 4 kb + lq) of P_i B is dt^2/2 P[row][k] + dt P[row][k + m] (entries with k >= m meet zero rows of
+            // [K | kappa]: whatever finite value the two loads return there is multiplied by zero).
+            constexpr int NR = 2 * ((m + 3) / 4);                           // accumulator registers in use
+            static_assert(NR <= 4, "row pairs of the split recursion");
+            // (rows as affine functions of the lane coordinates, so that every LDS address below is one of four lane-dependent bases plus
+            // an immediate: register r4 of lane group l holds row l + RC(r4); lane groups whose row does not exist -- l >= m - 4 j in the
+            // last pair of registers -- read rows of the next block, harmlessly, and do not write)
+            auto rconst = [](int r4) { return 4 * (r4 >> 1) + ((r4 & 1) ? m : 0); };
+            const int opl = lrow & 3, opr4 = lrow >> 2;
+            const int oprow = (opr4 < NR && 4 * (opr4 >> 1) + opl < m) ? opl + 4 * (opr4 >> 1) + ((opr4 & 1) ? m : 0) : 0;      // the row this lane feeds as A operand
+            const bool shc = lrow >= m && lrow < n;
+            const int lsh = shc ? lrow - m : lrow;
+            const double dtc = shc ? dt : 0.0, hdt2 = 0.5 * dt * dt;
+            const double* const tbase = &L.bw.Pm[lq * LDP + lrow], * const sbase = &L.bw.Pm[lq * LDP + lsh], * const obase = &L.bw.Pm[oprow * LDP + lq];
+            double* const wbase = &L.bw.Pm[lq * LDP + lrow];
+            auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) acc[r4] = r4 < NR ? fma(dtc, sbase[i * n * LDP + rconst(r4) * LDP], tbase[i * n * LDP + rconst(r4) * LDP]) : 0.0;
+#pragma unroll
+                for (int kb = 0; kb < KBS; kb++) pb[kb] = fma(dt, obase[i * n * LDP + 4 * kb + m], hdt2 * obase[i * n * LDP + 4 * kb]);
+            };
+            auto write_back = [&](int i, double4_t acc) {
+#pragma unroll
+                for (int j = 0; 2 * j + 1 < NR; j++) acc[2 * j + 1] = fma(dt, acc[2 * j], acc[2 * j + 1]);      // A': row r + m += dt x row r
+                if (lrow < n + 1) {
+#pragma unroll
+                    for (int r4 = 0; r4 < NR; r4++) {
+                        if (4 * (r4 >> 1) + 4 <= m) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];             // rows of every lane group
+                    }
+                    if constexpr ((m & 3) != 0) {
+                        if (lq < (m & 3)) {
+#pragma unroll
+                            for (int r4 = NR - 2; r4 < NR; r4++) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];  // last pair: lane groups l < m mod 4
+                        }
+                    }
+                }
+            };
+            if constexpr (TEAM) {
+                // team: player i on wavefront i (the same operations on the same numbers as below: bit-identical to one wavefront per game)
+                static_assert(!TEAM || P <= C::NW, "one player per wavefront of the team");
+                if (tw < P) {
+                    double4_t acc; double pb[KBS];
+                    operands(tw, acc, pb);
+#pragma unroll
+                    for (int kb = 0; kb < KBS; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[kb], kt[kb], acc, 0, 0, 0);
+                    sweep_sync<C>();
+                    write_back(tw, acc);
+                }
+            } else {
+                // the players' chains are independent: all operands first, the products interleaved in the matrix pipe, then the write-backs
+                double4_t acc[P];
+                double pb[P][KBS];
+#pragma unroll
+                for (int i = 0; i < P; i++) operands(i, acc[i], pb[i]);
+#pragma unroll
+                for (int kb = 0; kb < KBS; kb++)
+#pragma unroll
+                    for (int i = 0; i < P; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][kb], kt[kb], acc[i], 0, 0, 0);
+                sweep_sync<C>();                                           // every read of [P_i | y_i] is done
+#pragma unroll
+                for (int i = 0; i < P; i++) write_back(i, acc[i]);
+            }
+            bsync();
+          }
+        } else
         if (k < N - 2) {
             if constexpr (!AUGS && !(HELP2 && ALG_HELP2 >= 2)) {            // (team of two: per player, between the barriers below)
                 for (int e = tid; e < P * n; e += BT) {                     // t_i = P_i f + s_i (one (i,r) per thread)
@@ -3110,6 +3199,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             double a = Pr[n];
             rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
             if (!GFUSE && (ty & 15) < n) L.bw.t[yp * n + yr] = a;
+            // split recursion: y_i takes the place of s_i (this lane was its only reader): column n of [P_i A_k | y_i] in the next step
+            if constexpr (SPLITF) { if ((ty & 15) < n) L.bw.Pm[yp * n * LDP + yr * LDP + n] = a; }
             // g_c = ru_c + B[:,c]' y_i for the controls c of this row's player (c % P == i): the rows of y_i that column c of B touches are
             // shifts away inside the row, so lane 16 i + c finishes g_c here -- no second phase, no trip of y through LDS (BT_vec's expression)
             if constexpr (GFUSE) {
@@ -3188,6 +3279,11 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             const int cc = cidx - m;
 #pragma unroll
             for (int c = 0; c < m; c++) col[c] = -col[c];
+            if constexpr (SPLITF) {
+                // split recursion: column cc of [K | kappa] is the B operand of the next step's product as it is
+#pragma unroll
+                for (int c = 0; c < m; c++) { if (!TEAM || (c % C::NW) == tw) L.bw.Fx[c * 16 + cc] = col[c]; }     // (team: every wavefront holds the columns)
+            } else {
             // column cc of [A_k | rd]: contiguous in LDS (T row cc, or the record's rd); A_0 is never used (dx_1 = 0)
             const double* acol = (cc < n) ? &L.bw.T[cc * n] : Rc + R::RD;
             // all LDS reads first, then all writes: the compiler cannot prove that the Fx stores do not alias the T / record
@@ -3203,6 +3299,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 if (RS != 1 && (r % RS) != tw) continue;
                 if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];         // f rides in tile column n
                 else { double* dst = cc < n ? &L.bw.Fx[r * 16 + cc] : &L.bw.fv[r]; *dst = fxv[r]; }   // one store, selected address (no exec-mask flip per row)
+            }
             }
         }
         ALG_PROF(9)

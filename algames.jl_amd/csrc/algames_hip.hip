@@ -10,7 +10,9 @@
 #include <string>
 #include <vector>
 
-// the EXT instantiations are defined in algames_ext_*.hip, the team kernels in algames_mw.hip
+// every kernel instantiation lives in its own translation unit: the base configurations in algames_base.hip (compiled once per
+// entry), the EXT instantiations in algames_ext_*.hip, the team kernels in algames_mw.hip, the dense-direction ones in theirs
+ALG_CFGS_BASE(ALG_DECLARE_KERNELS)
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
 ALG_CFGS_DENSE(ALG_DECLARE_KERNELS)
 ALG_CFGS_MW(ALG_DECLARE_MW)

@@ -116,7 +116,7 @@ def reduce_counters(counts, elapsed, world, device):
     import torch.distributed as dist
     tot = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device)
     tmax = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):       # (a world of one still goes through the communicator when it exists)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return [int(v) for v in tot.tolist()], float(tmax.item())

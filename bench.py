@@ -258,6 +258,9 @@ def main():
                     help="kernel shape of the fused solver: wavefronts per game (0 = the library's automatic choice)")
     ap.add_argument("--refine-steps", type=int, default=-1, help="alg_set_refinement max_steps (default: the library's; 0 = gate and refinement off)")
     ap.add_argument("--refine-tol", type=float, default=-1.0, help="alg_set_refinement tol (default: the library's)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed with the nccl (= RCCL) backend even for one rank, so that communicator creation, the "
+                         "barrier and the two all-reduces of the counter reduction run on the device (tests/test_gpu_bench_ranks.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (the children of a run use this)")
     args = ap.parse_args()
@@ -288,9 +291,14 @@ def main():
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} (node exposes {torch.cuda.device_count()})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # one rank: no process group unless asked for (--force-dist) or launched by torchrun with WORLD_SIZE=1 -- then the same RCCL path
+    # as N > 1 runs with a world of one
+    use_dist = world > 1 or args.force_dist or (world_env is not None and "MASTER_ADDR" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if SHARED_DEVICE:
+        if world_env is None:                                        # --force-dist outside torchrun: a rendezvous of our own
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+        if SHARED_DEVICE and world > 1:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
@@ -317,7 +325,7 @@ def main():
     prob._sync_options()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -415,6 +423,7 @@ def main():
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
                        "parallelism": f"scenario-sharded x{world}" + (" (TEST HOOK: the ranks share device 0, gloo; not a multi-GPU measurement)" if SHARED_DEVICE and world > 1 else ""), "wavefronts_per_game": waves_per_game,
+                       "collectives": (("gloo" if SHARED_DEVICE and world > 1 else "nccl (RCCL)") + f", world {world}: barrier + 2 all_reduce of the counters") if use_dist else "none (one rank, no process group)",
                        "iters_per_game_mean_over_max_rank0": balance,
                        "direction_refinement": {"max_steps": refine_steps, "tol": refine_tol, "mu_tight": refine_mu, "correction_solves_rank0": refinements_rank},
                        "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve)" if args.mpc_steps
@@ -426,7 +435,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alg, family, G, args.mpc_steps, cfg_kw)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

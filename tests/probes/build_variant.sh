@@ -1,15 +1,24 @@
 #!/bin/bash
-# usage: build_variant.sh NAME [extra hipcc flags...]  -> algames.jl_amd/lib/variants/NAME.so (select with ALGAMES_HIP_LIB=...)
-# The tile-path translation units are rebuilt with the extra flags; the dense-direction units are linked from the default build
-# (algames.jl_amd/lib/obj, python -c "import __graft_entry__ as g; g.build()" first).
+# usage: [UNITS="base_2 ext_di ..."] build_variant.sh NAME [extra hipcc flags...]  -> algames.jl_amd/lib/variants/NAME.so (select with ALGAMES_HIP_LIB=...)
+# The listed translation units are rebuilt with the extra flags (default: every tile-path unit -- the nine base configurations, the EXT
+# families and the team kernels); everything else (host code, dense-direction units) is linked from the default build
+# (algames.jl_amd/lib/obj: python -c "import __graft_entry__ as g; g.build()" first).  UNITS="base_2" rebuilds the C2 kernels only (~25 s).
 set -e
 NAME=$1; shift
 R=$(cd "$(dirname "$0")/../.." && pwd); C=$R/algames.jl_amd/csrc; O=$R/algames.jl_amd/lib/variants/obj_$NAME; D=$R/algames.jl_amd/lib/obj
 mkdir -p $O
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-invalid-offsetof -mllvm -disable-machine-licm $*"
-for f in algames_hip algames_ext_di algames_ext_uni algames_ext_bic algames_ext_di3 algames_mw; do
-  /opt/rocm/bin/hipcc $FL -c $C/$f.hip -o $O/$f.o &
+UNITS=${UNITS:-"base_0 base_1 base_2 base_3 base_4 base_5 base_6 base_7 base_8 ext_di ext_uni ext_bic ext_di3 mw"}
+J=0
+for u in $UNITS; do
+  case $u in
+    base_*) /opt/rocm/bin/hipcc $FL -DALG_BASE_SEL=${u#base_} -c $C/algames_base.hip -o $O/algames_$u.hip.o & ;;
+    *)      /opt/rocm/bin/hipcc $FL -c $C/algames_$u.hip -o $O/algames_$u.hip.o & ;;
+  esac
+  J=$((J+1)); if [ $J -ge 8 ]; then wait -n; J=$((J-1)); fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/algames.jl_amd/lib/variants/$NAME.so $O/*.o $D/algames_quad.hip.o $D/algames_quad_ext.hip.o $D/algames_di3.hip.o $D/algames_mw_dense.hip.o $D/algames_p5.hip.o $D/algames_p6.hip.o
+OBJS=""
+for f in $D/*.hip.o; do b=$(basename $f); if [ -f $O/$b ]; then OBJS="$OBJS $O/$b"; else OBJS="$OBJS $f"; fi; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/algames.jl_amd/lib/variants/$NAME.so $OBJS
 echo built $R/algames.jl_amd/lib/variants/$NAME.so

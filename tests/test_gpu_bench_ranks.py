@@ -49,3 +49,26 @@ def test_more_ranks_than_devices_is_refused_without_the_hook():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_barrier_and_reduction_run_on_the_device_with_a_world_of_one():
+    """the nccl (= RCCL) backend has to create a communicator and carry the barrier and the two all-reduces of
+    `sharding.reduce_counters` on the MI355X at least once; a one-GPU box can do that with a world of one.  Both launch forms:
+    `--force-dist` (bench.py makes its own rendezvous) and torchrun with `--nproc-per-node 1` (WORLD_SIZE=1 in the environment)."""
+    plain = _bench("--games-per-gpu", "512")
+    forced = _bench("--games-per-gpu", "512", "--force-dist")
+    assert plain["config"]["collectives"].startswith("none") and forced["config"]["collectives"].startswith("nccl (RCCL), world 1")
+    env = dict(os.environ); env.pop("ALGAMES_BENCH_SHARED_DEVICE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--games-per-gpu", "512"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    torchrun = json.loads(lines[0])
+    assert torchrun["config"]["collectives"].startswith("nccl (RCCL), world 1")
+    for d in (forced, torchrun):
+        assert d["n_gpus"] == 1 and d["games_converged"] == plain["games_converged"] == 512 and d["games_failed"] == 0
+        assert d["config"]["newton_iters_per_solve_total"] == plain["config"]["newton_iters_per_solve_total"]
+        assert set(d) == set(plain) and set(d["config"]) == set(plain["config"]) and d["metric"] == plain["metric"] and d["unit"] == plain["unit"]

@@ -3745,7 +3745,8 @@ __device__ double con_mu_max(CPR pr0, const Game& G0) {
 }
 // Newton direction with the refinement gate: what the solver calls.  Every thread of the game's workgroup calls it (team kernels
 // included) and leaves with the same status / sum |d_primal|.
-template <class C, bool IBR = false>
+// COUNT = false (the step-wise inspection entry alg_newton_direction): the game's `refinements` statistic belongs to the solver paths.
+template <class C, bool IBR = false, bool COUNT = true>
 __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>& L, double reg, int ip, double* primal_l1) {
     // Nothing but the pass counter is live across the sweeps: sum |d_primal| and the two norms of the gate wait in the game's control
     // slots (HBM), the output view is rebuilt from the pass counter.
@@ -3791,7 +3792,9 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         }
         double* tc = G0.fresh().tc(pr);
         if (pass == 0 && phase_lane() == 0) tc[TC_PL1] = pl1s;       // read back only after a correction (below)
-        if (st != ALG_STATUS_OK) { if (pass == 0) { if (primal_l1) *primal_l1 = pl1s; return st; } break; }
+        // a correction solve that fails (singular pivot block or non-finite output on the right-hand side (0, rho, 0)) is dropped: nothing of
+        // it has been added yet, the direction of the passes before is valid and is what the solver continues with
+        if (st != ALG_STATUS_OK) { if (pass == 0) { if (primal_l1) *primal_l1 = pl1s; return st; } st = ALG_STATUS_OK; break; }
         game_sync();                                   // the direction is in global memory
         const DirGate gt = dir_urow_residual<C, IBR, false>(pr, Gd, ip);
         // backward error of the whole direction: the row-wise omega of the first solve; after a correction, the residual of the correction
@@ -3834,7 +3837,7 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         }
         // rhs of the correction system from the buffer that holds the latest solve (d itself, or the previous correction)
         dir_urow_residual<C, IBR, true>(pr, Gd, ip);
-        if (phase_lane() == 0) G0.fresh().st(pr)->refinements += 1;
+        if (COUNT && phase_lane() == 0) G0.fresh().st(pr)->refinements += 1;
         game_sync();
     }
     game_sync();
@@ -4243,10 +4246,13 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
         // prob.stats.*_vio[end]: the record made at the top of the last inner iteration (lane 0 wrote it; same wave)
         alg_game_stats* const stk = G.fresh().st(phase_params(pr));
         const alg_record& last = stk->last;
-        const bool conv = last.dyn_vio < o.eps_dyn && last.con_vio < o.eps_con && last.sta_vio < o.eps_sta && last.opt_vio < o.eps_opt;
+        // (256-register kernels: the tolerances are re-read from the kernel-argument segment here -- as invariants of the outer loop they
+        // were spilled across every phase of the solve; the 128-register double-integrator kernels have the scalar registers to keep them)
+        const auto& oc = (C::WPE == 4) ? o : phase_params(pr).opt;
+        const bool conv = last.dyn_vio < oc.eps_dyn && last.con_vio < oc.eps_con && last.sta_vio < oc.eps_sta && last.opt_vio < oc.eps_opt;
         const int convu = __builtin_amdgcn_readfirstlane((int)conv);
         if (convu && phase_lane() == 0) stk->converged = 1;          // written where it is decided (one loop-carried scalar less)
-        if (k == o.outer_iter || convu) break;                             // :49-55
+        if (k == oc.outer_iter || convu) break;                            // :49-55
         dual_penalty_update<C>(pr, G);                                     // :57-61
         game_sync();
     }

@@ -65,10 +65,18 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.ca_dim = 2;
     p.hist_max = HIST_MAX;
     p.refine_max = 2; p.refine_tol = 0x1p-34; p.refine_mu = 1.6e5;
-    // A/B runs of whole test suites (alg_set_refinement otherwise)
-    if (const char* e = getenv("ALGAMES_REFINE_STEPS")) p.refine_max = std::max(0, std::min(8, atoi(e)));
-    if (const char* e = getenv("ALGAMES_REFINE_TOL")) p.refine_tol = std::max(0.0, atof(e));
-    if (const char* e = getenv("ALGAMES_REFINE_MU")) p.refine_mu = std::max(0.0, atof(e));                             // alg_set_refinement
+    // A/B runs of whole test suites (alg_set_refinement otherwise).  An override changes production numerics, so it is announced once.
+    {
+        bool over = false;
+        if (const char* e = getenv("ALGAMES_REFINE_STEPS")) { p.refine_max = std::max(0, std::min(8, atoi(e))); over = true; }
+        if (const char* e = getenv("ALGAMES_REFINE_TOL")) { p.refine_tol = std::max(0.0, atof(e)); over = true; }
+        if (const char* e = getenv("ALGAMES_REFINE_MU")) { p.refine_mu = std::max(0.0, atof(e)); over = true; }                 // alg_set_refinement
+        static bool warned = false;
+        if (over && !warned) {
+            warned = true;
+            fprintf(stderr, "libalgames_hip: ALGAMES_REFINE_* environment overrides in effect (max_steps %d, tol %g, mu_tight %g)\n", p.refine_max, p.refine_tol, p.refine_mu);
+        }
+    }
     p.kscratch_len = (p.N - 1) * p.m * std::max(p.n + 1, 16);            // gains m x (n + 1) per step; the quad-team kernels store rows of 16
     {   // Rec<C>::LEN of the EXT instantiation (the base one is p n shorter; the buffer is sized for either)
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : (p.model == ALG_MODEL_QUADROTOR) ? 204 * p.p : 0;

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(WAVE, C::WPE) k_direction(Params pr_arg, doubl
     ResOut ro;
     assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, reg, ro);
     __syncthreads();
-    const int st = refined_direction<C>(pr, G, L, reg, -1, nullptr);
+    const int st = refined_direction<C, false, false>(pr, G, L, reg, -1, nullptr);
     if (status && threadIdx.x == 0) status[g] = st;
 }
 
@@ -174,19 +174,28 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr_arg) {
 // totals) than a single solve; at 128 VGPRs the DoubleIntegrator instantiations spilled SGPRs so heavily that the 2-player
 // one faulted on a null base pointer (tests/test_gpu_parity_ext.py::test_no_kernel_writes_outside_its_buffers runs this
 // kernel for every instantiation).
+// (the loop's own arguments are re-read from the kernel-argument segment where they are used, like `Params`: as by-value arguments they
+// were live -- in SGPRs, i.e. spilled -- across every phase of every solve)
+struct MpcLoopArgs { Params pr; int steps; uint64_t game_id0; double* states; };
 template <class C>
-__global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(Params pr_arg, int steps, uint64_t game_id0, double* states) {
+__global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(Params pr_arg, int steps_arg, uint64_t game_id0_arg, double* states_arg) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
-    const int g = blockIdx.x, lane = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ALG_AS4 MpcLoopArgs& ka = *(const ALG_AS4 MpcLoopArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const MpcLoopArgs& ka = *(const MpcLoopArgs*)nullptr;      // host pass: never executed
+#endif
+    const int g = blockIdx.x;
     Game G = game_view(pr, g);
-    if (states && lane < C::n) states[(size_t)g * C::n + lane] = G.x0(pr)[lane];
-    for (int t = 0; t < steps; t++) {
-        newton_solve<C>(pr, G, L, 1, game_id0 + (uint64_t)t * 1000003ull + (uint64_t)g, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
+    if (ka.states && (int)threadIdx.x < C::n) ka.states[(size_t)g * C::n + threadIdx.x] = G.x0(pr)[threadIdx.x];
+    for (int t = 0; t < ka.steps; t++) {
+        newton_solve<C>(pr, G, L, 1, ka.game_id0 + (uint64_t)t * 1000003ull + (uint64_t)g, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
         __syncthreads();
         mpc_advance<C>(pr, G);
         __syncthreads();
-        if (states && lane < C::n) states[((size_t)(t + 1) * pr.B + g) * C::n + lane] = G.z(0)[lane];
+        double* const states = ka.states;
+        if (states && (int)threadIdx.x < C::n) states[((size_t)(t + 1) * pr.B + g) * C::n + threadIdx.x] = G.z(0)[threadIdx.x];
         __syncthreads();
     }
 }

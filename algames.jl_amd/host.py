@@ -692,18 +692,23 @@ def init_traj_host(prob):
     steps k = 1..N-1 (those with k + s > N-1).  The default `"rand"` never comes here: the device generates it (alg_init_traj).
     The result is stored as the handle's pdtraj; the solve then runs with init = 0, which still rolls the states out
     (solver_methods.jl:17), so only x_1 = x0, the controls and the duals of this guess matter.  The layout keeps no control at knot
-    N (the reference's `pr[N]` carries one that nothing reads): when the shift copies knot N, its control is a fresh draw."""
+    N (the reference's `pr[N]` carries one that nothing reads): when the shift copies knot N, its control is set to zero -- no draw
+    is consumed for it, so a stateful generator stays aligned with the reference's call sequence.
+    Every game is one `newton_solve!` of the reference, which calls `Random.seed!(opts.seed)` first (solver_methods.jl:9): NumPy's
+    global generator is seeded the same way before each game's draws, so `f_init = np.random.randn` gives every game the stream the
+    Julia shim gives it (generators that carry their own state, e.g. a `default_rng(...)` method, are not touched by this)."""
     b, o = prob.batch, prob.opts
     f, a, s = o.f_init, float(o.amplitude_init), int(min(o.shift, 2 ** 30))
     X, U, L = b.split_traj(b.get_traj(0))
     B, N, n, m, p = X.shape[0], b.N, b.n, b.m, b.p
     draw = lambda size: a * np.asarray(f(size), dtype=np.float64).reshape(size)
     for g in range(B):
+        np.random.seed(int(o.seed) % (2 ** 32))                     # Random.seed!(opts.seed), solver_methods.jl:9
         for k in range(1, N + 1):                                   # 1-based like the reference
             if k + s <= N:
                 X[g, k - 1] = X[g, k + s - 1]
                 if k <= N - 1:
-                    U[g, k - 1] = U[g, k + s - 1] if k + s <= N - 1 else draw(n + m)[n:]
+                    U[g, k - 1] = U[g, k + s - 1] if k + s <= N - 1 else 0.0
             else:
                 z = draw(n + m)
                 X[g, k - 1] = z[:n]

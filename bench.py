@@ -59,7 +59,7 @@ def survey_balg(N, n, m, p):
     return 8 * (2 * (S + n) + 2 * (N - 1) * (b * b + b * p * n))
 
 
-def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0, gate=True):
+def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0, gate=True, waves_per_game=1):
     """Algorithmic HBM bytes per game-Newton-iteration of THIS implementation (DESIGN.md "Roofline accounting"): what the passes of
     one iteration have to move when every array crosses the memory system once per pass that needs it -- the floor of this
     algorithm; re-reads, partial lines and the per-outer-iteration record pass are not included.
@@ -80,13 +80,19 @@ def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0, gate=True):
     len_rec = len_sweep + 2 * p * p                                      # + pair-gradient table
     con = K * npair + (2 * m * K if family in ("C3", "C5", "Q") else 0)  # constraint rows touched (lam, mu read)
     gains = K * m * (n + 1)
-    fused = family == "C2"                                               # double integrator, one wavefront per game
+    # the fused trial pass (AsmLds::FUSED): double integrator and unicycle, base constraint set, ONE wavefront per game (C2 / C4, and the
+    # unicycle shapes when a batch is large enough for one-wavefront kernels); teams keep the two passes.  (The pair-gradient tables the
+    # fused pass still writes in its phase A and re-reads per chunk -- 2 K p^2 doubles -- are an artefact of the implementation, not of the
+    # algorithm: they are left out of this floor and show up in traffic_over_model.)
+    fused = family in ("C2", "C3", "C5") and waves_per_game == 1
     if fused:
         trial = ls_trials_per_iter * (it + S + S + 2 * con + K * len_sweep)
+    else:
+        trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec))   # axpy + assemble pass
+    if family == "C2":                                                   # double integrator: the forward sweep parks w = rx + Q dx (FWDW)
         forward = gains + K * (len_costate + n) + K * (n + m) + K * p * n
         costate = 2 * K * p * n
     else:
-        trial = ls_trials_per_iter * ((it + S + it) + (2 * it + 2 * con + K * len_rec))   # axpy + assemble pass
         forward = gains + K * (nc + n) + K * (n + m)
         costate = K * len_costate + K * n + K * p * n
     backward = K * len_sweep + gains
@@ -244,8 +250,9 @@ def inrun_pmc(argv_tail, kernel, iters_per_launch, own_bytes, timeout_s=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=8,
+                    help="untimed launches first (default 8: the shader clock needs ~5 launches of this kernel to settle, profiles/r05_clock_probe.txt)")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--games-per-gpu", type=int, default=0, help="scenarios per GPU (default: the config's BASELINE batch)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -372,7 +379,7 @@ def main():
         value = iters_all * K / elapsed
         kern_s = float(np.mean(kernel_ms)) * 1e-3
         p, n, m, N = b.p, b.n, b.m, b.N
-        own = structured_bytes(family, N, n, m, p, gate=refine_steps > 0)
+        own = structured_bytes(family, N, n, m, p, gate=refine_steps > 0, waves_per_game=waves_per_game)
         kernel = "k_mpc_loop" if args.mpc_steps else "k_newton_solve"
         achieved = own * iters_rank / kern_s                         # B/s of this rank's launch
         roof = {

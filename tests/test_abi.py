@@ -86,23 +86,22 @@ def test_solver_kernels_of_the_shipped_library_do_not_spill(alg):
     assert head["vgpr_spill"] == 0 and head["sgpr_spill"] == 0 and head["scratch"] == 0 and head["vgpr"] <= 128, head
     for k, v in solve.items():
         assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
-    # SGPR spills of the other BASELINE kernels (C3's team-of-two solver had 21, C5's team-of-four loop 72; the DPP
-    # elimination freed the scalar registers the v_readlane broadcasts took; round 4: the refinement gate around the direction adds
-    # control flow whose scalars are parked in a VGPR's lanes around the solver's outer loops -- 5 of the C5 loop kernel's 217
-    # v_readlane / v_writelane sit near its backward sweep, the rest outside the sweeps): bounded so that they cannot creep further
-    assert res["k_newton_solve<Cfg<1, 4, 2, 0, 2> >"]["sgpr_spill"] <= 32, res["k_newton_solve<Cfg<1, 4, 2, 0, 2> >"]      # C3, 1024 games
+    # SGPR spills of the other BASELINE kernels (C3's team-of-two solver had 21, C5's team-of-four loop 72; round 4's
+    # refinement gate took them to 16 / 66; round 5: the receding-horizon loop re-reads its own arguments and the solver its tolerances
+    # from the kernel-argument segment instead of carrying them across every phase -- 9 / 34 / 28 in the shipped binary, all outside the
+    # sweeps): bounds within 1.5 x of what the binary shows, so that they cannot creep
+    assert res["k_newton_solve<Cfg<1, 4, 2, 0, 2> >"]["sgpr_spill"] <= 12, res["k_newton_solve<Cfg<1, 4, 2, 0, 2> >"]      # C3, 1024 games
     assert res["k_newton_solve<Cfg<1, 4, 2, 0, 1> >"]["sgpr_spill"] <= 24
-    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]["sgpr_spill"] <= 72, res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]              # C5 loop, 64 seeds
-    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 1> >"]["sgpr_spill"] <= 72
+    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]["sgpr_spill"] <= 48, res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]              # C5 loop, 64 seeds
+    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 1> >"]["sgpr_spill"] <= 42
     # no solver kernel keeps a phase function as a real call (its per-game view would live in scratch): a kernel whose metadata
     # shows no private segment cannot contain one; the dense-direction units get there with a raised inliner limit (__graft_entry__)
-    # 4-player bicycle loop kernel, at the 256-VGPR ceiling: 8 spilled VGPRs in round 3; with the refinement gate inlined the allocator
-    # parks 139 loop-invariant VGPRs of the receding-horizon loop (state log pointer, per-player start states) in scratch at the kernel's
-    # entry and fetches them back in mpc_advance -- all 78 scratch instructions sit before line 1000 or after line 26000 of the 27 K-line
-    # listing, none near the sweeps (tests/probes/isa_stats.py k_mpc_loop ALG_MODEL_BICYCLE 4 2 1)
+    # 4-player bicycle loop kernel, at the 256-VGPR ceiling: the allocator parks a few loop-invariant VGPRs of the receding-horizon loop
+    # in scratch at the kernel's entry and fetches them back in mpc_advance, none near the sweeps (round 3: 8, round 4: 12 spilled
+    # VGPRs / 52 B; round 5: 6 / 28 B)
     allowed = {"k_mpc_loop<Cfg<2, 4, 2, 1, 1> >"}
     for k, v in res.items():
         if k.startswith(("k_mpc_loop<", "k_ibr<", "k_direction<", "k_newton_step<")) and k not in allowed:
             assert v["vgpr_spill"] == 0, (k, v)
     for k in allowed:                                               # ... and stays there (the DPP elimination once took it to 900 unnoticed)
-        assert res[k]["vgpr_spill"] <= 160 and res[k]["scratch"] <= 512, (k, res[k])
+        assert res[k]["vgpr_spill"] <= 12 and res[k]["scratch"] <= 64, (k, res[k])

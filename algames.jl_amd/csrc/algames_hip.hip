@@ -65,6 +65,11 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.ca_dim = 2;
     p.hist_max = HIST_MAX;
     p.refine_max = 2; p.refine_tol = 0x1p-34; p.refine_mu = 1.6e5;
+    // dense-direction configurations (Cfg::DENSE: quadrotor, n > 16, n % 4 != 0): ONE correction by default.  On the quadrotor seeds of
+    // tests/test_gpu_fuzz.py the first correction takes the backward error in the arbiter's Jacobian from <= 6.5e-14 to <= 3.3e-17 and a
+    // second one changes no digit of it (48 of 48 directions, profiles/r05_quad_gate_probe.txt): the gate's estimate of the remaining
+    // row-wise error is an upper bound that the rounding floor of the rows' own evaluation keeps above the tolerance.
+    if (p.model == ALG_MODEL_QUADROTOR || p.n > 16 || (p.n % 4) != 0) p.refine_max = 1;
     // A/B runs of whole test suites (alg_set_refinement otherwise).  An override changes production numerics, so it is announced once.
     {
         bool over = false;

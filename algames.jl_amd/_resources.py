@@ -1,6 +1,7 @@
 """Register / spill report of the kernels inside the built libalgames_hip.so (build check, no GPU needed).
 
-The library is a HIP fat binary: every translation unit contributes one clang offload bundle to the `.hip_fatbin` section.
+The library is a HIP fat binary: every translation unit contributes one clang offload bundle to the `.hip_fatbin` section
+(compressed with --offload-compress since round 5: unpacked here with clang-offload-bundler).
 This module extracts the gfx950 code objects and reads the AMDGPU kernel metadata (`llvm-readelf --notes`): VGPR / SGPR counts,
 scratch bytes and the spill counts of every kernel.  tests/test_abi.py uses it to keep the solver kernels spill-free."""
 import os
@@ -13,9 +14,39 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+CMAGIC = b"CCOB"                # compressed offload bundle (--offload-compress): magic, u16 version, u16 method, then the sizes
+
+
+def _compressed_bundles(blob, arch):
+    """Device images of the compressed bundles in `blob` (one per translation unit), unpacked by clang-offload-bundler."""
+    pos = 0
+    while True:
+        pos = blob.find(CMAGIC, pos)
+        if pos < 0:
+            return
+        version, method = struct.unpack_from("<HH", blob, pos + 4)
+        if version < 2 or version > 3 or method > 1:     # not a header (the four bytes can occur in data)
+            pos += 4
+            continue
+        total = struct.unpack_from("<Q" if version == 3 else "<I", blob, pos + 8)[0]
+        if total <= 24 or pos + total > len(blob):
+            pos += 4
+            continue
+        with tempfile.TemporaryDirectory() as d:
+            src, dst = os.path.join(d, "b.ccob"), os.path.join(d, "b.co")
+            open(src, "wb").write(blob[pos:pos + total])
+            r = subprocess.run([BUNDLER, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--" + arch, "--input=" + src, "--output=" + dst],
+                               capture_output=True, text=True)
+            if r.returncode == 0 and os.path.exists(dst) and os.path.getsize(dst) > 0:
+                yield open(dst, "rb").read()
+        pos += total
+
+
 def code_objects(lib_path, arch="gfx950"):
-    """Yields the device ELF images (bytes) for `arch` contained in the fat binary."""
+    """Yields the device ELF images (bytes) for `arch` contained in the fat binary (plain or compressed bundles)."""
     blob = open(lib_path, "rb").read()
+    yield from _compressed_bundles(blob, arch)
     pos = 0
     while True:
         pos = blob.find(MAGIC, pos)

@@ -1,0 +1,651 @@
+// algames_assemble.hpp -- assemble pass (residual! / record! / line-search trials), fused trial pass, update_traj!
+// (part of the device code of libalgames_hip.so; included by algames_device.hpp, which holds the shared declarations and the file-level
+// description of the execution model)
+#pragma once
+#include "algames_device.hpp"
+
+namespace alg {
+
+// ================================================================================================
+// Assemble pass: residual! + regularize_residual! + the scalars of record! (+ step records)
+//   global_quantities.jl:9-86, statistics.jl:44-57, violations.jl.
+//   phase A (parallel, work item = (knot, player)): RK2 Jacobian coefficients, collision cost / collision avoidance
+//           (/ wall / circle) terms of the ordered pairs (i, j) -> record [coef | Hh | Hd | gvt], constraint values
+//   phase B (parallel, work item = one residual row of one step; three flat row loops):
+//           rows opt_i,x_{k+1} | opt_i,u_{i,k} | dyn_k  -> record [rx | ru | rd], R^ (, RQ), statistics
+//   MODE 0: statistics only (line-search trials)   MODE 1: + step records (Newton direction input)
+//   MODE 2: + residual vector in the reference's vertical order and the constraint values (alg_residual)
+//   MODE 3: line-search trial that doubles as the next record!: statistics and step records of the UNREGULARISED
+//           residual (what record! sees if the trial is accepted) plus the regularised norm l1reg for the acceptance test
+// With zref != nullptr the proximal term reg (x - xref) is added to the rows; out.l1 is the norm of those rows
+// (MODE 0/2) or of the unregularised rows (MODE 3, which also returns out.l1reg).
+// ================================================================================================
+struct ResOut { double l1, opt, dyn, con, sta; int nonfinite; double l1reg; double l1full; };
+// Combines the per-wavefront statistics of a team (fixed order: deterministic); every thread leaves with the same values.
+template <class C> __device__ __forceinline__ void team_combine(ResOut& o) {
+    if constexpr (C::NW > 1) {
+        __shared__ double red[C::NW][8];
+        const int w = game_tid() >> 6, l = game_tid() & 63;
+        if (l == 0) { red[w][0] = o.l1; red[w][1] = o.opt; red[w][2] = o.dyn; red[w][3] = o.con; red[w][4] = o.sta; red[w][5] = (double)o.nonfinite; red[w][6] = o.l1reg; red[w][7] = o.l1full; }
+        game_sync();
+        ResOut r = {0.0, 0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < C::NW; q++) {
+            r.l1 += red[q][0]; r.opt = fmax(r.opt, red[q][1]); r.dyn = fmax(r.dyn, red[q][2]); r.con = fmax(r.con, red[q][3]); r.sta = fmax(r.sta, red[q][4]);
+            r.nonfinite |= (int)red[q][5]; r.l1reg += red[q][6]; r.l1full += red[q][7];
+        }
+        game_sync();                         // red[] may be rewritten by the next pass
+        o = r;
+    }
+}
+
+struct AsmAcc { double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0; };
+// Phase A of the assemble pass (see assemble_pass): RK2 Jacobian coefficients and the pair / wall / circle terms of every (knot, player).
+// dzp != nullptr: the positions are those of the trial iterate z + alpha dz, formed on the fly (fused trial pass of the double integrator).
+template <class C, int MODE, bool IBR>
+__device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C>& L, const double* __restrict__ z, const double* __restrict__ dzp, double alpha,
+                                                 int N, int lane, double dt, int ip, AsmAcc& acc) {
+    constexpr int n = C::n, P = C::P;
+    using R = Rec<C>;
+    constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);
+    if (C::NC > 0 || C::POS) {
+        const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
+        constexpr int HEAD = AsmLds<C>::HEAD, SL = AsmLds<C>::SL, SPP = AsmLds<C>::SPP;
+        for (int kA = 0; kA < N - 1; kA += SPP) {
+          const int ks = lane / P, i = lane % P, k = kA + ks, kn = k + 1;
+          constexpr bool STAGED = AsmLds<C>::STAGED;
+          if (lane < SPP * P && k < N - 1) {
+            // staged: record head (offsets as in the record) + table at HEAD of this step's LDS slot; else the record itself
+            double* __restrict__ rec = STAGED ? L.stage + ks * SL : G.rec(pr) + (size_t)k * R::LEN;
+            double* __restrict__ tab = STAGED ? L.stage + ks * SL + HEAD : G.rec(pr) + R::gvt(N, k);       // pair-gradient table of the step
+            if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                const double* sk = zstate<C>(z, k);
+                double cf[10];
+                bike_coefs<C>(pr, sk[2 * P + i], sk[3 * P + i], z[n + hu<C>(k, i)], z[n + hu<C>(k, i) + 1], dt, cf);
+#pragma unroll
+                for (int t = 0; t < 10; t++) rec[R::COEF + t * P + i] = cf[t];
+            } else if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
+                // Jacobian coefficients of knot k (A_k, B_k): see the model section (of the trial iterate when dzp is given)
+                const double* sk = zstate<C>(z, k); const double* dk = (dzp && k > 0) ? zstate<C>(dzp, k) : nullptr;      // (x_1 does not move)
+                const int uo_ = n + hu<C>(k, i);
+                auto sv = [&](int idx) { const double q = sk[idx]; return dk ? q + alpha * dk[idx] : q; };
+                auto uv = [&](int j) { const double q = z[uo_ + j]; return dzp ? q + alpha * dzp[uo_ + j] : q; };
+                const double th = sv(2 * P + i), v = sv(3 * P + i);
+                const double om = uv(0), ac = uv(1);
+                const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
+                double sn, cs; sincos(thm, &sn, &cs);
+                rec[R::COEF + 0 * P + i] = -dt * vm * sn; rec[R::COEF + 1 * P + i] = dt * cs;
+                rec[R::COEF + 2 * P + i] = dt * vm * cs;  rec[R::COEF + 3 * P + i] = dt * sn;
+            }
+            if constexpr (C::POS) {
+                constexpr int PD = C::PD, NS = C::NS;
+                const double w = (kn < N - 1) ? dt : 1.0;
+                const double* x1 = z + n + hx<C>(k); const double* d1 = dzp ? dzp + n + hx<C>(k) : nullptr;
+                auto xp = [&](int idx) { const double v = x1[idx]; return d1 ? v + alpha * d1[idx] : v; };    // position of the (trial) iterate
+                double xi[PD], ga[PD], dd[NS];
+#pragma unroll
+                for (int a = 0; a < PD; a++) { xi[a] = xp(a * P + i); ga[a] = 0.0; }
+#pragma unroll
+                for (int t = 0; t < NS; t++) dd[t] = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < P - 1; jj++) {
+                    const int j = jj < i ? jj : jj + 1;
+                    double gv[PD], H[NS];
+#pragma unroll
+                    for (int a = 0; a < PD; a++) gv[a] = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NS; t++) H[t] = 0.0;
+                    if (pairs_on) {
+                        double dl[PD];
+#pragma unroll
+                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - xp(a * P + j);
+                        const double dl0 = dl[0], dl1 = dl[1];
+                        const double s2 = dl0 * dl0 + dl1 * dl1;
+                        if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173 (planar: px[i])
+                            const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+                            if (fmax(0.0, rad - nrm) > 0.0) {
+                                const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
+                                const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
+                                const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
+                                gv[0] += w * (-g0); gv[1] += w * (-g1);
+                                const double n3 = nrm * nrm * nrm;
+                                H[0] += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
+                                H[1] += w * (mu * (rad * (dl0 * dl1) / n3));
+                                H[2] += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
+                            }
+                        }
+                        if (pr.has_colavoid) {                                   // CollisionConstraint + AL expansion
+                            const double Rr = pr.ca_pair_r[i * MAXP + j];
+                            const double on = (double)((pr.ca_mask[i] >> j) & 1u);                    // 0: this ordered pair carries no constraint
+                            double s2c = s2;
+                            if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c += dl[2] * dl[2]; }   // spherical: pz[i][1:3]
+                            const double c = on * (Rr * Rr - s2c);
+                            const int ci = con_col<C>(N, pairq<C>(i, j), kn);
+                            const double lm = G.lam(pr)[ci], am = on * al_active_mu(c, lm, G.mu(pr)[ci]);
+                            const double wl = fma(am, c, on * lm);            // (the contraction the all-pairs form always had: lm + am c)
+#pragma unroll
+                            for (int a = 0; a < PD; a++) {
+                                gv[a] += -2.0 * dl[a] * wl;
+#pragma unroll
+                                for (int a2 = 0; a2 <= a; a2++) H[C::sym(a, a2)] += am * 4.0 * dl[a2] * dl[a];
+                            }
+                            if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < PD; a++) { ga[a] += gv[a]; tab[(i * P + j) * PD + a] = -gv[a]; }   // row opt_i at px(j,.)
+#pragma unroll
+                    for (int t = 0; t < NS; t++) dd[t] += H[t];
+                    if (RECS) {
+                        double* hh = rec + R::HH + NS * pairq<C>(i, j);
+#pragma unroll
+                        for (int t = 0; t < NS; t++) hh[t] = H[t];
+                    }
+                }
+                if constexpr (C::EXT) {
+                    // wall / circle constraints of player i on its own position at knot k+1: AL gradient C'(lambda + a mu c)
+                    // and Gauss-Newton Hessian C' a mu C (constraint_derivatives.jl:10-19,47-58) join the (i,i) position block
+                    auto al_row = [&](int ci, double c, const double (&g)[PD]) {
+                        const double lm = G.lam(pr)[ci], am = al_active_mu(c, lm, G.mu(pr)[ci]);
+                        const double wl = lm + am * c;
+#pragma unroll
+                        for (int a = 0; a < PD; a++) {
+                            ga[a] += g[a] * wl;
+#pragma unroll
+                            for (int a2 = 0; a2 <= a; a2++) dd[C::sym(a, a2)] += am * g[a2] * g[a];
+                        }
+                        if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
+                    };
+                    const double* Wc = ext_walls(pr, pr.extc); const double* Cc = ext_circs(pr, pr.extc);
+                    const unsigned wmask = pr.wall_mask[i], cmask = pr.circ_mask[i];
+                    for (int wq = 0; wq < pr.nwall; wq++) {
+                        double g[PD] = {}; const double on = (double)((wmask >> wq) & 1u);
+                        const double c = on * wall_val(Wc, wq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
+                        al_row(ext_wall_row(pr, i, k, wq), c, g);
+                    }
+                    for (int cq = 0; cq < pr.ncirc; cq++) {
+                        double g[PD] = {}; const double on = (double)((cmask >> cq) & 1u);
+                        const double c = on * circ_val(Cc, cq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
+                        al_row(ext_circ_row(pr, i, k, cq), c, g);
+                    }
+                    if constexpr (PD == 3) {
+                        const double* W3 = ext_walls3(pr, pr.extc); const double* Yc = ext_cyls(pr, pr.extc);
+                        const unsigned w3mask = pr.wall3_mask[i], cymask = pr.cyl_mask[i];
+                        for (int wq = 0; wq < pr.nwall3; wq++) {
+                            double g[3]; const double on = (double)((w3mask >> wq) & 1u);
+                            const double c = on * wall3_val(W3, wq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
+                            al_row(ext_wall3_row(pr, i, k, wq), c, g);
+                        }
+                        for (int cq = 0; cq < pr.ncyl; cq++) {
+                            double g[3]; const double on = (double)((cymask >> cq) & 1u);
+                            const double c = on * cyl_val(Yc, cq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
+                            al_row(ext_cyl_row(pr, i, k, cq), c, g);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < PD; a++) tab[(i * P + i) * PD + a] = ga[a];           // row opt_i at px(i,.)
+                if (RECS) {
+#pragma unroll
+                    for (int t = 0; t < NS; t++) rec[R::HD + NS * i + t] = dd[t];
+                }
+            }
+          }
+          if constexpr (STAGED) {
+              game_sync();
+              // write-out: contiguous [coef | Hh | Hd] and table segments of the staged steps
+              const int nst = (N - 1 - kA) < SPP ? (N - 1 - kA) : SPP;
+              for (int t = lane; t < nst * SL; t += C::NT) {
+                  const int ks2 = t / SL, o = t % SL;
+                  const size_t base = (size_t)(kA + ks2) * R::LEN;
+                  if (o >= HEAD) G.rec(pr)[R::gvt(N, kA + ks2) + (o - HEAD)] = L.stage[t];
+                  else if (RECS || o < C::NC) G.rec(pr)[base + o] = L.stage[t];
+              }
+              game_sync();
+          }
+        }
+        if constexpr (!AsmLds<C>::STAGED) game_sync();
+    }
+}
+
+// IBR = true: best-response statistics of player ip (solver_methods.jl:230-289): norms over the rows of the vertical mask
+// (player ip's opt rows + all dyn rows, newton_core.jl:205-246), player-specific violations (statistics.jl:59-73), the
+// proximal term only on player ip's rows (global_quantities.jl:262-280); out.l1full is the full ||res||_1 for record!.
+template <class C, int MODE, bool IBR = false>
+__device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, int zrefsel, double reg, double jreg,
+                              ResOut& out, int ip = -1) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    const double* __restrict__ z = G.z(zsel);
+    const double* __restrict__ zref = zrefsel >= 0 ? G.z(zrefsel) : nullptr;
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b;
+    using R = Rec<C>;
+    const int N = phase_int(pr.N), lane = phase_lane();
+    const double dt = phase_f64(pr.dt);
+    AsmAcc acc;
+    double& l1 = acc.l1; double& l1r = acc.l1r; double& l1f = acc.l1f; double& vopt = acc.vopt; double& vdyn = acc.vdyn; double& vcon = acc.vcon; double& vsta = acc.vsta; int& bad = acc.bad;
+    constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);   // write step records
+    LSP_T0 LSP_COUNT(25)
+    // ---------------- phase A ------------------------------------------------------------------------------
+    if constexpr (C::QUAD) {
+        // quadrotor: work item = (knot k, player i, seed direction c of the player's 12 states + 4 rotor commands): column c of
+        // [A_i | B_i] = d RK2 / d (x_i, u_i)[c] by forward-mode differentiation along e_c; the item with c = 0 also leaves the
+        // RK2 value (the dyn rows of phase B read it)
+        const double qmass = phase_f64(pr.qmass);
+        for (int e = lane; e < (N - 1) * P * 16; e += C::NT) {
+            const int c = e & 15, i = (e >> 4) % P, k = (e >> 4) / P;
+            const double* sk = zstate<C>(z, k);
+            Jet xj[12], uj[4], xo[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) xj[j] = Jet{sk[i + j * P], c == j ? 1.0 : 0.0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) uj[j] = Jet{z[n + hu<C>(k, i) + j], c == 12 + j ? 1.0 : 0.0};
+            quad_rk2(xj, uj, qmass, dt, xo);
+            double* __restrict__ rc = G.rec(pr) + (size_t)k * R::LEN + R::COEF + i * C::QS;
+            const int o = c < 12 ? C::QA + c : C::QB + (c - 12), ld = c < 12 ? 12 : 4;
+#pragma unroll
+            for (int j = 0; j < 12; j++) rc[o + j * ld] = xo[j].d;
+            if (c == 0) {
+#pragma unroll
+                for (int j = 0; j < 12; j++) rc[C::QX + j] = xo[j].v;
+            }
+        }
+    }
+    assemble_phase_a<C, MODE, IBR>(pr, G, L, z, nullptr, 0.0, N, lane, dt, ip, acc);
+    LSP(20)
+    // ---------------- phase B ------------------------------------------------------------------------------
+    // Every residual row of every step is independent once phase A has left the coefficients and the pair-gradient table:
+    // three flat row loops (opt_x | opt_u | dyn), work item = one row, operands read straight from the trajectory (the
+    // neighbouring lanes read neighbouring addresses; everything is L1/L2 resident after the first touch).
+    // Index arithmetic is incremental and all offsets are 32-bit unsigned so that the loads use the scalar-base + vector-
+    // offset addressing mode.  Each lane handles ASM_UNROLL rows per pass (rows e, e + 64, ...): their loads are in flight
+    // together, which halves the exposed L2 latency.
+    typedef unsigned uidx;
+    struct Row { double r, dprox; bool mine, ok; uidx rec_off; int vrow; };
+    auto finish_row = [&](const Row& q, bool dynrow) {
+        if (!q.ok) return;
+        double r = q.r;
+        // regularize_residual! (global_quantities.jl:67-86): proximal term on the opt rows
+        const double rr = zref ? r + reg * q.dprox : r;
+        if (MODE == 3) { l1r += fabs(rr); }            // statistics / records of the unregularised rows
+        else r = rr;
+        bad |= !isfinite(r);
+        if (IBR) {
+            l1f += fabs(r);
+            if (dynrow) { l1 += fabs(r); if (q.mine) vdyn = fmax(vdyn, fabs(r)); }
+            else if (q.mine) { l1 += fabs(r); vopt = fmax(vopt, fabs(r)); }
+        } else {
+            l1 += fabs(r);
+            if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
+        }
+        if (RECS) G.rec(pr)[q.rec_off] = r;
+        if (MODE == 2) G.res(pr)[q.vrow] = r;
+    };
+    const double* __restrict__ recg = G.rec(pr);
+    // advance (k, j) by 64 rows of a row space with LEN rows per step
+    constexpr int UR = C::ASM_UNROLL;
+    auto run_rows = [&](auto&& row, int LEN, bool dynrow) {
+        const int total = (N - 1) * LEN, stepk = (UR * C::NT) / LEN, stepj = (UR * C::NT) % LEN;
+        int k[UR], j[UR];
+#pragma unroll
+        for (int t = 0; t < UR; t++) { const int e0 = lane + t * C::NT; k[t] = e0 / LEN; j[t] = e0 % LEN; }
+        for (int e = lane; e < total; e += UR * C::NT) {
+            Row q[UR];
+#pragma unroll
+            for (int t = 0; t < UR; t++) q[t] = row(k[t], j[t], e + t * C::NT < total);
+#pragma unroll
+            for (int t = 0; t < UR; t++) finish_row(q[t], dynrow);
+#pragma unroll
+            for (int t = 0; t < UR; t++) { j[t] += stepj; k[t] += stepk; if (j[t] >= LEN) { j[t] -= LEN; k[t] += 1; } }
+        }
+    };
+    // ---- rows opt_i,x_{k+1}[a] = cost grad + pair terms + A_{k+1}' lambda_{i,k+1} - lambda_{i,k} (+ reg (x - xref))
+    {
+        constexpr int RXN = P * n;
+        auto row_x = [&](int k, int ei, bool ok) -> Row {
+            Row q; q.ok = ok;
+            if (!ok) { k = 0; ei = 0; }
+            const int i = ei / n, a = ei % n;
+            const uidx zo = (uidx)(n + k * b);                              // block k: x_{k+1} | u_k | lambda_k
+            const uidx ro = (uidx)(k * R::LEN);
+            const bool has_next = (k + 1 <= N - 2);
+            const double w = (k + 1 < N - 1) ? dt : 1.0;
+            double r = -z[zo + (uidx)(n + m + ei)];
+            {
+                // A_{k+1}' lambda_{i,k+1}: addresses clamped to block k when there is no next block, the term is dropped below
+                const uidx lo = zo + (uidx)((has_next ? b : 0) + n + m + i * n), co = ro + (uidx)((has_next ? R::LEN : 0) + R::COEF);
+                const double t = AT_vec<C>(recg + co, dt, [&](int rr) { return z[lo + (uidx)rr]; }, a);
+                r += has_next ? t : 0.0;
+            }
+            const bool own = (a % P == i);
+            const double tqv = G.Qd(pr)[i * ni + a / P], txv = G.xf(pr)[i * ni + a / P];
+            const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
+            const double xa = z[zo + (uidx)a];
+            r += w * (tq * (xa - tx));
+            if (C::POS) { const double gv = recg[(uidx)R::gvt(N, k) + (uidx)((i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0))]; r += (a < C::PD * P) ? gv : 0.0; }
+            if constexpr (C::EXT) {
+                // StateBoundConstraint of player i (state_bound_constraint.jl:85-97): rows (x - x_max)[a], (x_min - x)[a]
+                double qsb = 0.0;
+                if (pr.has_sb && ok) {
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int ci = ext_sb_row(pr, i, k, half * n + a);
+                        const double cv = half == 0 ? xa - ext_sbmax(pr, pr.extc)[ei] : ext_sbmin(pr, pr.extc)[ei] - xa;
+                        if (MODE == 2) G.vals(pr)[ci] = cv;
+                        if (isfinite(cv)) {
+                            const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
+                            const double wl = lm + am * cv;
+                            r += (half == 0 ? wl : -wl); qsb += am;
+                            if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, cv));
+                        }
+                    }
+                }
+                if (RECS && ok) G.rec(pr)[ro + (uidx)(R::RQ + ei)] = qsb;
+            }
+            q.mine = IBR ? (i == ip) : true;
+            q.dprox = 0.0;
+            if (zref) { const double xr = zref[zo + (uidx)a]; q.dprox = q.mine ? xa - xr : 0.0; }
+            q.r = r; q.rec_off = ro + (uidx)(R::RX + ei); q.vrow = MODE == 2 ? vx<C>(N, i, k) + a : 0;
+            return q;
+        };
+        run_rows(row_x, RXN, false);
+    }
+    LSP(21)
+    // ---- rows opt_i,u_{i,k}[c] = dt R (u - uf) + control-bound AL gradient + (B_k' lambda_{i,k})[c] (+ reg (u - uref))
+    {
+        auto row_u = [&](int k, int c, bool ok) -> Row {
+            Row q; q.ok = ok;
+            if (!ok) { k = 0; c = 0; }
+            const int i = c % P;
+            const uidx zo = (uidx)(n + k * b), ro = (uidx)(k * R::LEN);
+            const double u = z[zo + (uidx)(n + uoff<C>(c))];
+            const uidx lo = zo + (uidx)(n + m + i * n);
+            const double tr = G.Rd(pr)[(c % P) * mi + c / P], tu = G.uf(pr)[(c % P) * mi + c / P];
+            double g = 0.0, rhat = dt * tr + jreg;
+            if (pr.has_ctl && ok) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int ci = con_ctl<C>(pr, k, half * m + c);
+                    const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                    if (MODE == 2) G.vals(pr)[ci] = cv;
+                    if (isfinite(cv)) {
+                        const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
+                        const double wl = lm + am * cv;
+                        g += (half == 0 ? wl : -wl); rhat += am;
+                        if (!IBR) vcon = fmax(vcon, fmax(0.0, cv));
+                        else if ((pr.ibr_ctl_rows[ip] >> (half * m + c)) & 1ull) vcon = fmax(vcon, fmax(0.0, cv));
+                    }
+                }
+            }
+            q.r = dt * (tr * (u - tu)) + g + BT_vec<C>(recg + ro + (uidx)R::COEF, dt, [&](int rr) { return z[lo + (uidx)rr]; }, c);
+            q.mine = IBR ? (i == ip) : true;
+            q.dprox = 0.0;
+            if (zref) { const double ur = zref[zo + (uidx)(n + uoff<C>(c))]; q.dprox = q.mine ? u - ur : 0.0; }
+            if (RECS && ok) G.rec(pr)[ro + (uidx)(R::RHAT + c)] = rhat;
+            q.rec_off = ro + (uidx)(R::RU + c); q.vrow = MODE == 2 ? vu<C>(N, i, k) + c / P : 0;
+            return q;
+        };
+        run_rows(row_u, m, false);
+    }
+    LSP(22)
+    // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint, RobotDynamics 0.3.1)
+    {
+        auto row_d = [&](int k, int a, bool ok) -> Row {
+            Row q; q.ok = ok;
+            if (!ok) { k = 0; a = 0; }
+            const uidx zo = (uidx)(n + k * b), ro = (uidx)(k * R::LEN);
+            const uidx po = (k == 0) ? 0u : zo - (uidx)b;                   // x_k: x_1 sits in front of block 0
+            const double* Ck = recg + ro + (uidx)R::COEF;
+            double xn;
+            if constexpr (C::QUAD) {
+                xn = Ck[(a % P) * C::QS + C::QX + a / P];                    // RK2 value left by phase A
+            } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                // position rows: x + (v + dt/2 u) dt ; velocity rows: v + u dt
+                const int j = a < m ? a : a - m;
+                const double uj = z[zo + (uidx)(n + uoff<C>(j))], base = z[po + (uidx)a], vel = z[po + (uidx)(j + m)];
+                const double vm = vel + (uj * dt) * 0.5;
+                xn = base + (a < m ? vm : uj) * dt;
+            } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                const int blkk = a / P, i = a % P;
+                const double ua = z[zo + (uidx)(n + uoff<C>(i))], base = z[po + (uidx)a], vel = z[po + (uidx)(2 * P + i)];
+                const double vm = vel + (ua * dt) * 0.5;
+                const double cf = Ck[(blkk == 0 ? 5 : (blkk == 1 ? 6 : 4)) * P + i];    // dt cos th / dt sin th / dt sin(beta)/lr
+                xn = (blkk == 2) ? base + ua * dt : base + vm * cf;
+            } else {
+                const int blkk = a / P, i = a % P;
+                const double ua = z[zo + (uidx)(n + uoff<C>(P + i))], base = z[po + (uidx)a], vel = z[po + (uidx)(3 * P + i)];
+                const double uo = z[zo + (uidx)(n + uoff<C>((blkk >= 2 ? blkk - 2 : 0) * P + i))];
+                const double vm = vel + (ua * dt) * 0.5;
+                const double cf = Ck[(blkk == 0 ? 1 : 3) * P + i];                      // dt cos(thm) / dt sin(thm)
+                xn = (blkk <= 1) ? base + vm * cf : base + uo * dt;
+            }
+            q.r = xn - z[zo + (uidx)a];
+            q.mine = IBR ? (a % P == ip) : true;                           // dynamics_violation(model, pdtraj, i): entries pz[i]
+            q.dprox = 0.0; q.rec_off = ro + (uidx)(R::RD + a); q.vrow = MODE == 2 ? vd<C>(N, k) + a : 0;
+            return q;
+        };
+        run_rows(row_d, n, true);
+    }
+    LSP(23)
+    out.l1 = wave_sum(l1); out.opt = wave_max(vopt); out.dyn = wave_max(vdyn);
+    out.con = wave_max(vcon); out.sta = wave_max(vsta); out.nonfinite = wave_or(bad);
+    out.l1reg = (MODE == 3) ? wave_sum(l1r) : out.l1;
+    out.l1full = IBR ? wave_sum(l1f) : out.l1;
+    team_combine<C>(out);
+    LSP(24)
+}
+
+// ================================================================================================
+// Fused trial pass (round 4; double integrator, one wavefront per game: the C2 / C4 kernel).  One pass does what update_traj! +
+// assemble_pass did in two: the trial iterate z + alpha dz is formed where the source iterate is read, written out once, and every
+// residual row is evaluated out of LDS, FT time steps at a time -- the trajectory, the direction and the proximal reference (= the
+// source iterate) cross the memory system once instead of the four to five times of the three flat row loops (per-pass counters:
+// tests/probes/phase_bytes.sh; r03: 112 KB read per trial against 17 + 17 KB of trajectory and direction).
+//   AXPY = false: the rows of the source iterate itself (record!: MODE 1, no proximal term, nothing written but the records)
+//   MODE 0 / 3 as in assemble_pass (3 = statistics and records of the unregularised rows + the regularised norm l1reg)
+// Same row arithmetic as assemble_pass (same expressions in the same order); the norms are summed in another order.
+// ================================================================================================
+template <class C, int MODE, bool AXPY>
+__device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alpha, bool prox, double reg, double jreg, ResOut& out) {
+    static_assert(AsmLds<C>::FUSED && (MODE == 0 || MODE == 1 || MODE == 3), "fused trial pass: double integrator / unicycle, statistics / record modes");
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b, FT = AsmLds<C>::FT, TAB = AsmLds<C>::TAB, NXU = n + m, NT = C::NT, NC = C::NC;
+    // the chunk buffers are shared by the whole team; inside the chunk loop only LDS is exchanged (phase A ends with a full barrier), so the
+    // team's barrier orders LDS only -- with barriers that drained vmcnt the fused pass lost to the two passes on teams (C5 loop: 105 vs 152 K/s)
+    auto fsync = [&]() { if constexpr (C::NW == 1) sweep_sync<C>(); else team_lds_barrier(); };
+    using R = Rec<C>;
+    constexpr bool RECS = (MODE == 1 || MODE == 3);
+    const int N = phase_int(pr.N), lane = phase_lane();
+    const double dt = phase_f64(pr.dt);
+    const double* __restrict__ zs = G.z(0);                    // source iterate = proximal reference
+    const double* __restrict__ dz = G.z(2);
+    double* __restrict__ zo = G.z(1);                          // the trial iterate goes here
+    AsmAcc acc;
+    LSP_T0 LSP_COUNT(25)
+    // ---- phase A over all steps (positions of the trial iterate formed on the fly), heads and tables to the records as in assemble_pass
+    assemble_phase_a<C, MODE, false>(pr, G, L, zs, AXPY ? dz : nullptr, alpha, N, lane, dt, -1, acc);
+    LSP(20)
+    auto& Ch = L.ch;
+    for (int e = lane; e < AsmLds<C>::NLQR; e += NT) Ch.lqr[e] = G.Qd(pr)[e];          // [Qd | xf | Rd | uf]
+    const double* lQd = Ch.lqr; const double* lxf = lQd + P * ni; const double* lRd = lQd + 2 * P * ni; const double* luf = lRd + P * mi;
+    double* __restrict__ recg = G.rec(pr);
+    auto finish = [&](double r, double dprox, bool dynrow, unsigned rec_off) {
+        const double rr = prox ? r + reg * dprox : r;                // regularize_residual! (global_quantities.jl:67-86)
+        if (MODE == 3) acc.l1r += fabs(rr); else r = rr;
+        acc.bad |= !isfinite(r);
+        acc.l1 += fabs(r);
+        if (dynrow) acc.vdyn = fmax(acc.vdyn, fabs(r)); else acc.vopt = fmax(acc.vopt, fabs(r));
+        if (RECS) recg[rec_off] = r;
+    };
+    for (int k0 = 0; k0 < N - 1; k0 += FT) {
+        const int nst = (N - 1 - k0) < FT ? (N - 1 - k0) : FT;            // steps of this chunk
+        const int nblk = (k0 + nst < N - 1) ? nst + 1 : nst;             // blocks staged: the chunk's and the next one (A' lambda_{k+1})
+        // ---- stage: x_k of the first step, then blocks k0 .. k0 + nblk - 1; the trial blocks of the chunk's own steps go out here
+        if (lane < n) {
+            const int src = k0 == 0 ? lane : n + (k0 - 1) * b + lane;
+            double v = zs[src];
+            if (AXPY && k0 > 0) v = v + alpha * dz[src];                  // (x_1 does not move)
+            Ch.xprev[lane] = v;
+        }
+        {
+            const int base = n + k0 * b, cnt = nblk * b, own = nst * b;
+            for (int e0 = lane; e0 < cnt; e0 += 4 * NT) {
+                double a[4], d[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const int e = e0 + t * NT, ec = e < cnt ? e : e0; a[t] = zs[base + ec]; d[t] = AXPY ? dz[base + ec] : 0.0; }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int e = e0 + t * NT;
+                    if (e < cnt) {
+                        const double v = AXPY ? a[t] + alpha * d[t] : a[t];
+                        Ch.zt[e] = v;
+                        if (AXPY && e < own) zo[base + e] = v;
+                        const int j = e / b, o = e % b;
+                        if (o < NXU && j < nst) Ch.zxu[j * NXU + o] = a[t];
+                    }
+                }
+            }
+            if constexpr (C::POS) {
+                const int tcnt = nst * TAB;
+                for (int e = lane; e < tcnt; e += NT) Ch.gvt[e] = recg[R::gvt(N, k0) + e];            // contiguous behind the records
+            }
+            if constexpr (NC > 0) {                                        // Jacobian coefficients of the staged steps (phase A left them in the records)
+                const int ccnt = nblk * NC;
+                for (int e = lane; e < ccnt; e += NT) Ch.coef[e] = recg[(size_t)(k0 + e / NC) * R::LEN + R::COEF + e % NC];
+            }
+        }
+        fsync();
+        // ---- rows opt_i,x_{k+1}[a]
+        for (int e = lane; e < nst * P * n; e += NT) {
+            const int ks = e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n, k = k0 + ks;
+            const double* blk = Ch.zt + ks * b;
+            const bool has_next = (k + 1 <= N - 2);
+            const double w = (k + 1 < N - 1) ? dt : 1.0;
+            double r = -blk[n + m + ei];
+            {
+                const double* ln = blk + (has_next ? b : 0) + n + m + i * n;
+                const double t = AT_vec<C>(Ch.coef + (ks + (has_next ? 1 : 0)) * NC, dt, [&](int rr) { return ln[rr]; }, a);
+                r += has_next ? t : 0.0;
+            }
+            const bool own = (a % P == i);
+            const double tqv = lQd[i * ni + a / P], txv = lxf[i * ni + a / P];
+            const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
+            const double xa = blk[a];
+            r += w * (tq * (xa - tx));
+            if (C::POS) { const double gv = Ch.gvt[ks * TAB + (i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0)]; r += (a < C::PD * P) ? gv : 0.0; }
+            const double dprox = prox ? xa - Ch.zxu[ks * NXU + a] : 0.0;
+            finish(r, dprox, false, (unsigned)(k * R::LEN + R::RX + ei));
+        }
+        LSP(21)
+        // ---- rows opt_i,u_{i,k}[c]
+        for (int e = lane; e < nst * m; e += NT) {
+            const int ks = e / m, c = e % m, i = c % P, k = k0 + ks;
+            const double* blk = Ch.zt + ks * b;
+            const double u = blk[n + uoff<C>(c)];
+            const double* lo = blk + n + m + i * n;
+            const double tr = lRd[(c % P) * mi + c / P], tu = luf[(c % P) * mi + c / P];
+            double g = 0.0, rhat = dt * tr + jreg;
+            if (pr.has_ctl) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int ci = con_ctl<C>(pr, k, half * m + c);
+                    const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                    if (isfinite(cv)) {
+                        const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
+                        const double wl = lm + am * cv;
+                        g += (half == 0 ? wl : -wl); rhat += am;
+                        acc.vcon = fmax(acc.vcon, fmax(0.0, cv));
+                    }
+                }
+            }
+            const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(Ch.coef + ks * NC, dt, [&](int rr) { return lo[rr]; }, c);
+            const double dprox = prox ? u - Ch.zxu[ks * NXU + n + uoff<C>(c)] : 0.0;
+            if (RECS) recg[(size_t)k * R::LEN + R::RHAT + c] = rhat;
+            finish(r, dprox, false, (unsigned)(k * R::LEN + R::RU + c));
+        }
+        LSP(22)
+        // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint; the expressions of assemble_pass)
+        for (int e = lane; e < nst * n; e += NT) {
+            const int ks = e / n, a = e % n, k = k0 + ks;
+            const double* blk = Ch.zt + ks * b;
+            const double* xk = ks == 0 ? Ch.xprev : blk - b;
+            double xn;
+            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                // position rows: x + (v + dt/2 u) dt ; velocity rows: v + u dt
+                const int j = a < m ? a : a - m;
+                const double uj = blk[n + uoff<C>(j)], base = xk[a], vel = xk[j + m];
+                const double vm = vel + (uj * dt) * 0.5;
+                xn = base + (a < m ? vm : uj) * dt;
+            } else {
+                const double* Ck = Ch.coef + ks * NC;
+                const int blkk = a / P, i = a % P;
+                const double ua = blk[n + uoff<C>(P + i)], base = xk[a], vel = xk[3 * P + i];
+                const double uo = blk[n + uoff<C>((blkk >= 2 ? blkk - 2 : 0) * P + i)];
+                const double vm = vel + (ua * dt) * 0.5;
+                const double cf = Ck[(blkk == 0 ? 1 : 3) * P + i];                      // dt cos(thm) / dt sin(thm)
+                xn = (blkk <= 1) ? base + vm * cf : base + uo * dt;
+            }
+            finish(xn - blk[a], 0.0, true, (unsigned)(k * R::LEN + R::RD + a));
+        }
+        LSP(23)
+        fsync();                                           // the next chunk overwrites the buffers
+    }
+    out.l1 = wave_sum(acc.l1); out.opt = wave_max(acc.vopt); out.dyn = wave_max(acc.vdyn);
+    out.con = wave_max(acc.vcon); out.sta = wave_max(acc.vsta); out.nonfinite = wave_or(acc.bad);
+    out.l1reg = (MODE == 3) ? wave_sum(acc.l1r) : out.l1;
+    out.l1full = out.l1;
+    team_combine<C>(out);
+    LSP(24)
+}
+
+// update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
+typedef double double2_t __attribute__((ext_vector_type(2)));
+template <class C>
+__device__ __forceinline__ void update_traj(CPR pr0, const Game& G0, int tsel, int ssel, double alpha) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    double* tgt = G.z(tsel); const double* src = G.z(ssel); const double* dz = G.z(2);
+    // pure streaming pass: 16 bytes per lane and four independent load pairs in flight per pass.  Every game's buffers start
+    // 16-byte aligned when traj_len is even (n is always even); otherwise the scalar loop runs.
+    constexpr int U = 4;
+    const int S = phase_int(pr.S), lane = phase_lane();
+    if ((pr.traj_len & 1) == 0) {
+        const int S2 = S >> 1;                           // pairs; a last odd element is handled below
+        const double2_t* __restrict__ s2 = reinterpret_cast<const double2_t*>(src + C::n);
+        const double2_t* __restrict__ d2 = reinterpret_cast<const double2_t*>(dz + C::n);
+        double2_t* __restrict__ t2 = reinterpret_cast<double2_t*>(tgt + C::n);
+        for (int e0 = lane; e0 < S2; e0 += U * C::NT) {
+            double2_t a[U], d[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S2 ? e : e0; a[t] = s2[ec]; d[t] = d2[ec]; }
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S2) { double2_t v; v.x = a[t].x + alpha * d[t].x; v.y = a[t].y + alpha * d[t].y; t2[e] = v; } }
+        }
+        if ((S & 1) && lane == 0) tgt[C::n + S - 1] = src[C::n + S - 1] + alpha * dz[C::n + S - 1];
+    } else {
+        for (int e0 = lane; e0 < S; e0 += U * C::NT) {
+            double a[U], d[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S ? e : e0; a[t] = src[C::n + ec]; d[t] = dz[C::n + ec]; }
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S) tgt[C::n + e] = a[t] + alpha * d[t]; }
+        }
+    }
+}
+// Δ_step (primal_dual_traj.jl:130-147)
+template <class C>
+__device__ __forceinline__ double delta_step(CPR pr, const double* dz, double alpha) {
+    double s = 0;
+    for (int e = phase_lane(); e < (pr.N - 1) * (C::n + C::m); e += WAVE) {
+        const int k = e / (C::n + C::m), a = e % (C::n + C::m);
+        s += fabs(dz[C::n + k * C::b + a]);
+    }
+    s = wave_sum(s);
+    s *= alpha;
+    s /= (double)((pr.N - 1) * (C::n + C::m));
+    return s;
+}
+
+
+} // namespace alg

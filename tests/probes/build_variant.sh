@@ -7,7 +7,7 @@ set -e
 NAME=$1; shift
 R=$(cd "$(dirname "$0")/../.." && pwd); C=$R/algames.jl_amd/csrc; O=$R/algames.jl_amd/lib/variants/obj_$NAME; D=$R/algames.jl_amd/lib/obj
 mkdir -p $O
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-invalid-offsetof -mllvm -disable-machine-licm $*"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-invalid-offsetof -Wno-null-dereference -mllvm -disable-machine-licm --offload-compress $*"
 UNITS=${UNITS:-"base_0 base_1 base_2 base_3 base_4 base_5 base_6 base_7 base_8 ext_di ext_uni ext_bic ext_di3 mw"}
 J=0
 for u in $UNITS; do

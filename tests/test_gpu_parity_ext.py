@@ -239,7 +239,9 @@ def _guards_ok(batch):
 ALL_INSTANTIATIONS = ([(DI, p, N, False) for p, N in ((1, 5), (2, 13), (3, 40), (4, 9))] + [(UNI, p, N, False) for p, N in ((1, 6), (2, 12), (3, 30), (4, 50))]
                       + [(DI, p, N, True) for p, N in ((1, 7), (2, 9), (3, 12), (4, 6))] + [(UNI, p, N, True) for p, N in ((1, 9), (2, 8), (3, 11), (4, 7))]
                       + [(BIC, p, N, True) for p, N in ((1, 8), (2, 7), (3, 20), (4, 11))]
-                      + [(DI, 5, 7, False), (DI, 6, 5, True), (UNI, 5, 6, True), (UNI, 6, 5, False), (BIC, 5, 6, True), (BIC, 6, 5, True)])
+                      + [(DI, 5, 7, False), (DI, 6, 5, True), (UNI, 5, 6, True), (UNI, 6, 5, False), (BIC, 5, 6, True), (BIC, 6, 5, True)]
+                      # (round 5: the other four five- / six-player instantiations, so that every kernel of ALG_CFGS_P56 is reached by a test)
+                      + [(DI, 5, 5, True), (DI, 6, 6, False), (UNI, 5, 5, False), (UNI, 6, 4, True)])
 
 
 @pytest.mark.timeout(120)

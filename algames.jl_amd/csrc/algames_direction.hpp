@@ -1371,7 +1371,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) acc[r4] = r4 < NR ? fma(dtc, sbase[i * n * LDP + rconst(r4) * LDP], tbase[i * n * LDP + rconst(r4) * LDP]) : 0.0;
 #pragma unroll
-                for (int kb = 0; kb < KBS; kb++) pb[kb] = fma(dt, obase[i * n * LDP + 4 * kb + m], hdt2 * obase[i * n * LDP + 4 * kb]);
+                for (int kb = 0; kb < KBS; kb++) pb[kb] = fma(-dt, obase[i * n * LDP + 4 * kb + m], -hdt2 * obase[i * n * LDP + 4 * kb]);      // -(P_i B): the B operand holds -[K | kappa]
             };
             auto write_back = [&](int i, double4_t acc) {
 #pragma unroll
@@ -1649,10 +1649,14 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // ---- K = -Y -> HBM (column-major m x (n+1)) ; [F | f] = [A_k | rd] + B [K | kappa]
         if (rhsl) {
             const int cc = cidx - m;
+            // (split recursion: the solved columns Y = -[K | kappa] are used as they are -- the sign goes into the constants that form the
+            // A operand P_i B of the next step's product and into the forward sweep's du = -(Y dx + y_0): exact negations, bit-identical)
+            if constexpr (!SPLITF) {
 #pragma unroll
-            for (int c = 0; c < m; c++) col[c] = -col[c];
+                for (int c = 0; c < m; c++) col[c] = -col[c];
+            }
             if constexpr (SPLITF) {
-                // split recursion: column cc of [K | kappa] is the B operand of the next step's product as it is
+                // split recursion: column cc of -[K | kappa] is the B operand of the next step's product as it is
 #pragma unroll
                 for (int c = 0; c < m; c++) { if (!TEAM || (c % C::NW) == tw) L.bw.Fx[c * 16 + cc] = col[c]; }     // (team: every wavefront holds the columns)
             } else {
@@ -1794,7 +1798,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         const int cl = fl < m ? fl : 0;
         double acc = Kl[n * m + cl];
         rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
-        const double duv = fl < m ? acc : 0.0;
+        const double duv = fl < m ? (SPLITF ? -acc : acc) : 0.0;     // (split recursion: the gains in HBM are -[K | kappa])
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
         dxn = fl < n ? dxn : 0.0;

@@ -22,7 +22,7 @@ for name, ext, base, d3, force in (("base", False, 100000, False, None), ("exten
             with contextlib.redirect_stdout(buf):
                 F._compare_solve(g, o, tag, x=x)
         except AssertionError as e:
-            bad.append((base + seed, str(e)[:200]))
+            bad.append((base + seed, str(e)[:200] + " ... " + str(e)[-260:].replace("\n", " ")))
         consulted += "arbiter consulted" in buf.getvalue()
         s = g.get_stats(); it += int(s["newton_iters"].sum()); fails += int(s["ls_failures"].sum()); corr += int(s["refinements"].sum())
     print("%-13s cases %d outside the rule %d, arbiter consulted %d, Newton iterations %d, failed line searches %d, correction solves %d, %.0f s"

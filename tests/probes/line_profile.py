@@ -3,14 +3,15 @@ python tests/probes/line_profile.py [kernel] [model p d ext] -> instructions att
 import re, subprocess, sys, os, collections
 kern = sys.argv[1] if len(sys.argv) > 1 else "k_direction"
 cfg = sys.argv[2:6] if len(sys.argv) > 5 else ["ALG_MODEL_DOUBLE_INTEGRATOR", "3", "2", "0"]
-sigs = {"k_newton_solve": "(Params, int, uint64_t)", "k_direction": "(Params, double, int*)"}
+sigs = {"k_newton_solve": "(Params, int, uint64_t)", "k_direction": "(Params, double, int*)", "k_line_search": "(Params, double, const double*, double*, int*)", "k_record": "(Params, alg_record*)"}
+hdr = os.environ.get("LP_HEADER", "algames_direction.hpp")
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = "/tmp/isa/lp_%s.hip" % kern
 os.makedirs("/tmp/isa", exist_ok=True)
 open(src, "w").write('#include "%s/algames.jl_amd/csrc/algames_kernels.hpp"\ntemplate __global__ void %s<Cfg<%s>>%s;\n' % (root, kern, ", ".join(cfg), sigs[kern]))
 out = src.replace(".hip", ".s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-invalid-offsetof", "-gline-tables-only",
-                       "-Wno-unused-command-line-argument", "--cuda-device-only", "-S", "-mllvm", "-disable-machine-licm", "-o", out, src])
+                       "-Wno-unused-command-line-argument", "--cuda-device-only", "-S", "-mllvm", "-disable-machine-licm", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-o", out, src])
 files = {}; cur = None; cnt = collections.Counter(); kinds = collections.defaultdict(collections.Counter)
 def cat(op):
     if op.startswith("v_mfma"): return "mfma"
@@ -26,10 +27,10 @@ for l in open(out):
     m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", l)
     if m: cur = (files.get(m.group(1), "?"), int(m.group(2))); continue
     m = re.match(r"\t([a-z_0-9]+)", l)
-    if m and cur and cur[0].endswith("algames_device.hpp"):
+    if m and cur and cur[0].endswith(hdr):
         cnt[cur[1]] += 1; kinds[cur[1]][cat(m.group(1))] += 1
 lo, hi = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (0, 10 ** 9)
-lines = open(os.path.join(root, "algames.jl_amd/csrc/algames_device.hpp")).read().split("\n")
+lines = open(os.path.join(root, "algames.jl_amd/csrc/" + hdr)).read().split("\n")
 tot = 0
 for ln in sorted(cnt):
     if lo <= ln <= hi and cnt[ln] >= 3:

@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 DI, UNI, BIC = 0, 1, 2
+ARBITER_CONSULTED = []          # problems of this session whose trajectories needed the arbiter rule (reported by the last test of the file)
 
 
 def _random_pair(alg, orc, rng, ext, d3=False, force=None, force_d3=True, arb=None):
@@ -91,6 +92,7 @@ def _compare_solve(g, o, tag, tol=None, x=None):
     the double oracle is: |hip - x| <= 4 |oracle - x| + FUZZ_TOL (both double programs miss the extended-precision run by the same
     amount; round 3 kept a list of such cases at 1e-7, tests/probes/fuzz_case_probe.py shows who is far)."""
     tol = FUZZ_TOL if tol is None else tol
+    sx, same = None, None
     sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
     for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
         assert np.array_equal(sg[f], so[f]), (tag, f, sg[f], so[f])
@@ -104,12 +106,23 @@ def _compare_solve(g, o, tag, tol=None, x=None):
             same = np.all([sx[f] == so[f] for f in ("status", "outer_iters", "newton_iters", "ls_failures")], axis=0) & ok
             zx = x.get_traj(0)
             eg, eo = np.abs(zg[same] - zx[same]).max(initial=0.0), np.abs(zo[same] - zx[same]).max(initial=0.0)
+            ARBITER_CONSULTED.append(tag[:4])
             print("arbiter consulted:", tag[:4], "|hip-orc| %.2e |hip-x| %.2e |orc-x| %.2e scale %.1f" % (err, eg, eo, scale))
             assert same.all() and eg <= 4.0 * eo + tol * scale, (tag, err, eg, eo, scale)
         else:
             assert err <= tol * scale, (tag, err, scale)
         for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
-            assert np.allclose(sg["last"][f][ok], so["last"][f][ok], rtol=1e-6, atol=1e-9), (tag, f)
+            a, b = sg["last"][f][ok], so["last"][f][ok]
+            if sx is None:
+                assert np.allclose(a, b, rtol=1e-6, atol=1e-9), (tag, f)
+            else:
+                # a problem that went through the arbiter for its trajectories (both double programs amplify rounding beyond the
+                # tolerance): the statistics of the last record are functions of those trajectories and follow the same rule -- the HIP
+                # path no further from the arbiter's value than four times the oracle's distance (round 5; until then this line compared
+                # the two diverged double programs with each other at 1e-6, which is what left the nine extended-bicycle seeds of
+                # tests/probes/fuzz_long_r4.py outside although their trajectories pass: profiles/r05_fuzz_tail.txt)
+                c = sx["last"][f][ok]
+                assert np.all(np.abs(a - c) <= 4.0 * np.abs(b - c) + 1e-6 * np.abs(c) + 1e-9), (tag, f, a, b, c)
     hg, ho = g.get_history(0), o.get_history(0)
     assert len(hg) == len(ho) and np.array_equal(hg["ls_j"], ho["ls_j"]) and np.array_equal(hg["alpha"], ho["alpha"]), tag
 
@@ -333,3 +346,12 @@ def test_direction_backward_error_against_the_arbiter(alg, orc, seed, fam):
         z = x.get_traj()
         for b in (g, o):
             b.set_traj(z)
+
+
+def test_zz_report_arbiter_consultations():
+    """Runs last in this file: how often the `4 x the oracle's distance` rule had to settle a trajectory comparison in this session (VERDICT r4
+    item 3 asks for the count).  One committed seed needs it: an extended-constraint bicycle problem on which the double oracle itself sits
+    3e-8 from the long-double arbiter, i.e. no double program can be within 1e-8 of it."""
+    print("arbiter rule consulted for %d problem(s): %s" % (len(ARBITER_CONSULTED), ARBITER_CONSULTED))
+    assert len(ARBITER_CONSULTED) <= 2
+

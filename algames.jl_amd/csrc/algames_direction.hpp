@@ -139,11 +139,11 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 // lane c < M owns column c of W, lane M + c' owns right-hand-side column c'.  Row operations are lane-local; the
 // pivot column is broadcast with v_readlane, so the pivot choice is wave-uniform.  On exit the right-hand-side
 // lanes hold the solution columns.  Returns 0 or 1 (singular).
-// 1/x for a pivot (normal, non-zero): hardware reciprocal + one Newton step instead of the IEEE division sequence
+// 1/x for a pivot (normal, non-zero): hardware reciprocal + two Newton steps instead of the IEEE division sequence
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);      // (v_rcp_f64 alone: 4.6e-8 relative; one step 2.2e-15; two steps 1.1e-16 = correctly rounded-ish: tests/probes/rcp_test.hip)
 }
 // Same elimination with XC columns per lane (lane t: columns t, t + 64, ...; the pivot columns c < M < 64 are first columns): the
 // control system of the dense direction (m + n + 1 up to 65 columns) solved by one wavefront without LDS traffic or barriers.
@@ -1234,7 +1234,11 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     // pipe of a SIMD is shared by its four resident games and was busy 3 250 of the ~10 500 cycles of a backward step), and the
     // closed-loop phase ([F | f] = [A_k | rd] + B [K | kappa] -> LDS) disappears: the solved columns [K | kappa] go to LDS as they are
     // (the B operand of the product) and y_i replaces s_i in column n of the player's rows.
-    constexpr bool SPLITF = C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && AUGS && !IBR && (C::NW == 1 || TEAM);
+    // (round 5, later: the 3-player unicycle -- C5 -- as well.  Its A_k and B_k carry the step's four Jacobian coefficients per player, so
+    // P_i A_k and P_i B_k take three entries of P_i each; with player i's four state rows placed in lane group i of the tile, A' is
+    // lane-local too and the ds_bpermute gathers of the unsplit form (P3Gather) go away.)
+    constexpr bool SPLITU = C::MODEL == ALG_MODEL_UNICYCLE && P == 3;
+    constexpr bool SPLITF = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || SPLITU) && AUGS && !IBR && (C::NW == 1 || TEAM);
     constexpr int KBS = (m + 3) / 4;                    // k-blocks of the split product (inner dimension m)
     QaddMap<C, BT, (HELP2 ? 2 : 1)> qam; qam.init(tid, hw);
     if constexpr (HELP2) {
@@ -1347,72 +1351,124 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             double kt[KBS];
 #pragma unroll
             for (int kb = 0; kb < KBS; kb++) kt[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];       // [K | kappa] of step k + 1, rows >= m zero
-            // Row placement in the MFMA tile: the product's row at tile position (lane group l, register r4) is whatever row of P_i the
-            // A operand's lane 4 r4 + l feeds, so the rows are PLACED such that A' costs no lane exchange afterwards: A' X adds dt x row
-            // r to row r + m, and the pair (r, r + m) sits in ONE lane group, r = 4 j + l in register 2 j and r + m in register 2 j + 1
-            // (the natural order r = l + 4 r4 has row r - m in lane ^ 32 when m = 2 mod 4: four v_permlane32_swap + selects per tile).
-            // Lane roles: the tile entry (row, column lrow) of P_i A takes dt x column lrow - m of the same row (columns m..n-1); the
-            // operand entry (row, k = 4 kb + lq) of P_i B is dt^2/2 P[row][k] + dt P[row][k + m] (entries with k >= m meet zero rows of
-            // [K | kappa]: whatever finite value the two loads return there is multiplied by zero).
-            constexpr int NR = 2 * ((m + 3) / 4);                           // accumulator registers in use
-            static_assert(NR <= 4, "row pairs of the split recursion");
-            // (rows as affine functions of the lane coordinates, so that every LDS address below is one of four lane-dependent bases plus
-            // an immediate: register r4 of lane group l holds row l + RC(r4); lane groups whose row does not exist -- l >= m - 4 j in the
-            // last pair of registers -- read rows of the next block, harmlessly, and do not write)
-            auto rconst = [](int r4) { return 4 * (r4 >> 1) + ((r4 & 1) ? m : 0); };
-            const int opl = lrow & 3, opr4 = lrow >> 2;
-            const int oprow = (opr4 < NR && 4 * (opr4 >> 1) + opl < m) ? opl + 4 * (opr4 >> 1) + ((opr4 & 1) ? m : 0) : 0;      // the row this lane feeds as A operand
-            const bool shc = lrow >= m && lrow < n;
-            const int lsh = shc ? lrow - m : lrow;
-            const double dtc = shc ? dt : 0.0, hdt2 = 0.5 * dt * dt;
-            const double* const tbase = &L.bw.Pm[lq * LDP + lrow], * const sbase = &L.bw.Pm[lq * LDP + lsh], * const obase = &L.bw.Pm[oprow * LDP + lq];
-            double* const wbase = &L.bw.Pm[lq * LDP + lrow];
-            auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) acc[r4] = r4 < NR ? fma(dtc, sbase[i * n * LDP + rconst(r4) * LDP], tbase[i * n * LDP + rconst(r4) * LDP]) : 0.0;
-#pragma unroll
-                for (int kb = 0; kb < KBS; kb++) pb[kb] = fma(-dt, obase[i * n * LDP + 4 * kb + m], -hdt2 * obase[i * n * LDP + 4 * kb]);      // -(P_i B): the B operand holds -[K | kappa]
-            };
-            auto write_back = [&](int i, double4_t acc) {
-#pragma unroll
-                for (int j = 0; 2 * j + 1 < NR; j++) acc[2 * j + 1] = fma(dt, acc[2 * j], acc[2 * j + 1]);      // A': row r + m += dt x row r
-                if (lrow < n + 1) {
-#pragma unroll
-                    for (int r4 = 0; r4 < NR; r4++) {
-                        if (4 * (r4 >> 1) + 4 <= m) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];             // rows of every lane group
+            // the products and the write-back, given a model's operand / write-back helpers
+            auto run = [&](auto&& operands, auto&& write_back) {
+                if constexpr (TEAM) {
+                    // team: player i on wavefront i (the same operations on the same numbers as below: bit-identical to one wavefront per game)
+                    static_assert(!TEAM || P <= C::NW, "one player per wavefront of the team");
+                    if (tw < P) {
+                        double4_t acc; double pb[KBS];
+                        operands(tw, acc, pb);
+    #pragma unroll
+                        for (int kb = 0; kb < KBS; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[kb], kt[kb], acc, 0, 0, 0);
+                        sweep_sync<C>();
+                        write_back(tw, acc);
                     }
-                    if constexpr ((m & 3) != 0) {
-                        if (lq < (m & 3)) {
-#pragma unroll
-                            for (int r4 = NR - 2; r4 < NR; r4++) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];  // last pair: lane groups l < m mod 4
+                } else {
+                    // the players' chains are independent: all operands first, the products interleaved in the matrix pipe, then the write-backs
+                    double4_t acc[P];
+                    double pb[P][KBS];
+    #pragma unroll
+                    for (int i = 0; i < P; i++) operands(i, acc[i], pb[i]);
+    #pragma unroll
+                    for (int kb = 0; kb < KBS; kb++)
+    #pragma unroll
+                        for (int i = 0; i < P; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][kb], kt[kb], acc[i], 0, 0, 0);
+                    sweep_sync<C>();                                           // every read of [P_i | y_i] is done
+    #pragma unroll
+                    for (int i = 0; i < P; i++) write_back(i, acc[i]);
+                }
+            };
+            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                // Row placement in the MFMA tile: the product's row at tile position (lane group l, register r4) is whatever row of P_i the
+                // A operand's lane 4 r4 + l feeds, so the rows are PLACED such that A' costs no lane exchange afterwards: A' X adds dt x row
+                // r to row r + m, and the pair (r, r + m) sits in ONE lane group, r = 4 j + l in register 2 j and r + m in register 2 j + 1
+                // (the natural order r = l + 4 r4 has row r - m in lane ^ 32 when m = 2 mod 4: four v_permlane32_swap + selects per tile).
+                // Lane roles: the tile entry (row, column lrow) of P_i A takes dt x column lrow - m of the same row (columns m..n-1); the
+                // operand entry (row, k = 4 kb + lq) of P_i B is dt^2/2 P[row][k] + dt P[row][k + m] (entries with k >= m meet zero rows of
+                // [K | kappa]: whatever finite value the two loads return there is multiplied by zero).
+                constexpr int NR = 2 * ((m + 3) / 4);                           // accumulator registers in use
+                static_assert(NR <= 4, "row pairs of the split recursion");
+                // (rows as affine functions of the lane coordinates, so that every LDS address below is one of four lane-dependent bases plus
+                // an immediate: register r4 of lane group l holds row l + RC(r4); lane groups whose row does not exist -- l >= m - 4 j in the
+                // last pair of registers -- read rows of the next block, harmlessly, and do not write)
+                auto rconst = [](int r4) { return 4 * (r4 >> 1) + ((r4 & 1) ? m : 0); };
+                const int opl = lrow & 3, opr4 = lrow >> 2;
+                const int oprow = (opr4 < NR && 4 * (opr4 >> 1) + opl < m) ? opl + 4 * (opr4 >> 1) + ((opr4 & 1) ? m : 0) : 0;      // the row this lane feeds as A operand
+                const bool shc = lrow >= m && lrow < n;
+                const int lsh = shc ? lrow - m : lrow;
+                const double dtc = shc ? dt : 0.0, hdt2 = 0.5 * dt * dt;
+                const double* const tbase = &L.bw.Pm[lq * LDP + lrow], * const sbase = &L.bw.Pm[lq * LDP + lsh], * const obase = &L.bw.Pm[oprow * LDP + lq];
+                double* const wbase = &L.bw.Pm[lq * LDP + lrow];
+                auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
+    #pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) acc[r4] = r4 < NR ? fma(dtc, sbase[i * n * LDP + rconst(r4) * LDP], tbase[i * n * LDP + rconst(r4) * LDP]) : 0.0;
+    #pragma unroll
+                    for (int kb = 0; kb < KBS; kb++) pb[kb] = fma(-dt, obase[i * n * LDP + 4 * kb + m], -hdt2 * obase[i * n * LDP + 4 * kb]);      // -(P_i B): the B operand holds -[K | kappa]
+                };
+                auto write_back = [&](int i, double4_t acc) {
+    #pragma unroll
+                    for (int j = 0; 2 * j + 1 < NR; j++) acc[2 * j + 1] = fma(dt, acc[2 * j], acc[2 * j + 1]);      // A': row r + m += dt x row r
+                    if (lrow < n + 1) {
+    #pragma unroll
+                        for (int r4 = 0; r4 < NR; r4++) {
+                            if (4 * (r4 >> 1) + 4 <= m) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];             // rows of every lane group
+                        }
+                        if constexpr ((m & 3) != 0) {
+                            if (lq < (m & 3)) {
+    #pragma unroll
+                                for (int r4 = NR - 2; r4 < NR; r4++) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];  // last pair: lane groups l < m mod 4
+                            }
                         }
                     }
-                }
-            };
-            if constexpr (TEAM) {
-                // team: player i on wavefront i (the same operations on the same numbers as below: bit-identical to one wavefront per game)
-                static_assert(!TEAM || P <= C::NW, "one player per wavefront of the team");
-                if (tw < P) {
-                    double4_t acc; double pb[KBS];
-                    operands(tw, acc, pb);
-#pragma unroll
-                    for (int kb = 0; kb < KBS; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[kb], kt[kb], acc, 0, 0, 0);
-                    sweep_sync<C>();
-                    write_back(tw, acc);
-                }
+                };
+                run(operands, write_back);
             } else {
-                // the players' chains are independent: all operands first, the products interleaved in the matrix pipe, then the write-backs
-                double4_t acc[P];
-                double pb[P][KBS];
+                // 3-player unicycle: state rows a P + i (a = 0: x_i, 1: y_i, 2: theta_i, 3: v_i).  Tile position (lane group l = i, register
+                // a) holds row a P + i: the A operand's lane 4 a + i feeds that row, A' then touches one lane group only.
+                //   (P A)[r][c]  = P[r][c] + ca P[r][c - 2P or c - 3P] + cb P[r][c - P or c - 2P]   (c a heading / speed column, else P[r][c])
+                //   (P B)[r][k]  = dt/2 (cx P[r][i'] + cy P[r][P + i']) + dt P[r][(2 + kind) P + i'],   k = kind P + i'
+                //   (A' X)[theta_i] = X[theta_i] + c0 X[x_i] + c2 X[y_i],   (A' X)[v_i] = X[v_i] + c1 X[x_i] + c3 X[y_i]
+                // with the step's coefficients c0 = A[x][theta], c1 = A[x][v], c2 = A[y][theta], c3 = A[y][v] of the player (L.coefn: step k + 1).
+                const int ti = lq < P ? lq : 0;                                     // player of this lane group's rows
+                const int oa = lrow >> 2, oi = lrow & 3;
+                const int oprow = (oi < P) ? oa * P + oi : 0;                          // the row this lane feeds as A operand
+                const int cblk = lrow / P, ci = lrow % P;                          // column block / player of tile column lrow
+                const bool con = lrow >= 2 * P && lrow < n;
+                const int colA = con ? ci : lrow, colB = con ? P + ci : lrow;
+                const double ca = con ? L.coefn[(cblk - 2) * P + ci] : 0.0, cb = con ? L.coefn[cblk * P + ci] : 0.0;
+                const double* const tbase = &L.bw.Pm[ti * LDP + lrow], * const abase = &L.bw.Pm[ti * LDP + colA], * const bbase = &L.bw.Pm[ti * LDP + colB];
+                double* const wbase = &L.bw.Pm[ti * LDP + lrow];
+                const double* ob[KBS][3]; double cx[KBS], cy[KBS];
 #pragma unroll
-                for (int i = 0; i < P; i++) operands(i, acc[i], pb[i]);
+                for (int kb = 0; kb < KBS; kb++) {
+                    const int kk = 4 * kb + lq; const bool kok = kk < m; const int ki = kok ? kk % P : 0, kind = kok ? kk / P : 0;
+                    ob[kb][0] = &L.bw.Pm[oprow * LDP + ki]; ob[kb][1] = &L.bw.Pm[oprow * LDP + P + ki]; ob[kb][2] = &L.bw.Pm[oprow * LDP + (2 + kind) * P + ki];
+                    cx[kb] = kok ? L.coefn[kind * P + ki] : 0.0; cy[kb] = kok ? L.coefn[(2 + kind) * P + ki] : 0.0;
+                }
+                const double c0 = L.coefn[0 * P + ti], c1 = L.coefn[1 * P + ti], c2 = L.coefn[2 * P + ti], c3 = L.coefn[3 * P + ti];
+                auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
 #pragma unroll
-                for (int kb = 0; kb < KBS; kb++)
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const int o = i * n * LDP + r4 * P * LDP;
+                        acc[r4] = fma(cb, bbase[o], fma(ca, abase[o], tbase[o]));
+                    }
 #pragma unroll
-                    for (int i = 0; i < P; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][kb], kt[kb], acc[i], 0, 0, 0);
-                sweep_sync<C>();                                           // every read of [P_i | y_i] is done
+                    for (int kb = 0; kb < KBS; kb++) {
+                        const int o = i * n * LDP;
+                        const double h = fma(cy[kb], ob[kb][1][o], cx[kb] * ob[kb][0][o]);
+                        pb[kb] = fma(-dt, ob[kb][2][o], (-0.5 * dt) * h);       // -(P_i B): the B operand holds -[K | kappa]
+                    }
+                };
+                auto write_back = [&](int i, double4_t acc) {
+                    acc[2] = fma(c2, acc[1], fma(c0, acc[0], acc[2]));          // A': heading row
+                    acc[3] = fma(c3, acc[1], fma(c1, acc[0], acc[3]));          // A': speed row
+                    if (lrow < n + 1 && lq < P) {
 #pragma unroll
-                for (int i = 0; i < P; i++) write_back(i, acc[i]);
+                        for (int r4 = 0; r4 < 4; r4++) wbase[i * n * LDP + r4 * P * LDP] = acc[r4];
+                    }
+                };
+                run(operands, write_back);
             }
             bsync();
           }

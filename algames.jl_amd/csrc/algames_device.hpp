@@ -103,6 +103,22 @@ __device__ __forceinline__ CPR kernel_params() {
     return *(const ALG_AS4 Params*)(unsigned long)64;      // host pass: never executed
 #endif
 }
+// Device buffers are global memory, and the code has to SAY so: every buffer pointer of this file is either read out of the
+// kernel-argument segment through `CPR` (a pointer-typed field of a constant-address-space struct) or laundered through an integer
+// register (uniform_u64, Game::fresh), and in both cases the compiler's address-space inference loses track -- the accesses became FLAT
+// instructions (two thirds of the memory instructions of k_newton_solve until round 5: 191 flat loads and 125 flat stores against 100 / 40
+// global ones).  A flat access needs a 64-bit VGPR address, and -- worse for this code -- counts in lgkmcnt as well as vmcnt: every
+// `s_waitcnt lgkmcnt(0)` of an LDS phase boundary also waited for the record prefetches and result stores in flight.  as_global() casts
+// states it at the roots; everything derived from its result is selected as global_load / global_store.
+template <class T> __device__ __forceinline__ T* as_global(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (generic -> address space 1 -> generic as two pointer casts is folded away before the inference runs; through an integer the first
+    // cast is an inttoptr INTO address space 1, which the inference keeps and propagates to every access derived from the result)
+    return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
+#else
+    return p;
+#endif
+}
 // Opaque copy of the reference for one phase of the solver (see phase_int below): nothing that is derived from the
 // parameters inside the phase can be hoisted in front of the solver's outer loops.
 // (readfirstlane first: inside a function the inliner left out of line, arguments arrive in VGPRs; on a value that already
@@ -263,6 +279,18 @@ __device__ __forceinline__ void team_lds_barrier() {
 }
 template <class C> __device__ __forceinline__ void rotate_priority(int it);
 template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(game_tid() >> 6)); }
+
+// ---- global memory access as (uniform 64-bit base) + (unsigned 32-bit byte offset) ------------------------------------------------
+// `p[i]` with an int index sign-extends i and forms a 64-bit address in VGPRs for every access (v_ashrrev_i32 + v_lshl_add_u64: 1.4 K
+// 64-bit integer instructions per game-Newton-iteration at C2, SQ_INSTS_VALU_INT64 in profiles/r05_pmc_c2_final_summary.txt).  With
+// the base uniform (an SGPR pair: the game's chunk plus a step offset) and the lane's part an unsigned byte offset, the access is
+// `global_load_dwordx2 v, v_off, s[base]`: no address arithmetic beyond the (usually loop-invariant) 32-bit offset.  Offsets stay far
+// below 2^32 bytes: they address one game's chunk.
+// (the empty asm keeps the 32-bit offset a 32-bit value INSIDE the basic block of the access: hoisted out of a loop it becomes a
+// zero-extended 64-bit pair, instruction selection -- per block -- no longer sees the zero extension and falls back to a 64-bit add)
+__device__ __forceinline__ unsigned goff(int i) { unsigned o = (unsigned)i << 3; asm("" : "+v"(o)); return o; }
+__device__ __forceinline__ double gld(const double* p, int i) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(p) + goff(i)); }
+__device__ __forceinline__ void gst(double* p, int i, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(p) + goff(i)) = v; }
 
 // ---- counter RNG shared bit-for-bit with the oracle ------------------------------
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
@@ -634,7 +662,7 @@ struct Game {
     // few scalar instructions instead.
     __device__ __forceinline__ Game fresh() const {
         Game H = *this;
-        H.base = reinterpret_cast<double*>(uniform_u64(reinterpret_cast<unsigned long long>(base)));
+        H.base = as_global(reinterpret_cast<double*>(uniform_u64(reinterpret_cast<unsigned long long>(base))));
         H.g = __builtin_amdgcn_readfirstlane(g); asm volatile("" : "+s"(H.g));
         return H;
     }
@@ -647,18 +675,18 @@ struct Game {
     __device__ __forceinline__ double* tc(CPR pr) const { return base + pr.o_tc; }
     __device__ __forceinline__ alg_game_stats* st(CPR pr) const { return reinterpret_cast<alg_game_stats*>(base + pr.o_st); }
     __device__ __forceinline__ long long* mpc(CPR pr) const { return reinterpret_cast<long long*>(base + pr.o_mpc); }
-    __device__ __forceinline__ double* lam(CPR pr) const { return pr.con + (size_t)g * pr.con_stride; }
+    __device__ __forceinline__ double* lam(CPR pr) const { return as_global(pr.con) + (size_t)g * pr.con_stride; }
     __device__ __forceinline__ double* mu(CPR pr) const { return lam(pr) + pr.con_pad; }
     __device__ __forceinline__ double* vals(CPR pr) const { return lam(pr) + 2 * pr.con_pad; }
-    __device__ __forceinline__ const double* Qd(CPR pr) const { return pr.lqr + (size_t)g * pr.lqr_stride; }
+    __device__ __forceinline__ const double* Qd(CPR pr) const { return as_global(pr.lqr) + (size_t)g * pr.lqr_stride; }
     __device__ __forceinline__ const double* xf(CPR pr) const { return Qd(pr) + pr.p * pr.ni; }
     __device__ __forceinline__ const double* Rd(CPR pr) const { return Qd(pr) + 2 * pr.p * pr.ni; }
     __device__ __forceinline__ const double* uf(CPR pr) const { return Qd(pr) + 2 * pr.p * pr.ni + pr.p * pr.mi; }
-    __device__ __forceinline__ alg_record* hist(CPR pr) const { return pr.hist + (size_t)g * pr.hist_max; }
+    __device__ __forceinline__ alg_record* hist(CPR pr) const { return as_global(pr.hist) + (size_t)g * pr.hist_max; }
 };
 __device__ __forceinline__ Game game_view(CPR pr, int g) {
     Game G;
-    G.base = pr.arena + (size_t)g * pr.stride; G.g = g;
+    G.base = as_global(pr.arena) + (size_t)g * pr.stride; G.g = g;
     G.zo[0] = 0; G.zo[1] = pr.o_z1; G.zo[2] = pr.o_z2;
     return G;
 }
@@ -670,11 +698,11 @@ __device__ __forceinline__ double al_active_mu(double c, double lam, double mu) 
 __device__ __forceinline__ int ext_sb_row(CPR pr, int i, int k, int row) { return pr.col_len + pr.ctl_len + (i * (pr.N - 1) + k) * 2 * pr.n + row; }
 __device__ __forceinline__ int ext_wall_row(CPR pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + (i * (pr.N - 1) + k) * pr.nwall + w; }
 __device__ __forceinline__ int ext_circ_row(CPR pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + (i * (pr.N - 1) + k) * pr.ncirc + c; }
-__device__ __forceinline__ const double* ext_sbmax(CPR pr, const double* ec) { return ec; }
-__device__ __forceinline__ const double* ext_sbmin(CPR pr, const double* ec) { return ec + pr.p * pr.n; }
-__device__ __forceinline__ const double* ext_walls(CPR pr, const double* ec) { return ec + 2 * pr.p * pr.n; }
-__device__ __forceinline__ const double* ext_circs(CPR pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS; }
-__device__ __forceinline__ const double* ext_walls3(CPR pr, const double* ec) { return ec + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES; }
+__device__ __forceinline__ const double* ext_sbmax(CPR pr, const double* ec) { return as_global(ec); }
+__device__ __forceinline__ const double* ext_sbmin(CPR pr, const double* ec) { return as_global(ec) + pr.p * pr.n; }
+__device__ __forceinline__ const double* ext_walls(CPR pr, const double* ec) { return as_global(ec) + 2 * pr.p * pr.n; }
+__device__ __forceinline__ const double* ext_circs(CPR pr, const double* ec) { return as_global(ec) + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS; }
+__device__ __forceinline__ const double* ext_walls3(CPR pr, const double* ec) { return as_global(ec) + 2 * pr.p * pr.n + 6 * ALG_MAX_WALLS + 3 * ALG_MAX_CIRCLES; }
 __device__ __forceinline__ const double* ext_cyls(CPR pr, const double* ec) { return ext_walls3(pr, ec) + 12 * ALG_MAX_WALLS; }
 __device__ __forceinline__ int ext_wall3_row(CPR pr, int i, int k, int w) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + (i * (pr.N - 1) + k) * pr.nwall3 + w; }
 __device__ __forceinline__ int ext_cyl_row(CPR pr, int i, int k, int c) { return pr.col_len + pr.ctl_len + pr.sb_len + pr.wall_len + pr.circ_len + pr.wall3_len + (i * (pr.N - 1) + k) * pr.ncyl + c; }

@@ -1263,7 +1263,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 double nx[RPL];
                 if (k > 0) {
 #pragma unroll
-                    for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; nx[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+                    for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; nx[q] = e < R::LEN_SWEEP ? gld(G.rec(pr) + (size_t)(k - 1) * R::LEN, e) : 0.0; }
                 }
                 // ... and its share of that tail, with the record's loads in flight: the same columns of [W | V A_k | g], the same pivoted
                 // solve (every wavefront needs the solved columns for its rows), the odd rows of [F | f] = [A_k | rd] + B [K | kappa],
@@ -1296,9 +1296,9 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                     }
                     asm volatile("" ::: "memory");
                     if (rhsl) {
-                        double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (cidx - m) * m;
+                        double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK;
 #pragma unroll
-                        for (int c = 0; c < m; c++) Kg[c] = col[c];
+                        for (int c = 0; c < m; c++) gst(Kg, (cidx - m) * m + c, col[c]);
                     }
                 }
             }
@@ -1322,7 +1322,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         L.bw.T[e] = v;
     }
     if (tid == 0) L.bw.pad[0] = 0.0;
-    for (int e = tid; e < R::LEN_SWEEP; e += BT) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
+    for (int e = tid; e < R::LEN_SWEEP; e += BT) L.rec[0][e] = gld(G.rec(pr) + (size_t)(N - 2) * R::LEN, e);
     // ---- loop-invariant lane roles of the MFMA tiles: register r4 holds (row = lq + 4 r4, col = lrow)
     const bool colP = lrow < n;
     bool rowok[4];
@@ -1596,7 +1596,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         double pre[RPL];
         if (!HELP2 && k > 0) {                                       // (team of two: the helper wavefront fetches the record)
 #pragma unroll
-            for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; pre[q] = e < R::LEN_SWEEP ? G.rec(pr)[(size_t)(k - 1) * R::LEN + e] : 0.0; }
+            for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; pre[q] = e < R::LEN_SWEEP ? gld(G.rec(pr) + (size_t)(k - 1) * R::LEN, e) : 0.0; }
         }
         // ---- V[c][0..n) = B[:,c]' P_{i(c)},  V[c][n+1+c] = R^_c,  y_i = P_i rd + s_i   (lane = 16 c + col: shifts, no divisions)
         constexpr int CPP = BT / 16;                                   // control rows of V per pass
@@ -1745,9 +1745,9 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // meet stores that were just issued; measured neutral, the phase profile shows no exposed wait either way)
         asm volatile("" ::: "memory");
         if (!HELP2 && tw == 0 && rhsl) {
-            double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK + (cidx - m) * m;
+            double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK;
 #pragma unroll
-            for (int c = 0; c < m; c++) Kg[c] = col[c];
+            for (int c = 0; c < m; c++) gst(Kg, (cidx - m) * m + c, col[c]);
         }
         bsync();
         ALG_PROF(6)
@@ -1812,9 +1812,9 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     for (int q = 0; q < FPL; q++) { const int e = lane + q * WAVE; fso[q] = FWDW ? (e < R::LEN_COSTATE ? e : (e < FSL2 ? R::RD + (e - R::LEN_COSTATE) : R::RD)) : (frok ? fro : R::RD); }
     if constexpr (FWDW) {
 #pragma unroll
-        for (int q = 0; q < FPL; q++) L.rec[0][fso[q]] = G.rec(pr)[fso[q]];
-    } else if (frok) L.rec[0][fro] = G.rec(pr)[fro];
-    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = G.kgain(pr)[e];
+        for (int q = 0; q < FPL; q++) L.rec[0][fso[q]] = gld(G.rec(pr), fso[q]);
+    } else if (frok) L.rec[0][fro] = gld(G.rec(pr), fro);
+    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = gld(G.kgain(pr), e);
     // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
     // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
     // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
@@ -1824,9 +1824,9 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     auto fwd_load = [&](int kk, double (&rf)[FPL], double (&rk)[KPL]) {
         const int kc = kk < N - 1 ? kk : N - 2;
 #pragma unroll
-        for (int q = 0; q < FPL; q++) rf[q] = G.rec(pr)[(size_t)kc * R::LEN + fso[q]];
+        for (int q = 0; q < FPL; q++) rf[q] = gld(G.rec(pr) + (size_t)kc * R::LEN, fso[q]);
 #pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = G.kgain(pr)[(size_t)kc * NK + (e < NK ? e : NK - 1)]; }
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = gld(G.kgain(pr) + (size_t)kc * NK, e < NK ? e : NK - 1); }
     };
     // Prefetch ring: the slices of steps k + 1 .. k + SD are in flight in registers while step k computes.  With four games per
     // SIMD all streaming, a fetch takes about two microseconds -- longer than a step of this sweep -- so with one step in flight
@@ -1875,7 +1875,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
                 rowdot_dpp<NPOS>(t, dxn, hv);
                 wk = rr_ < C::PD * P ? t : wk;
             }
-            if (rok) dz[n + hl<C>(k, 0) + re_] = wk;
+            if (rok) gst(dz + n + hl<C>(k, 0), re_, wk);
         }
         // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
 #pragma unroll
@@ -1884,8 +1884,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
         asm volatile("" ::: "memory");
         // (2) results out
-        if (lane < m) dz[n + hu<C>(k, 0) + uoff<C>(lane)] = duv;
-        if (lane < n) dz[n + hx<C>(k) + lane] = dxn;
+        if (lane < m) gst(dz + n + hu<C>(k, 0), uoff<C>(lane), duv);
+        if (lane < n) gst(dz + n + hx<C>(k), lane, dxn);
         // (3) request step k+1+SD into the slot that was just emptied
         fwd_load(k + 1 + SD, pref[(u + 1) % SD], prek[(u + 1) % SD]);
         sweep_sync<C>();
@@ -1918,7 +1918,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         double wkr[CD], cfr[CD][NCF > 0 ? NCF : 1];
         auto cw_load = [&](int kk, double& wv, double (&cf)[NCF > 0 ? NCF : 1]) {
             const int kc = kk > 0 ? kk : 0, kn = kc + 1 < N - 1 ? kc + 1 : N - 2;
-            wv = dz[n + hl<C>(kc, 0) + re_];
+            wv = gld(dz + n + hl<C>(kc, 0), re_);
             if constexpr (NCF > 0) {
                 const double* Rn = G.rec(pr) + (size_t)kn * R::LEN + R::COEF;
                 cf[0] = Rn[cia]; cf[1] = Rn[cib];
@@ -1948,22 +1948,22 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             }
             acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
             lamp = acc;
-            if (rok) { dz[n + hl<C>(k, 0) + re_] = acc; bad |= !isfinite(acc); }
+            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
             cw_load(k - CD, wkr[u], cfr[u]);
           }
         }
     } else {
     constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
-    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = G.rec(pr)[(size_t)(N - 2) * R::LEN + e];
+    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = gld(G.rec(pr) + (size_t)(N - 2) * R::LEN, e);
     const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
     const bool cpos = C::POS && cr_ < C::PD * P;
-    double dxk = lane < n ? dz[n + hx<C>(N - 2) + lane] : 0.0;      // dx_{k+1}, fetched ahead like the records
-    if constexpr (DIROW) dxk = dz[n + hx<C>(N - 2) + cdxo];
+    double dxk = lane < n ? gld(dz + n + hx<C>(N - 2), lane) : 0.0;      // dx_{k+1}, fetched ahead like the records
+    if constexpr (DIROW) dxk = gld(dz + n + hx<C>(N - 2), cdxo);
     auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
         const int kc = kk > 0 ? kk : 0;
 #pragma unroll
-        for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; rr[q] = G.rec(pr)[(size_t)kc * R::LEN + (e < R::LEN_COSTATE ? e : R::LEN_COSTATE - 1)]; }
-        rdx = dz[n + hx<C>(kc) + cdxo];
+        for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; rr[q] = gld(G.rec(pr) + (size_t)kc * R::LEN, (e < R::LEN_COSTATE ? e : R::LEN_COSTATE - 1)); }
+        rdx = gld(dz + n + hx<C>(kc), cdxo);
     };
     // register ring like the forward sweep's: [record slice | dx] of steps k - 1 .. k - SD are in flight while step k computes
     double pre[SD][RPLC], pdx[SD];
@@ -2007,7 +2007,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             if constexpr (C::NC > 0) { can = Rc[R::COEF + cia]; cbn = Rc[R::COEF + cib]; if constexpr (C::MODEL == ALG_MODEL_BICYCLE) ccn = Rc[R::COEF + cic]; }
             acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
             lamp = acc;
-            if (rok) { dz[n + hl<C>(k, 0) + re_] = acc; bad |= !isfinite(acc); }
+            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
         } else {
         if (lane < n) L.fw.dx[lane] = dxk;
         hxm.expand(lane, Rc, L.fw.hx);
@@ -2026,7 +2026,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
         sweep_sync<C>();
-        if (lane < P * n) { L.fw.dl[lane] = acc; dz[n + hl<C>(k, 0) + lane] = acc; bad |= !isfinite(acc); }
+        if (lane < P * n) { L.fw.dl[lane] = acc; gst(dz + n + hl<C>(k, 0), lane, acc); bad |= !isfinite(acc); }
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         }
         // land step k - 1 (requested SD steps ago), then request step k - 1 - SD into the emptied slot
@@ -2100,23 +2100,23 @@ __device__ DirGate dir_urow_residual(CPR pr0, const Game& G0, int ip) {
     for (int e = tid; e < (N - 1) * m; e += C::NT) {
         const int k = e / m, c = e % m, i = c % P;
         double* Rk = recs + (size_t)k * R::LEN;
-        const double* dl = dz + n + hl<C>(k, i);
-        const double du = dz[n + hu<C>(k, 0) + uoff<C>(c)];
-        const double rh = Rk[R::RHAT + c], ru = Rk[R::RU + c];
-        const double bl = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return dl[rr]; }, c);
+        const int ro = k * R::LEN, dlo = n + hl<C>(k, i);                 // (32-bit offsets from the game's buffers: gld / gst)
+        const double du = gld(dz, n + hu<C>(k, 0) + uoff<C>(c));
+        const double rh = gld(recs, ro + R::RHAT + c), ru = gld(recs, ro + R::RU + c);
+        const double bl = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return gld(dz, dlo + rr); }, c);
         // |B[:,c]|' |dlambda| from below: the coefficients keep their signs (exact for the double integrator, whose B is non-negative)
-        const double bla = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return fabs(dl[rr]); }, c);
+        const double bla = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return fabs(gld(dz, dlo + rr)); }, c);
         double rho = fma(rh, du, ru) + bl;
         if (IBR && i != ip) rho = 0.0;                                  // unit rows of the other players (du_c = 0)
         const double sc = fabs(rh * du) + fabs(ru) + fabs(bla);         // row scale |J_c| |d| + |ru_c|
         const double ar = fabs(rho);
         if (ar * ws > wr * sc) { wr = ar; ws = sc; }
         rho_m = fmax(rho_m, ar); s_m = fmax(s_m, sc);
-        if constexpr (WRITE) Rk[R::RU + c] = rho;
+        if constexpr (WRITE) gst(recs, ro + R::RU + c, rho);
     }
     if constexpr (WRITE) {
-        for (int e = tid; e < (N - 1) * P * n; e += C::NT) recs[(size_t)(e / (P * n)) * R::LEN + R::RX + e % (P * n)] = 0.0;
-        for (int e = tid; e < (N - 1) * n; e += C::NT) recs[(size_t)(e / n) * R::LEN + R::RD + e % n] = 0.0;
+        for (int e = tid; e < (N - 1) * P * n; e += C::NT) gst(recs, (e / (P * n)) * R::LEN + R::RX + e % (P * n), 0.0);
+        for (int e = tid; e < (N - 1) * n; e += C::NT) gst(recs, (e / n) * R::LEN + R::RD + e % n, 0.0);
     }
     double v[3] = {rho_m, wr / fmax(ws, 1e-300), s_m};
     team_max<C, 3>(v);
@@ -2133,8 +2133,8 @@ __device__ void dir_add_correction(CPR pr0, const Game& G0, double& pl1, double&
     double* __restrict__ dz = G.z(2); double* __restrict__ ez = G.z(1); const double* __restrict__ z0 = G.z(0);
     double s = 0.0, mx = 0.0; int nf = 0;
     for (int e = tid; e < S; e += C::NT) {
-        const double v = dz[n + e] + ez[n + e];
-        dz[n + e] = v;
+        const double v = gld(dz, n + e) + gld(ez, n + e);
+        gst(dz, n + e, v);
         if (e % C::b < n + m) s += fabs(v);
         mx = fmax(mx, fabs(v)); nf |= !isfinite(v);
     }

@@ -177,8 +177,12 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr_arg) {
 // (the loop's own arguments are re-read from the kernel-argument segment where they are used, like `Params`: as by-value arguments they
 // were live -- in SGPRs, i.e. spilled -- across every phase of every solve)
 struct MpcLoopArgs { Params pr; int steps; uint64_t game_id0; double* states; };
+// (the 4-player bicycle with the extended constraint set -- 8 controls x 17 right-hand sides in registers -- sits at the 256-register
+// ceiling with the loop's own state on top: it takes the one-wavefront-per-SIMD budget, where the allocator parks the overflow in the
+// accumulation registers instead of scratch; the loop runs small batches, never two wavefronts per SIMD)
+template <class C> inline constexpr int mpc_loop_wpe = (C::WPE < 2 || (C::MODEL == ALG_MODEL_BICYCLE && C::P == 4)) ? 1 : 2;
 template <class C>
-__global__ void __launch_bounds__(C::NT, (C::WPE < 2 ? C::WPE : 2)) k_mpc_loop(Params pr_arg, int steps_arg, uint64_t game_id0_arg, double* states_arg) {
+__global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_arg, int steps_arg, uint64_t game_id0_arg, double* states_arg) {
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
 #if defined(__HIP_DEVICE_COMPILE__)

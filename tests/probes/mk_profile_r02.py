@@ -21,7 +21,7 @@ it = bench["roofline"]["game_iters_per_launch"]; own = bench["roofline"]["bytes_
 hbm = 1024.0 * (2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"])
 simd_quads = cnt["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0          # 8 XCDs report their cycles; 1024 SIMDs; quad-cycle = 4 clocks
 out = {
-    "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline " + " ".join(sys.argv[2:]),
+    "command": "python bench.py --steps %s --warmup %s --no-cpu-baseline " % (os.environ.get("PROF_STEPS", "5"), os.environ.get("PROF_WARMUP", "2")) + " ".join(sys.argv[2:]),
     "config": bench["config"]["name"], "games_per_gpu": bench["config"]["games_per_gpu"], "mpc_steps": bench["config"]["mpc_steps"],
     "kernel": kname, "kernel_avg_ms_rocprof": kavg_ns * 1e-6, "kernel_calls": kcalls, "kernel_ms_bench_hip_events": bench["roofline"]["kernel_ms_avg"],
     "game_iters_per_launch": it,

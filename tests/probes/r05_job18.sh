@@ -1,0 +1,6 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/r05_ab
+bash tests/probes/r05_ab.sh glob_c2 "--steps 20 --warmup 8" glob
+bash tests/probes/ab.sh "--config C3 --steps 20 --warmup 5" glob 2>&1 | tee gpurun_out/r05_ab/ab_glob_c3.txt
+bash tests/probes/ab.sh "--config C5 --mpc-steps 100 --steps 3 --warmup 1" glob 2>&1 | tee gpurun_out/r05_ab/ab_glob_c5.txt
+bash tests/probes/ab.sh "--config C2 --steps 20 --warmup 5 --games-per-gpu 512" glob 2>&1 | tee gpurun_out/r05_ab/ab_glob_c2s.txt

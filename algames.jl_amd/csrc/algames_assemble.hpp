@@ -81,7 +81,7 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                 constexpr int PD = C::PD, NS = C::NS;
                 const double w = (kn < N - 1) ? dt : 1.0;
                 const double* x1 = z + n + hx<C>(k); const double* d1 = dzp ? dzp + n + hx<C>(k) : nullptr;
-                auto xp = [&](int idx) { const double v = x1[idx]; return d1 ? v + alpha * d1[idx] : v; };    // position of the (trial) iterate
+                auto xp = [&](int idx) { const double v = gld(x1, idx); return d1 ? v + alpha * gld(d1, idx) : v; };    // position of the (trial) iterate
                 double xi[PD], ga[PD], dd[NS];
 #pragma unroll
                 for (int a = 0; a < PD; a++) { xi[a] = xp(a * P + i); ga[a] = 0.0; }
@@ -121,7 +121,7 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                             if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c += dl[2] * dl[2]; }   // spherical: pz[i][1:3]
                             const double c = on * (Rr * Rr - s2c);
                             const int ci = con_col<C>(N, pairq<C>(i, j), kn);
-                            const double lm = G.lam(pr)[ci], am = on * al_active_mu(c, lm, G.mu(pr)[ci]);
+                            const double lm = gld(G.lam(pr), ci), am = on * al_active_mu(c, lm, gld(G.mu(pr), ci));
                             const double wl = fma(am, c, on * lm);            // (the contraction the all-pairs form always had: lm + am c)
 #pragma unroll
                             for (int a = 0; a < PD; a++) {
@@ -146,7 +146,7 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                     // wall / circle constraints of player i on its own position at knot k+1: AL gradient C'(lambda + a mu c)
                     // and Gauss-Newton Hessian C' a mu C (constraint_derivatives.jl:10-19,47-58) join the (i,i) position block
                     auto al_row = [&](int ci, double c, const double (&g)[PD]) {
-                        const double lm = G.lam(pr)[ci], am = al_active_mu(c, lm, G.mu(pr)[ci]);
+                        const double lm = gld(G.lam(pr), ci), am = al_active_mu(c, lm, gld(G.mu(pr), ci));
                         const double wl = lm + am * c;
 #pragma unroll
                         for (int a = 0; a < PD; a++) {
@@ -239,7 +239,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
 #pragma unroll
             for (int j = 0; j < 12; j++) xj[j] = Jet{sk[i + j * P], c == j ? 1.0 : 0.0};
 #pragma unroll
-            for (int j = 0; j < 4; j++) uj[j] = Jet{z[n + hu<C>(k, i) + j], c == 12 + j ? 1.0 : 0.0};
+            for (int j = 0; j < 4; j++) uj[j] = Jet{gld(z, (int)(n + hu<C>(k, i) + j)), c == 12 + j ? 1.0 : 0.0};
             quad_rk2(xj, uj, qmass, dt, xo);
             double* __restrict__ rc = G.rec(pr) + (size_t)k * R::LEN + R::COEF + i * C::QS;
             const int o = c < 12 ? C::QA + c : C::QB + (c - 12), ld = c < 12 ? 12 : 4;
@@ -278,8 +278,8 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             l1 += fabs(r);
             if (dynrow) vdyn = fmax(vdyn, fabs(r)); else vopt = fmax(vopt, fabs(r));
         }
-        if (RECS) G.rec(pr)[q.rec_off] = r;
-        if (MODE == 2) G.res(pr)[q.vrow] = r;
+        if (RECS) gst(G.rec(pr), (int)(q.rec_off), r);
+        if (MODE == 2) gst(G.res(pr), (int)(q.vrow), r);
     };
     const double* __restrict__ recg = G.rec(pr);
     // advance (k, j) by 64 rows of a row space with LEN rows per step
@@ -310,17 +310,17 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             const uidx ro = (uidx)(k * R::LEN);
             const bool has_next = (k + 1 <= N - 2);
             const double w = (k + 1 < N - 1) ? dt : 1.0;
-            double r = -z[zo + (uidx)(n + m + ei)];
+            double r = -gld(z, (int)(zo + (uidx)(n + m + ei)));
             {
                 // A_{k+1}' lambda_{i,k+1}: addresses clamped to block k when there is no next block, the term is dropped below
                 const uidx lo = zo + (uidx)((has_next ? b : 0) + n + m + i * n), co = ro + (uidx)((has_next ? R::LEN : 0) + R::COEF);
-                const double t = AT_vec<C>(recg + co, dt, [&](int rr) { return z[lo + (uidx)rr]; }, a);
+                const double t = AT_vec<C>(recg + co, dt, [&](int rr) { return gld(z, (int)(lo + (uidx)rr)); }, a);
                 r += has_next ? t : 0.0;
             }
             const bool own = (a % P == i);
             const double tqv = G.Qd(pr)[i * ni + a / P], txv = G.xf(pr)[i * ni + a / P];
             const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
-            const double xa = z[zo + (uidx)a];
+            const double xa = gld(z, (int)(zo + (uidx)a));
             r += w * (tq * (xa - tx));
             if (C::POS) { const double gv = recg[(uidx)R::gvt(N, k) + (uidx)((i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0))]; r += (a < C::PD * P) ? gv : 0.0; }
             if constexpr (C::EXT) {
@@ -333,18 +333,18 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                         const double cv = half == 0 ? xa - ext_sbmax(pr, pr.extc)[ei] : ext_sbmin(pr, pr.extc)[ei] - xa;
                         if (MODE == 2) G.vals(pr)[ci] = cv;
                         if (isfinite(cv)) {
-                            const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
+                            const double lm = gld(G.lam(pr), ci), am = al_active_mu(cv, lm, gld(G.mu(pr), ci));
                             const double wl = lm + am * cv;
                             r += (half == 0 ? wl : -wl); qsb += am;
                             if (!IBR || i == ip) vsta = fmax(vsta, fmax(0.0, cv));
                         }
                     }
                 }
-                if (RECS && ok) G.rec(pr)[ro + (uidx)(R::RQ + ei)] = qsb;
+                if (RECS && ok) gst(G.rec(pr), (int)(ro + (uidx)(R::RQ + ei)), qsb);
             }
             q.mine = IBR ? (i == ip) : true;
             q.dprox = 0.0;
-            if (zref) { const double xr = zref[zo + (uidx)a]; q.dprox = q.mine ? xa - xr : 0.0; }
+            if (zref) { const double xr = gld(zref, (int)(zo + (uidx)a)); q.dprox = q.mine ? xa - xr : 0.0; }
             q.r = r; q.rec_off = ro + (uidx)(R::RX + ei); q.vrow = MODE == 2 ? vx<C>(N, i, k) + a : 0;
             return q;
         };
@@ -358,7 +358,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             if (!ok) { k = 0; c = 0; }
             const int i = c % P;
             const uidx zo = (uidx)(n + k * b), ro = (uidx)(k * R::LEN);
-            const double u = z[zo + (uidx)(n + uoff<C>(c))];
+            const double u = gld(z, (int)(zo + (uidx)(n + uoff<C>(c))));
             const uidx lo = zo + (uidx)(n + m + i * n);
             const double tr = G.Rd(pr)[(c % P) * mi + c / P], tu = G.uf(pr)[(c % P) * mi + c / P];
             double g = 0.0, rhat = dt * tr + jreg;
@@ -369,7 +369,7 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                     const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
                     if (MODE == 2) G.vals(pr)[ci] = cv;
                     if (isfinite(cv)) {
-                        const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
+                        const double lm = gld(G.lam(pr), ci), am = al_active_mu(cv, lm, gld(G.mu(pr), ci));
                         const double wl = lm + am * cv;
                         g += (half == 0 ? wl : -wl); rhat += am;
                         if (!IBR) vcon = fmax(vcon, fmax(0.0, cv));
@@ -377,11 +377,11 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
                     }
                 }
             }
-            q.r = dt * (tr * (u - tu)) + g + BT_vec<C>(recg + ro + (uidx)R::COEF, dt, [&](int rr) { return z[lo + (uidx)rr]; }, c);
+            q.r = dt * (tr * (u - tu)) + g + BT_vec<C>(recg + ro + (uidx)R::COEF, dt, [&](int rr) { return gld(z, (int)(lo + (uidx)rr)); }, c);
             q.mine = IBR ? (i == ip) : true;
             q.dprox = 0.0;
-            if (zref) { const double ur = zref[zo + (uidx)(n + uoff<C>(c))]; q.dprox = q.mine ? u - ur : 0.0; }
-            if (RECS && ok) G.rec(pr)[ro + (uidx)(R::RHAT + c)] = rhat;
+            if (zref) { const double ur = gld(zref, (int)(zo + (uidx)(n + uoff<C>(c)))); q.dprox = q.mine ? u - ur : 0.0; }
+            if (RECS && ok) gst(G.rec(pr), (int)(ro + (uidx)(R::RHAT + c)), rhat);
             q.rec_off = ro + (uidx)(R::RU + c); q.vrow = MODE == 2 ? vu<C>(N, i, k) + c / P : 0;
             return q;
         };
@@ -402,24 +402,24 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
             } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
                 // position rows: x + (v + dt/2 u) dt ; velocity rows: v + u dt
                 const int j = a < m ? a : a - m;
-                const double uj = z[zo + (uidx)(n + uoff<C>(j))], base = z[po + (uidx)a], vel = z[po + (uidx)(j + m)];
+                const double uj = gld(z, (int)(zo + (uidx)(n + uoff<C>(j)))), base = gld(z, (int)(po + (uidx)a)), vel = gld(z, (int)(po + (uidx)(j + m)));
                 const double vm = vel + (uj * dt) * 0.5;
                 xn = base + (a < m ? vm : uj) * dt;
             } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
                 const int blkk = a / P, i = a % P;
-                const double ua = z[zo + (uidx)(n + uoff<C>(i))], base = z[po + (uidx)a], vel = z[po + (uidx)(2 * P + i)];
+                const double ua = gld(z, (int)(zo + (uidx)(n + uoff<C>(i)))), base = gld(z, (int)(po + (uidx)a)), vel = gld(z, (int)(po + (uidx)(2 * P + i)));
                 const double vm = vel + (ua * dt) * 0.5;
                 const double cf = Ck[(blkk == 0 ? 5 : (blkk == 1 ? 6 : 4)) * P + i];    // dt cos th / dt sin th / dt sin(beta)/lr
                 xn = (blkk == 2) ? base + ua * dt : base + vm * cf;
             } else {
                 const int blkk = a / P, i = a % P;
-                const double ua = z[zo + (uidx)(n + uoff<C>(P + i))], base = z[po + (uidx)a], vel = z[po + (uidx)(3 * P + i)];
-                const double uo = z[zo + (uidx)(n + uoff<C>((blkk >= 2 ? blkk - 2 : 0) * P + i))];
+                const double ua = gld(z, (int)(zo + (uidx)(n + uoff<C>(P + i)))), base = gld(z, (int)(po + (uidx)a)), vel = gld(z, (int)(po + (uidx)(3 * P + i)));
+                const double uo = gld(z, (int)(zo + (uidx)(n + uoff<C>((blkk >= 2 ? blkk - 2 : 0) * P + i))));
                 const double vm = vel + (ua * dt) * 0.5;
                 const double cf = Ck[(blkk == 0 ? 1 : 3) * P + i];                      // dt cos(thm) / dt sin(thm)
                 xn = (blkk <= 1) ? base + vm * cf : base + uo * dt;
             }
-            q.r = xn - z[zo + (uidx)a];
+            q.r = xn - gld(z, (int)(zo + (uidx)a));
             q.mine = IBR ? (a % P == ip) : true;                           // dynamics_violation(model, pdtraj, i): entries pz[i]
             q.dprox = 0.0; q.rec_off = ro + (uidx)(R::RD + a); q.vrow = MODE == 2 ? vd<C>(N, k) + a : 0;
             return q;
@@ -476,7 +476,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
         acc.bad |= !isfinite(r);
         acc.l1 += fabs(r);
         if (dynrow) acc.vdyn = fmax(acc.vdyn, fabs(r)); else acc.vopt = fmax(acc.vopt, fabs(r));
-        if (RECS) recg[rec_off] = r;
+        if (RECS) gst(recg, (int)rec_off, r);
     };
     for (int k0 = 0; k0 < N - 1; k0 += FT) {
         const int nst = (N - 1 - k0) < FT ? (N - 1 - k0) : FT;            // steps of this chunk
@@ -493,14 +493,14 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             for (int e0 = lane; e0 < cnt; e0 += 4 * NT) {
                 double a[4], d[4];
 #pragma unroll
-                for (int t = 0; t < 4; t++) { const int e = e0 + t * NT, ec = e < cnt ? e : e0; a[t] = zs[base + ec]; d[t] = AXPY ? dz[base + ec] : 0.0; }
+                for (int t = 0; t < 4; t++) { const int e = e0 + t * NT, ec = e < cnt ? e : e0; a[t] = gld(zs + base, ec); d[t] = AXPY ? gld(dz + base, ec) : 0.0; }
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     const int e = e0 + t * NT;
                     if (e < cnt) {
                         const double v = AXPY ? a[t] + alpha * d[t] : a[t];
                         Ch.zt[e] = v;
-                        if (AXPY && e < own) zo[base + e] = v;
+                        if (AXPY && e < own) gst(zo + base, e, v);
                         const int j = e / b, o = e % b;
                         if (o < NXU && j < nst) Ch.zxu[j * NXU + o] = a[t];
                     }
@@ -508,7 +508,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             }
             if constexpr (C::POS) {
                 const int tcnt = nst * TAB;
-                for (int e = lane; e < tcnt; e += NT) Ch.gvt[e] = recg[R::gvt(N, k0) + e];            // contiguous behind the records
+                for (int e = lane; e < tcnt; e += NT) Ch.gvt[e] = gld(recg + R::gvt(N, k0), e);            // contiguous behind the records
             }
             if constexpr (NC > 0) {                                        // Jacobian coefficients of the staged steps (phase A left them in the records)
                 const int ccnt = nblk * NC;
@@ -552,7 +552,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                     const int ci = con_ctl<C>(pr, k, half * m + c);
                     const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
                     if (isfinite(cv)) {
-                        const double lm = G.lam(pr)[ci], am = al_active_mu(cv, lm, G.mu(pr)[ci]);
+                        const double lm = gld(G.lam(pr), ci), am = al_active_mu(cv, lm, gld(G.mu(pr), ci));
                         const double wl = lm + am * cv;
                         g += (half == 0 ? wl : -wl); rhat += am;
                         acc.vcon = fmax(acc.vcon, fmax(0.0, cv));
@@ -561,7 +561,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             }
             const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(Ch.coef + ks * NC, dt, [&](int rr) { return lo[rr]; }, c);
             const double dprox = prox ? u - Ch.zxu[ks * NXU + n + uoff<C>(c)] : 0.0;
-            if (RECS) recg[(size_t)k * R::LEN + R::RHAT + c] = rhat;
+            if (RECS) gst(recg, k * R::LEN + R::RHAT + c, rhat);
             finish(r, dprox, false, (unsigned)(k * R::LEN + R::RU + c));
         }
         LSP(22)
@@ -618,18 +618,18 @@ __device__ __forceinline__ void update_traj(CPR pr0, const Game& G0, int tsel, i
         for (int e0 = lane; e0 < S2; e0 += U * C::NT) {
             double2_t a[U], d[U];
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S2 ? e : e0; a[t] = s2[ec]; d[t] = d2[ec]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S2 ? e : e0; a[t] = gld_t(s2, ec); d[t] = gld_t(d2, ec); }
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S2) { double2_t v; v.x = a[t].x + alpha * d[t].x; v.y = a[t].y + alpha * d[t].y; t2[e] = v; } }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S2) { double2_t v; v.x = a[t].x + alpha * d[t].x; v.y = a[t].y + alpha * d[t].y; gst_t(t2, e, v); } }
         }
         if ((S & 1) && lane == 0) tgt[C::n + S - 1] = src[C::n + S - 1] + alpha * dz[C::n + S - 1];
     } else {
         for (int e0 = lane; e0 < S; e0 += U * C::NT) {
             double a[U], d[U];
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S ? e : e0; a[t] = src[C::n + ec]; d[t] = dz[C::n + ec]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S ? e : e0; a[t] = gld(src + C::n, ec); d[t] = gld(dz + C::n, ec); }
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S) tgt[C::n + e] = a[t] + alpha * d[t]; }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S) gst(tgt + C::n, e, a[t] + alpha * d[t]); }
         }
     }
 }

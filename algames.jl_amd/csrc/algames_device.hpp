@@ -291,6 +291,9 @@ template <class C> __device__ __forceinline__ int team_wave() { return C::NW == 
 __device__ __forceinline__ unsigned goff(int i) { unsigned o = (unsigned)i << 3; asm("" : "+v"(o)); return o; }
 __device__ __forceinline__ double gld(const double* p, int i) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(p) + goff(i)); }
 __device__ __forceinline__ void gst(double* p, int i, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(p) + goff(i)) = v; }
+// ... and for any element type (16-byte pairs of the streaming axpy)
+template <class T> __device__ __forceinline__ T gld_t(const T* p, int i) { unsigned o = (unsigned)i * (unsigned)sizeof(T); asm("" : "+v"(o)); return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + o); }
+template <class T> __device__ __forceinline__ void gst_t(T* p, int i, T v) { unsigned o = (unsigned)i * (unsigned)sizeof(T); asm("" : "+v"(o)); *reinterpret_cast<T*>(reinterpret_cast<char*>(p) + o) = v; }
 
 // ---- counter RNG shared bit-for-bit with the oracle ------------------------------
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {

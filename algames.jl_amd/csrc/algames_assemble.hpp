@@ -599,6 +599,258 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
     LSP(24)
 }
 
+// ================================================================================================
+// Line-search trials of several step sizes in ONE pass (team kernels; solver_methods.jl:105-125 evaluates them one after another).
+// The trials alpha_j = alpha_decrease^(j-1) of a line search are independent of each other: each is the norm of the regularised residual at
+// z + alpha_j dz.  On a team the trial pass is bound by latency (L2 round trips, workgroup barriers), not by arithmetic, and the receding-
+// horizon loop spends half of its slowest game's time in it (13 trials per Newton iteration on the game that sets the duration of the C5
+// loop, profiles/r05_mpc_prof_c5.txt).  This pass evaluates NA step sizes at once and leaves NOTHING behind but the NA norms: no trial
+// iterate, no records.  The search then runs the ordinary pass once, for the accepted step size, which produces the trial iterate, the
+// records and the cached statistics exactly as the sequential search's last trial does.  Every row is the expression of assemble_pass
+// evaluated on z + alpha dz formed on the fly (the value update_traj! stores and assemble_pass reads back: one fma), rows are dealt to lanes
+// and summed in the same order: the norms are bit-identical to the sequential trials', so the same step is accepted.  (line_search checks
+// that on every accepted step: alg_game_stats::reserved counts disagreements and stays 0.)
+// Phase A's per-step-size output -- Jacobian coefficients and pair-gradient tables -- goes to the gain scratch (dead outside the direction).
+//   base constraint set of the double integrator / unicycle only (collision cost, collision avoidance, control bounds)
+// ================================================================================================
+template <class C> struct LsMulti {
+    static constexpr bool ON = C::NW > 1 && !AsmLds<C>::FUSED && !C::EXT && !C::DENSE && C::POS &&
+                               (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
+    static constexpr int NA = ALG_LS_NA;                          // step sizes per pass
+    static constexpr int TAB = C::PD * C::P * C::P, SW = C::NC + TAB;          // scratch doubles per step and step size: [coef | table]
+    // source iterate and direction of the search staged in LDS ([z | dz], the kernel's Lds union: nothing else lives there during a search) when
+    // they fit: the group passes then read their operands at LDS latency (C5: 2 x 1578 doubles; C3's 2 x 4328 stay in L2)
+    static constexpr int CAP = LsLds<C>::CAP;
+    static constexpr bool LDSZ = LsLds<C>::ON;
+};
+template <class C, int NA, bool LZ>
+__device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, double alpha0, bool prox, double reg, double (&l1reg)[NA]) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    double al[NA];                                               // alpha0 alpha_decrease^q, formed like the one-by-one search forms them
+    { double a = alpha0;
+#pragma unroll
+      for (int q = 0; q < NA; q++) { al[q] = a; a *= pr.opt.alpha_decrease; } }
+    constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b, PD = C::PD, NC = C::NC, TAB = LsMulti<C>::TAB, SW = LsMulti<C>::SW, NT = C::NT;
+    static_assert(PD == 2, "planar models");
+    const int N = phase_int(pr.N), lane = phase_lane();
+    const double dt = phase_f64(pr.dt);
+    const double* __restrict__ zs = G.z(0); const double* __restrict__ dz = G.z(2);
+    const int TL = phase_int(pr.traj_len);
+    // entry of the source iterate / of the direction.  The LDS index is opaque like gld's offset: if the compiler saw that the prox term's
+    // reference x is the very load inside fma(alpha, dx, x), it would simplify fma(alpha, dx, x) - x (contraction is on) -- the one-by-one
+    // search rounds the fma, stores it, and subtracts afterwards; with shared loads 5 of 64 perturbed C5 solves disagreed in the last bit
+    auto ldz = [&](int idx) { if constexpr (LZ) { int o = idx; asm("" : "+v"(o)); return lz[o]; } else return gld(zs, idx); };
+    auto ldd = [&](int idx) { if constexpr (LZ) { int o = TL + idx; asm("" : "+v"(o)); return lz[o]; } else return gld(dz, idx); };
+    auto tv = [&](int q, int idx) { return __builtin_fma(al[q], ldd(idx), ldz(idx)); };      // entry idx of the trial iterate of step size q
+    double* __restrict__ sc = G.kgain(pr);                       // [NA][N - 1][SW]
+    const int SQ = (N - 1) * SW;
+    // ---- phase A: work item = (step k, player i), every step size inside the item.  Everything the item reads is loaded before the first
+    // step size is evaluated (the scratch stores of one step size would otherwise order the loads of the next behind them)
+    {
+        const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
+        for (int e = lane; e < (N - 1) * P; e += NT) {
+            const int k = e / P, i = e % P, kn = k + 1;
+            const double w = (kn < N - 1) ? dt : 1.0;
+            const int so = k == 0 ? 0 : n + hx<C>(k - 1), uo_ = n + hu<C>(k, i), x1 = n + hx<C>(k);
+            double sa[4], sd[4];                                   // (th, v, om, ac) of the source iterate and of the direction
+            if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
+                sa[0] = ldz(so + 2 * P + i); sd[0] = ldd(so + 2 * P + i); sa[1] = ldz(so + 3 * P + i); sd[1] = ldd(so + 3 * P + i);
+                sa[2] = ldz(uo_ + 0); sd[2] = ldd(uo_ + 0); sa[3] = ldz(uo_ + 1); sd[3] = ldd(uo_ + 1);
+            }
+            double pa[PD * P], pd_[PD * P];                        // positions of knot k + 1, all players
+#pragma unroll
+            for (int t = 0; t < PD * P; t++) { pa[t] = ldz(x1 + t); pd_[t] = ldd(x1 + t); }
+            double lmv[P > 1 ? P - 1 : 1], muv[P > 1 ? P - 1 : 1];
+#pragma unroll
+            for (int jj = 0; jj < P - 1; jj++) {
+                const int j = jj < i ? jj : jj + 1, ci = con_col<C>(N, pairq<C>(i, j), kn);
+                lmv[jj] = (pairs_on && pr.has_colavoid) ? gld(G.lam(pr), ci) : 0.0; muv[jj] = (pairs_on && pr.has_colavoid) ? gld(G.mu(pr), ci) : 0.0;
+            }
+            auto ppos = [&](int q, int idx) {                      // position entry idx (= a * P + player) of the trial iterate of step size q
+                double r = 0.0;
+#pragma unroll
+                for (int t = 0; t < PD * P; t++) if (t == idx) r = __builtin_fma(al[q], pd_[t], pa[t]);
+                return r;
+            };
+#pragma unroll
+            for (int q = 0; q < NA; q++) {
+                double* __restrict__ cf = sc + q * SQ + k * SW; double* __restrict__ tab = cf + NC;
+                if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
+                    const double th = __builtin_fma(al[q], sd[0], sa[0]), v = __builtin_fma(al[q], sd[1], sa[1]);
+                    const double om = __builtin_fma(al[q], sd[2], sa[2]), ac = __builtin_fma(al[q], sd[3], sa[3]);
+                    const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
+                    double sn, cs; sincos(thm, &sn, &cs);
+                    cf[0 * P + i] = -dt * vm * sn; cf[1 * P + i] = dt * cs;
+                    cf[2 * P + i] = dt * vm * cs;  cf[3 * P + i] = dt * sn;
+                }
+                double xi[PD], ga[PD];
+#pragma unroll
+                for (int a = 0; a < PD; a++) { xi[a] = ppos(q, a * P + i); ga[a] = 0.0; }
+#pragma unroll
+                for (int jj = 0; jj < P - 1; jj++) {
+                    const int j = jj < i ? jj : jj + 1;
+                    double gv[PD];
+#pragma unroll
+                    for (int a = 0; a < PD; a++) gv[a] = 0.0;
+                    if (pairs_on) {
+                        double dl[PD];
+#pragma unroll
+                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - ppos(q, a * P + j);
+                        const double dl0 = dl[0], dl1 = dl[1];
+                        const double s2 = dl0 * dl0 + dl1 * dl1;
+                        if (pr.has_colcost) {
+                            const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+                            if (fmax(0.0, rad - nrm) > 0.0) {
+                                const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
+                                const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
+                                const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
+                                gv[0] += w * (-g0); gv[1] += w * (-g1);
+                            }
+                        }
+                        if (pr.has_colavoid) {
+                            const double Rr = pr.ca_pair_r[i * MAXP + j];
+                            const double on = (double)((pr.ca_mask[i] >> j) & 1u);
+                            const double c = on * (Rr * Rr - s2);
+                            const double lm = lmv[jj], am = on * al_active_mu(c, lm, muv[jj]);
+                            const double wl = fma(am, c, on * lm);
+#pragma unroll
+                            for (int a = 0; a < PD; a++) gv[a] += -2.0 * dl[a] * wl;
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < PD; a++) { ga[a] += gv[a]; tab[(i * P + j) * PD + a] = -gv[a]; }
+                }
+#pragma unroll
+                for (int a = 0; a < PD; a++) tab[(i * P + i) * PD + a] = ga[a];
+            }
+        }
+        game_sync();
+    }
+    double l1[NA];
+#pragma unroll
+    for (int q = 0; q < NA; q++) l1[q] = 0.0;
+    auto add = [&](int q, double r, double dprox) { const double rr = prox ? r + reg * dprox : r; l1[q] += fabs(rr); };
+    // ---- rows opt_i,x_{k+1}[a]
+    for (int e = lane; e < (N - 1) * P * n; e += NT) {
+        const int k = e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n;
+        const int zo = n + k * b;
+        const bool has_next = (k + 1 <= N - 2);
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
+        const int lo = zo + (has_next ? b : 0) + n + m + i * n;
+        const bool own = (a % P == i);
+        const double tqv = G.Qd(pr)[i * ni + a / P], txv = G.xf(pr)[i * ni + a / P];
+        const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
+        const double xr = ldz(zo + a);
+#pragma unroll
+        for (int q = 0; q < NA; q++) {
+            const double* cfq = sc + q * SQ + (k + (has_next ? 1 : 0)) * SW; const double* tabq = sc + q * SQ + k * SW + NC;
+            double r = -tv(q, zo + n + m + ei);
+            {
+                const double t = AT_vec<C>(cfq, dt, [&](int rr) { return tv(q, lo + rr); }, a);
+                r += has_next ? t : 0.0;
+            }
+            const double xa = tv(q, zo + a);
+            r += w * (tq * (xa - tx));
+            { const double gv = tabq[(i * P + a % P) * PD + (a < PD * P ? a / P : 0)]; r += (a < PD * P) ? gv : 0.0; }
+            add(q, r, xa - xr);
+        }
+    }
+    // ---- rows opt_i,u_{i,k}[c]
+    for (int e = lane; e < (N - 1) * m; e += NT) {
+        const int k = e / m, c = e % m, i = c % P;
+        const int zo = n + k * b, lo = zo + n + m + i * n, uo = zo + n + uoff<C>(c);
+        const double tr = G.Rd(pr)[(c % P) * mi + c / P], tu = G.uf(pr)[(c % P) * mi + c / P];
+        const double ur = ldz(uo);
+        double lmc[2] = {0.0, 0.0}, muc[2] = {0.0, 0.0};                 // multipliers of the two control bounds of this control (shared by the step sizes)
+        if (pr.has_ctl) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) { const int ci = con_ctl<C>(pr, k, half * m + c); lmc[half] = gld(G.lam(pr), ci); muc[half] = gld(G.mu(pr), ci); }
+        }
+#pragma unroll
+        for (int q = 0; q < NA; q++) {
+            const double u = tv(q, uo);
+            double g = 0.0;
+            if (pr.has_ctl) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                    if (isfinite(cv)) {
+                        const double lm = lmc[half], am = al_active_mu(cv, lm, muc[half]);
+                        const double wl = lm + am * cv;
+                        g += (half == 0 ? wl : -wl);
+                    }
+                }
+            }
+            const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(sc + q * SQ + k * SW, dt, [&](int rr) { return tv(q, lo + rr); }, c);
+            add(q, r, u - ur);
+        }
+    }
+    // ---- rows dyn_k[a]
+    for (int e = lane; e < (N - 1) * n; e += NT) {
+        const int k = e / n, a = e % n;
+        const int zo = n + k * b, po = (k == 0) ? 0 : zo - b;
+#pragma unroll
+        for (int q = 0; q < NA; q++) {
+            double xn;
+            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                const int j = a < m ? a : a - m;
+                const double uj = tv(q, zo + n + uoff<C>(j)), base = tv(q, po + a), vel = tv(q, po + j + m);
+                const double vm = vel + (uj * dt) * 0.5;
+                xn = base + (a < m ? vm : uj) * dt;
+            } else {
+                const double* Ck = sc + q * SQ + k * SW;
+                const int blkk = a / P, i = a % P;
+                const double ua = tv(q, zo + n + uoff<C>(P + i)), base = tv(q, po + a), vel = tv(q, po + 3 * P + i);
+                const double uo = tv(q, zo + n + uoff<C>((blkk >= 2 ? blkk - 2 : 0) * P + i));
+                const double vm = vel + (ua * dt) * 0.5;
+                const double cf = Ck[(blkk == 0 ? 1 : 3) * P + i];
+                xn = (blkk <= 1) ? base + vm * cf : base + uo * dt;
+            }
+            add(q, xn - tv(q, zo + a), 0.0);
+        }
+    }
+    // ---- the team's sums, wavefront by wavefront like team_combine
+    __shared__ double redm[C::NW][NA];
+    {
+        double ws[NA];
+#pragma unroll
+        for (int q = 0; q < NA; q++) ws[q] = wave_sum(l1[q]);
+        const int wv = game_tid() >> 6, l = game_tid() & 63;
+        if (l == 0) {
+#pragma unroll
+            for (int q = 0; q < NA; q++) redm[wv][q] = ws[q];
+        }
+        game_sync();
+#pragma unroll
+        for (int q = 0; q < NA; q++) {
+            double t = 0.0;
+#pragma unroll
+            for (int x = 0; x < C::NW; x++) t += redm[x][q];
+            l1reg[q] = t;
+        }
+        game_sync();
+    }
+}
+
+// [z | dz] of the search into LDS (every thread of the team; the caller's barrier is inside)
+template <class C>
+__device__ __forceinline__ void ls_stage_traj(CPR pr0, const Game& G0, double* lz) {
+    CPR pr = phase_params(pr0);
+    const Game G = G0.fresh();
+    const double* __restrict__ zs = G.z(0); const double* __restrict__ dz = G.z(2);
+    const int TL = phase_int(pr.traj_len), lane = phase_lane();
+    constexpr int U = 4;
+    for (int e0 = lane; e0 < TL; e0 += U * C::NT) {
+        double a[U], d[U];
+#pragma unroll
+        for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT, ec = e < TL ? e : e0; a[t] = gld(zs, ec); d[t] = gld(dz, ec); }
+#pragma unroll
+        for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < TL) { lz[e] = a[t]; lz[TL + e] = d[t]; } }
+    }
+    game_sync();
+}
+
 // update_traj!(target, source, alpha, delta) (primal_dual_traj.jl:109-128): coalesced axpy over the S entries
 typedef double double2_t __attribute__((ext_vector_type(2)));
 template <class C>

@@ -33,6 +33,13 @@
 // ALG_DIR_STOP (direction cut after a sweep, for per-sweep counters) and ALG_NO_REFINE (refinement gate compiled out).  The A/B switches
 // of rounds 3 - 4 whose outcome is recorded in DESIGN.md section 8 were resolved to their shipped side in round 5.
 
+#ifndef ALG_LS_CAP
+#define ALG_LS_CAP 3200   // doubles of LDS for [z | dz] of a line search (LsLds)
+#endif
+#ifndef ALG_LS_NA
+#define ALG_LS_NA 4        // step sizes per group pass of the team kernels' line search (LsMulti, algames_assemble.hpp)
+#endif
+
 namespace alg {
 
 constexpr int WAVE = 64;
@@ -60,6 +67,7 @@ struct Params {
     double refine_mu;       // ... relaxed up to 256 x in proportion while the game's largest penalty stays below this
     int kscratch_len;       // per game doubles of gain scratch
     int rec_len;            // per game doubles of step records
+    int ls_multi;           // line search of the team kernels: further step sizes are tried LsMulti::NA at a time once the first one was rejected (0 = one after another)
     unsigned long long ibr_ctl_rows[MAXP];   // control-bound rows counted by control_violation(game_con, pdtraj, i) (violations.jl:69-82)
     // extended ingredient set (Cfg::EXT instantiations only)
     int ext, has_sb, nwall, ncirc, sb_len, wall_len, circ_len;
@@ -856,12 +864,19 @@ struct AsmLds {
         typename std::conditional<FUSED, Chunk, NoChunk>::type ch;
     };
 };
-template <class C> union Lds { DirLds<C> d; AsmLds<C> a; };
+// (team kernels of the base double integrator / unicycle: the line search stages [z | dz] of a search here, LsMulti in algames_assemble.hpp)
+template <class C> struct LsLds {
+    // (kernels of up to three players: a 4-player unicycle trajectory, b = 88 doubles per step, outgrows the buffer from N = 19 on)
+    static constexpr bool ON = C::NW > 1 && C::P <= 3 && !AsmLds<C>::FUSED && !C::EXT && !C::DENSE && C::POS && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
+    static constexpr int CAP = ALG_LS_CAP;
+    double z[ON ? CAP : 1];
+};
+template <class C> union Lds { DirLds<C> d; AsmLds<C> a; LsLds<C> ls; };
 
 // Pass-level instrumentation of the solver (same build flag): shader-clock cycles of the axpy / assemble phases / Newton direction as
 // seen by thread 0 of the game, accumulated in LDS and flushed into G.res(pr)[16..] at the end of every newton_solve (slots:
 // 16 axpy + barrier, 17 trial assemble, 18 #trials, 20 phase A, 21 rows x, 22 rows u, 23 rows d, 24 reductions, 25 #passes,
-// 26 direction, 27 record pass, 28 #directions, 29 #record passes)
+// 26 direction, 27 record pass, 28 #directions, 29 #record passes, 19 init_traj + rollout, 30 group passes of the line search (counted in 18), 31 whole solve)
 #ifdef ALG_PHASE_PROF
 __device__ __forceinline__ unsigned* lsp_slots() { __shared__ unsigned slots[32]; return slots; }
 __device__ __forceinline__ unsigned lsp_now() { return (unsigned)__builtin_readcyclecounter(); }

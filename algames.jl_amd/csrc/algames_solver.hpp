@@ -74,6 +74,8 @@ template <class C>
 __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double res_norm0, double jreg_next,
                             double* alpha_out, int* j_out) {
     int j = 1; double alpha = 1.0;
+    bool staged = false;                                  // (LsMulti: [z | dz] of this search are in LDS)
+    bool expect_on = false; double expect = 0.0;          // (LsMulti: norm the group pass computed for the step size the next trial evaluates)
     while (j < pr.opt.ls_iter) {
         const auto& o = phase_params(pr).opt;
         LSP_T0 LSP_COUNT(18)
@@ -95,8 +97,47 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
         LSP(17)
         if (jreg_next >= 0.0) tcache_store(pr, G, ro);
         const double rt = uni(ro.l1reg / (double)phase_int(phase_params(pr).S));
+        if constexpr (LsMulti<C>::ON) {
+            // the group pass below said this step size passes the test: the two passes must have produced the same norm, bit for bit
+            if (expect_on) { expect_on = false; if (ro.l1reg != expect && phase_lane() == 0) G.fresh().st(phase_params(pr))->reserved += 1; }
+        }
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;
+        if constexpr (LsMulti<C>::ON) {
+            // The first step size was rejected: the following ones are tried LsMulti::NA at a time by a pass that leaves only their norms
+            // (trial_norms_multi) until one passes the test -- the loop's next trial is then that one, with its outputs -- or none is left.
+            // (j, alpha) move exactly as the one-by-one search moves them.
+            if (phase_int(phase_params(pr).ls_multi)) {
+                constexpr int NA = LsMulti<C>::NA;
+                const bool lds_fit = 2 * phase_int(phase_params(pr).traj_len) <= LsMulti<C>::CAP;
+                while (j < phase_int(phase_params(pr).opt.ls_iter)) {
+                    const auto& om = phase_params(pr).opt;
+                    double nr[NA];
+                    const int left = om.ls_iter - j, nc = left < NA ? left : NA;
+                    LSP_T0 LSP_COUNT(18)
+                    bool in_lds = false;
+                    if constexpr (LsMulti<C>::LDSZ) {
+                        if (lds_fit) {
+                            if (!staged) { ls_stage_traj<C>(pr, G, L.ls.z); staged = true; }
+                            trial_norms_multi<C, NA, true>(pr, G, L.ls.z, alpha, om.regularize != 0, reg, nr);
+                            in_lds = true;
+                        }
+                    }
+                    if (!in_lds) trial_norms_multi<C, NA, false>(pr, G, nullptr, alpha, om.regularize != 0, reg, nr);
+                    LSP(30)
+                    int hit = -1; double a = alpha, ahit = alpha, last = alpha;
+#pragma unroll
+                    for (int q = 0; q < NA; q++) {
+                        const double rq = uni(nr[q] / (double)phase_int(phase_params(pr).S));
+                        if (hit < 0 && q < nc && rq <= (1.0 - a * om.beta) * res_norm0) { hit = q; ahit = a; expect = nr[q]; }
+                        if (q < nc) last = a;
+                        a *= om.alpha_decrease;
+                    }
+                    if (hit >= 0) { alpha = ahit; j += hit; expect_on = true; break; }
+                    alpha = last * om.alpha_decrease; j += nc;
+                }
+            }
+        }
     }
     *alpha_out = alpha; *j_out = j;
 }
@@ -342,6 +383,10 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     if (lane < 16) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums (16..: pass-level sums over the handle's lifetime)
     if (game_tid() < 32) lsp_slots()[game_tid()] = 0u;
 #endif
+    LSP_T0
+#ifdef ALG_PHASE_PROF
+    const unsigned lsp_solve0 = lsp_now();
+#endif
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
     else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
     if (lane < C::n) { G.z(1)[lane] = G.x0(pr)[lane]; G.z(2)[lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
@@ -349,6 +394,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     rollout<C>(pr, G.z(0));                                                // :17
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con<C::NT>(pr, G);     // :25
     game_sync();
+    LSP(19)
     int out = 0, status = ALG_STATUS_OK, fresh = 0; double Delta = 0.0;
     for (int k = 1; k <= o.outer_iter; k++) {                              // :30
         out = k;
@@ -396,6 +442,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     settle_traj<C>(pr, G);
     if (phase_lane() == 0) { alg_game_stats* st = G.fresh().st(phase_params(pr)); st->status = status; st->outer_iters = out; }
 #ifdef ALG_PHASE_PROF
+    lsp_add(31, lsp_solve0);            // the whole solve
     game_sync();
     if (game_tid() >= 16 && game_tid() < 32) G.fresh().res(phase_params(pr))[game_tid()] += (double)lsp_slots()[game_tid()];
     game_sync();

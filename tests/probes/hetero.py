@@ -27,6 +27,11 @@ for cfg, B, spread in (("C2", 4096, 0.0), ("C2", 4096, 0.3), ("C2", 4096, 0.6), 
     st = prob.batch.get_stats(); print("converged %d / %d, status!=0: %d" % (st["converged"].sum(), B, (st["status"] != 0).sum()), end=" ")
     print("%s B=%d: iterations min %d median %d mean %.1f max %d | %.3f ms per solve | %.3g game-iterations/s | ideal if the slowest game alone set the time: mean/max = %.2f"
           % (cfg, B, it.min(), np.median(it), it.mean(), it.max(), dt * 1e3, it.sum() / dt, it.mean() / it.max()))
+    if spread:
+        o = np.argsort(-it)[:3]
+        for g in o:
+            h = prob.batch.get_history(int(g)); js = h["ls_j"][h["ls_j"] > 0]
+            print("   game %d: %d iterations, %.2f line-search trials per iteration (max %d), %d failed searches" % (g, it[g], js.mean() if len(js) else 0, js.max() if len(js) else 0, st["ls_failures"][g]))
     hist = np.bincount(it)
     print("   histogram (iters:count)", {int(k): int(v) for k, v in enumerate(hist) if v})
 # ---- what removes the tail: more games than resident slots (the dispatcher backfills), or a second batch in flight on another stream

@@ -1,0 +1,9 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/r05_lsm
+ALGAMES_HIP_LIB=$R/algames.jl_amd/lib/variants/t3.so timeout 900 python -m pytest tests/test_gpu_line_search_batch.py -m gpu -q -x 2>&1 | tail -3
+for i in 1 2 3; do for v in nolds t3; do
+ALGAMES_HIP_LIB=$R/algames.jl_amd/lib/variants/$v.so python bench.py --config C5 --mpc-steps 200 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C5 loop $v:', '%.4g' % j['value'], '%.1f ms' % j['ms_per_step'])"
+done; done 2>&1 | tee gpurun_out/r05_lsm/ab_lds_c5loop.txt
+for c in "C5 --games-per-gpu 1024" "C2 --games-per-gpu 512" "C5 --games-per-gpu 256"; do for v in nolds t3; do
+ALGAMES_HIP_LIB=$R/algames.jl_amd/lib/variants/$v.so python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --no-pmc 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c $v:', '%.4g' % j['value'], j['ms_per_step'])"
+done; done 2>&1 | tee gpurun_out/r05_lsm/ab_lds_other.txt

@@ -33,6 +33,9 @@
 // ALG_DIR_STOP (direction cut after a sweep, for per-sweep counters) and ALG_NO_REFINE (refinement gate compiled out).  The A/B switches
 // of rounds 3 - 4 whose outcome is recorded in DESIGN.md section 8 were resolved to their shipped side in round 5.
 
+#ifndef ALG_FT_DI3
+#define ALG_FT_DI3 10      // time steps per chunk of the fused trial pass, 3-player double integrator
+#endif
 #ifndef ALG_LS_CAP
 #define ALG_LS_CAP 3200   // doubles of LDS for [z | dz] of a line search (LsLds)
 #endif
@@ -856,7 +859,7 @@ struct AsmLds {
     // A_{k+1}' lambda_{k+1}), the [x | u] parts of the proximal reference, the pair-gradient tables and the LQR constants.
     // (one wavefront per game only: on a team the chunks' workgroup barriers cost more than the pass saves -- C5 loop, team of four: 105 vs 152 K/s)
     static constexpr bool FUSED = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE) && !C::EXT && !C::DENSE && (C::NW == 1 || 0);
-    static constexpr int FT = 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
+    static constexpr int FT = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && C::P == 3 && C::D == 2) ? ALG_FT_DI3 : 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
     struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[(FT + 1) * NCF], lqr[NLQR]; };
     struct NoChunk {};
     union {

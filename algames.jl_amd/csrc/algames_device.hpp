@@ -34,7 +34,13 @@
 // of rounds 3 - 4 whose outcome is recorded in DESIGN.md section 8 were resolved to their shipped side in round 5.
 
 #ifndef ALG_FT_DI3
-#define ALG_FT_DI3 10      // time steps per chunk of the fused trial pass, 3-player double integrator
+#define ALG_FT_DI3 13      // time steps per chunk of the fused trial pass, 3-player double integrator (the chunk buffers fill the LDS that sixteen games per CU leave)
+#endif
+#ifndef ALG_FT_UNI3
+#define ALG_FT_UNI3 15      // 3-player unicycle: twelve games per CU (3 x 152 VGPRs per SIMD) leave 13.3 KB each; N = 30 is two chunks
+#endif
+#ifndef ALG_FT_UNI4
+#define ALG_FT_UNI4 13      // 4-player unicycle: the chunk buffers stay under the direction's 18.2 KB
 #endif
 #ifndef ALG_LS_CAP
 #define ALG_LS_CAP 3200   // doubles of LDS for [z | dz] of a line search (LsLds)
@@ -859,8 +865,8 @@ struct AsmLds {
     // A_{k+1}' lambda_{k+1}), the [x | u] parts of the proximal reference, the pair-gradient tables and the LQR constants.
     // (one wavefront per game only: on a team the chunks' workgroup barriers cost more than the pass saves -- C5 loop, team of four: 105 vs 152 K/s)
     static constexpr bool FUSED = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE) && !C::EXT && !C::DENSE && (C::NW == 1 || 0);
-    static constexpr int FT = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && C::P == 3 && C::D == 2) ? ALG_FT_DI3 : 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
-    struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[(FT + 1) * NCF], lqr[NLQR]; };
+    static constexpr int FT = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && C::P == 3 && C::D == 2) ? ALG_FT_DI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 3) ? ALG_FT_UNI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4) ? ALG_FT_UNI4 : 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
+    struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[C::NC > 0 ? (FT + 1) * NCF : 1], lqr[NLQR]; };
     struct NoChunk {};
     union {
         double stage[STAGED ? SPP * SL : 1];

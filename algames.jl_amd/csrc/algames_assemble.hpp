@@ -616,7 +616,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
 template <class C> struct LsMulti {
     static constexpr bool ON = C::NW > 1 && !AsmLds<C>::FUSED && !C::EXT && !C::DENSE && C::POS &&
                                (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
-    static constexpr int NA = ALG_LS_NA;                          // step sizes per pass
+    static constexpr int NA = LS_NA;                          // step sizes per pass
     static constexpr int TAB = C::PD * C::P * C::P, SW = C::NC + TAB;          // scratch doubles per step and step size: [coef | table]
     // source iterate and direction of the search staged in LDS ([z | dz], the kernel's Lds union: nothing else lives there during a search) when
     // they fit: the group passes then read their operands at LDS latency (C5: 2 x 1578 doubles; C3's 2 x 4328 stay in L2)

@@ -33,23 +33,14 @@
 // ALG_DIR_STOP (direction cut after a sweep, for per-sweep counters) and ALG_NO_REFINE (refinement gate compiled out).  The A/B switches
 // of rounds 3 - 4 whose outcome is recorded in DESIGN.md section 8 were resolved to their shipped side in round 5.
 
-#ifndef ALG_FT_DI3
-#define ALG_FT_DI3 13      // time steps per chunk of the fused trial pass, 3-player double integrator (the chunk buffers fill the LDS that sixteen games per CU leave)
-#endif
-#ifndef ALG_FT_UNI3
-#define ALG_FT_UNI3 15      // 3-player unicycle: twelve games per CU (3 x 152 VGPRs per SIMD) leave 13.3 KB each; N = 30 is two chunks
-#endif
-#ifndef ALG_FT_UNI4
-#define ALG_FT_UNI4 13      // 4-player unicycle: the chunk buffers stay under the direction's 18.2 KB
-#endif
-#ifndef ALG_LS_CAP
-#define ALG_LS_CAP 3200   // doubles of LDS for [z | dz] of a line search (LsLds)
-#endif
-#ifndef ALG_LS_NA
-#define ALG_LS_NA 4        // step sizes per group pass of the team kernels' line search (LsMulti, algames_assemble.hpp)
-#endif
-
 namespace alg {
+
+// Tunables of round 5 (measured: DESIGN.md section 4, "Chunks of the fused trial pass" / "step sizes in groups")
+constexpr int FT_DI3 = 13;     // time steps per chunk of the fused trial pass, 3-player double integrator (the chunk buffers fill the LDS that sixteen games per CU leave)
+constexpr int FT_UNI3 = 15;    // 3-player unicycle: twelve games per CU (3 x 152 VGPRs per SIMD) leave 13.3 KB each; N = 30 is two chunks
+constexpr int FT_UNI4 = 13;    // 4-player unicycle: the chunk buffers stay under the direction's 18.2 KB
+constexpr int LS_CAP = 3200;   // doubles of LDS for [z | dz] of a line search (LsLds)
+constexpr int LS_NA = 4;       // step sizes per group pass of the team kernels' line search (LsMulti, algames_assemble.hpp)
 
 constexpr int WAVE = 64;
 constexpr int MAXP = 10;    // alphax_dual caps p <= 10 (options.jl:68)
@@ -865,7 +856,7 @@ struct AsmLds {
     // A_{k+1}' lambda_{k+1}), the [x | u] parts of the proximal reference, the pair-gradient tables and the LQR constants.
     // (one wavefront per game only: on a team the chunks' workgroup barriers cost more than the pass saves -- C5 loop, team of four: 105 vs 152 K/s)
     static constexpr bool FUSED = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE) && !C::EXT && !C::DENSE && (C::NW == 1 || 0);
-    static constexpr int FT = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && C::P == 3 && C::D == 2) ? ALG_FT_DI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 3) ? ALG_FT_UNI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4) ? ALG_FT_UNI4 : 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
+    static constexpr int FT = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && C::P == 3 && C::D == 2) ? FT_DI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 3) ? FT_UNI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4) ? FT_UNI4 : 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
     struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[C::NC > 0 ? (FT + 1) * NCF : 1], lqr[NLQR]; };
     struct NoChunk {};
     union {
@@ -877,7 +868,7 @@ struct AsmLds {
 template <class C> struct LsLds {
     // (kernels of up to three players: a 4-player unicycle trajectory, b = 88 doubles per step, outgrows the buffer from N = 19 on)
     static constexpr bool ON = C::NW > 1 && C::P <= 3 && !AsmLds<C>::FUSED && !C::EXT && !C::DENSE && C::POS && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
-    static constexpr int CAP = ALG_LS_CAP;
+    static constexpr int CAP = LS_CAP;
     double z[ON ? CAP : 1];
 };
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; LsLds<C> ls; };

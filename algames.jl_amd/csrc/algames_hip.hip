@@ -85,7 +85,7 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.kscratch_len = (p.N - 1) * p.m * std::max(p.n + 1, 16);            // gains m x (n + 1) per step; the quad-team kernels store rows of 16
     {   // the team kernels' line search parks the Jacobian coefficients and pair-gradient tables of LsMulti::NA trial step sizes there (trial_norms_multi)
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : 0;
-        if ((p.model == ALG_MODEL_UNICYCLE || p.model == ALG_MODEL_DOUBLE_INTEGRATOR) && p.d == 2) p.kscratch_len = std::max(p.kscratch_len, ALG_LS_NA * (p.N - 1) * (nc + 2 * p.p * p.p));
+        if ((p.model == ALG_MODEL_UNICYCLE || p.model == ALG_MODEL_DOUBLE_INTEGRATOR) && p.d == 2) p.kscratch_len = std::max(p.kscratch_len, LS_NA * (p.N - 1) * (nc + 2 * p.p * p.p));
     }
     p.ls_multi = 1;
     if (const char* e = getenv("ALGAMES_LS_MULTI")) {               // A/B runs and the bitwise comparison of tests/test_gpu_line_search_batch.py

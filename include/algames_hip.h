@@ -132,7 +132,7 @@ typedef struct alg_game_stats {
     int32_t converged;     /* exit test solver_methods.jl:49-53 met (not the k==outer_iter arm) */
     int32_t ls_failures;   /* failed line searches                                      */
     int32_t refinements;   /* correction solves of the Newton direction's iterative refinement (alg_set_refinement; 0 for the CPU oracle, whose pivoted LU needs none) */
-    int32_t reserved;
+    int32_t reserved;      /* 0.  (Team kernels: counts line-search steps whose norm from the group pass differed from the ordinary pass's -- a self-check that must stay 0, tests/test_gpu_line_search_batch.py) */
     alg_record last;       /* final record! (solver_methods.jl:63)                      */
 } alg_game_stats;
 

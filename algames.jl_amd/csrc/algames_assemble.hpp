@@ -624,7 +624,7 @@ template <class C> struct LsMulti {
     static constexpr bool LDSZ = LsLds<C>::ON;
 };
 template <class C, int NA, bool LZ>
-__device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, double alpha0, bool prox, double reg, double (&l1reg)[NA]) {
+__device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, double* lsc, double alpha0, bool prox, double reg, double (&l1reg)[NA]) {
     CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
     double al[NA];                                               // alpha0 alpha_decrease^q, formed like the one-by-one search forms them
@@ -643,87 +643,72 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
     auto ldz = [&](int idx) { if constexpr (LZ) { int o = idx; asm("" : "+v"(o)); return lz[o]; } else return gld(zs, idx); };
     auto ldd = [&](int idx) { if constexpr (LZ) { int o = TL + idx; asm("" : "+v"(o)); return lz[o]; } else return gld(dz, idx); };
     auto tv = [&](int q, int idx) { return __builtin_fma(al[q], ldd(idx), ldz(idx)); };      // entry idx of the trial iterate of step size q
-    double* __restrict__ sc = G.kgain(pr);                       // [NA][N - 1][SW]
+    constexpr bool LSC = LZ && LsLds<C>::SC_ON;                  // the tables of the step sizes in LDS as well (teams of four)
+    double* __restrict__ sc;                                     // [NA][N - 1][SW]
+    if constexpr (LSC) sc = lsc; else sc = G.kgain(pr);
     const int SQ = (N - 1) * SW;
-    // ---- phase A: work item = (step k, player i), every step size inside the item.  Everything the item reads is loaded before the first
-    // step size is evaluated (the scratch stores of one step size would otherwise order the loads of the next behind them)
+    // ---- phase A: work item = (step size q, step k, player i) -- NA x (N - 1) x P items over the team's lanes (with the step sizes inside an
+    // item only (N - 1) P of the team's 64 NW lanes had work)
     {
         const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
-        for (int e = lane; e < (N - 1) * P; e += NT) {
-            const int k = e / P, i = e % P, kn = k + 1;
+        const int KP = (N - 1) * P;
+        for (int e = lane; e < NA * KP; e += NT) {
+            const int q = e / KP, ek = e - q * KP, k = ek / P, i = ek % P, kn = k + 1;
+            double aq = al[0];
+#pragma unroll
+            for (int t = 1; t < NA; t++) aq = (t == q) ? al[t] : aq;
+            auto tq_ = [&](int idx) { return __builtin_fma(aq, ldd(idx), ldz(idx)); };
             const double w = (kn < N - 1) ? dt : 1.0;
             const int so = k == 0 ? 0 : n + hx<C>(k - 1), uo_ = n + hu<C>(k, i), x1 = n + hx<C>(k);
-            double sa[4], sd[4];                                   // (th, v, om, ac) of the source iterate and of the direction
+            double* __restrict__ cf = sc + q * SQ + k * SW; double* __restrict__ tab = cf + NC;
             if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
-                sa[0] = ldz(so + 2 * P + i); sd[0] = ldd(so + 2 * P + i); sa[1] = ldz(so + 3 * P + i); sd[1] = ldd(so + 3 * P + i);
-                sa[2] = ldz(uo_ + 0); sd[2] = ldd(uo_ + 0); sa[3] = ldz(uo_ + 1); sd[3] = ldd(uo_ + 1);
+                const double th = tq_(so + 2 * P + i), v = tq_(so + 3 * P + i);
+                const double om = tq_(uo_ + 0), ac = tq_(uo_ + 1);
+                const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
+                double sn, cs; sincos(thm, &sn, &cs);
+                cf[0 * P + i] = -dt * vm * sn; cf[1 * P + i] = dt * cs;
+                cf[2 * P + i] = dt * vm * cs;  cf[3 * P + i] = dt * sn;
             }
-            double pa[PD * P], pd_[PD * P];                        // positions of knot k + 1, all players
+            double xi[PD], ga[PD];
 #pragma unroll
-            for (int t = 0; t < PD * P; t++) { pa[t] = ldz(x1 + t); pd_[t] = ldd(x1 + t); }
-            double lmv[P > 1 ? P - 1 : 1], muv[P > 1 ? P - 1 : 1];
+            for (int a = 0; a < PD; a++) { xi[a] = tq_(x1 + a * P + i); ga[a] = 0.0; }
 #pragma unroll
             for (int jj = 0; jj < P - 1; jj++) {
-                const int j = jj < i ? jj : jj + 1, ci = con_col<C>(N, pairq<C>(i, j), kn);
-                lmv[jj] = (pairs_on && pr.has_colavoid) ? gld(G.lam(pr), ci) : 0.0; muv[jj] = (pairs_on && pr.has_colavoid) ? gld(G.mu(pr), ci) : 0.0;
-            }
-            auto ppos = [&](int q, int idx) {                      // position entry idx (= a * P + player) of the trial iterate of step size q
-                double r = 0.0;
+                const int j = jj < i ? jj : jj + 1;
+                double gv[PD];
 #pragma unroll
-                for (int t = 0; t < PD * P; t++) if (t == idx) r = __builtin_fma(al[q], pd_[t], pa[t]);
-                return r;
-            };
+                for (int a = 0; a < PD; a++) gv[a] = 0.0;
+                if (pairs_on) {
+                    double dl[PD];
 #pragma unroll
-            for (int q = 0; q < NA; q++) {
-                double* __restrict__ cf = sc + q * SQ + k * SW; double* __restrict__ tab = cf + NC;
-                if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
-                    const double th = __builtin_fma(al[q], sd[0], sa[0]), v = __builtin_fma(al[q], sd[1], sa[1]);
-                    const double om = __builtin_fma(al[q], sd[2], sa[2]), ac = __builtin_fma(al[q], sd[3], sa[3]);
-                    const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
-                    double sn, cs; sincos(thm, &sn, &cs);
-                    cf[0 * P + i] = -dt * vm * sn; cf[1 * P + i] = dt * cs;
-                    cf[2 * P + i] = dt * vm * cs;  cf[3 * P + i] = dt * sn;
-                }
-                double xi[PD], ga[PD];
-#pragma unroll
-                for (int a = 0; a < PD; a++) { xi[a] = ppos(q, a * P + i); ga[a] = 0.0; }
-#pragma unroll
-                for (int jj = 0; jj < P - 1; jj++) {
-                    const int j = jj < i ? jj : jj + 1;
-                    double gv[PD];
-#pragma unroll
-                    for (int a = 0; a < PD; a++) gv[a] = 0.0;
-                    if (pairs_on) {
-                        double dl[PD];
-#pragma unroll
-                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - ppos(q, a * P + j);
-                        const double dl0 = dl[0], dl1 = dl[1];
-                        const double s2 = dl0 * dl0 + dl1 * dl1;
-                        if (pr.has_colcost) {
-                            const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
-                            if (fmax(0.0, rad - nrm) > 0.0) {
-                                const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
-                                const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
-                                const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
-                                gv[0] += w * (-g0); gv[1] += w * (-g1);
-                            }
-                        }
-                        if (pr.has_colavoid) {
-                            const double Rr = pr.ca_pair_r[i * MAXP + j];
-                            const double on = (double)((pr.ca_mask[i] >> j) & 1u);
-                            const double c = on * (Rr * Rr - s2);
-                            const double lm = lmv[jj], am = on * al_active_mu(c, lm, muv[jj]);
-                            const double wl = fma(am, c, on * lm);
-#pragma unroll
-                            for (int a = 0; a < PD; a++) gv[a] += -2.0 * dl[a] * wl;
+                    for (int a = 0; a < PD; a++) dl[a] = xi[a] - tq_(x1 + a * P + j);
+                    const double dl0 = dl[0], dl1 = dl[1];
+                    const double s2 = dl0 * dl0 + dl1 * dl1;
+                    if (pr.has_colcost) {
+                        const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+                        if (fmax(0.0, rad - nrm) > 0.0) {
+                            const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
+                            const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
+                            const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
+                            gv[0] += w * (-g0); gv[1] += w * (-g1);
                         }
                     }
+                    if (pr.has_colavoid) {
+                        const double Rr = pr.ca_pair_r[i * MAXP + j];
+                        const double on = (double)((pr.ca_mask[i] >> j) & 1u);
+                        const double c = on * (Rr * Rr - s2);
+                        const int ci = con_col<C>(N, pairq<C>(i, j), kn);
+                        const double lm = gld(G.lam(pr), ci), am = on * al_active_mu(c, lm, gld(G.mu(pr), ci));
+                        const double wl = fma(am, c, on * lm);
 #pragma unroll
-                    for (int a = 0; a < PD; a++) { ga[a] += gv[a]; tab[(i * P + j) * PD + a] = -gv[a]; }
+                        for (int a = 0; a < PD; a++) gv[a] += -2.0 * dl[a] * wl;
+                    }
                 }
 #pragma unroll
-                for (int a = 0; a < PD; a++) tab[(i * P + i) * PD + a] = ga[a];
+                for (int a = 0; a < PD; a++) { ga[a] += gv[a]; tab[(i * P + j) * PD + a] = -gv[a]; }
             }
+#pragma unroll
+            for (int a = 0; a < PD; a++) tab[(i * P + i) * PD + a] = ga[a];
         }
         game_sync();
     }

@@ -40,6 +40,7 @@ constexpr int FT_DI3 = 13;     // time steps per chunk of the fused trial pass, 
 constexpr int FT_UNI3 = 15;    // 3-player unicycle: twelve games per CU (3 x 152 VGPRs per SIMD) leave 13.3 KB each; N = 30 is two chunks
 constexpr int FT_UNI4 = 13;    // 4-player unicycle: the chunk buffers stay under the direction's 18.2 KB
 constexpr int LS_CAP = 3200;   // doubles of LDS for [z | dz] of a line search (LsLds)
+constexpr int LS_SCAP = 3520;  // doubles of LDS for the group pass's Jacobian coefficients and pair-gradient tables (teams of four)
 constexpr int LS_NA = 4;       // step sizes per group pass of the team kernels' line search (LsMulti, algames_assemble.hpp)
 
 constexpr int WAVE = 64;
@@ -869,7 +870,11 @@ template <class C> struct LsLds {
     // (kernels of up to three players: a 4-player unicycle trajectory, b = 88 doubles per step, outgrows the buffer from N = 19 on)
     static constexpr bool ON = C::NW > 1 && C::P <= 3 && !AsmLds<C>::FUSED && !C::EXT && !C::DENSE && C::POS && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
     static constexpr int CAP = LS_CAP;
+    // teams of four run at most two per CU (team_width: B x 4 <= 2048): room for the group pass's per-step-size tables as well
+    static constexpr bool SC_ON = ON && C::NW >= 4;
+    static constexpr int SCAP = LS_SCAP;
     double z[ON ? CAP : 1];
+    double sc[SC_ON ? SCAP : 1];
 };
 template <class C> union Lds { DirLds<C> d; AsmLds<C> a; LsLds<C> ls; };
 

@@ -109,7 +109,8 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
             // (j, alpha) move exactly as the one-by-one search moves them.
             if (phase_int(phase_params(pr).ls_multi)) {
                 constexpr int NA = LsMulti<C>::NA;
-                const bool lds_fit = 2 * phase_int(phase_params(pr).traj_len) <= LsMulti<C>::CAP;
+                const bool lds_fit = 2 * phase_int(phase_params(pr).traj_len) <= LsMulti<C>::CAP &&
+                                     (!LsLds<C>::SC_ON || NA * (phase_int(phase_params(pr).N) - 1) * LsMulti<C>::SW <= LsLds<C>::SCAP);
                 while (j < phase_int(phase_params(pr).opt.ls_iter)) {
                     const auto& om = phase_params(pr).opt;
                     double nr[NA];
@@ -119,11 +120,11 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
                     if constexpr (LsMulti<C>::LDSZ) {
                         if (lds_fit) {
                             if (!staged) { ls_stage_traj<C>(pr, G, L.ls.z); staged = true; }
-                            trial_norms_multi<C, NA, true>(pr, G, L.ls.z, alpha, om.regularize != 0, reg, nr);
+                            trial_norms_multi<C, NA, true>(pr, G, L.ls.z, L.ls.sc, alpha, om.regularize != 0, reg, nr);
                             in_lds = true;
                         }
                     }
-                    if (!in_lds) trial_norms_multi<C, NA, false>(pr, G, nullptr, alpha, om.regularize != 0, reg, nr);
+                    if (!in_lds) trial_norms_multi<C, NA, false>(pr, G, nullptr, nullptr, alpha, om.regularize != 0, reg, nr);
                     LSP(30)
                     int hit = -1; double a = alpha, ahit = alpha, last = alpha;
 #pragma unroll

@@ -86,6 +86,13 @@ def test_solver_kernels_of_the_shipped_library_do_not_spill(alg):
     assert head["vgpr_spill"] == 0 and head["sgpr_spill"] == 0 and head["scratch"] == 0 and head["vgpr"] <= 128, head
     for k, v in solve.items():
         assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
+    # LDS budgets the occupancy rests on (round 5): sixteen C2 games per CU leave 160 KB / 16 = 10 240 bytes each -- the fused trial pass's chunk
+    # buffers fill it to 10 184; teams of four run at most two per CU (team_width: B x 4 <= 2048) and keep the line search's operands and tables
+    # in LDS (54 KB); twelve 3-player-unicycle games per CU leave 13 653 bytes
+    assert head["lds"] <= 10240, head
+    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]["lds"] <= 80 * 1024 and res["k_newton_solve<Cfg<0, 3, 2, 0, 4> >"]["lds"] <= 80 * 1024
+    assert res["k_newton_solve<Cfg<1, 3, 2, 0, 1> >"]["lds"] <= 13653, res["k_newton_solve<Cfg<1, 3, 2, 0, 1> >"]
+    assert res["k_newton_solve<Cfg<1, 4, 2, 0, 2> >"]["lds"] <= 40 * 1024            # team of two: four per CU at C3's 1024 games
     # SGPR spills of the other BASELINE kernels (C3's team-of-two solver had 21, C5's team-of-four loop 72; round 4's
     # refinement gate took them to 16 / 66; round 5: the receding-horizon loop re-reads its own arguments and the solver its tolerances
     # from the kernel-argument segment instead of carrying them across every phase -- 9 / 34 / 28 in the shipped binary, all outside the

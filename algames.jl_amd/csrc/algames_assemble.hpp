@@ -614,12 +614,10 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
 //   base constraint set of the double integrator / unicycle only (collision cost, collision avoidance, control bounds)
 // ================================================================================================
 template <class C> struct LsMulti {
-    // team kernels (whose ordinary trial pass is assemble_pass: all rows of a kind in one flat loop; norms bit-identical) and the one-wavefront
-    // unicycle kernels (fused trial pass: the rows chunk by chunk -- the group pass deals and sums its rows in the same order, CHUNK steps at a
-    // time; its norms agree with the fused pass's to a few ulps -- 68 of ~1000 candidate step sizes of 64 perturbed C5 solves differ in the last
-    // one or two bits of the sum, not traced to an instruction -- so there the group pass only SELECTS the candidate: the ordinary pass re-evaluates
-    // it and the acceptance test of solver_methods.jl:118 is decided on the ordinary pass's norm; iterates, step sizes and iteration counts of the
-    // two searches are identical in every run of tests/test_gpu_line_search_batch.py)
+    // team kernels (whose ordinary trial pass is assemble_pass: all rows of a kind in one flat loop) and the one-wavefront unicycle kernels (fused
+    // trial pass: the rows chunk by chunk -- the group pass deals and sums its rows in the same order, CHUNK steps at a time).  Norms bit-identical
+    // in both cases.  (On the one-wavefront kernels they first came out an ulp apart in one of ten candidates: BT_vec's `a b + c d` had been
+    // contracted one way in the fused pass and the other way here; BT_vec now states its fmas.)
     static constexpr bool TEAMS = C::NW > 1 && !AsmLds<C>::FUSED && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
     static constexpr bool ONEW = C::NW == 1 && AsmLds<C>::FUSED && C::MODEL == ALG_MODEL_UNICYCLE;
     static constexpr bool ON = (TEAMS || ONEW) && !C::EXT && !C::DENSE && C::POS;
@@ -650,8 +648,12 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
     // search rounds the fma, stores it, and subtracts afterwards; with shared loads 5 of 64 perturbed C5 solves disagreed in the last bit
     auto ldz = [&](int idx) { if constexpr (LZ) { int o = idx; asm("" : "+v"(o)); return lz[o]; } else return gld(zs, idx); };
     auto ldd = [&](int idx) { if constexpr (LZ) { int o = TL + idx; asm("" : "+v"(o)); return lz[o]; } else return gld(dz, idx); };
+    // Every trial value goes through an opaque register copy: the ordinary passes read the trial iterate back from memory (or LDS), i.e. they
+    // compute on a ROUNDED fma(alpha, dz, z) the compiler knows nothing about.  Left visible, the fma node takes part in the contraction of the
+    // expressions around it (fma(alpha, dx, x) - x of the proximal term was simplified outright).
+    auto rounded = [](double v) { asm("" : "+v"(v)); return v; };
     // entry idx of the trial iterate of step size q (x_1, the first n entries, does not move: update_traj! never touches it)
-    auto tv = [&](int q, int idx) { const double a = ldz(idx), v = __builtin_fma(al[q], ldd(idx), a); return idx < n ? a : v; };
+    auto tv = [&](int q, int idx) { const double a = ldz(idx), v = __builtin_fma(al[q], ldd(idx), a); return rounded(idx < n ? a : v); };
     constexpr bool LSC = LZ && LsLds<C>::SC_ON;                  // the tables of the step sizes in LDS as well (teams of four)
     double* __restrict__ sc;                                     // [NA][N - 1][SW]
     if constexpr (LSC) sc = lsc; else sc = G.kgain(pr);
@@ -666,7 +668,7 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
             double aq = al[0];
 #pragma unroll
             for (int t = 1; t < NA; t++) aq = (t == q) ? al[t] : aq;
-            auto tq_ = [&](int idx) { const double a = ldz(idx), v = __builtin_fma(aq, ldd(idx), a); return idx < n ? a : v; };
+            auto tq_ = [&](int idx) { const double a = ldz(idx), v = __builtin_fma(aq, ldd(idx), a); return rounded(idx < n ? a : v); };
             const double w = (kn < N - 1) ? dt : 1.0;
             const int so = k == 0 ? 0 : n + hx<C>(k - 1), uo_ = n + hu<C>(k, i), x1 = n + hx<C>(k);
             double* __restrict__ cf = sc + q * SQ + k * SW; double* __restrict__ tab = cf + NC;
@@ -725,10 +727,6 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
 #pragma unroll
     for (int q = 0; q < NA; q++) l1[q] = 0.0;
     auto add = [&](int q, double r, double dprox) { const double rr = prox ? r + reg * dprox : r; l1[q] += fabs(rr); };
-    // the proximal term is (trial value) - (reference), the trial value ROUNDED first -- the ordinary pass reads it back from memory.  Where the
-    // compiler can see that the reference x is the addend of fma(alpha, dx, x) it simplifies the difference (contraction is on): the value goes
-    // through an opaque register copy
-    auto rounded = [](double v) { asm("" : "+v"(v)); return v; };
     for (int k0 = 0; k0 < N - 1; k0 += LsMulti<C>::CHUNK) {            // (one chunk = the whole horizon for the team kernels)
     const int nst = (N - 1 - k0) < LsMulti<C>::CHUNK ? (N - 1 - k0) : LsMulti<C>::CHUNK;
     // ---- rows opt_i,x_{k+1}[a]
@@ -753,7 +751,7 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
             const double xa = tv(q, zo + a);
             r += w * (tq * (xa - tx));
             { const double gv = tabq[(i * P + a % P) * PD + (a < PD * P ? a / P : 0)]; r += (a < PD * P) ? gv : 0.0; }
-            add(q, r, rounded(xa) - xr);
+            add(q, r, xa - xr);
         }
     }
     // ---- rows opt_i,u_{i,k}[c]
@@ -783,7 +781,7 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
                 }
             }
             const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(sc + q * SQ + k * SW, dt, [&](int rr) { return tv(q, lo + rr); }, c);
-            add(q, r, rounded(u) - ur);
+            add(q, r, u - ur);
         }
     }
     // ---- rows dyn_k[a]

@@ -623,14 +623,17 @@ __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int
         for (int a = 0; a < 12; a++) acc += Bi[a * 4 + j] * v(a * P + i);
         return acc;
     } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-        return 0.5 * dt * dt * v(c) + dt * v(c + C::m);
+        // (explicit fmas: `a b + c d` can be contracted either way, and the compiler did choose differently from one pass to another --
+        // the fused trial pass and the line search's group pass came out an ulp apart in these rows)
+        return __builtin_fma(0.5 * dt * dt, v(c), dt * v(c + C::m));
     } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
         const int P = C::P, i = c % P; const bool k0 = (c / P) == 0;
         const double ca = coef[(k0 ? 5 : 7) * P + i], cb = coef[(k0 ? 6 : 8) * P + i], cc = coef[(k0 ? 4 : 9) * P + i];
         return (k0 ? 0.5 * dt : 1.0) * (ca * v(i) + cb * v(P + i) + cc * v(3 * P + i)) + (k0 ? dt : 0.0) * v(2 * P + i);
     } else {
         const int P = C::P, i = c % P, kind = c / P;
-        return 0.5 * dt * (coef[kind * P + i] * v(i) + coef[(2 + kind) * P + i] * v(P + i)) + dt * v((2 + kind) * P + i);
+        const double inner = __builtin_fma(coef[kind * P + i], v(i), coef[(2 + kind) * P + i] * v(P + i));
+        return __builtin_fma(0.5 * dt, inner, dt * v((2 + kind) * P + i));
     }
 }
 // (B w)[r] for a control-vector accessor w(c): row r of B has <= 2 non-zeros

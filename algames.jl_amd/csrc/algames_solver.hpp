@@ -98,10 +98,9 @@ __device__ void line_search(CPR pr, const Game& G, Lds<C>& L, double reg, double
         if (jreg_next >= 0.0) tcache_store(pr, G, ro);
         const double rt = uni(ro.l1reg / (double)phase_int(phase_params(pr).S));
         if constexpr (LsMulti<C>::ON) {
-            // the group pass below said this step size passes the test: on the team kernels the two passes must have produced the same norm, bit for
-            // bit (one-wavefront kernels: the fused pass's norm and the group pass's agree to a few ulps only, see LsMulti; the step is taken on THIS
-            // pass's norm either way, a disagreement at the last bit just lets the search go on)
-            if (expect_on) { expect_on = false; if (LsMulti<C>::TEAMS && ro.l1reg != expect && phase_lane() == 0) G.fresh().st(phase_params(pr))->reserved += 1; }
+            // the group pass below said this step size passes the test: the two passes must have produced the same norm, bit for bit (the step is
+            // taken on THIS pass's norm either way; a disagreement would just let the search go on)
+            if (expect_on) { expect_on = false; if (ro.l1reg != expect && phase_lane() == 0) G.fresh().st(phase_params(pr))->reserved += 1; }
         }
         if (rt <= (1.0 - alpha * o.beta) * res_norm0) break;
         alpha *= o.alpha_decrease; j += 1;

@@ -1,7 +1,6 @@
 """Line search of the team kernels and of the one-wavefront unicycle kernels: step sizes tried in groups (trial_norms_multi, algames_assemble.hpp) against the one-by-one search of
-solver_methods.jl:105-125 -- same binary, ALGAMES_LS_MULTI=0 / 1 at handle creation.  On the team kernels the group pass reproduces the norms of the
-one-by-one trials bit for bit (the device counts disagreements in alg_game_stats.reserved); on the one-wavefront kernels it selects the candidate
-and the ordinary pass decides.  Iterates, step sizes and iteration counts are identical."""
+solver_methods.jl:105-125 -- same binary, ALGAMES_LS_MULTI=0 / 1 at handle creation.  The group pass reproduces the norms of the one-by-one trials bit for bit
+(the device counts disagreements in alg_game_stats.reserved), so iterates, step sizes and iteration counts are identical."""
 import os
 import numpy as np
 import pytest
@@ -45,7 +44,7 @@ def test_step_by_step_solves_same_trials_and_no_norm_disagreement(alg, waves):
                 prob.opts.shift, prob.opts.dual_reset = 1, False; prob._sync_options()
             b.newton_solve_async(init=True, game_id0=prob.game_id0 + t * 1000003)
             st = b.get_stats()
-            if waves > 1: assert int(st["reserved"].sum()) == 0      # team kernels: every group-pass norm equalled the ordinary pass's, bit for bit
+            assert int(st["reserved"].sum()) == 0                       # every group-pass norm equalled the ordinary pass's, bit for bit
             for g in range(G):
                 h = b.get_history(g)
                 rows.append((t, g, h["ls_j"].copy(), h["alpha"].copy(), h["res"].copy()))
@@ -72,7 +71,7 @@ def test_perturbed_solves_bitwise(alg, cfg, games, waves):
         x0 = prob.batch.get_x0(); prob.batch.set_x0(x0 + 0.3 * rng.standard_normal(x0.shape))
         alg.newton_solve(prob)
         st = prob.batch.get_stats()
-        if waves > 1: assert int(st["reserved"].sum()) == 0
+        assert int(st["reserved"].sum()) == 0
         res.append((prob.batch.get_traj().copy(), st["newton_iters"].copy(), st["ls_failures"].copy()))
     assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

@@ -109,8 +109,8 @@ def test_gate_lowers_backward_and_forward_error_at_penalty_ceiling(alg, orc):
     # the device's figure (evaluated on the first solve) is the host's figure of the unrefined direction, from ABOVE -- the side that matters
     # for a gate: its row scale |B[:,c]|' |dlambda| keeps the signs of the RK2 coefficients, a lower estimate of the scale (measured on this
     # state: up to 9 x with the round-4 direction, up to 92 x with the split recursion's of round 5, whose largest opt-u residual sits in a row
-    # with cancelling signs).  The upper factor only documents how conservative the estimate can get.
-    assert np.all(w0 <= gate1[:, 1] * (1 + 1e-6) + 1e-15) and np.all(gate1[:, 1] <= 256 * w0 + 1e-15)
+    # with cancelling signs; 259 x once B' lambda states its fmas, BT_vec).  The upper factor only documents how conservative the estimate can get.
+    assert np.all(w0 <= gate1[:, 1] * (1 + 1e-6) + 1e-15) and np.all(gate1[:, 1] <= 1024 * w0 + 1e-15)
     assert w0.max() > 2.0 ** -34                                         # the state does need the gate ...
     assert w1.max() <= 4 * 2.0 ** -34 and np.all(w1 <= w0 * 1.01 + 1e-16)         # ... and the gate delivers its tolerance
     assert np.all(e1 <= e0 * 1.01 + 1e-13) and np.median(e1) <= np.median(e0) / 50 and e1.max() <= min(1e-8, e0.max() / 50)   # measured: 7.7e-7 -> 1.5e-9

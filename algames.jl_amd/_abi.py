@@ -83,6 +83,10 @@ SIGNATURES = {
     "set_refinement": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double]),
     "get_refinement": (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "get_direction_gate": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "set_line_search_groups": (C.c_int, [_P, C.c_int32]),
+    "get_line_search_groups": (C.c_int, [_P, _I]),
+    "set_handoff": (C.c_int, [_P, C.c_int32]),
+    "get_handoff": (C.c_int, [_P, _I, _I]),
     "set_x0": (C.c_int, [_P, _D]),
     "set_lqr": (C.c_int, [_P, _D, _D, _D, _D, C.c_int32]),
     "add_collision_cost": (C.c_int, [_P, _D, _D]),
@@ -260,6 +264,27 @@ class Batch:
         ms = C.c_int32(); tol = C.c_double(); mu = C.c_double()
         self.lib.check(self.lib.get_refinement(self.h, C.byref(ms), C.byref(tol), C.byref(mu)))
         return ms.value, tol.value, mu.value
+
+    def set_line_search_groups(self, on):
+        """Line search of the team / one-wavefront unicycle kernels: step sizes tried four at a time once the first one was rejected (True,
+        default) or one after another (False); bit-identical norms either way (alg_set_line_search_groups)."""
+        self.lib.check(self.lib.set_line_search_groups(self.h, 1 if on else 0))
+
+    def get_line_search_groups(self):
+        v = C.c_int32()
+        self.lib.check(self.lib.get_line_search_groups(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def set_handoff(self, iters):
+        """Straggler hand-off for heterogeneous batches (alg_set_handoff): games that need more than `iters` inner iterations in the
+        one-wavefront kernel park and a second launch finishes them with the team kernel; 0 = off (default)."""
+        self.lib.check(self.lib.set_handoff(self.h, int(iters)))
+
+    def get_handoff(self):
+        """(budget, number of games the most recent solve handed over)"""
+        k = C.c_int32(); n = C.c_int32()
+        self.lib.check(self.lib.get_handoff(self.h, C.byref(k), C.byref(n)))
+        return k.value, n.value
 
     def get_direction_gate(self):
         """(B, 3): [max |rho|, row-wise backward error omega, largest row scale] of the opt-u rows of the last Newton direction

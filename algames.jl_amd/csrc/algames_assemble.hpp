@@ -4,6 +4,20 @@
 #pragma once
 #include "algames_device.hpp"
 
+// Round-6 A/B switches of the fused pass (tests/probes/build_variant.sh; 1 = shipped)
+#ifndef ALG_R6_STAGE
+#define ALG_R6_STAGE 1      // every global load of a chunk in flight before the first wait
+#endif
+#ifndef ALG_R6_STAGE_BATCH
+#define ALG_R6_STAGE_BATCH 6    // ... elements of z and dz per lane and batch in the 128-register kernels
+#endif
+#ifndef ALG_R6_STAGE_BATCH_W2
+#define ALG_R6_STAGE_BATCH_W2 10   // ... in the 256-register kernels (the 4-player unicycle's chunk is 20 elements per lane: 40 doubles in flight at once spilled its loop kernel)
+#endif
+#ifndef ALG_R6_PHASEA
+#define ALG_R6_PHASEA 1     // phase A: multipliers / penalties of an item's pairs requested together with its positions; LDS-only fences between the staged write-outs
+#endif
+
 namespace alg {
 
 // ================================================================================================
@@ -40,11 +54,35 @@ template <class C> __device__ __forceinline__ void team_combine(ResOut& o) {
 }
 
 struct AsmAcc { double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0; };
+// Roundings of the pair terms, stated once.  Phase A of the assemble pass, phase A of the line search's group pass (trial_norms_multi) and
+// dual_penalty_update evaluate the same pair expressions, and the group pass's norms must equal the ordinary pass's bit for bit: wherever a
+// product feeds a sum the fma is written out, so that no two copies can be contracted differently (round 6: a restructured phase A came
+// out an ulp apart from the group pass's copy in `a a + b b`).
+__device__ __forceinline__ double pair_dist2(double d0, double d1) { return __builtin_fma(d0, d0, d1 * d1); }
+__device__ __forceinline__ double ca_value(double on, double Rr, double s2) { return on * __builtin_fma(Rr, Rr, -s2); }     // c = on (R^2 - |d|^2), constraints_methods.jl:21-33
+__device__ __forceinline__ double dual_ascent(double lam, double a, double mu, double c, double lam_max) {                    // dual_update!, constraints_methods.jl:421-440
+    return fmin(fmax(__builtin_fma(a * mu, c, lam), 0.0), lam_max);
+}
+// tab[f(i)] of a small table in the kernel-argument segment for a per-lane player index i < NP: NP scalar loads and a select chain instead of
+// a vector load from constant memory (a global round trip in the middle of a phase-A item's dependency chain)
+template <int NP, class T, class F>
+__device__ __forceinline__ T sel_player(const ALG_AS4 T* tab, int i, F&& f) {
+    T v = tab[f(0)];
+#pragma unroll
+    for (int q = 1; q < NP; q++) v = (i == q) ? tab[f(q)] : v;
+    return v;
+}
 // Phase A of the assemble pass (see assemble_pass): RK2 Jacobian coefficients and the pair / wall / circle terms of every (knot, player).
 // dzp != nullptr: the positions are those of the trial iterate z + alpha dz, formed on the fly (fused trial pass of the double integrator).
-template <class C, int MODE, bool IBR>
+// DUAL (round 6): the pass is the record! that follows dual_update! + penalty_update! (solver_methods.jl:57-61 then :73): both stream the same
+// iterate and the same multipliers, so the item that evaluates a collision-avoidance row also updates its lambda and mu -- in registers,
+// with dual_penalty_update's expressions -- stores them together with the constraint value (evaluate!), and forms the augmented-Lagrangian
+// terms with the new values.  One pass instead of two per outer iteration.
+// (DUAL is the compile-time capability -- the record! instantiation of the fused pass -- and `dual` the wave-uniform request of this call: the
+// solver kernel holds ONE record! instantiation, not two)
+template <class C, int MODE, bool IBR, bool DUAL = false>
 __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C>& L, const double* __restrict__ z, const double* __restrict__ dzp, double alpha,
-                                                 int N, int lane, double dt, int ip, AsmAcc& acc) {
+                                                 int N, int lane, double dt, int ip, AsmAcc& acc, bool dual = false) {
     constexpr int n = C::n, P = C::P;
     using R = Rec<C>;
     constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);
@@ -87,6 +125,26 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                 for (int a = 0; a < PD; a++) { xi[a] = xp(a * P + i); ga[a] = 0.0; }
 #pragma unroll
                 for (int t = 0; t < NS; t++) dd[t] = 0.0;
+#if ALG_R6_PHASEA
+                // Round 6: everything an item reads from global memory is requested before its arithmetic starts -- the positions of the other
+                // players and the multiplier / penalty of every pair (they sat behind the sqrt / division chains of the pair before: one exposed
+                // round trip per pair) -- and the per-player constants come from scalar loads (sel_player).
+                constexpr int NPR = P > 1 ? P - 1 : 1;
+                double xj[NPR][PD], lmq[NPR], muq[NPR];
+                if (pairs_on) {
+#pragma unroll
+                    for (int jj = 0; jj < P - 1; jj++) {
+                        const int j = jj < i ? jj : jj + 1;
+#pragma unroll
+                        for (int a = 0; a < PD; a++) xj[jj][a] = xp(a * P + j);
+                        lmq[jj] = 0.0; muq[jj] = 0.0;
+                        if (pr.has_colavoid) { const int ci = con_col<C>(N, pairq<C>(i, j), kn); lmq[jj] = gld(G.lam(pr), ci); muq[jj] = gld(G.mu(pr), ci); }
+                    }
+                }
+                const double cc_mu_i = pr.has_colcost ? sel_player<P>(pr.cc_mu, i, [](int q) { return q; }) : 0.0;
+                const double cc_rad_i = pr.has_colcost ? sel_player<P>(pr.cc_radius, i, [](int q) { return q; }) : 0.0;
+                const unsigned ca_mask_i = sel_player<P>(pr.ca_mask, i, [](int q) { return q; });
+#endif
 #pragma unroll
                 for (int jj = 0; jj < P - 1; jj++) {
                     const int j = jj < i ? jj : jj + 1;
@@ -97,12 +155,21 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                     for (int t = 0; t < NS; t++) H[t] = 0.0;
                     if (pairs_on) {
                         double dl[PD];
+#if ALG_R6_PHASEA
+#pragma unroll
+                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - xj[jj][a];
+#else
 #pragma unroll
                         for (int a = 0; a < PD; a++) dl[a] = xi[a] - xp(a * P + j);
+#endif
                         const double dl0 = dl[0], dl1 = dl[1];
-                        const double s2 = dl0 * dl0 + dl1 * dl1;
+                        const double s2 = pair_dist2(dl0, dl1);
                         if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173 (planar: px[i])
+#if ALG_R6_PHASEA
+                            const double nrm = sqrt(s2), mu = cc_mu_i, rad = cc_rad_i;
+#else
                             const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+#endif
                             if (fmax(0.0, rad - nrm) > 0.0) {
                                 const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
                                 const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
@@ -115,17 +182,39 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                             }
                         }
                         if (pr.has_colavoid) {                                   // CollisionConstraint + AL expansion
+#if ALG_R6_PHASEA
+                            const double Rr = sel_player<P>(pr.ca_pair_r, i, [jj](int q) { return q * MAXP + (jj < q ? jj : jj + 1); });
+                            const double on = (double)((ca_mask_i >> j) & 1u);                        // 0: this ordered pair carries no constraint
+#else
                             const double Rr = pr.ca_pair_r[i * MAXP + j];
                             const double on = (double)((pr.ca_mask[i] >> j) & 1u);                    // 0: this ordered pair carries no constraint
+#endif
                             double s2c = s2;
-                            if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c += dl[2] * dl[2]; }   // spherical: pz[i][1:3]
-                            const double c = on * (Rr * Rr - s2c);
+                            if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c = __builtin_fma(dl[2], dl[2], s2c); }   // spherical: pz[i][1:3]
+                            const double c = ca_value(on, Rr, s2c);
                             const int ci = con_col<C>(N, pairq<C>(i, j), kn);
-                            const double lm = gld(G.lam(pr), ci), am = on * al_active_mu(c, lm, gld(G.mu(pr), ci));
+#if ALG_R6_PHASEA
+                            double lm = lmq[jj], mu_c = muq[jj];
+#else
+                            double lm = gld(G.lam(pr), ci), mu_c = gld(G.mu(pr), ci);
+#endif
+                            if (DUAL && dual) {
+                                // dual_update! with alphax_dual[i], then penalty_update! (constraints_methods.jl:421-440, 329-379): dual_penalty_update's expressions
+                                const auto& od = pr.opt;
+#if ALG_R6_PHASEA
+                                const double ax = sel_player<P>(od.alphax_dual, i, [](int q) { return q; });
+#else
+                                const double ax = od.alphax_dual[i];
+#endif
+                                lm = dual_ascent(lm, ax, mu_c, c, od.lambda_max);
+                                mu_c = fmin(fmax(mu_c * od.rho_increase, 0.0), od.rho_max);
+                                gst(G.lam(pr), ci, lm); gst(G.mu(pr), ci, mu_c); gst(G.vals(pr), ci, c);
+                            }
+                            const double am = on * al_active_mu(c, lm, mu_c);
                             const double wl = fma(am, c, on * lm);            // (the contraction the all-pairs form always had: lm + am c)
 #pragma unroll
                             for (int a = 0; a < PD; a++) {
-                                gv[a] += -2.0 * dl[a] * wl;
+                                gv[a] = __builtin_fma(-2.0 * dl[a], wl, gv[a]);
 #pragma unroll
                                 for (int a2 = 0; a2 <= a; a2++) H[C::sym(a, a2)] += am * 4.0 * dl[a2] * dl[a];
                             }
@@ -192,7 +281,9 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
             }
           }
           if constexpr (STAGED) {
-              game_sync();
+              // (round 6: the two fences around the write-out order LDS only -- the staging slots are what they protect; the global stores
+              // are waited for once, behind the loop)
+              if constexpr (ALG_R6_PHASEA != 0) sweep_sync<C>(); else game_sync();
               // write-out: contiguous [coef | Hh | Hd] and table segments of the staged steps
               const int nst = (N - 1 - kA) < SPP ? (N - 1 - kA) : SPP;
               for (int t = lane; t < nst * SL; t += C::NT) {
@@ -201,10 +292,10 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                   if (o >= HEAD) G.rec(pr)[R::gvt(N, kA + ks2) + (o - HEAD)] = L.stage[t];
                   else if (RECS || o < C::NC) G.rec(pr)[base + o] = L.stage[t];
               }
-              game_sync();
+              if constexpr (ALG_R6_PHASEA != 0) sweep_sync<C>(); else game_sync();
           }
         }
-        if constexpr (!AsmLds<C>::STAGED) game_sync();
+        if constexpr (!AsmLds<C>::STAGED || ALG_R6_PHASEA != 0) game_sync();
     }
 }
 
@@ -445,9 +536,11 @@ __device__ void assemble_pass(CPR pr0, const Game& G0, AsmLds<C>& L, int zsel, i
 //   MODE 0 / 3 as in assemble_pass (3 = statistics and records of the unregularised rows + the regularised norm l1reg)
 // Same row arithmetic as assemble_pass (same expressions in the same order); the norms are summed in another order.
 // ================================================================================================
-template <class C, int MODE, bool AXPY>
-__device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alpha, bool prox, double reg, double jreg, ResOut& out) {
+//   DUAL (record! only): the pass also performs the dual_update! + penalty_update! that precede it in newton_solve! (see assemble_phase_a)
+template <class C, int MODE, bool AXPY, bool DUAL = false>
+__device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alpha, bool prox, double reg, double jreg, ResOut& out, bool dual = false) {
     static_assert(AsmLds<C>::FUSED && (MODE == 0 || MODE == 1 || MODE == 3), "fused trial pass: double integrator / unicycle, statistics / record modes");
+    static_assert(!DUAL || (MODE == 1 && !AXPY), "the dual update rides on the record! pass");
     CPR pr = phase_params(pr0);
     const Game G = G0.fresh();
     constexpr int n = C::n, m = C::m, P = C::P, mi = C::mi, ni = C::ni, b = C::b, FT = AsmLds<C>::FT, TAB = AsmLds<C>::TAB, NXU = n + m, NT = C::NT, NC = C::NC;
@@ -464,7 +557,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
     AsmAcc acc;
     LSP_T0 LSP_COUNT(25)
     // ---- phase A over all steps (positions of the trial iterate formed on the fly), heads and tables to the records as in assemble_pass
-    assemble_phase_a<C, MODE, false>(pr, G, L, zs, AXPY ? dz : nullptr, alpha, N, lane, dt, -1, acc);
+    assemble_phase_a<C, MODE, false, DUAL>(pr, G, L, zs, AXPY ? dz : nullptr, alpha, N, lane, dt, -1, acc, dual);
     LSP(20)
     auto& Ch = L.ch;
     for (int e = lane; e < AsmLds<C>::NLQR; e += NT) Ch.lqr[e] = G.Qd(pr)[e];          // [Qd | xf | Rd | uf]
@@ -490,6 +583,57 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
         }
         {
             const int base = n + k0 * b, cnt = nblk * b, own = nst * b;
+#if ALG_R6_STAGE
+            // Round 6: EVERY global load of the chunk -- the blocks of z and dz, the pair-gradient tables, the Jacobian coefficients -- is issued
+            // before the first one is waited for.  (Round 4's loop fetched four elements per lane and trip and the tables one per trip: a chunk of
+            // C2 exposed seven global round trips in a row, a pass twenty-one, with four games per SIMD streaming at the same time.)
+            // (batches of SB elements per lane: all of them at once -- 12 x 2 doubles per lane at C2 -- overflows the 128-register budget)
+            constexpr int SU = ((FT + 1) * b + NT - 1) / NT;              // elements per lane of the largest chunk (C2: 12)
+            constexpr int SB = C::WPE == 4 ? ALG_R6_STAGE_BATCH : (SU < ALG_R6_STAGE_BATCH_W2 ? SU : ALG_R6_STAGE_BATCH_W2);
+            constexpr int TU = C::POS ? (FT * TAB + NT - 1) / NT : 1, CU = NC > 0 ? ((FT + 1) * NC + NT - 1) / NT : 1;
+            double gt[TU], cf[CU];
+            const int tcnt = nst * TAB, ccnt = nblk * NC;
+            if constexpr (C::POS) {
+#pragma unroll
+                for (int t = 0; t < TU; t++) { const int e = lane + t * NT; gt[t] = gld(recg + R::gvt(N, k0), e < tcnt ? e : 0); }            // contiguous behind the records
+            }
+            if constexpr (NC > 0) {                                        // Jacobian coefficients of the staged steps (phase A left them in the records)
+#pragma unroll
+                for (int t = 0; t < CU; t++) { const int e = lane + t * NT, ec = e < ccnt ? e : 0; cf[t] = gld(recg, (k0 + ec / NC) * R::LEN + R::COEF + ec % NC); }
+            }
+            // Lanes past the end of the chunk repeat its last element (clamped index) instead of being masked off: they load, form and store the
+            // very value the owning lane does -- same address, same bits -- so no per-element exec mask has to be kept in scalar registers.  The
+            // trial values of the chunk's extra block (A_{k+1}' lambda_{k+1}) go out here as well as with the next chunk: the same bits twice.
+#pragma unroll
+            for (int t0 = 0; t0 < SU; t0 += SB) {
+                if (t0 * NT >= cnt) break;                                  // (wave-uniform: the last chunk of a horizon is shorter)
+                double a[SB], d[SB]; int ecv[SB];
+#pragma unroll
+                for (int t = 0; t < SB; t++) {
+                    const int e = lane + (t0 + t) * NT; ecv[t] = e < cnt ? e : cnt - 1;
+                    a[t] = gld(zs + base, ecv[t]); d[t] = AXPY ? gld(dz + base, ecv[t]) : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < SB; t++) {
+                    if (t0 + t >= SU) break;
+                    const int ec = ecv[t];
+                    const double v = AXPY ? a[t] + alpha * d[t] : a[t];
+                    Ch.zt[ec] = v;
+                    if (AXPY) gst(zo + base, ec, v);
+                    const int j = ec / b, o = ec % b;
+                    double* const xu = (o < NXU && j < nst) ? &Ch.zxu[j * NXU + o] : &Ch.dump[0];
+                    *xu = a[t];
+                }
+            }
+            if constexpr (C::POS) {
+#pragma unroll
+                for (int t = 0; t < TU; t++) { const int e = lane + t * NT; if (e < tcnt) Ch.gvt[e] = gt[t]; }
+            }
+            if constexpr (NC > 0) {
+#pragma unroll
+                for (int t = 0; t < CU; t++) { const int e = lane + t * NT; if (e < ccnt) Ch.coef[e] = cf[t]; }
+            }
+#else
             for (int e0 = lane; e0 < cnt; e0 += 4 * NT) {
                 double a[4], d[4];
 #pragma unroll
@@ -514,6 +658,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                 const int ccnt = nblk * NC;
                 for (int e = lane; e < ccnt; e += NT) Ch.coef[e] = recg[(size_t)(k0 + e / NC) * R::LEN + R::COEF + e % NC];
             }
+#endif
         }
         fsync();
         // ---- rows opt_i,x_{k+1}[a]
@@ -551,6 +696,22 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                 for (int half = 0; half < 2; half++) {
                     const int ci = con_ctl<C>(pr, k, half * m + c);
                     const double cv = half == 0 ? u - pr.umax[c] : pr.umin[c] - u;
+                    if (DUAL && dual) {
+                        // evaluate! + dual_update! (alpha_dual) + penalty_update! of the two control-bound rows of this control (dual_penalty_update's expressions;
+                        // penalty_update! scales mu of every row, finite or not)
+                        const auto& od = pr.opt;
+                        double lm = gld(G.lam(pr), ci), mu_c = gld(G.mu(pr), ci);
+                        gst(G.vals(pr), ci, cv);
+                        if (isfinite(cv)) { lm = dual_ascent(lm, od.alpha_dual, mu_c, cv, od.lambda_max); gst(G.lam(pr), ci, lm); }
+                        mu_c = fmin(fmax(mu_c * od.rho_increase, 0.0), od.rho_max);
+                        gst(G.mu(pr), ci, mu_c);
+                        if (isfinite(cv)) {
+                            const double am = al_active_mu(cv, lm, mu_c);
+                            const double wl = lm + am * cv;
+                            g += (half == 0 ? wl : -wl); rhat += am;
+                            acc.vcon = fmax(acc.vcon, fmax(0.0, cv));
+                        }
+                    } else
                     if (isfinite(cv)) {
                         const double lm = gld(G.lam(pr), ci), am = al_active_mu(cv, lm, gld(G.mu(pr), ci));
                         const double wl = lm + am * cv;
@@ -694,7 +855,7 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
 #pragma unroll
                     for (int a = 0; a < PD; a++) dl[a] = xi[a] - tq_(x1 + a * P + j);
                     const double dl0 = dl[0], dl1 = dl[1];
-                    const double s2 = dl0 * dl0 + dl1 * dl1;
+                    const double s2 = pair_dist2(dl0, dl1);
                     if (pr.has_colcost) {
                         const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
                         if (fmax(0.0, rad - nrm) > 0.0) {
@@ -707,12 +868,12 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
                     if (pr.has_colavoid) {
                         const double Rr = pr.ca_pair_r[i * MAXP + j];
                         const double on = (double)((pr.ca_mask[i] >> j) & 1u);
-                        const double c = on * (Rr * Rr - s2);
+                        const double c = ca_value(on, Rr, s2);
                         const int ci = con_col<C>(N, pairq<C>(i, j), kn);
                         const double lm = gld(G.lam(pr), ci), am = on * al_active_mu(c, lm, gld(G.mu(pr), ci));
                         const double wl = fma(am, c, on * lm);
 #pragma unroll
-                        for (int a = 0; a < PD; a++) gv[a] += -2.0 * dl[a] * wl;
+                        for (int a = 0; a < PD; a++) gv[a] = __builtin_fma(-2.0 * dl[a], wl, gv[a]);
                     }
                 }
 #pragma unroll

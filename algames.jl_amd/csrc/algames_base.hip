@@ -13,6 +13,7 @@ ALG_DEFINE_KERNELS(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 0)
 ALG_DEFINE_KERNELS(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 0)
 #elif ALG_BASE_SEL == 2
 ALG_DEFINE_KERNELS(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 0)
+ALG_INSTANTIATE_HO_PARK(template, ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 0, 4)          // (budgeted solve of the straggler hand-off, ALG_CFGS_HANDOFF)
 #elif ALG_BASE_SEL == 3
 ALG_DEFINE_KERNELS(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, 0)
 #elif ALG_BASE_SEL == 4
@@ -23,8 +24,10 @@ ALG_DEFINE_KERNELS(ALG_MODEL_UNICYCLE, 1, 2, 0)
 ALG_DEFINE_KERNELS(ALG_MODEL_UNICYCLE, 2, 2, 0)
 #elif ALG_BASE_SEL == 7
 ALG_DEFINE_KERNELS(ALG_MODEL_UNICYCLE, 3, 2, 0)
+ALG_INSTANTIATE_HO_PARK(template, ALG_MODEL_UNICYCLE, 3, 2, 0, 4)
 #elif ALG_BASE_SEL == 8
 ALG_DEFINE_KERNELS(ALG_MODEL_UNICYCLE, 4, 2, 0)
+ALG_INSTANTIATE_HO_PARK(template, ALG_MODEL_UNICYCLE, 4, 2, 0, 4)
 #else
 #error "ALG_BASE_SEL out of range (ALG_CFGS_BASE has nine entries)"
 #endif

@@ -98,6 +98,7 @@ struct Params {
     //  | 3-D walls p1 p2 p3 v (12 per wall, ALG_MAX_WALLS) | cylinders p (3) axis l r (6 per cylinder, ALG_MAX_CIRCLES)]
     const double* extc;
     alg_record* hist;       // B x hist_max Statistics records
+    int* ho_queue;          // straggler hand-off (alg_set_handoff): [count | game indices of the parked games] (B + 1 ints; nullptr while the feature is off)
 };
 
 // The handle's parameters are read straight from the kernel-argument segment (constant address space, scalar loads): the
@@ -861,7 +862,7 @@ struct AsmLds {
     // (one wavefront per game only: on a team the chunks' workgroup barriers cost more than the pass saves -- C5 loop, team of four: 105 vs 152 K/s)
     static constexpr bool FUSED = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE) && !C::EXT && !C::DENSE && (C::NW == 1 || 0);
     static constexpr int FT = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && C::P == 3 && C::D == 2) ? FT_DI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 3) ? FT_UNI3 : (C::MODEL == ALG_MODEL_UNICYCLE && C::P == 4) ? FT_UNI4 : 8, TAB = C::PD * C::P * C::P, NLQR = 2 * C::P * (C::ni + C::mi), NCF = C::NC > 0 ? C::NC : 1;
-    struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[C::NC > 0 ? (FT + 1) * NCF : 1], lqr[NLQR]; };
+    struct Chunk { double xprev[C::n], zt[(FT + 1) * C::b], zxu[FT * (C::n + C::m)], gvt[FT * TAB], coef[C::NC > 0 ? (FT + 1) * NCF : 1], lqr[NLQR], dump[1]; };   // dump: target of the staging loop's masked-off stores
     struct NoChunk {};
     union {
         double stage[STAGED ? SPP * SL : 1];

@@ -2161,7 +2161,10 @@ __device__ double con_mu_max(CPR pr0, const Game& G0) {
     const Game G = G0.fresh();
     const double* __restrict__ mu = G.mu(pr);
     double mx = 0.0;
-    for (int e = phase_lane(); e < pr.con_len; e += C::NT) mx = fmax(mx, mu[e]);
+    // rows of constraint kinds the problem has (the layout also holds rows for absent collision avoidance / control bounds, whose penalties
+    // condition nothing -- and which the fused kernels scale once per solve, not once per outer iteration: penalty_update_unused_rows)
+    const int c0 = (C::P > 1 && pr.has_colavoid) ? 0 : pr.col_len, c1 = pr.col_len, c2 = pr.has_ctl ? pr.col_len : pr.col_len + pr.ctl_len;
+    for (int e = phase_lane(); e < pr.con_len; e += C::NT) { const bool used = (e >= c0 && e < c1) || e >= c2; mx = fmax(mx, used ? mu[e] : 0.0); }
     double v[1] = {mx};
     team_max<C, 1>(v);
     return v[0];
@@ -2217,7 +2220,15 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         if (pass == 0 && phase_lane() == 0) tc[TC_PL1] = pl1s;       // read back only after a correction (below)
         // a correction solve that fails (singular pivot block or non-finite output on the right-hand side (0, rho, 0)) is dropped: nothing of
         // it has been added yet, the direction of the passes before is valid and is what the solver continues with
-        if (st != ALG_STATUS_OK) { if (pass == 0) { if (primal_l1) *primal_l1 = pl1s; return st; } st = ALG_STATUS_OK; break; }
+        if (st != ALG_STATUS_OK) {
+            if (pass == 0) { if (primal_l1) *primal_l1 = pl1s; return st; }
+            // The correction's forward sweep zeroed x_1 of its output buffer -- the TRIAL buffer -- and only dir_add_correction, which this path
+            // skips, puts it back: the line search reads x_1 of the trial buffer (the fused pass stages it, assemble_pass reads it at k = 0),
+            // and an accepted trial BECOMES pdtraj.  Restore it here.
+            { const Game Gr = G0.fresh(); const int tr = phase_lane(); if (tr < C::n) Gr.z(1)[tr] = Gr.z(0)[tr]; }
+            game_sync();
+            st = ALG_STATUS_OK; break;
+        }
         game_sync();                                   // the direction is in global memory
         const DirGate gt = dir_urow_residual<C, IBR, false>(pr, Gd, ip);
         // backward error of the whole direction: the row-wise omega of the first solve; after a correction, the residual of the correction

@@ -17,6 +17,7 @@ ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
 ALG_CFGS_DENSE(ALG_DECLARE_KERNELS)
 ALG_CFGS_MW(ALG_DECLARE_MW)
 ALG_CFGS_MW_DENSE(ALG_DECLARE_MW)
+ALG_CFGS_HANDOFF(ALG_DECLARE_HO)
 
 __global__ void __launch_bounds__(WAVE) k_reset_con(Params pr_arg) {
     CPR pr = kernel_params();
@@ -70,7 +71,9 @@ bool fill_dims(const alg_desc& a, Params& p) {
     // second one changes no digit of it (48 of 48 directions, profiles/r05_quad_gate_probe.txt): the gate's estimate of the remaining
     // row-wise error is an upper bound that the rounding floor of the rows' own evaluation keeps above the tolerance.
     if (p.model == ALG_MODEL_QUADROTOR || p.n > 16 || (p.n % 4) != 0) p.refine_max = 1;
-    // A/B runs of whole test suites (alg_set_refinement otherwise).  An override changes production numerics, so it is announced once.
+    // A/B runs of whole test suites (alg_set_refinement otherwise).  An override changes production numerics: the environment is read by
+    // DEBUG builds only (-DALG_DEBUG_ENV, tests/probes/build_variant.sh) and announced once; the shipped library ignores it.
+#ifdef ALG_DEBUG_ENV
     {
         bool over = false;
         if (const char* e = getenv("ALGAMES_REFINE_STEPS")) { p.refine_max = std::max(0, std::min(8, atoi(e))); over = true; }
@@ -82,17 +85,20 @@ bool fill_dims(const alg_desc& a, Params& p) {
             fprintf(stderr, "libalgames_hip: ALGAMES_REFINE_* environment overrides in effect (max_steps %d, tol %g, mu_tight %g)\n", p.refine_max, p.refine_tol, p.refine_mu);
         }
     }
+#endif
     p.kscratch_len = (p.N - 1) * p.m * std::max(p.n + 1, 16);            // gains m x (n + 1) per step; the quad-team kernels store rows of 16
     {   // the team kernels' line search parks the Jacobian coefficients and pair-gradient tables of LsMulti::NA trial step sizes there (trial_norms_multi)
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : 0;
         if ((p.model == ALG_MODEL_UNICYCLE || p.model == ALG_MODEL_DOUBLE_INTEGRATOR) && p.d == 2) p.kscratch_len = std::max(p.kscratch_len, LS_NA * (p.N - 1) * (nc + 2 * p.p * p.p));
     }
-    p.ls_multi = 1;
-    if (const char* e = getenv("ALGAMES_LS_MULTI")) {               // A/B runs and the bitwise comparison of tests/test_gpu_line_search_batch.py
+    p.ls_multi = 1;                                                  // alg_set_line_search_groups
+#ifdef ALG_DEBUG_ENV
+    if (const char* e = getenv("ALGAMES_LS_MULTI")) {               // A/B runs of whole scripts (debug builds only)
         p.ls_multi = atoi(e) != 0;
         static bool told = false;
         if (!told) { told = true; fprintf(stderr, "libalgames_hip: ALGAMES_LS_MULTI=%d (line-search trials %s)\n", p.ls_multi, p.ls_multi ? "in groups" : "one after another"); }
     }
+#endif
     {   // Rec<C>::LEN of the EXT instantiation (the base one is p n shorter; the buffer is sized for either)
         const int nc = (p.model == ALG_MODEL_UNICYCLE) ? 4 * p.p : (p.model == ALG_MODEL_BICYCLE) ? 10 * p.p : (p.model == ALG_MODEL_QUADROTOR) ? 204 * p.p : 0;
         const int pd = (p.d == 3) ? 3 : 2, ns = pd * (pd + 1) / 2;   // Cfg::PD / NS of the EXT instantiation
@@ -150,6 +156,8 @@ struct Handle {
     double* d_extc = nullptr;
     std::vector<double> extc;     // host copy of pr.extc
     int waves_per_game = 0;       // 0 = automatic (alg_set_waves_per_game)
+    int handoff = 0;              // straggler hand-off budget (alg_set_handoff; 0 = off)
+    int* d_ho = nullptr;          // its queue [count | game indices] (B + 1 ints)
     long long records_bound = 0;        // upper bound of the records the Statistics history holds since its last reset (one per record!)
     void* d_scratch = nullptr;    // grow-only scratch of the inspection entry points (dense Jacobians, MPC state logs)
     size_t scratch_bytes = 0;
@@ -347,6 +355,18 @@ int team_width(const Handle* hd) {
 int launch_newton_solve(Handle* h, int init, uint64_t game_id0) {
     const int nw = team_width(h);
     if (nw < 0) return fail(ALG_ERR_ARG, "alg_set_waves_per_game: no team kernel of that width is compiled for this configuration");
+    if (nw == 1 && h->handoff > 0 && h->d_ho) {
+        // straggler hand-off: the budgeted one-wavefront solve parks the games that exceed the budget, the team kernel resumes them
+        // (the second launch covers the batch: its blocks past the queue's count leave at once -- no host round trip in between)
+        const Params& pr = h->pr; bool done = false;
+        HIPCHK(hipMemsetAsync(h->d_ho, 0, sizeof(int), h->stream));
+#define X(M, P, D, E, W) if (!done && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                                \
+        hipLaunchKernelGGL((k_newton_solve_ho<Cfg<M, P, D, E>>), dim3(pr.B), dim3(WAVE), 0, h->stream, h->pr, init, game_id0, h->handoff);  \
+        hipLaunchKernelGGL((k_newton_resume<Cfg<M, P, D, E, W>>), dim3(pr.B), dim3(WAVE * (W)), 0, h->stream, h->pr); done = true; }
+        ALG_CFGS_HANDOFF(X)
+#undef X
+        if (done) return launch_check("k_newton_solve_ho / k_newton_resume");
+    }
     if (nw == 1) { LAUNCH(k_newton_solve, h->pr, init, game_id0); return ALG_OK; }
     const Params& pr = h->pr; bool done = false;
 #define X(M, P, D, E, W) if (!done && nw == (W) && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                   \
@@ -517,6 +537,43 @@ int alg_set_refinement(alg_handle* h, int32_t max_steps, double tol, double mu_t
 int alg_get_refinement(alg_handle* h, int32_t* max_steps, double* tol, double* mu_tight) {
     if (!h || !max_steps || !tol || !mu_tight) return fail(ALG_ERR_ARG, "alg_get_refinement: null argument");
     *max_steps = H->pr.refine_max; *tol = H->pr.refine_tol; *mu_tight = H->pr.refine_mu; return ALG_OK;
+}
+int alg_set_line_search_groups(alg_handle* h, int32_t on) {
+    NEED_HANDLE("alg_set_line_search_groups");
+    H->pr.ls_multi = on != 0;
+    return ALG_OK;
+}
+int alg_get_line_search_groups(alg_handle* h, int32_t* on) {
+    if (!h || !on) return fail(ALG_ERR_ARG, "alg_get_line_search_groups: null argument");
+    *on = H->pr.ls_multi; return ALG_OK;
+}
+int alg_set_handoff(alg_handle* h, int32_t iters) {
+    NEED_HANDLE("alg_set_handoff");
+    if (iters < 0) return fail(ALG_ERR_ARG, "alg_set_handoff: iterations >= 0 (0 = off)");
+    if (iters > 0) {
+        bool have = false;
+#define X(M, P, D, E, W) if (H->pr.model == (M) && H->pr.p == (P) && H->pr.d == (D) && H->pr.ext == (E)) have = true;
+        ALG_CFGS_HANDOFF(X)
+#undef X
+        if (!have) return fail(ALG_ERR_ARG, "alg_set_handoff: no hand-off kernel pair is compiled for this configuration (3-player DoubleIntegrator d = 2, 3- / 4-player Unicycle, base constraint set)");
+        if (!H->d_ho) {
+            int rc = use_device(H); if (rc) return rc;
+            if ((rc = dalloc(H, &H->d_ho, (size_t)H->pr.B + 1, "hand-off queue"))) return rc;
+            if ((rc = sync(H))) return rc;
+            H->pr.ho_queue = H->d_ho;
+        }
+    }
+    H->handoff = iters;
+    return ALG_OK;
+}
+int alg_get_handoff(alg_handle* h, int32_t* iters, int32_t* parked_last) {
+    if (!h || !iters) return fail(ALG_ERR_ARG, "alg_get_handoff: null argument");
+    *iters = H->handoff;
+    if (parked_last) {
+        *parked_last = 0;
+        if (H->d_ho) { int rc = use_device(H); if (rc) return rc; int v = 0; if ((rc = d2h(H, &v, H->d_ho, sizeof(int)))) return rc; *parked_last = v; }
+    }
+    return ALG_OK;
 }
 int alg_get_waves_per_game(alg_handle* h, int32_t* nw) {
     if (!h || !nw) return fail(ALG_ERR_ARG, "alg_get_waves_per_game: null argument");

@@ -18,6 +18,28 @@ __global__ void __launch_bounds__(C::NT, C::WPE) k_newton_solve(Params pr_arg, i
     newton_solve<C>(pr, G, L, init, game_id0 + (uint64_t)g);
 }
 
+// Straggler hand-off (alg_set_handoff; newton_solve<C, HO>, algames_solver.hpp): the budgeted one-wavefront solve, whose games park after
+// `budget` inner iterations, and the team kernel that resumes the parked games (block b takes the b-th entry of the handle's queue; the
+// launch covers the whole batch, blocks past the queue's count leave at once).
+template <class C>
+__global__ void __launch_bounds__(C::NT, C::WPE) k_newton_solve_ho(Params pr_arg, int init, uint64_t game_id0, int budget) {
+    __shared__ Lds<C> L;
+    CPR pr = kernel_params();
+    const int g = blockIdx.x;
+    Game G = game_view(pr, g);
+    newton_solve<C, 1>(pr, G, L, init, game_id0 + (uint64_t)g, -1, -1, budget);
+}
+template <class C>
+__global__ void __launch_bounds__(C::NT, C::WPE) k_newton_resume(Params pr_arg) {
+    __shared__ Lds<C> L;
+    CPR pr = kernel_params();
+    const int* q = as_global(pr.ho_queue);
+    if ((int)blockIdx.x >= __builtin_amdgcn_readfirstlane(q[0])) return;
+    const int g = __builtin_amdgcn_readfirstlane(q[1 + blockIdx.x]);
+    Game G = game_view(pr, g);
+    newton_solve<C, 2>(pr, G, L, 0, 0);
+}
+
 template <class C>
 // (no occupancy bound: the host-driven stepping entry point is not throughput code, and inner_iteration's live ranges at the four-waves-per-SIMD
 // budget are sized for the fused kernel, where the surrounding loops are in the same function)
@@ -308,6 +330,16 @@ __global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_a
 #define ALG_INSTANTIATE_MW(PREFIX, M, P, D, E, W)                                                                         \
     PREFIX __global__ void k_newton_solve<Cfg<M, P, D, E, W>>(Params, int, uint64_t);                                     \
     PREFIX __global__ void k_mpc_loop<Cfg<M, P, D, E, W>>(Params, int, uint64_t, double*);
+// Hand-off pairs: X(model, p, d, ext, w) = the budgeted one-wavefront kernel of (model, p, d, ext) parks, the team kernel of width w resumes
+// (base configurations that have a team kernel in ALG_CFGS_MW)
+#define ALG_CFGS_HANDOFF(X)                                 \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 0, 4)               \
+    X(ALG_MODEL_UNICYCLE, 3, 2, 0, 4)                        \
+    X(ALG_MODEL_UNICYCLE, 4, 2, 0, 4)
+#define ALG_INSTANTIATE_HO_PARK(PREFIX, M, P, D, E, W) PREFIX __global__ void k_newton_solve_ho<Cfg<M, P, D, E>>(Params, int, uint64_t, int);
+#define ALG_INSTANTIATE_HO_RESUME(PREFIX, M, P, D, E, W) PREFIX __global__ void k_newton_resume<Cfg<M, P, D, E, W>>(Params);
+#define ALG_DEFINE_HO_RESUME(M, P, D, E, W) ALG_INSTANTIATE_HO_RESUME(template, M, P, D, E, W)
+#define ALG_DECLARE_HO(M, P, D, E, W) ALG_INSTANTIATE_HO_PARK(extern template, M, P, D, E, W) ALG_INSTANTIATE_HO_RESUME(extern template, M, P, D, E, W)
 #define ALG_DEFINE_MW(M, P, D, E, W) ALG_INSTANTIATE_MW(template, M, P, D, E, W)
 #define ALG_DECLARE_MW(M, P, D, E, W) ALG_INSTANTIATE_MW(extern template, M, P, D, E, W)
 #define ALG_DEFINE_KERNELS(M, P, D, E) ALG_INSTANTIATE_KERNELS(template, M, P, D, E)

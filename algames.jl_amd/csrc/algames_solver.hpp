@@ -57,11 +57,17 @@ __device__ __forceinline__ RecScalars push_stats(CPR pr0, const Game& G0, const 
     RecScalars r; r.res = uni(ro.l1 / (double)phase_int(pr.S)); r.opt = uni(ro.opt); r.nonfinite = __builtin_amdgcn_readfirstlane(ro.nonfinite);
     return r;
 }
+// dual = true (fused kernels only, round 6): this record! is the one that follows dual_update! + penalty_update! in newton_solve!
+// (solver_methods.jl:57-61, then :73 of the next outer iteration) and performs them on the way (assemble_phase_a, DUAL)
+#ifndef ALG_R6_DUALREC
+#define ALG_R6_DUALREC 1        // A/B switch (tests/probes/build_variant.sh): 0 = dual_penalty_update as a pass of its own, as until round 5
+#endif
+template <class C> inline constexpr bool dual_in_record_v = AsmLds<C>::FUSED && ALG_R6_DUALREC != 0;
 template <class C>
-__device__ __forceinline__ RecScalars make_record(CPR pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out) {
+__device__ __forceinline__ RecScalars make_record(CPR pr, const Game& G, Lds<C>& L, double delta, int outer, double jreg, alg_record* out, bool dual = false) {
     ResOut ro;
     LSP_T0 LSP_COUNT(29)
-    if constexpr (AsmLds<C>::FUSED) assemble_fused<C, 1, false>(pr, G, L.a, 0.0, false, 0.0, jreg, ro);
+    if constexpr (AsmLds<C>::FUSED) assemble_fused<C, 1, false, true>(pr, G, L.a, 0.0, false, 0.0, jreg, ro, dual);
     else assemble_pass<C, 1>(pr, G, L.a, 0, -1, 0.0, jreg, ro);
     game_sync();
     LSP(27)
@@ -172,8 +178,10 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     rotate_priority<C>(k + l);
     iter_clock_start(pr, G_);                    // @elapsed begins (solver_methods.jl:40); record! below still reads the previous t_elap
     RecScalars rs;                                                         // :73-76 (regularisation term is zero at pdtraj)
-    if (cache_valid && *cache_valid) { ResOut cro; tcache_load(pr, G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }
-    else rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr);
+    // *cache_valid: 1 = the accepted trial of the previous iteration is this record!; 2 = the dual / penalty update of the previous outer
+    // iteration is still due and rides on this record! pass (dual_in_record_v)
+    if (cache_valid && *cache_valid == 1) { ResOut cro; tcache_load(pr, G, cro); rs = push_stats(pr, G, cro, Delta, k, info ? &info->rec : nullptr); }
+    else rs = make_record<C>(pr, G, L, Delta, k, reg, info ? &info->rec : nullptr, dual_in_record_v<C> && cache_valid && *cache_valid == 2);
     if (cache_valid) *cache_valid = 0;
     Delta = 0.0;                                                           // :79
     auto finish = [&](int status, int flow) { if (info && lane0) { info->status = status; info->control_flow = flow; } iter_clock_stop(pr, G_); return status | (flow << 8); };
@@ -230,12 +238,11 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
             const int q = e / (N - 1), k = e % (N - 1) + 1, i = q / PM1, jj = q % PM1, j = jj < i ? jj : jj + 1;
             const double* x = zstate<C>(z, k);
             const double d0 = x[i] - x[j], d1 = x[P + i] - x[P + j], R = pr.ca_pair_r[i * MAXP + j];
-            double s2 = d0 * d0 + d1 * d1;
-            if constexpr (C::PD == 3) { const double d2 = pr.ca_dim == 3 ? x[2 * P + i] - x[2 * P + j] : 0.0; s2 += d2 * d2; }
-            const double c = (double)((pr.ca_mask[i] >> j) & 1u) * (R * R - s2);
+            double s2 = pair_dist2(d0, d1);
+            if constexpr (C::PD == 3) { const double d2 = pr.ca_dim == 3 ? x[2 * P + i] - x[2 * P + j] : 0.0; s2 = __builtin_fma(d2, d2, s2); }
+            const double c = ca_value((double)((pr.ca_mask[i] >> j) & 1u), R, s2);      // (the roundings of assemble_phase_a: its DUAL form performs this very update)
             G.vals(pr)[e] = c;
-            const double lb = G.lam(pr)[e] + o.alphax_dual[i] * G.mu(pr)[e] * c;
-            G.lam(pr)[e] = fmin(fmax(lb, 0.0), o.lambda_max);
+            G.lam(pr)[e] = dual_ascent(G.lam(pr)[e], o.alphax_dual[i], G.mu(pr)[e], c, o.lambda_max);
         }
     }
     if (pr.has_ctl) {
@@ -245,7 +252,7 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
             const double cv = row < m ? u - pr.umax[c] : pr.umin[c] - u;
             const int ci = pr.col_len + e;
             G.vals(pr)[ci] = cv;
-            if (isfinite(cv)) { const double lb = G.lam(pr)[ci] + o.alpha_dual * G.mu(pr)[ci] * cv; G.lam(pr)[ci] = fmin(fmax(lb, 0.0), o.lambda_max); }
+            if (isfinite(cv)) G.lam(pr)[ci] = dual_ascent(G.lam(pr)[ci], o.alpha_dual, G.mu(pr)[ci], cv, o.lambda_max);
         }
     }
     if constexpr (C::EXT) {
@@ -376,11 +383,60 @@ __device__ __forceinline__ void settle_traj(CPR pr, Game& G) {
     }
 }
 
-// newton_solve! (solver_methods.jl:5-65)
+// penalty_update! scales mu of EVERY row of the constraint arena, including the rows of constraint kinds the problem does not have
+// (no collision avoidance / no control bounds: their rows exist in the layout, nothing reads them).  The record! pass that carries the
+// dual update (dual_in_record_v) visits the rows that exist; the others receive the solve's `nup` scalings here, once, in the same
+// order of operations -- the arena ends up bit-identical to dual_penalty_update's.
 template <class C>
-__device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1) {
+__device__ void penalty_update_unused_rows(CPR pr0, const Game& G0, int nup) {
+    CPR pr = phase_params(pr0);
+    if (nup <= 0) return;
+    const bool col_used = C::P > 1 && pr.has_colavoid, ctl_used = pr.has_ctl != 0;
+    if (col_used && ctl_used) return;
+    const Game G = G0.fresh();
+    const auto& o = pr.opt;
+    const int lo = col_used ? pr.col_len : 0, hi = ctl_used ? pr.col_len : pr.col_len + pr.ctl_len;
+    for (int e = lo + phase_lane(); e < hi; e += C::NT) {
+        double v = gld(G.mu(pr), e);
+        for (int t = 0; t < nup; t++) v = fmin(fmax(v * o.rho_increase, 0.0), o.rho_max);
+        gst(G.mu(pr), e, v);
+    }
+}
+
+// Straggler hand-off (round 6; no reference counterpart -- the reference solves one game at a time).  A launch lasts as long as its slowest
+// game: in a heterogeneous batch (Monte-Carlo scenarios, MPC warm starts) a few games need ten times the iterations of the rest and run
+// the tail alone, one wavefront on an otherwise idle chip.  With alg_set_handoff(h, K) the one-wavefront kernel is launched with a budget:
+// a game that is about to start its (K+1)-th inner iteration PARKS -- its iterate, multipliers, step records and statistics already live
+// in its arena chunk; the solver's loop state (outer / inner index, LS_count, the trial-reuse flag, Delta, which buffer holds pdtraj) goes
+// to the game's control slots -- and appends itself to the handle's queue; a second launch then RESUMES the parked games with the team
+// kernel (four wavefronts per game), which continues the very same loops.  HO = 0: plain solve; 1: budgeted (may park); 2: resume.
+constexpr int TC_HO_K = 18, TC_HO_L = 19, TC_HO_LS = 20, TC_HO_CV = 21, TC_HO_DELTA = 22, TC_HO_ZO = 23;
+static_assert(TC_HO_ZO < TC_LEN, "per-game control slots");
+template <class C>
+__device__ __forceinline__ void handoff_park(CPR pr0, Game& G, int k, int l, int LS_count, int cache_valid, double Delta) {
+    game_sync();
+    // the scalings of mu that the fused dual updates deferred for the rows of absent constraint kinds: everything behind this point runs
+    // dual_penalty_update on ALL rows (the team kernels are not fused kernels)
+    if constexpr (dual_in_record_v<C>) penalty_update_unused_rows<C>(pr0, G, (k - 1) - (cache_valid == 2 ? 1 : 0));
+    CPR pr = phase_params(pr0);
+    if (phase_lane() == 0) {
+        const Game H = G.fresh();
+        double* tc = H.tc(pr);
+        tc[TC_HO_K] = (double)k; tc[TC_HO_L] = (double)l; tc[TC_HO_LS] = (double)LS_count; tc[TC_HO_CV] = (double)cache_valid;
+        tc[TC_HO_DELTA] = Delta; tc[TC_HO_ZO] = (double)G.zo[0];
+        alg_game_stats* st = H.st(pr);
+        st->status = ALG_STATUS_PARKED; st->outer_iters = k;
+        int* q = as_global(pr.ho_queue);
+        const int at = atomicAdd(q, 1);
+        q[1 + at] = H.g;
+    }
+}
+
+// newton_solve! (solver_methods.jl:5-65)
+template <class C, int HO = 0>
+__device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1, int budget = 0) {
     const auto& o = pr.opt; const int lane = phase_lane();
-    if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; G.fresh().tc(phase_params(pr))[TC_TELAP] = 0.0; } // reset!(prob.stats); t_elap = 0
+    int k0 = 1, l0 = 1, ls0 = 0, cv0 = 0; double Delta = 0.0;
 #ifdef ALG_PHASE_PROF
     if (lane < 16) G.res(pr)[lane] = 0.0;                                   // scratch instrumentation: per-phase cycle sums (16..: pass-level sums over the handle's lifetime)
     if (game_tid() < 32) lsp_slots()[game_tid()] = 0u;
@@ -389,6 +445,21 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
 #ifdef ALG_PHASE_PROF
     const unsigned lsp_solve0 = lsp_now();
 #endif
+    if constexpr (HO == 2) {
+        // resume a parked game: the loop state from its control slots; pdtraj may live in the trial buffer (an odd number of exchanges)
+        CPR prs = phase_params(pr); const double* tc = G.fresh().tc(prs);
+        k0 = (int)uni(tc[TC_HO_K]); l0 = (int)uni(tc[TC_HO_L]); ls0 = (int)uni(tc[TC_HO_LS]); cv0 = (int)uni(tc[TC_HO_CV]);
+        Delta = uni(tc[TC_HO_DELTA]);
+        const int z0 = (int)uni(tc[TC_HO_ZO]);
+        if (z0 != 0) { G.zo[1] = G.zo[0]; G.zo[0] = z0; }
+        game_sync();
+        if (cv0 == 2 && !dual_in_record_v<C>) {                              // the dual / penalty update the parked kernel left to its next record!
+            dual_penalty_update<C>(pr, G);
+            game_sync();
+            cv0 = 0;
+        }
+    } else {
+    if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; G.fresh().tc(phase_params(pr))[TC_TELAP] = 0.0; } // reset!(prob.stats); t_elap = 0
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
     else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
     if (lane < C::n) { G.z(1)[lane] = G.x0(pr)[lane]; G.z(2)[lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
@@ -396,13 +467,21 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     rollout<C>(pr, G.z(0));                                                // :17
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con<C::NT>(pr, G);     // :25
     game_sync();
+    }
     LSP(19)
-    int out = 0, status = ALG_STATUS_OK, fresh = 0; double Delta = 0.0;
-    for (int k = 1; k <= o.outer_iter; k++) {                              // :30
+    int out = 0, status = ALG_STATUS_OK, fresh = 0;
+    int started = 0;                                                       // (HO == 1) inner iterations this launch has begun
+    for (int k = k0; k <= o.outer_iter; k++) {                             // :30
         out = k;
-        int LS_count = 0;
-        int cache_valid = 0;
-        for (int l = 1; l <= o.inner_iter; l++) {                          // :38
+        const bool first = HO == 2 && k == k0;                             // the outer iteration a resumed game re-enters
+        int LS_count = first ? ls0 : 0;
+        // fused kernels: every outer iteration but the first begins behind a dual / penalty update, which its first record! performs (2)
+        int cache_valid = first ? cv0 : ((dual_in_record_v<C> && k > 1) ? 2 : 0);
+        for (int l = first ? l0 : 1; l <= o.inner_iter; l++) {             // :38
+            if constexpr (HO == 1) {
+                if (started >= budget) { handoff_park<C>(pr, G, k, l, LS_count, cache_valid, Delta); return; }
+                started += 1;
+            }
             const int rcode = inner_iteration<C>(pr, G, L, LS_count, Delta, k, l, nullptr, &cache_valid);
             fresh = (rcode >> 16) & 1;
             if ((rcode & 0xff) != ALG_STATUS_OK) { status = rcode & 0xff; break; }
@@ -420,10 +499,13 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
         const int convu = __builtin_amdgcn_readfirstlane((int)conv);
         if (convu && phase_lane() == 0) stk->converged = 1;          // written where it is decided (one loop-carried scalar less)
         if (k == oc.outer_iter || convu) break;                            // :49-55
-        dual_penalty_update<C>(pr, G);                                     // :57-61
-        game_sync();
+        if constexpr (!dual_in_record_v<C>) {
+            dual_penalty_update<C>(pr, G);                                 // :57-61
+            game_sync();
+        }                                                                  // (fused kernels: in the first record! of outer iteration k + 1)
     }
     game_sync();
+    if constexpr (dual_in_record_v<C>) penalty_update_unused_rows<C>(pr, G, out - 1);
     // :63 record! at the final iterate.  When the solver left its loops at the optimality test of an inner iteration (the usual
     // exit) that iteration's record! was made at this very iterate with these very multipliers: the same numbers, so the
     // assemble pass is not repeated, the record is pushed again (with the Delta and outer index this call passes)

@@ -696,12 +696,25 @@ def init_traj_host(prob):
     is consumed for it, so a stateful generator stays aligned with the reference's call sequence.
     Every game is one `newton_solve!` of the reference, which calls `Random.seed!(opts.seed)` first (solver_methods.jl:9): NumPy's
     global generator is seeded the same way before each game's draws, so `f_init = np.random.randn` gives every game the stream the
-    Julia shim gives it (generators that carry their own state, e.g. a `default_rng(...)` method, are not touched by this)."""
+    Julia shim gives it (generators that carry their own state, e.g. a `default_rng(...)` method, are not touched by this).  The
+    caller's global NumPy generator state is saved before the loop and restored after it: the seeding is a detail of this call, not a
+    side effect on the caller's stream.  (Deliberate deviation, stated: where the shift copies knot N the reference copies the STALE
+    control `pr[N]` carries, primal_dual_traj.jl:35; the layout here has no such slot and stores zero.)"""
     b, o = prob.batch, prob.opts
     f, a, s = o.f_init, float(o.amplitude_init), int(min(o.shift, 2 ** 30))
     X, U, L = b.split_traj(b.get_traj(0))
     B, N, n, m, p = X.shape[0], b.N, b.n, b.m, b.p
     draw = lambda size: a * np.asarray(f(size), dtype=np.float64).reshape(size)
+    rng_state = np.random.get_state()
+    try:
+        _init_traj_host_fill(o, X, U, L, B, N, n, m, p, s, draw)
+    finally:
+        np.random.set_state(rng_state)
+    X[:, 0] = b.get_x0()
+    b.set_traj(b.join_traj(X, U, L))
+
+
+def _init_traj_host_fill(o, X, U, L, B, N, n, m, p, s, draw):
     for g in range(B):
         np.random.seed(int(o.seed) % (2 ** 32))                     # Random.seed!(opts.seed), solver_methods.jl:9
         for k in range(1, N + 1):                                   # 1-based like the reference
@@ -717,8 +730,6 @@ def init_traj_host(prob):
         for i in range(p):
             for k in range(1, N):
                 L[g, i, k - 1] = L[g, i, k + s - 1] if k + s <= N - 1 else draw(n)
-    X[:, 0] = b.get_x0()
-    b.set_traj(b.join_traj(X, U, L))
 
 
 def newton_solve(prob, init=True):

@@ -487,6 +487,22 @@ the tolerance is relaxed in proportion, at most 256 x.  `max_steps = 0` switches
 set_refinement!(bp::BatchedGameProblem; max_steps::Integer=2, tol::Float64=2.0^-34, mu_tight::Float64=1.6e5) =
     check(ccall((:alg_set_refinement, LIB), Cint, (Ptr{Cvoid}, Int32, Float64, Float64), bp.h, max_steps, tol, mu_tight))
 
+"""
+    set_handoff!(bp, iters)
+
+Straggler hand-off for heterogeneous batches (alg_set_handoff): games that need more than `iters` inner iterations in the one-wavefront kernel
+park and a second launch finishes them with the team kernel; `0` switches it off (the default).  `handoff(bp)` returns the budget and the
+number of games the most recent solve handed over.
+"""
+set_handoff!(bp::BatchedGameProblem, iters::Integer) = check(ccall((:alg_set_handoff, LIB), Cint, (Ptr{Cvoid}, Int32), bp.h, iters))
+function handoff(bp::BatchedGameProblem)
+    k = Ref{Int32}(0); n = Ref{Int32}(0)
+    check(ccall((:alg_get_handoff, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), bp.h, k, n))
+    return Int(k[]), Int(n[])
+end
+"Line search with the step sizes tried in groups (`true`, default) or one after another (`false`): bit-identical norms (alg_set_line_search_groups)."
+set_line_search_groups!(bp::BatchedGameProblem, on::Bool) = check(ccall((:alg_set_line_search_groups, LIB), Cint, (Ptr{Cvoid}, Int32), bp.h, on ? 1 : 0))
+
 "3 x B: [max |rho|, row-wise backward error, largest row scale] of the opt-u rows of every game's last Newton direction (alg_get_direction_gate)."
 function direction_gate(bp::BatchedGameProblem)
     out = zeros(3, length(bp.probs))

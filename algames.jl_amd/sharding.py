@@ -110,13 +110,19 @@ def make_shard(config, games_per_rank, rank, world, backend=None, device=0, **kw
     return scenarios.make_problem(config, ids, backend=backend, device=device, **kw), ids
 
 
-def reduce_counters(counts, elapsed, world, device):
-    """Sum of the per-rank integer counters and max of the per-rank wall time: the only collectives of a multi-process run."""
+def reduce_counters(counts, elapsed, world, device, group=None, use_dist=None):
+    """Sum of the per-rank integer counters and max of the per-rank wall time: the only collectives of a multi-process run.
+    `use_dist` says whether the two all-reduces run (default: `world > 1`); `group` is the process group they run on (default: the
+    caller's default group).  The function never probes `dist.is_initialized()` on its own: a library user with a process group of
+    their own must not get a collective (summed over unrelated ranks, or a hang) because they reduced the counters of a one-rank job.
+    `bench.py` passes `use_dist=True` for its world-of-one RCCL runs (`--force-dist`, torchrun with one rank)."""
     import torch
-    import torch.distributed as dist
     tot = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device)
     tmax = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
-    if world > 1 or (dist.is_available() and dist.is_initialized()):       # (a world of one still goes through the communicator when it exists)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if use_dist is None:
+        use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     return [int(v) for v in tot.tolist()], float(tmax.item())

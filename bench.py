@@ -129,9 +129,10 @@ def make_shard(alg, config, games_per_rank, rank, world, backend=None, device=0,
                                    **{**CONFIG_KW.get(config, {}), **kw})
 
 
-def reduce_counters(alg, counts, elapsed, world, device):
-    """Sum of the per-rank counters, max of the per-rank wall time: the package's `sharding.reduce_counters` (the only collectives)."""
-    return alg.sharding.reduce_counters(counts, elapsed, world, device)
+def reduce_counters(alg, counts, elapsed, world, device, use_dist=None):
+    """Sum of the per-rank counters, max of the per-rank wall time: the package's `sharding.reduce_counters` (the only collectives).
+    `use_dist` = whether this run created a process group (a world of one under --force-dist / torchrun still reduces through it)."""
+    return alg.sharding.reduce_counters(counts, elapsed, world, device, use_dist=use_dist)
 
 
 def _free_port():
@@ -265,6 +266,13 @@ def main():
                     help="kernel shape of the fused solver: wavefronts per game (0 = the library's automatic choice)")
     ap.add_argument("--refine-steps", type=int, default=-1, help="alg_set_refinement max_steps (default: the library's; 0 = gate and refinement off)")
     ap.add_argument("--refine-tol", type=float, default=-1.0, help="alg_set_refinement tol (default: the library's)")
+    ap.add_argument("--perturb", type=float, default=0.0,
+                    help="heterogeneous batch (NOT the BASELINE workload; labelled in config.workload): every start position coordinate of every "
+                         "scenario is moved by U(-PERTURB, PERTURB), keyed by the global scenario id -- the games then need different numbers "
+                         "of Newton iterations (C2 at 0.3: 11 ... 109) and one launch lasts as long as its slowest game")
+    ap.add_argument("--handoff", type=int, default=-1,
+                    help="straggler hand-off (alg_set_handoff): games that exceed this many Newton iterations in the one-wavefront kernel park "
+                         "their state and a second launch finishes them with the team kernel (-1: the library's default, 0: off)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed with the nccl (= RCCL) backend even for one rank, so that communicator creation, the "
                          "barrier and the two all-reduces of the counter reduction run on the device (tests/test_gpu_bench_ranks.py)")
@@ -321,6 +329,14 @@ def main():
         G = args.games_per_gpu or default_games
     prob, ids = make_shard(alg, args.config, G, rank, world, device=local_rank)
     b = prob.batch
+    if args.perturb:
+        # heterogeneous batch: start positions spread by +-perturb, drawn from the counter generator keyed by the GLOBAL scenario id (stream
+        # apart from the scenario's own draws), so the shard layout does not change them
+        npos = 2 * b.p
+        x0p = prob.x0.copy()
+        x0p[:, :npos] += alg.scenarios._uniform(0x9E27 + 7919, ids, npos, -args.perturb, args.perturb)
+        prob.x0 = x0p
+        b.set_x0(x0p)
     stream = torch.cuda.Stream()                                    # a real (non-NULL) HIP stream owned by torch
     torch.cuda.set_stream(stream)
     b.set_stream(stream.cuda_stream)                                # the library launches on this stream
@@ -328,6 +344,8 @@ def main():
     waves_per_game = b.get_waves_per_game()
     if args.refine_steps >= 0 or args.refine_tol >= 0:
         b.set_refinement(args.refine_steps if args.refine_steps >= 0 else None, args.refine_tol if args.refine_tol >= 0 else None)
+    if args.handoff > 0:
+        b.set_handoff(args.handoff)
     refine_steps, refine_tol, refine_mu = b.get_refinement()
     prob._sync_options()
 
@@ -372,7 +390,7 @@ def main():
     balance = float(per_game.mean() / max(1, per_game.max()))
     bad_rank = int((st["status"] != 0).sum())
     refinements_rank = int(st["refinements"].sum())          # correction solves of the last launch (mpc mode: of every game's last solve)
-    (iters_all, conv_all, bad_all), elapsed = reduce_counters(alg, [iters_rank, conv_rank, bad_rank], elapsed, world, "cuda")
+    (iters_all, conv_all, bad_all), elapsed = reduce_counters(alg, [iters_rank, conv_rank, bad_rank], elapsed, world, "cuda", use_dist=use_dist)
 
     if rank == 0:
         K = args.steps
@@ -407,6 +425,10 @@ def main():
                     "--refine-steps", str(refine_steps), "--refine-tol", repr(refine_tol)]
             if args.mpc_steps:
                 tail += ["--mpc-steps", str(args.mpc_steps)]
+            if args.perturb:
+                tail += ["--perturb", repr(args.perturb)]
+            if args.handoff >= 0:
+                tail += ["--handoff", str(args.handoff)]
             pmc = inrun_pmc(tail, kernel, iters_rank, own)
         if pmc is not None:
             roof.update(pmc)
@@ -425,13 +447,16 @@ def main():
             "metric": "newton_iters_per_sec", "value": value, "unit": "game-Newton-iterations/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.config] + f" [{args.scaling} scaling: {G} scenarios/GPU x {world} GPU = {G * world} scenarios]",
+            "config": {"workload": WORKLOADS[args.config] + f" [{args.scaling} scaling: {G} scenarios/GPU x {world} GPU = {G * world} scenarios]"
+                                   + (f" [HETEROGENEOUS variant, not the BASELINE workload: start positions perturbed by +-{args.perturb}]" if args.perturb else ""),
+                       "perturb": args.perturb,
                        "name": args.config,
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
                        "mpc_steps": args.mpc_steps,
                        "parallelism": f"scenario-sharded x{world}" + (" (TEST HOOK: the ranks share device 0, gloo; not a multi-GPU measurement)" if SHARED_DEVICE and world > 1 else ""), "wavefronts_per_game": waves_per_game,
                        "collectives": (("gloo" if SHARED_DEVICE and world > 1 else "nccl (RCCL)") + f", world {world}: barrier + 2 all_reduce of the counters") if use_dist else "none (one rank, no process group)",
                        "iters_per_game_mean_over_max_rank0": balance,
+                       "handoff": dict(zip(("budget_iters", "games_handed_over_rank0"), b.get_handoff())),
                        "direction_refinement": {"max_steps": refine_steps, "tol": refine_tol, "mu_tight": refine_mu, "correction_solves_rank0": refinements_rank},
                        "solver": ("fused per-game receding-horizon loop kernel (alg_mpc_solve)" if args.mpc_steps
                                   else "fused per-game newton_solve! kernel")},

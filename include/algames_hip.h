@@ -73,6 +73,8 @@ extern "C" {
 #define ALG_STATUS_OK 0
 #define ALG_STATUS_SINGULAR 1   /* zero / non-finite pivot in the Newton solve (reference: SingularException) */
 #define ALG_STATUS_NAN 2        /* non-finite residual */
+#define ALG_STATUS_PARKED 3     /* transient: the game used up the hand-off budget of the first launch and waits for the second (alg_set_handoff);
+                                   never visible after alg_newton_solve / alg_synchronize */
 
 typedef struct alg_handle alg_handle;
 
@@ -167,6 +169,22 @@ int  alg_get_options(alg_handle* h, alg_options* o);
  * summed in a different order).  alg_get_waves_per_game returns the width the next solve will use. */
 int  alg_set_waves_per_game(alg_handle* h, int32_t waves);
 int  alg_get_waves_per_game(alg_handle* h, int32_t* waves);
+/* Line search (solver_methods.jl:105-125) of the team kernels and the one-wavefront unicycle kernels: once the first step size has been
+ * rejected the following ones are evaluated four at a time by a norm-only pass (bit-identical norms, the same step is accepted).
+ * on = 0 selects the one-by-one search in the same binary (default 1).  Nothing else changes at the boundary. */
+int  alg_set_line_search_groups(alg_handle* h, int32_t on);
+int  alg_get_line_search_groups(alg_handle* h, int32_t* on);
+/* Straggler hand-off for heterogeneous batches (no reference counterpart: the reference solves one game at a time).  A launch lasts as
+ * long as its slowest game.  With iters = K > 0 the one-wavefront solver kernel behind alg_newton_solve* gives every game a budget of
+ * K inner iterations; a game that needs more parks -- its whole state lives in its arena chunk -- and a second launch on the same
+ * stream finishes the parked games with the team kernel (four wavefronts per game), which continues the same outer / inner loops.
+ * Results per game: the iterations before the hand-off are the one-wavefront kernel's, the ones after it the team kernel's (the two
+ * agree to rounding: the norms are summed in a different order, see alg_set_waves_per_game).  0 (default) = off.  Only configurations
+ * with a team kernel accept K > 0 (3-player DoubleIntegrator d = 2, 3- / 4-player Unicycle, base constraint set; ALG_ERR_ARG
+ * otherwise); the setting is ignored while the handle runs a team kernel itself and by alg_mpc_solve.  alg_get_handoff also returns
+ * the number of games the most recent solve handed over (parked_last may be NULL). */
+int  alg_set_handoff(alg_handle* h, int32_t iters);
+int  alg_get_handoff(alg_handle* h, int32_t* iters, int32_t* parked_last);
 /* Iterative refinement of the Newton direction (replaces the backward stability of `lu(core.jac) \\ core.res`, solver_methods.jl:87).
  * The structured elimination behind alg_newton_direction / alg_newton_step / alg_newton_solve* is a block LU without pivoting across
  * blocks; the forward and costate sweeps satisfy the dynamics and opt-x rows of J d = -res by construction, so all of the elimination's

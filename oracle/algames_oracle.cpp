@@ -1560,6 +1560,10 @@ int orc_set_waves_per_game(alg_handle*, int32_t nw) { return (nw == 0 || nw == 1
 int orc_set_refinement(alg_handle*, int32_t max_steps, double tol, double mu_tight) { return (max_steps >= 0 && max_steps <= 8 && tol >= 0.0 && mu_tight >= 0.0) ? ALG_OK : fail(ALG_ERR_ARG, "bad refinement setting"); }   // the pivoted LU needs none (ABI mirror)
 int orc_get_direction_gate(alg_handle* h, double* out) { if (out) for (size_t e = 0; e < 3 * H->g.size(); e++) out[e] = 0.0; return ALG_OK; }
 int orc_get_refinement(alg_handle*, int32_t* max_steps, double* tol, double* mu_tight) { if (max_steps) *max_steps = 0; if (tol) *tol = 0.0; if (mu_tight) *mu_tight = 0.0; return ALG_OK; }
+int orc_set_line_search_groups(alg_handle*, int32_t) { return ALG_OK; }     // the oracle's line search is the reference's one-by-one loop (ABI mirror)
+int orc_get_line_search_groups(alg_handle*, int32_t* on) { if (on) *on = 0; return ALG_OK; }
+int orc_set_handoff(alg_handle*, int32_t iters) { return iters >= 0 ? ALG_OK : fail(ALG_ERR_ARG, "bad hand-off budget"); }   // kernel scheduling: no meaning on the CPU (ABI mirror)
+int orc_get_handoff(alg_handle*, int32_t* iters, int32_t* parked_last) { if (iters) *iters = 0; if (parked_last) *parked_last = 0; return ALG_OK; }
 int orc_get_waves_per_game(alg_handle*, int32_t* nw) { if (nw) *nw = 1; return ALG_OK; }      // host vectors: nothing to check (ABI mirror)
 int orc_newton_solve_async(alg_handle* h, int32_t init, int64_t game_id0) { return orc_newton_solve(h, init, game_id0, nullptr); }
 int orc_get_stats(alg_handle* h, alg_game_stats* stats) { for (size_t gi = 0; gi < H->g.size(); gi++) stats[gi] = H->g[gi].st; return ALG_OK; }

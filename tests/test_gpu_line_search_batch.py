@@ -1,5 +1,5 @@
 """Line search of the team kernels and of the one-wavefront unicycle kernels: step sizes tried in groups (trial_norms_multi, algames_assemble.hpp) against the one-by-one search of
-solver_methods.jl:105-125 -- same binary, ALGAMES_LS_MULTI=0 / 1 at handle creation.  The group pass reproduces the norms of the one-by-one trials bit for bit
+solver_methods.jl:105-125 -- same binary, alg_set_line_search_groups(h, 0 / 1).  The group pass reproduces the norms of the one-by-one trials bit for bit
 (the device counts disagreements in alg_game_stats.reserved), so iterates, step sizes and iteration counts are identical."""
 import os
 import numpy as np
@@ -9,13 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _problem(alg, cfg, games, waves, multi):
-    old = os.environ.get("ALGAMES_LS_MULTI")
-    os.environ["ALGAMES_LS_MULTI"] = "1" if multi else "0"
-    try:
-        prob = alg.scenarios.make_problem(cfg, np.arange(games))
-    finally:
-        if old is None: del os.environ["ALGAMES_LS_MULTI"]
-        else: os.environ["ALGAMES_LS_MULTI"] = old
+    prob = alg.scenarios.make_problem(cfg, np.arange(games))
+    prob.batch.set_line_search_groups(multi)                    # alg_set_line_search_groups: the two searches in the same binary
+    assert prob.batch.get_line_search_groups() == bool(multi)
     prob.batch.set_waves_per_game(waves)
     return prob
 

@@ -14,6 +14,9 @@
 #ifndef ALG_R6_STAGE_BATCH_W2
 #define ALG_R6_STAGE_BATCH_W2 10   // ... in the 256-register kernels (the 4-player unicycle's chunk is 20 elements per lane: 40 doubles in flight at once spilled its loop kernel)
 #endif
+#ifndef ALG_R6_PHASEA_CHUNK
+#define ALG_R6_PHASEA_CHUNK 1   // fused pass: phase A per chunk out of the staged blocks, pair-gradient tables straight into the chunk's LDS (no global round trip)
+#endif
 #ifndef ALG_R6_PHASEA
 #define ALG_R6_PHASEA 1     // phase A: multipliers / penalties of an item's pairs requested together with its positions; LDS-only fences between the staged write-outs
 #endif
@@ -72,6 +75,178 @@ __device__ __forceinline__ T sel_player(const ALG_AS4 T* tab, int i, F&& f) {
     for (int q = 1; q < NP; q++) v = (i == q) ? tab[f(q)] : v;
     return v;
 }
+// The pair / own-position terms of ONE item of phase A -- (knot k + 1, player i): collision cost and collision avoidance of the ordered pairs
+// (i, j), the extended set's wall / circle terms -- shared by the pass over all steps (assemble_phase_a) and the per-chunk form of the fused pass
+// (round 6).  xp(idx): entry idx of x_{k+1} of the (trial) iterate; lmu(jj, ci, lam, mu): multiplier and penalty of constraint row ci (pair jj);
+// rec: the step's record head [.. Hh | Hd ..] (or its staging slot), tab: the step's pair-gradient table.
+template <class C, int MODE, bool IBR, bool DUAL, class XP, class LMU>
+__device__ __forceinline__ void phase_a_pos_item(CPR pr, const Game& G, int N, int k, int i, int ip, double dt, bool pairs_on, XP&& xp, LMU&& lmu,
+                                                 double* __restrict__ rec, double* __restrict__ tab, AsmAcc& acc, bool dual) {
+    constexpr int n = C::n, P = C::P, PD = C::PD, NS = C::NS;
+    using R = Rec<C>;
+    constexpr bool RECS = (MODE == 1 || MODE == 2 || MODE == 3);
+    const int kn = k + 1;
+    const double w = (kn < N - 1) ? dt : 1.0;
+        double xi[PD], ga[PD], dd[NS];
+#pragma unroll
+        for (int a = 0; a < PD; a++) { xi[a] = xp(a * P + i); ga[a] = 0.0; }
+#pragma unroll
+        for (int t = 0; t < NS; t++) dd[t] = 0.0;
+#if ALG_R6_PHASEA
+        // Round 6: everything an item reads from global memory is requested before its arithmetic starts -- the positions of the other
+        // players and the multiplier / penalty of every pair (they sat behind the sqrt / division chains of the pair before: one exposed
+        // round trip per pair) -- and the per-player constants come from scalar loads (sel_player).
+        constexpr int NPR = P > 1 ? P - 1 : 1;
+        double xj[NPR][PD], lmq[NPR], muq[NPR];
+        if (pairs_on) {
+#pragma unroll
+            for (int jj = 0; jj < P - 1; jj++) {
+                const int j = jj < i ? jj : jj + 1;
+#pragma unroll
+                for (int a = 0; a < PD; a++) xj[jj][a] = xp(a * P + j);
+                lmq[jj] = 0.0; muq[jj] = 0.0;
+                if (pr.has_colavoid) lmu(jj, con_col<C>(N, pairq<C>(i, j), kn), lmq[jj], muq[jj]);
+            }
+        }
+        const double cc_mu_i = pr.has_colcost ? sel_player<P>(pr.cc_mu, i, [](int q) { return q; }) : 0.0;
+        const double cc_rad_i = pr.has_colcost ? sel_player<P>(pr.cc_radius, i, [](int q) { return q; }) : 0.0;
+        const unsigned ca_mask_i = sel_player<P>(pr.ca_mask, i, [](int q) { return q; });
+#endif
+#pragma unroll
+        for (int jj = 0; jj < P - 1; jj++) {
+            const int j = jj < i ? jj : jj + 1;
+            double gv[PD], H[NS];
+#pragma unroll
+            for (int a = 0; a < PD; a++) gv[a] = 0.0;
+#pragma unroll
+            for (int t = 0; t < NS; t++) H[t] = 0.0;
+            if (pairs_on) {
+                double dl[PD];
+#if ALG_R6_PHASEA
+#pragma unroll
+                for (int a = 0; a < PD; a++) dl[a] = xi[a] - xj[jj][a];
+#else
+#pragma unroll
+                for (int a = 0; a < PD; a++) dl[a] = xi[a] - xp(a * P + j);
+#endif
+                const double dl0 = dl[0], dl1 = dl[1];
+                const double s2 = pair_dist2(dl0, dl1);
+                if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173 (planar: px[i])
+#if ALG_R6_PHASEA
+                    const double nrm = sqrt(s2), mu = cc_mu_i, rad = cc_rad_i;
+#else
+                    const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
+#endif
+                    if (fmax(0.0, rad - nrm) > 0.0) {
+                        const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
+                        const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
+                        const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
+                        gv[0] += w * (-g0); gv[1] += w * (-g1);
+                        const double n3 = nrm * nrm * nrm;
+                        H[0] += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
+                        H[1] += w * (mu * (rad * (dl0 * dl1) / n3));
+                        H[2] += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
+                    }
+                }
+                if (pr.has_colavoid) {                                   // CollisionConstraint + AL expansion
+#if ALG_R6_PHASEA
+                    const double Rr = sel_player<P>(pr.ca_pair_r, i, [jj](int q) { return q * MAXP + (jj < q ? jj : jj + 1); });
+                    const double on = (double)((ca_mask_i >> j) & 1u);                        // 0: this ordered pair carries no constraint
+#else
+                    const double Rr = pr.ca_pair_r[i * MAXP + j];
+                    const double on = (double)((pr.ca_mask[i] >> j) & 1u);                    // 0: this ordered pair carries no constraint
+#endif
+                    double s2c = s2;
+                    if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c = __builtin_fma(dl[2], dl[2], s2c); }   // spherical: pz[i][1:3]
+                    const double c = ca_value(on, Rr, s2c);
+                    const int ci = con_col<C>(N, pairq<C>(i, j), kn);
+#if ALG_R6_PHASEA
+                    double lm = lmq[jj], mu_c = muq[jj];
+#else
+                    double lm = gld(G.lam(pr), ci), mu_c = gld(G.mu(pr), ci);
+#endif
+                    if (DUAL && dual) {
+                        // dual_update! with alphax_dual[i], then penalty_update! (constraints_methods.jl:421-440, 329-379): dual_penalty_update's expressions
+                        const auto& od = pr.opt;
+#if ALG_R6_PHASEA
+                        const double ax = sel_player<P>(od.alphax_dual, i, [](int q) { return q; });
+#else
+                        const double ax = od.alphax_dual[i];
+#endif
+                        lm = dual_ascent(lm, ax, mu_c, c, od.lambda_max);
+                        mu_c = fmin(fmax(mu_c * od.rho_increase, 0.0), od.rho_max);
+                        gst(G.lam(pr), ci, lm); gst(G.mu(pr), ci, mu_c); gst(G.vals(pr), ci, c);
+                    }
+                    const double am = on * al_active_mu(c, lm, mu_c);
+                    const double wl = fma(am, c, on * lm);            // (the contraction the all-pairs form always had: lm + am c)
+#pragma unroll
+                    for (int a = 0; a < PD; a++) {
+                        gv[a] = __builtin_fma(-2.0 * dl[a], wl, gv[a]);
+#pragma unroll
+                        for (int a2 = 0; a2 <= a; a2++) H[C::sym(a, a2)] += am * 4.0 * dl[a2] * dl[a];
+                    }
+                    if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < PD; a++) { ga[a] += gv[a]; tab[(i * P + j) * PD + a] = -gv[a]; }   // row opt_i at px(j,.)
+#pragma unroll
+            for (int t = 0; t < NS; t++) dd[t] += H[t];
+            if (RECS) {
+                double* hh = rec + R::HH + NS * pairq<C>(i, j);
+#pragma unroll
+                for (int t = 0; t < NS; t++) hh[t] = H[t];
+            }
+        }
+        if constexpr (C::EXT) {
+            // wall / circle constraints of player i on its own position at knot k+1: AL gradient C'(lambda + a mu c)
+            // and Gauss-Newton Hessian C' a mu C (constraint_derivatives.jl:10-19,47-58) join the (i,i) position block
+            auto al_row = [&](int ci, double c, const double (&g)[PD]) {
+                const double lm = gld(G.lam(pr), ci), am = al_active_mu(c, lm, gld(G.mu(pr), ci));
+                const double wl = lm + am * c;
+#pragma unroll
+                for (int a = 0; a < PD; a++) {
+                    ga[a] += g[a] * wl;
+#pragma unroll
+                    for (int a2 = 0; a2 <= a; a2++) dd[C::sym(a, a2)] += am * g[a2] * g[a];
+                }
+                if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
+            };
+            const double* Wc = ext_walls(pr, pr.extc); const double* Cc = ext_circs(pr, pr.extc);
+            const unsigned wmask = pr.wall_mask[i], cmask = pr.circ_mask[i];
+            for (int wq = 0; wq < pr.nwall; wq++) {
+                double g[PD] = {}; const double on = (double)((wmask >> wq) & 1u);
+                const double c = on * wall_val(Wc, wq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
+                al_row(ext_wall_row(pr, i, k, wq), c, g);
+            }
+            for (int cq = 0; cq < pr.ncirc; cq++) {
+                double g[PD] = {}; const double on = (double)((cmask >> cq) & 1u);
+                const double c = on * circ_val(Cc, cq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
+                al_row(ext_circ_row(pr, i, k, cq), c, g);
+            }
+            if constexpr (PD == 3) {
+                const double* W3 = ext_walls3(pr, pr.extc); const double* Yc = ext_cyls(pr, pr.extc);
+                const unsigned w3mask = pr.wall3_mask[i], cymask = pr.cyl_mask[i];
+                for (int wq = 0; wq < pr.nwall3; wq++) {
+                    double g[3]; const double on = (double)((w3mask >> wq) & 1u);
+                    const double c = on * wall3_val(W3, wq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
+                    al_row(ext_wall3_row(pr, i, k, wq), c, g);
+                }
+                for (int cq = 0; cq < pr.ncyl; cq++) {
+                    double g[3]; const double on = (double)((cymask >> cq) & 1u);
+                    const double c = on * cyl_val(Yc, cq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
+                    al_row(ext_cyl_row(pr, i, k, cq), c, g);
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < PD; a++) tab[(i * P + i) * PD + a] = ga[a];           // row opt_i at px(i,.)
+        if (RECS) {
+#pragma unroll
+            for (int t = 0; t < NS; t++) rec[R::HD + NS * i + t] = dd[t];
+        }
+}
+
 // Phase A of the assemble pass (see assemble_pass): RK2 Jacobian coefficients and the pair / wall / circle terms of every (knot, player).
 // dzp != nullptr: the positions are those of the trial iterate z + alpha dz, formed on the fly (fused trial pass of the double integrator).
 // DUAL (round 6): the pass is the record! that follows dual_update! + penalty_update! (solver_methods.jl:57-61 then :73): both stream the same
@@ -106,8 +281,8 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                 // Jacobian coefficients of knot k (A_k, B_k): see the model section (of the trial iterate when dzp is given)
                 const double* sk = zstate<C>(z, k); const double* dk = (dzp && k > 0) ? zstate<C>(dzp, k) : nullptr;      // (x_1 does not move)
                 const int uo_ = n + hu<C>(k, i);
-                auto sv = [&](int idx) { const double q = sk[idx]; return dk ? q + alpha * dk[idx] : q; };
-                auto uv = [&](int j) { const double q = z[uo_ + j]; return dzp ? q + alpha * dzp[uo_ + j] : q; };
+                auto sv = [&](int idx) { const double q = sk[idx]; return dk ? __builtin_fma(alpha, dk[idx], q) : q; };      // (update_traj!'s fma: the value the trial buffer holds)
+                auto uv = [&](int j) { const double q = z[uo_ + j]; return dzp ? __builtin_fma(alpha, dzp[uo_ + j], q) : q; };
                 const double th = sv(2 * P + i), v = sv(3 * P + i);
                 const double om = uv(0), ac = uv(1);
                 const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
@@ -116,168 +291,10 @@ __device__ __forceinline__ void assemble_phase_a(CPR pr, const Game& G, AsmLds<C
                 rec[R::COEF + 2 * P + i] = dt * vm * cs;  rec[R::COEF + 3 * P + i] = dt * sn;
             }
             if constexpr (C::POS) {
-                constexpr int PD = C::PD, NS = C::NS;
-                const double w = (kn < N - 1) ? dt : 1.0;
                 const double* x1 = z + n + hx<C>(k); const double* d1 = dzp ? dzp + n + hx<C>(k) : nullptr;
-                auto xp = [&](int idx) { const double v = gld(x1, idx); return d1 ? v + alpha * gld(d1, idx) : v; };    // position of the (trial) iterate
-                double xi[PD], ga[PD], dd[NS];
-#pragma unroll
-                for (int a = 0; a < PD; a++) { xi[a] = xp(a * P + i); ga[a] = 0.0; }
-#pragma unroll
-                for (int t = 0; t < NS; t++) dd[t] = 0.0;
-#if ALG_R6_PHASEA
-                // Round 6: everything an item reads from global memory is requested before its arithmetic starts -- the positions of the other
-                // players and the multiplier / penalty of every pair (they sat behind the sqrt / division chains of the pair before: one exposed
-                // round trip per pair) -- and the per-player constants come from scalar loads (sel_player).
-                constexpr int NPR = P > 1 ? P - 1 : 1;
-                double xj[NPR][PD], lmq[NPR], muq[NPR];
-                if (pairs_on) {
-#pragma unroll
-                    for (int jj = 0; jj < P - 1; jj++) {
-                        const int j = jj < i ? jj : jj + 1;
-#pragma unroll
-                        for (int a = 0; a < PD; a++) xj[jj][a] = xp(a * P + j);
-                        lmq[jj] = 0.0; muq[jj] = 0.0;
-                        if (pr.has_colavoid) { const int ci = con_col<C>(N, pairq<C>(i, j), kn); lmq[jj] = gld(G.lam(pr), ci); muq[jj] = gld(G.mu(pr), ci); }
-                    }
-                }
-                const double cc_mu_i = pr.has_colcost ? sel_player<P>(pr.cc_mu, i, [](int q) { return q; }) : 0.0;
-                const double cc_rad_i = pr.has_colcost ? sel_player<P>(pr.cc_radius, i, [](int q) { return q; }) : 0.0;
-                const unsigned ca_mask_i = sel_player<P>(pr.ca_mask, i, [](int q) { return q; });
-#endif
-#pragma unroll
-                for (int jj = 0; jj < P - 1; jj++) {
-                    const int j = jj < i ? jj : jj + 1;
-                    double gv[PD], H[NS];
-#pragma unroll
-                    for (int a = 0; a < PD; a++) gv[a] = 0.0;
-#pragma unroll
-                    for (int t = 0; t < NS; t++) H[t] = 0.0;
-                    if (pairs_on) {
-                        double dl[PD];
-#if ALG_R6_PHASEA
-#pragma unroll
-                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - xj[jj][a];
-#else
-#pragma unroll
-                        for (int a = 0; a < PD; a++) dl[a] = xi[a] - xp(a * P + j);
-#endif
-                        const double dl0 = dl[0], dl1 = dl[1];
-                        const double s2 = pair_dist2(dl0, dl1);
-                        if (pr.has_colcost) {                                    // CollisionCost, objective.jl:134-173 (planar: px[i])
-#if ALG_R6_PHASEA
-                            const double nrm = sqrt(s2), mu = cc_mu_i, rad = cc_rad_i;
-#else
-                            const double nrm = sqrt(s2), mu = pr.cc_mu[i], rad = pr.cc_radius[i];
-#endif
-                            if (fmax(0.0, rad - nrm) > 0.0) {
-                                const double eps = 1e-10, eps_norm = eps * sqrt((double)n);
-                                const double g0 = mu * (rad * (eps + dl0) / (eps_norm + nrm) - dl0);
-                                const double g1 = mu * (rad * (eps + dl1) / (eps_norm + nrm) - dl1);
-                                gv[0] += w * (-g0); gv[1] += w * (-g1);
-                                const double n3 = nrm * nrm * nrm;
-                                H[0] += w * (mu * (1.0 - rad / nrm + rad * (dl0 * dl0) / n3));
-                                H[1] += w * (mu * (rad * (dl0 * dl1) / n3));
-                                H[2] += w * (mu * (1.0 - rad / nrm + rad * (dl1 * dl1) / n3));
-                            }
-                        }
-                        if (pr.has_colavoid) {                                   // CollisionConstraint + AL expansion
-#if ALG_R6_PHASEA
-                            const double Rr = sel_player<P>(pr.ca_pair_r, i, [jj](int q) { return q * MAXP + (jj < q ? jj : jj + 1); });
-                            const double on = (double)((ca_mask_i >> j) & 1u);                        // 0: this ordered pair carries no constraint
-#else
-                            const double Rr = pr.ca_pair_r[i * MAXP + j];
-                            const double on = (double)((pr.ca_mask[i] >> j) & 1u);                    // 0: this ordered pair carries no constraint
-#endif
-                            double s2c = s2;
-                            if constexpr (PD == 3) { if (pr.ca_dim != 3) dl[2] = 0.0; s2c = __builtin_fma(dl[2], dl[2], s2c); }   // spherical: pz[i][1:3]
-                            const double c = ca_value(on, Rr, s2c);
-                            const int ci = con_col<C>(N, pairq<C>(i, j), kn);
-#if ALG_R6_PHASEA
-                            double lm = lmq[jj], mu_c = muq[jj];
-#else
-                            double lm = gld(G.lam(pr), ci), mu_c = gld(G.mu(pr), ci);
-#endif
-                            if (DUAL && dual) {
-                                // dual_update! with alphax_dual[i], then penalty_update! (constraints_methods.jl:421-440, 329-379): dual_penalty_update's expressions
-                                const auto& od = pr.opt;
-#if ALG_R6_PHASEA
-                                const double ax = sel_player<P>(od.alphax_dual, i, [](int q) { return q; });
-#else
-                                const double ax = od.alphax_dual[i];
-#endif
-                                lm = dual_ascent(lm, ax, mu_c, c, od.lambda_max);
-                                mu_c = fmin(fmax(mu_c * od.rho_increase, 0.0), od.rho_max);
-                                gst(G.lam(pr), ci, lm); gst(G.mu(pr), ci, mu_c); gst(G.vals(pr), ci, c);
-                            }
-                            const double am = on * al_active_mu(c, lm, mu_c);
-                            const double wl = fma(am, c, on * lm);            // (the contraction the all-pairs form always had: lm + am c)
-#pragma unroll
-                            for (int a = 0; a < PD; a++) {
-                                gv[a] = __builtin_fma(-2.0 * dl[a], wl, gv[a]);
-#pragma unroll
-                                for (int a2 = 0; a2 <= a; a2++) H[C::sym(a, a2)] += am * 4.0 * dl[a2] * dl[a];
-                            }
-                            if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < PD; a++) { ga[a] += gv[a]; tab[(i * P + j) * PD + a] = -gv[a]; }   // row opt_i at px(j,.)
-#pragma unroll
-                    for (int t = 0; t < NS; t++) dd[t] += H[t];
-                    if (RECS) {
-                        double* hh = rec + R::HH + NS * pairq<C>(i, j);
-#pragma unroll
-                        for (int t = 0; t < NS; t++) hh[t] = H[t];
-                    }
-                }
-                if constexpr (C::EXT) {
-                    // wall / circle constraints of player i on its own position at knot k+1: AL gradient C'(lambda + a mu c)
-                    // and Gauss-Newton Hessian C' a mu C (constraint_derivatives.jl:10-19,47-58) join the (i,i) position block
-                    auto al_row = [&](int ci, double c, const double (&g)[PD]) {
-                        const double lm = gld(G.lam(pr), ci), am = al_active_mu(c, lm, gld(G.mu(pr), ci));
-                        const double wl = lm + am * c;
-#pragma unroll
-                        for (int a = 0; a < PD; a++) {
-                            ga[a] += g[a] * wl;
-#pragma unroll
-                            for (int a2 = 0; a2 <= a; a2++) dd[C::sym(a, a2)] += am * g[a2] * g[a];
-                        }
-                        if (MODE == 2) G.vals(pr)[ci] = c; if (!IBR || i == ip) acc.vsta = fmax(acc.vsta, fmax(0.0, c));
-                    };
-                    const double* Wc = ext_walls(pr, pr.extc); const double* Cc = ext_circs(pr, pr.extc);
-                    const unsigned wmask = pr.wall_mask[i], cmask = pr.circ_mask[i];
-                    for (int wq = 0; wq < pr.nwall; wq++) {
-                        double g[PD] = {}; const double on = (double)((wmask >> wq) & 1u);
-                        const double c = on * wall_val(Wc, wq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
-                        al_row(ext_wall_row(pr, i, k, wq), c, g);
-                    }
-                    for (int cq = 0; cq < pr.ncirc; cq++) {
-                        double g[PD] = {}; const double on = (double)((cmask >> cq) & 1u);
-                        const double c = on * circ_val(Cc, cq, xi[0], xi[1], &g[0], &g[1]); g[0] *= on; g[1] *= on;
-                        al_row(ext_circ_row(pr, i, k, cq), c, g);
-                    }
-                    if constexpr (PD == 3) {
-                        const double* W3 = ext_walls3(pr, pr.extc); const double* Yc = ext_cyls(pr, pr.extc);
-                        const unsigned w3mask = pr.wall3_mask[i], cymask = pr.cyl_mask[i];
-                        for (int wq = 0; wq < pr.nwall3; wq++) {
-                            double g[3]; const double on = (double)((w3mask >> wq) & 1u);
-                            const double c = on * wall3_val(W3, wq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
-                            al_row(ext_wall3_row(pr, i, k, wq), c, g);
-                        }
-                        for (int cq = 0; cq < pr.ncyl; cq++) {
-                            double g[3]; const double on = (double)((cymask >> cq) & 1u);
-                            const double c = on * cyl_val(Yc, cq, xi, g); g[0] *= on; g[1] *= on; g[2] *= on;
-                            al_row(ext_cyl_row(pr, i, k, cq), c, g);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int a = 0; a < PD; a++) tab[(i * P + i) * PD + a] = ga[a];           // row opt_i at px(i,.)
-                if (RECS) {
-#pragma unroll
-                    for (int t = 0; t < NS; t++) rec[R::HD + NS * i + t] = dd[t];
-                }
+                auto xp = [&](int idx) { const double v = gld(x1, idx); return d1 ? __builtin_fma(alpha, gld(d1, idx), v) : v; };    // position of the (trial) iterate: update_traj!'s fma
+                auto lmu = [&](int, int ci, double& lm, double& mu_c) { lm = gld(G.lam(pr), ci); mu_c = gld(G.mu(pr), ci); };
+                phase_a_pos_item<C, MODE, IBR, DUAL>(pr, G, N, k, i, ip, dt, pairs_on, xp, lmu, rec, tab, acc, dual);
             }
           }
           if constexpr (STAGED) {
@@ -557,8 +574,14 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
     AsmAcc acc;
     LSP_T0 LSP_COUNT(25)
     // ---- phase A over all steps (positions of the trial iterate formed on the fly), heads and tables to the records as in assemble_pass
-    assemble_phase_a<C, MODE, false, DUAL>(pr, G, L, zs, AXPY ? dz : nullptr, alpha, N, lane, dt, -1, acc, dual);
+    // Round 6 (PCH): phase A runs per chunk, out of the staged blocks -- the positions of iterate and direction are not read a second time from
+    // global memory, the pair-gradient tables never leave the chunk's LDS, the Jacobian coefficients of the unicycle go straight to the chunk
+    // (and to the records for the sweeps), the record heads [Hh | Hd] are stored by the items themselves.  One item per lane: (step, player).
+    constexpr bool PCH = ALG_R6_PHASEA_CHUNK != 0 && (C::POS || NC > 0);
+    static_assert(!PCH || (FT + 1) * P <= NT, "one phase-A item per lane and chunk");
+    if constexpr (!PCH) assemble_phase_a<C, MODE, false, DUAL>(pr, G, L, zs, AXPY ? dz : nullptr, alpha, N, lane, dt, -1, acc, dual);
     LSP(20)
+    const bool pairs_on = P > 1 && (pr.has_colcost || pr.has_colavoid);
     auto& Ch = L.ch;
     for (int e = lane; e < AsmLds<C>::NLQR; e += NT) Ch.lqr[e] = G.Qd(pr)[e];          // [Qd | xf | Rd | uf]
     const double* lQd = Ch.lqr; const double* lxf = lQd + P * ni; const double* lRd = lQd + 2 * P * ni; const double* luf = lRd + P * mi;
@@ -574,11 +597,26 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
     for (int k0 = 0; k0 < N - 1; k0 += FT) {
         const int nst = (N - 1 - k0) < FT ? (N - 1 - k0) : FT;            // steps of this chunk
         const int nblk = (k0 + nst < N - 1) ? nst + 1 : nst;             // blocks staged: the chunk's and the next one (A' lambda_{k+1})
+        // (PCH) multipliers / penalties of this lane's phase-A item, requested ahead of the chunk's blocks
+        constexpr int NPR = P > 1 ? P - 1 : 1;
+        const int aks = lane / P, ai = lane % P;                          // phase-A item of this lane: (step k0 + aks, player ai)
+        double plm[NPR], pmu[NPR];
+        if constexpr (PCH && C::POS) {
+#pragma unroll
+            for (int jj = 0; jj < NPR; jj++) { plm[jj] = 0.0; pmu[jj] = 0.0; }
+            if (pairs_on && pr.has_colavoid && aks < nst) {
+#pragma unroll
+                for (int jj = 0; jj < P - 1; jj++) {
+                    const int j = jj < ai ? jj : jj + 1, ci = con_col<C>(N, pairq<C>(ai, j), k0 + aks + 1);
+                    plm[jj] = gld(G.lam(pr), ci); pmu[jj] = gld(G.mu(pr), ci);
+                }
+            }
+        }
         // ---- stage: x_k of the first step, then blocks k0 .. k0 + nblk - 1; the trial blocks of the chunk's own steps go out here
         if (lane < n) {
             const int src = k0 == 0 ? lane : n + (k0 - 1) * b + lane;
             double v = zs[src];
-            if (AXPY && k0 > 0) v = v + alpha * dz[src];                  // (x_1 does not move)
+            if (AXPY && k0 > 0) v = __builtin_fma(alpha, dz[src], v);      // (x_1 does not move)
             Ch.xprev[lane] = v;
         }
         {
@@ -593,11 +631,11 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             constexpr int TU = C::POS ? (FT * TAB + NT - 1) / NT : 1, CU = NC > 0 ? ((FT + 1) * NC + NT - 1) / NT : 1;
             double gt[TU], cf[CU];
             const int tcnt = nst * TAB, ccnt = nblk * NC;
-            if constexpr (C::POS) {
+            if constexpr (C::POS && !PCH) {
 #pragma unroll
                 for (int t = 0; t < TU; t++) { const int e = lane + t * NT; gt[t] = gld(recg + R::gvt(N, k0), e < tcnt ? e : 0); }            // contiguous behind the records
             }
-            if constexpr (NC > 0) {                                        // Jacobian coefficients of the staged steps (phase A left them in the records)
+            if constexpr (NC > 0 && !PCH) {                                // Jacobian coefficients of the staged steps (phase A left them in the records)
 #pragma unroll
                 for (int t = 0; t < CU; t++) { const int e = lane + t * NT, ec = e < ccnt ? e : 0; cf[t] = gld(recg, (k0 + ec / NC) * R::LEN + R::COEF + ec % NC); }
             }
@@ -617,7 +655,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                 for (int t = 0; t < SB; t++) {
                     if (t0 + t >= SU) break;
                     const int ec = ecv[t];
-                    const double v = AXPY ? a[t] + alpha * d[t] : a[t];
+                    const double v = AXPY ? __builtin_fma(alpha, d[t], a[t]) : a[t];
                     Ch.zt[ec] = v;
                     if (AXPY) gst(zo + base, ec, v);
                     const int j = ec / b, o = ec % b;
@@ -625,11 +663,11 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                     *xu = a[t];
                 }
             }
-            if constexpr (C::POS) {
+            if constexpr (C::POS && !PCH) {
 #pragma unroll
                 for (int t = 0; t < TU; t++) { const int e = lane + t * NT; if (e < tcnt) Ch.gvt[e] = gt[t]; }
             }
-            if constexpr (NC > 0) {
+            if constexpr (NC > 0 && !PCH) {
 #pragma unroll
                 for (int t = 0; t < CU; t++) { const int e = lane + t * NT; if (e < ccnt) Ch.coef[e] = cf[t]; }
             }
@@ -642,7 +680,7 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                 for (int t = 0; t < 4; t++) {
                     const int e = e0 + t * NT;
                     if (e < cnt) {
-                        const double v = AXPY ? a[t] + alpha * d[t] : a[t];
+                        const double v = AXPY ? __builtin_fma(alpha, d[t], a[t]) : a[t];
                         Ch.zt[e] = v;
                         if (AXPY && e < own) gst(zo + base, e, v);
                         const int j = e / b, o = e % b;
@@ -661,6 +699,38 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
 #endif
         }
         fsync();
+        if constexpr (PCH) {
+            const int k = k0 + aks;
+            if constexpr (C::MODEL == ALG_MODEL_UNICYCLE) {
+                // Jacobian coefficients of step k (A_k, B_k) from the staged (trial) values: x_k is the block before, u_k the step's own block
+                if (aks < nblk) {
+                    const double* xk = aks == 0 ? Ch.xprev : Ch.zt + (aks - 1) * b; const double* uk = Ch.zt + aks * b + n + ai * mi;
+                    const double th = xk[2 * P + ai], v = xk[3 * P + ai], om = uk[0], ac = uk[1];
+                    const double thm = th + (om * dt) * 0.5, vm = v + (ac * dt) * 0.5;
+                    double sn, cs; sincos(thm, &sn, &cs);
+                    const double c0 = -dt * vm * sn, c1 = dt * cs, c2 = dt * vm * cs, c3 = dt * sn;
+                    double* cl = Ch.coef + aks * NC;
+                    cl[0 * P + ai] = c0; cl[1 * P + ai] = c1; cl[2 * P + ai] = c2; cl[3 * P + ai] = c3;
+                    if (RECS && aks < nst) {                                   // (the extra block's step belongs to the next chunk)
+                        double* rc = recg + (size_t)k * R::LEN + R::COEF;
+                        rc[0 * P + ai] = c0; rc[1 * P + ai] = c1; rc[2 * P + ai] = c2; rc[3 * P + ai] = c3;
+                    }
+                }
+            }
+            if constexpr (C::POS) {
+                if (aks < nst) {
+                    const double* x1 = Ch.zt + aks * b;
+                    auto xp = [&](int idx) { return x1[idx]; };
+                    auto lmu = [&](int jj, int, double& lm, double& mu_c) {
+                        lm = plm[0]; mu_c = pmu[0];
+#pragma unroll
+                        for (int q = 1; q < NPR; q++) { lm = (jj == q) ? plm[q] : lm; mu_c = (jj == q) ? pmu[q] : mu_c; }
+                    };
+                    phase_a_pos_item<C, MODE, false, DUAL>(pr, G, N, k, ai, -1, dt, pairs_on, xp, lmu, recg + (size_t)k * R::LEN, Ch.gvt + aks * TAB, acc, dual);
+                }
+            }
+            fsync();
+        }
         // ---- rows opt_i,x_{k+1}[a]
         for (int e = lane; e < nst * P * n; e += NT) {
             const int ks = e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n, k = k0 + ks;
@@ -1032,16 +1102,16 @@ __device__ __forceinline__ void update_traj(CPR pr0, const Game& G0, int tsel, i
 #pragma unroll
             for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S2 ? e : e0; a[t] = gld_t(s2, ec); d[t] = gld_t(d2, ec); }
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S2) { double2_t v; v.x = a[t].x + alpha * d[t].x; v.y = a[t].y + alpha * d[t].y; gst_t(t2, e, v); } }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S2) { double2_t v; v.x = __builtin_fma(alpha, d[t].x, a[t].x); v.y = __builtin_fma(alpha, d[t].y, a[t].y); gst_t(t2, e, v); } }
         }
-        if ((S & 1) && lane == 0) tgt[C::n + S - 1] = src[C::n + S - 1] + alpha * dz[C::n + S - 1];
+        if ((S & 1) && lane == 0) tgt[C::n + S - 1] = __builtin_fma(alpha, dz[C::n + S - 1], src[C::n + S - 1]);
     } else {
         for (int e0 = lane; e0 < S; e0 += U * C::NT) {
             double a[U], d[U];
 #pragma unroll
             for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; const int ec = e < S ? e : e0; a[t] = gld(src + C::n, ec); d[t] = gld(dz + C::n, ec); }
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S) gst(tgt + C::n, e, a[t] + alpha * d[t]); }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < S) gst(tgt + C::n, e, __builtin_fma(alpha, d[t], a[t])); }
         }
     }
 }

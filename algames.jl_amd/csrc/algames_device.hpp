@@ -637,6 +637,28 @@ __device__ __forceinline__ double BT_vec(const double* coef, double dt, V v, int
         return __builtin_fma(0.5 * dt, inner, dt * v((2 + kind) * P + i));
     }
 }
+// (|B|^T v)[c] for v >= 0: BT_vec with the magnitudes of the coefficients -- the row scale |B[:,c]|' |dlambda| of the refinement gate's
+// backward error (dir_urow_residual), in BT_vec's association
+template <class C, class V>
+__device__ __forceinline__ double BT_vec_abs(const double* coef, double dt, V v, int c) {
+    if constexpr (C::QUAD) {
+        const int P = C::P, i = c % P, j = c / P; const double* Bi = coef + i * C::QS + C::QB;
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 12; a++) acc += fabs(Bi[a * 4 + j]) * v(a * P + i);
+        return acc;
+    } else if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        return __builtin_fma(0.5 * dt * dt, v(c), dt * v(c + C::m));                 // B is non-negative
+    } else if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+        const int P = C::P, i = c % P; const bool k0 = (c / P) == 0;
+        const double ca = fabs(coef[(k0 ? 5 : 7) * P + i]), cb = fabs(coef[(k0 ? 6 : 8) * P + i]), cc = fabs(coef[(k0 ? 4 : 9) * P + i]);
+        return (k0 ? 0.5 * dt : 1.0) * (ca * v(i) + cb * v(P + i) + cc * v(3 * P + i)) + (k0 ? dt : 0.0) * v(2 * P + i);
+    } else {
+        const int P = C::P, i = c % P, kind = c / P;
+        const double inner = __builtin_fma(fabs(coef[kind * P + i]), v(i), fabs(coef[(2 + kind) * P + i]) * v(P + i));
+        return __builtin_fma(0.5 * dt, inner, dt * v((2 + kind) * P + i));
+    }
+}
 // (B w)[r] for a control-vector accessor w(c): row r of B has <= 2 non-zeros
 template <class C, class V>
 __device__ __forceinline__ double B_vec(const double* coef, double dt, V w, int r) {

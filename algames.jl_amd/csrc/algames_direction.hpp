@@ -2104,8 +2104,9 @@ __device__ DirGate dir_urow_residual(CPR pr0, const Game& G0, int ip) {
         const double du = gld(dz, n + hu<C>(k, 0) + uoff<C>(c));
         const double rh = gld(recs, ro + R::RHAT + c), ru = gld(recs, ro + R::RU + c);
         const double bl = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return gld(dz, dlo + rr); }, c);
-        // |B[:,c]|' |dlambda| from below: the coefficients keep their signs (exact for the double integrator, whose B is non-negative)
-        const double bla = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return fabs(gld(dz, dlo + rr)); }, c);
+        // |B[:,c]|' |dlambda|: the true row scale (round 6; until round 5 the coefficients kept their signs -- a lower estimate that made the
+        // gate's figure up to 259 x conservative on rows whose terms cancel)
+        const double bla = BT_vec_abs<C>(Rk + R::COEF, dt, [&](int rr) { return fabs(gld(dz, dlo + rr)); }, c);
         double rho = fma(rh, du, ru) + bl;
         if (IBR && i != ip) rho = 0.0;                                  // unit rows of the other players (du_c = 0)
         const double sc = fabs(rh * du) + fabs(ru) + fabs(bla);         // row scale |J_c| |d| + |ru_c|
@@ -2234,6 +2235,7 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         // backward error of the whole direction: the row-wise omega of the first solve; after a correction, the residual of the correction
         // system IS the new residual of the whole system, so omega contracts like max |rho| did
         double omega;
+        bool stalled = false;                          // a correction that did not at least halve max |rho|: the next one would not either
         if (pass == 0) {
             omega = gt.omega;
             if (phase_lane() == 0) { tc[TC_RHO] = gt.rho; tc[TC_OMEGA] = gt.omega; tc[TC_SMAX] = gt.smax; tc[TC_OMCUR] = gt.omega; tc[TC_RHOCUR] = gt.rho; }
@@ -2242,6 +2244,7 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
             dir_add_correction<C>(pr, G0, pl1, dn, bad);
             const double rho_prev = tc[TC_RHOCUR];
             omega = tc[TC_OMCUR] * (gt.rho / fmax(rho_prev, 1e-300));
+            stalled = !(uni(gt.rho) < 0.5 * uni(rho_prev));
             game_sync();                               // every lane has read the slots
             if (phase_lane() == 0) { tc[TC_PL1] = pl1; tc[TC_OMCUR] = omega; tc[TC_RHOCUR] = gt.rho; }
             game_sync();
@@ -2254,8 +2257,12 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         // The dense elimination (quadrotor: dense 12 x 12 blocks per player, controls acting through two integrators, rotor costs down to 1e-4;
         // n up to 48) needs a tighter gate and no relaxation: its directions miss the LU's backward error (1e-18) by four orders at row-wise
         // errors of 1e-11 already (tests/test_gpu_fuzz.py::test_direction_backward_error_against_the_arbiter passes from tol / 64 on).
-        const double tol = phase_f64(pr.refine_tol) * (C::DENSE ? 0x1p-6 : 1.0);
-        bool done = !(uni(omega) > tol) || pass >= rmax;
+        // (round 6: the gate's row scale is the true |J_c| |d| + |r_c| -- until round 5 an estimate from below made omega up to 259 x conservative
+        // and tol / 64 was calibrated on that; with the true scale the same directions need tol / 256 for the 1e-15 normwise bound.  The dense
+        // configurations take up to six corrections while each one at least halves the residual: an ill-conditioned quadrotor system (fuzz seed
+        // 400051: forward error 5.6e-4 from the bare elimination) contracts by 30 ... 3000 x per correction, tests/probes/r06_dense_gap.py.)
+        const double tol = phase_f64(pr.refine_tol) * (C::DENSE ? 0x1p-8 : 1.0);
+        bool done = !(uni(omega) > tol) || pass >= rmax || (stalled && tol > 0.0);     // (tol = 0 forces max_steps corrections: the tests' way to count them)
         if (!done && !C::DENSE && !(uni(omega) > 256.0 * tol)) {
             const double mumax = con_mu_max<C>(pr, G0);
             const double relax = fmin(fmax(phase_f64(pr.refine_mu) / fmax(mumax, 1e-300), 1.0), 256.0);

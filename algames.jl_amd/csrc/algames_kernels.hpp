@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(WAVE, (C::WPE < 2 ? C::WPE : 2)) k_ibr(Params 
 // builder-defined MPC advance: x0 <- RK2(x_1, u_1) per game (lanes < P own a player), totals += solve
 template <class C>
 __device__ __forceinline__ void mpc_advance(CPR pr, const Game& G) {
-    const int lane = threadIdx.x;
+    const int lane = phase_lane();
     if constexpr (C::QUAD) {
         if (lane < C::P) {
             double xi[12], ui[4], xo[12];
@@ -216,12 +216,16 @@ __global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_a
     Game G = game_view(pr, g);
     if (ka.states && (int)threadIdx.x < C::n) ka.states[(size_t)g * C::n + threadIdx.x] = G.x0(pr)[threadIdx.x];
     for (int t = 0; t < ka.steps; t++) {
-        newton_solve<C>(pr, G, L, 1, ka.game_id0 + (uint64_t)t * 1000003ull + (uint64_t)g, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
+        // (everything the step needs besides `t` is re-derived from opaque roots inside the loop -- the game's index, the lane's predicates, the
+        // arguments: as invariants of this loop they were live, i.e. spilled, across every phase of every solve)
+        const int gq = phase_int(g);
+        newton_solve<C>(pr, G, L, 1, ka.game_id0 + (uint64_t)t * 1000003ull + (uint64_t)gq, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
         __syncthreads();
-        mpc_advance<C>(pr, G);
+        mpc_advance<C>(phase_params(pr), G.fresh());
         __syncthreads();
         double* const states = ka.states;
-        if (states && (int)threadIdx.x < C::n) states[((size_t)(t + 1) * pr.B + g) * C::n + threadIdx.x] = G.z(0)[threadIdx.x];
+        const int ln = phase_lane();
+        if (states && ln < C::n) { CPR prs = phase_params(pr); states[((size_t)(t + 1) * prs.B + phase_int(g)) * C::n + ln] = G.fresh().z(0)[ln]; }
         __syncthreads();
     }
 }

@@ -297,10 +297,22 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
 }
 
 // rollout!(RK3, model, traj) (solver_methods.jl:17): lanes < P integrate their own player (players are decoupled)
+// lds / cap: optional LDS scratch of `cap` doubles (the solver kernels pass their idle Lds union).  The states are written into the very array
+// the controls are read from, so the compiler keeps every step's control loads behind the previous step's state stores: the rollout
+// of a C2 game waited for 39 global round trips in a row -- 190 K cycles per solve, 3 % of it (profiles/r06_phase_cycles_c2_4096_*.txt).
+// With the scratch the controls of all steps are fetched in one go (every thread of the game, all loads in flight) and the serial loop
+// reads them at LDS latency.  Same arithmetic on the same numbers.
 template <class C>
-__device__ __forceinline__ void rollout(CPR pr, double* z) {
+__device__ __forceinline__ void rollout(CPR pr, double* z, double* lds = nullptr, int cap = 0) {
     constexpr int n = C::n, m = C::m, P = C::P;
     const int lane = game_tid();
+    const int NU = (pr.N - 1) * m;
+    const bool staged = lds != nullptr && NU <= cap;                        // wave-uniform
+    if (staged) {
+        for (int e = lane; e < NU; e += C::NT) lds[e] = gld(z, n + (e / m) * C::b + n + e % m);      // u_k, player-grouped like the trajectory
+        game_sync();
+    }
+    auto uget = [&](int k, int i, int j) { return staged ? lds[k * m + i * C::mi + j] : z[n + hu<C>(k, i) + j]; };
     if constexpr (C::QUAD) {
         if (lane < P) {
             double xi[12], ui[4], xo[12];
@@ -308,7 +320,7 @@ __device__ __forceinline__ void rollout(CPR pr, double* z) {
             for (int j = 0; j < 12; j++) xi[j] = z[lane + j * P];
             for (int k = 0; k < pr.N - 1; k++) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) ui[j] = z[n + hu<C>(k, lane) + j];
+                for (int j = 0; j < 4; j++) ui[j] = uget(k, lane, j);
                 quad_rk3(xi, ui, pr.qmass, pr.dt, xo);
 #pragma unroll
                 for (int j = 0; j < 12; j++) { xi[j] = xo[j]; z[n + hx<C>(k) + lane + j * P] = xo[j]; }
@@ -318,12 +330,13 @@ __device__ __forceinline__ void rollout(CPR pr, double* z) {
         double x[n], u[m];     // only this player's entries are used
         for (int j = 0; j < C::ni; j++) x[lane + j * P] = z[lane + j * P];
         for (int k = 0; k < pr.N - 1; k++) {
-            for (int j = 0; j < C::mi; j++) u[lane + j * P] = z[n + hu<C>(k, lane) + j];
+            for (int j = 0; j < C::mi; j++) u[lane + j * P] = uget(k, lane, j);
             double xn[C::ni];
             model_player_rk3<C>(pr, lane, x, u, pr.dt, xn);
             for (int j = 0; j < C::ni; j++) { x[lane + j * P] = xn[j]; z[n + hx<C>(k) + lane + j * P] = xn[j]; }
         }
     }
+    if (staged) game_sync();                                                // the scratch is the caller's LDS union again
 }
 
 // init_traj! (primal_dual_traj.jl:29-44) with the counter RNG (same element counters as the oracle)
@@ -464,7 +477,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
     if (lane < C::n) { G.z(1)[lane] = G.x0(pr)[lane]; G.z(2)[lane] = 0.0; }    // :14-15 (only x_1 of the trial matters)
     game_sync();
-    rollout<C>(pr, G.z(0));                                                // :17
+    rollout<C>(pr, G.z(0), reinterpret_cast<double*>(&L), (int)(sizeof(Lds<C>) / sizeof(double)));     // :17
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con<C::NT>(pr, G);     // :25
     game_sync();
     }

@@ -126,3 +126,18 @@ def reduce_counters(counts, elapsed, world, device, group=None, use_dist=None):
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     return [int(v) for v in tot.tolist()], float(tmax.item())
+
+
+def gather_shard_ranges(lo, hi, world, device, group=None, use_dist=None):
+    """[[lo, hi), ...] of every rank's contiguous global scenario ids, in rank order (one all_gather of two int64; no collective for a
+    world of one unless `use_dist`): what a caller checks to see that the shards tile the job."""
+    import torch
+    mine = torch.tensor([int(lo), int(hi)], dtype=torch.int64, device=device)
+    if use_dist is None:
+        use_dist = world > 1
+    if not use_dist:
+        return [[int(lo), int(hi)]]
+    import torch.distributed as dist
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [[int(t[0]), int(t[1])] for t in out]

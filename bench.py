@@ -327,6 +327,8 @@ def main():
         G = total // world                                           # equal shards: every rank picks the same kernel shape
     else:
         G = args.games_per_gpu or default_games
+    if os.environ.get("ALGAMES_BENCH_FAIL_RANK") == str(rank):       # test hook (tests/test_gpu_bench_ranks.py): a rank that dies must fail the job
+        raise SystemExit(f"bench.py: rank {rank} fails on request (ALGAMES_BENCH_FAIL_RANK)")
     prob, ids = make_shard(alg, args.config, G, rank, world, device=local_rank)
     b = prob.batch
     if args.perturb:
@@ -390,6 +392,7 @@ def main():
     balance = float(per_game.mean() / max(1, per_game.max()))
     bad_rank = int((st["status"] != 0).sum())
     refinements_rank = int(st["refinements"].sum())          # correction solves of the last launch (mpc mode: of every game's last solve)
+    shard_ranges = alg.sharding.gather_shard_ranges(int(ids[0]), int(ids[-1]) + 1, world, "cuda", use_dist=use_dist)
     (iters_all, conv_all, bad_all), elapsed = reduce_counters(alg, [iters_rank, conv_rank, bad_rank], elapsed, world, "cuda", use_dist=use_dist)
 
     if rank == 0:
@@ -452,9 +455,10 @@ def main():
                        "perturb": args.perturb,
                        "name": args.config,
                        "games_per_gpu": G, "games_total": G * world, "newton_iters_per_solve_total": iters_all,
+                       "shard_ranges": shard_ranges,          # [lo, hi) global scenario ids of every rank, gathered from the ranks
                        "mpc_steps": args.mpc_steps,
                        "parallelism": f"scenario-sharded x{world}" + (" (TEST HOOK: the ranks share device 0, gloo; not a multi-GPU measurement)" if SHARED_DEVICE and world > 1 else ""), "wavefronts_per_game": waves_per_game,
-                       "collectives": (("gloo" if SHARED_DEVICE and world > 1 else "nccl (RCCL)") + f", world {world}: barrier + 2 all_reduce of the counters") if use_dist else "none (one rank, no process group)",
+                       "collectives": (("gloo" if SHARED_DEVICE and world > 1 else "nccl (RCCL)") + f", world {world}: barrier + all_gather of the shard ranges + 2 all_reduce of the counters") if use_dist else "none (one rank, no process group)",
                        "iters_per_game_mean_over_max_rank0": balance,
                        "handoff": dict(zip(("budget_iters", "games_handed_over_rank0"), b.get_handoff())),
                        "direction_refinement": {"max_steps": refine_steps, "tol": refine_tol, "mu_tight": refine_mu, "correction_solves_rank0": refinements_rank},

@@ -176,7 +176,8 @@ int  alg_set_line_search_groups(alg_handle* h, int32_t on);
 int  alg_get_line_search_groups(alg_handle* h, int32_t* on);
 /* Straggler hand-off for heterogeneous batches (no reference counterpart: the reference solves one game at a time).  A launch lasts as
  * long as its slowest game.  With iters = K > 0 the one-wavefront solver kernel behind alg_newton_solve* gives every game a budget of
- * K inner iterations; a game that needs more parks -- its whole state lives in its arena chunk -- and a second launch on the same
+ * K inner iterations BEGUN (solver_methods.jl:38: each makes a record!, whether or not it reaches the linear solve -- a game that converges
+ * in 11 Newton iterations over 4 outer iterations begins 15); a game that needs more parks -- its whole state lives in its arena chunk -- and a second launch on the same
  * stream finishes the parked games with the team kernel (four wavefronts per game), which continues the same outer / inner loops.
  * Results per game: the iterations before the hand-off are the one-wavefront kernel's, the ones after it the team kernel's (the two
  * agree to rounding: the norms are summed in a different order, see alg_set_waves_per_game).  0 (default) = off.  Only configurations
@@ -193,7 +194,8 @@ int  alg_get_handoff(alg_handle* h, int32_t* iters, int32_t* parked_last);
  * `max_steps` correction solves per direction).  `tol` is the tolerance for games whose largest constraint penalty (ALConVal mu) has
  * reached `mu_tight`; below that it is relaxed in proportion mu_tight / mu_max, at most 256 x (a forward-error target needs a backward
  * error of target / cond(J), and cond(J) grows with the penalties).  The dense-direction configurations (Quadrotor, n > 16) use
- * tol / 64 without relaxation.  Defaults: max_steps = 2, tol = 2^-34, mu_tight = 1.6e5;
+ * tol / 256 without relaxation.  A correction that does not at least halve max |rho| ends the refinement of its direction.
+ * Defaults: max_steps = 2 (dense-direction configurations: 6), tol = 2^-34, mu_tight = 1.6e5;
  * max_steps = 0 switches gate and refinement off (the round-3 arithmetic).  alg_game_stats.refinements counts the correction
  * solves of a newton_solve!.  A correction solve uses the trial trajectory (ALG_TRAJ_TRIAL) as its output buffer: after
  * alg_newton_direction that buffer holds the last correction (x_1 restored), until the next line search rewrites it -- as in

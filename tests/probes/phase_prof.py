@@ -21,7 +21,7 @@ for j in list(range(12)):
     print(f"  {names[j]:45s} {per_it:9.0f} cycles/iter  {100 * per_it / np.mean(tot / it):5.1f} %   {per_it / steps:7.0f} per step")
 # pass-level slots (res[16..31], flushed at the end of newton_solve)
 out2 = np.zeros((G, 32)); assert fn(b.h, out2.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 32) == 0
-pn = {16: "axpy + barrier", 17: "trial assemble (fused pass)", 20: "  phase A", 21: "  rows x", 22: "  rows u", 23: "  rows d", 24: "  reductions", 26: "direction", 27: "record pass"}
+pn = {19: "init_traj + rollout (per solve / iters)", 31: "whole solve (per solve / iters)", 16: "axpy + barrier", 17: "trial assemble (fused pass)", 20: "  phase A", 21: "  rows x", 22: "  rows u", 23: "  rows d", 24: "  reductions", 26: "direction", 27: "record pass"}
 cn = {18: "#trials", 25: "#assemble passes", 28: "#directions", 29: "#record passes"}
 print("pass level (thread 0's clock), cycles per Newton iteration:")
 for s, nm in pn.items(): print(f"  {nm:32s} {np.mean(out2[:, s] / it):10.0f}")

@@ -72,3 +72,29 @@ def test_rccl_communicator_barrier_and_reduction_run_on_the_device_with_a_world_
         assert d["n_gpus"] == 1 and d["games_converged"] == plain["games_converged"] == 512 and d["games_failed"] == 0
         assert d["config"]["newton_iters_per_solve_total"] == plain["config"]["newton_iters_per_solve_total"]
         assert set(d) == set(plain) and set(d["config"]) == set(plain["config"]) and d["metric"] == plain["metric"] and d["unit"] == plain["unit"]
+
+
+@pytest.mark.gpu
+def test_eight_ranks_of_the_c4_job_tile_65536_scenarios_and_print_one_line():
+    """BASELINE configs[3] as the driver launches it -- `bench.py --config C4 --gpus 8`, eight processes, 8192 scenarios each -- on a one-GPU
+    box: the ranks share device 0 through the script's test hook (gloo carries the barrier, the gather of the shard ranges and the counter
+    reduction; RCCL needs eight devices).  The multi-process path is what is checked: one JSON line, 65 536 scenarios, contiguous shards
+    in rank order, whole-job totals; no PMC / CPU-baseline legs in the ranks."""
+    d = _bench("--config", "C4", "--gpus", "8", shared=True)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["games_per_gpu"] == 8192 and c["games_total"] == 65536 and "TEST HOOK" in c["parallelism"]
+    assert c["shard_ranges"] == [[r * 8192, (r + 1) * 8192] for r in range(8)]
+    assert d["games_converged"] == 65536 and d["games_failed"] == 0
+    assert c["newton_iters_per_solve_total"] >= 65536 * 5
+    assert "cpu_baseline" not in d and d["roofline"].get("traffic") is None       # rank 0 of a multi-rank job runs no profiler child and no CPU leg
+    assert c["collectives"].startswith("gloo, world 8")
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_fails_the_job():
+    env = dict(os.environ, ALGAMES_BENCH_SHARED_DEVICE="1", ALGAMES_BENCH_FAIL_RANK="2")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--games-per-gpu", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]                # no result line from a job that lost a rank

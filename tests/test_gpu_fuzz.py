@@ -94,26 +94,43 @@ def _compare_solve(g, o, tag, tol=None, x=None):
     tol = FUZZ_TOL if tol is None else tol
     sx, same = None, None
     sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
+    # Round 6: a game on which the two double programs end with different STATUSES is legitimate only where the oracle's own answer is noise:
+    # the long-double run of the same algorithm on the same inputs ends somewhere else entirely, or nowhere (non-finite iterates).  That is the
+    # diverged quadrotor game of seeds 400040 / 400059 / 400074 -- iterates of 1e11 ... 1e186, Newton directions of 1e54 ... inf,
+    # tests/probes/r06_dense_gap.py -- on which the structured elimination reports SINGULAR while the banded LU keeps returning finite numbers
+    # that the arbiter contradicts in the first digit.  Such a game is taken out of the comparison; any other status difference fails.
+    noise = np.zeros(len(sg), bool)
+    if not np.array_equal(sg["status"], so["status"]):
+        assert x is not None, (tag, "status", sg["status"], so["status"])
+        sx = x.newton_solve(init=True, game_id0=7)
+        zo_, zx_ = o.get_traj(0), x.get_traj(0)
+        for game in np.nonzero(sg["status"] != so["status"])[0]:
+            fin = np.isfinite(zo_[game]).all() and np.isfinite(zx_[game]).all()
+            far = (not fin) or np.abs(zo_[game] - zx_[game]).max() > 1e-3 * max(1.0, np.abs(zx_[game]).max())
+            assert far, (tag, "status", sg["status"], so["status"])
+            noise[game] = True
+        print("status differs on a game whose oracle run is noise against the arbiter:", tag[:4], np.nonzero(noise)[0], sg["status"], so["status"])
+    keep = ~noise
     for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
-        assert np.array_equal(sg[f], so[f]), (tag, f, sg[f], so[f])
-    ok = so["status"] == 0
+        assert np.array_equal(sg[f][keep], so[f][keep]), (tag, f, sg[f], so[f])
+    ok = (so["status"] == 0) & keep
     zg, zo = g.get_traj(0), o.get_traj(0)
     if ok.any():
         scale = max(1.0, np.abs(zo[ok]).max())
         err = np.abs(zg[ok] - zo[ok]).max()
         if err > tol * scale and x is not None:
-            sx = x.newton_solve(init=True, game_id0=7)
+            sx = x.newton_solve(init=True, game_id0=7) if sx is None else sx
             same = np.all([sx[f] == so[f] for f in ("status", "outer_iters", "newton_iters", "ls_failures")], axis=0) & ok
             zx = x.get_traj(0)
             eg, eo = np.abs(zg[same] - zx[same]).max(initial=0.0), np.abs(zo[same] - zx[same]).max(initial=0.0)
             ARBITER_CONSULTED.append(tag[:4])
             print("arbiter consulted:", tag[:4], "|hip-orc| %.2e |hip-x| %.2e |orc-x| %.2e scale %.1f" % (err, eg, eo, scale))
-            assert same.all() and eg <= 4.0 * eo + tol * scale, (tag, err, eg, eo, scale)
+            assert same[ok].all() and eg <= 4.0 * eo + tol * scale, (tag, err, eg, eo, scale)
         else:
             assert err <= tol * scale, (tag, err, scale)
         for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
             a, b = sg["last"][f][ok], so["last"][f][ok]
-            if sx is None:
+            if sx is None or not (err > tol * scale):
                 assert np.allclose(a, b, rtol=1e-6, atol=1e-9), (tag, f)
             else:
                 # a problem that went through the arbiter for its trajectories (both double programs amplify rounding beyond the
@@ -123,8 +140,9 @@ def _compare_solve(g, o, tag, tol=None, x=None):
                 # tests/probes/fuzz_long_r4.py outside although their trajectories pass: profiles/r05_fuzz_tail.txt)
                 c = sx["last"][f][ok]
                 assert np.all(np.abs(a - c) <= 4.0 * np.abs(b - c) + 1e-6 * np.abs(c) + 1e-9), (tag, f, a, b, c)
-    hg, ho = g.get_history(0), o.get_history(0)
-    assert len(hg) == len(ho) and np.array_equal(hg["ls_j"], ho["ls_j"]) and np.array_equal(hg["alpha"], ho["alpha"]), tag
+    if not noise[0]:
+        hg, ho = g.get_history(0), o.get_history(0)
+        assert len(hg) == len(ho) and np.array_equal(hg["ls_j"], ho["ls_j"]) and np.array_equal(hg["alpha"], ho["alpha"]), tag
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -232,6 +250,21 @@ def test_fuzz_dense_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
         for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
             assert abs(hg[f][0] - ho[f][0]) <= 1e-9 * abs(ho[f][0]) + 1e-12, (tag, game, f, hg[f][0], ho[f][0])
         assert hg["ls_j"][0] == ho["ls_j"][0] and hg["alpha"][0] == ho["alpha"][0], (tag, game)
+
+
+# The seeds the long run of round 5 left outside the rule (profiles/r05_fuzz_long_final.txt), under _compare_solve itself:
+#   400051  two quadrotors, an ill-conditioned direction (5.6e-4 from the bare elimination): the dense direction now refines while a correction
+#           still contracts (up to six), round 5 stopped after one at 9.5e-7
+#   400040, 400059, 400074  two quadrotors, one game diverges (iterates 1e11 ... 1e186): SINGULAR against the LU's noise -- the status rule above
+#   200041  extended bicycle, a rounding amplifier that passes on its trajectories through the arbiter
+@pytest.mark.parametrize("seed", [400040, 400051, 400059, 400074, 200041])
+def test_fuzz_long_run_seeds_of_round_5(alg, orc, seed):
+    rng = np.random.default_rng(seed)
+    if seed >= 400000:
+        g, o, x, tag = _random_pair(alg, orc, rng, True, d3=True, force=(3, 2), arb="x")
+    else:
+        g, o, x, tag = _random_pair(alg, orc, rng, True, arb="x")
+    _compare_solve(g, o, tag, x=x)
 
 
 @pytest.mark.parametrize("seed", [100005, 100031, 100063, 100122, 100136, 100154, 100170, 100178])

@@ -22,8 +22,8 @@ def test_refinement_controls_round_trip(alg, orc):
     g, _ = _pair(alg, orc, DI, 2, 2, 8, B=2)
     ms, tol, mu = g.get_refinement()
     assert (ms, tol, mu) == (2, 2.0 ** -34, 1.6e5)                     # the library's defaults
-    gd, _ = _pair(alg, orc, DI, 3, 3, 6, B=2)                          # dense-direction configuration: one correction by default (round 5)
-    assert gd.get_refinement() == (1, 2.0 ** -34, 1.6e5)
+    gd, _ = _pair(alg, orc, DI, 3, 3, 6, B=2)                          # dense-direction configuration: up to six corrections, each only while the previous one contracted (round 6)
+    assert gd.get_refinement() == (6, 2.0 ** -34, 1.6e5)
     g.set_refinement(1, 1e-9, 10.0); assert g.get_refinement() == (1, 1e-9, 10.0)
     g.set_refinement(tol=0.0); assert g.get_refinement() == (1, 0.0, 10.0)
     for bad in ((-1, 1e-9, 1.0), (9, 1e-9, 1.0), (1, -1.0, 1.0), (1, float("nan"), 1.0), (1, 1e-9, -2.0)):
@@ -110,7 +110,10 @@ def test_gate_lowers_backward_and_forward_error_at_penalty_ceiling(alg, orc):
     # for a gate: its row scale |B[:,c]|' |dlambda| keeps the signs of the RK2 coefficients, a lower estimate of the scale (measured on this
     # state: up to 9 x with the round-4 direction, up to 92 x with the split recursion's of round 5, whose largest opt-u residual sits in a row
     # with cancelling signs; 259 x once B' lambda states its fmas, BT_vec).  The upper factor only documents how conservative the estimate can get.
-    assert np.all(w0 <= gate1[:, 1] * (1 + 1e-6) + 1e-15) and np.all(gate1[:, 1] <= 1024 * w0 + 1e-15)
+    # Round 6: the device's row scale is the true |J_c| |d| + |r_c| (|B[:,c]|' |dlambda| with the coefficients' magnitudes, BT_vec_abs), so its
+    # figure is the host's up to rounding and to the pair it tracks by cross-multiplication: the factor below was 1024 in round 5.
+    print("device omega / host omega: max %.3f min %.3f" % ((gate1[:, 1] / w0).max(), (gate1[:, 1] / w0).min()))
+    assert np.all(w0 <= gate1[:, 1] * (1 + 1e-6) + 1e-15) and np.all(gate1[:, 1] <= 2 * w0 + 1e-15)
     assert w0.max() > 2.0 ** -34                                         # the state does need the gate ...
     assert w1.max() <= 4 * 2.0 ** -34 and np.all(w1 <= w0 * 1.01 + 1e-16)         # ... and the gate delivers its tolerance
     assert np.all(e1 <= e0 * 1.01 + 1e-13) and np.median(e1) <= np.median(e0) / 50 and e1.max() <= min(1e-8, e0.max() / 50)   # measured: 7.7e-7 -> 1.5e-9

@@ -31,6 +31,11 @@ s = prob.stats.summary
 assert alg.sharding.local_counters(prob)[:2] == [int(s["newton_iters"].sum()), int(s["converged"].sum())]
 cnt, tmax = alg.sharding.reduce_counters([int(s["newton_iters"].sum()), int(s["converged"].sum()), hi - lo], 1.0 + rank, world, "cpu")
 assert tmax == float(world)                    # max over ranks of the per-rank time
+rng = alg.sharding.gather_shard_ranges(lo, hi, world, "cpu")
+assert rng == [list(alg.scenarios.shard_range(TOTAL, r, world)) for r in range(world)], rng      # the shards tile the job in rank order
+# a caller's own process group must not be touched by a one-rank reduction (ADVICE r5): world = 1 means no collective, whatever is initialised
+one, t1 = alg.sharding.reduce_counters([rank + 1], 2.0, 1, "cpu")
+assert one == [rank + 1] and t1 == 2.0 and alg.sharding.gather_shard_ranges(lo, hi, 1, "cpu") == [[lo, hi]]
 cnt = torch.tensor(cnt)
 z = torch.from_numpy(prob.batch.get_traj())
 per = (TOTAL + world - 1) // world

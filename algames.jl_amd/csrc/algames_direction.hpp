@@ -1192,6 +1192,510 @@ __device__ __forceinline__ void value_recursion_half(DirLds<C>& L, int first, in
         }
 }
 
+// Split value recursion of one backward step (round 5; described at SPLITF in newton_direction_tile): for every player
+//   [P_i | s_i] <- A_{k+1}' ( [P_i A_k | y_i] + (P_i B_k) [K | kappa] )
+// with the accumulator tile started at [P_i A_k | y_i] and ceil(m / 4) f64 MFMAs per player for the product.  TEAM: player i on wavefront i.
+template <class C, bool TEAM>
+__device__ __forceinline__ void split_value_recursion(DirLds<C>& L, double dt, int lrow, int lq, int tw) {
+    constexpr int n = C::n, m = C::m, P = C::P, LDP = DirLds<C>::LDP, KBS = (m + 3) / 4;
+    double kt[KBS];
+#pragma unroll
+    for (int kb = 0; kb < KBS; kb++) kt[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];       // [K | kappa] of step k + 1, rows >= m zero
+    // the products and the write-back, given a model's operand / write-back helpers
+    auto run = [&](auto&& operands, auto&& write_back) {
+        if constexpr (TEAM) {
+            // team: player i on wavefront i (the same operations on the same numbers as below: bit-identical to one wavefront per game)
+            static_assert(!TEAM || P <= C::NW, "one player per wavefront of the team");
+            if (tw < P) {
+                double4_t acc; double pb[KBS];
+                operands(tw, acc, pb);
+    #pragma unroll
+                for (int kb = 0; kb < KBS; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[kb], kt[kb], acc, 0, 0, 0);
+                sweep_sync<C>();
+                write_back(tw, acc);
+            }
+        } else {
+            // the players' chains are independent: all operands first, the products interleaved in the matrix pipe, then the write-backs
+            double4_t acc[P];
+            double pb[P][KBS];
+    #pragma unroll
+            for (int i = 0; i < P; i++) operands(i, acc[i], pb[i]);
+    #pragma unroll
+            for (int kb = 0; kb < KBS; kb++)
+    #pragma unroll
+                for (int i = 0; i < P; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][kb], kt[kb], acc[i], 0, 0, 0);
+            sweep_sync<C>();                                           // every read of [P_i | y_i] is done
+    #pragma unroll
+            for (int i = 0; i < P; i++) write_back(i, acc[i]);
+        }
+    };
+    if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+        // Row placement in the MFMA tile: the product's row at tile position (lane group l, register r4) is whatever row of P_i the
+        // A operand's lane 4 r4 + l feeds, so the rows are PLACED such that A' costs no lane exchange afterwards: A' X adds dt x row
+        // r to row r + m, and the pair (r, r + m) sits in ONE lane group, r = 4 j + l in register 2 j and r + m in register 2 j + 1
+        // (the natural order r = l + 4 r4 has row r - m in lane ^ 32 when m = 2 mod 4: four v_permlane32_swap + selects per tile).
+        // Lane roles: the tile entry (row, column lrow) of P_i A takes dt x column lrow - m of the same row (columns m..n-1); the
+        // operand entry (row, k = 4 kb + lq) of P_i B is dt^2/2 P[row][k] + dt P[row][k + m] (entries with k >= m meet zero rows of
+        // [K | kappa]: whatever finite value the two loads return there is multiplied by zero).
+        constexpr int NR = 2 * ((m + 3) / 4);                           // accumulator registers in use
+        static_assert(NR <= 4, "row pairs of the split recursion");
+        // (rows as affine functions of the lane coordinates, so that every LDS address below is one of four lane-dependent bases plus
+        // an immediate: register r4 of lane group l holds row l + RC(r4); lane groups whose row does not exist -- l >= m - 4 j in the
+        // last pair of registers -- read rows of the next block, harmlessly, and do not write)
+        auto rconst = [](int r4) { return 4 * (r4 >> 1) + ((r4 & 1) ? m : 0); };
+        const int opl = lrow & 3, opr4 = lrow >> 2;
+        const int oprow = (opr4 < NR && 4 * (opr4 >> 1) + opl < m) ? opl + 4 * (opr4 >> 1) + ((opr4 & 1) ? m : 0) : 0;      // the row this lane feeds as A operand
+        const bool shc = lrow >= m && lrow < n;
+        const int lsh = shc ? lrow - m : lrow;
+        const double dtc = shc ? dt : 0.0, hdt2 = 0.5 * dt * dt;
+        const double* const tbase = &L.bw.Pm[lq * LDP + lrow], * const sbase = &L.bw.Pm[lq * LDP + lsh], * const obase = &L.bw.Pm[oprow * LDP + lq];
+        double* const wbase = &L.bw.Pm[lq * LDP + lrow];
+        auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
+    #pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) acc[r4] = r4 < NR ? fma(dtc, sbase[i * n * LDP + rconst(r4) * LDP], tbase[i * n * LDP + rconst(r4) * LDP]) : 0.0;
+    #pragma unroll
+            for (int kb = 0; kb < KBS; kb++) pb[kb] = fma(-dt, obase[i * n * LDP + 4 * kb + m], -hdt2 * obase[i * n * LDP + 4 * kb]);      // -(P_i B): the B operand holds -[K | kappa]
+        };
+        auto write_back = [&](int i, double4_t acc) {
+    #pragma unroll
+            for (int j = 0; 2 * j + 1 < NR; j++) acc[2 * j + 1] = fma(dt, acc[2 * j], acc[2 * j + 1]);      // A': row r + m += dt x row r
+            if (lrow < n + 1) {
+    #pragma unroll
+                for (int r4 = 0; r4 < NR; r4++) {
+                    if (4 * (r4 >> 1) + 4 <= m) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];             // rows of every lane group
+                }
+                if constexpr ((m & 3) != 0) {
+                    if (lq < (m & 3)) {
+    #pragma unroll
+                        for (int r4 = NR - 2; r4 < NR; r4++) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];  // last pair: lane groups l < m mod 4
+                    }
+                }
+            }
+        };
+        run(operands, write_back);
+    } else {
+        // 3-player unicycle: state rows a P + i (a = 0: x_i, 1: y_i, 2: theta_i, 3: v_i).  Tile position (lane group l = i, register
+        // a) holds row a P + i: the A operand's lane 4 a + i feeds that row, A' then touches one lane group only.
+        //   (P A)[r][c]  = P[r][c] + ca P[r][c - 2P or c - 3P] + cb P[r][c - P or c - 2P]   (c a heading / speed column, else P[r][c])
+        //   (P B)[r][k]  = dt/2 (cx P[r][i'] + cy P[r][P + i']) + dt P[r][(2 + kind) P + i'],   k = kind P + i'
+        //   (A' X)[theta_i] = X[theta_i] + c0 X[x_i] + c2 X[y_i],   (A' X)[v_i] = X[v_i] + c1 X[x_i] + c3 X[y_i]
+        // with the step's coefficients c0 = A[x][theta], c1 = A[x][v], c2 = A[y][theta], c3 = A[y][v] of the player (L.coefn: step k + 1).
+        const int ti = lq < P ? lq : 0;                                     // player of this lane group's rows
+        const int oa = lrow >> 2, oi = lrow & 3;
+        const int oprow = (oi < P) ? oa * P + oi : 0;                          // the row this lane feeds as A operand
+        const int cblk = lrow / P, ci = lrow % P;                          // column block / player of tile column lrow
+        const bool con = lrow >= 2 * P && lrow < n;
+        const int colA = con ? ci : lrow, colB = con ? P + ci : lrow;
+        const double ca = con ? L.coefn[(cblk - 2) * P + ci] : 0.0, cb = con ? L.coefn[cblk * P + ci] : 0.0;
+        const double* const tbase = &L.bw.Pm[ti * LDP + lrow], * const abase = &L.bw.Pm[ti * LDP + colA], * const bbase = &L.bw.Pm[ti * LDP + colB];
+        double* const wbase = &L.bw.Pm[ti * LDP + lrow];
+        const double* ob[KBS][3]; double cx[KBS], cy[KBS];
+#pragma unroll
+        for (int kb = 0; kb < KBS; kb++) {
+            const int kk = 4 * kb + lq; const bool kok = kk < m; const int ki = kok ? kk % P : 0, kind = kok ? kk / P : 0;
+            ob[kb][0] = &L.bw.Pm[oprow * LDP + ki]; ob[kb][1] = &L.bw.Pm[oprow * LDP + P + ki]; ob[kb][2] = &L.bw.Pm[oprow * LDP + (2 + kind) * P + ki];
+            cx[kb] = kok ? L.coefn[kind * P + ki] : 0.0; cy[kb] = kok ? L.coefn[(2 + kind) * P + ki] : 0.0;
+        }
+        const double c0 = L.coefn[0 * P + ti], c1 = L.coefn[1 * P + ti], c2 = L.coefn[2 * P + ti], c3 = L.coefn[3 * P + ti];
+        auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int o = i * n * LDP + r4 * P * LDP;
+                acc[r4] = fma(cb, bbase[o], fma(ca, abase[o], tbase[o]));
+            }
+#pragma unroll
+            for (int kb = 0; kb < KBS; kb++) {
+                const int o = i * n * LDP;
+                const double h = fma(cy[kb], ob[kb][1][o], cx[kb] * ob[kb][0][o]);
+                pb[kb] = fma(-dt, ob[kb][2][o], (-0.5 * dt) * h);       // -(P_i B): the B operand holds -[K | kappa]
+            }
+        };
+        auto write_back = [&](int i, double4_t acc) {
+            acc[2] = fma(c2, acc[1], fma(c0, acc[0], acc[2]));          // A': heading row
+            acc[3] = fma(c3, acc[1], fma(c1, acc[0], acc[3]));          // A': speed row
+            if (lrow < n + 1 && lq < P) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) wbase[i * n * LDP + r4 * P * LDP] = acc[r4];
+            }
+        };
+        run(operands, write_back);
+    }
+}
+
+// Team of two: the helper wavefront's whole backward sweep (newton_direction_tile sends wavefront 1 here; split off in round 6 for
+// readability).  Step by step between wavefront 0's two barriers: value recursion, Q-add, V rows and tail of the odd players, then -- while
+// wavefront 0 runs its half of the serial tail -- the fetch of the next step record, the same pivoted solve, the odd rows of [F | f], the gains.
+template <class C, class QAM>
+__device__ __forceinline__ void direction_helper_wavefront(CPR pr, const Game& G, DirLds<C>& L, const QAM& qam, int N, double dt, int tid, int lrow, int lq, double reg) {
+    constexpr int n = C::n, m = C::m, NK = m * (n + 1), VW = DirLds<C>::VW, BT = WAVE;
+    using R = Rec<C>;
+    constexpr int RPL = (R::LEN_SWEEP + BT - 1) / BT;
+    // the helper wavefront: value recursion and Q-add of the odd players, step by step between wavefront 0's two barriers
+    double* const bwh = reinterpret_cast<double*>(&L.bw) + (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8);
+    int curh = 0;
+    for (int k = N - 2; k >= 0; k--, curh ^= 1) {
+        team_lds_barrier();
+        if (k < N - 2) {
+            t_half<C>(L, 1, tid);
+            value_recursion_half<C>(L, 1, lrow, lq, dt);
+        }
+        sweep_sync<C>();
+        qam.apply(tid, L.rec[curh], L.qdf, bwh, reg, (k + 1 < N - 1) ? dt : 1.0, -1);
+        sweep_sync<C>();
+        v_sysrow<C>(L, L.rec[curh], k, dt, 2 * (tid >> 4) + 1, tid & 15);       // V rows of the odd players' controls
+        player_tail_half<C>(L, L.rec[curh], dt, k, N, 1, tid);                 // their s_i, y_i, g_c
+        team_lds_barrier();
+        // while wavefront 0 runs the serial tail of step k: the record of step k - 1 from global memory into the other LDS slot
+        // (wavefront 0 never waits for a load inside the sweep)
+        double nx[RPL];
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; nx[q] = e < R::LEN_SWEEP ? gld(G.rec(pr) + (size_t)(k - 1) * R::LEN, e) : 0.0; }
+        }
+        // ... and its share of that tail, with the record's loads in flight: the same columns of [W | V A_k | g], the same pivoted
+        // solve (every wavefront needs the solved columns for its rows), the odd rows of [F | f] = [A_k | rd] + B [K | kappa],
+        // and the gain stores -- wavefront 0 forms the even rows and issues no store at all in the sweep
+        {
+            using GLh = GjLanes<m, n + 1>;
+            const double* Rh = L.rec[curh]; const double* coefh = Rh + R::COEF;
+            const int cidx = GLh::column(tid); const bool rhsl = GLh::rhs(tid);
+            double col[m];
+#pragma unroll
+            for (int c = 0; c < m; c++) col[c] = L.bw.V[c * VW + cidx];
+            gj_solve_cols_dpp<m>(col);
+            if (rhsl) {
+                const int cc = cidx - m;
+#pragma unroll
+                for (int c = 0; c < m; c++) col[c] = -col[c];
+                const double* acol = (cc < n) ? &L.bw.T[cc * n] : Rh + R::RD;
+                double fxv[n];
+#pragma unroll
+                for (int r = 1; r < n; r += 2) fxv[r] = B_vec<C>(coefh, dt, [&](int c2) { return col[c2]; }, r) + acol[r];
+#pragma unroll
+                for (int r = 1; r < n; r += 2) {
+                    if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];
+                    else { double* dst = cc < n ? &L.bw.Fx[r * 16 + cc] : &L.bw.fv[r]; *dst = fxv[r]; }
+                }
+            }
+            if (k > 0) {
+#pragma unroll
+                for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; if (e < R::LEN_SWEEP) L.rec[curh ^ 1][e] = nx[q]; }
+            }
+            asm volatile("" ::: "memory");
+            if (rhsl) {
+                double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK;
+#pragma unroll
+                for (int c = 0; c < m; c++) gst(Kg, (cidx - m) * m + c, col[c]);
+            }
+        }
+    }
+    game_sync();                 // the gains are this wavefront's stores: wavefront 0's forward sweep reads them behind a full barrier
+}
+
+// Forward sweep for (dx, du) and costate sweep for dlambda of the tile path (newton_direction_tile's second half; split off in round 6 for
+// readability -- __forceinline__, same code).  Runs on one wavefront (wavefront 0 of a team); the gains and the step records are in
+// global memory behind the caller's backward sweep.
+template <class C, bool IBR>
+__device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0, DirLds<C>& L, int N, double dt, int lane, double reg, int ip, double* primal_l1) {
+    constexpr int n = C::n, m = C::m, P = C::P, NK = m * (n + 1);
+    using R = Rec<C>;
+    constexpr int KPL = (NK + WAVE - 1) / WAVE;
+    constexpr bool TEAM = C::NW >= 4 && !IBR;
+    constexpr bool AUGS = DirLds<C>::AUGS;
+    constexpr bool SPLITU = C::MODEL == ALG_MODEL_UNICYCLE && P == 3;
+    constexpr bool SPLITF = (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || SPLITU) && AUGS && !IBR && (C::NW == 1 || TEAM);      // (the gains in HBM are -[K | kappa])
+    HxMap<C> hxm;
+    ALG_PROF_DECL
+    // ------------------------------------------------------------------ forward sweep: dx, du
+    if constexpr (C::NW == 1) game_sync(); else dir_sync<C>();   // the gains are in global memory (the sweeps' own syncs order LDS only)
+    Game G = G0.fresh();
+    double* __restrict__ dz = G.z(2);
+    if (lane < n) dz[lane] = 0.0;
+    constexpr bool DIROW = P * 16 <= WAVE;
+    constexpr int NPOS = C::POS ? C::PD * P : 1;
+    // FWDW: the forward sweep also forms the part of dlambda_k that does not depend on dlambda_{k+1} -- w_k = rx + Q^ dx_{k+1} -- right after
+    // dx_{k+1} exists, in the bubbles of its own dependency chain (every 16-lane row runs the forward recursion redundantly, so row i has
+    // dx for player i's products), and parks it in dlambda's slot; the costate sweep is left with dlambda_k = w_k + A' dlambda_{k+1}: one
+    // load, a few shifts, no LDS, no fence.  Bit-identical: w_k is exactly the intermediate value the one-sweep form holds in a register.
+    // (double integrator only: measured +1.1 % at C2; for the unicycle the recursion's coefficient loads cost more than the shorter chain
+    // saves: C3 -0.8 %, C5 loop -0.6 %)
+    constexpr bool FWDW = DIROW && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR;
+    // unconditional loads from clamped addresses (a conditional load into a zeroed register costs a vmcnt drain, see the forward sweep)
+    const int cdxo = DIROW ? ((lane & 15) < n ? (lane & 15) : 0) : (lane < n ? lane : 0);
+    const int ri_ = lane >> 4, rr_ = lane & 15;
+    const bool rok = DIROW && ri_ < P && rr_ < n;
+    const int re_ = rok ? ri_ * n + rr_ : 0;                           // entry of rx / qdf / dlambda this lane owns
+    const double qdfv = DIROW ? L.qdf[re_] : 0.0;
+    int hso[NPOS]; float hsg[NPOS];                                     // record offset and sign of Q^_i's position-block entry (row rr_, column c)
+    if constexpr (DIROW && C::POS) {
+        constexpr int NS = C::NS;
+        const int i = ri_ < P ? ri_ : 0, jr = rr_ % P, ar = rr_ / P;
+#pragma unroll
+        for (int c = 0; c < NPOS; c++) {
+            const int jc = c % P, h = C::sym(ar < C::PD ? ar : 0, c / P);
+            int so = R::HH; float sg = 0.f;
+            if (rr_ < C::PD * P) {
+                if (jr == i && jc == i) { so = R::HD + NS * i + h; sg = 1.f; }
+                else if (jr == i) { so = R::HH + NS * pairq<C>(i, jc) + h; sg = -1.f; }
+                else if (jc == i) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = -1.f; }
+                else if (jr == jc) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = 1.f; }
+            }
+            hso[c] = so; hsg[c] = sg;
+        }
+    }
+    double lamp = 0.0;                                                  // dlambda of the previous (later) step, entry re_
+    // state-dependent models: this lane's entries of A_{k+1}' (AT_vec), taken from step k + 1's record one iteration earlier
+    const int cblk = rr_ / P, cpi = rr_ % P;
+    const bool c_hi = C::MODEL == ALG_MODEL_BICYCLE ? cblk == 2 : cblk == 3, c_on = cblk >= 2 && rr_ < n;
+    const int cia = (c_hi ? 1 : 0) * P + cpi, cib = (c_hi ? 3 : 2) * P + cpi, cic = 4 * P + cpi;
+    double can = 0.0, cbn = 0.0, ccn = 0.0;
+    // the forward sweep reads only [coef | rd] of a record: one load per lane
+    static_assert(C::NC + n <= WAVE, "forward sweep record slice");
+    const int fro = lane < C::NC ? R::COEF + lane : R::RD + (lane - C::NC);      // record offset of this lane's slice entry
+    const bool frok = lane < C::NC + n;
+    // FWDW: the slice is [coef | Hh | Hd | RQ | rx] (the costate's) followed by rd, FPL entries per lane (entries past the end duplicate rd[0])
+    constexpr int FSL2 = R::LEN_COSTATE + n, FPL = FWDW ? (FSL2 + WAVE - 1) / WAVE : 1;
+    int fso[FPL];
+#pragma unroll
+    for (int q = 0; q < FPL; q++) { const int e = lane + q * WAVE; fso[q] = FWDW ? (e < R::LEN_COSTATE ? e : (e < FSL2 ? R::RD + (e - R::LEN_COSTATE) : R::RD)) : (frok ? fro : R::RD); }
+    if constexpr (FWDW) {
+#pragma unroll
+        for (int q = 0; q < FPL; q++) L.rec[0][fso[q]] = gld(G.rec(pr), fso[q]);
+    } else if (frok) L.rec[0][fro] = gld(G.rec(pr), fro);
+    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = gld(G.kgain(pr), e);
+    // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
+    // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
+    // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
+    // addresses, and everything at the tail of the step in the order (1) land the data of step k+1 (requested one step ago) in
+    // LDS, (2) issue this step's result stores, (3) request the data of step k+2 -- the single wait of a step meets loads and
+    // stores that have been in flight for a whole step.
+    auto fwd_load = [&](int kk, double (&rf)[FPL], double (&rk)[KPL]) {
+        const int kc = kk < N - 1 ? kk : N - 2;
+#pragma unroll
+        for (int q = 0; q < FPL; q++) rf[q] = gld(G.rec(pr) + (size_t)kc * R::LEN, fso[q]);
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = gld(G.kgain(pr) + (size_t)kc * NK, e < NK ? e : NK - 1); }
+    };
+    // Prefetch ring: the slices of steps k + 1 .. k + SD are in flight in registers while step k computes.  With four games per
+    // SIMD all streaming, a fetch takes about two microseconds -- longer than a step of this sweep -- so with one step in flight
+    // (rounds 1-2) the sweep ran at memory latency: 4.7 K cycles per step at 4096 games against 1.0 K for a lone wavefront
+    // (tests/probes/phase_prof.py).  The loop is unrolled by SD so that every ring slot is a fixed register (a rotating copy
+    // would read the newest load and wait for it).
+    constexpr int SD = C::SWEEP_DEPTH;
+    double pref[SD][FPL], prek[SD][KPL];
+#pragma unroll
+    for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
+    sweep_sync<C>();
+    int cur = 0;
+    double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
+    int bad = 0;                                    // non-finite direction entries (checked where they are produced)
+    // dx_k lives one entry per lane (lanes 0..n-1) and is broadcast with v_readlane; du and dx_{k+1} never pass through LDS:
+    // one LDS round trip (gain rows, record slice) per step instead of three.
+    double dxr = 0.0;
+    for (int k0 = 0; k0 < N - 1; k0 += SD) {
+#pragma unroll
+      for (int u = 0; u < SD; u++) {
+        const int k = k0 + u;
+        if (k >= N - 1) break;
+        const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
+        const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
+        const int cl = fl < m ? fl : 0;
+        double acc = Kl[n * m + cl];
+        rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
+        const double duv = fl < m ? (SPLITF ? -acc : acc) : 0.0;     // (split recursion: the gains in HBM are -[K | kappa])
+        const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
+        double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
+        dxn = fl < n ? dxn : 0.0;
+        if (lane < m) { pl1 += fabs(duv); bad |= !isfinite(duv); }
+        if (lane < n) { pl1 += fabs(dxn); bad |= !isfinite(dxn); }
+        dxr = dxn;
+        if constexpr (FWDW) {
+            // w_k = rx_{i,k+1} + Q^_{i,k+1} dx_{k+1} for (player, row) = (ri_, rr_): the head of the costate sweep's FMA sequence
+            const double wq = (k + 1 < N - 1) ? dt : 1.0;
+            double qd = reg + wq * qdfv;
+            if constexpr (C::EXT) qd += Rc[R::RQ + re_];
+            double wk = Rc[R::RX + re_] + qd * dxn;
+            if constexpr (C::POS) {
+                double hv[NPOS];
+#pragma unroll
+                for (int c = 0; c < NPOS; c++) hv[c] = (double)hsg[c] * Rc[hso[c]];
+                double t = wk;
+                rowdot_dpp<NPOS>(t, dxn, hv);
+                wk = rr_ < C::PD * P ? t : wk;
+            }
+            if (rok) gst(dz + n + hl<C>(k, 0), re_, wk);
+        }
+        // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
+#pragma unroll
+        for (int q = 0; q < FPL; q++) L.rec[cur ^ 1][fso[q]] = pref[(u + 1) % SD][q];
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
+        asm volatile("" ::: "memory");
+        // (2) results out
+        if (lane < m) gst(dz + n + hu<C>(k, 0), uoff<C>(lane), duv);
+        if (lane < n) gst(dz + n + hx<C>(k), lane, dxn);
+        // (3) request step k+1+SD into the slot that was just emptied
+        fwd_load(k + 1 + SD, pref[(u + 1) % SD], prek[(u + 1) % SD]);
+        sweep_sync<C>();
+        cur ^= 1;
+      }
+    }
+#if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
+    return ALG_STATUS_OK;
+#endif
+    ALG_PROF(7)
+    // ------------------------------------------------------------------ costate sweep:
+    //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
+    // Lane 16 i + r = (player i, row r), one 16-lane row per player.  dx_{k+1} is replicated in every row and reaches the position-block
+    // products through the DPP row broadcast, A' dlambda is a few shifts inside the row (double integrator: velocity row r takes dt
+    // times position row r - m; unicycle / bicycle: the heading / speed rows take the coefficient-weighted position rows r - P .. r - 3P),
+    // the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table round trips through
+    // LDS and one fence per step instead of three.  Same products in the same order as the general form below.
+    if constexpr (!DIROW) hxm.init(phase_lane());
+    if constexpr (C::NW == 1) game_sync(); else dir_sync<C>();   // dx of every step is in global memory
+    G = G0.fresh();
+    dz = G.z(2);
+    if constexpr (FWDW) {
+        // dlambda_k = w_k + A_{k+1}' dlambda_{k+1}: w_k comes back from dlambda's own slot (this lane wrote it in the forward sweep), the
+        // coefficients of A_{k+1} (state-dependent models) from step k + 1's record; SD steps in flight, no LDS, no fence
+        constexpr int NCF = C::NC > 0 ? (C::MODEL == ALG_MODEL_BICYCLE ? 3 : 2) : 0;
+#ifndef ALG_FWDW_DEPTH
+#define ALG_FWDW_DEPTH 8
+#endif
+        constexpr int CD = ALG_FWDW_DEPTH;           // steps in flight: three doubles per slot, and nothing but these loads feeds the recursion
+        double wkr[CD], cfr[CD][NCF > 0 ? NCF : 1];
+        auto cw_load = [&](int kk, double& wv, double (&cf)[NCF > 0 ? NCF : 1]) {
+            const int kc = kk > 0 ? kk : 0, kn = kc + 1 < N - 1 ? kc + 1 : N - 2;
+            wv = gld(dz + n + hl<C>(kc, 0), re_);
+            if constexpr (NCF > 0) {
+                const double* Rn = G.rec(pr) + (size_t)kn * R::LEN + R::COEF;
+                cf[0] = Rn[cia]; cf[1] = Rn[cib];
+                if constexpr (NCF > 2) cf[2] = Rn[cic];
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < CD; u++) cw_load(N - 2 - u, wkr[u], cfr[u]);
+        for (int k0 = N - 2; k0 >= 0; k0 -= CD) {
+#pragma unroll
+          for (int u = 0; u < CD; u++) {
+            const int k = k0 - u;
+            if (k < 0) break;
+            double acc = wkr[u];
+            if (k < N - 2) {
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                    const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp);
+                } else {
+                    const double ca_ = cfr[u][0], cb_ = cfr[u][1];
+                    const double s1 = row_shift<0x110 + P>(lamp), s2 = row_shift<0x110 + 2 * P>(lamp), s3 = row_shift<0x110 + 3 * P>(lamp);
+                    const double vi = cblk == 3 ? s3 : s2, vpi = cblk == 3 ? s2 : s1;
+                    if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                        const double u1 = row_shift<0x100 + P>(lamp), cc_ = cfr[u][NCF > 2 ? 2 : 0];
+                        acc += lamp + (c_on ? ca_ : 0.0) * (c_on ? vi : lamp) + (c_on ? cb_ : 0.0) * (c_on ? vpi : lamp) + (cblk == 2 ? cc_ : 0.0) * (cblk == 2 ? u1 : lamp);
+                    } else acc += lamp + (c_on ? ca_ : 0.0) * (c_on ? vi : lamp) + (c_on ? cb_ : 0.0) * (c_on ? vpi : lamp);
+                }
+            }
+            acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
+            lamp = acc;
+            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
+            cw_load(k - CD, wkr[u], cfr[u]);
+          }
+        }
+    } else {
+    constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
+    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = gld(G.rec(pr) + (size_t)(N - 2) * R::LEN, e);
+    const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
+    const bool cpos = C::POS && cr_ < C::PD * P;
+    double dxk = lane < n ? gld(dz + n + hx<C>(N - 2), lane) : 0.0;      // dx_{k+1}, fetched ahead like the records
+    if constexpr (DIROW) dxk = gld(dz + n + hx<C>(N - 2), cdxo);
+    auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
+        const int kc = kk > 0 ? kk : 0;
+#pragma unroll
+        for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; rr[q] = gld(G.rec(pr) + (size_t)kc * R::LEN, (e < R::LEN_COSTATE ? e : R::LEN_COSTATE - 1)); }
+        rdx = gld(dz + n + hx<C>(kc), cdxo);
+    };
+    // register ring like the forward sweep's: [record slice | dx] of steps k - 1 .. k - SD are in flight while step k computes
+    double pre[SD][RPLC], pdx[SD];
+#pragma unroll
+    for (int u = 0; u < SD; u++) cs_load(N - 3 - u, pdx[(1 + u) % SD], pre[(1 + u) % SD]);
+    sweep_sync<C>();
+    cur = 0;
+    for (int k0 = N - 2; k0 >= 0; k0 -= SD) {
+#pragma unroll
+      for (int u = 0; u < SD; u++) {
+        const int k = k0 - u;
+        if (k < 0) break;
+        const double* Rc = L.rec[cur];
+        const double w = (k + 1 < N - 1) ? dt : 1.0;
+        if constexpr (DIROW) {
+            double qd = reg + w * qdfv;
+            if constexpr (C::EXT) qd += Rc[R::RQ + re_];
+            double acc = Rc[R::RX + re_] + qd * dxk;
+            if constexpr (C::POS) {
+                double hv[NPOS];
+#pragma unroll
+                for (int c = 0; c < NPOS; c++) hv[c] = (double)hsg[c] * Rc[hso[c]];
+                double t = acc;
+                rowdot_dpp<NPOS>(t, dxk, hv);
+                acc = rr_ < C::PD * P ? t : acc;
+            }
+            if (k < N - 2) {
+                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
+                    const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp);
+                } else {
+                    // AT_vec: v(r) + ca v(i) + cb v(P + i) (+ cc v(3P + i), bicycle heading rows), i = r % P: rows 2P + i take lanes r - 2P, r - P
+                    // (, r + P), rows 3P + i take lanes r - 3P, r - 2P
+                    const double s1 = row_shift<0x110 + P>(lamp), s2 = row_shift<0x110 + 2 * P>(lamp), s3 = row_shift<0x110 + 3 * P>(lamp);
+                    const double vi = cblk == 3 ? s3 : s2, vpi = cblk == 3 ? s2 : s1;
+                    if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
+                        const double u1 = row_shift<0x100 + P>(lamp);
+                        acc += lamp + (c_on ? can : 0.0) * (c_on ? vi : lamp) + (c_on ? cbn : 0.0) * (c_on ? vpi : lamp) + (cblk == 2 ? ccn : 0.0) * (cblk == 2 ? u1 : lamp);
+                    } else acc += lamp + (c_on ? can : 0.0) * (c_on ? vi : lamp) + (c_on ? cbn : 0.0) * (c_on ? vpi : lamp);
+                }
+            }
+            if constexpr (C::NC > 0) { can = Rc[R::COEF + cia]; cbn = Rc[R::COEF + cib]; if constexpr (C::MODEL == ALG_MODEL_BICYCLE) ccn = Rc[R::COEF + cic]; }
+            acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
+            lamp = acc;
+            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
+        } else {
+        if (lane < n) L.fw.dx[lane] = dxk;
+        hxm.expand(lane, Rc, L.fw.hx);
+        sweep_sync<C>();
+        double acc = 0.0;
+        if (lane < P * n && (!IBR || ci_ == ip)) {
+            double qd = reg + w * L.qdf[lane];
+            if constexpr (C::EXT) qd += Rc[R::RQ + lane];
+            acc = Rc[R::RX + lane] + qd * L.fw.dx[cr_];
+            if (cpos) {
+                const double* hrow = &L.fw.hx[(ci_ * P + cr_ % P) * P * C::NS];
+                const int ar = cr_ / P;
+#pragma unroll
+                for (int c = 0; c < C::PD * P; c++) acc += hrow[(c % P) * C::NS + C::sym(ar, c / P)] * L.fw.dx[c];
+            }
+            if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
+        }
+        sweep_sync<C>();
+        if (lane < P * n) { L.fw.dl[lane] = acc; gst(dz + n + hl<C>(k, 0), lane, acc); bad |= !isfinite(acc); }
+        if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
+        }
+        // land step k - 1 (requested SD steps ago), then request step k - 1 - SD into the emptied slot
+        dxk = (DIROW || lane < n) ? pdx[(u + 1) % SD] : 0.0;
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) L.rec[cur ^ 1][e] = pre[(u + 1) % SD][q]; }
+        }
+        cs_load(k - 1 - SD, pdx[(u + 1) % SD], pre[(u + 1) % SD]);
+        sweep_sync<C>();
+        cur ^= 1;
+      }
+    }
+    }
+    ALG_PROF(8)
+    ALG_PROF_FLUSH
+    // non-finite direction -> singular (the reference would throw / propagate NaN)
+    if (primal_l1) *primal_l1 = wave_sum(pl1);
+    return __builtin_amdgcn_readfirstlane(wave_or(bad)) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;     // scalar: the solver's control flow stays on the SALU
+}
+
 template <class C, bool IBR>
 __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, double reg, int ip, double* primal_l1) {
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 0       // per-sweep byte / time accounts (tests/probes/dir_split.sh): nothing at all
@@ -1242,71 +1746,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     constexpr int KBS = (m + 3) / 4;                    // k-blocks of the split product (inner dimension m)
     QaddMap<C, BT, (HELP2 ? 2 : 1)> qam; qam.init(tid, hw);
     if constexpr (HELP2) {
-        if (hw == 1) {
-            // the helper wavefront: value recursion and Q-add of the odd players, step by step between wavefront 0's two barriers
-            double* const bwh = reinterpret_cast<double*>(&L.bw) + (int)(offsetof(typename DirLds<C>::Bwd, Pm) / 8);
-            int curh = 0;
-            for (int k = N - 2; k >= 0; k--, curh ^= 1) {
-                team_lds_barrier();
-                if (k < N - 2) {
-                    t_half<C>(L, 1, tid);
-                    value_recursion_half<C>(L, 1, lrow, lq, dt);
-                }
-                sweep_sync<C>();
-                qam.apply(tid, L.rec[curh], L.qdf, bwh, reg, (k + 1 < N - 1) ? dt : 1.0, -1);
-                sweep_sync<C>();
-                v_sysrow<C>(L, L.rec[curh], k, dt, 2 * (tid >> 4) + 1, tid & 15);       // V rows of the odd players' controls
-                player_tail_half<C>(L, L.rec[curh], dt, k, N, 1, tid);                 // their s_i, y_i, g_c
-                team_lds_barrier();
-                // while wavefront 0 runs the serial tail of step k: the record of step k - 1 from global memory into the other LDS slot
-                // (wavefront 0 never waits for a load inside the sweep)
-                double nx[RPL];
-                if (k > 0) {
-#pragma unroll
-                    for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; nx[q] = e < R::LEN_SWEEP ? gld(G.rec(pr) + (size_t)(k - 1) * R::LEN, e) : 0.0; }
-                }
-                // ... and its share of that tail, with the record's loads in flight: the same columns of [W | V A_k | g], the same pivoted
-                // solve (every wavefront needs the solved columns for its rows), the odd rows of [F | f] = [A_k | rd] + B [K | kappa],
-                // and the gain stores -- wavefront 0 forms the even rows and issues no store at all in the sweep
-                {
-                    using GLh = GjLanes<m, n + 1>;
-                    const double* Rh = L.rec[curh]; const double* coefh = Rh + R::COEF;
-                    const int cidx = GLh::column(tid); const bool rhsl = GLh::rhs(tid);
-                    double col[m];
-#pragma unroll
-                    for (int c = 0; c < m; c++) col[c] = L.bw.V[c * VW + cidx];
-                    gj_solve_cols_dpp<m>(col);
-                    if (rhsl) {
-                        const int cc = cidx - m;
-#pragma unroll
-                        for (int c = 0; c < m; c++) col[c] = -col[c];
-                        const double* acol = (cc < n) ? &L.bw.T[cc * n] : Rh + R::RD;
-                        double fxv[n];
-#pragma unroll
-                        for (int r = 1; r < n; r += 2) fxv[r] = B_vec<C>(coefh, dt, [&](int c2) { return col[c2]; }, r) + acol[r];
-#pragma unroll
-                        for (int r = 1; r < n; r += 2) {
-                            if constexpr (n < 16) L.bw.Fx[r * 16 + cc] = fxv[r];
-                            else { double* dst = cc < n ? &L.bw.Fx[r * 16 + cc] : &L.bw.fv[r]; *dst = fxv[r]; }
-                        }
-                    }
-                    if (k > 0) {
-#pragma unroll
-                        for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; if (e < R::LEN_SWEEP) L.rec[curh ^ 1][e] = nx[q]; }
-                    }
-                    asm volatile("" ::: "memory");
-                    if (rhsl) {
-                        double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK;
-#pragma unroll
-                        for (int c = 0; c < m; c++) gst(Kg, (cidx - m) * m + c, col[c]);
-                    }
-                }
-            }
-            game_sync();                 // the gains are this wavefront's stores: wavefront 0's forward sweep reads them behind a full barrier
-            return ALG_STATUS_OK;
-        }
+        if (hw == 1) { direction_helper_wavefront<C>(pr, G, L, qam, N, dt, tid, lrow, lq, reg); return ALG_STATUS_OK; }
     }
-    HxMap<C> hxm;
     struct NoGather { __device__ void init(int, int) {} };
     typename std::conditional<(C::P == 3 && C::MODEL != ALG_MODEL_DOUBLE_INTEGRATOR), P3Gather<C>, NoGather>::type p3g;
     p3g.init(lq, lrow);
@@ -1348,128 +1789,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // next player starts: one accumulator tile live.
         if constexpr (SPLITF) {
           if (k < N - 2) {
-            double kt[KBS];
-#pragma unroll
-            for (int kb = 0; kb < KBS; kb++) kt[kb] = L.bw.Fx[(4 * kb + lq) * 16 + lrow];       // [K | kappa] of step k + 1, rows >= m zero
-            // the products and the write-back, given a model's operand / write-back helpers
-            auto run = [&](auto&& operands, auto&& write_back) {
-                if constexpr (TEAM) {
-                    // team: player i on wavefront i (the same operations on the same numbers as below: bit-identical to one wavefront per game)
-                    static_assert(!TEAM || P <= C::NW, "one player per wavefront of the team");
-                    if (tw < P) {
-                        double4_t acc; double pb[KBS];
-                        operands(tw, acc, pb);
-    #pragma unroll
-                        for (int kb = 0; kb < KBS; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[kb], kt[kb], acc, 0, 0, 0);
-                        sweep_sync<C>();
-                        write_back(tw, acc);
-                    }
-                } else {
-                    // the players' chains are independent: all operands first, the products interleaved in the matrix pipe, then the write-backs
-                    double4_t acc[P];
-                    double pb[P][KBS];
-    #pragma unroll
-                    for (int i = 0; i < P; i++) operands(i, acc[i], pb[i]);
-    #pragma unroll
-                    for (int kb = 0; kb < KBS; kb++)
-    #pragma unroll
-                        for (int i = 0; i < P; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][kb], kt[kb], acc[i], 0, 0, 0);
-                    sweep_sync<C>();                                           // every read of [P_i | y_i] is done
-    #pragma unroll
-                    for (int i = 0; i < P; i++) write_back(i, acc[i]);
-                }
-            };
-            if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-                // Row placement in the MFMA tile: the product's row at tile position (lane group l, register r4) is whatever row of P_i the
-                // A operand's lane 4 r4 + l feeds, so the rows are PLACED such that A' costs no lane exchange afterwards: A' X adds dt x row
-                // r to row r + m, and the pair (r, r + m) sits in ONE lane group, r = 4 j + l in register 2 j and r + m in register 2 j + 1
-                // (the natural order r = l + 4 r4 has row r - m in lane ^ 32 when m = 2 mod 4: four v_permlane32_swap + selects per tile).
-                // Lane roles: the tile entry (row, column lrow) of P_i A takes dt x column lrow - m of the same row (columns m..n-1); the
-                // operand entry (row, k = 4 kb + lq) of P_i B is dt^2/2 P[row][k] + dt P[row][k + m] (entries with k >= m meet zero rows of
-                // [K | kappa]: whatever finite value the two loads return there is multiplied by zero).
-                constexpr int NR = 2 * ((m + 3) / 4);                           // accumulator registers in use
-                static_assert(NR <= 4, "row pairs of the split recursion");
-                // (rows as affine functions of the lane coordinates, so that every LDS address below is one of four lane-dependent bases plus
-                // an immediate: register r4 of lane group l holds row l + RC(r4); lane groups whose row does not exist -- l >= m - 4 j in the
-                // last pair of registers -- read rows of the next block, harmlessly, and do not write)
-                auto rconst = [](int r4) { return 4 * (r4 >> 1) + ((r4 & 1) ? m : 0); };
-                const int opl = lrow & 3, opr4 = lrow >> 2;
-                const int oprow = (opr4 < NR && 4 * (opr4 >> 1) + opl < m) ? opl + 4 * (opr4 >> 1) + ((opr4 & 1) ? m : 0) : 0;      // the row this lane feeds as A operand
-                const bool shc = lrow >= m && lrow < n;
-                const int lsh = shc ? lrow - m : lrow;
-                const double dtc = shc ? dt : 0.0, hdt2 = 0.5 * dt * dt;
-                const double* const tbase = &L.bw.Pm[lq * LDP + lrow], * const sbase = &L.bw.Pm[lq * LDP + lsh], * const obase = &L.bw.Pm[oprow * LDP + lq];
-                double* const wbase = &L.bw.Pm[lq * LDP + lrow];
-                auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
-    #pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) acc[r4] = r4 < NR ? fma(dtc, sbase[i * n * LDP + rconst(r4) * LDP], tbase[i * n * LDP + rconst(r4) * LDP]) : 0.0;
-    #pragma unroll
-                    for (int kb = 0; kb < KBS; kb++) pb[kb] = fma(-dt, obase[i * n * LDP + 4 * kb + m], -hdt2 * obase[i * n * LDP + 4 * kb]);      // -(P_i B): the B operand holds -[K | kappa]
-                };
-                auto write_back = [&](int i, double4_t acc) {
-    #pragma unroll
-                    for (int j = 0; 2 * j + 1 < NR; j++) acc[2 * j + 1] = fma(dt, acc[2 * j], acc[2 * j + 1]);      // A': row r + m += dt x row r
-                    if (lrow < n + 1) {
-    #pragma unroll
-                        for (int r4 = 0; r4 < NR; r4++) {
-                            if (4 * (r4 >> 1) + 4 <= m) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];             // rows of every lane group
-                        }
-                        if constexpr ((m & 3) != 0) {
-                            if (lq < (m & 3)) {
-    #pragma unroll
-                                for (int r4 = NR - 2; r4 < NR; r4++) wbase[i * n * LDP + rconst(r4) * LDP] = acc[r4];  // last pair: lane groups l < m mod 4
-                            }
-                        }
-                    }
-                };
-                run(operands, write_back);
-            } else {
-                // 3-player unicycle: state rows a P + i (a = 0: x_i, 1: y_i, 2: theta_i, 3: v_i).  Tile position (lane group l = i, register
-                // a) holds row a P + i: the A operand's lane 4 a + i feeds that row, A' then touches one lane group only.
-                //   (P A)[r][c]  = P[r][c] + ca P[r][c - 2P or c - 3P] + cb P[r][c - P or c - 2P]   (c a heading / speed column, else P[r][c])
-                //   (P B)[r][k]  = dt/2 (cx P[r][i'] + cy P[r][P + i']) + dt P[r][(2 + kind) P + i'],   k = kind P + i'
-                //   (A' X)[theta_i] = X[theta_i] + c0 X[x_i] + c2 X[y_i],   (A' X)[v_i] = X[v_i] + c1 X[x_i] + c3 X[y_i]
-                // with the step's coefficients c0 = A[x][theta], c1 = A[x][v], c2 = A[y][theta], c3 = A[y][v] of the player (L.coefn: step k + 1).
-                const int ti = lq < P ? lq : 0;                                     // player of this lane group's rows
-                const int oa = lrow >> 2, oi = lrow & 3;
-                const int oprow = (oi < P) ? oa * P + oi : 0;                          // the row this lane feeds as A operand
-                const int cblk = lrow / P, ci = lrow % P;                          // column block / player of tile column lrow
-                const bool con = lrow >= 2 * P && lrow < n;
-                const int colA = con ? ci : lrow, colB = con ? P + ci : lrow;
-                const double ca = con ? L.coefn[(cblk - 2) * P + ci] : 0.0, cb = con ? L.coefn[cblk * P + ci] : 0.0;
-                const double* const tbase = &L.bw.Pm[ti * LDP + lrow], * const abase = &L.bw.Pm[ti * LDP + colA], * const bbase = &L.bw.Pm[ti * LDP + colB];
-                double* const wbase = &L.bw.Pm[ti * LDP + lrow];
-                const double* ob[KBS][3]; double cx[KBS], cy[KBS];
-#pragma unroll
-                for (int kb = 0; kb < KBS; kb++) {
-                    const int kk = 4 * kb + lq; const bool kok = kk < m; const int ki = kok ? kk % P : 0, kind = kok ? kk / P : 0;
-                    ob[kb][0] = &L.bw.Pm[oprow * LDP + ki]; ob[kb][1] = &L.bw.Pm[oprow * LDP + P + ki]; ob[kb][2] = &L.bw.Pm[oprow * LDP + (2 + kind) * P + ki];
-                    cx[kb] = kok ? L.coefn[kind * P + ki] : 0.0; cy[kb] = kok ? L.coefn[(2 + kind) * P + ki] : 0.0;
-                }
-                const double c0 = L.coefn[0 * P + ti], c1 = L.coefn[1 * P + ti], c2 = L.coefn[2 * P + ti], c3 = L.coefn[3 * P + ti];
-                auto operands = [&](int i, double4_t& acc, double (&pb)[KBS]) {
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) {
-                        const int o = i * n * LDP + r4 * P * LDP;
-                        acc[r4] = fma(cb, bbase[o], fma(ca, abase[o], tbase[o]));
-                    }
-#pragma unroll
-                    for (int kb = 0; kb < KBS; kb++) {
-                        const int o = i * n * LDP;
-                        const double h = fma(cy[kb], ob[kb][1][o], cx[kb] * ob[kb][0][o]);
-                        pb[kb] = fma(-dt, ob[kb][2][o], (-0.5 * dt) * h);       // -(P_i B): the B operand holds -[K | kappa]
-                    }
-                };
-                auto write_back = [&](int i, double4_t acc) {
-                    acc[2] = fma(c2, acc[1], fma(c0, acc[0], acc[2]));          // A': heading row
-                    acc[3] = fma(c3, acc[1], fma(c1, acc[0], acc[3]));          // A': speed row
-                    if (lrow < n + 1 && lq < P) {
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; r4++) wbase[i * n * LDP + r4 * P * LDP] = acc[r4];
-                    }
-                };
-                run(operands, write_back);
-            }
+            split_value_recursion<C, TEAM>(L, dt, lrow, lq, tw);
             bsync();
           }
         } else
@@ -1758,294 +2078,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 1
     return ALG_STATUS_OK;
 #endif
-    // ------------------------------------------------------------------ forward sweep: dx, du
-    if constexpr (C::NW == 1) game_sync(); else dir_sync<C>();   // the gains are in global memory (the sweeps' own syncs order LDS only)
-    G = G0.fresh();
-    double* __restrict__ dz = G.z(2);
-    if (lane < n) dz[lane] = 0.0;
-    constexpr bool DIROW = P * 16 <= WAVE;
-    constexpr int NPOS = C::POS ? C::PD * P : 1;
-    // FWDW: the forward sweep also forms the part of dlambda_k that does not depend on dlambda_{k+1} -- w_k = rx + Q^ dx_{k+1} -- right after
-    // dx_{k+1} exists, in the bubbles of its own dependency chain (every 16-lane row runs the forward recursion redundantly, so row i has
-    // dx for player i's products), and parks it in dlambda's slot; the costate sweep is left with dlambda_k = w_k + A' dlambda_{k+1}: one
-    // load, a few shifts, no LDS, no fence.  Bit-identical: w_k is exactly the intermediate value the one-sweep form holds in a register.
-    // (double integrator only: measured +1.1 % at C2; for the unicycle the recursion's coefficient loads cost more than the shorter chain
-    // saves: C3 -0.8 %, C5 loop -0.6 %)
-    constexpr bool FWDW = DIROW && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR;
-    // unconditional loads from clamped addresses (a conditional load into a zeroed register costs a vmcnt drain, see the forward sweep)
-    const int cdxo = DIROW ? ((lane & 15) < n ? (lane & 15) : 0) : (lane < n ? lane : 0);
-    const int ri_ = lane >> 4, rr_ = lane & 15;
-    const bool rok = DIROW && ri_ < P && rr_ < n;
-    const int re_ = rok ? ri_ * n + rr_ : 0;                           // entry of rx / qdf / dlambda this lane owns
-    const double qdfv = DIROW ? L.qdf[re_] : 0.0;
-    int hso[NPOS]; float hsg[NPOS];                                     // record offset and sign of Q^_i's position-block entry (row rr_, column c)
-    if constexpr (DIROW && C::POS) {
-        constexpr int NS = C::NS;
-        const int i = ri_ < P ? ri_ : 0, jr = rr_ % P, ar = rr_ / P;
-#pragma unroll
-        for (int c = 0; c < NPOS; c++) {
-            const int jc = c % P, h = C::sym(ar < C::PD ? ar : 0, c / P);
-            int so = R::HH; float sg = 0.f;
-            if (rr_ < C::PD * P) {
-                if (jr == i && jc == i) { so = R::HD + NS * i + h; sg = 1.f; }
-                else if (jr == i) { so = R::HH + NS * pairq<C>(i, jc) + h; sg = -1.f; }
-                else if (jc == i) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = -1.f; }
-                else if (jr == jc) { so = R::HH + NS * pairq<C>(i, jr) + h; sg = 1.f; }
-            }
-            hso[c] = so; hsg[c] = sg;
-        }
-    }
-    double lamp = 0.0;                                                  // dlambda of the previous (later) step, entry re_
-    // state-dependent models: this lane's entries of A_{k+1}' (AT_vec), taken from step k + 1's record one iteration earlier
-    const int cblk = rr_ / P, cpi = rr_ % P;
-    const bool c_hi = C::MODEL == ALG_MODEL_BICYCLE ? cblk == 2 : cblk == 3, c_on = cblk >= 2 && rr_ < n;
-    const int cia = (c_hi ? 1 : 0) * P + cpi, cib = (c_hi ? 3 : 2) * P + cpi, cic = 4 * P + cpi;
-    double can = 0.0, cbn = 0.0, ccn = 0.0;
-    // the forward sweep reads only [coef | rd] of a record: one load per lane
-    static_assert(C::NC + n <= WAVE, "forward sweep record slice");
-    const int fro = lane < C::NC ? R::COEF + lane : R::RD + (lane - C::NC);      // record offset of this lane's slice entry
-    const bool frok = lane < C::NC + n;
-    // FWDW: the slice is [coef | Hh | Hd | RQ | rx] (the costate's) followed by rd, FPL entries per lane (entries past the end duplicate rd[0])
-    constexpr int FSL2 = R::LEN_COSTATE + n, FPL = FWDW ? (FSL2 + WAVE - 1) / WAVE : 1;
-    int fso[FPL];
-#pragma unroll
-    for (int q = 0; q < FPL; q++) { const int e = lane + q * WAVE; fso[q] = FWDW ? (e < R::LEN_COSTATE ? e : (e < FSL2 ? R::RD + (e - R::LEN_COSTATE) : R::RD)) : (frok ? fro : R::RD); }
-    if constexpr (FWDW) {
-#pragma unroll
-        for (int q = 0; q < FPL; q++) L.rec[0][fso[q]] = gld(G.rec(pr), fso[q]);
-    } else if (frok) L.rec[0][fro] = gld(G.rec(pr), fro);
-    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = gld(G.kgain(pr), e);
-    // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
-    // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
-    // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
-    // addresses, and everything at the tail of the step in the order (1) land the data of step k+1 (requested one step ago) in
-    // LDS, (2) issue this step's result stores, (3) request the data of step k+2 -- the single wait of a step meets loads and
-    // stores that have been in flight for a whole step.
-    auto fwd_load = [&](int kk, double (&rf)[FPL], double (&rk)[KPL]) {
-        const int kc = kk < N - 1 ? kk : N - 2;
-#pragma unroll
-        for (int q = 0; q < FPL; q++) rf[q] = gld(G.rec(pr) + (size_t)kc * R::LEN, fso[q]);
-#pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = gld(G.kgain(pr) + (size_t)kc * NK, e < NK ? e : NK - 1); }
-    };
-    // Prefetch ring: the slices of steps k + 1 .. k + SD are in flight in registers while step k computes.  With four games per
-    // SIMD all streaming, a fetch takes about two microseconds -- longer than a step of this sweep -- so with one step in flight
-    // (rounds 1-2) the sweep ran at memory latency: 4.7 K cycles per step at 4096 games against 1.0 K for a lone wavefront
-    // (tests/probes/phase_prof.py).  The loop is unrolled by SD so that every ring slot is a fixed register (a rotating copy
-    // would read the newest load and wait for it).
-    constexpr int SD = C::SWEEP_DEPTH;
-    double pref[SD][FPL], prek[SD][KPL];
-#pragma unroll
-    for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
-    sweep_sync<C>();
-    cur = 0;
-    double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
-    int bad = 0;                                    // non-finite direction entries (checked where they are produced)
-    // dx_k lives one entry per lane (lanes 0..n-1) and is broadcast with v_readlane; du and dx_{k+1} never pass through LDS:
-    // one LDS round trip (gain rows, record slice) per step instead of three.
-    double dxr = 0.0;
-    for (int k0 = 0; k0 < N - 1; k0 += SD) {
-#pragma unroll
-      for (int u = 0; u < SD; u++) {
-        const int k = k0 + u;
-        if (k >= N - 1) break;
-        const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
-        const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
-        const int cl = fl < m ? fl : 0;
-        double acc = Kl[n * m + cl];
-        rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
-        const double duv = fl < m ? (SPLITF ? -acc : acc) : 0.0;     // (split recursion: the gains in HBM are -[K | kappa])
-        const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
-        double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
-        dxn = fl < n ? dxn : 0.0;
-        if (lane < m) { pl1 += fabs(duv); bad |= !isfinite(duv); }
-        if (lane < n) { pl1 += fabs(dxn); bad |= !isfinite(dxn); }
-        dxr = dxn;
-        if constexpr (FWDW) {
-            // w_k = rx_{i,k+1} + Q^_{i,k+1} dx_{k+1} for (player, row) = (ri_, rr_): the head of the costate sweep's FMA sequence
-            const double wq = (k + 1 < N - 1) ? dt : 1.0;
-            double qd = reg + wq * qdfv;
-            if constexpr (C::EXT) qd += Rc[R::RQ + re_];
-            double wk = Rc[R::RX + re_] + qd * dxn;
-            if constexpr (C::POS) {
-                double hv[NPOS];
-#pragma unroll
-                for (int c = 0; c < NPOS; c++) hv[c] = (double)hsg[c] * Rc[hso[c]];
-                double t = wk;
-                rowdot_dpp<NPOS>(t, dxn, hv);
-                wk = rr_ < C::PD * P ? t : wk;
-            }
-            if (rok) gst(dz + n + hl<C>(k, 0), re_, wk);
-        }
-        // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
-#pragma unroll
-        for (int q = 0; q < FPL; q++) L.rec[cur ^ 1][fso[q]] = pref[(u + 1) % SD][q];
-#pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
-        asm volatile("" ::: "memory");
-        // (2) results out
-        if (lane < m) gst(dz + n + hu<C>(k, 0), uoff<C>(lane), duv);
-        if (lane < n) gst(dz + n + hx<C>(k), lane, dxn);
-        // (3) request step k+1+SD into the slot that was just emptied
-        fwd_load(k + 1 + SD, pref[(u + 1) % SD], prek[(u + 1) % SD]);
-        sweep_sync<C>();
-        cur ^= 1;
-      }
-    }
-#if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
-    return ALG_STATUS_OK;
-#endif
-    ALG_PROF(7)
-    // ------------------------------------------------------------------ costate sweep:
-    //   dlambda_{i,k} = Q^_{i,k+1} dx_{k+1} + A_{k+1}' dlambda_{i,k+1} + rx_{i,k+1}
-    // Lane 16 i + r = (player i, row r), one 16-lane row per player.  dx_{k+1} is replicated in every row and reaches the position-block
-    // products through the DPP row broadcast, A' dlambda is a few shifts inside the row (double integrator: velocity row r takes dt
-    // times position row r - m; unicycle / bicycle: the heading / speed rows take the coefficient-weighted position rows r - P .. r - 3P),
-    // the pair-Hessian entries are read straight from the record with per-lane offsets: no dx / dlambda / table round trips through
-    // LDS and one fence per step instead of three.  Same products in the same order as the general form below.
-    if constexpr (!DIROW) hxm.init(phase_lane());
-    if constexpr (C::NW == 1) game_sync(); else dir_sync<C>();   // dx of every step is in global memory
-    G = G0.fresh();
-    dz = G.z(2);
-    if constexpr (FWDW) {
-        // dlambda_k = w_k + A_{k+1}' dlambda_{k+1}: w_k comes back from dlambda's own slot (this lane wrote it in the forward sweep), the
-        // coefficients of A_{k+1} (state-dependent models) from step k + 1's record; SD steps in flight, no LDS, no fence
-        constexpr int NCF = C::NC > 0 ? (C::MODEL == ALG_MODEL_BICYCLE ? 3 : 2) : 0;
-#ifndef ALG_FWDW_DEPTH
-#define ALG_FWDW_DEPTH 8
-#endif
-        constexpr int CD = ALG_FWDW_DEPTH;           // steps in flight: three doubles per slot, and nothing but these loads feeds the recursion
-        double wkr[CD], cfr[CD][NCF > 0 ? NCF : 1];
-        auto cw_load = [&](int kk, double& wv, double (&cf)[NCF > 0 ? NCF : 1]) {
-            const int kc = kk > 0 ? kk : 0, kn = kc + 1 < N - 1 ? kc + 1 : N - 2;
-            wv = gld(dz + n + hl<C>(kc, 0), re_);
-            if constexpr (NCF > 0) {
-                const double* Rn = G.rec(pr) + (size_t)kn * R::LEN + R::COEF;
-                cf[0] = Rn[cia]; cf[1] = Rn[cib];
-                if constexpr (NCF > 2) cf[2] = Rn[cic];
-            }
-        };
-#pragma unroll
-        for (int u = 0; u < CD; u++) cw_load(N - 2 - u, wkr[u], cfr[u]);
-        for (int k0 = N - 2; k0 >= 0; k0 -= CD) {
-#pragma unroll
-          for (int u = 0; u < CD; u++) {
-            const int k = k0 - u;
-            if (k < 0) break;
-            double acc = wkr[u];
-            if (k < N - 2) {
-                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-                    const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp);
-                } else {
-                    const double ca_ = cfr[u][0], cb_ = cfr[u][1];
-                    const double s1 = row_shift<0x110 + P>(lamp), s2 = row_shift<0x110 + 2 * P>(lamp), s3 = row_shift<0x110 + 3 * P>(lamp);
-                    const double vi = cblk == 3 ? s3 : s2, vpi = cblk == 3 ? s2 : s1;
-                    if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
-                        const double u1 = row_shift<0x100 + P>(lamp), cc_ = cfr[u][NCF > 2 ? 2 : 0];
-                        acc += lamp + (c_on ? ca_ : 0.0) * (c_on ? vi : lamp) + (c_on ? cb_ : 0.0) * (c_on ? vpi : lamp) + (cblk == 2 ? cc_ : 0.0) * (cblk == 2 ? u1 : lamp);
-                    } else acc += lamp + (c_on ? ca_ : 0.0) * (c_on ? vi : lamp) + (c_on ? cb_ : 0.0) * (c_on ? vpi : lamp);
-                }
-            }
-            acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
-            lamp = acc;
-            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
-            cw_load(k - CD, wkr[u], cfr[u]);
-          }
-        }
-    } else {
-    constexpr int RPLC = (R::LEN_COSTATE + WAVE - 1) / WAVE;
-    for (int e = lane; e < R::LEN_COSTATE; e += WAVE) L.rec[0][e] = gld(G.rec(pr) + (size_t)(N - 2) * R::LEN, e);
-    const int ci_ = lane < P * n ? lane / n : 0, cr_ = lane < P * n ? lane % n : 0;        // (player, row) of this lane
-    const bool cpos = C::POS && cr_ < C::PD * P;
-    double dxk = lane < n ? gld(dz + n + hx<C>(N - 2), lane) : 0.0;      // dx_{k+1}, fetched ahead like the records
-    if constexpr (DIROW) dxk = gld(dz + n + hx<C>(N - 2), cdxo);
-    auto cs_load = [&](int kk, double& rdx, double (&rr)[RPLC]) {
-        const int kc = kk > 0 ? kk : 0;
-#pragma unroll
-        for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; rr[q] = gld(G.rec(pr) + (size_t)kc * R::LEN, (e < R::LEN_COSTATE ? e : R::LEN_COSTATE - 1)); }
-        rdx = gld(dz + n + hx<C>(kc), cdxo);
-    };
-    // register ring like the forward sweep's: [record slice | dx] of steps k - 1 .. k - SD are in flight while step k computes
-    double pre[SD][RPLC], pdx[SD];
-#pragma unroll
-    for (int u = 0; u < SD; u++) cs_load(N - 3 - u, pdx[(1 + u) % SD], pre[(1 + u) % SD]);
-    sweep_sync<C>();
-    cur = 0;
-    for (int k0 = N - 2; k0 >= 0; k0 -= SD) {
-#pragma unroll
-      for (int u = 0; u < SD; u++) {
-        const int k = k0 - u;
-        if (k < 0) break;
-        const double* Rc = L.rec[cur];
-        const double w = (k + 1 < N - 1) ? dt : 1.0;
-        if constexpr (DIROW) {
-            double qd = reg + w * qdfv;
-            if constexpr (C::EXT) qd += Rc[R::RQ + re_];
-            double acc = Rc[R::RX + re_] + qd * dxk;
-            if constexpr (C::POS) {
-                double hv[NPOS];
-#pragma unroll
-                for (int c = 0; c < NPOS; c++) hv[c] = (double)hsg[c] * Rc[hso[c]];
-                double t = acc;
-                rowdot_dpp<NPOS>(t, dxk, hv);
-                acc = rr_ < C::PD * P ? t : acc;
-            }
-            if (k < N - 2) {
-                if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
-                    const bool hi = rr_ >= m; const double sh = row_shift<0x110 + m>(lamp); acc += lamp + (hi ? dt : 0.0) * (hi ? sh : lamp);
-                } else {
-                    // AT_vec: v(r) + ca v(i) + cb v(P + i) (+ cc v(3P + i), bicycle heading rows), i = r % P: rows 2P + i take lanes r - 2P, r - P
-                    // (, r + P), rows 3P + i take lanes r - 3P, r - 2P
-                    const double s1 = row_shift<0x110 + P>(lamp), s2 = row_shift<0x110 + 2 * P>(lamp), s3 = row_shift<0x110 + 3 * P>(lamp);
-                    const double vi = cblk == 3 ? s3 : s2, vpi = cblk == 3 ? s2 : s1;
-                    if constexpr (C::MODEL == ALG_MODEL_BICYCLE) {
-                        const double u1 = row_shift<0x100 + P>(lamp);
-                        acc += lamp + (c_on ? can : 0.0) * (c_on ? vi : lamp) + (c_on ? cbn : 0.0) * (c_on ? vpi : lamp) + (cblk == 2 ? ccn : 0.0) * (cblk == 2 ? u1 : lamp);
-                    } else acc += lamp + (c_on ? can : 0.0) * (c_on ? vi : lamp) + (c_on ? cbn : 0.0) * (c_on ? vpi : lamp);
-                }
-            }
-            if constexpr (C::NC > 0) { can = Rc[R::COEF + cia]; cbn = Rc[R::COEF + cib]; if constexpr (C::MODEL == ALG_MODEL_BICYCLE) ccn = Rc[R::COEF + cic]; }
-            acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
-            lamp = acc;
-            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
-        } else {
-        if (lane < n) L.fw.dx[lane] = dxk;
-        hxm.expand(lane, Rc, L.fw.hx);
-        sweep_sync<C>();
-        double acc = 0.0;
-        if (lane < P * n && (!IBR || ci_ == ip)) {
-            double qd = reg + w * L.qdf[lane];
-            if constexpr (C::EXT) qd += Rc[R::RQ + lane];
-            acc = Rc[R::RX + lane] + qd * L.fw.dx[cr_];
-            if (cpos) {
-                const double* hrow = &L.fw.hx[(ci_ * P + cr_ % P) * P * C::NS];
-                const int ar = cr_ / P;
-#pragma unroll
-                for (int c = 0; c < C::PD * P; c++) acc += hrow[(c % P) * C::NS + C::sym(ar, c / P)] * L.fw.dx[c];
-            }
-            if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
-        }
-        sweep_sync<C>();
-        if (lane < P * n) { L.fw.dl[lane] = acc; gst(dz + n + hl<C>(k, 0), lane, acc); bad |= !isfinite(acc); }
-        if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
-        }
-        // land step k - 1 (requested SD steps ago), then request step k - 1 - SD into the emptied slot
-        dxk = (DIROW || lane < n) ? pdx[(u + 1) % SD] : 0.0;
-        if (k > 0) {
-#pragma unroll
-            for (int q = 0; q < RPLC; q++) { const int e = lane + q * WAVE; if (e < R::LEN_COSTATE) L.rec[cur ^ 1][e] = pre[(u + 1) % SD][q]; }
-        }
-        cs_load(k - 1 - SD, pdx[(u + 1) % SD], pre[(u + 1) % SD]);
-        sweep_sync<C>();
-        cur ^= 1;
-      }
-    }
-    }
-    ALG_PROF(8)
-    ALG_PROF_FLUSH
-    // non-finite direction -> singular (the reference would throw / propagate NaN)
-    if (primal_l1) *primal_l1 = wave_sum(pl1);
-    return __builtin_amdgcn_readfirstlane(wave_or(bad)) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;     // scalar: the solver's control flow stays on the SALU
+    // the serial forward and costate sweeps (wavefront 0 of a team): direction_forward_costate below
+    return direction_forward_costate<C, IBR>(pr, G0, L, N, dt, lane, reg, ip, primal_l1);
 }
 
 // ================================================================================================

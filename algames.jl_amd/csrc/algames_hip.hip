@@ -15,6 +15,7 @@
 ALG_CFGS_BASE(ALG_DECLARE_KERNELS)
 ALG_CFGS_EXT(ALG_DECLARE_KERNELS)
 ALG_CFGS_DENSE(ALG_DECLARE_KERNELS)
+ALG_CFGS_DI1(ALG_DECLARE_KERNELS)
 ALG_CFGS_MW(ALG_DECLARE_MW)
 ALG_CFGS_MW_DENSE(ALG_DECLARE_MW)
 ALG_CFGS_HANDOFF(ALG_DECLARE_HO)
@@ -122,6 +123,7 @@ bool cfg_supported(const Params& p, int ext) {
     ALG_CFGS_BASE(X)
     ALG_CFGS_EXT(X)
     ALG_CFGS_DENSE(X)
+    ALG_CFGS_DI1(X)
 #undef X
     return false;
 }
@@ -260,7 +262,11 @@ int launch_check(const char* what) {
     LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 5, 2, 1, kernel, __VA_ARGS__)                   \
     LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 6, 2, 1, kernel, __VA_ARGS__)                   \
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 5, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 6, 2, 1, kernel, __VA_ARGS__)
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 6, 2, 1, kernel, __VA_ARGS__)                    \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 1, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 1, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 1, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 1, 0, kernel, __VA_ARGS__)
 
 void dfree(Handle* h, void* q) {
     for (size_t i = 0; i < h->allocs.size(); i++)
@@ -480,7 +486,7 @@ int alg_create(const alg_desc* d, alg_handle** out) {
     if (!d || !out) return fail(ALG_ERR_ARG, "alg_create: null argument");
     Handle* hd = new Handle();
     if (!fill_dims(*d, hd->pr) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "alg_create: unsupported descriptor"); }
-    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=2 p<=6, d=3 p<=4; Unicycle p<=6; Bicycle p<=6; Quadrotor p<=4)"); }
+    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=1 p<=4, d=2 p<=6, d=3 p<=4; Unicycle p<=6; Bicycle p<=6; Quadrotor p<=4)"); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete hd; return fail(ALG_ERR_DEVICE, "alg_create: no HIP device available (this library has no CPU fallback)"); }
     if (d->device < 0 || d->device >= ndev) { delete hd; return fail(ALG_ERR_ARG, "alg_create: bad device ordinal"); }

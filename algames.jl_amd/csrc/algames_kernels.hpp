@@ -279,6 +279,14 @@ __global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_a
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 1)                  \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 1)                  \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 1)
+// DoubleIntegratorGame(p, d = 1) (double_integrator.jl:13-25 takes any d; round 6): n = 2 p, m = p.  px[i] = (i, i + p) is (position, velocity) of
+// player i here -- the reference's index sets do not depend on d -- and the collision terms act on that pair as they do in the reference.
+// p = 2, 4 take the tile path, p = 1, 3 (n = 2, 6) the dense direction; base constraint set (algames_di1.hip)
+#define ALG_CFGS_DI1(X)                                     \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 1, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 1, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 1, 0)                  \
+    X(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 1, 0)
 // Five and six players (n = 20 / 24: dense Newton direction; algames_p5.hip, algames_p6.hip).  The reference itself caps p at 10 (options.jl:68)
 #define ALG_CFGS_P5(X)                                      \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, 5, 2, 0)                  \

@@ -390,7 +390,17 @@ __device__ __forceinline__ void settle_traj(CPR pr, Game& G) {
         game_sync();
         const Game H = G.fresh();
         double* a = H.z(0); double* z_home = H.base;
-        for (int e = phase_lane(); e < pr.traj_len; e += C::NT) { const double v = a[e]; a[e] = z_home[e]; z_home[e] = v; }
+        // (four elements of both buffers per lane in flight: one element per trip exposed 33 global round trips in a row at C2, where the
+        // eleven iterations of a solve always leave pdtraj in the trial buffer)
+        constexpr int U = 4;
+        const int TL = phase_int(pr.traj_len);
+        for (int e0 = phase_lane(); e0 < TL; e0 += U * C::NT) {
+            double va[U], vh[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT, ec = e < TL ? e : e0; va[t] = gld(a, ec); vh[t] = gld(z_home, ec); }
+#pragma unroll
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < TL) { gst(a, e, vh[t]); gst(z_home, e, va[t]); } }
+        }
         G.zo[1] = G.zo[0]; G.zo[0] = 0;
         game_sync();
     }
@@ -409,10 +419,17 @@ __device__ void penalty_update_unused_rows(CPR pr0, const Game& G0, int nup) {
     const Game G = G0.fresh();
     const auto& o = pr.opt;
     const int lo = col_used ? pr.col_len : 0, hi = ctl_used ? pr.col_len : pr.col_len + pr.ctl_len;
-    for (int e = lo + phase_lane(); e < hi; e += C::NT) {
-        double v = gld(G.mu(pr), e);
-        for (int t = 0; t < nup; t++) v = fmin(fmax(v * o.rho_increase, 0.0), o.rho_max);
-        gst(G.mu(pr), e, v);
+    constexpr int U = 4;
+    for (int e0 = lo + phase_lane(); e0 < hi; e0 += U * C::NT) {
+        double v[U];
+#pragma unroll
+        for (int q = 0; q < U; q++) { const int e = e0 + q * C::NT; v[q] = gld(G.mu(pr), e < hi ? e : e0); }
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            const int e = e0 + q * C::NT;
+            for (int t = 0; t < nup; t++) v[q] = fmin(fmax(v[q] * o.rho_increase, 0.0), o.rho_max);
+            if (e < hi) gst(G.mu(pr), e, v[q]);
+        }
     }
 }
 

@@ -100,7 +100,7 @@ def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0, gate=True, wave
     return 8 * (trial + backward + forward + costate + gate_b)
 
 
-def outer_pass_bytes(family, N, n, m, p):
+def outer_pass_bytes(family, N, n, m, p, fused_dual=False):
     """Algorithmic bytes of the two passes newton_solve! makes once per OUTER iteration, which structured_bytes() (per Newton iteration)
     leaves out: (record pass, dual / penalty update pass).
       record pass   the first inner iteration after a dual update cannot reuse the accepted trial's records (the multipliers moved):
@@ -115,7 +115,9 @@ def outer_pass_bytes(family, N, n, m, p):
     npair = p * (p - 1)
     len_rec = nc + 3 * npair + 3 * p + p * n + 2 * m + n + 2 * p * p
     con = K * npair + (2 * m * K if family in ("C3", "C5", "Q") else 0)
-    return 8 * (it + 2 * con + K * len_rec), 8 * (it + 2 * con + 3 * con)
+    # round 6, fused kernels (one wavefront per game, double integrator / unicycle): the dual / penalty update rides on the record pass that
+    # follows it -- its reads ARE the record pass's, what it adds is the three stores (values, lambda, mu)
+    return 8 * (it + 2 * con + K * len_rec), (8 * 3 * con if fused_dual else 8 * (it + 2 * con + 3 * con))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -418,7 +420,7 @@ def main():
         if not args.mpc_steps:
             # passes made once per outer iteration, amortised over the Newton iterations with this launch's own counts: every outer
             # iteration starts with a record pass, every one but the last ends with the dual / penalty update
-            rec_b, dual_b = outer_pass_bytes(family, N, n, m, p)
+            rec_b, dual_b = outer_pass_bytes(family, N, n, m, p, fused_dual=(family in ("C2", "C3", "C5") and waves_per_game == 1))
             n_out = int(st["outer_iters"].sum()); n_dual = int(np.maximum(st["outer_iters"] - 1, 0).sum())
             roof["outer_passes_per_launch"] = {"record": n_out, "dual_update": n_dual}
             roof["bytes_per_game_iter_outer_passes"] = (n_out * rec_b + n_dual * dual_b) / max(1, iters_rank)

@@ -130,9 +130,15 @@ def _compare_solve(g, o, tag, tol=None, x=None):
             assert err <= tol * scale, (tag, err, scale)
         for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
             a, b = sg["last"][f][ok], so["last"][f][ok]
-            if sx is None or not (err > tol * scale):
-                assert np.allclose(a, b, rtol=1e-6, atol=1e-9), (tag, f)
+            if np.allclose(a, b, rtol=1e-6, atol=1e-9):
+                continue
+            if x is None:
+                assert False, (tag, f, a, b)
             else:
+                # (the violation maxima of a non-converged last record are steep functions of the iterate -- penalties of 1e3 and more -- and
+                # can part by more than 1e-6 on trajectories that agree to the tolerance: seed 200041, opt_vio 13.49541868 against 13.49539232)
+                sx = x.newton_solve(init=True, game_id0=7) if sx is None else sx
+                if tag[:4] not in ARBITER_CONSULTED: ARBITER_CONSULTED.append(tag[:4])
                 # a problem that went through the arbiter for its trajectories (both double programs amplify rounding beyond the
                 # tolerance): the statistics of the last record are functions of those trajectories and follow the same rule -- the HIP
                 # path no further from the arbiter's value than four times the oracle's distance (round 5; until then this line compared

@@ -17,6 +17,8 @@ CASES = [  # (model, p, d, N)
     (UNI, 1, 2, 9), (UNI, 2, 2, 20), (UNI, 3, 2, 10), (UNI, 4, 2, 8),
     # outside the 16 x 16 tile (dense Newton direction): five / six players, DoubleIntegrator d = 3 with p = 1, 3, 4
     (DI, 5, 2, 6), (DI, 6, 2, 5), (UNI, 5, 2, 6), (UNI, 6, 2, 5), (DI, 1, 3, 7), (DI, 3, 3, 6), (DI, 4, 3, 5),
+    # DoubleIntegratorGame(p, d = 1) (double_integrator.jl:13-25; round 6): p = 2, 4 on the tile path, p = 1, 3 on the dense direction
+    (DI, 1, 1, 7), (DI, 2, 1, 9), (DI, 3, 1, 6), (DI, 4, 1, 8),
 ]
 
 
@@ -577,3 +579,26 @@ def test_violation_profile_parity(alg, orc, model, p, N, ext):
         assert np.abs(vg[f] - vo[f]).max() <= 1e-9 * (1 + np.abs(vo[f]).max()), f
         assert np.array_equal(vg[f].max(axis=1), rg[f + "_vio"]), f
     assert np.all(vg["sta"][:, 0] == 0.0)
+
+
+@pytest.mark.parametrize("case", [(DI, 1, 1, 7), (DI, 2, 1, 9), (DI, 3, 1, 6), (DI, 4, 1, 8)])
+def test_double_integrator_d1_inner_iterations_and_solve(alg, orc, case):
+    """DoubleIntegratorGame(p, d = 1) (double_integrator.jl:13-25; VERDICT r5 "missing" 3): two inner iterations and the whole newton_solve!
+    against the oracle -- identical discrete histories, trajectories to 1e-8 (residual / Jacobian / direction parity: the CASES list above)."""
+    g, o = _pair(alg, orc, *case, B=4, seed=5)
+    for l in (1, 2):
+        ig, io = g.newton_step(1, l), o.newton_step(1, l)
+        for f in ("status", "control_flow", "ls_j", "ls_failed"):
+            assert np.array_equal(ig[f], io[f]), f
+        assert np.array_equal(ig["alpha"], io["alpha"])
+        for f in ("res", "dyn_vio", "con_vio", "sta_vio", "opt_vio"):
+            assert np.allclose(ig["rec"][f], io["rec"][f], rtol=1e-9, atol=1e-14), f
+        assert np.abs(g.get_traj(0) - o.get_traj(0)).max() <= 1e-9 * max(1.0, np.abs(o.get_traj(0)).max())
+    g, o = _pair(alg, orc, *case, B=4, seed=11)
+    sg, so = g.newton_solve(init=True, game_id0=3), o.newton_solve(init=True, game_id0=3)
+    for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]), f
+    assert sg["newton_iters"].min() > 0
+    assert np.abs(g.get_traj(0) - o.get_traj(0)).max() <= 1e-8 * max(1.0, np.abs(o.get_traj(0)).max())
+    lg, mg = g.get_con_duals(); lo, mo = o.get_con_duals()
+    assert np.array_equal(mg, mo) and np.abs(lg - lo).max() <= 1e-6 * (1 + np.abs(lo).max())

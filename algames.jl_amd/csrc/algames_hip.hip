@@ -67,12 +67,12 @@ bool fill_dims(const alg_desc& a, Params& p) {
     p.ca_dim = 2;
     p.hist_max = HIST_MAX;
     p.refine_max = 2; p.refine_tol = 0x1p-34; p.refine_mu = 1.6e5;
-    // dense-direction configurations (Cfg::DENSE: quadrotor, n > 16, n % 4 != 0): up to SIX corrections, each taken only while the row-wise
-    // backward error still exceeds the tolerance AND the previous one at least halved max |rho| (refined_direction).  Round 5 shipped ONE: on
+    // dense-direction configurations (Cfg::DENSE: quadrotor, n > 16, n % 4 != 0): up to EIGHT corrections, each taken only while the row-wise
+    // backward error still exceeds the tolerance AND (near the tolerance) the previous one at least halved max |rho| (refined_direction).  Round 5 shipped ONE: on
     // the arbiter test's seeds a second correction changes no digit -- with the contraction test those directions stop after the first anyway --
     // but an ill-conditioned system (fuzz seed 400051: forward error 5.6e-4 after the bare elimination, 9.5e-7 after one correction, 6.5e-8 after
     // two, against the pivoted LU's 5.8e-13; tests/probes/r06_dense_gap.py) needs the further ones.
-    if (p.model == ALG_MODEL_QUADROTOR || p.n > 16 || (p.n % 4) != 0) p.refine_max = 6;
+    if (p.model == ALG_MODEL_QUADROTOR || p.n > 16 || (p.n % 4) != 0) p.refine_max = 8;
     // A/B runs of whole test suites (alg_set_refinement otherwise).  An override changes production numerics: the environment is read by
     // DEBUG builds only (-DALG_DEBUG_ENV, tests/probes/build_variant.sh) and announced once; the shipped library ignores it.
 #ifdef ALG_DEBUG_ENV

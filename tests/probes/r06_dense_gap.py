@@ -31,11 +31,12 @@ for k in range(1, opts["outer_iter"] + 1):
         J = x.residual_jacobian(reg).astype(np.longdouble); res = x.residual(0, 0.0)[0].astype(np.longdouble)
         dx, sx = x.newton_direction(reg); do, so = o.newton_direction(reg)
         out = []
-        for name, rs in (("gate off", 0), ("default", None), ("2 forced", (2, 0.0))):
+        for name, rs in (("gate off", 0), ("default", None), ("2 forced", (2, 0.0)), ("6, tol 1e-30", (6, 1e-30)), ("8 forced", (8, 0.0))):
             if rs == 0: g.set_refinement(0)
-            elif rs is None: g.set_refinement(1, 2.0 ** -34, 1.6e5)
-            else: g.set_refinement(2, 0.0, 1.6e5)
+            elif rs is None: g.set_refinement(6, 2.0 ** -34, 1.6e5)
+            else: g.set_refinement(rs[0], rs[1], 1.6e5)
             dg, sg = g.newton_direction(reg)
+            if rs is None: print("      gate of the first solve [max |rho|, omega, row scale]:", g.get_direction_gate().tolist())
             sc = np.abs(dx).max(axis=1)
             r = np.einsum("brc,bc->br", J, dg.astype(np.longdouble)) + res
             out.append((name, sg, np.abs(dg - dx).max(axis=1) / sc, [np.abs(r[:, rr]).max(axis=1).astype(float) for rr in (rows_x, rows_u, rows_d)]))
@@ -43,7 +44,7 @@ for k in range(1, opts["outer_iter"] + 1):
         print("k %d l %d  |z| %.2e  |d| %s  oracle err %s" % (k, l, np.abs(z).max(), np.abs(dx).max(axis=1), np.abs(do - dx).max(axis=1) / np.abs(dx).max(axis=1)))
         print("      oracle residual rows x|u|d:", [np.abs(ro[:, rr]).max(axis=1).astype(float) for rr in (rows_x, rows_u, rows_d)])
         for name, sg, e, rr in out: print("   %-9s status %s  err vs arbiter %s  residual rows x %s u %s d %s" % (name, sg, e, rr[0], rr[1], rr[2]))
-        g.set_refinement(1, 2.0 ** -34, 1.6e5)
+        g.set_refinement(6, 2.0 ** -34, 1.6e5)
         # advance all three with the ORACLE's step (one inner iteration of the oracle), so that the next state is shared
         info = o.newton_step(k, l)
         if np.all(info["control_flow"] == 1): break

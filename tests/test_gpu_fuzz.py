@@ -94,22 +94,22 @@ def _compare_solve(g, o, tag, tol=None, x=None):
     tol = FUZZ_TOL if tol is None else tol
     sx, same = None, None
     sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
-    # Round 6: a game on which the two double programs end with different STATUSES is legitimate only where the oracle's own answer is noise:
-    # the long-double run of the same algorithm on the same inputs ends somewhere else entirely, or nowhere (non-finite iterates).  That is the
-    # diverged quadrotor game of seeds 400040 / 400059 / 400074 -- iterates of 1e11 ... 1e186, Newton directions of 1e54 ... inf,
-    # tests/probes/r06_dense_gap.py -- on which the structured elimination reports SINGULAR while the banded LU keeps returning finite numbers
-    # that the arbiter contradicts in the first digit.  Such a game is taken out of the comparison; any other status difference fails.
+    # Round 6: a game on which the two double programs end with different STATUSES is accepted only when the game has DIVERGED: the arbiter's
+    # own iterate (long double, same algorithm, same inputs) is non-finite or beyond 1e10.  That is the one game of seeds 400040 / 400059 /
+    # 400074 -- iterates 1e11 -> 1e54 -> 1e186, Newton directions of 1e54 ... inf (profiles/r06_dense_gap_seed_400040.txt) -- on which the
+    # structured elimination (a block LU without pivoting across blocks) runs out of range and reports SINGULAR while the pivoted LU keeps
+    # returning finite directions: a known limit of the elimination, on iterates no caller can use.  Such a game is taken out of the
+    # comparison; any other status difference fails.
     noise = np.zeros(len(sg), bool)
     if not np.array_equal(sg["status"], so["status"]):
         assert x is not None, (tag, "status", sg["status"], so["status"])
         sx = x.newton_solve(init=True, game_id0=7)
-        zo_, zx_ = o.get_traj(0), x.get_traj(0)
+        zx_ = x.get_traj(0)
         for game in np.nonzero(sg["status"] != so["status"])[0]:
-            fin = np.isfinite(zo_[game]).all() and np.isfinite(zx_[game]).all()
-            far = (not fin) or np.abs(zo_[game] - zx_[game]).max() > 1e-3 * max(1.0, np.abs(zx_[game]).max())
-            assert far, (tag, "status", sg["status"], so["status"])
+            diverged = (not np.isfinite(zx_[game]).all()) or np.abs(zx_[game]).max() > 1e10
+            assert diverged, (tag, "status", sg["status"], so["status"], np.abs(zx_[game]).max())
             noise[game] = True
-        print("status differs on a game whose oracle run is noise against the arbiter:", tag[:4], np.nonzero(noise)[0], sg["status"], so["status"])
+        print("status differs on a diverged game (arbiter iterate beyond 1e10):", tag[:4], np.nonzero(noise)[0], sg["status"], so["status"])
     keep = ~noise
     for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
         assert np.array_equal(sg[f][keep], so[f][keep]), (tag, f, sg[f], so[f])
@@ -261,7 +261,8 @@ def test_fuzz_dense_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
 # The seeds the long run of round 5 left outside the rule (profiles/r05_fuzz_long_final.txt), under _compare_solve itself:
 #   400051  two quadrotors, an ill-conditioned direction (5.6e-4 from the bare elimination): the dense direction now refines while a correction
 #           still contracts (up to six), round 5 stopped after one at 9.5e-7
-#   400040, 400059, 400074  two quadrotors, one game diverges (iterates 1e11 ... 1e186): SINGULAR against the LU's noise -- the status rule above
+#   400040, 400059, 400074  two quadrotors, one game diverges (iterates 1e11 ... 1e186): the elimination reports SINGULAR, the LU does not -- the
+#           status rule of _compare_solve (diverged games only); a limit of the elimination, not fixed
 #   200041  extended bicycle, a rounding amplifier that passes on its trajectories through the arbiter
 @pytest.mark.parametrize("seed", [400040, 400051, 400059, 400074, 200041])
 def test_fuzz_long_run_seeds_of_round_5(alg, orc, seed):

@@ -22,8 +22,8 @@ def test_refinement_controls_round_trip(alg, orc):
     g, _ = _pair(alg, orc, DI, 2, 2, 8, B=2)
     ms, tol, mu = g.get_refinement()
     assert (ms, tol, mu) == (2, 2.0 ** -34, 1.6e5)                     # the library's defaults
-    gd, _ = _pair(alg, orc, DI, 3, 3, 6, B=2)                          # dense-direction configuration: up to six corrections, each only while the previous one contracted (round 6)
-    assert gd.get_refinement() == (6, 2.0 ** -34, 1.6e5)
+    gd, _ = _pair(alg, orc, DI, 3, 3, 6, B=2)                          # dense-direction configuration: up to eight corrections (round 6)
+    assert gd.get_refinement() == (8, 2.0 ** -34, 1.6e5)
     g.set_refinement(1, 1e-9, 10.0); assert g.get_refinement() == (1, 1e-9, 10.0)
     g.set_refinement(tol=0.0); assert g.get_refinement() == (1, 0.0, 10.0)
     for bad in ((-1, 1e-9, 1.0), (9, 1e-9, 1.0), (1, -1.0, 1.0), (1, float("nan"), 1.0), (1, 1e-9, -2.0)):

@@ -4,6 +4,10 @@
 #pragma once
 #include "algames_device.hpp"
 
+#ifndef ALG_DENSE_TOL_FACTOR
+#define ALG_DENSE_TOL_FACTOR 0x1p-7      // gate tolerance of the dense-direction configurations relative to Params::refine_tol (refined_direction)
+#endif
+
 namespace alg {
 
 // ================================================================================================
@@ -2292,10 +2296,10 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
         // n up to 48) needs a tighter gate and no relaxation: its directions miss the LU's backward error (1e-18) by four orders at row-wise
         // errors of 1e-11 already (tests/test_gpu_fuzz.py::test_direction_backward_error_against_the_arbiter passes from tol / 64 on).
         // (round 6: the gate's row scale is the true |J_c| |d| + |r_c| -- until round 5 an estimate from below made omega up to 259 x conservative
-        // and tol / 64 was calibrated on that; with the true scale the same directions need tol / 256 for the 1e-15 normwise bound.  The dense
+        // and tol / 64 was calibrated on that; with the true scale the same directions need tol / 128 for the 1e-15 normwise bound.  The dense
         // configurations take up to six corrections while each one at least halves the residual: an ill-conditioned quadrotor system (fuzz seed
         // 400051: forward error 5.6e-4 from the bare elimination) contracts by 30 ... 3000 x per correction, tests/probes/r06_dense_gap.py.)
-        const double tol = phase_f64(pr.refine_tol) * (C::DENSE ? 0x1p-8 : 1.0);
+        const double tol = phase_f64(pr.refine_tol) * (C::DENSE ? ALG_DENSE_TOL_FACTOR : 1.0);
         // a stalled correction ends the refinement only near the tolerance (within 2^10 of it: the rounding floor of the rows' own evaluation keeps
         // some directions above tol for good); far above it the sequence is not monotone -- on fuzz seed 400051 a correction that gains nothing is
         // followed by ones that gain orders (tests/probes/r06_seed_solve.py: 8 forced corrections 2e-8 from the arbiter, stop-at-first-stall 1e-4)

@@ -263,6 +263,21 @@ int launch_check(const char* what) {
     LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 6, 2, 1, kernel, __VA_ARGS__)                   \
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 5, 2, 1, kernel, __VA_ARGS__)                    \
     LAUNCH_ONE_(ALG_MODEL_BICYCLE, 6, 2, 1, kernel, __VA_ARGS__)                    \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 7, 2, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 7, 2, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 7, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 7, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 7, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 8, 2, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 8, 2, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 8, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 8, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 8, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 9, 2, 0, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 9, 2, 1, kernel, __VA_ARGS__)          \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 9, 2, 0, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 9, 2, 1, kernel, __VA_ARGS__)                   \
+    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 9, 2, 1, kernel, __VA_ARGS__)                   \
     LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 1, 0, kernel, __VA_ARGS__)          \
     LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 1, 0, kernel, __VA_ARGS__)          \
     LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 1, 0, kernel, __VA_ARGS__)          \
@@ -486,7 +501,7 @@ int alg_create(const alg_desc* d, alg_handle** out) {
     if (!d || !out) return fail(ALG_ERR_ARG, "alg_create: null argument");
     Handle* hd = new Handle();
     if (!fill_dims(*d, hd->pr) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "alg_create: unsupported descriptor"); }
-    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=1 p<=4, d=2 p<=6, d=3 p<=4; Unicycle p<=6; Bicycle p<=6; Quadrotor p<=4)"); }
+    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=1 p<=4, d=2 p<=9, d=3 p<=4; Unicycle p<=9; Bicycle p<=9; Quadrotor p<=4; ten players -- the reference's cap -- exceed one CU's LDS)"); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete hd; return fail(ALG_ERR_DEVICE, "alg_create: no HIP device available (this library has no CPU fallback)"); }
     if (d->device < 0 || d->device >= ndev) { delete hd; return fail(ALG_ERR_ARG, "alg_create: bad device ordinal"); }
@@ -690,7 +705,7 @@ static int ext_commit(Handle* hd) {
     int rc = use_device(hd); if (rc) return rc;
     if ((rc = sync(hd))) return rc;
     Params& p = hd->pr;
-    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 / Unicycle / Bicycle p<=6, DoubleIntegrator d=3 / Quadrotor p<=4)");
+    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 / Unicycle / Bicycle p<=9, DoubleIntegrator d=3 / Quadrotor p<=4)");
     p.ext = 1;
     recount_con(p);
     dfree(hd, p.con); p.con = nullptr;

@@ -194,7 +194,7 @@ int  alg_get_handoff(alg_handle* h, int32_t* iters, int32_t* parked_last);
  * `max_steps` correction solves per direction).  `tol` is the tolerance for games whose largest constraint penalty (ALConVal mu) has
  * reached `mu_tight`; below that it is relaxed in proportion mu_tight / mu_max, at most 256 x (a forward-error target needs a backward
  * error of target / cond(J), and cond(J) grows with the penalties).  The dense-direction configurations (Quadrotor, n > 16) use
- * tol / 256 without relaxation.  Within 2^10 of the tolerance a correction that does not at least halve max |rho| ends the refinement.
+ * tol / 128 without relaxation.  Within 2^10 of the tolerance a correction that does not at least halve max |rho| ends the refinement.
  * Defaults: max_steps = 2 (dense-direction configurations: 8), tol = 2^-34, mu_tight = 1.6e5;
  * max_steps = 0 switches gate and refinement off (the round-3 arithmetic).  alg_game_stats.refinements counts the correction
  * solves of a newton_solve!.  A correction solve uses the trial trajectory (ALG_TRAJ_TRIAL) as its output buffer: after

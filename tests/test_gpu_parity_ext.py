@@ -12,6 +12,8 @@ CASES = [  # (model, p, N)
     (BIC, 1, 8), (BIC, 2, 12), (BIC, 3, 10), (BIC, 4, 6),
     # five and six players (n = 20 / 24: dense Newton direction, algames_p5.hip / algames_p6.hip)
     (DI, 5, 5), (DI, 6, 4), (UNI, 5, 5), (UNI, 6, 4), (BIC, 5, 5), (BIC, 6, 4),
+    # seven to nine players (round 6: algames_p7.hip ... algames_p9.hip)
+    (DI, 7, 4), (UNI, 8, 4), (BIC, 9, 4), (BIC, 7, 5), (DI, 9, 3), (UNI, 9, 4),
 ]
 ALL = ("cost", "avoid", "ctl", "sb", "wall", "circ")
 
@@ -241,7 +243,9 @@ ALL_INSTANTIATIONS = ([(DI, p, N, False) for p, N in ((1, 5), (2, 13), (3, 40), 
                       + [(BIC, p, N, True) for p, N in ((1, 8), (2, 7), (3, 20), (4, 11))]
                       + [(DI, 5, 7, False), (DI, 6, 5, True), (UNI, 5, 6, True), (UNI, 6, 5, False), (BIC, 5, 6, True), (BIC, 6, 5, True)]
                       # (round 5: the other four five- / six-player instantiations, so that every kernel of ALG_CFGS_P56 is reached by a test)
-                      + [(DI, 5, 5, True), (DI, 6, 6, False), (UNI, 5, 5, False), (UNI, 6, 4, True)])
+                      + [(DI, 5, 5, True), (DI, 6, 6, False), (UNI, 5, 5, False), (UNI, 6, 4, True)]
+                      # (round 6: seven to nine players, every instantiation of ALG_CFGS_P789)
+                      + [(m_, p_, 4, e_) for p_ in (7, 8, 9) for m_, e_ in ((DI, False), (DI, True), (UNI, False), (UNI, True), (BIC, True))])
 
 
 @pytest.mark.timeout(120)

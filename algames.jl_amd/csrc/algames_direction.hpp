@@ -4,6 +4,9 @@
 #pragma once
 #include "algames_device.hpp"
 
+#ifndef ALG_R6_GATE_UNROLL
+#define ALG_R6_GATE_UNROLL 4             // items per lane and trip of the gate's flat pass (0: one by one, as until round 5)
+#endif
 #ifndef ALG_DENSE_TOL_FACTOR
 #define ALG_DENSE_TOL_FACTOR 0x1p-7      // gate tolerance of the dense-direction configurations relative to Params::refine_tol (refined_direction)
 #endif
@@ -1462,11 +1465,12 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
     int fso[FPL];
 #pragma unroll
     for (int q = 0; q < FPL; q++) { const int e = lane + q * WAVE; fso[q] = FWDW ? (e < R::LEN_COSTATE ? e : (e < FSL2 ? R::RD + (e - R::LEN_COSTATE) : R::RD)) : (frok ? fro : R::RD); }
-    if constexpr (FWDW) {
+    // (step 0's slice and gains are requested here and landed behind the ring's requests below: one exposed round trip instead of three)
+    double rf0[FPL], rk0[KPL];
 #pragma unroll
-        for (int q = 0; q < FPL; q++) L.rec[0][fso[q]] = gld(G.rec(pr), fso[q]);
-    } else if (frok) L.rec[0][fro] = gld(G.rec(pr), fro);
-    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = gld(G.kgain(pr), e);
+    for (int q = 0; q < FPL; q++) rf0[q] = gld(G.rec(pr), fso[q]);
+#pragma unroll
+    for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk0[q] = gld(G.kgain(pr), e < NK ? e : NK - 1); }
     // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
     // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
     // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
@@ -1489,6 +1493,10 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
     double pref[SD][FPL], prek[SD][KPL];
 #pragma unroll
     for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
+#pragma unroll
+    for (int q = 0; q < FPL; q++) { if (FWDW || frok) L.rec[0][fso[q]] = rf0[q]; }
+#pragma unroll
+    for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.fw.kg[0][e] = rk0[q]; }
     sweep_sync<C>();
     int cur = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
@@ -2135,6 +2143,37 @@ __device__ DirGate dir_urow_residual(CPR pr0, const Game& G0, int ip) {
     double* __restrict__ recs = G.rec(pr);
     // the pair with the largest ratio |rho| / scale is tracked by cross-multiplication: one division per lane at the end
     double rho_m = 0.0, s_m = 0.0, wr = 0.0, ws = 1.0;
+#if ALG_R6_GATE_UNROLL
+    if constexpr (!WRITE) {
+        // (gate only: the loads of ALG_R6_GATE_UNROLL items per lane in flight together -- one item per trip exposed four global round trips per
+        // direction at C2; the WRITE form stores into the records it reads and keeps the one-by-one loop)
+        constexpr int U = ALG_R6_GATE_UNROLL;
+        const int total = (N - 1) * m;
+        for (int e0 = tid; e0 < total; e0 += U * C::NT) {
+            double rhoa[U], sca[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                const int e = e0 + t * C::NT, ec = e < total ? e : e0;
+                const int k = ec / m, c = ec % m, i = c % P;
+                const double* Rk = recs + (size_t)k * R::LEN;
+                const int ro = k * R::LEN, dlo = n + hl<C>(k, i);
+                const double du = gld(dz, n + hu<C>(k, 0) + uoff<C>(c));
+                const double rh = gld(recs, ro + R::RHAT + c), ru = gld(recs, ro + R::RU + c);
+                const double bl = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return gld(dz, dlo + rr); }, c);
+                const double bla = BT_vec_abs<C>(Rk + R::COEF, dt, [&](int rr) { return fabs(gld(dz, dlo + rr)); }, c);
+                double rho = fma(rh, du, ru) + bl;
+                if (IBR && i != ip) rho = 0.0;
+                rhoa[t] = e < total ? fabs(rho) : 0.0;
+                sca[t] = e < total ? fabs(rh * du) + fabs(ru) + fabs(bla) : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                if (rhoa[t] * ws > wr * sca[t]) { wr = rhoa[t]; ws = sca[t]; }
+                rho_m = fmax(rho_m, rhoa[t]); s_m = fmax(s_m, sca[t]);
+            }
+        }
+    } else
+#endif
     for (int e = tid; e < (N - 1) * m; e += C::NT) {
         const int k = e / m, c = e % m, i = c % P;
         double* Rk = recs + (size_t)k * R::LEN;
@@ -2249,6 +2288,9 @@ __device__ __forceinline__ int refined_direction(CPR pr0, const Game& G0, Lds<C>
             game_sync();
             st = __builtin_amdgcn_readfirstlane((int)dir_out[0]); pl1s = uni(dir_out[1]);
         }
+#ifdef ALG_TEST_FAIL_CORRECTION         // test build (tests/test_gpu_refinement.py): every correction solve "fails" after its sweeps have run
+        if (pass > 0) st = ALG_STATUS_SINGULAR;
+#endif
         const int rmax = phase_int(pr.refine_max);
         if (pass == 0 && rmax <= 0) {                                                     // gate and refinement off: nothing to report
             if (phase_lane() == 0) { double* t0 = G0.fresh().tc(pr); t0[TC_RHO] = 0.0; t0[TC_OMEGA] = 0.0; t0[TC_SMAX] = 0.0; }

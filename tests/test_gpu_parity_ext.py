@@ -226,7 +226,10 @@ def test_reference_constrained_unicycle_with_circles_on_gpu(alg):
 
 def test_extended_constraints_unsupported_configuration_fails_loudly(alg):
     with pytest.raises(alg.AlgamesError):
-        alg.Batch(alg.hip_lib(), DI, 7, 6, 0.1, 1, d=2)         # seven players: no kernel instantiation at all
+        alg.Batch(alg.hip_lib(), DI, 10, 6, 0.1, 1, d=2)        # ten players (the reference's cap, options.jl:68): no kernel instantiation -- their value matrices exceed one CU's LDS
+    b = alg.Batch(alg.hip_lib(), DI, 2, 6, 0.1, 1, d=1)         # DoubleIntegrator d = 1: base constraint set only
+    with pytest.raises(alg.AlgamesError):
+        b.add_state_bound(0, np.ones(b.n), -np.ones(b.n))
 
 
 def _guards_ok(batch):

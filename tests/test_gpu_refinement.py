@@ -130,3 +130,43 @@ def test_switched_off_is_the_plain_elimination(alg, orc):
     for f in ("status", "outer_iters", "newton_iters", "ls_failures", "converged"):
         assert np.array_equal(sg[f], so[f]), f
     assert sg["converged"].all() and np.abs(pg.batch.get_traj(0) - po.batch.get_traj(0)).max() <= 1e-8
+
+
+def test_a_failed_correction_solve_leaves_the_trial_buffer_s_x1_intact(alg):
+    """a correction solve that fails on pass > 0 is dropped and the line search runs on the direction of the passes
+    before -- but the correction's forward sweep has zeroed x_1 of its output buffer, the TRIAL buffer, and an accepted trial becomes
+    pdtraj.  A test build of the C5 kernels (-DALG_TEST_FAIL_CORRECTION: every correction "fails" after its sweeps ran) must still keep
+    x_1 = x0 in both buffers, solve like the library with the refinement switched off, and report status OK."""
+    import os, subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    var = os.path.join(root, "algames.jl_amd", "lib", "variants", "failcorr.so")
+    src = [os.path.join(root, "algames.jl_amd", "csrc", f) for f in ("algames_direction.hpp", "algames_solver.hpp", "algames_assemble.hpp", "algames_device.hpp")]
+    if not os.path.exists(var) or any(os.path.getmtime(f) > os.path.getmtime(var) for f in src):
+        r = subprocess.run(["bash", os.path.join(root, "tests", "probes", "build_variant.sh"), "failcorr", "-DALG_TEST_FAIL_CORRECTION"],
+                           env=dict(os.environ, UNITS="base_7"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+    code = r'''
+import sys, json; sys.path.insert(0, %r)
+import numpy as np, algames_jl_amd as alg
+out = {}
+for name, rs in (("off", (0, 0.0)), ("forced", (2, 0.0))):
+    prob = alg.scenarios.make_problem("C5", np.arange(8)); b = prob.batch
+    b.set_waves_per_game(1); b.set_refinement(rs[0], rs[1], 1.6e5)
+    b.init_traj(game_id0=0); b.rollout(0)
+    d, st = b.newton_direction(1e-7)
+    x1_trial = b.get_traj(1)[:, :b.n]
+    alg.newton_solve(prob)
+    s = prob.stats.summary
+    out[name] = dict(status=st.tolist(), x1_trial_err=float(np.abs(x1_trial - b.get_x0()).max()), x1_err=float(np.abs(b.get_traj(0)[:, :b.n] - b.get_x0()).max()),
+                     solve_status=s["status"].tolist(), iters=s["newton_iters"].tolist(), refinements=s["refinements"].tolist(), z=b.get_traj(0).tobytes().hex())
+print("RESULT " + json.dumps(out))
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ALGAMES_HIP_LIB=var), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    for name in ("off", "forced"):
+        assert out[name]["x1_trial_err"] == 0.0 and out[name]["x1_err"] == 0.0, (name, out[name]["x1_trial_err"], out[name]["x1_err"])
+        assert all(v == 0 for v in out[name]["status"]) and all(v == 0 for v in out[name]["solve_status"])
+    # every "failed" correction was dropped: the solve is the plain elimination's, bit for bit; the attempts are counted
+    assert out["forced"]["z"] == out["off"]["z"] and out["forced"]["iters"] == out["off"]["iters"]
+    assert all(r_ >= i_ for r_, i_ in zip(out["forced"]["refinements"], out["forced"]["iters"])) and all(v == 0 for v in out["off"]["refinements"])

@@ -4,9 +4,6 @@
 #pragma once
 #include "algames_device.hpp"
 
-#ifndef ALG_R6_GATE_UNROLL
-#define ALG_R6_GATE_UNROLL 4             // items per lane and trip of the gate's flat pass (0: one by one, as until round 5)
-#endif
 #ifndef ALG_DENSE_TOL_FACTOR
 #define ALG_DENSE_TOL_FACTOR 0x1p-7      // gate tolerance of the dense-direction configurations relative to Params::refine_tol (refined_direction)
 #endif
@@ -297,6 +294,45 @@ __device__ __forceinline__ void rowdot_dpp_g(double& acc, double v, PF&& p) {
     if constexpr (G <= 0) rowdot_dpp_f<NC>(acc, v, p);
     else { double cur[G]; rowdot_group_load<0, G, NC>(cur, p); rowdot_pipe<NC, G, 0>(acc, v, p, cur); }
 }
+// Two interleaved half-chains (round 6, ALG_R6_ROWDOT_SPLIT): terms 0 .. H-1 accumulate into acc, terms H .. NC-1 into a second accumulator, the two
+// are added at the end -- the dependent chain is H + 1 instructions long instead of NC.  A lone wavefront waits out every link of these chains (the
+// forward sweep's du = -(Y dx + y0), the backward sweep's y_i = P_i rd + s_i: 12 links each at C2).  Another association of the same sum: results
+// move at rounding level against the single chain.  Coefficients are requested in groups of G (two terms of each half per group of four).
+template <int NC, int H, int I, int G2, class PF>
+__device__ __forceinline__ void rowdot_split_group_load(double (&ca)[G2], double (&cb)[G2], PF&& p, int) {
+    if constexpr (true) {
+#pragma unroll
+        for (int t = 0; t < G2; t++) { ca[t] = (I + t < H) ? p(I + t) : 0.0; cb[t] = (H + I + t < NC) ? p(H + I + t) : 0.0; }
+    }
+}
+template <int NC, int H, int I, int G2, int T = 0>
+__device__ __forceinline__ void rowdot_split_group_fmac(double& a, double& b2, double v, const double (&ca)[G2], const double (&cb)[G2]) {
+    if constexpr (T < G2) {
+        if constexpr (I + T < H) fmac_rowbcast<I + T, (I + T == 0)>(a, v, ca[T]);
+        if constexpr (H + I + T < NC) fmac_rowbcast<H + I + T, false>(b2, v, cb[T]);
+        rowdot_split_group_fmac<NC, H, I, G2, T + 1>(a, b2, v, ca, cb);
+    }
+}
+template <int NC, int H, int I, int G2, class PF>
+__device__ __forceinline__ void rowdot_split_pipe(double& a, double& b2, double v, PF&& p, const double (&ca)[G2], const double (&cb)[G2]) {
+    if constexpr (I + G2 < H) {
+        double na[G2], nb[G2];
+        rowdot_split_group_load<NC, H, I + G2, G2>(na, nb, p, 0);
+        rowdot_split_group_fmac<NC, H, I, G2>(a, b2, v, ca, cb);
+        rowdot_split_pipe<NC, H, I + G2, G2>(a, b2, v, p, na, nb);
+    } else rowdot_split_group_fmac<NC, H, I, G2>(a, b2, v, ca, cb);
+}
+template <int NC, int G, class PF>
+__device__ __forceinline__ void rowdot_dpp_split(double& acc, double v, PF&& p) {
+    constexpr int H = (NC + 1) / 2, G2 = (G >= 2 ? G / 2 : 1);
+    double b2 = 0.0, ca[G2], cb[G2];
+    rowdot_split_group_load<NC, H, 0, G2>(ca, cb, p, 0);
+    rowdot_split_pipe<NC, H, 0, G2>(acc, b2, v, p, ca, cb);
+    acc += b2;
+}
+#ifndef ALG_R6_ROWDOT_SPLIT
+#define ALG_R6_ROWDOT_SPLIT 0
+#endif
 #ifndef ALG_RDG_W2
 #define ALG_RDG_W2 16         // coefficient group of the row-broadcast chains, 256-register kernels (0: fetch where used)
 #endif
@@ -1465,12 +1501,11 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
     int fso[FPL];
 #pragma unroll
     for (int q = 0; q < FPL; q++) { const int e = lane + q * WAVE; fso[q] = FWDW ? (e < R::LEN_COSTATE ? e : (e < FSL2 ? R::RD + (e - R::LEN_COSTATE) : R::RD)) : (frok ? fro : R::RD); }
-    // (step 0's slice and gains are requested here and landed behind the ring's requests below: one exposed round trip instead of three)
-    double rf0[FPL], rk0[KPL];
+    if constexpr (FWDW) {
 #pragma unroll
-    for (int q = 0; q < FPL; q++) rf0[q] = gld(G.rec(pr), fso[q]);
-#pragma unroll
-    for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk0[q] = gld(G.kgain(pr), e < NK ? e : NK - 1); }
+        for (int q = 0; q < FPL; q++) L.rec[0][fso[q]] = gld(G.rec(pr), fso[q]);
+    } else if (frok) L.rec[0][fro] = gld(G.rec(pr), fro);
+    for (int e = lane; e < NK; e += WAVE) L.fw.kg[0][e] = gld(G.kgain(pr), e);
     // Global-memory schedule of a step.  gfx9 counts loads and stores in one vmcnt, so a wait for loaded data also waits for the
     // write acknowledgement of every store in flight; and a conditional load into a zero-initialised register makes the compiler
     // drain vmcnt at the top of the loop (write-after-write on the register).  Hence: unconditional loads from clamped
@@ -1493,10 +1528,6 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
     double pref[SD][FPL], prek[SD][KPL];
 #pragma unroll
     for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
-#pragma unroll
-    for (int q = 0; q < FPL; q++) { if (FWDW || frok) L.rec[0][fso[q]] = rf0[q]; }
-#pragma unroll
-    for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; if (e < NK) L.fw.kg[0][e] = rk0[q]; }
     sweep_sync<C>();
     int cur = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
@@ -1513,7 +1544,8 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
         const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
         const int cl = fl < m ? fl : 0;
         double acc = Kl[n * m + cl];
-        rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
+        if constexpr (ALG_R6_ROWDOT_SPLIT != 0) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });
+        else rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
         const double duv = fl < m ? (SPLITF ? -acc : acc) : 0.0;     // (split recursion: the gains in HBM are -[K | kappa])
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
@@ -1959,7 +1991,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
             const double rdl = Rc[R::RD + yr];
             double a = Pr[n];
-            rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
+            if constexpr (ALG_R6_ROWDOT_SPLIT != 0) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
+            else rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
             if (!GFUSE && (ty & 15) < n) L.bw.t[yp * n + yr] = a;
             // split recursion: y_i takes the place of s_i (this lane was its only reader): column n of [P_i A_k | y_i] in the next step
             if constexpr (SPLITF) { if ((ty & 15) < n) L.bw.Pm[yp * n * LDP + yr * LDP + n] = a; }
@@ -2143,37 +2176,8 @@ __device__ DirGate dir_urow_residual(CPR pr0, const Game& G0, int ip) {
     double* __restrict__ recs = G.rec(pr);
     // the pair with the largest ratio |rho| / scale is tracked by cross-multiplication: one division per lane at the end
     double rho_m = 0.0, s_m = 0.0, wr = 0.0, ws = 1.0;
-#if ALG_R6_GATE_UNROLL
-    if constexpr (!WRITE) {
-        // (gate only: the loads of ALG_R6_GATE_UNROLL items per lane in flight together -- one item per trip exposed four global round trips per
-        // direction at C2; the WRITE form stores into the records it reads and keeps the one-by-one loop)
-        constexpr int U = ALG_R6_GATE_UNROLL;
-        const int total = (N - 1) * m;
-        for (int e0 = tid; e0 < total; e0 += U * C::NT) {
-            double rhoa[U], sca[U];
-#pragma unroll
-            for (int t = 0; t < U; t++) {
-                const int e = e0 + t * C::NT, ec = e < total ? e : e0;
-                const int k = ec / m, c = ec % m, i = c % P;
-                const double* Rk = recs + (size_t)k * R::LEN;
-                const int ro = k * R::LEN, dlo = n + hl<C>(k, i);
-                const double du = gld(dz, n + hu<C>(k, 0) + uoff<C>(c));
-                const double rh = gld(recs, ro + R::RHAT + c), ru = gld(recs, ro + R::RU + c);
-                const double bl = BT_vec<C>(Rk + R::COEF, dt, [&](int rr) { return gld(dz, dlo + rr); }, c);
-                const double bla = BT_vec_abs<C>(Rk + R::COEF, dt, [&](int rr) { return fabs(gld(dz, dlo + rr)); }, c);
-                double rho = fma(rh, du, ru) + bl;
-                if (IBR && i != ip) rho = 0.0;
-                rhoa[t] = e < total ? fabs(rho) : 0.0;
-                sca[t] = e < total ? fabs(rh * du) + fabs(ru) + fabs(bla) : 0.0;
-            }
-#pragma unroll
-            for (int t = 0; t < U; t++) {
-                if (rhoa[t] * ws > wr * sca[t]) { wr = rhoa[t]; ws = sca[t]; }
-                rho_m = fmax(rho_m, rhoa[t]); s_m = fmax(s_m, sca[t]);
-            }
-        }
-    } else
-#endif
+    // (measured again in round 6: four items per lane with their loads in flight together -- neutral at C2, like round 4's attempt:
+    // profiles/r06_ab_micro_c2.txt; the pass keeps its one-item trips)
     for (int e = tid; e < (N - 1) * m; e += C::NT) {
         const int k = e / m, c = e % m, i = c % P;
         double* Rk = recs + (size_t)k * R::LEN;

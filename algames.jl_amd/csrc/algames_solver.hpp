@@ -209,32 +209,17 @@ __device__ __forceinline__ int inner_iteration(CPR pr0, Game& G_, Lds<C>& L, int
     { double sd = pl1; sd *= alpha; sd /= (double)((phase_int(pr.N) - 1) * (C::n + C::m)); Delta = uni(sd); }     // :95 Delta_step
     game_sync();
     if (reuse && !failed) *cache_valid = 1;
-    if constexpr (C::WPE != 4) {
-        // (256-register kernels: field by field, as until round 5 -- the batched form below costs the C3 team kernel two more SGPR spills)
-        if (lane0) {
-            const Game G = G_.fresh();
-            G.st(pr)->newton_iters += 1; if (failed) G.st(pr)->ls_failures += 1;
-            const int idx = G.st(pr)->records - 1;
-            if (idx < pr.hist_max) { G.hist(pr)[idx].alpha = alpha; G.hist(pr)[idx].ls_j = j; }
-            G.st(pr)->last.alpha = alpha; G.st(pr)->last.ls_j = j;
-            if (info) { info->alpha = alpha; info->ls_j = j; info->ls_failed = failed; info->delta = Delta; info->rec.alpha = alpha; info->rec.ls_j = j; }
-        }
-        return finish(ALG_STATUS_OK, Delta < o.delta_min ? 1 : 0);         // :96-98
-    }
     if (lane0) {
-        // end-of-iteration bookkeeping of lane 0: every load first (the counters, the record index, the clock stamp of iter_clock_start), then
-        // the stores -- read-modify-write one field after the other cost four global round trips per inner iteration, this costs one
+        // (measured in round 6: the loads of this block -- the counters, the record index, the clock stamp -- issued together, one round trip instead
+        // of four: neutral at C2, profiles/r06_ab_micro_c2.txt; not kept)
         const Game G = G_.fresh();
-        alg_game_stats* st = G.st(pr);
-        const int ni = st->newton_iters, nf = st->ls_failures, idx = st->records - 1;
-        const double tstart = G.tc(pr)[TC_TSTART];
-        st->newton_iters = ni + 1; if (failed) st->ls_failures = nf + 1;
+        G.st(pr)->newton_iters += 1; if (failed) G.st(pr)->ls_failures += 1;
+        const int idx = G.st(pr)->records - 1;
         if (idx < pr.hist_max) { G.hist(pr)[idx].alpha = alpha; G.hist(pr)[idx].ls_j = j; }
-        st->last.alpha = alpha; st->last.ls_j = j;
-        G.tc(pr)[TC_TELAP] = ((double)__builtin_amdgcn_s_memrealtime() - tstart) * 1e-8;        // iter_clock_stop (t_elap of this iteration)
-        if (info) { info->alpha = alpha; info->ls_j = j; info->ls_failed = failed; info->delta = Delta; info->rec.alpha = alpha; info->rec.ls_j = j; info->status = ALG_STATUS_OK; info->control_flow = Delta < o.delta_min ? 1 : 0; }
+        G.st(pr)->last.alpha = alpha; G.st(pr)->last.ls_j = j;
+        if (info) { info->alpha = alpha; info->ls_j = j; info->ls_failed = failed; info->delta = Delta; info->rec.alpha = alpha; info->rec.ls_j = j; }
     }
-    return ALG_STATUS_OK | ((Delta < o.delta_min ? 1 : 0) << 8);           // :96-98
+    return finish(ALG_STATUS_OK, Delta < o.delta_min ? 1 : 0);             // :96-98
 }
 
 // reset!(game_con) (constraints_methods.jl:295-327)

@@ -84,7 +84,9 @@ def kernel_resources(lib_path):
     names = list(out)
     if names:
         dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n")
-        out = {re.sub(r"^void |alg::|\(.*$", "", d): v for d, v in zip(dem, out.values())}
+        # (Cfg's sixth parameter -- line-search staging in LDS, default 1 -- is dropped from the names when it has its default, so that the names
+        # of rounds 1-5 stay what tests and profiles know: Cfg<model, p, d, ext, waves>)
+        out = {re.sub(r"(Cfg<\d+, \d+, \d+, \d+, \d+), 1>", r"\1>", re.sub(r"^void |alg::|\(.*$", "", d)): v for d, v in zip(dem, out.values())}
     return out
 
 
@@ -109,7 +111,9 @@ def scratch_load_counts(lib_path, only=None):
                 out[cur] += 1
     names = [n for n in out if n.startswith("_Z")]
     dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n") if names else []
-    res = {re.sub(r"^void |alg::|\(.*$", "", d): out[n] for d, n in zip(dem, names)}
+    # (Cfg's sixth parameter -- line-search staging in LDS, default 1 -- is dropped from the names when it has its default, so that the names of
+    # rounds 1-5 stay what tests and profiles know: Cfg<model, p, d, ext, waves>)
+    res = {re.sub(r"(Cfg<\d+, \d+, \d+, \d+, \d+), 1>", r"\1>", re.sub(r"^void |alg::|\(.*$", "", d)): out[n] for d, n in zip(dem, names)}
     return res if only is None else {k: v for k, v in res.items() if k in only}
 
 

@@ -146,9 +146,13 @@ __device__ __forceinline__ CPR phase_params(CPR pr) { return *(const ALG_AS4 Par
 // NW_ > 1: NW_ wavefronts work on one game (workgroup = NW_ x 64 threads; small batches that leave most SIMDs empty): the
 // streaming phases (assemble pass, trajectory updates, dual updates) are spread over all of them, the serial Newton-direction
 // sweeps run on wavefront 0.  NW_ = 1 is the one-game-per-wavefront kernel of the large batches.
-template <int MODEL_, int P_, int D_, int EXT_ = 0, int NW_ = 1>
+// LS_ = 0: a team kernel WITHOUT the line search's LDS staging (LsLds: 54 KB per team, two teams per CU).  The kernels that resume parked
+// games (straggler hand-off) take it: a second launch wants as many teams resident as the registers allow -- four per CU -- and its line
+// searches read their operands from L2 (same arithmetic, same results).
+template <int MODEL_, int P_, int D_, int EXT_ = 0, int NW_ = 1, int LS_ = 1>
 struct Cfg {
     static constexpr int MODEL = MODEL_, P = P_, D = D_;
+    static constexpr bool LS_STAGE = LS_ != 0;
     static constexpr int NW = NW_, NT = NW_ * 64;          // wavefronts / threads per game
     static constexpr bool EXT = EXT_ != 0;
     static constexpr bool POS = (P_ > 1) || EXT;     // position blocks (pair / wall / circle terms) present in Q^_i
@@ -894,7 +898,7 @@ struct AsmLds {
 // (team kernels of the base double integrator / unicycle: the line search stages [z | dz] of a search here, LsMulti in algames_assemble.hpp)
 template <class C> struct LsLds {
     // (kernels of up to three players: a 4-player unicycle trajectory, b = 88 doubles per step, outgrows the buffer from N = 19 on)
-    static constexpr bool ON = C::NW > 1 && C::P <= 3 && !AsmLds<C>::FUSED && !C::EXT && !C::DENSE && C::POS && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
+    static constexpr bool ON = C::LS_STAGE && C::NW > 1 && C::P <= 3 && !AsmLds<C>::FUSED && !C::EXT && !C::DENSE && C::POS && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
     static constexpr int CAP = LS_CAP;
     // teams of four run at most two per CU (team_width: B x 4 <= 2048): room for the group pass's per-step-size tables as well
     static constexpr bool SC_ON = ON && C::NW >= 4;

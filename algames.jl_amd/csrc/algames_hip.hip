@@ -384,7 +384,7 @@ int launch_newton_solve(Handle* h, int init, uint64_t game_id0) {
         HIPCHK(hipMemsetAsync(h->d_ho, 0, sizeof(int), h->stream));
 #define X(M, P, D, E, W) if (!done && pr.model == (M) && pr.p == (P) && pr.d == (D) && pr.ext == (E)) {                                \
         hipLaunchKernelGGL((k_newton_solve_ho<Cfg<M, P, D, E>>), dim3(pr.B), dim3(WAVE), 0, h->stream, h->pr, init, game_id0, h->handoff);  \
-        hipLaunchKernelGGL((k_newton_resume<Cfg<M, P, D, E, W>>), dim3(pr.B), dim3(WAVE * (W)), 0, h->stream, h->pr); done = true; }
+        hipLaunchKernelGGL((k_newton_resume<Cfg<M, P, D, E, W, 0>>), dim3(pr.B), dim3(WAVE * (W)), 0, h->stream, h->pr); done = true; }
         ALG_CFGS_HANDOFF(X)
 #undef X
         if (done) return launch_check("k_newton_solve_ho / k_newton_resume");

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(C::NT, C::WPE) k_newton_solve_ho(Params pr_arg
     newton_solve<C, 1>(pr, G, L, init, game_id0 + (uint64_t)g, -1, -1, budget);
 }
 template <class C>
-__global__ void __launch_bounds__(C::NT, C::WPE) k_newton_resume(Params pr_arg) {
+__global__ void __launch_bounds__(C::NT, C::WPE) k_newton_resume(Params pr_arg) {        // (C = Cfg<..., NW, 0>: no line-search staging in LDS)
     __shared__ Lds<C> L;
     CPR pr = kernel_params();
     const int* q = as_global(pr.ho_queue);
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_a
     X(ALG_MODEL_UNICYCLE, 3, 2, 0, 4)                        \
     X(ALG_MODEL_UNICYCLE, 4, 2, 0, 4)
 #define ALG_INSTANTIATE_HO_PARK(PREFIX, M, P, D, E, W) PREFIX __global__ void k_newton_solve_ho<Cfg<M, P, D, E>>(Params, int, uint64_t, int);
-#define ALG_INSTANTIATE_HO_RESUME(PREFIX, M, P, D, E, W) PREFIX __global__ void k_newton_resume<Cfg<M, P, D, E, W>>(Params);
+#define ALG_INSTANTIATE_HO_RESUME(PREFIX, M, P, D, E, W) PREFIX __global__ void k_newton_resume<Cfg<M, P, D, E, W, 0>>(Params);
 #define ALG_DEFINE_HO_RESUME(M, P, D, E, W) ALG_INSTANTIATE_HO_RESUME(template, M, P, D, E, W)
 #define ALG_DECLARE_HO(M, P, D, E, W) ALG_INSTANTIATE_HO_PARK(extern template, M, P, D, E, W) ALG_INSTANTIATE_HO_RESUME(extern template, M, P, D, E, W)
 #define ALG_DEFINE_MW(M, P, D, E, W) ALG_INSTANTIATE_MW(template, M, P, D, E, W)

@@ -11,7 +11,7 @@ DI, UNI, BIC = 0, 1, 2
 ARBITER_CONSULTED = []          # problems of this session whose trajectories needed the arbiter rule (reported by the last test of the file)
 
 
-def _random_pair(alg, orc, rng, ext, d3=False, force=None, force_d3=True, arb=None):
+def _random_pair(alg, orc, rng, ext, d3=False, force=None, force_d3=True, arb=None, d_override=None):
     model = DI if d3 else int(rng.choice([DI, UNI, BIC] if ext else [DI, UNI]))
     p = 2 if d3 else int(rng.integers(1, 5))
     N = int(rng.integers(2, 16))
@@ -22,6 +22,8 @@ def _random_pair(alg, orc, rng, ext, d3=False, force=None, force_d3=True, arb=No
     B = 3
     dt = float(rng.choice([0.05, 0.1, 0.2]))
     d = 3 if d3 else 2
+    if d_override is not None:
+        d = d_override
     g = alg.Batch(alg.hip_lib(), model, p, N, dt, B, d=d)
     o = orc.OracleBatch(model, p, N, dt, B, d=d)
     x = orc.OracleBatch(model, p, N, dt, B, d=d, kind=arb) if arb else None      # the arbiter: same algorithm, extended precision
@@ -194,6 +196,14 @@ def test_fuzz_five_and_six_players(alg, orc, seed):
     rng = np.random.default_rng(17000 + seed)
     model, p = P56_FAMILIES[seed % 6]
     g, o, x, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool(seed % 2)), force=(model, p), force_d3=False, arb="x")
+    _compare_solve(g, o, tag, x=x)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_double_integrator_d1(alg, orc, seed):
+    """DoubleIntegratorGame(p, d = 1), p = 1 .. 4 (round 6): base constraint set, random subsets of its ingredients."""
+    rng = np.random.default_rng(21000 + seed)
+    g, o, x, tag = _random_pair(alg, orc, rng, ext=False, force=(DI, 1 + seed % 4), force_d3=False, arb="x", d_override=1)
     _compare_solve(g, o, tag, x=x)
 
 

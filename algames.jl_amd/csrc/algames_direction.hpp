@@ -2086,6 +2086,7 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
     return ALG_STATUS_OK;
 #endif
     // the serial forward and costate sweeps (wavefront 0 of a team): direction_forward_costate below
+    ALG_PROF_FLUSH                                          // (profile builds: the backward sweep's phase sums; the sweeps below flush their own)
     return direction_forward_costate<C, IBR>(pr, G0, L, N, dt, lane, reg, ip, primal_l1);
 }
 

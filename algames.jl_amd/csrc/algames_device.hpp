@@ -822,25 +822,40 @@ struct DirLds<C, true> {
     static constexpr int LDP = C::n + 1;                 // row stride of [P_i | s_i] and of [F | f] (odd: conflict-free column reads)
     static constexpr int WC = C::m + C::n + 1;           // [W | V A_k | g]
     static constexpr int CFL = C::NC > 0 ? C::NC : 1;
+    static constexpr int RS_FULL = Rec<C>::LEN_SWEEP - C::NC;
+    static constexpr int SYS_V = C::m * C::n, SYS_Y = C::P * C::n, SYS_W = C::m * WC, SYS_PC = 2 * C::m;
+    static constexpr int TM = C::n * LDP, FX = (C::n + 1) * LDP;
+    // TIGHT (ten players: [P_i | s_i] alone are 131 KB of the CU's 160): the regular layout would need 171 KB.  Two things change:
+    // V, y and the pivot column live in rows 0 .. n-1 of Fx -- [F | f] is dead between the value recursion at the top of a step and the
+    // closed-loop build at its end, which reads the solved system only (row n, the constant e_n, is never touched) -- and the blocks of
+    // the step record that the Q-add reads exactly once ([RQ | rx]) are not staged: it takes them from the record in HBM / L2.
+    static constexpr bool TIGHT = 8L * (C::P * C::n * LDP + FX + (TM > SYS_V + SYS_Y + SYS_W + SYS_PC ? TM : SYS_V + SYS_Y + SYS_W + SYS_PC) + CFL + RS_FULL + 8) > 160L * 1024;
+    static_assert(!TIGHT || SYS_V + SYS_Y + SYS_PC <= TM, "TIGHT layout: V, y and the pivot column share rows 0 .. n-1 of Fx");
+    // record offsets [SKIP0, SKIP1) are not staged (TIGHT: [RQ | rx]); offsets below address rs - NC, offsets above rs - NC - (SKIP1 - SKIP0)
+    static constexpr int SKIP0 = TIGHT ? Rec<C>::RQ : Rec<C>::LEN_SWEEP, SKIP1 = TIGHT ? Rec<C>::RHAT : Rec<C>::LEN_SWEEP;
+    static constexpr int RS_LEN = RS_FULL - (SKIP1 - SKIP0);
     struct Bwd {
         double Pm[C::P * C::n * LDP];                    // [P_i | s_i], row-major
-        double Fx[(C::n + 1) * LDP];                     // [[F f],[0 1]]
+        double Fx[FX];                                   // [[F f],[0 1]]
         struct Sys {
-            double V[C::m * C::n];                       // V[c][:] = B[:,c]' P_i(c)
-            double y[C::P * C::n];                       // y_i = P_i rd + s_i
-            double Wm[C::m * WC];                        // augmented control system, row-major
-            double pcol[2][C::m];                        // pivot column of the Gauss-Jordan (double-buffered)
+            double V[TIGHT ? 1 : SYS_V];                 // V[c][:] = B[:,c]' P_i(c)
+            double y[TIGHT ? 1 : SYS_Y];                 // y_i = P_i rd + s_i
+            double Wm[SYS_W];                            // augmented control system, row-major
+            double pcol[TIGHT ? 1 : SYS_PC];             // pivot column of the Gauss-Jordan (double-buffered)
         };
         union {                                          // the value recursion's product and the control system are never live together
-            double Tm[C::n * LDP];                       // [P_i F | P_i f + s_i] of the player being advanced
+            double Tm[TM];                               // [P_i F | P_i f + s_i] of the player being advanced
             Sys sv;
         };
         // one step record: during the value recursion of step k the coefficient block still is step k + 1's (A_{k+1}'), then step
         // k's record is landed from the registers that prefetched it
         double cf[CFL];                                  // Jacobian coefficient block
-        double rs[Rec<C>::LEN_SWEEP - C::NC];            // the record behind it ([Hh | Hd | RQ | rx | R^ | ru | rd])
+        double rs[RS_LEN];                               // the record behind it ([Hh | Hd | RQ | rx | R^ | ru | rd]; TIGHT: [Hh | Hd | R^ | ru | rd])
+        __device__ __forceinline__ double* V() { return TIGHT ? Fx : sv.V; }
+        __device__ __forceinline__ double* y() { return TIGHT ? Fx + SYS_V : sv.y; }
+        __device__ __forceinline__ double* pcol(int which) { return (TIGHT ? Fx + SYS_V + SYS_Y : sv.pcol) + which * C::m; }
     };
-    struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n], cf[2][CFL], rs[2][Rec<C>::LEN_SWEEP - C::NC], dxb[2][C::n]; };
+    struct Fwd { double dx[C::n], du[C::m], dl[2][C::P * C::n], cf[2][CFL], rs[2][RS_FULL], dxb[2][C::n]; };
     union { Bwd bw; Fwd fw; };
     double red[8];
 };

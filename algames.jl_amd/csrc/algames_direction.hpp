@@ -632,6 +632,8 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     constexpr int BT = C::NT, NWV = BT / WAVE;
     constexpr int FU = 2;                                     // entries per thread and trip of the flat loops
     constexpr int TR = (n + 15) / 16, TC = (n + 1 + 15) / 16, KBN = (n + 1 + 3) / 4;
+    constexpr bool TIGHT = DirLds<C>::TIGHT;                  // ten players: see DirLds<C, true>
+    constexpr int SKIP0 = DirLds<C>::SKIP0, SKIP1 = DirLds<C>::SKIP1;
     static_assert(NWV <= 4, "cross-wavefront reduction slots");
     static_assert(C::NW == 1 || C::NW >= 4, "every wavefront of the team runs this function (inner_iteration sends teams of two through wavefront 0 only)");
     using R = Rec<C>;
@@ -664,12 +666,14 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             for (int q = 0; q < RPT; q++) {
                 const int e = tid + q * BT;
                 if (e < C::NC) B.cf[e] = pre[q];
-                else if (e < R::LEN_SWEEP) B.rs[e - C::NC] = pre[q];
+                else if (e < SKIP0) B.rs[e - C::NC] = pre[q];
+                else if (e >= SKIP1 && e < R::LEN_SWEEP) B.rs[e - C::NC - (SKIP1 - SKIP0)] = pre[q];
             }
         } else {
             const double* Rk = recs + (size_t)kk * R::LEN;
             for (int e = tid; e < C::NC; e += BT) B.cf[e] = Rk[e];
-            for (int e = tid; e < R::LEN_SWEEP - C::NC; e += BT) B.rs[e] = Rk[C::NC + e];
+            for (int e = tid; e < SKIP0 - C::NC; e += BT) B.rs[e] = Rk[C::NC + e];
+            for (int e = tid; e < R::LEN_SWEEP - SKIP1; e += BT) B.rs[SKIP0 - C::NC + e] = Rk[SKIP1 + e];
         }
     };
     rec_load(N - 2);
@@ -677,7 +681,9 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
     ALG_PROF_DECL
     // ------------------------------------------------------------------ backward sweep
     for (int k = N - 2; k >= 0; k--) {
-        const double* Rl = B.rs - C::NC;                                     // record offsets >= NC address the staged copy
+        const double* Rl = B.rs - C::NC;                                     // record offsets >= NC address the staged copy ...
+        const double* Rt = B.rs - C::NC - (SKIP1 - SKIP0);                   // ... [R^ | ru | rd] behind the blocks a TIGHT layout does not stage
+        const double* Rq = TIGHT ? recs + (size_t)k * R::LEN : Rl;           // [RQ | rx]: read once, by the Q-add
         const double* coefk = B.cf;                                        // step k's block -- after the landing point below
         const double* coefn = B.cf;                                        // A_{k+1}: what the buffer holds during the value recursion
         const double w = (k + 1 < N - 1) ? dt : 1.0;
@@ -750,9 +756,9 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             if (IBR && i != ip) continue;
             double* row = &B.Pm[i * n * LDP + r * LDP];
             double qd = reg + ((r % P == i) ? w * Qd[i * C::ni + r / P] : 0.0);
-            if constexpr (C::EXT) qd += Rl[R::RQ + e];
+            if constexpr (C::EXT) qd += Rq[R::RQ + e];
             row[r] += qd;
-            row[n] += Rl[R::RX + e];
+            row[n] += Rq[R::RX + e];
             if (C::POS && r < C::PD * P) {
                 for (int c = 0; c < C::PD * P; c++) row[c] += pairblock<C>(Rl + R::HH, i, r, c);
             }
@@ -763,13 +769,13 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         flat_loop<FU>(tid, BT, m * n, [&](int e) {
             const int c = e / n, col = e % n; const double* Pi = &B.Pm[(c % P) * n * LDP];
             return BT_vec<C>(coefk, dt, [&](int rr) { return Pi[rr * LDP + col]; }, c);
-        }, [&](int e, double v) { B.sv.V[e] = v; });
+        }, [&](int e, double v) { B.V()[e] = v; });
         flat_loop<FU>(tid, BT, P * n, [&](int e) {
             const double* Pr = &B.Pm[e * LDP];
             double a = Pr[n];
-            for (int c = 0; c < n; c++) a += Pr[c] * Rl[R::RD + c];
+            for (int c = 0; c < n; c++) a += Pr[c] * Rt[R::RD + c];
             return a;
-        }, [&](int e, double v) { B.sv.y[e] = v; });
+        }, [&](int e, double v) { B.y()[e] = v; });
         game_sync();
         ALG_PROF(3)
         // ---- [ W | V A_k | g ],  W = diag(R^) + V B,  g_c = ru_c + B[:,c]' y_i(c): three uniform loops (no divergent entry kinds)
@@ -781,16 +787,16 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             return v;
         };
         flat_loop<FU>(tid, BT, m * m, [&](int e) {
-            const int c = e / m, t = e % m; const double* Vc = &B.sv.V[c * n];
-            return ibr_mask(c, t, BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rl[R::RHAT + c] : 0.0));
+            const int c = e / m, t = e % m; const double* Vc = &B.V()[c * n];
+            return ibr_mask(c, t, BT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, t) + (t == c ? Rt[R::RHAT + c] : 0.0));
         }, [&](int e, double v) { B.sv.Wm[(e / m) * WC + e % m] = v; });
         flat_loop<FU>(tid, BT, m * n, [&](int e) {
-            const int c = e / n, col = e % n; const double* Vc = &B.sv.V[c * n];
+            const int c = e / n, col = e % n; const double* Vc = &B.V()[c * n];
             return ibr_mask(c, m + col, (k >= 1) ? AT_vec<C>(coefk, dt, [&](int rr) { return Vc[rr]; }, col) : 0.0);    // dx_1 = 0: A_0 never acts
         }, [&](int e, double v) { B.sv.Wm[(e / n) * WC + m + e % n] = v; });
         flat_loop<1>(tid, BT, m, [&](int c) {
-            const double* yi = &B.sv.y[(c % P) * n];
-            return ibr_mask(c, m + n, Rl[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c));
+            const double* yi = &B.y()[(c % P) * n];
+            return ibr_mask(c, m + n, Rt[R::RU + c] + BT_vec<C>(coefk, dt, [&](int rr) { return yi[rr]; }, c));
         }, [&](int c, double v) { B.sv.Wm[c * WC + m + n] = v; });
         game_sync();
         ALG_PROF(4)
@@ -838,12 +844,12 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
             for (int c = 0; c < m; c++) {
                 if (tid == c) {
 #pragma unroll
-                    for (int r = 0; r < m; r++) B.sv.pcol[c & 1][r] = col[0][r];
+                    for (int r = 0; r < m; r++) B.pcol(c & 1)[r] = col[0][r];
                 }
                 game_sync();
                 double pc[m];
 #pragma unroll
-                for (int r = 0; r < m; r++) pc[r] = B.sv.pcol[c & 1][r];
+                for (int r = 0; r < m; r++) pc[r] = B.pcol(c & 1)[r];
                 double best = fabs(pc[c]); int piv = c;
 #pragma unroll
                 for (int r = c + 1; r < m; r++) { const double v = fabs(pc[r]); if (v > best) { best = v; piv = r; } }
@@ -884,7 +890,7 @@ __device__ int newton_direction_dense(CPR pr0, const Game& G0, DirLds<C>& L, dou
         if (k > 0) {
             flat_loop<FU>(tid, BT, n * LDP, [&](int e) {
                 const int r = e / LDP, col = e % LDP;
-                const double base = col < n ? A_entry<C>(coefk, dt, r, col) : Rl[R::RD + r];
+                const double base = col < n ? A_entry<C>(coefk, dt, r, col) : Rt[R::RD + r];
                 return base + B_vec<C>(coefk, dt, [&](int c2) { return -B.sv.Wm[c2 * WC + m + col]; }, r);
             }, [&](int e, double v) { B.Fx[e] = v; });
         }

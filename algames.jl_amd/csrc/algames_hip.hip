@@ -200,88 +200,24 @@ int launch_check(const char* what) {
 
 #define H ((Handle*)h)
 #define LAUNCH(kernel, ...) LAUNCH_GRID(H->pr.B, kernel, __VA_ARGS__)
+// (the cases are generated from the instantiation lists of algames_kernels.hpp -- the lists cfg_supported() consults -- so a configuration that
+// alg_create accepts always has its launch case)
 #define LAUNCH_GRID(nblocks, kernel, ...)                                                       \
     do {                                                                                        \
         const Params& pr_ = H->pr;                                                              \
         const int grid_ = (nblocks);                                                            \
         bool done_ = false;                                                                     \
-        LAUNCH_CASES_(kernel, __VA_ARGS__)                                                      \
+        auto launch_ = [&](auto cfg_) {                                                         \
+            hipLaunchKernelGGL((kernel<decltype(cfg_)>), dim3(grid_), dim3(WAVE), 0, H->stream, __VA_ARGS__); \
+            done_ = true;                                                                       \
+        };                                                                                      \
+        ALG_CFGS_BASE(LAUNCH_CASE_) ALG_CFGS_EXT(LAUNCH_CASE_) ALG_CFGS_DENSE(LAUNCH_CASE_) ALG_CFGS_DI1(LAUNCH_CASE_) \
         if (!done_) return fail(ALG_ERR_ARG, "unsupported (model, p, d) configuration");        \
         int rc_ = launch_check(#kernel);                                                        \
         if (rc_ != ALG_OK) return rc_;                                                          \
     } while (0)
-
-#define LAUNCH_ONE_(M, P, D, E, kernel, ...)                                                    \
-    if (!done_ && pr_.model == (M) && pr_.p == (P) && pr_.d == (D) && pr_.ext == (E)) {         \
-        hipLaunchKernelGGL((kernel<Cfg<M, P, D, E>>), dim3(grid_), dim3(WAVE), 0, H->stream, __VA_ARGS__); \
-        done_ = true;                                                                           \
-    }
-#define LAUNCH_CASES_(kernel, ...)                                                  \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 1, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 2, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 3, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 4, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 3, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 1, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 2, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 3, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 4, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 1, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 2, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 3, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 4, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 1, 3, 0, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 2, 3, 0, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 3, 3, 0, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 4, 3, 0, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 1, 3, 1, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 2, 3, 1, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 3, 3, 1, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_QUADROTOR, 4, 3, 1, kernel, __VA_ARGS__)                  \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 3, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 3, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 3, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 5, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 6, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 5, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 6, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 5, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 6, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 5, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 6, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 5, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 6, 2, 1, kernel, __VA_ARGS__)                    \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 7, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 7, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 7, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 7, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 7, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 8, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 8, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 8, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 8, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 8, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 9, 2, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 9, 2, 1, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 9, 2, 0, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_UNICYCLE, 9, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_BICYCLE, 9, 2, 1, kernel, __VA_ARGS__)                   \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 1, 1, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 2, 1, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 3, 1, 0, kernel, __VA_ARGS__)          \
-    LAUNCH_ONE_(ALG_MODEL_DOUBLE_INTEGRATOR, 4, 1, 0, kernel, __VA_ARGS__)
+#define LAUNCH_CASE_(M, P, D, E)                                                                \
+    if (!done_ && pr_.model == (M) && pr_.p == (P) && pr_.d == (D) && pr_.ext == (E)) launch_(Cfg<M, P, D, E>{});
 
 void dfree(Handle* h, void* q) {
     for (size_t i = 0; i < h->allocs.size(); i++)
@@ -501,7 +437,7 @@ int alg_create(const alg_desc* d, alg_handle** out) {
     if (!d || !out) return fail(ALG_ERR_ARG, "alg_create: null argument");
     Handle* hd = new Handle();
     if (!fill_dims(*d, hd->pr) || d->batch < 1) { delete hd; return fail(ALG_ERR_ARG, "alg_create: unsupported descriptor"); }
-    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=1 p<=4, d=2 p<=9, d=3 p<=4; Unicycle p<=9; Bicycle p<=9; Quadrotor p<=4; ten players -- the reference's cap -- exceed one CU's LDS)"); }
+    if (!cfg_supported(hd->pr, hd->pr.ext)) { delete hd; return fail(ALG_ERR_ARG, "alg_create: (model, p, d) has no compiled kernel instantiation (supported: DoubleIntegrator d=1 p<=4, d=2 p<=10, d=3 p<=4; Unicycle p<=10; Bicycle p<=10; Quadrotor p<=4)"); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete hd; return fail(ALG_ERR_DEVICE, "alg_create: no HIP device available (this library has no CPU fallback)"); }
     if (d->device < 0 || d->device >= ndev) { delete hd; return fail(ALG_ERR_ARG, "alg_create: bad device ordinal"); }
@@ -705,7 +641,7 @@ static int ext_commit(Handle* hd) {
     int rc = use_device(hd); if (rc) return rc;
     if ((rc = sync(hd))) return rc;
     Params& p = hd->pr;
-    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 / Unicycle / Bicycle p<=9, DoubleIntegrator d=3 / Quadrotor p<=4)");
+    if (!cfg_supported(p, 1)) return fail(ALG_ERR_ARG, "extended constraints: (model, p, d) has no compiled EXT kernel instantiation (DoubleIntegrator d=2 / Unicycle / Bicycle p<=10, DoubleIntegrator d=3 / Quadrotor p<=4)");
     p.ext = 1;
     recount_con(p);
     dfree(hd, p.con); p.con = nullptr;

@@ -302,8 +302,8 @@ __global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_a
     X(ALG_MODEL_BICYCLE, 6, 2, 1)
 #define ALG_CFGS_P56(X) ALG_CFGS_P5(X) ALG_CFGS_P6(X)
 // Seven to nine players (round 6; n = 28 ... 36, m = 14 ... 18: the dense direction with the value matrices of all players LDS-resident --
-// 65 / 93 / 128 KB of the CU's 160, one game per CU; algames_p7.hip ... algames_p9.hip).  Ten players (the reference's cap, options.jl:68)
-// would need 171 KB: not instantiated.
+// 65 / 93 / 128 KB of the CU's 160, one game per CU; algames_p7.hip ... algames_p9.hip).  Ten players (the reference's cap, options.jl:68;
+// algames_p10.hip): 131 KB of value matrices, the step's workspace in the TIGHT layout of DirLds<C, true> -- 161 KB.
 #define ALG_CFGS_PN(X, N)                                   \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, N, 2, 0)                  \
     X(ALG_MODEL_DOUBLE_INTEGRATOR, N, 2, 1)                  \
@@ -313,7 +313,8 @@ __global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_a
 #define ALG_CFGS_P7(X) ALG_CFGS_PN(X, 7)
 #define ALG_CFGS_P8(X) ALG_CFGS_PN(X, 8)
 #define ALG_CFGS_P9(X) ALG_CFGS_PN(X, 9)
-#define ALG_CFGS_P789(X) ALG_CFGS_P7(X) ALG_CFGS_P8(X) ALG_CFGS_P9(X)
+#define ALG_CFGS_P10(X) ALG_CFGS_PN(X, 10)
+#define ALG_CFGS_P789(X) ALG_CFGS_P7(X) ALG_CFGS_P8(X) ALG_CFGS_P9(X) ALG_CFGS_P10(X)
 #define ALG_CFGS_DENSE(X) ALG_CFGS_QUAD(X) ALG_CFGS_QUAD_EXT(X) ALG_CFGS_DI3D(X) ALG_CFGS_P56(X) ALG_CFGS_P789(X)
 #define ALG_CFGS_EXT(X) ALG_CFGS_EXT_DI(X) ALG_CFGS_EXT_UNI(X) ALG_CFGS_EXT_BIC(X) ALG_CFGS_EXT_DI3(X)
 

@@ -175,11 +175,17 @@ P56_FAMILIES = [(DI, 5), (DI, 6), (UNI, 5), (UNI, 6), (BIC, 5), (BIC, 6)]
 # random many-player problems (thirty ordered pairs inside the collision-cost radius, control costs down to 1e-4) diverge; the oracle
 # ITSELF amplifies a 1e-13 relative change of x0 to 1e-3 .. 1e-7 in exactly the games that differ (tests/probes/fuzz_sensitivity.py) and
 # by ~1 on ordinary seeds.
-@pytest.mark.parametrize("seed", [500258, 500262, 500365])
+# (round 6: 900022 is the one case of 25 of the ten-player family of tests/probes/fuzz_long_r6.py outside the rule -- Unicycle, extended set, iterates
+# up to 1.2e3, four failed line searches: at record 8 the three programs' residual norms already differ in the sixth digit, at record 9 the
+# HIP path takes the arbiter's step size (j = 8) and the oracle j = 7; profiles/r06_p10_seed_900022.txt)
+@pytest.mark.parametrize("seed", [500258, 500262, 500365, 900022])
 def test_fuzz_five_and_six_players_hard_seeds_agree_where_arithmetic_decides(alg, orc, seed):
     rng = np.random.default_rng(seed)
-    model, p = P56_FAMILIES[(seed - 500000) % 6]
-    g, o, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool((seed - 500000) % 2)), force=(model, p), force_d3=False)
+    if seed >= 900000:
+        model, p, extd = (DI, UNI, BIC)[(seed - 900000) % 3], 10, bool(((seed - 900000) // 3) % 2)
+    else:
+        (model, p), extd = P56_FAMILIES[(seed - 500000) % 6], bool((seed - 500000) % 2)
+    g, o, tag = _random_pair(alg, orc, rng, ext=(model == BIC or extd), force=(model, p), force_d3=False)
     sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
     assert np.array_equal(sg["status"], so["status"]), tag
     for game in range(g.B):
@@ -216,6 +222,15 @@ def test_fuzz_seven_to_nine_players(alg, orc, seed):
     rng = np.random.default_rng(19000 + seed)
     model, p = P789_FAMILIES[seed % 9]
     g, o, x, tag = _random_pair(alg, orc, rng, ext=(model == BIC or bool(seed % 2)), force=(model, p), force_d3=False, arb="x")
+    _compare_solve(g, o, tag, x=x)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_ten_players(alg, orc, seed):
+    """Ten players, the reference's cap (options.jl:68): DoubleIntegrator d = 2, Unicycle, Bicycle; the dense direction in its TIGHT LDS layout."""
+    rng = np.random.default_rng(23000 + seed)
+    model = (DI, UNI, BIC)[seed % 3]
+    g, o, x, tag = _random_pair(alg, orc, rng, ext=(model == BIC or seed >= 3), force=(model, 10), force_d3=False, arb="x")
     _compare_solve(g, o, tag, x=x)
 
 
@@ -355,7 +370,7 @@ def _arbitrate(g, o, x, tag, bound=True):
 
 
 def test_arbiter_on_the_hard_seeds(alg, orc):
-    """All committed hard seeds of the tile-path families (16), the dense families (6) and five / six players (3)."""
+    """All committed hard seeds of the tile-path families (16), the dense families (6), five / six players (3) and ten players (1)."""
     hip_right = orc_right = 0
     for seed in HARD_SEEDS:
         g, o, x, tag = _random_pair(alg, orc, np.random.default_rng(seed), ext=True, arb="x")
@@ -368,9 +383,13 @@ def test_arbiter_on_the_hard_seeds(alg, orc):
         model, p = P56_FAMILIES[(seed - 500000) % 6]
         g, o, x, tag = _random_pair(alg, orc, np.random.default_rng(seed), ext=(model == BIC or bool((seed - 500000) % 2)), force=(model, p), force_d3=False, arb="x")
         a, b = _arbitrate(g, o, x, tag); hip_right += a; orc_right += b
+    for seed in [900022]:                                               # ten players (round 6)
+        model = (DI, UNI, BIC)[(seed - 900000) % 3]
+        g, o, x, tag = _random_pair(alg, orc, np.random.default_rng(seed), ext=(model == BIC or bool(((seed - 900000) // 3) % 2)), force=(model, 10), force_d3=False, arb="x")
+        a, b = _arbitrate(g, o, x, tag); hip_right += a; orc_right += b
     print("decision splits: HIP with the arbiter", hip_right, "oracle with the arbiter", orc_right)
     # (measured: 0 : 2 without the refinement gate, 0 : 3 with it at any tolerance -- single decisions of diverging problems; three of
-    # the 25 seeds split at all)
+    # the 25 seeds split at all; round 6: 1 : 3 with the ten-player seed, where the HIP path takes the arbiter's step)
     assert hip_right + 3 >= orc_right, (hip_right, orc_right)
 
 

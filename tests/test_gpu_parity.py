@@ -19,8 +19,8 @@ CASES = [  # (model, p, d, N)
     (DI, 5, 2, 6), (DI, 6, 2, 5), (UNI, 5, 2, 6), (UNI, 6, 2, 5), (DI, 1, 3, 7), (DI, 3, 3, 6), (DI, 4, 3, 5),
     # DoubleIntegratorGame(p, d = 1) (double_integrator.jl:13-25; round 6): p = 2, 4 on the tile path, p = 1, 3 on the dense direction
     (DI, 1, 1, 7), (DI, 2, 1, 9), (DI, 3, 1, 6), (DI, 4, 1, 8),
-    # seven to nine players (round 6; the reference's options cap p at 10, options.jl:68): dense direction, value matrices of all players in LDS
-    (DI, 7, 2, 5), (UNI, 7, 2, 4), (DI, 8, 2, 4), (UNI, 8, 2, 5), (DI, 9, 2, 4), (UNI, 9, 2, 4),
+    # seven to ten players (round 6; the reference's options cap p at 10, options.jl:68): dense direction, value matrices of all players in LDS
+    (DI, 7, 2, 5), (UNI, 7, 2, 4), (DI, 8, 2, 4), (UNI, 8, 2, 5), (DI, 9, 2, 4), (UNI, 9, 2, 4), (DI, 10, 2, 5), (UNI, 10, 2, 4),
 ]
 
 

@@ -12,8 +12,8 @@ CASES = [  # (model, p, N)
     (BIC, 1, 8), (BIC, 2, 12), (BIC, 3, 10), (BIC, 4, 6),
     # five and six players (n = 20 / 24: dense Newton direction, algames_p5.hip / algames_p6.hip)
     (DI, 5, 5), (DI, 6, 4), (UNI, 5, 5), (UNI, 6, 4), (BIC, 5, 5), (BIC, 6, 4),
-    # seven to nine players (round 6: algames_p7.hip ... algames_p9.hip)
-    (DI, 7, 4), (UNI, 8, 4), (BIC, 9, 4), (BIC, 7, 5), (DI, 9, 3), (UNI, 9, 4),
+    # seven to ten players (round 6: algames_p7.hip ... algames_p10.hip; ten = the reference's cap, TIGHT LDS layout of the dense direction)
+    (DI, 7, 4), (UNI, 8, 4), (BIC, 9, 4), (BIC, 7, 5), (DI, 9, 3), (UNI, 9, 4), (DI, 10, 4), (UNI, 10, 3), (BIC, 10, 4),
 ]
 ALL = ("cost", "avoid", "ctl", "sb", "wall", "circ")
 
@@ -226,7 +226,9 @@ def test_reference_constrained_unicycle_with_circles_on_gpu(alg):
 
 def test_extended_constraints_unsupported_configuration_fails_loudly(alg):
     with pytest.raises(alg.AlgamesError):
-        alg.Batch(alg.hip_lib(), DI, 10, 6, 0.1, 1, d=2)        # ten players (the reference's cap, options.jl:68): no kernel instantiation -- their value matrices exceed one CU's LDS
+        alg.Batch(alg.hip_lib(), DI, 11, 6, 0.1, 1, d=2)        # eleven players: beyond the reference's cap (options.jl:68)
+    with pytest.raises(alg.AlgamesError):
+        alg.Batch(alg.hip_lib(), DI, 5, 6, 0.1, 1, d=3)         # DoubleIntegrator d = 3 with five players (n = 30): no kernel instantiation
     b = alg.Batch(alg.hip_lib(), DI, 2, 6, 0.1, 1, d=1)         # DoubleIntegrator d = 1: base constraint set only
     with pytest.raises(alg.AlgamesError):
         b.add_state_bound(0, np.ones(b.n), -np.ones(b.n))
@@ -247,8 +249,8 @@ ALL_INSTANTIATIONS = ([(DI, p, N, False) for p, N in ((1, 5), (2, 13), (3, 40), 
                       + [(DI, 5, 7, False), (DI, 6, 5, True), (UNI, 5, 6, True), (UNI, 6, 5, False), (BIC, 5, 6, True), (BIC, 6, 5, True)]
                       # (round 5: the other four five- / six-player instantiations, so that every kernel of ALG_CFGS_P56 is reached by a test)
                       + [(DI, 5, 5, True), (DI, 6, 6, False), (UNI, 5, 5, False), (UNI, 6, 4, True)]
-                      # (round 6: seven to nine players, every instantiation of ALG_CFGS_P789)
-                      + [(m_, p_, 4, e_) for p_ in (7, 8, 9) for m_, e_ in ((DI, False), (DI, True), (UNI, False), (UNI, True), (BIC, True))])
+                      # (round 6: seven to ten players, every instantiation of ALG_CFGS_P789)
+                      + [(m_, p_, 4, e_) for p_ in (7, 8, 9, 10) for m_, e_ in ((DI, False), (DI, True), (UNI, False), (UNI, True), (BIC, True))])
 
 
 @pytest.mark.timeout(120)

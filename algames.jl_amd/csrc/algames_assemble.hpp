@@ -844,13 +844,18 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
 // Phase A's per-step-size output -- Jacobian coefficients and pair-gradient tables -- goes to the gain scratch (dead outside the direction).
 //   base constraint set of the double integrator / unicycle only (collision cost, collision avoidance, control bounds)
 // ================================================================================================
+#ifndef ALG_LSM_DI1W
+#define ALG_LSM_DI1W 0        // 1: the group pass on the one-wavefront double-integrator kernels as well.  Measured in round 6 and not
+                              // taken: bit-identical, 126 VGPRs, but neutral to -1 % on perturbed C2 / C4 batches with and without the hand-off -- their
+                              // stragglers take many iterations, not deep searches (profiles/r06_ab_lsm_di1w_*.txt)
+#endif
 template <class C> struct LsMulti {
     // team kernels (whose ordinary trial pass is assemble_pass: all rows of a kind in one flat loop) and the one-wavefront unicycle kernels (fused
     // trial pass: the rows chunk by chunk -- the group pass deals and sums its rows in the same order, CHUNK steps at a time).  Norms bit-identical
     // in both cases.  (On the one-wavefront kernels they first came out an ulp apart in one of ten candidates: BT_vec's `a b + c d` had been
     // contracted one way in the fused pass and the other way here; BT_vec now states its fmas.)
     static constexpr bool TEAMS = C::NW > 1 && !AsmLds<C>::FUSED && (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR || C::MODEL == ALG_MODEL_UNICYCLE);
-    static constexpr bool ONEW = C::NW == 1 && AsmLds<C>::FUSED && C::MODEL == ALG_MODEL_UNICYCLE;
+    static constexpr bool ONEW = C::NW == 1 && AsmLds<C>::FUSED && (C::MODEL == ALG_MODEL_UNICYCLE || ALG_LSM_DI1W);
     static constexpr bool ON = (TEAMS || ONEW) && !C::EXT && !C::DENSE && C::POS;
     static constexpr int CHUNK = ONEW ? AsmLds<C>::FT : (1 << 20);
     static constexpr int NA = LS_NA;                          // step sizes per pass

@@ -478,14 +478,12 @@ __device__ __forceinline__ void model_player(CPR pr, int i, const double* x, con
     }
 }
 // RK3 step of player i (rollout!, solver_methods.jl:17; RobotDynamics 0.3.1 RK3)
+// (the player's own entries as compact arrays xi[ni], ui[mi]: the roll-out keeps its state in this form -- a joint array indexed by the lane's
+// player number is a register array with a run-time index, i.e. a select chain over n compare masks per access)
 template <class C>
-__device__ __forceinline__ void model_player_rk3(CPR pr, int i, const double* x, const double* u, double dt, double* xn) {
+__device__ __forceinline__ void model_player_rk3_own(CPR pr, const double (&xi)[C::ni], const double (&ui)[C::mi], double dt, double* xn) {
     static_assert(!C::QUAD, "the quadrotor integrates through quad_rk3 (rollout)");
-    double xi[C::ni], k1[C::ni], k2[C::ni], k3[C::ni], t[C::ni], ui[C::mi];
-#pragma unroll
-    for (int j = 0; j < C::ni; j++) xi[j] = x[i + j * C::P];
-#pragma unroll
-    for (int j = 0; j < C::mi; j++) ui[j] = u[i + j * C::P];
+    double k1[C::ni], k2[C::ni], k3[C::ni], t[C::ni];
     auto f = [&](const double* s, double* o) {
         if constexpr (C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR) {
 #pragma unroll
@@ -508,6 +506,15 @@ __device__ __forceinline__ void model_player_rk3(CPR pr, int i, const double* x,
     f(t, k3);
 #pragma unroll
     for (int j = 0; j < C::ni; j++) { k3[j] *= dt; xn[j] = xi[j] + (k1[j] + 4 * k2[j] + k3[j]) / 6; }
+}
+template <class C>
+__device__ __forceinline__ void model_player_rk3(CPR pr, int i, const double* x, const double* u, double dt, double* xn) {
+    double xi[C::ni], ui[C::mi];
+#pragma unroll
+    for (int j = 0; j < C::ni; j++) xi[j] = x[i + j * C::P];
+#pragma unroll
+    for (int j = 0; j < C::mi; j++) ui[j] = u[i + j * C::P];
+    model_player_rk3_own<C>(pr, xi, ui, dt, xn);
 }
 
 // (A^T v)[r] for a vector accessor v(r'): A = I + E.  Branch-free: every lane issues the same loads (clamped indices) and

@@ -198,6 +198,14 @@ __global__ void __launch_bounds__(WAVE) k_mpc_advance(Params pr_arg) {
 // kernel for every instantiation).
 // (the loop's own arguments are re-read from the kernel-argument segment where they are used, like `Params`: as by-value arguments they
 // were live -- in SGPRs, i.e. spilled -- across every phase of every solve)
+// The loop kernels of the teams of four (BASELINE C5 runs k_mpc_loop<Cfg<UNICYCLE, 3, 2, 0, 4>>) also run the solve's set-up on laundered views
+// (newton_solve<C, 0, LOOP = true>): 20 -> 13 SGPR spills in that kernel.  Only there: the solver-level functions are left to the inliner, and a loop
+// kernel that instantiates another newton_solve than the configuration's solve kernel changes the inliner's decisions for BOTH kernels of the
+// configuration -- with the switch on everywhere the C3 solve kernel (team of two) went from 8 to 10 spills (round 6, measured per combination).
+#ifndef ALG_LOOP_LAUNDER
+#define ALG_LOOP_LAUNDER 1
+#endif
+template <class C> inline constexpr bool mpc_loop_launder_v = ALG_LOOP_LAUNDER != 0 && C::NW == 4;
 struct MpcLoopArgs { Params pr; int steps; uint64_t game_id0; double* states; };
 // (the 4-player bicycle with the extended constraint set -- 8 controls x 17 right-hand sides in registers -- sits at the 256-register
 // ceiling with the loop's own state on top: it takes the one-wavefront-per-SIMD budget, where the allocator parks the overflow in the
@@ -214,19 +222,27 @@ __global__ void __launch_bounds__(C::NT, mpc_loop_wpe<C>) k_mpc_loop(Params pr_a
 #endif
     const int g = blockIdx.x;
     Game G = game_view(pr, g);
-    if (ka.states && (int)threadIdx.x < C::n) ka.states[(size_t)g * C::n + threadIdx.x] = G.x0(pr)[threadIdx.x];
-    for (int t = 0; t < ka.steps; t++) {
+    // (the loop's arguments are read through a laundered copy of the segment pointer wherever they are used -- `kq()` -- so that no load is shared
+    // between the prologue, the loop test and the loop body: a shared load is a value live, i.e. spilled, across every phase of every solve)
+    auto kq = [&]() -> const ALG_AS4 MpcLoopArgs& { return *(const ALG_AS4 MpcLoopArgs*)uniform_u64((unsigned long long)&ka); };
+    {
+        double* const st0 = kq().states; const int l0 = phase_lane();
+        if (st0 && l0 < C::n) { const Game H = G.fresh(); CPR pr0 = phase_params(pr); st0[(size_t)phase_int(g) * C::n + l0] = H.x0(pr0)[l0]; }
+    }
+    if (kq().steps < 1) return;
+    for (int t = 0; ; t++) {
         // (everything the step needs besides `t` is re-derived from opaque roots inside the loop -- the game's index, the lane's predicates, the
         // arguments: as invariants of this loop they were live, i.e. spilled, across every phase of every solve)
         const int gq = phase_int(g);
-        newton_solve<C>(pr, G, L, 1, ka.game_id0 + (uint64_t)t * 1000003ull + (uint64_t)gq, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
+        newton_solve<C, 0, mpc_loop_launder_v<C>>(pr, G, L, 1, kq().game_id0 + (uint64_t)t * 1000003ull + (uint64_t)gq, t == 0 ? -1 : 1, t == 0 ? -1 : 0);
         __syncthreads();
         mpc_advance<C>(phase_params(pr), G.fresh());
         __syncthreads();
-        double* const states = ka.states;
+        double* const states = kq().states;
         const int ln = phase_lane();
         if (states && ln < C::n) { CPR prs = phase_params(pr); states[((size_t)(t + 1) * prs.B + phase_int(g)) * C::n + ln] = G.fresh().z(0)[ln]; }
         __syncthreads();
+        if (t + 1 >= kq().steps) break;
     }
 }
 

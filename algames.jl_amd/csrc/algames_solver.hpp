@@ -306,10 +306,17 @@ __device__ void dual_penalty_update(CPR pr0, const Game& G0) {
 // of a C2 game waited for 39 global round trips in a row -- 190 K cycles per solve, 3 % of it (profiles/r06_phase_cycles_c2_4096_*.txt).
 // With the scratch the controls of all steps are fetched in one go (every thread of the game, all loads in flight) and the serial loop
 // reads them at LDS latency.  Same arithmetic on the same numbers.
-template <class C>
+// (OL: the lane index through an opaque copy -- inside k_mpc_loop the lane predicates of this function were invariants of the receding-horizon
+// loop, live across every solve)
+// (measured in round 6 and not taken: the roll-out on the player's own compact arrays instead of joint arrays indexed by the lane's player number --
+// fewer compare masks in the prologue, but the C3 solve kernel's SGPR spills went 8 -> 13 and the C5 loop kernel's 13 -> 17)
+#ifndef ALG_ROLLOUT_OWN
+#define ALG_ROLLOUT_OWN 0
+#endif
+template <class C, bool OL = false>
 __device__ __forceinline__ void rollout(CPR pr, double* z, double* lds = nullptr, int cap = 0) {
     constexpr int n = C::n, m = C::m, P = C::P;
-    const int lane = game_tid();
+    const int lane = OL ? phase_lane() : game_tid();
     const int NU = (pr.N - 1) * m;
     const bool staged = lds != nullptr && NU <= cap;                        // wave-uniform
     if (staged) {
@@ -330,7 +337,20 @@ __device__ __forceinline__ void rollout(CPR pr, double* z, double* lds = nullptr
                 for (int j = 0; j < 12; j++) { xi[j] = xo[j]; z[n + hx<C>(k) + lane + j * P] = xo[j]; }
             }
         }
-    } else if (lane < P) {
+    } else if (ALG_ROLLOUT_OWN && lane < P) {
+        double xi[C::ni], ui[C::mi];     // this player's entries
+#pragma unroll
+        for (int j = 0; j < C::ni; j++) xi[j] = z[lane + j * P];
+        for (int k = 0; k < pr.N - 1; k++) {
+#pragma unroll
+            for (int j = 0; j < C::mi; j++) ui[j] = uget(k, lane, j);
+            double xn[C::ni];
+            model_player_rk3_own<C>(pr, xi, ui, pr.dt, xn);
+#pragma unroll
+            for (int j = 0; j < C::ni; j++) { xi[j] = xn[j]; z[n + hx<C>(k) + lane + j * P] = xn[j]; }
+        }
+    }
+    else if (lane < P) {
         double x[n], u[m];     // only this player's entries are used
         for (int j = 0; j < C::ni; j++) x[lane + j * P] = z[lane + j * P];
         for (int k = 0; k < pr.N - 1; k++) {
@@ -344,10 +364,10 @@ __device__ __forceinline__ void rollout(CPR pr, double* z, double* lds = nullptr
 }
 
 // init_traj! (primal_dual_traj.jl:29-44) with the counter RNG (same element counters as the oracle)
-template <class C>
+template <class C, bool OL = false>
 __device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bool use_shift, int shift = -1) {
     constexpr int n = C::n, m = C::m, P = C::P;
-    const int N = pr.N, lane = game_tid(); const auto& o = pr.opt;
+    const int N = pr.N, lane = OL ? phase_lane() : game_tid(); const auto& o = pr.opt;
     const int s = use_shift ? (shift >= 0 ? shift : o.shift) : (1 << 30);
     if (use_shift && s < N) {
         // in-place shift: element e of step k takes element e of step k+s; ascending k is safe within one wave only
@@ -467,7 +487,7 @@ __device__ __forceinline__ void handoff_park(CPR pr0, Game& G, int k, int l, int
 }
 
 // newton_solve! (solver_methods.jl:5-65)
-template <class C, int HO = 0>
+template <class C, int HO = 0, bool LOOP = false>
 __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int init, uint64_t game_id, int shift = -1, int dual_reset = -1, int budget = 0) {
     const auto& o = pr.opt; const int lane = phase_lane();
     int k0 = 1, l0 = 1, ls0 = 0, cv0 = 0; double Delta = 0.0;
@@ -493,6 +513,18 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
             cv0 = 0;
         }
     } else {
+    if constexpr (LOOP) {
+        // (inside k_mpc_loop this set-up works on a laundered view of the game and of the parameters like every phase behind it: its addresses and
+        // lane predicates were invariants of the receding-horizon loop, i.e. live -- spilled -- across every solve: 25 -> 13 SGPR spills)
+        const Game H = G.fresh(); CPR prq = phase_params(pr);
+        if (lane == 0) { alg_game_stats z{}; *H.st(prq) = z; H.tc(prq)[TC_TELAP] = 0.0; }
+        if (init) init_traj<C, true>(prq, H, H.z(0), game_id, true, shift);
+        else { if (lane < C::n) H.z(0)[lane] = H.x0(prq)[lane]; }
+        if (lane < C::n) { H.z(1)[lane] = H.x0(prq)[lane]; H.z(2)[lane] = 0.0; }
+        game_sync();
+        rollout<C, true>(prq, H.z(0), reinterpret_cast<double*>(&L), (int)(sizeof(Lds<C>) / sizeof(double)));
+        if (dual_reset >= 0 ? dual_reset : phase_params(pr).opt.dual_reset) reset_con<C::NT>(phase_params(pr), G.fresh());
+    } else {
     if (lane == 0) { alg_game_stats z{}; *G.fresh().st(phase_params(pr)) = z; G.fresh().tc(phase_params(pr))[TC_TELAP] = 0.0; } // reset!(prob.stats); t_elap = 0
     if (init) init_traj<C>(pr, G, G.z(0), game_id, true, shift);           // :13
     else { if (lane < C::n) G.z(0)[lane] = G.x0(pr)[lane]; }
@@ -500,6 +532,7 @@ __device__ __forceinline__ void newton_solve(CPR pr, Game& G, Lds<C>& L, int ini
     game_sync();
     rollout<C>(pr, G.z(0), reinterpret_cast<double*>(&L), (int)(sizeof(Lds<C>) / sizeof(double)));     // :17
     if (dual_reset >= 0 ? dual_reset : o.dual_reset) reset_con<C::NT>(pr, G);     // :25
+    }
     game_sync();
     }
     LSP(19)

@@ -98,8 +98,8 @@ def test_solver_kernels_of_the_shipped_library_do_not_spill(alg):
     # 8 / 25; the bounds sit within 1.1 x of what the binary shows (VERDICT r5 item 7 asked for <= 8 / <= 16: the first is met, the second is not)
     assert res["k_newton_solve<Cfg<1, 4, 2, 0, 2> >"]["sgpr_spill"] <= 8, res["k_newton_solve<Cfg<1, 4, 2, 0, 2> >"]       # C3, 1024 games
     assert res["k_newton_solve<Cfg<1, 4, 2, 0, 1> >"]["sgpr_spill"] <= 9
-    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]["sgpr_spill"] <= 27, res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]              # C5 loop, 64 seeds
-    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 1> >"]["sgpr_spill"] <= 30
+    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]["sgpr_spill"] <= 14, res["k_mpc_loop<Cfg<1, 3, 2, 0, 4> >"]              # C5 loop, 64 seeds (<= 16; binary: 13)
+    assert res["k_mpc_loop<Cfg<1, 3, 2, 0, 1> >"]["sgpr_spill"] <= 24
     # the hand-off pair of the headline configuration (alg_set_handoff): the budgeted solve keeps the headline kernel's budget
     ho = res["k_newton_solve_ho<Cfg<0, 3, 2, 0, 1> >"]
     assert ho["vgpr_spill"] == 0 and ho["scratch"] == 0 and ho["vgpr"] <= 128 and ho["lds"] <= 10240, ho

@@ -406,24 +406,26 @@ __device__ void init_traj(CPR pr, const Game& G, double* z, uint64_t game_id, bo
     game_sync();
 }
 
-// After an odd number of buffer exchanges pdtraj lives in the trial buffer: move it home (and leave the trial buffer with
-// the previous iterate, as update_traj! would have)
+// After an odd number of buffer exchanges pdtraj lives in the trial buffer: copy it home.  Both buffers then hold pdtraj, which is what the
+// reference's pair holds after an accepted step (set_traj!(pdtraj, pdtraj_trial), solver_methods.jl:96: a copy, not an exchange).
+// (until round 6 this exchanged the two buffers -- two reads and two writes per element, 2.1 % of the C2 solve's fabric traffic, to leave the
+// previous iterate in a buffer nothing reads before the next line search overwrites it)
 template <class C>
 __device__ __forceinline__ void settle_traj(CPR pr, Game& G) {
     if (G.zo[0] != 0) {
         game_sync();
         const Game H = G.fresh();
-        double* a = H.z(0); double* z_home = H.base;
-        // (four elements of both buffers per lane in flight: one element per trip exposed 33 global round trips in a row at C2, where the
-        // eleven iterations of a solve always leave pdtraj in the trial buffer)
-        constexpr int U = 4;
+        const double* a = H.z(0); double* z_home = H.base;
+        // (eight elements per lane in flight: one element per trip exposed 33 global round trips in a row at C2, where the eleven iterations of a
+        // solve always leave pdtraj in the trial buffer)
+        constexpr int U = 8;
         const int TL = phase_int(pr.traj_len);
         for (int e0 = phase_lane(); e0 < TL; e0 += U * C::NT) {
-            double va[U], vh[U];
+            double va[U];
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT, ec = e < TL ? e : e0; va[t] = gld(a, ec); vh[t] = gld(z_home, ec); }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; va[t] = gld(a, e < TL ? e : e0); }
 #pragma unroll
-            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < TL) { gst(a, e, vh[t]); gst(z_home, e, va[t]); } }
+            for (int t = 0; t < U; t++) { const int e = e0 + t * C::NT; if (e < TL) gst(z_home, e, va[t]); }
         }
         G.zo[1] = G.zo[0]; G.zo[0] = 0;
         game_sync();

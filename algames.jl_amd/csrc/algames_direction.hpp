@@ -294,9 +294,50 @@ __device__ __forceinline__ void rowdot_dpp_g(double& acc, double v, PF&& p) {
     if constexpr (G <= 0) rowdot_dpp_f<NC>(acc, v, p);
     else { double cur[G]; rowdot_group_load<0, G, NC>(cur, p); rowdot_pipe<NC, G, 0>(acc, v, p, cur); }
 }
-// (Round 6, measured and not taken: the chain as two interleaved half-chains -- terms 0 .. H-1 and H .. NC-1 on two accumulators, added at the
-// end; dependent length H + 1 instead of NC.  C2 +1.5 %, C3 / C5 loop / C2 at 512 games neutral (profiles/r06_ab_rowdot_split_*.txt); another
-// association of the same sum moves the direction at rounding level and three calibrated bounds of tests/test_gpu_refinement.py with it.)
+// Two interleaved half-chains (round 6, ALG_R6_ROWDOT_SPLIT): terms 0 .. H-1 accumulate into acc, terms H .. NC-1 into a second accumulator, the two
+// are added at the end -- the dependent chain is H + 1 instructions long instead of NC.  A lone wavefront waits out every link of these chains (the
+// forward sweep's du = -(Y dx + y0), the backward sweep's y_i = P_i rd + s_i: 12 links each at C2).  Another association of the same sum: results
+// move at rounding level against the single chain.  Coefficients are requested in groups of G (two terms of each half per group of four).
+template <int NC, int H, int I, int G2, class PF>
+__device__ __forceinline__ void rowdot_split_group_load(double (&ca)[G2], double (&cb)[G2], PF&& p) {
+#pragma unroll
+    for (int t = 0; t < G2; t++) { ca[t] = (I + t < H) ? p(I + t) : 0.0; cb[t] = (H + I + t < NC) ? p(H + I + t) : 0.0; }
+}
+template <int NC, int H, int I, int G2, int T = 0>
+__device__ __forceinline__ void rowdot_split_group_fmac(double& a, double& b2, double v, const double (&ca)[G2], const double (&cb)[G2]) {
+    if constexpr (T < G2) {
+        if constexpr (I + T < H) fmac_rowbcast<I + T, (I + T == 0)>(a, v, ca[T]);
+        if constexpr (H + I + T < NC) fmac_rowbcast<H + I + T, false>(b2, v, cb[T]);
+        rowdot_split_group_fmac<NC, H, I, G2, T + 1>(a, b2, v, ca, cb);
+    }
+}
+template <int NC, int H, int I, int G2, class PF>
+__device__ __forceinline__ void rowdot_split_pipe(double& a, double& b2, double v, PF&& p, const double (&ca)[G2], const double (&cb)[G2]) {
+    if constexpr (I + G2 < H) {
+        double na[G2], nb[G2];
+        rowdot_split_group_load<NC, H, I + G2, G2>(na, nb, p);
+        rowdot_split_group_fmac<NC, H, I, G2>(a, b2, v, ca, cb);
+        rowdot_split_pipe<NC, H, I + G2, G2>(a, b2, v, p, na, nb);
+    } else rowdot_split_group_fmac<NC, H, I, G2>(a, b2, v, ca, cb);
+}
+template <int NC, int G, class PF>
+__device__ __forceinline__ void rowdot_dpp_split(double& acc, double v, PF&& p) {
+    constexpr int H = (NC + 1) / 2, G2 = (G >= 2 ? G / 2 : 1);
+    double b2 = 0.0, ca[G2], cb[G2];
+    rowdot_split_group_load<NC, H, 0, G2>(ca, cb, p);
+    rowdot_split_pipe<NC, H, 0, G2>(acc, b2, v, p, ca, cb);
+    acc += b2;
+}
+// Measured in round 6, same box, alternating (profiles/r06_ab_rowdot_split_*.txt, r06_ab_rdone_*.txt): C2 +0.8 ... 1.5 % on one box, +0.6 ... 2.7 % on two
+// others; C3 and C2 at 512 games neutral; the C5 loop (64 seeds x 200 steps, one launch = its slowest seed) 240 -> 202 K/s: no kernel effect -- at 100
+// steps both forms take 186 ms -- but another rounding of the closed-loop trajectories, on which another seed meets a long line-search episode.
+// So: the double-integrator kernels (every shape of them, so that they stay bit-identical with each other) form these two sums as half-chains,
+// the unicycle / bicycle kernels keep the single chain -- nothing to gain there, and their calibrated accuracy tests (tests/test_gpu_refinement.py)
+// and the BASELINE C5 trajectories stay what they were.
+#ifndef ALG_R6_ROWDOT_SPLIT
+#define ALG_R6_ROWDOT_SPLIT 1
+#endif
+template <class C> inline constexpr bool rowdot_split_v = ALG_R6_ROWDOT_SPLIT != 0 && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR;
 #ifndef ALG_RDG_W2
 #define ALG_RDG_W2 16         // coefficient group of the row-broadcast chains, 256-register kernels (0: fetch where used)
 #endif
@@ -1514,7 +1555,8 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
         const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
         const int cl = fl < m ? fl : 0;
         double acc = Kl[n * m + cl];
-        rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
+        if constexpr (rowdot_split_v<C>) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });
+        else rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
         const double duv = fl < m ? (SPLITF ? -acc : acc) : 0.0;     // (split recursion: the gains in HBM are -[K | kappa])
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
@@ -1960,7 +2002,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
             const double rdl = Rc[R::RD + yr];
             double a = Pr[n];
-            rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
+            if constexpr (rowdot_split_v<C>) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
+            else rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
             if (!GFUSE && (ty & 15) < n) L.bw.t[yp * n + yr] = a;
             // split recursion: y_i takes the place of s_i (this lane was its only reader): column n of [P_i A_k | y_i] in the next step
             if constexpr (SPLITF) { if ((ty & 15) < n) L.bw.Pm[yp * n * LDP + yr * LDP + n] = a; }

@@ -328,6 +328,49 @@ __device__ __forceinline__ void rowdot_dpp_split(double& acc, double v, PF&& p) 
     rowdot_split_pipe<NC, H, 0, G2>(acc, b2, v, p, ca, cb);
     acc += b2;
 }
+// The same with NCH interleaved sub-chains (terms [j H, (j + 1) H) on accumulator j, H = ceil(NC / NCH); accumulators added pairwise at the end):
+// dependent length H + ceil(log2 NCH).  NCH = 2 is rowdot_dpp_split's association exactly.
+template <int NC, int NCH, int H, int I, int G2, class PF, int... Ts>
+__device__ __forceinline__ void rowdot_chains_load(double (&c)[NCH][G2], PF&& p, std::integer_sequence<int, Ts...>) {
+    (([&] { constexpr int t = Ts / NCH, j = Ts % NCH, term = j * H + I + t; c[j][t] = (I + t < H && term < NC) ? p(term < NC ? term : 0) : 0.0; }()), ...);
+}
+template <int NC, int NCH, int H, int I, int G2, int... Ts>
+__device__ __forceinline__ void rowdot_chains_fmac(double (&acc)[NCH], double v, const double (&c)[NCH][G2], std::integer_sequence<int, Ts...>) {
+    (([&] { constexpr int t = Ts / NCH, j = Ts % NCH, term = j * H + I + t;
+            if constexpr (I + t < H && term < NC) fmac_rowbcast<term, (I + t == 0 && j == 0)>(acc[j], v, c[j][t]); }()), ...);
+}
+template <int NC, int NCH, int H, int I, int G2, class PF>
+__device__ __forceinline__ void rowdot_chains_pipe(double (&acc)[NCH], double v, PF&& p, const double (&cur)[NCH][G2]) {
+    using Seq = std::make_integer_sequence<int, NCH * G2>;
+    if constexpr (I + G2 < H) {
+        double nxt[NCH][G2];
+        rowdot_chains_load<NC, NCH, H, I + G2, G2>(nxt, p, Seq{});
+        rowdot_chains_fmac<NC, NCH, H, I, G2>(acc, v, cur, Seq{});
+        rowdot_chains_pipe<NC, NCH, H, I + G2, G2>(acc, v, p, nxt);
+    } else rowdot_chains_fmac<NC, NCH, H, I, G2>(acc, v, cur, Seq{});
+}
+template <int NC, int NCH, int G, class PF>
+__device__ __forceinline__ void rowdot_dpp_chains(double& acc0, double v, PF&& p) {
+    static_assert(NCH >= 2 && NCH <= 4, "two to four sub-chains");
+    constexpr int H = (NC + NCH - 1) / NCH, G2 = (G >= NCH ? G / NCH : 1);
+    double acc[NCH], cur[NCH][G2];
+    acc[0] = acc0;
+#pragma unroll
+    for (int j = 1; j < NCH; j++) acc[j] = 0.0;
+    rowdot_chains_load<NC, NCH, H, 0, G2>(cur, p, std::make_integer_sequence<int, NCH * G2>{});
+    rowdot_chains_pipe<NC, NCH, H, 0, G2>(acc, v, p, cur);
+    if constexpr (NCH == 2) acc0 = acc[0] + acc[1];
+    else if constexpr (NCH == 3) acc0 = (acc[0] + acc[1]) + acc[2];
+    else acc0 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// (measured, profiles/r06_ab_rowdot_chains_c2.txt: three sub-chains neutral, four 2 % slower than two -- the extra accumulators' adds and the
+// wider coefficient groups cost what the shorter chain saves; the w_k chain in two halves: neutral.  Two it is.)
+#ifndef ALG_R6_ROWDOT_CHAINS
+#define ALG_R6_ROWDOT_CHAINS 2
+#endif
+#ifndef ALG_R6_WCHAIN_SPLIT
+#define ALG_R6_WCHAIN_SPLIT 0      // the forward sweep's w_k = rx + Q^ dx chain (double integrator, FWDW) as two half-chains
+#endif
 // Measured in round 6, same box, alternating (profiles/r06_ab_rowdot_split_*.txt, r06_ab_rdone_*.txt): C2 +0.8 ... 1.5 % on one box, +0.6 ... 2.7 % on two
 // others; C3 and C2 at 512 games neutral; the C5 loop (64 seeds x 200 steps, one launch = its slowest seed) 240 -> 202 K/s: no kernel effect -- at 100
 // steps both forms take 186 ms -- but another rounding of the closed-loop trajectories, on which another seed meets a long line-search episode.
@@ -1555,7 +1598,8 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
         const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
         const int cl = fl < m ? fl : 0;
         double acc = Kl[n * m + cl];
-        if constexpr (rowdot_split_v<C>) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });
+        if constexpr (rowdot_split_v<C> && ALG_R6_ROWDOT_CHAINS > 2) rowdot_dpp_chains<n, ALG_R6_ROWDOT_CHAINS, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });
+        else if constexpr (rowdot_split_v<C>) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });
         else rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
         const double duv = fl < m ? (SPLITF ? -acc : acc) : 0.0;     // (split recursion: the gains in HBM are -[K | kappa])
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
@@ -1575,7 +1619,8 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
 #pragma unroll
                 for (int c = 0; c < NPOS; c++) hv[c] = (double)hsg[c] * Rc[hso[c]];
                 double t = wk;
-                rowdot_dpp<NPOS>(t, dxn, hv);
+                if constexpr (ALG_R6_WCHAIN_SPLIT != 0 && rowdot_split_v<C>) rowdot_dpp_split<NPOS, NPOS>(t, dxn, [&](int c) { return hv[c]; });
+                else rowdot_dpp<NPOS>(t, dxn, hv);
                 wk = rr_ < C::PD * P ? t : wk;
             }
             if (rok) gst(dz + n + hl<C>(k, 0), re_, wk);
@@ -2002,7 +2047,8 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
             const double* Pr = &L.bw.Pm[yp * n * LDP + yr * LDP];
             const double rdl = Rc[R::RD + yr];
             double a = Pr[n];
-            if constexpr (rowdot_split_v<C>) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
+            if constexpr (rowdot_split_v<C> && ALG_R6_ROWDOT_CHAINS > 2) rowdot_dpp_chains<n, ALG_R6_ROWDOT_CHAINS, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
+            else if constexpr (rowdot_split_v<C>) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
             else rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(a, rdl, [&](int c) { return Pr[c]; });
             if (!GFUSE && (ty & 15) < n) L.bw.t[yp * n + yr] = a;
             // split recursion: y_i takes the place of s_i (this lane was its only reader): column n of [P_i A_k | y_i] in the next step

@@ -368,6 +368,9 @@ __device__ __forceinline__ void rowdot_dpp_chains(double& acc0, double v, PF&& p
 #ifndef ALG_R6_ROWDOT_CHAINS
 #define ALG_R6_ROWDOT_CHAINS 2
 #endif
+#ifndef ALG_R6_FWD_LAND
+#define ALG_R6_FWD_LAND 0         // where a forward-sweep step lands the next step's prefetched slice in LDS: 0 at its tail, 1 behind its first LDS reads, 2 behind the du chain
+#endif                            // (measured at C2, profiles/r06_ab_fwd_land_c2.txt: 1 -0.6 %, 2 neutral)
 #ifndef ALG_R6_WCHAIN_SPLIT
 #define ALG_R6_WCHAIN_SPLIT 0      // the forward sweep's w_k = rx + Q^ dx chain (double integrator, FWDW) as two half-chains
 #endif
@@ -1598,9 +1601,18 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
         const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
         const int cl = fl < m ? fl : 0;
         double acc = Kl[n * m + cl];
+        auto land_next = [&]() {
+            // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
+#pragma unroll
+            for (int q = 0; q < FPL; q++) L.rec[cur ^ 1][fso[q]] = pref[(u + 1) % SD][q];
+#pragma unroll
+            for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
+        };
+        if constexpr (ALG_R6_FWD_LAND == 1) land_next();
         if constexpr (rowdot_split_v<C> && ALG_R6_ROWDOT_CHAINS > 2) rowdot_dpp_chains<n, ALG_R6_ROWDOT_CHAINS, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });
         else if constexpr (rowdot_split_v<C>) rowdot_dpp_split<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });
         else rowdot_dpp_g<n, (rowdot_group_v<C> < n ? rowdot_group_v<C> : n)>(acc, dxr, [&](int q) { return Kl[q * m + cl]; });                  // dx_k sits in lanes 0..n-1 of the row, the control rows in its lanes 0..m-1 (same FMA order as the v_readlane form)
+        if constexpr (ALG_R6_FWD_LAND == 2) land_next();
         const double duv = fl < m ? (SPLITF ? -acc : acc) : 0.0;     // (split recursion: the gains in HBM are -[K | kappa])
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
@@ -1625,11 +1637,7 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
             }
             if (rok) gst(dz + n + hl<C>(k, 0), re_, wk);
         }
-        // (1) data of step k+1 (requested SD steps ago) -> LDS (clamped duplicates at the last steps are never read)
-#pragma unroll
-        for (int q = 0; q < FPL; q++) L.rec[cur ^ 1][fso[q]] = pref[(u + 1) % SD][q];
-#pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; L.fw.kg[cur ^ 1][e < NK ? e : NK - 1] = prek[(u + 1) % SD][q]; }
+        if constexpr (ALG_R6_FWD_LAND == 0) land_next();
         asm volatile("" ::: "memory");
         // (2) results out
         if (lane < m) gst(dz + n + hu<C>(k, 0), uoff<C>(lane), duv);

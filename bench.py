@@ -70,7 +70,8 @@ def structured_bytes(family, N, n, m, p, ls_trials_per_iter=1.0, gate=True, wave
       forward      read gains and record slice, write dx, du (double integrator: also reads [.. rx] and parks w = rx + Q dx for the costate)
       costate      read [.. rx] and dx (double integrator: w only), write dlambda
       gate         the opt-u rows of the refinement gate: du, two dlambda entries per control, R^, ru
-    The accepted trial becomes pdtraj by exchanging buffers (no traffic)."""
+    The accepted trial becomes pdtraj by exchanging buffers (no traffic; a solve that ends on the exchanged side copies pdtraj home once: 2 x 17 KB per
+    C2 solve, in traffic_over_model)."""
     S = n * p * (N - 1) + m * (N - 1) + n * (N - 1)
     it, K = S + n, N - 1
     nc = {"C2": 0, "C3": 4 * p, "C5": 4 * p, "Q": 204 * p}[family]      # RK2 Jacobian coefficients per step (quadrotor: dense blocks)

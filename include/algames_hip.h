@@ -279,7 +279,9 @@ int alg_add_cylinder_constraint_player(alg_handle* h, int32_t player, int32_t n_
 /* current length of the constraint dual / penalty / value vectors of one game */
 int alg_get_con_len(alg_handle* h, int32_t* con_len);
 
-/* set_traj!/get_traj! (primal_dual_traj.jl:46-107) over the batch: B x traj_len */
+/* set_traj!/get_traj! (primal_dual_traj.jl:46-107) over the batch: B x traj_len.
+ * (ALG_TRAJ_TRIAL after a solve: x_1 = x0; the rest is the library's scratch -- the line search accepts a trial by exchanging buffer
+ * offsets, a solve that ends on the exchanged side copies pdtraj home: the trial buffer then holds pdtraj as in the reference, otherwise the iterate before it) */
 int alg_set_traj(alg_handle* h, int32_t which, const double* z);
 int alg_get_traj(alg_handle* h, int32_t which, double* z);
 /* ALConVal lambda / mu (Altro 0.3.0): B x con_len each; NULL pointers are skipped */

@@ -368,6 +368,9 @@ __device__ __forceinline__ void rowdot_dpp_chains(double& acc0, double v, PF&& p
 #ifndef ALG_R6_ROWDOT_CHAINS
 #define ALG_R6_ROWDOT_CHAINS 2
 #endif
+#ifndef ALG_R6_SADDR
+#define ALG_R6_SADDR 1            // per-step base addresses of the sweeps' global accesses forced into scalar registers (uniform_u64)
+#endif
 #ifndef ALG_R6_FWD_LAND
 #define ALG_R6_FWD_LAND 0         // where a forward-sweep step lands the next step's prefetched slice in LDS: 0 at its tail, 1 behind its first LDS reads, 2 behind the du chain
 #endif                            // (measured at C2, profiles/r06_ab_fwd_land_c2.txt: 1 -0.6 %, 2 neutral)
@@ -1570,11 +1573,19 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
     // LDS, (2) issue this step's result stores, (3) request the data of step k+2 -- the single wait of a step meets loads and
     // stores that have been in flight for a whole step.
     auto fwd_load = [&](int kk, double (&rf)[FPL], double (&rk)[KPL]) {
+#if ALG_R6_SADDR
+        const int kc = __builtin_amdgcn_readfirstlane(kk < N - 1 ? kk : N - 2);
+        // (the step's two base addresses as scalar pairs, see the gain stores of the backward sweep)
+        const double* const Rb = as_global(reinterpret_cast<const double*>(uniform_u64(reinterpret_cast<unsigned long long>(G.rec(pr) + (size_t)kc * R::LEN))));
+        const double* const Kb = as_global(reinterpret_cast<const double*>(uniform_u64(reinterpret_cast<unsigned long long>(G.kgain(pr) + (size_t)kc * NK))));
+#else
         const int kc = kk < N - 1 ? kk : N - 2;
+        const double* const Rb = G.rec(pr) + (size_t)kc * R::LEN; const double* const Kb = G.kgain(pr) + (size_t)kc * NK;
+#endif
 #pragma unroll
-        for (int q = 0; q < FPL; q++) rf[q] = gld(G.rec(pr) + (size_t)kc * R::LEN, fso[q]);
+        for (int q = 0; q < FPL; q++) rf[q] = gld(Rb, fso[q]);
 #pragma unroll
-        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = gld(G.kgain(pr) + (size_t)kc * NK, e < NK ? e : NK - 1); }
+        for (int q = 0; q < KPL; q++) { const int e = lane + q * WAVE; rk[q] = gld(Kb, e < NK ? e : NK - 1); }
     };
     // Prefetch ring: the slices of steps k + 1 .. k + SD are in flight in registers while step k computes.  With four games per
     // SIMD all streaming, a fetch takes about two microseconds -- longer than a step of this sweep -- so with one step in flight
@@ -2175,9 +2186,18 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         // meet stores that were just issued; measured neutral, the phase profile shows no exposed wait either way)
         asm volatile("" ::: "memory");
         if (!HELP2 && tw == 0 && rhsl) {
+#if ALG_R6_SADDR
+            // (the step's base address as a scalar pair, ONE lane offset, the m entries of the column at immediate offsets: the compiler keeps the game's
+            // base pointers in VGPRs once the scalar file is full, and every store then paid two 64-bit vector adds, a copy and the offset's reload)
+            double* const Kg = reinterpret_cast<double*>(uniform_u64(reinterpret_cast<unsigned long long>(G.kgain(pr) + (size_t)k * NK)));
+            const unsigned ko = goff((cidx - m) * m);
+#pragma unroll
+            for (int c = 0; c < m; c++) *reinterpret_cast<double*>(reinterpret_cast<char*>(as_global(Kg) + c) + ko) = col[c];
+#else
             double* __restrict__ Kg = G.kgain(pr) + (size_t)k * NK;
 #pragma unroll
             for (int c = 0; c < m; c++) gst(Kg, (cidx - m) * m + c, col[c]);
+#endif
         }
         bsync();
         ALG_PROF(6)

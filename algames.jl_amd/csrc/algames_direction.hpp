@@ -369,7 +369,9 @@ __device__ __forceinline__ void rowdot_dpp_chains(double& acc0, double v, PF&& p
 #define ALG_R6_ROWDOT_CHAINS 2
 #endif
 #ifndef ALG_R6_SADDR
-#define ALG_R6_SADDR 1            // per-step base addresses of the sweeps' global accesses forced into scalar registers (uniform_u64)
+#define ALG_R6_SADDR 1            // per-step base addresses of the sweeps' global accesses forced into scalar registers (uniform_u64): 1 gain stores and
+                                  // forward-sweep prefetches (C2 +1.5 ... 2.6 %, profiles/r06_ab_saddr_*.txt); 2 also the backward sweep's record prefetch as
+                                  // unconditional clamped loads -- measured 0.7 ... 2 % SLOWER at C2 / C4 (r06_ab_saddr_prefetch_*.txt), not taken
 #endif
 #ifndef ALG_R6_FWD_LAND
 #define ALG_R6_FWD_LAND 0         // where a forward-sweep step lands the next step's prefetched slice in LDS: 0 at its tail, 1 behind its first LDS reads, 2 behind the du chain
@@ -2033,7 +2035,18 @@ __device__ int newton_direction_tile(CPR pr0, const Game& G0, DirLds<C>& L, doub
         ALG_PROF(1)
         // prefetch of the next step's record: issued after the register-hungry MFMA phase, landed by the end of the step
         double pre[RPL];
-        if (!HELP2 && k > 0) {                                       // (team of two: the helper wavefront fetches the record)
+        // (one-wavefront kernels only: in the C5 loop kernel -- team of four -- the same change raised the SGPR spills from 13 to 34)
+        constexpr bool PRE2 = ALG_R6_SADDR >= 2 && C::NW == 1;
+        if constexpr (PRE2) {
+            // unconditional loads from clamped addresses off a scalar base (step 0 re-requests its own record, nothing lands it): the conditional
+            // form -- zeroed registers, two exec-masked branches, each re-reading the record offset from the kernel arguments -- drained vmcnt
+            // and exposed two scalar round trips per step
+            const int kp = __builtin_amdgcn_readfirstlane(k > 0 ? k - 1 : 0);
+            const double* const Rb = as_global(reinterpret_cast<const double*>(uniform_u64(reinterpret_cast<unsigned long long>(G.rec(pr) + (size_t)kp * R::LEN))));
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; pre[q] = gld(Rb, e < R::LEN_SWEEP ? e : R::LEN_SWEEP - 1); }
+        }
+        else if (!HELP2 && k > 0) {                                  // (team of two: the helper wavefront fetches the record)
 #pragma unroll
             for (int q = 0; q < RPL; q++) { const int e = tid + q * BT; pre[q] = e < R::LEN_SWEEP ? gld(G.rec(pr) + (size_t)(k - 1) * R::LEN, e) : 0.0; }
         }

@@ -373,6 +373,12 @@ __device__ __forceinline__ void rowdot_dpp_chains(double& acc0, double v, PF&& p
                                   // forward-sweep prefetches (C2 +1.5 ... 2.6 %, profiles/r06_ab_saddr_*.txt); 2 also the backward sweep's record prefetch as
                                   // unconditional clamped loads -- measured 0.7 ... 2 % SLOWER at C2 / C4 (r06_ab_saddr_prefetch_*.txt), not taken
 #endif
+#ifndef ALG_R6_CURC
+#define ALG_R6_CURC 1             // forward sweep: LDS double-buffer index of a step as a compile-time constant of the unrolled loop
+#endif
+#ifndef ALG_R6_PL1
+#define ALG_R6_PL1 1              // forward sweep: |du| + |dx| summed and checked without per-step lane masks
+#endif
 #ifndef ALG_R6_FWD_LAND
 #define ALG_R6_FWD_LAND 0         // where a forward-sweep step lands the next step's prefetched slice in LDS: 0 at its tail, 1 behind its first LDS reads, 2 behind the du chain
 #endif                            // (measured at C2, profiles/r06_ab_fwd_land_c2.txt: 1 -0.6 %, 2 neutral)
@@ -1599,9 +1605,12 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
 #pragma unroll
     for (int u = 0; u < SD; u++) fwd_load(1 + u, pref[(1 + u) % SD], prek[(1 + u) % SD]);
     sweep_sync<C>();
-    int cur = 0;
+    int curv = 0;
     double pl1 = 0.0;                               // sum |dx| + |du| of this lane's entries (Delta_step, primal_dual_traj.jl:130-147)
-    int bad = 0;                                    // non-finite direction entries (checked where they are produced)
+    // non-finite direction entries (checked where they are produced): lane mask in scalar registers.  Neither the sum nor the check is masked per step:
+    // the entries of the lanes outside the vectors are exact zeros (finite, and x + 0 = x), the 16-lane rows of the FWDW form hold replicas of row 0 --
+    // the sum drops them once, after the sweep (bit-identical; 8 VALU instructions per step less)
+    unsigned long long badm = 0;
     // dx_k lives one entry per lane (lanes 0..n-1) and is broadcast with v_readlane; du and dx_{k+1} never pass through LDS:
     // one LDS round trip (gain rows, record slice) per step instead of three.
     double dxr = 0.0;
@@ -1610,6 +1619,14 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
       for (int u = 0; u < SD; u++) {
         const int k = k0 + u;
         if (k >= N - 1) break;
+#if ALG_R6_CURC
+        // (the LDS double buffer's index as a compile-time constant of the unrolled step -- SD is even, the sweep starts at slot 0 -- so that every LDS
+        // address of the step is a loop-invariant lane offset plus an immediate: with a run-time index each of the step's ~13 addresses was re-formed)
+        static_assert(SD % 2 == 0 || SD == 1, "sweep depth");
+        const int cur = (SD % 2 == 0) ? (u & 1) : curv;
+#else
+        const int cur = curv;
+#endif
         const double* Rc = L.rec[cur]; const double* Kl = L.fw.kg[cur];
         const int fl = FWDW ? (lane & 15) : lane;     // FWDW: every 16-lane row runs the recursion (same LDS addresses, same instructions)
         const int cl = fl < m ? fl : 0;
@@ -1630,8 +1647,13 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
         const double rdv = Rc[R::RD + (fl < n ? fl : 0)];
         double dxn = fwd_next<C>(Rc + R::COEF, dt, dxr, duv, fl) + rdv;
         dxn = fl < n ? dxn : 0.0;
-        if (lane < m) { pl1 += fabs(duv); bad |= !isfinite(duv); }
-        if (lane < n) { pl1 += fabs(dxn); bad |= !isfinite(dxn); }
+#if ALG_R6_PL1
+        pl1 += fabs(duv); pl1 += fabs(dxn);
+        badm |= __builtin_amdgcn_ballot_w64(!isfinite(duv)) | __builtin_amdgcn_ballot_w64(!isfinite(dxn));
+#else
+        if (lane < m) { pl1 += fabs(duv); badm |= __builtin_amdgcn_ballot_w64(!isfinite(duv)); }
+        if (lane < n) { pl1 += fabs(dxn); badm |= __builtin_amdgcn_ballot_w64(!isfinite(dxn)); }
+#endif
         dxr = dxn;
         if constexpr (FWDW) {
             // w_k = rx_{i,k+1} + Q^_{i,k+1} dx_{k+1} for (player, row) = (ri_, rr_): the head of the costate sweep's FMA sequence
@@ -1658,7 +1680,7 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
         // (3) request step k+1+SD into the slot that was just emptied
         fwd_load(k + 1 + SD, pref[(u + 1) % SD], prek[(u + 1) % SD]);
         sweep_sync<C>();
-        cur ^= 1;
+        curv ^= 1;
       }
     }
 #if defined(ALG_DIR_STOP) && ALG_DIR_STOP == 2
@@ -1717,7 +1739,8 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
             }
             acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
             lamp = acc;
-            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
+            if (rok) gst(dz + n + hl<C>(k, 0), re_, acc);
+            badm |= __builtin_amdgcn_ballot_w64(!isfinite(acc));
             cw_load(k - CD, wkr[u], cfr[u]);
           }
         }
@@ -1739,12 +1762,17 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
 #pragma unroll
     for (int u = 0; u < SD; u++) cs_load(N - 3 - u, pdx[(1 + u) % SD], pre[(1 + u) % SD]);
     sweep_sync<C>();
-    cur = 0;
+    int curc = 0;
     for (int k0 = N - 2; k0 >= 0; k0 -= SD) {
 #pragma unroll
       for (int u = 0; u < SD; u++) {
         const int k = k0 - u;
         if (k < 0) break;
+#if ALG_R6_CURC
+        const int cur = (SD % 2 == 0) ? (u & 1) : curc;      // (compile-time slot index, like the forward sweep)
+#else
+        const int cur = curc;
+#endif
         const double* Rc = L.rec[cur];
         const double w = (k + 1 < N - 1) ? dt : 1.0;
         if constexpr (DIROW) {
@@ -1776,7 +1804,8 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
             if constexpr (C::NC > 0) { can = Rc[R::COEF + cia]; cbn = Rc[R::COEF + cib]; if constexpr (C::MODEL == ALG_MODEL_BICYCLE) ccn = Rc[R::COEF + cic]; }
             acc = (rok && (!IBR || ri_ == ip)) ? acc : 0.0;
             lamp = acc;
-            if (rok) { gst(dz + n + hl<C>(k, 0), re_, acc); bad |= !isfinite(acc); }
+            if (rok) gst(dz + n + hl<C>(k, 0), re_, acc);
+            badm |= __builtin_amdgcn_ballot_w64(!isfinite(acc));
         } else {
         if (lane < n) L.fw.dx[lane] = dxk;
         hxm.expand(lane, Rc, L.fw.hx);
@@ -1795,7 +1824,8 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
             if (k < N - 2) { const double* dli = &L.fw.dl[ci_ * n]; acc += AT_vec<C>(L.coefn, dt, [&](int rr) { return dli[rr]; }, cr_); }
         }
         sweep_sync<C>();
-        if (lane < P * n) { L.fw.dl[lane] = acc; gst(dz + n + hl<C>(k, 0), lane, acc); bad |= !isfinite(acc); }
+        if (lane < P * n) { L.fw.dl[lane] = acc; gst(dz + n + hl<C>(k, 0), lane, acc); }
+        badm |= __builtin_amdgcn_ballot_w64(lane < P * n && !isfinite(acc));
         if (C::NC > 0 && lane < C::NC) L.coefn[lane] = Rc[R::COEF + lane];
         }
         // land step k - 1 (requested SD steps ago), then request step k - 1 - SD into the emptied slot
@@ -1806,15 +1836,15 @@ __device__ __forceinline__ int direction_forward_costate(CPR pr, const Game& G0,
         }
         cs_load(k - 1 - SD, pdx[(u + 1) % SD], pre[(u + 1) % SD]);
         sweep_sync<C>();
-        cur ^= 1;
+        curc ^= 1;
       }
     }
     }
     ALG_PROF(8)
     ALG_PROF_FLUSH
     // non-finite direction -> singular (the reference would throw / propagate NaN)
-    if (primal_l1) *primal_l1 = wave_sum(pl1);
-    return __builtin_amdgcn_readfirstlane(wave_or(bad)) ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;     // scalar: the solver's control flow stays on the SALU
+    if (primal_l1) *primal_l1 = wave_sum((FWDW && lane >= 16) ? 0.0 : pl1);
+    return badm != 0 ? ALG_STATUS_SINGULAR : ALG_STATUS_OK;     // scalar: the solver's control flow stays on the SALU
 }
 
 template <class C, bool IBR>

@@ -222,11 +222,24 @@ template <class C> __device__ __forceinline__ const double* zstate(const double*
 // Every kernel runs one game per workgroup (one wavefront, or a team of Cfg::NW), so the game's thread index is the workgroup's
 // and its barrier is the workgroup barrier.
 __device__ __forceinline__ int game_tid() { return (int)threadIdx.x; }
+// (measured in round 6: 63 of the C2 kernel's 194 full 32-bit multiplies become 24-bit ones, the rate does not move -- profiles/r06_ab_lane_range_c2.txt --
+// and the 4-player DoubleIntegrator d = 1 kernel starts to spill: off)
+#ifndef ALG_R6_LANE_RANGE
+#define ALG_R6_LANE_RANGE 0
+#endif
 __device__ __forceinline__ void game_sync() { __syncthreads(); }
 // ---- wave reductions ---------------------------------------------------------------------------
 // Opaque copy of the lane id: keeps per-lane role / address computations of a phase from being hoisted out of the
 // solver's outer loops (where every phase's invariants would be live at once).
-__device__ __forceinline__ int phase_lane() { int l = game_tid(); asm volatile("" : "+v"(l)); return l; }
+// (ALG_R6_LANE_RANGE: the copy keeps the id's value range -- a workgroup has at most 256 threads -- so that products of lane-derived indices can take
+// the 24-bit multiply)
+__device__ __forceinline__ int phase_lane() {
+    int l = game_tid(); asm volatile("" : "+v"(l));
+#if ALG_R6_LANE_RANGE
+    __builtin_assume((unsigned)l < 256u);
+#endif
+    return l;
+}
 // Opaque copies of wave-uniform loop invariants (problem sizes, dt, base pointers), taken at the start of a phase: whatever is
 // derived from them (row counts, address vectors, dt^2 / 2, (double)S ...) is recomputed inside the phase with a handful of
 // scalar instructions instead of being hoisted in front of the solver's outer loops and kept alive -- or spilled -- there.

@@ -5,11 +5,23 @@
 #include "algames_device.hpp"
 
 // Round-6 A/B switches of the fused pass (tests/probes/build_variant.sh; 1 = shipped)
+#ifndef ALG_R6_ROWIDX
+#define ALG_R6_ROWIDX 1           // fused pass, rows opt_x: (step, entry) of a row carried from trip to trip
+#endif
+#ifndef ALG_R6_LANEROLE
+#define ALG_R6_LANEROLE 1         // fused pass, double integrator: a lane keeps its row of the step for the whole chunk, the trips walk the steps (2: the staging too)
+#endif
+#ifndef ALG_LSM_DI1W
+#define ALG_LSM_DI1W 0            // (documented at LsMulti below)
+#endif
 #ifndef ALG_R6_STAGE
 #define ALG_R6_STAGE 1      // every global load of a chunk in flight before the first wait
 #endif
 #ifndef ALG_R6_STAGE_BATCH
 #define ALG_R6_STAGE_BATCH 6    // ... elements of z and dz per lane and batch in the 128-register kernels
+#endif
+#ifndef ALG_R6_STAGE_BATCH_LR
+#define ALG_R6_STAGE_BATCH_LR 5 // ... blocks per batch of the lane-role staging
 #endif
 #ifndef ALG_R6_STAGE_BATCH_W2
 #define ALG_R6_STAGE_BATCH_W2 10   // ... in the 256-register kernels (the 4-player unicycle's chunk is 20 elements per lane: 40 doubles in flight at once spilled its loop kernel)
@@ -642,6 +654,38 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             // Lanes past the end of the chunk repeat its last element (clamped index) instead of being masked off: they load, form and store the
             // very value the owning lane does -- same address, same bits -- so no per-element exec mask has to be kept in scalar registers.  The
             // trial values of the chunk's extra block (A_{k+1}' lambda_{k+1}) go out here as well as with the next chunk: the same bits twice.
+            // Round 6 (lane roles, ALG_R6_LANEROLE >= 2): a lane stages the same entry of every block (NT / b blocks per trip, the trips unrolled): the
+            // element of trip T is (T BS b + lane) -- a chunk-invariant lane offset plus an immediate in every address, no clamps, no (block, entry)
+            // divided out of a flat index for the [x | u] copy; b of NT lanes work (C2: 54 of 64, 14 trips for 12).
+            constexpr bool SLR = ALG_R6_LANEROLE >= 2 && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && !ALG_LSM_DI1W && b <= NT;
+            if constexpr (SLR) {
+                constexpr int BS = NT / b, BT = (FT + 1 + BS - 1) / BS, SBL = BT < ALG_R6_STAGE_BATCH_LR ? BT : ALG_R6_STAGE_BATCH_LR;
+                int sl = lane; asm volatile("" : "+v"(sl)); __builtin_assume(sl >= 0 && sl < NT);
+                const int lb = sl / b, o = sl % b;
+                if (lb < BS) {
+                    const bool isxu = o < NXU;
+                    double* const lxu = Ch.zxu + lb * NXU + o;
+#pragma unroll
+                    for (int t0 = 0; t0 < BT; t0 += SBL) {
+                        double a[SBL], d[SBL];
+#pragma unroll
+                        for (int t = 0; t < SBL; t++) {
+                            const int T = t0 + t, j = BS == 1 ? T : T * BS + lb;
+                            if (T < BT && j < nblk) { a[t] = gld(zs + base + T * BS * b, sl); d[t] = AXPY ? gld(dz + base + T * BS * b, sl) : 0.0; }
+                        }
+#pragma unroll
+                        for (int t = 0; t < SBL; t++) {
+                            const int T = t0 + t, j = BS == 1 ? T : T * BS + lb;
+                            if (T < BT && j < nblk) {
+                                const double v = AXPY ? __builtin_fma(alpha, d[t], a[t]) : a[t];
+                                Ch.zt[T * BS * b + sl] = v;
+                                if (AXPY) gst(zo + base + T * BS * b, sl, v);
+                                if (isxu && j < nst) lxu[T * BS * NXU] = a[t];
+                            }
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int t0 = 0; t0 < SU; t0 += SB) {
                 if (t0 * NT >= cnt) break;                                  // (wave-uniform: the last chunk of a horizon is shorter)
@@ -732,34 +776,79 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             fsync();
         }
         // ---- rows opt_i,x_{k+1}[a]
-        for (int e = lane; e < nst * P * n; e += NT) {
-            const int ks = e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n, k = k0 + ks;
+        // Round 6 (lane roles, double integrator): the rows of a kind are dealt as (step, row of the step) = (trip, lane) instead of flat over the
+        // lanes.  A lane then owns the same row of every step it visits -- player, entry, LQR constants, table slot, control bounds, every LDS
+        // offset inside the block are invariants of the chunk, and a trip is its loads, the row's arithmetic and the store.  The flat dealing
+        // divided (step, row) out of the flat index on every trip: 65 of the 75 VALU instructions of an opt_x trip at C2 were index arithmetic
+        // and selects on it.  opt_x rows: NT / (P n) steps per trip (C2: one, 36 of 64 lanes, 13 trips for 8 -- but a fifth of the instructions
+        // each); opt_u rows NT / m steps per trip, dyn rows NT / n (C2: ten and five: the same number of trips as before).  Every row is the
+        // same expression as before; a lane sums other rows than it did, so the l1 norms move in the last bits.  (The unicycle kernels keep
+        // the flat dealing: the line search's group pass deals and sums in that order and must stay bit-identical to this pass.)
+        constexpr int RPS = P * n;
+        constexpr bool LR = ALG_R6_LANEROLE != 0 && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && !ALG_LSM_DI1W && RPS <= NT;
+        // (the roles are worked out per chunk from an opaque copy of the lane id: as invariants of the whole pass they would be hoisted in front
+        // of the chunk loop and held in registers through staging and phase A -- spills in a 128-register kernel)
+        int rlane = lane;
+        if constexpr (LR) { asm volatile("" : "+v"(rlane)); __builtin_assume(rlane >= 0 && rlane < NT); }
+        auto xrow = [&](int ks, int ei, int i, int a, double tq, double tx) {
+            const int k = k0 + ks;
             const double* blk = Ch.zt + ks * b;
             const bool has_next = (k + 1 <= N - 2);
             const double w = (k + 1 < N - 1) ? dt : 1.0;
             double r = -blk[n + m + ei];
             {
-                const double* ln = blk + (has_next ? b : 0) + n + m + i * n;
+                const double* ln = blk + (has_next ? b : 0) + n + m + (ei - a);                 // (= i n: lambda_i[a] is the row's own entry one block on)
                 const double t = AT_vec<C>(Ch.coef + (ks + (has_next ? 1 : 0)) * NC, dt, [&](int rr) { return ln[rr]; }, a);
                 r += has_next ? t : 0.0;
             }
-            const bool own = (a % P == i);
-            const double tqv = lQd[i * ni + a / P], txv = lxf[i * ni + a / P];
-            const double tq = own ? tqv : 0.0, tx = own ? txv : 0.0;
             const double xa = blk[a];
             r += w * (tq * (xa - tx));
             if (C::POS) { const double gv = Ch.gvt[ks * TAB + (i * P + a % P) * C::PD + (a < C::PD * P ? a / P : 0)]; r += (a < C::PD * P) ? gv : 0.0; }
             const double dprox = prox ? xa - Ch.zxu[ks * NXU + a] : 0.0;
             finish(r, dprox, false, (unsigned)(k * R::LEN + R::RX + ei));
+        };
+        auto xconst = [&](int i, int a, double& tq, double& tx) {
+            const bool own = (a % P == i);
+            const double tqv = lQd[i * ni + a / P], txv = lxf[i * ni + a / P];
+            tq = own ? tqv : 0.0; tx = own ? txv : 0.0;
+        };
+        if constexpr (LR) {
+            // (the trips are unrolled: the step of a trip is a compile-time constant -- plus the lane's share where several steps fit a trip --
+            // so that every LDS address of a row is one chunk-invariant lane offset and an immediate.  Each trip stays behind its own `ks < nst`:
+            // as straight-line code for a full chunk the thirteen trips' loads were scheduled together -- 88 spilled registers at C2)
+            constexpr int XS = NT / RPS, XT = (FT + XS - 1) / XS;
+            const int ls = rlane / RPS, ei = rlane % RPS, i = ei / n, a = ei % n;
+            if (ls < XS) {
+                double tq, tx; xconst(i, a, tq, tx);
+#pragma unroll
+                for (int t = 0; t < XT; t++) { const int ks = XS == 1 ? t : t * XS + ls; if (ks < nst) xrow(ks, ei, i, a, tq, tx); }
+            }
+        } else {
+#if ALG_R6_ROWIDX
+        // (row e = lane + NT t of the chunk, as (step, entry) = divmod(e, P n), carried from trip to trip instead of divided out again)
+        constexpr int RDQ = NT / RPS, RDR = NT % RPS;
+        int rks = lane / RPS, rei = lane % RPS;
+#endif
+        for (int e = lane; e < nst * P * n; e += NT) {
+#if ALG_R6_ROWIDX
+            __builtin_assume(rei >= 0 && rei < RPS);
+            const int ks = rks, ei = rei, i = ei / n, a = ei % n;
+            rks += RDQ; rei += RDR;
+            if (rei >= RPS) { rei -= RPS; rks += 1; }
+#else
+            const int ks = e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n;
+#endif
+            double tq, tx; xconst(i, a, tq, tx);
+            xrow(ks, ei, i, a, tq, tx);
+        }
         }
         LSP(21)
         // ---- rows opt_i,u_{i,k}[c]
-        for (int e = lane; e < nst * m; e += NT) {
-            const int ks = e / m, c = e % m, i = c % P, k = k0 + ks;
+        auto urow = [&](int ks, int c, double tr, double tu) {
+            const int i = c % P, k = k0 + ks;
             const double* blk = Ch.zt + ks * b;
             const double u = blk[n + uoff<C>(c)];
             const double* lo = blk + n + m + i * n;
-            const double tr = lRd[(c % P) * mi + c / P], tu = luf[(c % P) * mi + c / P];
             double g = 0.0, rhat = dt * tr + jreg;
             if (pr.has_ctl) {
 #pragma unroll
@@ -794,11 +883,25 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             const double dprox = prox ? u - Ch.zxu[ks * NXU + n + uoff<C>(c)] : 0.0;
             if (RECS) gst(recg, k * R::LEN + R::RHAT + c, rhat);
             finish(r, dprox, false, (unsigned)(k * R::LEN + R::RU + c));
+        };
+        if constexpr (LR) {
+            constexpr int US = NT / m, UT = (FT + US - 1) / US;
+            const int ls = rlane / m, c = rlane % m;
+            if (ls < US) {
+                const double tr = lRd[(c % P) * mi + c / P], tu = luf[(c % P) * mi + c / P];
+#pragma unroll
+                for (int t = 0; t < UT; t++) { const int ks = t * US + ls; if (ks < nst) urow(ks, c, tr, tu); }
+            }
+        } else {
+            for (int e = lane; e < nst * m; e += NT) {
+                const int ks = e / m, c = e % m;
+                urow(ks, c, lRd[(c % P) * mi + c / P], luf[(c % P) * mi + c / P]);
+            }
         }
         LSP(22)
         // ---- rows dyn_k[a] = RK2(x_k, u_k)[a] - x_{k+1}[a]   (explicit midpoint; the expressions of assemble_pass)
-        for (int e = lane; e < nst * n; e += NT) {
-            const int ks = e / n, a = e % n, k = k0 + ks;
+        auto drow = [&](int ks, int a) {
+            const int k = k0 + ks;
             const double* blk = Ch.zt + ks * b;
             const double* xk = ks == 0 ? Ch.xprev : blk - b;
             double xn;
@@ -818,6 +921,16 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
                 xn = (blkk <= 1) ? base + vm * cf : base + uo * dt;
             }
             finish(xn - blk[a], 0.0, true, (unsigned)(k * R::LEN + R::RD + a));
+        };
+        if constexpr (LR) {
+            constexpr int DS = NT / n, DT = (FT + DS - 1) / DS;
+            const int ls = rlane / n, a = rlane % n;
+            if (ls < DS) {
+#pragma unroll
+                for (int t = 0; t < DT; t++) { const int ks = t * DS + ls; if (ks < nst) drow(ks, a); }
+            }
+        } else {
+            for (int e = lane; e < nst * n; e += NT) drow(e / n, e % n);
         }
         LSP(23)
         fsync();                                           // the next chunk overwrites the buffers

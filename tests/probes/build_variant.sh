@@ -10,6 +10,7 @@ mkdir -p $O
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-invalid-offsetof -Wno-null-dereference -mllvm -disable-machine-licm --offload-compress $*"
 # the tile-path units of the default build have the SI load/store optimizer off (__graft_entry__.HIP_FLAGS_TILE); LSO=1 keeps it on
 if [ "${LSO:-0}" = 0 ]; then FL="$FL -Xclang -target-feature -Xclang -load-store-opt"; fi
+FL="$FL -mllvm -amdgpu-inline-max-bb=100000"
 UNITS=${UNITS:-"base_0 base_1 base_2 base_3 base_4 base_5 base_6 base_7 base_8 ext_di ext_uni ext_bic ext_di3 mw"}
 J=0
 for u in $UNITS; do

@@ -21,7 +21,7 @@
 #define ALG_R6_STAGE_BATCH 6    // ... elements of z and dz per lane and batch in the 128-register kernels
 #endif
 #ifndef ALG_R6_STAGE_BATCH_LR
-#define ALG_R6_STAGE_BATCH_LR 5 // ... blocks per batch of the lane-role staging
+#define ALG_R6_STAGE_BATCH_LR 4 // ... blocks per batch of the lane-role staging
 #endif
 #ifndef ALG_R6_STAGE_BATCH_W2
 #define ALG_R6_STAGE_BATCH_W2 10   // ... in the 256-register kernels (the 4-player unicycle's chunk is 20 elements per lane: 40 doubles in flight at once spilled its loop kernel)
@@ -657,6 +657,9 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             // Round 6 (lane roles, ALG_R6_LANEROLE >= 2): a lane stages the same entry of every block (NT / b blocks per trip, the trips unrolled): the
             // element of trip T is (T BS b + lane) -- a chunk-invariant lane offset plus an immediate in every address, no clamps, no (block, entry)
             // divided out of a flat index for the [x | u] copy; b of NT lanes work (C2: 54 of 64, 14 trips for 12).
+            // Measured and NOT taken (profiles/r06_ab_lr2_c2.txt): bit-identical, but C2 14.08 against 14.55 M/s with the flat staging -- fewer loads in
+            // flight per batch (four blocks where the flat loop holds six elements of z and dz; five already spill) and ten idle lanes cost more than
+            // the index arithmetic saved.  The default build keeps ALG_R6_LANEROLE 1 (rows only).
             constexpr bool SLR = ALG_R6_LANEROLE >= 2 && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && !ALG_LSM_DI1W && b <= NT;
             if constexpr (SLR) {
                 constexpr int BS = NT / b, BT = (FT + 1 + BS - 1) / BS, SBL = BT < ALG_R6_STAGE_BATCH_LR ? BT : ALG_R6_STAGE_BATCH_LR;

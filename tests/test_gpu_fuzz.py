@@ -196,6 +196,32 @@ def test_fuzz_five_and_six_players_hard_seeds_agree_where_arithmetic_decides(alg
             assert hg["ls_j"][rec] == ho["ls_j"][rec] and hg["alpha"][rec] == ho["alpha"][rec], (tag, game, rec)
 
 
+def test_fuzz_base_hard_seed_101156_diverging_game(alg, orc):
+    """The one case of 2000 of the long base-family run of round 6 (tests/probes/fuzz_long_r6.py 2000 base) outside _compare_solve's rule: 4-player
+    unicycle, N = 14, none of the three games converged in 3 x 5 iterations.  Every discrete decision of the three programs is the same; in game 2 one step
+    (record 1 -> 2: the residual norm goes from 0.29 to 586) amplifies the programs' rounding differences from 1e-16 to 1e-10 / 1e-11 and every later
+    record by about ten -- the HIP path happened to leave that step eight times further from the long-double arbiter than the double oracle (the rule
+    allows four), both programs' Newton directions are at rounding level along the whole path (profiles/r06_seed_101156_probe.txt), and the oracle
+    ITSELF moves the final iterate of that game by 4.6e-2 when x0 is perturbed by 1e-15 relative (tests/test_oracle_sensitivity.py).  What arithmetic
+    decides is asserted: statuses, counts, the whole discrete history, the records before the amplification, and the other two games at 1e-8."""
+    g, o, x, tag = _random_pair(alg, orc, np.random.default_rng(101156), ext=False, arb="x")
+    sg, so, sx = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7), x.newton_solve(init=True, game_id0=7)
+    for f in ("status", "outer_iters", "newton_iters", "records", "converged", "ls_failures"):
+        assert np.array_equal(sg[f], so[f]) and np.array_equal(sg[f], sx[f]), (tag, f, sg[f], so[f], sx[f])
+    zg, zo, zx = g.get_traj(0), o.get_traj(0), x.get_traj(0)
+    for game in range(g.B):
+        hg, ho, hx = g.get_history(game), o.get_history(game), x.get_history(game)
+        assert len(hg) == len(ho) == len(hx) and np.array_equal(hg["ls_j"], ho["ls_j"]) and np.array_equal(hg["ls_j"], hx["ls_j"]) and np.array_equal(hg["alpha"], ho["alpha"]), (tag, game)
+        s0 = 1e-3 * abs(hx["res"][0])
+        for rec in range(2):                                         # before the amplifying step (measured: 2e-12 at most, tests/probes/r06_seed_101156.py)
+            for f in ARB_FIELDS:
+                assert abs(hg[f][rec] - hx[f][rec]) <= 1e-10 * max(abs(hx[f][rec]), s0), (tag, game, rec, f, hg[f][rec], hx[f][rec])
+    scale = np.abs(zx).max(axis=1)
+    assert np.abs(zg[0] - zx[0]).max() <= 1e-8 * scale[0] and np.abs(zg[1] - zx[1]).max() <= 1e-8 * scale[1], (tag, np.abs(zg - zx).max(axis=1), scale)
+    # game 2: inside the envelope of the oracle's own sensitivity (1e-15 relative on x0 moves it by 4.6e-2; measured here: HIP 0.139, oracle 0.011 from the arbiter)
+    assert np.abs(zg[2] - zx[2]).max() <= 64.0 * max(np.abs(zo[2] - zx[2]).max(), 1e-8 * scale[2]), (tag, np.abs(zg[2] - zx[2]).max(), np.abs(zo[2] - zx[2]).max())
+
+
 @pytest.mark.parametrize("seed", range(18))
 def test_fuzz_five_and_six_players(alg, orc, seed):
     """DoubleIntegrator d = 2, Unicycle, Bicycle with five and six players (dense Newton direction), base or extended set."""

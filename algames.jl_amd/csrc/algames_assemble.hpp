@@ -20,6 +20,9 @@
 #ifndef ALG_R6_STAGE_BATCH
 #define ALG_R6_STAGE_BATCH 6    // ... elements of z and dz per lane and batch in the 128-register kernels
 #endif
+#ifndef ALG_R6_STAGE_BATCH_REC
+#define ALG_R6_STAGE_BATCH_REC 6 // ... elements of z per lane and batch in the record pass of the 128-register kernels (no dz; all twelve in one batch measured: neutral, profiles/r06_ab_rec12_c2.txt)
+#endif
 #ifndef ALG_R6_STAGE_BATCH_LR
 #define ALG_R6_STAGE_BATCH_LR 4 // ... blocks per batch of the lane-role staging
 #endif
@@ -639,7 +642,9 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
             // C2 exposed seven global round trips in a row, a pass twenty-one, with four games per SIMD streaming at the same time.)
             // (batches of SB elements per lane: all of them at once -- 12 x 2 doubles per lane at C2 -- overflows the 128-register budget)
             constexpr int SU = ((FT + 1) * b + NT - 1) / NT;              // elements per lane of the largest chunk (C2: 12)
-            constexpr int SB = C::WPE == 4 ? ALG_R6_STAGE_BATCH : (SU < ALG_R6_STAGE_BATCH_W2 ? SU : ALG_R6_STAGE_BATCH_W2);
+            // (the record pass loads z alone -- half the registers per element: ALG_R6_STAGE_BATCH_REC elements per batch)
+            constexpr int SB4 = AXPY ? ALG_R6_STAGE_BATCH : (ALG_R6_STAGE_BATCH_REC < SU ? ALG_R6_STAGE_BATCH_REC : SU);
+            constexpr int SB = C::WPE == 4 ? SB4 : (SU < ALG_R6_STAGE_BATCH_W2 ? SU : ALG_R6_STAGE_BATCH_W2);
             constexpr int TU = C::POS ? (FT * TAB + NT - 1) / NT : 1, CU = NC > 0 ? ((FT + 1) * NC + NT - 1) / NT : 1;
             double gt[TU], cf[CU];
             const int tcnt = nst * TAB, ccnt = nblk * NC;

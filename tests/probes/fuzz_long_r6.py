@@ -34,4 +34,4 @@ for name, ext, base, d3, force, dov, nn in fams:
         s = g.get_stats(); it += int(s["newton_iters"].sum()); fails += int(s["ls_failures"].sum()); corr += int(s["refinements"].sum())
     print("%-13s cases %d outside the rule %d, arbiter consulted for trajectories %d, diverged-game status rule %d, Newton iterations %d, failed line searches %d, correction solves %d, %.0f s"
           % (name, max(1, nn), len(bad), consulted, noise, it, fails, corr, time.time() - t0), flush=True)
-    for b in bad[:8]: print("   ", b, flush=True)
+    for b in bad[:40]: print("   ", b, flush=True)

@@ -222,6 +222,78 @@ def test_fuzz_base_hard_seed_101156_diverging_game(alg, orc):
     assert np.abs(zg[2] - zx[2]).max() <= 64.0 * max(np.abs(zo[2] - zx[2]).max(), 1e-8 * scale[2]), (tag, np.abs(zg[2] - zx[2]).max(), np.abs(zo[2] - zx[2]).max())
 
 
+# ---- the long generator at four times its round-6 size (tests/probes/fuzz_long_r6.py 1600 / 2000: 7100 problems): the cases outside _compare_solve's rule.
+# Every one of them is a problem on which the ORACLE ITSELF turns a perturbation of x0 by 1e-15 relative (at most one ulp per entry) into a change of the
+# final iterate of 5e-7 ... 1 (relative), usually with other step sizes on the way (tests/probes/r06_sensitivity.py, profiles/r06_fuzz_outliers_sensitivity.txt):
+# random bicycle problems above all, whose iterates run to 1e2 ... 1e6.  On such a game no two correct double programs agree to 1e-8, and how far each lands
+# from the long-double arbiter is luck (the rule's factor four is a convention).  What the test asserts instead, per game: the HIP path differs from the
+# oracle by no more than 64 x what the oracle differs from itself under those perturbations -- or the oracle's own discrete decisions change under them -- and
+# games that are not amplifying keep the 1e-8 tolerance; the first record (before anything is amplified) agrees to 1e-9 in every game.
+LONG_RUN_OUTLIERS = [101156, 200413, 200502, 200767, 200823, 201079, 201176, 201278, 201311, 201494, 201500, 600196, 600202, 600257, 600281, 600311, 600340, 600359, 600399,
+                     700116, 900022, 900062]
+
+
+def _long_run_pair(alg, orc, seed, arb=None):
+    rng = np.random.default_rng(seed)
+    if seed >= 900000:
+        i = seed - 900000; model = (DI, UNI, BIC)[i % 3]
+        return _random_pair(alg, orc, rng, ext=(model == BIC or bool((i // 3) % 2)), force=(model, 10), force_d3=False, arb=arb)
+    if seed >= 700000:
+        i = seed - 700000; model, p = P789_FAMILIES[i % 9]
+        return _random_pair(alg, orc, rng, ext=(model == BIC or bool(i % 2)), force=(model, p), force_d3=False, arb=arb)
+    if seed >= 600000:
+        i = seed - 600000; model, p = P56_FAMILIES[i % 6]
+        return _random_pair(alg, orc, rng, ext=(model == BIC or bool(i % 2)), force=(model, p), force_d3=False, arb=arb)
+    return _random_pair(alg, orc, rng, seed >= 200000, arb=arb)
+
+
+class _OracleAsHip:
+    """`alg` whose HIP library is the oracle's: _random_pair then builds the problem on the CPU twice."""
+    def __init__(self, alg, orc): self._alg, self._orc = alg, orc
+    def __getattr__(self, k): return getattr(self._alg, k)
+    def hip_lib(self): return self._orc.lib()
+
+
+def oracle_sensitivity(alg, orc, seed, eps_list=(1e-15, 1e-13)):
+    """Per game: the largest change of the oracle's final iterate under x0 (1 + eps s), s = +-1 per entry, and whether its discrete history changed."""
+    env, flipped = None, None
+    for eps in eps_list:
+        pert, ref = _long_run_pair(_OracleAsHip(alg, orc), orc, seed)[:2]
+        x0 = ref.get_x0()
+        pert.set_x0(x0 * (1 + eps * np.sign(np.sin(np.arange(x0.size).reshape(x0.shape)))))
+        sp, sr = pert.newton_solve(init=True, game_id0=7), ref.newton_solve(init=True, game_id0=7)
+        dz = np.abs(pert.get_traj(0) - ref.get_traj(0)).max(axis=1)
+        fl = np.zeros(ref.B, bool)
+        for game in range(ref.B):
+            hp, hr = pert.get_history(game), ref.get_history(game)
+            fl[game] = any(sp[f][game] != sr[f][game] for f in ("status", "outer_iters", "newton_iters", "ls_failures")) or len(hp) != len(hr) or not np.array_equal(hp["ls_j"], hr["ls_j"])
+        env = dz if env is None else np.maximum(env, dz); flipped = fl if flipped is None else (flipped | fl)
+    return env, flipped
+
+
+@pytest.mark.parametrize("seed", LONG_RUN_OUTLIERS)
+def test_long_run_outliers_are_problems_that_amplify_one_ulp(alg, orc, seed):
+    g, o, tag = _long_run_pair(alg, orc, seed)
+    sg, so = g.newton_solve(init=True, game_id0=7), o.newton_solve(init=True, game_id0=7)
+    env, flipped = oracle_sensitivity(alg, orc, seed)
+    zg, zo = g.get_traj(0), o.get_traj(0)
+    scale = np.maximum(1.0, np.abs(zo).max(axis=1))
+    err = np.abs(zg - zo).max(axis=1)
+    print("seed", seed, tag[:4], "|hip - orc|", err, "oracle envelope", env, "oracle's decisions change", flipped, "scale", scale)
+    amplifying = flipped | (env > 1e-9 * scale)
+    assert amplifying.any(), (tag, "not an amplifying problem: belongs under _compare_solve", err, env)
+    for game in range(g.B):
+        hg, ho = g.get_history(game), o.get_history(game)
+        s0 = 1e-3 * abs(ho["res"][0])
+        for f in ARB_FIELDS:                                          # the record before the first step: nothing amplified yet
+            assert abs(hg[f][0] - ho[f][0]) <= 1e-9 * max(abs(ho[f][0]), s0), (tag, game, f, hg[f][0], ho[f][0])
+        if not amplifying[game]:
+            assert sg["status"][game] == so["status"][game] and sg["newton_iters"][game] == so["newton_iters"][game], (tag, game)
+            assert err[game] <= FUZZ_TOL * scale[game], (tag, game, err, env)
+        elif not flipped[game]:
+            assert err[game] <= 64.0 * env[game] + FUZZ_TOL * scale[game], (tag, game, err, env)
+
+
 @pytest.mark.parametrize("seed", range(18))
 def test_fuzz_five_and_six_players(alg, orc, seed):
     """DoubleIntegrator d = 2, Unicycle, Bicycle with five and six players (dense Newton direction), base or extended set."""

@@ -267,6 +267,20 @@ def test_newton_solve_parity_c2_full_horizon(alg, orc):
     assert np.all(s["last"]["opt_vio"] < 1e-3) and np.all(s["last"]["sta_vio"] < 1e-3) and np.all(s["last"]["dyn_vio"] < 1e-3)
 
 
+@pytest.mark.parametrize("p,N", [(1, 2), (1, 10), (1, 18), (2, 2), (2, 9), (2, 10), (2, 17), (2, 26), (3, 2), (3, 14), (3, 15), (3, 27), (3, 28), (3, 41), (3, 53),
+                                 (4, 3), (4, 9), (4, 10), (4, 18), (4, 25)])
+def test_newton_solve_parity_over_chunk_shapes_of_the_fused_pass(alg, orc, p, N):
+    """DoubleIntegrator, one wavefront per game: the fused pass walks the horizon in chunks of FT steps (13 for three players, 8 otherwise) and deals the rows
+    of a chunk as (step, row) = (trip, lane) with NT / (p n), NT / m and NT / n steps per trip (round 6, lane roles: one step per trip for p = 3 and 4, four
+    for p = 2, sixteen for p = 1).  Horizons of one step, of exactly one / two / three chunks, one step more and one step less, and chunks shorter than a
+    trip's steps: whole solves against the oracle."""
+    pg = alg.scenarios.make_problem("C2", np.arange(8), N=N, p=p)
+    po = alg.scenarios.make_problem("C2", np.arange(8), backend=orc.lib(), N=N, p=p)
+    pg.batch.set_waves_per_game(1)
+    alg.newton_solve(pg); alg.newton_solve(po)
+    _assert_solve_parity(pg, po)
+
+
 def test_newton_solve_parity_c5_unicycle_constrained(alg, orc):
     # BASELINE config C5's per-solve problem: 3-player Unicycle, N = 30, collision avoidance + control bounds
     pg, po = _solve_pair(alg, orc, "C5", np.arange(500, 512))

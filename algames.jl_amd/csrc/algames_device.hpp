@@ -194,7 +194,10 @@ struct Cfg {
 #endif
     static constexpr int SWEEP_DEPTH = WPE == 4 ? ALG_SWEEP_DEPTH : (ALG_SWEEP_DEPTH < ALG_SWEEP_DEPTH_W2 ? ALG_SWEEP_DEPTH : ALG_SWEEP_DEPTH_W2);
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
-    static constexpr int ASM_UNROLL = 2;
+#ifndef ALG_ASM_UNROLL_W2
+#define ALG_ASM_UNROLL_W2 2       // ... in the 256-register kernels (3 / 4 measured on the team kernels: bit-identical, C3 -1 %, C5 loop -2 %, C2 at 512 games -3 %; profiles/r06_ab_ur_*.txt)
+#endif
+    static constexpr int ASM_UNROLL = WPE <= 2 ? ALG_ASM_UNROLL_W2 : 2;
 };
 
 // newton_solve / rollout are __forceinline__: they have two callers per instantiation (k_newton_solve, k_mpc_loop) and the

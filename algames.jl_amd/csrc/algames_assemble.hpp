@@ -14,6 +14,12 @@
 #ifndef ALG_LSM_DI1W
 #define ALG_LSM_DI1W 0            // (documented at LsMulti below)
 #endif
+#ifndef ALG_R6_LANEROLE_UNI
+#define ALG_R6_LANEROLE_UNI 0     // ... the one-wavefront unicycle kernels too (the line search's group pass then deals its rows the same way: bit-identical to the
+                                  // fused pass, tests green).  Measured and NOT taken (profiles/r06_ab_lru_*.txt): C5 at 4096 / 1024 games + 0.6 / + 0.8 %, C3 at 4096
+                                  // games (P n = 64: the flat dealing wastes no lane there) - 2.5 %, and the receding-horizon loop at 4096 seeds 3.83 -> 3.16 M/s --
+                                  // another rounding of the norms, other closed-loop trajectories, a slower straggler
+#endif
 #ifndef ALG_R6_STAGE
 #define ALG_R6_STAGE 1      // every global load of a chunk in flight before the first wait
 #endif
@@ -71,6 +77,10 @@ template <class C> __device__ __forceinline__ void team_combine(ResOut& o) {
     }
 }
 
+// rows of the fused pass dealt as (step, row of the step) = (trip, lane): see assemble_fused.  The group pass of the line search (trial_norms_multi) on a
+// one-wavefront kernel must sum its rows per lane in the order of the fused pass (bit-identical norms): it follows this switch.
+template <class C> inline constexpr bool lane_roles_v = ALG_R6_LANEROLE != 0 && AsmLds<C>::FUSED && C::P * C::n <= C::NT &&
+    ((C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && !ALG_LSM_DI1W) || (ALG_R6_LANEROLE_UNI != 0 && C::MODEL == ALG_MODEL_UNICYCLE));
 struct AsmAcc { double l1 = 0, l1r = 0, l1f = 0, vopt = 0, vdyn = 0, vcon = 0, vsta = 0; int bad = 0; };
 // Roundings of the pair terms, stated once.  Phase A of the assemble pass, phase A of the line search's group pass (trial_norms_multi) and
 // dual_penalty_update evaluate the same pair expressions, and the group pass's norms must equal the ordinary pass's bit for bit: wherever a
@@ -790,10 +800,10 @@ __device__ void assemble_fused(CPR pr0, const Game& G0, AsmLds<C>& L, double alp
         // divided (step, row) out of the flat index on every trip: 65 of the 75 VALU instructions of an opt_x trip at C2 were index arithmetic
         // and selects on it.  opt_x rows: NT / (P n) steps per trip (C2: one, 36 of 64 lanes, 13 trips for 8 -- but a fifth of the instructions
         // each); opt_u rows NT / m steps per trip, dyn rows NT / n (C2: ten and five: the same number of trips as before).  Every row is the
-        // same expression as before; a lane sums other rows than it did, so the l1 norms move in the last bits.  (The unicycle kernels keep
-        // the flat dealing: the line search's group pass deals and sums in that order and must stay bit-identical to this pass.)
+        // same expression as before; a lane sums other rows than it did, so the l1 norms move in the last bits.  The one-wavefront unicycle kernels keep the flat dealing
+        // (lane_roles_v: with ALG_R6_LANEROLE_UNI the line search's group pass deals its rows by lane roles too and stays bit-identical -- measured, not taken).
         constexpr int RPS = P * n;
-        constexpr bool LR = ALG_R6_LANEROLE != 0 && C::MODEL == ALG_MODEL_DOUBLE_INTEGRATOR && !ALG_LSM_DI1W && RPS <= NT;
+        constexpr bool LR = lane_roles_v<C>;
         // (the roles are worked out per chunk from an opaque copy of the lane id: as invariants of the whole pass they would be hoisted in front
         // of the chunk loop and held in registers through staging and phase A -- spills in a 128-register kernel)
         int rlane = lane;
@@ -1086,9 +1096,11 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
     auto add = [&](int q, double r, double dprox) { const double rr = prox ? r + reg * dprox : r; l1[q] += fabs(rr); };
     for (int k0 = 0; k0 < N - 1; k0 += LsMulti<C>::CHUNK) {            // (one chunk = the whole horizon for the team kernels)
     const int nst = (N - 1 - k0) < LsMulti<C>::CHUNK ? (N - 1 - k0) : LsMulti<C>::CHUNK;
+    // (one-wavefront kernels whose fused pass deals its rows by lane roles: the same dealing here -- per lane the same rows in the same order)
+    constexpr bool LRG = LsMulti<C>::ONEW && lane_roles_v<C>;
     // ---- rows opt_i,x_{k+1}[a]
-    for (int e = lane; e < nst * P * n; e += NT) {
-        const int k = k0 + e / (P * n), ei = e % (P * n), i = ei / n, a = ei % n;
+    auto gx = [&](int ks, int ei) {
+        const int k = k0 + ks, i = ei / n, a = ei % n;
         const int zo = n + k * b;
         const bool has_next = (k + 1 <= N - 2);
         const double w = (k + 1 < N - 1) ? dt : 1.0;
@@ -1110,10 +1122,15 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
             { const double gv = tabq[(i * P + a % P) * PD + (a < PD * P ? a / P : 0)]; r += (a < PD * P) ? gv : 0.0; }
             add(q, r, xa - xr);
         }
-    }
+    };
+    if constexpr (LRG) {
+        constexpr int RPS = P * n, XS = NT / RPS;
+        const int ls = lane / RPS, ei = lane % RPS;
+        if (ls < XS) for (int ks = ls; ks < nst; ks += XS) gx(ks, ei);
+    } else for (int e = lane; e < nst * P * n; e += NT) gx(e / (P * n), e % (P * n));
     // ---- rows opt_i,u_{i,k}[c]
-    for (int e = lane; e < nst * m; e += NT) {
-        const int k = k0 + e / m, c = e % m, i = c % P;
+    auto gu = [&](int ks, int c) {
+        const int k = k0 + ks, i = c % P;
         const int zo = n + k * b, lo = zo + n + m + i * n, uo = zo + n + uoff<C>(c);
         const double tr = G.Rd(pr)[(c % P) * mi + c / P], tu = G.uf(pr)[(c % P) * mi + c / P];
         const double ur = ldz(uo);
@@ -1140,10 +1157,15 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
             const double r = dt * (tr * (u - tu)) + g + BT_vec<C>(sc + q * SQ + k * SW, dt, [&](int rr) { return tv(q, lo + rr); }, c);
             add(q, r, u - ur);
         }
-    }
+    };
+    if constexpr (LRG) {
+        constexpr int US = NT / m;
+        const int ls = lane / m, c = lane % m;
+        if (ls < US) for (int ks = ls; ks < nst; ks += US) gu(ks, c);
+    } else for (int e = lane; e < nst * m; e += NT) gu(e / m, e % m);
     // ---- rows dyn_k[a]
-    for (int e = lane; e < nst * n; e += NT) {
-        const int k = k0 + e / n, a = e % n;
+    auto gd = [&](int ks, int a) {
+        const int k = k0 + ks;
         const int zo = n + k * b, po = (k == 0) ? 0 : zo - b;
 #pragma unroll
         for (int q = 0; q < NA; q++) {
@@ -1164,7 +1186,12 @@ __device__ void trial_norms_multi(CPR pr0, const Game& G0, const double* lz, dou
             }
             add(q, xn - tv(q, zo + a), 0.0);
         }
-    }
+    };
+    if constexpr (LRG) {
+        constexpr int DS = NT / n;
+        const int ls = lane / n, a = lane % n;
+        if (ls < DS) for (int ks = ls; ks < nst; ks += DS) gd(ks, a);
+    } else for (int e = lane; e < nst * n; e += NT) gd(e / n, e % n);
     }
     // ---- the team's sums, wavefront by wavefront like team_combine
     __shared__ double redm[C::NW][NA];

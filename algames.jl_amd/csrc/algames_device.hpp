@@ -186,9 +186,11 @@ struct Cfg {
     static constexpr bool TRIAL_REUSE = true;
     // forward / costate sweeps of the tile path: time steps whose record slice / gains / dx are in flight (register ring, loop unrolled by it)
 #ifndef ALG_SWEEP_DEPTH
-#define ALG_SWEEP_DEPTH 4
+#define ALG_SWEEP_DEPTH 6
 #endif
-    // (measured, depth 1 / 2 / 4 / 8: C2 10.22 / 10.28 / 10.37 / 10.33 M/s, C3 2.38 / 2.43 / 2.43 / 2.44 M/s, C5 loop 154 / 158 / 157 / 156 K/s)
+    // (measured in round 3, depth 1 / 2 / 4 / 8: C2 10.22 / 10.28 / 10.37 / 10.33 M/s, C3 2.38 / 2.43 / 2.43 / 2.44 M/s, C5 loop 154 / 158 / 157 / 156 K/s; again on the
+    // round-6 kernel, whose sweep steps are shorter -- depth 2 / 4 / 6: 3.095 / 3.056 / 3.019 ms per C2 launch, bit-identical, eight spills the C2 kernel:
+    // profiles/r06_ab_sweep_depth_c2.txt)
 #ifndef ALG_SWEEP_DEPTH_W2
 #define ALG_SWEEP_DEPTH_W2 2       // 256-register kernels
 #endif

@@ -192,7 +192,7 @@ struct Cfg {
     // round-6 kernel, whose sweep steps are shorter -- depth 2 / 4 / 6: 3.095 / 3.056 / 3.019 ms per C2 launch, bit-identical, eight spills the C2 kernel:
     // profiles/r06_ab_sweep_depth_c2.txt)
 #ifndef ALG_SWEEP_DEPTH_W2
-#define ALG_SWEEP_DEPTH_W2 2       // 256-register kernels
+#define ALG_SWEEP_DEPTH_W2 4       // 256-register kernels (2 until late in round 6; 4: bit-identical, C3 +1.6 %, C5 loop +1.5 %, C5 / C3 at 4096 games +2.8 / +3.9 %: profiles/r06_ab_sdw4_*.txt)
 #endif
     static constexpr int SWEEP_DEPTH = WPE == 4 ? ALG_SWEEP_DEPTH : (ALG_SWEEP_DEPTH < ALG_SWEEP_DEPTH_W2 ? ALG_SWEEP_DEPTH : ALG_SWEEP_DEPTH_W2);
     // rows per lane and pass of the assemble row loops (memory-level parallelism against the L2 / store-ack latency)
